@@ -1,0 +1,370 @@
+"""ctypes front-end of the CPU ORACLE (oracle/liboracle.so) and of the compiled
+reference SimSIMD (oracle/_ref/libsimsimd_ref.so, when present).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ISA = {"serial": 0, "haswell": 1, "skylake": 2}
+SPACE = {"L2": 0, "IP": 1, "COSINE": 1}
+
+_f32p = C.POINTER(C.c_float)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def build(ref: bool = True) -> None:
+    """Compile liboracle.so (always) and _ref (only where /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", str(HERE), "liboracle.so"])
+    if ref and Path("/root/reference/third_party/simsimd/c/lib.c").exists():
+        subprocess.check_call(["make", "-s", "-C", str(HERE), "ref"], stderr=subprocess.DEVNULL)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _load():
+    so = HERE / "liboracle.so"
+    if not so.exists():
+        build(ref=False)
+    lib = C.CDLL(str(so))
+    lib.vko_dot_f32.restype = C.c_double
+    lib.vko_dot_f32.argtypes = [C.c_int, _f32p, _f32p, C.c_size_t]
+    lib.vko_l2sq_f32.restype = C.c_double
+    lib.vko_l2sq_f32.argtypes = [C.c_int, _f32p, _f32p, C.c_size_t]
+    lib.vko_distance.restype = C.c_float
+    lib.vko_distance.argtypes = [C.c_int, C.c_int, _f32p, _f32p, C.c_size_t]
+    lib.vko_normalize.restype = C.c_float
+    lib.vko_normalize.argtypes = [_f32p, _f32p, C.c_size_t]
+    lib.vko_cpu_path.restype = C.c_char_p
+    lib.vko_last_error.restype = C.c_char_p
+    lib.vko_flat_new.restype = C.c_void_p
+    lib.vko_flat_new.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_size_t]
+    lib.vko_flat_free.argtypes = [C.c_void_p]
+    for n in ("vko_flat_add", "vko_flat_add_borrowed"):
+        getattr(lib, n).restype = C.c_int
+        getattr(lib, n).argtypes = [C.c_void_p, _f32p, C.c_uint64]
+    lib.vko_flat_remove.argtypes = [C.c_void_p, C.c_uint64]
+    lib.vko_flat_resize.argtypes = [C.c_void_p, C.c_size_t]
+    lib.vko_flat_count.restype = C.c_size_t
+    lib.vko_flat_count.argtypes = [C.c_void_p]
+    lib.vko_flat_capacity.restype = C.c_size_t
+    lib.vko_flat_capacity.argtypes = [C.c_void_p]
+    lib.vko_flat_search.restype = C.c_size_t
+    lib.vko_flat_search.argtypes = [C.c_void_p, _f32p, C.c_size_t, _u64p, C.c_uint64, C.c_long, _f32p, _u64p]
+    lib.vko_flat_distance.restype = C.c_int
+    lib.vko_flat_distance.argtypes = [C.c_void_p, C.c_uint64, _f32p, _f32p]
+    lib.vko_prefilter_topk.restype = C.c_size_t
+    lib.vko_prefilter_topk.argtypes = [C.c_int, C.c_int, C.c_size_t, _f32p, C.POINTER(_f32p), _u64p,
+                                       C.c_size_t, C.c_size_t, _f32p, _u64p]
+    lib.vko_hnsw_new.restype = C.c_void_p
+    lib.vko_hnsw_new.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    lib.vko_hnsw_free.argtypes = [C.c_void_p]
+    lib.vko_hnsw_set_ef.argtypes = [C.c_void_p, C.c_size_t]
+    lib.vko_hnsw_add.restype = C.c_int
+    lib.vko_hnsw_add.argtypes = [C.c_void_p, _f32p, C.c_uint64]
+    lib.vko_hnsw_mark_delete.restype = C.c_int
+    lib.vko_hnsw_mark_delete.argtypes = [C.c_void_p, C.c_uint64]
+    lib.vko_hnsw_resize.argtypes = [C.c_void_p, C.c_size_t]
+    for n in ("vko_hnsw_count", "vko_hnsw_deleted_count", "vko_hnsw_capacity"):
+        getattr(lib, n).restype = C.c_size_t
+        getattr(lib, n).argtypes = [C.c_void_p]
+    lib.vko_hnsw_max_level.restype = C.c_int
+    lib.vko_hnsw_max_level.argtypes = [C.c_void_p]
+    lib.vko_hnsw_entry_point.restype = C.c_uint32
+    lib.vko_hnsw_entry_point.argtypes = [C.c_void_p]
+    lib.vko_hnsw_search.restype = C.c_size_t
+    lib.vko_hnsw_search.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, _u64p, C.c_uint64, C.c_long,
+                                    _f32p, _u64p, _u64p, _u64p]
+    lib.vko_hnsw_distance.restype = C.c_int
+    lib.vko_hnsw_distance.argtypes = [C.c_void_p, C.c_uint64, _f32p, _f32p]
+    lib.vko_hnsw_level_of.restype = C.c_int
+    lib.vko_hnsw_level_of.argtypes = [C.c_void_p, C.c_uint32]
+    lib.vko_hnsw_label_of.restype = C.c_uint64
+    lib.vko_hnsw_label_of.argtypes = [C.c_void_p, C.c_uint32]
+    lib.vko_hnsw_is_deleted.restype = C.c_int
+    lib.vko_hnsw_is_deleted.argtypes = [C.c_void_p, C.c_uint32]
+    lib.vko_hnsw_links.restype = C.c_size_t
+    lib.vko_hnsw_links.argtypes = [C.c_void_p, C.c_uint32, C.c_int, _u32p, C.c_size_t]
+    lib.vko_hnsw_row.restype = _f32p
+    lib.vko_hnsw_row.argtypes = [C.c_void_p, C.c_uint32]
+    lib.vko_merge_topk.restype = C.c_size_t
+    lib.vko_merge_topk.argtypes = [_f32p, _u64p, _u32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p, _u64p]
+    return lib
+
+
+LIB = _load()
+
+
+def cpu_path() -> str:
+    return LIB.vko_cpu_path().decode()
+
+
+def last_error() -> str:
+    return LIB.vko_last_error().decode()
+
+
+def f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def dot(a, b, isa="skylake") -> float:
+    a, b = f32(a), f32(b)
+    return LIB.vko_dot_f32(ISA[isa], _fp(a), _fp(b), a.size)
+
+
+def l2sq(a, b, isa="skylake") -> float:
+    a, b = f32(a), f32(b)
+    return LIB.vko_l2sq_f32(ISA[isa], _fp(a), _fp(b), a.size)
+
+
+def distance(space, a, b, isa="skylake") -> np.float32:
+    a, b = f32(a), f32(b)
+    return np.float32(LIB.vko_distance(SPACE[space], ISA[isa], _fp(a), _fp(b), a.size))
+
+
+def normalize(v):
+    v = f32(v)
+    out = np.empty_like(v)
+    mag = LIB.vko_normalize(_fp(out), _fp(v), v.size)
+    return out, np.float32(mag)
+
+
+def allow_bitmap(labels, nbits: int) -> np.ndarray:
+    """Bitmap indexed by label (bit set = allowed)."""
+    bits = np.zeros((nbits + 63) // 64, dtype=np.uint64)
+    labels = np.asarray(labels, dtype=np.uint64)
+    np.bitwise_or.at(bits, (labels >> np.uint64(6)).astype(np.int64),
+                     np.uint64(1) << (labels & np.uint64(63)))
+    return bits
+
+
+def _allow_args(allow, nbits):
+    if allow is None:
+        return None, 0
+    allow = np.ascontiguousarray(allow, dtype=np.uint64)
+    return allow.ctypes.data_as(_u64p), int(nbits if nbits is not None else allow.size * 64)
+
+
+class Flat:
+    """hnswlib::BruteforceSearch<float> restated (bruteforce.h)."""
+
+    def __init__(self, dim, space="L2", isa="skylake", max_elements=1024):
+        self.dim, self.space = dim, space
+        self._h = LIB.vko_flat_new(dim, SPACE[space], ISA[isa], max_elements)
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            LIB.vko_flat_free(self._h)
+            self._h = None
+
+    def add(self, row, label) -> int:
+        row = f32(row)
+        assert row.size == self.dim
+        return LIB.vko_flat_add(self._h, _fp(row), int(label))
+
+    def add_many(self, rows, labels=None, borrowed=False):
+        rows = f32(rows)
+        if borrowed:
+            self._keep.append(rows)
+        fn = LIB.vko_flat_add_borrowed if borrowed else LIB.vko_flat_add
+        base = rows.ctypes.data
+        stride = rows.strides[0]
+        for i in range(rows.shape[0]):
+            lab = int(labels[i]) if labels is not None else i
+            rc = fn(self._h, C.cast(base + i * stride, _f32p), lab)
+            if rc:
+                raise RuntimeError(last_error())
+
+    def remove(self, label):
+        LIB.vko_flat_remove(self._h, int(label))
+
+    def resize(self, n):
+        LIB.vko_flat_resize(self._h, n)
+
+    @property
+    def count(self):
+        return LIB.vko_flat_count(self._h)
+
+    @property
+    def capacity(self):
+        return LIB.vko_flat_capacity(self._h)
+
+    def search(self, q, k, allow=None, allow_nbits=None, cancel_after=-1):
+        q = f32(q)
+        od = np.empty(max(k, 1), dtype=np.float32)
+        ol = np.empty(max(k, 1), dtype=np.uint64)
+        ap, nb = _allow_args(allow, allow_nbits)
+        n = LIB.vko_flat_search(self._h, _fp(q), k, ap, nb, cancel_after, _fp(od), ol.ctypes.data_as(_u64p))
+        return od[:n].copy(), ol[:n].copy()
+
+    def distance(self, label, q):
+        q = f32(q)
+        out = C.c_float()
+        rc = LIB.vko_flat_distance(self._h, int(label), _fp(q), C.byref(out))
+        return None if rc else np.float32(out.value)
+
+
+class HNSW:
+    """hnswlib::HierarchicalNSW<float> restated (hnswalg.h), single-threaded."""
+
+    def __init__(self, dim, space="L2", isa="skylake", max_elements=1024, M=16, ef_construction=200,
+                 seed=100, allow_replace_deleted=False, ef=10):
+        self.dim, self.space, self.M = dim, space, M
+        self._h = LIB.vko_hnsw_new(dim, SPACE[space], ISA[isa], max_elements, M, ef_construction, seed,
+                                   int(allow_replace_deleted))
+        LIB.vko_hnsw_set_ef(self._h, ef)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            LIB.vko_hnsw_free(self._h)
+            self._h = None
+
+    def add(self, row, label) -> int:
+        row = f32(row)
+        assert row.size == self.dim
+        return LIB.vko_hnsw_add(self._h, _fp(row), int(label))
+
+    def add_many(self, rows, labels=None):
+        rows = f32(rows)
+        base, stride = rows.ctypes.data, rows.strides[0]
+        for i in range(rows.shape[0]):
+            lab = int(labels[i]) if labels is not None else i
+            rc = LIB.vko_hnsw_add(self._h, C.cast(base + i * stride, _f32p), lab)
+            if rc:
+                raise RuntimeError(last_error())
+
+    def mark_delete(self, label) -> int:
+        return LIB.vko_hnsw_mark_delete(self._h, int(label))
+
+    def resize(self, n):
+        LIB.vko_hnsw_resize(self._h, n)
+
+    def set_ef(self, ef):
+        LIB.vko_hnsw_set_ef(self._h, ef)
+
+    count = property(lambda s: LIB.vko_hnsw_count(s._h))
+    deleted_count = property(lambda s: LIB.vko_hnsw_deleted_count(s._h))
+    capacity = property(lambda s: LIB.vko_hnsw_capacity(s._h))
+    max_level = property(lambda s: LIB.vko_hnsw_max_level(s._h))
+    entry_point = property(lambda s: LIB.vko_hnsw_entry_point(s._h))
+
+    def search(self, q, k, ef=0, allow=None, allow_nbits=None, cancel_after=-1, stats=False):
+        q = f32(q)
+        od = np.empty(max(k, 1), dtype=np.float32)
+        ol = np.empty(max(k, 1), dtype=np.uint64)
+        ne, nh = C.c_uint64(), C.c_uint64()
+        ap, nb = _allow_args(allow, allow_nbits)
+        n = LIB.vko_hnsw_search(self._h, _fp(q), k, ef, ap, nb, cancel_after, _fp(od),
+                                ol.ctypes.data_as(_u64p), C.byref(ne), C.byref(nh))
+        if stats:
+            return od[:n].copy(), ol[:n].copy(), ne.value, nh.value
+        return od[:n].copy(), ol[:n].copy()
+
+    def distance(self, label, q):
+        q = f32(q)
+        out = C.c_float()
+        rc = LIB.vko_hnsw_distance(self._h, int(label), _fp(q), C.byref(out))
+        return None if rc else np.float32(out.value)
+
+    def export_graph(self):
+        """Dense arrays describing the graph (for feeding the device path the same graph)."""
+        n = self.count
+        levels = np.array([LIB.vko_hnsw_level_of(self._h, i) for i in range(n)], dtype=np.int32)
+        labels = np.array([LIB.vko_hnsw_label_of(self._h, i) for i in range(n)], dtype=np.uint64)
+        deleted = np.array([LIB.vko_hnsw_is_deleted(self._h, i) for i in range(n)], dtype=np.uint8)
+        maxm0 = 2 * self.M
+        l0 = np.zeros((n, maxm0 + 1), dtype=np.uint32)
+        buf = (C.c_uint32 * (maxm0 + 1))()
+        upper = {}
+        for i in range(n):
+            c = LIB.vko_hnsw_links(self._h, i, 0, buf, maxm0)
+            l0[i, 0] = c
+            l0[i, 1:1 + c] = np.frombuffer(buf, dtype=np.uint32, count=c)
+            for lv in range(1, levels[i] + 1):
+                c = LIB.vko_hnsw_links(self._h, i, lv, buf, self.M)
+                upper[(i, lv)] = np.frombuffer(buf, dtype=np.uint32, count=c).copy()
+        rows = np.stack([np.ctypeslib.as_array(LIB.vko_hnsw_row(self._h, i), shape=(self.dim,)).copy()
+                         for i in range(n)]) if n else np.zeros((0, self.dim), np.float32)
+        return dict(levels=levels, labels=labels, deleted=deleted, l0=l0, upper=upper, rows=rows,
+                    entry_point=self.entry_point, max_level=self.max_level)
+
+
+def prefilter_topk(space, q, rows, labels, k, isa="skylake"):
+    q, rows = f32(q), f32(rows)
+    labels = np.ascontiguousarray(labels, dtype=np.uint64)
+    n = rows.shape[0]
+    ptrs = (_f32p * max(n, 1))()
+    for i in range(n):
+        ptrs[i] = C.cast(rows.ctypes.data + i * rows.strides[0], _f32p)
+    od = np.empty(max(k, 1), dtype=np.float32)
+    ol = np.empty(max(k, 1), dtype=np.uint64)
+    m = LIB.vko_prefilter_topk(SPACE[space], ISA[isa], rows.shape[1] if n else q.size, _fp(q), ptrs,
+                               labels.ctypes.data_as(_u64p), n, k, _fp(od), ol.ctypes.data_as(_u64p))
+    return od[:m].copy(), ol[:m].copy()
+
+
+def merge_topk(dist, label, counts, k):
+    dist = f32(dist)
+    label = np.ascontiguousarray(label, dtype=np.uint64)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    parts, per = dist.shape
+    od = np.empty(max(k, 1), dtype=np.float32)
+    ol = np.empty(max(k, 1), dtype=np.uint64)
+    n = LIB.vko_merge_topk(_fp(dist), label.ctypes.data_as(_u64p), counts.ctypes.data_as(_u32p), parts, per, k,
+                           _fp(od), ol.ctypes.data_as(_u64p))
+    return od[:n].copy(), ol[:n].copy()
+
+
+# ---- the compiled reference SimSIMD (present only after `make ref`) -------------
+class Ref:
+    """oracle/_ref/libsimsimd_ref.so: the reference's own simsimd c/lib.c + export shims."""
+
+    def __init__(self):
+        so = HERE / "_ref" / "libsimsimd_ref.so"
+        if not so.exists():
+            raise FileNotFoundError(so)
+        self.lib = C.CDLL(str(so))
+        for n in ("dot", "l2sq"):
+            for isa in ("serial", "haswell", "skylake"):
+                fn = getattr(self.lib, f"ref_{n}_f32_{isa}")
+                fn.argtypes = [_f32p, _f32p, C.c_size_t, C.POINTER(C.c_double)]
+                fn.restype = None
+            fn = getattr(self.lib, f"simsimd_{n}_f32")
+            fn.argtypes = [_f32p, _f32p, C.c_size_t, C.POINTER(C.c_double)]
+            fn.restype = None
+        self.lib.ref_InnerProductDistanceSimsimd.restype = C.c_float
+        self.lib.ref_InnerProductDistanceSimsimd.argtypes = [_f32p, _f32p, C.c_size_t]
+        self.lib.ref_L2SqrSimsimd.restype = C.c_float
+        self.lib.ref_L2SqrSimsimd.argtypes = [_f32p, _f32p, C.c_size_t]
+        self.lib.ref_capabilities.restype = C.c_uint
+
+    @staticmethod
+    def available() -> bool:
+        return (HERE / "_ref" / "libsimsimd_ref.so").exists()
+
+    def capabilities(self) -> int:
+        return self.lib.ref_capabilities()
+
+    def kernel(self, name, isa, a, b) -> float:
+        a, b = f32(a), f32(b)
+        out = C.c_double()
+        fn = getattr(self.lib, f"simsimd_{name}_f32" if isa == "dispatch" else f"ref_{name}_f32_{isa}")
+        fn(_fp(a), _fp(b), a.size, C.byref(out))
+        return out.value
+
+    def distance(self, space, a, b) -> np.float32:
+        a, b = f32(a), f32(b)
+        fn = self.lib.ref_InnerProductDistanceSimsimd if SPACE[space] == 1 else self.lib.ref_L2SqrSimsimd
+        return np.float32(fn(_fp(a), _fp(b), a.size))

@@ -1,0 +1,42 @@
+"""pytest config: `-m gpu` tests need a real MI355X (run through gpurun / the driver);
+everything else runs on CPU.  The oracle (oracle/) is test infrastructure and is
+built on demand."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+
+
+def _have_gpu() -> bool:
+    return os.path.exists("/dev/kfd")
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container (run via gpurun)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+def reference_vectors(size, dims, max_value):
+    """testing/common.cc:42-53 DeterministicallyGenerateVectors (f32 arithmetic)."""
+    import numpy as np
+    i = np.arange(size, dtype=np.float32)[:, None]
+    j = np.arange(dims, dtype=np.float32)[None, :]
+    return (np.float32(max_value) * ((i + j) / np.float32(size + dims))).astype(np.float32)
