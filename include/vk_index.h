@@ -1,0 +1,192 @@
+/*
+ * vk_index.h -- C ABI of the MI355X-native vector-kNN backend (libvkindex.so).
+ *
+ * Drop-in boundary for valkey-search's vector hot path.  The reference has no
+ * FFI on this path: `VectorFlat<float>` / `VectorHNSW<float>`
+ * (src/indexes/vector_flat.cc, vector_hnsw.cc) own an `hnswlib::BruteforceSearch`
+ * / `hnswlib::HierarchicalNSW` object and call its C++ members.  This header
+ * replaces exactly that seam -- the hnswlib `AlgorithmInterface`
+ * (third_party/hnswlib/hnswlib.h:215-235) plus the members valkey-search reaches
+ * into -- with a plain C ABI (pointers and sizes only), so the host classes that
+ * sit above it (valkey-search_amd/csrc/host/, or the reference's own classes via
+ * the adaptor shown in INTEGRATION.md) stay ordinary C++.  Each entry point cites
+ * the reference interface it stands in for (paths relative to the reference tree).
+ *
+ * Conventions
+ *  - every function returns a vk_status; the message of the last failure on the
+ *    calling thread is vk_last_error().  No C++ exception crosses the ABI (the
+ *    reference turns every hnswlib exception into absl::InternalError at this
+ *    seam: vector_flat.cc:68-72,165-176,238-242; vector_hnsw.cc:102-106,186-197,331-335).
+ *  - rows/queries are `dim` elements of the index dtype (f32 = 4*dim bytes), borrowed
+ *    for the call only; the library copies what it keeps (the reference keeps the
+ *    caller's pointer: bruteforce.h:81, hnswalg.h:1576-1577).
+ *  - COSINE: as in the reference (vector_base.cc:61-76,140-150) the caller
+ *    normalises rows and queries; the library then works in the inner-product space.
+ *  - labels are the u64 "internal ids" VectorBase hands to hnswlib (vector_base.cc:340-358).
+ *  - results are ascending by (distance, label) -- the order VectorBase::CreateReply
+ *    produces from hnswlib's heap (vector_base.cc:258-277).
+ *  - all entry points are thread safe; searches may run concurrently, mutations are
+ *    staged on the host and published to HBM by vk_index_flush() (implicitly before
+ *    the next search), matching the reference's reader/writer phases
+ *    (vmsdk/src/time_sliced_mrmw_mutex.h:42-52).
+ *  - the library needs a gfx950 device; without one vk_index_create fails with
+ *    VK_ERR_NO_DEVICE.  There is no CPU fallback.
+ */
+#ifndef VK_INDEX_H_
+#define VK_INDEX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vk_index vk_index;
+
+typedef enum {
+  VK_OK = 0,
+  VK_ERR_INVALID = 1,    /* bad argument (absl::InvalidArgumentError) */
+  VK_ERR_CAPACITY = 2,   /* "The number of elements exceeds the specified limit" (bruteforce.h:74, hnswalg.h:1551) */
+  VK_ERR_NOT_FOUND = 3,  /* unknown / tombstoned label */
+  VK_ERR_INTERNAL = 4,   /* absl::InternalError: device or library failure */
+  VK_ERR_CANCELLED = 5,  /* search cancelled and partial results not wanted (vector_hnsw.cc:327-329) */
+  VK_ERR_NO_DEVICE = 6   /* no usable gfx950 device */
+} vk_status;
+
+typedef enum { VK_ALGO_FLAT = 0, VK_ALGO_HNSW = 1 } vk_algo;          /* IndexerType kFlat / kHNSW */
+typedef enum { VK_METRIC_L2 = 0, VK_METRIC_IP = 1, VK_METRIC_COSINE = 2 } vk_metric; /* index_schema.proto DistanceMetric */
+typedef enum { VK_DTYPE_F32 = 0, VK_DTYPE_BF16 = 1 } vk_dtype;         /* FLOAT32 is the only reference type (vector_base.h:112-114) */
+
+typedef struct vk_index_params {
+  uint32_t struct_size;       /* = sizeof(vk_index_params) */
+  uint32_t algo;              /* vk_algo */
+  uint32_t metric;            /* vk_metric */
+  uint32_t dtype;             /* vk_dtype (storage type on the device) */
+  uint32_t dim;               /* VectorIndex.dimension_count */
+  uint32_t block_size;        /* FLAT BLOCK_SIZE / hnsw-block-size: informational, growth is vk_index_resize */
+  uint64_t initial_cap;       /* VectorIndex.initial_cap == max_elements of the hnswlib ctor */
+  uint32_t m;                 /* HNSW M (hnswalg.h:121) */
+  uint32_t ef_construction;   /* HNSW efC */
+  uint32_t ef_runtime;        /* HNSW default ef (setEf, vector_hnsw.cc:98) */
+  uint32_t allow_replace_deleted; /* hnsw-allow-replace-deleted (vector_hnsw.cc:99-100) */
+  uint64_t random_seed;       /* hnswlib ctor random_seed, reference default 100 */
+  int32_t device_id;          /* HIP device ordinal, -1 = current device */
+  uint32_t build_threads;     /* HNSW: host threads used by vk_index_add_batch, 0 = hardware */
+} vk_index_params;
+
+typedef struct vk_index_stats {
+  uint64_t count;             /* cur_element_count_ (live + tombstoned) */
+  uint64_t deleted;           /* num_deleted_ (HNSW tombstones) */
+  uint64_t capacity;          /* GetCapacity(): data_->getCapacity() / max_elements_ */
+  uint64_t device_bytes;      /* HBM held by the index */
+  uint64_t host_bytes;        /* host memory held by the library */
+  uint64_t staged_ops;        /* mutations not yet published to the device */
+  int32_t max_level;          /* HNSW maxlevel_ (-1 when empty) */
+  uint32_t entry_point;       /* HNSW enterpoint_node_ */
+  /* work counters of the most recent search batch (HNSW layer 0; hnswlib only counts
+   * upper layers, hnswalg.h:1679-1680): */
+  uint64_t last_n_eval;       /* distance evaluations */
+  uint64_t last_n_hops;       /* expanded nodes */
+} vk_index_stats;
+
+/* ---- life cycle ------------------------------------------------------------------
+ * BruteforceSearch(space, maxElements) bruteforce.h:54-64 /
+ * HierarchicalNSW(space, max_elements, M, ef_construction, seed) hnswalg.h:121-179,
+ * as called from VectorFlat::Create vector_flat.cc:53-74 and VectorHNSW::Create
+ * vector_hnsw.cc:84-108. */
+int vk_index_create(const vk_index_params *params, vk_index **out);
+void vk_index_destroy(vk_index *ix);
+int vk_device_count(void);
+const char *vk_last_error(void);
+
+/* ---- mutations (writer phase) -------------------------------------------------------
+ * addPoint: bruteforce.h:66-83 / hnswalg.h:1278-1340 (same label again = in-place update,
+ * which is how ModifyRecordImpl is expressed: vector_flat.cc:178-193, vector_hnsw.cc:273-286). */
+int vk_index_add(vk_index *ix, uint64_t label, const void *row);
+/* n rows, row-contiguous.  HNSW inserts them with params.build_threads host threads
+ * (the reference's writer pool calling addPoint concurrently: valkey_search.cc:1171-1174). */
+int vk_index_add_batch(vk_index *ix, const uint64_t *labels, const void *rows, uint64_t n);
+/* removePoint bruteforce.h:92-113 (last element moves into the hole) /
+ * markDelete hnswalg.h:1173-1187 (tombstone). */
+int vk_index_remove(vk_index *ix, uint64_t label);
+/* resizeIndex: bruteforce.h:209-211 / hnswalg.h:758-777 (ResizeIfFull: vector_flat.cc:137-155,
+ * vector_hnsw.cc:238-271 grow by block_size when add returns VK_ERR_CAPACITY). */
+int vk_index_resize(vk_index *ix, uint64_t new_max_elements);
+/* HierarchicalNSW::setEf hnswalg.h:210 */
+int vk_index_set_ef(vk_index *ix, uint32_t ef);
+/* publish staged mutations to HBM; call at the write->read phase switch */
+int vk_index_flush(vk_index *ix);
+
+/* ---- queries (reader phase) ----------------------------------------------------------
+ * searchKnn: bruteforce.h:116-145 / hnswalg.h:1659-1725.
+ *   k            : FLAT clamps to the element count like vector_flat.cc:234-236
+ *   ef_runtime   : HNSW per-query EF_RUNTIME, 0 = index default (std::nullopt)
+ *   allow_bits   : optional filter, the materialised BaseFilterFunctor (hnswlib.h:144-149):
+ *                  bit `label` set = allowed, labels >= allow_nbits rejected; NULL = no filter
+ *   cancel_flag  : optional host word, non-zero = cancelled (BaseCancellationFunctor,
+ *                  hnswlib.h:153-157); polled between kernel phases.  FLAT returns what it
+ *                  has; HNSW returns VK_ERR_CANCELLED unless partial_ok
+ *   out_dist/out_label : caller buffers of k entries; *out_n receives the count */
+int vk_index_search(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime,
+                    const uint64_t *allow_bits, uint64_t allow_nbits,
+                    const volatile int *cancel_flag, int partial_ok,
+                    float *out_dist, uint64_t *out_label, uint64_t *out_n);
+/* nq independent queries answered by one device pass (what a query coalescer between
+ * the reader pool, search.cc:886-910, and the device submits).  Outputs are [nq][k]
+ * with out_n[nq]; the same filter applies to every query of the batch. */
+int vk_index_search_batch(vk_index *ix, const void *queries, uint64_t nq, uint64_t k,
+                          uint64_t ef_runtime, const uint64_t *allow_bits, uint64_t allow_nbits,
+                          const volatile int *cancel_flag, int partial_ok,
+                          float *out_dist, uint64_t *out_label, uint64_t *out_n);
+/* Same, but queries and outputs are DEVICE pointers and the work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the index's own stream) without a host sync:
+ * the shard leg of the multi-GPU path, whose outputs feed an RCCL all-gather.
+ * out_n entries past the count are filled with (+inf, UINT64_MAX). */
+int vk_index_search_batch_device(vk_index *ix, const void *d_queries, uint64_t nq, uint64_t k,
+                                 uint64_t ef_runtime, const uint64_t *d_allow_bits,
+                                 uint64_t allow_nbits, float *d_out_dist, uint64_t *d_out_label,
+                                 uint32_t *d_out_n, void *hip_stream);
+/* Exact kNN over an explicit label list: the pre-filter path
+ * (search.cc:457-481 CalcBestMatchingPrefilteredKeys -> vector_base.cc:509-530
+ * AddPrefilteredKey): heap of k, a later key replaces the top only on strictly
+ * smaller distance.  Unknown / tombstoned labels are skipped. */
+int vk_index_search_labels(vk_index *ix, const void *query, uint64_t k, const uint64_t *labels,
+                           uint64_t n_labels, float *out_dist, uint64_t *out_label,
+                           uint64_t *out_n);
+/* fstdistfunc_(query, stored row) for one record
+ * (ComputeDistanceFromRecordImpl: vector_flat.cc:256-271, vector_hnsw.cc:369-383) */
+int vk_index_distance(vk_index *ix, uint64_t label, const void *query, float *out);
+/* the stored row (GetValueImpl -> getPoint bruteforce.h:85-90 / getDataByInternalId) */
+int vk_index_get_row(vk_index *ix, uint64_t label, void *out_row);
+int vk_index_contains(vk_index *ix, uint64_t label, int *out_found);
+int vk_index_get_stats(vk_index *ix, vk_index_stats *out);
+
+/* ---- device-resident bulk load (benchmarks / GPU-side ingest) --------------------------
+ * Rows already in HBM in the index's own row layout (row i at d_rows + i*row_stride_bytes,
+ * `dim` elements then zero padding): reserve, let the caller fill, then commit with labels
+ * (NULL = 0..n-1).  FLAT only. */
+int vk_index_device_rows(vk_index *ix, uint64_t n_rows, void **d_rows, uint64_t *row_stride_bytes);
+int vk_index_commit_device_rows(vk_index *ix, uint64_t n_rows, const uint64_t *labels);
+
+/* ---- shard merge (multi-GPU) ---------------------------------------------------------------
+ * k smallest by (distance,label) out of `parts` per-shard lists: the role of
+ * SearchPartitionResultsTracker::AddResult (fanout.cc:162-175), with the total order of
+ * bruteforce.h's heap so that an n-shard answer equals the 1-shard answer.
+ * Device pointers; lists laid out [parts][nq][k]; enqueued on hip_stream. */
+int vk_merge_topk_device(const float *d_dist, const uint64_t *d_label, uint32_t parts, uint64_t nq,
+                         uint64_t k, float *d_out_dist, uint64_t *d_out_label, uint32_t *d_out_n,
+                         int device_id, void *hip_stream);
+
+/* ---- persistence: SaveIndex / LoadIndex chunk streams ----------------------------------------
+ * bruteforce.h:147-207, hnswalg.h:808-1139 via RDBChunkOutputStream / RDBChunkInputStream
+ * (rdb_serialization.h:289-340).  The callbacks carry one chunk each. */
+typedef int (*vk_write_chunk_fn)(void *user, const void *data, uint64_t len);
+typedef int (*vk_read_chunk_fn)(void *user, void *buf, uint64_t cap, uint64_t *len);
+int vk_index_save(vk_index *ix, vk_write_chunk_fn write_chunk, void *user);
+int vk_index_load(const vk_index_params *params, vk_read_chunk_fn read_chunk, void *user, vk_index **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VK_INDEX_H_ */

@@ -1,0 +1,66 @@
+"""CPU-side checks of the drop-in boundary: libvkindex.so builds for gfx950, loads, and
+exports every entry point include/vk_index.h declares.  No compute calls (no GPU here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def vsa():
+    import _pkg
+    v = _pkg.vsa
+    if not v.LIB_PATH.exists():
+        v.build()
+    return v
+
+
+def declared_functions():
+    text = (ROOT / "include" / "vk_index.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|char)\s*\*?\s*(vk_[a-z_0-9]+)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("vk_index_create", "vk_index_add", "vk_index_remove", "vk_index_search", "vk_index_search_batch",
+                 "vk_index_search_batch_device", "vk_index_search_labels", "vk_index_distance", "vk_index_save",
+                 "vk_index_load", "vk_merge_topk_device", "vk_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(vsa):
+    lib = C.CDLL(str(vsa.LIB_PATH))
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_struct_layouts_match_header(vsa):
+    # vk_index_params: 9 u32 + padding-free u64s; keep the ctypes mirror honest
+    assert C.sizeof(vsa.Params) == 64
+    assert C.sizeof(vsa.Stats) == 72
+
+
+def test_fails_loudly_without_device(vsa):
+    import os
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    with pytest.raises(vsa.VkError) as e:
+        vsa.Index("FLAT", 16)
+    assert e.value.code == vsa.VK_ERR_NO_DEVICE
+
+
+def test_argument_validation_needs_no_device(vsa):
+    lib = vsa.lib()
+    h = C.c_void_p()
+    p = vsa.make_params("FLAT", 0, "L2", 10)
+    assert lib.vk_index_create(C.byref(p), C.byref(h)) == vsa.VK_ERR_INVALID
+    p = vsa.make_params("FLAT", 16, "L2", 10)
+    p.struct_size = 8
+    assert lib.vk_index_create(C.byref(p), C.byref(h)) == vsa.VK_ERR_INVALID
+    assert b"struct_size" in lib.vk_last_error()
+    assert lib.vk_index_add(None, 1, None) == vsa.VK_ERR_INVALID

@@ -1,0 +1,265 @@
+"""valkey-search_amd: MI355X-native vector-kNN backend for valkey-search.
+
+The product is libvkindex.so (HIP kernels + the C ABI of include/vk_index.h) and the C++
+host classes in csrc/host/.  This Python module is only the ctypes binding the tests and
+bench.py drive it with -- it contains no search logic and NO fallback: if the shared
+library is missing, or there is no gfx950 device, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libvkindex.so"
+HOST_LIB_PATH = PKG_DIR / "libvkhost.so"
+
+VK_OK, VK_ERR_INVALID, VK_ERR_CAPACITY, VK_ERR_NOT_FOUND, VK_ERR_INTERNAL, VK_ERR_CANCELLED, VK_ERR_NO_DEVICE = range(7)
+ALGO = {"FLAT": 0, "HNSW": 1}
+METRIC = {"L2": 0, "IP": 1, "COSINE": 2}
+
+
+class VkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vk_status {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class Params(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("algo", C.c_uint32), ("metric", C.c_uint32), ("dtype", C.c_uint32),
+                ("dim", C.c_uint32), ("block_size", C.c_uint32), ("initial_cap", C.c_uint64), ("m", C.c_uint32),
+                ("ef_construction", C.c_uint32), ("ef_runtime", C.c_uint32), ("allow_replace_deleted", C.c_uint32),
+                ("random_seed", C.c_uint64), ("device_id", C.c_int32), ("build_threads", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("deleted", C.c_uint64), ("capacity", C.c_uint64),
+                ("device_bytes", C.c_uint64), ("host_bytes", C.c_uint64), ("staged_ops", C.c_uint64),
+                ("max_level", C.c_int32), ("entry_point", C.c_uint32), ("last_n_eval", C.c_uint64),
+                ("last_n_hops", C.c_uint64)]
+
+
+WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
+READ_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
+
+
+def build(verbose: bool = False) -> None:
+    """Compile every HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-s", "-j8", "-C", str(PKG_DIR / "csrc")], stdout=out)
+    if (PKG_DIR / "csrc" / "host" / "Makefile").exists():
+        subprocess.check_call(["make", "-s", "-j8", "-C", str(PKG_DIR / "csrc" / "host")], stdout=out)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The C ABI.  Raises if libvkindex.so has not been built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(str(LIB_PATH))
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    u64p, f32p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    L.vk_last_error.restype = C.c_char_p
+    L.vk_device_count.restype = i32
+    L.vk_index_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.vk_index_destroy.argtypes = [vp]
+    L.vk_index_destroy.restype = None
+    L.vk_index_add.argtypes = [vp, u64, vp]
+    L.vk_index_add_batch.argtypes = [vp, vp, vp, u64]
+    L.vk_index_remove.argtypes = [vp, u64]
+    L.vk_index_resize.argtypes = [vp, u64]
+    L.vk_index_set_ef.argtypes = [vp, u32]
+    L.vk_index_flush.argtypes = [vp]
+    L.vk_index_search.argtypes = [vp, vp, u64, u64, vp, u64, vp, i32, vp, vp, u64p]
+    L.vk_index_search_batch.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, i32, vp, vp, vp]
+    L.vk_index_search_batch_device.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, vp, vp, vp]
+    L.vk_index_search_labels.argtypes = [vp, vp, u64, vp, u64, vp, vp, u64p]
+    L.vk_index_distance.argtypes = [vp, u64, vp, f32p]
+    L.vk_index_get_row.argtypes = [vp, u64, vp]
+    L.vk_index_contains.argtypes = [vp, u64, C.POINTER(i32)]
+    L.vk_index_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.vk_index_device_rows.argtypes = [vp, u64, C.POINTER(vp), u64p]
+    L.vk_index_commit_device_rows.argtypes = [vp, u64, vp]
+    L.vk_merge_topk_device.argtypes = [vp, vp, u32, u64, u64, vp, vp, vp, i32, vp]
+    L.vk_index_save.argtypes = [vp, WRITE_CHUNK, vp]
+    L.vk_index_load.argtypes = [C.POINTER(Params), READ_CHUNK, vp, C.POINTER(vp)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != VK_OK:
+        raise VkError(rc, lib().vk_last_error().decode(errors="replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_params(algo, dim, metric, initial_cap, block_size=1024, m=16, ef_construction=200, ef_runtime=10,
+                seed=100, allow_replace_deleted=False, device_id=-1, build_threads=0) -> Params:
+    return Params(C.sizeof(Params), ALGO[algo], METRIC[metric], 0, dim, block_size, initial_cap, m, ef_construction,
+                  ef_runtime, int(allow_replace_deleted), seed, device_id, build_threads)
+
+
+class Index:
+    """Thin RAII wrapper over vk_index_* (one per hnswlib algorithm object)."""
+
+    def __init__(self, algo, dim, metric="L2", initial_cap=1024, **kw):
+        self.algo, self.dim, self.metric = algo, dim, metric
+        self.params = make_params(algo, dim, metric, initial_cap, **kw)
+        h = C.c_void_p()
+        _check(lib().vk_index_create(C.byref(self.params), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def _from_handle(cls, h, params, algo, dim, metric):
+        self = cls.__new__(cls)
+        self._h, self.params, self.algo, self.dim, self.metric = h, params, algo, dim, metric
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vk_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- mutations
+    def add(self, label, row):
+        row = np.ascontiguousarray(row, dtype=np.float32)
+        assert row.size == self.dim
+        return lib().vk_index_add(self._h, int(label), _ptr(row))
+
+    def add_batch(self, rows, labels=None):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        assert rows.ndim == 2 and rows.shape[1] == self.dim
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint64)
+        _check(lib().vk_index_add_batch(self._h, _ptr(lab), _ptr(rows), rows.shape[0]))
+
+    def remove(self, label):
+        return lib().vk_index_remove(self._h, int(label))
+
+    def resize(self, n):
+        _check(lib().vk_index_resize(self._h, int(n)))
+
+    def set_ef(self, ef):
+        _check(lib().vk_index_set_ef(self._h, int(ef)))
+
+    def flush(self):
+        _check(lib().vk_index_flush(self._h))
+
+    # ---- queries
+    def search(self, q, k, ef=0, allow=None, allow_nbits=None, cancel=None, partial_ok=True):
+        d, l, n = self.search_batch(np.asarray(q, dtype=np.float32).reshape(1, -1), k, ef, allow, allow_nbits,
+                                    cancel, partial_ok)
+        return d[0, :n[0]], l[0, :n[0]]
+
+    def search_batch(self, Q, k, ef=0, allow=None, allow_nbits=None, cancel=None, partial_ok=True):
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        nq = Q.shape[0]
+        od = np.full((nq, max(k, 1)), np.inf, dtype=np.float32)
+        ol = np.full((nq, max(k, 1)), np.iinfo(np.uint64).max, dtype=np.uint64)
+        on = np.zeros(nq, dtype=np.uint64)
+        if allow is not None:
+            allow = np.ascontiguousarray(allow, dtype=np.uint64)
+            nbits = int(allow_nbits if allow_nbits is not None else allow.size * 64)
+        else:
+            nbits = 0
+        cflag = None if cancel is None else C.cast(C.pointer(cancel), C.c_void_p)
+        _check(lib().vk_index_search_batch(self._h, _ptr(Q), nq, k, ef, _ptr(allow), nbits, cflag, int(partial_ok),
+                                           _ptr(od), _ptr(ol), _ptr(on)))
+        return od[:, :k], ol[:, :k], on
+
+    def search_labels(self, q, k, labels):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        labels = np.ascontiguousarray(labels, dtype=np.uint64)
+        od = np.empty(max(k, 1), np.float32)
+        ol = np.empty(max(k, 1), np.uint64)
+        n = C.c_uint64()
+        _check(lib().vk_index_search_labels(self._h, _ptr(q), k, _ptr(labels), labels.size, _ptr(od), _ptr(ol),
+                                            C.byref(n)))
+        return od[:n.value].copy(), ol[:n.value].copy()
+
+    def distance(self, label, q):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = C.c_float()
+        rc = lib().vk_index_distance(self._h, int(label), _ptr(q), C.byref(out))
+        return None if rc == VK_ERR_NOT_FOUND else (_check(rc) or np.float32(out.value))
+
+    def get_row(self, label):
+        out = np.empty(self.dim, np.float32)
+        rc = lib().vk_index_get_row(self._h, int(label), _ptr(out))
+        return None if rc == VK_ERR_NOT_FOUND else (_check(rc) or out)
+
+    def contains(self, label) -> bool:
+        f = C.c_int()
+        _check(lib().vk_index_contains(self._h, int(label), C.byref(f)))
+        return bool(f.value)
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _check(lib().vk_index_get_stats(self._h, C.byref(s)))
+        return s
+
+    # ---- device-resident paths (pointers are raw device addresses, e.g. torch .data_ptr())
+    def device_rows(self, n):
+        p, stride = C.c_void_p(), C.c_uint64()
+        _check(lib().vk_index_device_rows(self._h, n, C.byref(p), C.byref(stride)))
+        return p.value, stride.value
+
+    def commit_device_rows(self, n, labels=None):
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint64)
+        _check(lib().vk_index_commit_device_rows(self._h, n, _ptr(lab)))
+
+    def search_batch_device(self, d_queries, nq, k, d_out_dist, d_out_label, d_out_n, ef=0, d_allow=None,
+                            allow_nbits=0, stream=None):
+        _check(lib().vk_index_search_batch_device(self._h, d_queries, nq, k, ef, d_allow, allow_nbits, d_out_dist,
+                                                  d_out_label, d_out_n, stream))
+
+    # ---- persistence
+    def save(self):
+        chunks = []
+
+        @WRITE_CHUNK
+        def wr(_u, data, n):
+            chunks.append(C.string_at(data, n))
+            return 0
+
+        _check(lib().vk_index_save(self._h, wr, None))
+        return chunks
+
+    @classmethod
+    def load(cls, chunks, algo, dim, metric="L2", **kw):
+        params = make_params(algo, dim, metric, kw.pop("initial_cap", 0), **kw)
+        it = iter(chunks)
+
+        @READ_CHUNK
+        def rd(_u, buf, cap, out_len):
+            try:
+                c = next(it)
+            except StopIteration:
+                return 1
+            if len(c) > cap:
+                return 2
+            C.memmove(buf, c, len(c))
+            out_len[0] = len(c)
+            return 0
+
+        h = C.c_void_p()
+        _check(lib().vk_index_load(C.byref(params), rd, None, C.byref(h)))
+        return cls._from_handle(h, params, algo, dim, metric)
+
+
+def merge_topk_device(d_dist, d_label, parts, nq, k, d_out_dist, d_out_label, d_out_n, device_id=-1, stream=None):
+    _check(lib().vk_merge_topk_device(d_dist, d_label, parts, nq, k, d_out_dist, d_out_label, d_out_n, device_id,
+                                      stream))

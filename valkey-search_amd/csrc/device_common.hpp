@@ -1,0 +1,174 @@
+// device_common.hpp -- CDNA4 (gfx950) device building blocks shared by the FLAT scan,
+// the label gather-scan, the HNSW expansion and the top-k merge kernels.
+//
+// Distance arithmetic.  The reference's fstdistfunc_ is SimSIMD 5.0.1's f32 dot / l2sq
+// as dispatched on an AVX-512 host (third_party/simsimd/include/simsimd/dot.h:1183-1204,
+// spatial.h:1131-1153): 16 independent f32 accumulators, accumulator l fed
+// fma(a[16c+l], b[16c+l], acc[l]) for c = 0,1,..., zero-masked tail, then the
+// _mm512_reduce_add_ps tree (l,l+8) -> (l,l+4) -> (l,l+2) -> (0,1); the hnswlib bridge
+// returns (float)(1.0 - (double)dot) resp. (float)l2sq (third_party/hnswlib/simsimd.h:16-34).
+// To return bit-identical distances (hence identical neighbour ids, ties included) the
+// device keeps exactly those 16 chains: a row is owned by a QUAD of lanes, lane j of
+// the quad holds accumulators 4j..4j+3 and walks the row 64 B (one chunk of 16 floats)
+// at a time with one 16-B load per lane; the tree is two DPP quad permutes plus three
+// adds.  Rows are stored zero-padded to a multiple of 16 floats, which reproduces the
+// masked tail (fma(0,0,x) == x; an accumulator that starts at +0 never becomes -0).
+// 1.0f - dot equals the reference's double-precision subtract: a single add of two
+// f32 values rounded through f64 is innocuous double rounding (53 >= 2*24+2).
+//
+// Everything here must be compiled with -ffp-contract=off: only the explicit fmaf may fuse.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vk {
+
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kRowsPerWave = 16;     // one row per quad of lanes
+constexpr uint64_t kNoLabel = ~0ull;
+
+__device__ __forceinline__ float dpp_quad_xor1(float v) {
+  // quad_perm [1,0,3,2]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v) {
+  // quad_perm [2,3,0,1]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+// acc = this lane's accumulators 4j..4j+3 of a row.  Every lane of the quad returns the
+// full 16-accumulator sum in _mm512_reduce_add_ps order.
+__device__ __forceinline__ float quad_reduce16(float4 acc) {
+  acc.x += dpp_quad_xor2(acc.x);  // (l, l+8): lane j <-> lane j^2
+  acc.y += dpp_quad_xor2(acc.y);
+  acc.z += dpp_quad_xor2(acc.z);
+  acc.w += dpp_quad_xor2(acc.w);
+  acc.x += dpp_quad_xor1(acc.x);  // (l, l+4): lane j <-> lane j^1
+  acc.y += dpp_quad_xor1(acc.y);
+  acc.z += dpp_quad_xor1(acc.z);
+  acc.w += dpp_quad_xor1(acc.w);
+  float u0 = acc.x + acc.z;       // (l, l+2)
+  float u1 = acc.y + acc.w;
+  return u0 + u1;                 // (0, 1)
+}
+
+template <bool kL2>
+__device__ __forceinline__ void chunk_fma(float4 &acc, const float4 x, const float4 q) {
+  if constexpr (kL2) {
+    float dx = x.x - q.x, dy = x.y - q.y, dz = x.z - q.z, dw = x.w - q.w;
+    acc.x = fmaf(dx, dx, acc.x);
+    acc.y = fmaf(dy, dy, acc.y);
+    acc.z = fmaf(dz, dz, acc.z);
+    acc.w = fmaf(dw, dw, acc.w);
+  } else {
+    acc.x = fmaf(x.x, q.x, acc.x);
+    acc.y = fmaf(x.y, q.y, acc.y);
+    acc.z = fmaf(x.z, q.z, acc.z);
+    acc.w = fmaf(x.w, q.w, acc.w);
+  }
+}
+
+template <bool kL2>
+__device__ __forceinline__ float finish_distance(float sum) {
+  if constexpr (kL2) return sum;   // (float)l2sq: exact
+  return 1.0f - sum;               // == (float)(1.0 - (double)dot), see header comment
+}
+
+// ---- (distance,label) total order: std::pair<float,size_t> operator< ------------------
+__device__ __forceinline__ bool dl_less(float da, uint64_t la, float db, uint64_t lb) {
+  return da < db || (da == db && la < lb);
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+  uint32_t lo = __shfl_xor((int)(uint32_t)v, m), hi = __shfl_xor((int)(uint32_t)(v >> 32), m);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+  uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+  uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// ---- per-wave running top-k ---------------------------------------------------------------
+// The k best (smallest by (distance,label)) entries seen by one wave, spread over the
+// lanes: slot s = e*64 + lane, kE slots per lane, k <= 64*kE.  The current worst kept
+// entry (the heap top of bruteforce.h:128-141) is cached wave-uniformly so the hot loop
+// pays one compare per row; the rare insert replaces the worst slot and re-reduces.
+template <int kE>
+struct WaveTopK {
+  float d[kE];
+  uint64_t lab[kE];
+  uint32_t k, cnt;       // wave-uniform
+  float thr_d;           // wave-uniform: worst kept distance, +inf while cnt < k
+  uint64_t thr_lab;
+  uint32_t thr_slot;
+
+  __device__ __forceinline__ void init(uint32_t k_) {
+    k = k_;
+    cnt = 0;
+    thr_d = __builtin_inff();
+    thr_lab = kNoLabel;
+    thr_slot = 0;
+#pragma unroll
+    for (int e = 0; e < kE; ++e) { d[e] = __builtin_inff(); lab[e] = kNoLabel; }
+  }
+
+  __device__ __forceinline__ void recompute_worst(int lane) {
+    float bd = -__builtin_inff();
+    uint64_t bl = 0;
+    uint32_t bs = 0;
+    bool have = false;
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+      uint32_t s = (uint32_t)e * kWave + lane;
+      if (s < k && (!have || dl_less(bd, bl, d[e], lab[e]))) { bd = d[e]; bl = lab[e]; bs = s; have = true; }
+    }
+    if (!have) { bd = -__builtin_inff(); bl = 0; }
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) {
+      float od = __shfl_xor(bd, m);
+      uint64_t ol = shfl_xor_u64(bl, m);
+      uint32_t os = __shfl_xor((int)bs, m);
+      int oh = __shfl_xor((int)have, m);
+      if (oh && (!have || dl_less(bd, bl, od, ol))) { bd = od; bl = ol; bs = os; have = true; }
+    }
+    thr_d = bd;
+    thr_lab = bl;
+    thr_slot = bs;
+  }
+
+  // (cd, cl) wave-uniform.  Caller has already checked the distance gate cd <= thr_d.
+  __device__ __forceinline__ void insert(float cd, uint64_t cl, int lane) {
+    uint32_t slot;
+    if (cnt < k) {
+      slot = cnt++;
+    } else {
+      if (!dl_less(cd, cl, thr_d, thr_lab)) return;
+      slot = thr_slot;
+    }
+#pragma unroll
+    for (int e = 0; e < kE; ++e)
+      if (slot == (uint32_t)e * kWave + lane) { d[e] = cd; lab[e] = cl; }
+    if (cnt == k) recompute_worst(lane);
+  }
+
+  // Write the kept entries to out[0..k) (unsorted; empty slots are (+inf, kNoLabel)).
+  __device__ __forceinline__ void store(float *out_d, uint64_t *out_l, int lane) const {
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+      uint32_t s = (uint32_t)e * kWave + lane;
+      if (s < k) { out_d[s] = d[e]; out_l[s] = lab[e]; }
+    }
+  }
+};
+
+__device__ __forceinline__ bool allow_bit(const uint64_t *__restrict__ bits, uint64_t nbits, uint64_t label) {
+  if (!bits) return true;
+  if (label >= nbits) return false;
+  return (bits[label >> 6] >> (label & 63)) & 1ull;
+}
+
+}  // namespace vk

@@ -1,0 +1,608 @@
+// flat_index.cc -- FlatIndex: hnswlib::BruteforceSearch<float> semantics
+// (third_party/hnswlib/bruteforce.h) over an HBM-resident row table.
+//
+//   addPoint     bruteforce.h:66-83    label known -> overwrite in place, else append,
+//                                      "exceeds the specified limit" when full
+//   removePoint  bruteforce.h:92-113   last element moves into the hole
+//   searchKnn    bruteforce.h:116-145  -> flat_scan.hip (K3) + merge; result = the k
+//                                      smallest by (distance,label)
+//   resizeIndex  bruteforce.h:209-211
+// Difference kept on purpose: with a filter, bruteforce.h:120-141 can return fewer than k
+// allowed rows when fewer than k of the FIRST k rows pass (lastdist is then the max of
+// those that passed).  That corner is unreachable through FT.SEARCH (FLAT + filter always
+// takes the pre-filter path, src/query/planner.cc:23-29); here a filtered scan returns
+// the exact k best allowed rows.
+#include <string.h>
+
+#include <algorithm>
+#include <queue>
+
+#include "index.hpp"
+
+namespace vk {
+
+// ---- buffers / contexts ---------------------------------------------------------------
+Status DevBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return Status::Ok();
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+  size_t want = std::max<size_t>(bytes, 4096);
+  want = (want + 4095) & ~(size_t)4095;
+  VK_HIP_TRY(hipMalloc(&p, want));
+  cap = want;
+  return Status::Ok();
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+Status PinBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return Status::Ok();
+  if (p) (void)hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+  size_t want = std::max<size_t>(bytes, 4096);
+  want = (want + 4095) & ~(size_t)4095;
+  VK_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+  cap = want;
+  return Status::Ok();
+}
+void PinBuf::release() {
+  if (p) (void)hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+SearchCtx::~SearchCtx() {
+  if (stream) (void)hipStreamSynchronize(stream);
+  for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats})
+    b->release();
+  for (PinBuf *b : {&h_q, &h_out_d, &h_out_l, &h_out_n, &h_tmp, &h_idx}) b->release();
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+CtxPool::~CtxPool() {
+  (void)hipSetDevice(device_);
+  all_.clear();
+}
+
+SearchCtx *CtxPool::acquire() {
+  std::unique_lock<std::mutex> lk(mu_);
+  for (;;) {
+    if (!free_.empty()) {
+      SearchCtx *c = free_.back();
+      free_.pop_back();
+      return c;
+    }
+    if (all_.size() < max_) {
+      (void)hipSetDevice(device_);
+      auto c = std::make_unique<SearchCtx>();
+      (void)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+      all_.push_back(std::move(c));
+      return all_.back().get();
+    }
+    cv_.wait(lk);
+  }
+}
+
+void CtxPool::release(SearchCtx *c) {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    free_.push_back(c);
+  }
+  cv_.notify_one();
+}
+
+Status upload_queries(SearchCtx *ctx, const float *queries, uint64_t nq, uint32_t dim, uint32_t stride_f) {
+  size_t bytes = (size_t)nq * stride_f * 4;
+  VK_TRY(ctx->h_q.ensure(bytes));
+  VK_TRY(ctx->d_q.ensure(bytes));
+  float *h = ctx->h_q.as<float>();
+  if (stride_f == dim) {
+    memcpy(h, queries, bytes);
+  } else {
+    for (uint64_t q = 0; q < nq; ++q) {
+      memcpy(h + q * stride_f, queries + q * dim, (size_t)dim * 4);
+      memset(h + q * stride_f + dim, 0, (size_t)(stride_f - dim) * 4);
+    }
+  }
+  VK_HIP_TRY(hipMemcpyAsync(ctx->d_q.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return Status::Ok();
+}
+
+Status upload_allow(SearchCtx *ctx, const uint64_t *allow_bits, uint64_t allow_nbits, const uint64_t **d_allow) {
+  *d_allow = nullptr;
+  if (!allow_bits) return Status::Ok();
+  size_t words = (size_t)((allow_nbits + 63) / 64);
+  VK_TRY(ctx->d_allow.ensure(std::max<size_t>(words * 8, 8)));
+  if (words) VK_HIP_TRY(hipMemcpyAsync(ctx->d_allow.p, allow_bits, words * 8, hipMemcpyHostToDevice, ctx->stream));
+  *d_allow = ctx->d_allow.as<uint64_t>();
+  return Status::Ok();
+}
+
+// vector_base.cc:509-530: fill to k, then a key replaces the heap top only when its
+// distance is strictly smaller (ties keep what is already there).
+void prefilter_heap_select(const float *dist, const uint64_t *labels, uint64_t n, uint64_t k, float *out_dist,
+                           uint64_t *out_label, uint64_t *out_n) {
+  std::priority_queue<std::pair<float, uint64_t>> results;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (labels[i] == ~0ull) continue;  // unknown key: ComputeDistanceFromRecord failed
+    if (results.size() < k) {
+      results.emplace(dist[i], labels[i]);
+    } else if (k && dist[i] < results.top().first) {
+      results.pop();
+      results.emplace(dist[i], labels[i]);
+    }
+  }
+  uint64_t m = results.size();
+  *out_n = m;
+  while (m) {
+    --m;
+    out_dist[m] = results.top().first;
+    out_label[m] = results.top().second;
+    results.pop();
+  }
+}
+
+// ---- FlatIndex ---------------------------------------------------------------------------
+class FlatIndex final : public Index {
+ public:
+  explicit FlatIndex(const vk_index_params &p, int device)
+      : Index(p), store_(device, p.dim), pool_(device), capacity_(p.initial_cap) {}
+
+  Status add(uint64_t label, const float *row) override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    return add_locked(label, row);
+  }
+
+  Status add_batch(const uint64_t *labels, const float *rows, uint64_t n) override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    for (uint64_t i = 0; i < n; ++i) {
+      VK_TRY(add_locked(labels ? labels[i] : i, rows + i * params_.dim));
+      if (store_.staged_bytes() >= ((size_t)256 << 20)) VK_TRY(store_.flush());
+    }
+    return Status::Ok();
+  }
+
+  Status remove(uint64_t label) override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    auto it = slot_of_.find(label);
+    if (it == slot_of_.end()) return Status::Ok();  // bruteforce.h:95-98: silently ignored
+    uint32_t cur = it->second;
+    slot_of_.erase(it);
+    uint32_t last = (uint32_t)count_ - 1;
+    if (cur != last) {
+      uint64_t moved = store_.host_labels()[last];
+      slot_of_[moved] = cur;
+      store_.stage_move(cur, last, moved);
+    }
+    count_--;
+    return Status::Ok();
+  }
+
+  Status resize(uint64_t new_max) override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    capacity_ = new_max;
+    return Status::Ok();
+  }
+
+  Status set_ef(uint32_t) override { return Status::Ok(); }
+
+  Status flush() override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    return store_.flush();
+  }
+
+  Status search(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) override {
+    VK_TRY(flush_if_dirty());
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    (void)hipSetDevice(store_.device());
+    const uint64_t count = count_;
+    const uint64_t k = std::min<uint64_t>(rq.k, count);  // vector_flat.cc:234-236
+    if (k == 0 || rq.nq == 0) {
+      for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
+      return Status::Ok();
+    }
+    CtxLease lease(pool_);
+    SearchCtx *ctx = lease.ctx;
+    VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f()));
+    const uint64_t *d_allow = nullptr;
+    VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
+    VK_TRY(ctx->d_out_d.ensure(rq.nq * k * 4));
+    VK_TRY(ctx->d_out_l.ensure(rq.nq * k * 8));
+    VK_TRY(ctx->d_out_n.ensure(rq.nq * 4));
+    VK_TRY(scan(ctx, ctx->d_q.as<float>(), rq.nq, k, count, d_allow, rq.allow_nbits, rq.cancel_flag,
+                ctx->d_out_d.as<float>(), ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream));
+    VK_TRY(ctx->h_out_d.ensure(rq.nq * k * 4));
+    VK_TRY(ctx->h_out_l.ensure(rq.nq * k * 8));
+    VK_TRY(ctx->h_out_n.ensure(rq.nq * 4));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, ctx->d_out_d.p, rq.nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // caller's buffers are [nq][rq.k]
+    for (uint64_t q = 0; q < rq.nq; ++q) {
+      uint32_t n = ctx->h_out_n.as<uint32_t>()[q];
+      out_n[q] = n;
+      memcpy(out_dist + q * rq.k, ctx->h_out_d.as<float>() + q * k, (size_t)n * 4);
+      memcpy(out_label + q * rq.k, ctx->h_out_l.as<uint64_t>() + q * k, (size_t)n * 8);
+    }
+    return Status::Ok();
+  }
+
+  Status search_device(const SearchRequest &rq, float *d_out_dist, uint64_t *d_out_label, uint32_t *d_out_n,
+                       hipStream_t stream) override {
+    VK_TRY(flush_if_dirty());
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    (void)hipSetDevice(store_.device());
+    if (rq.nq == 0) return Status::Ok();
+    if (!dev_ctx_) {
+      dev_ctx_ = std::make_unique<SearchCtx>();
+      VK_HIP_TRY(hipStreamCreateWithFlags(&dev_ctx_->stream, hipStreamNonBlocking));
+    }
+    hipStream_t s = stream ? stream : dev_ctx_->stream;
+    const uint64_t count = count_;
+    if (rq.k > count || rq.k == 0)
+      return Status::Err(VK_ERR_INVALID, "search_batch_device needs 0 < k <= element count");
+    const float *dq = rq.queries;
+    if (store_.stride_f() != params_.dim) {
+      VK_TRY(dev_ctx_->d_q.ensure(rq.nq * store_.row_bytes()));
+      VK_HIP_TRY(hipMemsetAsync(dev_ctx_->d_q.p, 0, rq.nq * store_.row_bytes(), s));
+      VK_HIP_TRY(hipMemcpy2DAsync(dev_ctx_->d_q.p, store_.row_bytes(), rq.queries, (size_t)params_.dim * 4,
+                                  (size_t)params_.dim * 4, rq.nq, hipMemcpyDeviceToDevice, s));
+      dq = dev_ctx_->d_q.as<float>();
+    }
+    return scan(dev_ctx_.get(), dq, rq.nq, rq.k, count, rq.allow_bits, rq.allow_nbits, nullptr, d_out_dist,
+                d_out_label, d_out_n, s);
+  }
+
+  Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n, float *out_dist,
+                       uint64_t *out_label, uint64_t *out_n) override {
+    VK_TRY(flush_if_dirty());
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    (void)hipSetDevice(store_.device());
+    *out_n = 0;
+    if (n == 0 || k == 0) return Status::Ok();
+    CtxLease lease(pool_);
+    SearchCtx *ctx = lease.ctx;
+    // label -> slot on the host (dict_external_to_internal, vector_flat.cc:260-265)
+    VK_TRY(ctx->h_idx.ensure(n * 4));
+    VK_TRY(ctx->h_tmp.ensure(n * 4));
+    std::vector<uint64_t> found(n);
+    uint32_t *idx = ctx->h_idx.as<uint32_t>();
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      auto it = slot_of_.find(labels[i]);
+      if (it == slot_of_.end()) continue;
+      idx[m] = it->second;
+      found[m++] = labels[i];
+    }
+    if (m == 0) return Status::Ok();
+    VK_TRY(upload_queries(ctx, query, 1, params_.dim, store_.stride_f()));
+    VK_TRY(ctx->d_idx.ensure(m * 4));
+    VK_TRY(ctx->d_tmp.ensure(m * 4));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->d_idx.p, idx, m * 4, hipMemcpyHostToDevice, ctx->stream));
+    GatherArgs ga{store_.d_rows(), ctx->d_q.as<float>(), ctx->d_idx.as<uint32_t>(), ctx->d_tmp.as<float>(),
+                  store_.stride_f(), store_.stride_f() / 16, (uint32_t)m};
+    VK_HIP_TRY(launch_gather_distance(ga, l2(), ctx->stream));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_tmp.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    prefilter_heap_select(ctx->h_tmp.as<float>(), found.data(), m, k, out_dist, out_label, out_n);
+    return Status::Ok();
+  }
+
+  Status distance(uint64_t label, const float *query, float *out) override {
+    float d;
+    uint64_t l, n = 0;
+    {
+      std::shared_lock<std::shared_mutex> lk(rw_);
+      if (!slot_of_.count(label)) return Status::Err(VK_ERR_NOT_FOUND, "Couldn't find internal id");
+    }
+    VK_TRY(search_labels(query, 1, &label, 1, &d, &l, &n));
+    if (n != 1) return Status::Err(VK_ERR_NOT_FOUND, "Couldn't find internal id");
+    *out = d;
+    return Status::Ok();
+  }
+
+  Status get_row(uint64_t label, float *out) override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    auto it = slot_of_.find(label);
+    if (it == slot_of_.end()) return Status::Err(VK_ERR_NOT_FOUND, "label not found");
+    return store_.read_row(it->second, out);
+  }
+
+  Status contains(uint64_t label, bool *found) override {
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    *found = slot_of_.count(label) != 0;
+    return Status::Ok();
+  }
+
+  Status stats(vk_index_stats *out) override {
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    memset(out, 0, sizeof(*out));
+    out->count = count_;
+    out->capacity = capacity_;
+    out->device_bytes = store_.device_bytes();
+    out->host_bytes = store_.host_bytes() + slot_of_.size() * 24;
+    out->staged_ops = store_.staged_ops();
+    out->max_level = -1;
+    return Status::Ok();
+  }
+
+  Status device_rows(uint64_t n, void **d_rows, uint64_t *stride_bytes) override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    if (count_ != 0) return Status::Err(VK_ERR_INVALID, "device bulk load needs an empty index");
+    if (n > capacity_) return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+    VK_TRY(store_.flush());
+    VK_TRY(store_.reserve(n));
+    *d_rows = store_.d_rows_mut();
+    *stride_bytes = store_.row_bytes();
+    return Status::Ok();
+  }
+
+  Status commit_device_rows(uint64_t n, const uint64_t *labels) override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    if (count_ != 0) return Status::Err(VK_ERR_INVALID, "device bulk load needs an empty index");
+    if (n > store_.alloc_rows()) return Status::Err(VK_ERR_INVALID, "commit exceeds the reserved rows");
+    slot_of_.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) {
+      uint64_t lab = labels ? labels[i] : i;
+      if (!slot_of_.emplace(lab, (uint32_t)i).second) {
+        slot_of_.clear();
+        return Status::Err(VK_ERR_INVALID, "duplicate label in bulk load");
+      }
+      store_.stage_label((uint32_t)i, lab);
+    }
+    count_ = n;
+    return store_.flush();
+  }
+
+  Status save(vk_write_chunk_fn fn, void *user) override;
+  Status load_from(vk_read_chunk_fn fn, void *user);
+
+ private:
+  Status add_locked(uint64_t label, const float *row) {
+    auto it = slot_of_.find(label);
+    uint32_t slot;
+    if (it != slot_of_.end()) {
+      slot = it->second;
+    } else {
+      if (count_ >= capacity_)
+        return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+      slot = (uint32_t)count_++;
+      slot_of_.emplace(label, slot);
+    }
+    return store_.stage_write(slot, row, label);
+  }
+
+  Status flush_if_dirty() {
+    {
+      std::shared_lock<std::shared_mutex> lk(rw_);
+      if (!store_.dirty()) return Status::Ok();
+    }
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    return store_.flush();
+  }
+
+  // enqueue scan + merge of rows [0,count) on stream s; all pointers device
+  Status scan(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
+              uint64_t allow_nbits, const volatile int *cancel, float *d_out_d, uint64_t *d_out_l,
+              uint32_t *d_out_n, hipStream_t s) {
+    const int e = flat_scan_slots_per_lane(k);
+    if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 is not served by this build of the FLAT scan");
+    const uint32_t chunks = store_.stride_f() / 16;
+    if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
+    const int qb = flat_scan_pick_qb(nq, chunks, e);
+    const uint32_t nqg = (uint32_t)((nq + qb - 1) / qb);
+    // rows: cancelled at entry -> only the first k rows are looked at (bruteforce.h:120-129)
+    uint64_t row_end = count;
+    bool cancelled = cancel && *cancel;
+    if (cancelled) row_end = std::min<uint64_t>(count, k);
+    const uint64_t seg_rows = cancel ? ((uint64_t)4 << 20) : row_end;
+    const uint32_t nseg = (uint32_t)((row_end + seg_rows - 1) / seg_rows);
+    // row partitions: enough blocks to fill 256 CUs, never more waves than 16-row tiles
+    const uint64_t tiles = (std::min<uint64_t>(seg_rows, row_end) + 15) / 16;
+    uint32_t nrp = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, std::max<uint32_t>(2048 / nqg, 256));
+    nrp = std::max<uint32_t>(8, (nrp + 7) & ~7u);
+    const uint64_t per_q = (uint64_t)nrp * 4 * k;
+    VK_TRY(ctx->d_part_d.ensure((size_t)nseg * nq * per_q * 4));
+    VK_TRY(ctx->d_part_l.ensure((size_t)nseg * nq * per_q * 8));
+    uint32_t done = 0;
+    for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
+      if (sgi > 0 && cancel) {
+        VK_HIP_TRY(hipStreamSynchronize(s));
+        if (*cancel) break;
+      }
+      FlatScanArgs a{};
+      a.rows = store_.d_rows();
+      a.labels = store_.d_labels();
+      a.queries = d_q;
+      a.allow_bits = d_allow;
+      a.allow_nbits = allow_nbits;
+      a.part_dist = ctx->d_part_d.as<float>() + (size_t)sgi * nq * per_q;
+      a.part_label = ctx->d_part_l.as<uint64_t>() + (size_t)sgi * nq * per_q;
+      a.row_stride_f = a.q_stride_f = store_.stride_f();
+      a.chunks = chunks;
+      a.row_begin = (uint32_t)(sgi * seg_rows);
+      a.row_end = (uint32_t)std::min<uint64_t>(row_end, (uint64_t)(sgi + 1) * seg_rows);
+      a.nq = (uint32_t)nq;
+      a.k = (uint32_t)k;
+      a.nrp = nrp;
+      a.nqg = nqg;
+      VK_HIP_TRY(launch_flat_scan(a, l2(), qb, e, s));
+      ++done;
+    }
+    MergeArgs m{};
+    m.in_dist = ctx->d_part_d.as<float>();
+    m.in_label = ctx->d_part_l.as<uint64_t>();
+    m.part_stride = nq * per_q;
+    m.q_stride = per_q;
+    m.parts = done;
+    m.per_part = (uint32_t)per_q;
+    m.k = (uint32_t)k;
+    m.out_dist = d_out_d;
+    m.out_label = d_out_l;
+    m.out_n = d_out_n;
+    VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
+    return Status::Ok();
+  }
+
+  RowStore store_;
+  CtxPool pool_;
+  std::unique_ptr<SearchCtx> dev_ctx_;
+  std::shared_mutex rw_;
+  std::unordered_map<uint64_t, uint32_t> slot_of_;  // dict_external_to_internal
+  uint64_t count_ = 0;                               // cur_element_count_
+  uint64_t capacity_;                                // data_->getCapacity()
+};
+
+// ---- persistence: bruteforce.h:147-207 --------------------------------------------------------
+// chunk 0: BruteForceIndexHeader{max_elements=1, size_per_element=2, curr_element_count=3}
+// (index.proto), then one chunk per element: [vector bytes | label u64].
+Status FlatIndex::save(vk_write_chunk_fn fn, void *user) {
+  VK_TRY(flush_if_dirty());
+  std::shared_lock<std::shared_mutex> lk(rw_);
+  (void)hipSetDevice(store_.device());
+  const size_t vec_bytes = (size_t)params_.dim * 4;
+  std::string hdr;
+  pb_put_varint_field(hdr, 1, capacity_);
+  pb_put_varint_field(hdr, 2, vec_bytes + 8);
+  pb_put_varint_field(hdr, 3, count_);
+  if (fn(user, hdr.data(), hdr.size())) return Status::Err(VK_ERR_INTERNAL, "write_chunk failed");
+  const size_t rb = store_.row_bytes();
+  const uint64_t batch = std::max<uint64_t>(1, ((size_t)64 << 20) / rb);
+  std::vector<char> rows(batch * rb), buf(vec_bytes + 8);
+  for (uint64_t i0 = 0; i0 < count_; i0 += batch) {
+    uint64_t nb = std::min<uint64_t>(batch, count_ - i0);
+    VK_HIP_TRY(hipMemcpy(rows.data(), reinterpret_cast<const char *>(store_.d_rows()) + i0 * rb, nb * rb,
+                         hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < nb; ++i) {
+      memcpy(buf.data(), rows.data() + i * rb, vec_bytes);
+      uint64_t lab = store_.host_labels()[i0 + i];
+      memcpy(buf.data() + vec_bytes, &lab, 8);
+      if (fn(user, buf.data(), buf.size())) return Status::Err(VK_ERR_INTERNAL, "write_chunk failed");
+    }
+  }
+  return Status::Ok();
+}
+
+Status FlatIndex::load_from(vk_read_chunk_fn fn, void *user) {
+  std::vector<char> buf((size_t)params_.dim * 4 + 64);
+  uint64_t len = 0;
+  if (fn(user, buf.data(), buf.size(), &len)) return Status::Err(VK_ERR_INTERNAL, "read_chunk failed");
+  uint64_t max_elements = 0, size_per_element = 0, cur = 0;
+  PbReader r{reinterpret_cast<const uint8_t *>(buf.data()), reinterpret_cast<const uint8_t *>(buf.data()) + len};
+  uint32_t field, wire;
+  uint64_t val;
+  while (r.next(&field, &wire, &val)) {
+    if (field == 1) max_elements = val;
+    else if (field == 2) size_per_element = val;
+    else if (field == 3) cur = val;
+  }
+  if (size_per_element != (uint64_t)params_.dim * 4 + 8)
+    return Status::Err(VK_ERR_INTERNAL, "Persisted size_per_element does not match expectation.");
+  if (cur > max_elements) return Status::Err(VK_ERR_INTERNAL, "corrupt header: count exceeds max_elements");
+  std::unique_lock<std::shared_mutex> lk(rw_);
+  capacity_ = max_elements;
+  for (uint64_t i = 0; i < cur; ++i) {
+    if (fn(user, buf.data(), buf.size(), &len) || len != size_per_element)
+      return Status::Err(VK_ERR_INTERNAL, "truncated element chunk");
+    uint64_t lab;
+    memcpy(&lab, buf.data() + (size_t)params_.dim * 4, 8);
+    VK_TRY(add_locked(lab, reinterpret_cast<const float *>(buf.data())));
+    if (store_.staged_bytes() >= ((size_t)256 << 20)) VK_TRY(store_.flush());
+  }
+  return store_.flush();
+}
+
+static Status pick_device(const vk_index_params &p, int *device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return Status::Err(VK_ERR_NO_DEVICE, "no HIP device: libvkindex needs a gfx950 GPU (no CPU fallback)");
+  int d = p.device_id;
+  if (d < 0) {
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+  }
+  if (d >= n) return Status::Err(VK_ERR_INVALID, "device_id out of range");
+  *device = d;
+  return Status::Ok();
+}
+
+Status create_flat(const vk_index_params &p, std::unique_ptr<Index> *out) {
+  int device = 0;
+  VK_TRY(pick_device(p, &device));
+  *out = std::make_unique<FlatIndex>(p, device);
+  return Status::Ok();
+}
+
+Status load_flat(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std::unique_ptr<Index> *out) {
+  int device = 0;
+  VK_TRY(pick_device(p, &device));
+  auto ix = std::make_unique<FlatIndex>(p, device);
+  VK_TRY(ix->load_from(fn, user));
+  *out = std::move(ix);
+  return Status::Ok();
+}
+
+// ---- protobuf helpers --------------------------------------------------------------------------
+static void pb_put_varint(std::string &s, uint64_t v) {
+  while (v >= 0x80) { s.push_back((char)(v | 0x80)); v >>= 7; }
+  s.push_back((char)v);
+}
+void pb_put_varint_field(std::string &s, uint32_t field, uint64_t v) {
+  if (v == 0) return;  // proto3: default values are not serialised
+  pb_put_varint(s, (uint64_t)field << 3);
+  pb_put_varint(s, v);
+}
+void pb_put_double_field(std::string &s, uint32_t field, double v) {
+  if (v == 0.0) return;
+  pb_put_varint(s, ((uint64_t)field << 3) | 1);
+  char b[8];
+  memcpy(b, &v, 8);
+  s.append(b, 8);
+}
+bool PbReader::next(uint32_t *field, uint32_t *wire, uint64_t *val) {
+  auto varint = [&](uint64_t *o) {
+    uint64_t v = 0;
+    int shift = 0;
+    while (p < end && shift < 64) {
+      uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7F) << shift;
+      if (!(b & 0x80)) { *o = v; return true; }
+      shift += 7;
+    }
+    return false;
+  };
+  if (p >= end) return false;
+  uint64_t key;
+  if (!varint(&key)) return false;
+  *field = (uint32_t)(key >> 3);
+  *wire = (uint32_t)(key & 7);
+  if (*wire == 0) return varint(val);
+  if (*wire == 1) {
+    if (end - p < 8) return false;
+    memcpy(val, p, 8);
+    p += 8;
+    return true;
+  }
+  if (*wire == 5) {
+    if (end - p < 4) return false;
+    uint32_t v;
+    memcpy(&v, p, 4);
+    *val = v;
+    p += 4;
+    return true;
+  }
+  if (*wire == 2) {
+    uint64_t n;
+    if (!varint(&n) || (uint64_t)(end - p) < n) return false;
+    p += n;
+    *val = n;
+    return true;
+  }
+  return false;
+}
+
+}  // namespace vk

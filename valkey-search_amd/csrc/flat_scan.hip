@@ -1,0 +1,275 @@
+// flat_scan.hip -- K3: the FLAT brute-force scan (hnswlib::BruteforceSearch::searchKnn,
+// third_party/hnswlib/bruteforce.h:116-145) as an HBM-streaming CDNA4 kernel, plus the
+// per-query merge of the per-wave partial top-k lists and the label gather-scan used by
+// the pre-filter path (src/indexes/vector_base.cc:509-530) and by single-record distance
+// (vector_flat.cc:256-271).
+//
+// Roofline: memory bound.  Algorithmic bytes per pass = n_rows * row_stride (+ n/8 when
+// a filter bitmap is consulted); kQB queries share one pass.
+//
+// Mapping (see device_common.hpp for why): a wave owns 16 rows at a time, one per quad;
+// lane j of a quad streams the row with 16-B loads at chunk*64 + j*16, so every load
+// instruction of the wave touches 16 rows x 64 contiguous bytes and the whole row is
+// consumed exactly once.  The query block lives in LDS and is read with quad-broadcast
+// ds_read_b128.  Distances come out bit-identical to the reference CPU path, ties are
+// resolved by (distance,label) exactly like the std::pair heap of bruteforce.h.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace vk {
+
+template <int kQB, bool kL2, int kE>
+__global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
+  extern __shared__ float4 qs[];  // [kQB][chunks][4] float4 == kQB padded queries
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 3;
+  const int rq = lane >> 2;
+  const uint32_t chunks = a.chunks;
+  // XCD-aware decode of the 1-D grid.  Hardware places consecutive block ids on
+  // consecutive XCDs (id % 8); the blocks that re-read the SAME rows for different
+  // query groups are made consecutive on ONE XCD so the re-reads hit its private L2:
+  //   xcd = id % 8, s = id / 8, row partition = (s / nqg) * 8 + xcd, query group = s % nqg
+  const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+  const uint32_t rp = (seq / a.nqg) * 8u + xcd;
+  const uint32_t qbase = (seq % a.nqg) * kQB;
+
+  // stage the query block: queries past nq replicate the last one (results discarded)
+  {
+    const uint32_t per_q = chunks * 4;
+    for (uint32_t i = threadIdx.x; i < per_q * kQB; i += blockDim.x) {
+      uint32_t qi = i / per_q, off = i - qi * per_q;
+      uint32_t q = qbase + qi < a.nq ? qbase + qi : a.nq - 1;
+      qs[i] = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f)[off];
+    }
+  }
+  __syncthreads();
+
+  WaveTopK<kE> top[kQB];
+#pragma unroll
+  for (int qi = 0; qi < kQB; ++qi) top[qi].init(a.k);
+
+  const uint32_t total_waves = a.nrp * 4;   // nrp is a multiple of 8
+  const uint32_t wave_gid = rp * 4 + wave;
+  const uint32_t n_rows = a.row_end - a.row_begin;
+  const uint32_t n_tiles = (n_rows + kRowsPerWave - 1) / kRowsPerWave;
+
+  for (uint32_t tile = wave_gid; tile < n_tiles; tile += total_waves) {
+    const uint32_t row = a.row_begin + tile * kRowsPerWave + rq;
+    const bool valid = row < a.row_end;
+    const uint32_t lrow = valid ? row : a.row_end - 1;
+    const float4 *__restrict__ p = reinterpret_cast<const float4 *>(a.rows + (size_t)lrow * a.row_stride_f) + j;
+
+    float4 acc[kQB];
+#pragma unroll
+    for (int qi = 0; qi < kQB; ++qi) acc[qi] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    uint32_t c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = p[(c + u) * 4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int qi = 0; qi < kQB; ++qi) chunk_fma<kL2>(acc[qi], x[u], qs[(qi * chunks + c + u) * 4 + j]);
+      }
+    }
+    for (; c < chunks; ++c) {
+      float4 x = p[c * 4];
+#pragma unroll
+      for (int qi = 0; qi < kQB; ++qi) chunk_fma<kL2>(acc[qi], x, qs[(qi * chunks + c) * 4 + j]);
+    }
+
+#pragma unroll
+    for (int qi = 0; qi < kQB; ++qi) {
+      const float dist = finish_distance<kL2>(quad_reduce16(acc[qi]));
+      // distance gate first, filter second -- the order of bruteforce.h:131-135
+      const bool cand = valid && j == 0 && dist <= top[qi].thr_d;
+      uint64_t mask = __ballot(cand);
+      while (mask) {
+        const int b = __ffsll((unsigned long long)mask) - 1;
+        mask &= mask - 1;
+        const float cd = readlane_f32(dist, b);
+        if (!(cd <= top[qi].thr_d)) continue;
+        const uint32_t crow = __builtin_amdgcn_readlane((int)row, b);
+        const uint64_t cl = a.labels[crow];
+        if (!allow_bit(a.allow_bits, a.allow_nbits, cl)) continue;
+        top[qi].insert(cd, cl, lane);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int qi = 0; qi < kQB; ++qi) {
+    const uint32_t q = qbase + qi;
+    if (q < a.nq) {
+      const size_t base = ((size_t)q * total_waves + wave_gid) * a.k;
+      top[qi].store(a.part_dist + base, a.part_label + base, lane);
+    }
+  }
+}
+
+// One wave per query: k best of `n_entries` (distance,label) pairs, written ascending.
+// Empty entries are (+inf, kNoLabel).
+template <int kE>
+__global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs a) {
+  const int lane = threadIdx.x;
+  const uint64_t q = blockIdx.x;
+  WaveTopK<kE> top;
+  top.init(a.k);
+  for (uint32_t part = 0; part < a.parts; ++part) {
+    const float *__restrict__ pd = a.in_dist + ((size_t)part * a.part_stride + q * a.q_stride);
+    const uint64_t *__restrict__ pl = a.in_label + ((size_t)part * a.part_stride + q * a.q_stride);
+    for (uint32_t i0 = 0; i0 < a.per_part; i0 += kWave) {
+      const uint32_t i = i0 + lane;
+      float dist = __builtin_inff();
+      uint64_t lab = kNoLabel;
+      if (i < a.per_part) { dist = pd[i]; lab = pl[i]; }
+      uint64_t mask = __ballot(lab != kNoLabel && dist <= top.thr_d);
+      while (mask) {
+        const int b = __ffsll((unsigned long long)mask) - 1;
+        mask &= mask - 1;
+        const float cd = readlane_f32(dist, b);
+        if (!(cd <= top.thr_d)) continue;
+        top.insert(cd, readlane_u64(lab, b), lane);
+      }
+    }
+  }
+  // rank sort of the kept entries (all keys distinct: labels are unique)
+  const uint32_t cnt = top.cnt;
+  float *od = a.out_dist + q * a.k;
+  uint64_t *ol = a.out_label + q * a.k;
+#pragma unroll
+  for (int e = 0; e < kE; ++e) {
+    const uint32_t s = (uint32_t)e * kWave + lane;
+    uint32_t rank = 0;
+#pragma unroll
+    for (int e2 = 0; e2 < kE; ++e2) {
+      for (int l2 = 0; l2 < kWave; ++l2) {
+        const uint32_t t = (uint32_t)e2 * kWave + l2;
+        if (t >= cnt) break;
+        const float td = readlane_f32(top.d[e2], l2);
+        const uint64_t tl = readlane_u64(top.lab[e2], l2);
+        rank += dl_less(td, tl, top.d[e], top.lab[e]) ? 1u : 0u;
+      }
+    }
+    if (s < cnt) { od[rank] = top.d[e]; ol[rank] = top.lab[e]; }
+    if (s >= cnt && s < a.k) { od[s] = __builtin_inff(); ol[s] = kNoLabel; }
+  }
+  if (lane == 0) a.out_n[q] = cnt;
+}
+
+// Distances of an explicit row list (K8).  out[i] = distance(query, rows[idx[i]]).
+template <bool kL2>
+__global__ __launch_bounds__(256) void gather_distance_kernel(GatherArgs a) {
+  extern __shared__ float4 qs[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 3;
+  const int rq = lane >> 2;
+  const uint32_t chunks = a.chunks;
+  for (uint32_t i = threadIdx.x; i < chunks * 4; i += blockDim.x)
+    qs[i] = reinterpret_cast<const float4 *>(a.query)[i];
+  __syncthreads();
+  const uint32_t total_waves = gridDim.x * 4;
+  const uint32_t n_tiles = (a.n + kRowsPerWave - 1) / kRowsPerWave;
+  for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += total_waves) {
+    const uint32_t i = tile * kRowsPerWave + rq;
+    const bool valid = i < a.n;
+    const uint32_t row = a.idx[valid ? i : a.n - 1];
+    const float4 *__restrict__ p = reinterpret_cast<const float4 *>(a.rows + (size_t)row * a.row_stride_f) + j;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = p[(c + u) * 4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) chunk_fma<kL2>(acc, x[u], qs[(c + u) * 4 + j]);
+    }
+    for (; c < chunks; ++c) chunk_fma<kL2>(acc, p[c * 4], qs[c * 4 + j]);
+    const float dist = finish_distance<kL2>(quad_reduce16(acc));
+    if (valid && j == 0) a.out[i] = dist;
+  }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+template <int kQB, bool kL2, int kE>
+static hipError_t launch_scan_t(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<kQB, kL2, kE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((flat_scan_kernel<kQB, kL2, kE>), grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+template <bool kL2, int kE>
+static hipError_t launch_scan_qb(int qb, const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+  switch (qb) {
+    case 1: return launch_scan_t<1, kL2, kE>(a, grid, lds, s);
+    case 2: return launch_scan_t<2, kL2, kE>(a, grid, lds, s);
+    case 4: return launch_scan_t<4, kL2, kE>(a, grid, lds, s);
+    default: return launch_scan_t<8, kL2, kE>(a, grid, lds, s);
+  }
+}
+
+int flat_scan_slots_per_lane(uint64_t k) {
+  if (k <= 64) return 1;
+  if (k <= 256) return 4;
+  if (k <= 1024) return 16;
+  return 0;  // not served by the register-resident top-k
+}
+
+int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e) {
+  // query block must fit LDS (<= 64 KiB so that two blocks share a CU) and, with wide
+  // per-lane top-k state, registers
+  int qb = nq >= 8 ? 8 : nq >= 4 ? 4 : nq >= 2 ? 2 : 1;
+  if (e > 1) qb = qb > 2 ? 2 : qb;
+  if (e > 4) qb = 1;
+  while (qb > 1 && (size_t)qb * chunks * 64 > 64 * 1024) qb >>= 1;
+  return qb;
+}
+
+hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, int qb, int e, hipStream_t s) {
+  if (a.nrp == 0 || (a.nrp & 7u) || a.nqg != (a.nq + qb - 1) / qb) return hipErrorInvalidValue;
+  dim3 grid(a.nrp * a.nqg);
+  size_t lds = (size_t)qb * a.chunks * 64;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (e == 1) return l2 ? launch_scan_qb<true, 1>(qb, a, grid, lds, s) : launch_scan_qb<false, 1>(qb, a, grid, lds, s);
+  if (e == 4) return l2 ? launch_scan_qb<true, 4>(qb, a, grid, lds, s) : launch_scan_qb<false, 4>(qb, a, grid, lds, s);
+  if (e == 16) return l2 ? launch_scan_qb<true, 16>(qb, a, grid, lds, s) : launch_scan_qb<false, 16>(qb, a, grid, lds, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s) {
+  if (nq == 0) return hipSuccess;
+  dim3 grid((uint32_t)nq);
+  if (e == 1) hipLaunchKernelGGL((merge_topk_kernel<1>), grid, dim3(64), 0, s, a);
+  else if (e == 4) hipLaunchKernelGGL((merge_topk_kernel<4>), grid, dim3(64), 0, s, a);
+  else if (e == 16) hipLaunchKernelGGL((merge_topk_kernel<16>), grid, dim3(64), 0, s, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_distance(const GatherArgs &a, bool l2, hipStream_t s) {
+  if (a.n == 0) return hipSuccess;
+  uint32_t tiles = (a.n + kRowsPerWave - 1) / kRowsPerWave;
+  uint32_t blocks = (tiles + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  size_t lds = (size_t)a.chunks * 64;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    const void *f = l2 ? reinterpret_cast<const void *>(&gather_distance_kernel<true>)
+                       : reinterpret_cast<const void *>(&gather_distance_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  if (l2) hipLaunchKernelGGL((gather_distance_kernel<true>), dim3(blocks), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((gather_distance_kernel<false>), dim3(blocks), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace vk

@@ -1,0 +1,132 @@
+// index.hpp -- the objects behind the C ABI (include/vk_index.h).
+//
+//   FlatIndex  stands in for hnswlib::BruteforceSearch<float>  (third_party/hnswlib/bruteforce.h)
+//   HnswIndex  stands in for hnswlib::HierarchicalNSW<float>   (third_party/hnswlib/hnswalg.h)
+// Host side keeps what the reference keeps on the host (label<->slot maps, the HNSW
+// graph's authoritative copy); the device holds the row table (row_store.hpp) and, for
+// HNSW, a fixed-stride mirror of the link lists, and answers the searches.
+#pragma once
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vk_index.h"
+#include "kernels.hpp"
+#include "row_store.hpp"
+
+namespace vk {
+
+// grow-only device / pinned buffers
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  Status ensure(size_t bytes);
+  void release();
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  Status ensure(size_t bytes);
+  void release();
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+// Per-call resources: a stream plus scratch, so that concurrent reader threads
+// (search.cc:886-910 schedules one query per reader-pool thread) do not serialise.
+struct SearchCtx {
+  hipStream_t stream = nullptr;
+  DevBuf d_q, d_part_d, d_part_l, d_out_d, d_out_l, d_out_n, d_allow, d_idx, d_tmp, d_stats;
+  PinBuf h_q, h_out_d, h_out_l, h_out_n, h_tmp, h_idx;
+  ~SearchCtx();
+};
+
+class CtxPool {
+ public:
+  explicit CtxPool(int device, size_t max_ctx = 16) : device_(device), max_(max_ctx) {}
+  ~CtxPool();
+  SearchCtx *acquire();
+  void release(SearchCtx *c);
+
+ private:
+  int device_;
+  size_t max_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<SearchCtx *> free_;
+  std::vector<std::unique_ptr<SearchCtx>> all_;
+};
+
+struct CtxLease {
+  CtxPool &pool;
+  SearchCtx *ctx;
+  explicit CtxLease(CtxPool &p) : pool(p), ctx(p.acquire()) {}
+  ~CtxLease() { pool.release(ctx); }
+};
+
+struct SearchRequest {
+  const float *queries = nullptr;   // host or device, [nq][dim] (host) / [nq][stride_f] padded (device)
+  uint64_t nq = 0, k = 0, ef = 0;
+  const uint64_t *allow_bits = nullptr;
+  uint64_t allow_nbits = 0;
+  const volatile int *cancel_flag = nullptr;
+  bool partial_ok = true;
+};
+
+class Index {
+ public:
+  virtual ~Index() = default;
+  const vk_index_params &params() const { return params_; }
+  bool l2() const { return params_.metric == VK_METRIC_L2; }
+
+  virtual Status add(uint64_t label, const float *row) = 0;
+  virtual Status add_batch(const uint64_t *labels, const float *rows, uint64_t n) = 0;
+  virtual Status remove(uint64_t label) = 0;
+  virtual Status resize(uint64_t new_max) = 0;
+  virtual Status set_ef(uint32_t ef) = 0;
+  virtual Status flush() = 0;
+  // host buffers in/out
+  virtual Status search(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) = 0;
+  // device buffers in/out, enqueued on `stream` (nullptr = internal) without host sync
+  virtual Status search_device(const SearchRequest &rq, float *d_out_dist, uint64_t *d_out_label,
+                               uint32_t *d_out_n, hipStream_t stream) = 0;
+  virtual Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n,
+                               float *out_dist, uint64_t *out_label, uint64_t *out_n) = 0;
+  virtual Status distance(uint64_t label, const float *query, float *out) = 0;
+  virtual Status get_row(uint64_t label, float *out) = 0;
+  virtual Status contains(uint64_t label, bool *found) = 0;
+  virtual Status stats(vk_index_stats *out) = 0;
+  virtual Status device_rows(uint64_t n, void **d_rows, uint64_t *stride_bytes) = 0;
+  virtual Status commit_device_rows(uint64_t n, const uint64_t *labels) = 0;
+  virtual Status save(vk_write_chunk_fn fn, void *user) = 0;
+
+ protected:
+  explicit Index(const vk_index_params &p) : params_(p) {}
+  vk_index_params params_;
+};
+
+Status create_flat(const vk_index_params &p, std::unique_ptr<Index> *out);
+Status create_hnsw(const vk_index_params &p, std::unique_ptr<Index> *out);
+Status load_flat(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std::unique_ptr<Index> *out);
+Status load_hnsw(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std::unique_ptr<Index> *out);
+
+// shared helpers --------------------------------------------------------------------
+// pad nq host queries of `dim` floats into ctx->h_q ([nq][stride_f]) and copy to ctx->d_q
+Status upload_queries(SearchCtx *ctx, const float *queries, uint64_t nq, uint32_t dim, uint32_t stride_f);
+Status upload_allow(SearchCtx *ctx, const uint64_t *allow_bits, uint64_t allow_nbits, const uint64_t **d_allow);
+// exact kNN over gathered distances with the AddPrefilteredKey rule (vector_base.cc:509-530)
+void prefilter_heap_select(const float *dist, const uint64_t *labels, uint64_t n, uint64_t k,
+                           float *out_dist, uint64_t *out_label, uint64_t *out_n);
+
+// protobuf varint helpers for the index.proto headers (persist.cc)
+void pb_put_varint_field(std::string &s, uint32_t field, uint64_t v);
+void pb_put_double_field(std::string &s, uint32_t field, double v);
+struct PbReader {
+  const uint8_t *p, *end;
+  bool next(uint32_t *field, uint32_t *wire, uint64_t *val);
+};
+
+}  // namespace vk

@@ -1,0 +1,156 @@
+// row_store.cc -- see row_store.hpp
+#include "row_store.hpp"
+
+#include <string.h>
+
+#include <algorithm>
+
+namespace vk {
+
+RowStore::RowStore(int device, uint32_t dim) : device_(device), dim_(dim), stride_f_(padded_dim(dim)) {
+  (void)hipSetDevice(device_);
+  (void)hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
+  size_t rb = row_bytes();
+  chunk_bytes_ = std::max<size_t>(rb * 64, (size_t)8 << 20);
+  chunk_bytes_ -= chunk_bytes_ % rb;
+}
+
+RowStore::~RowStore() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (char *c : chunks_) (void)hipHostFree(c);
+  if (d_rows_) (void)hipFree(d_rows_);
+  if (d_labels_) (void)hipFree(d_labels_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+uint64_t RowStore::host_bytes() const {
+  return chunks_.size() * chunk_bytes_ + h_labels_.capacity() * 8 + ops_.capacity() * sizeof(Op);
+}
+
+Status RowStore::staging_alloc(size_t bytes, size_t *off, char **ptr) {
+  if (chunks_.empty() || chunk_used_ + bytes > chunk_bytes_) {
+    size_t next = chunks_.empty() ? 0 : cur_chunk_ + 1;
+    if (next >= chunks_.size()) {
+      (void)hipSetDevice(device_);
+      char *p = nullptr;
+      VK_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p), chunk_bytes_, hipHostMallocDefault));
+      chunks_.push_back(p);
+    }
+    cur_chunk_ = next;
+    chunk_used_ = 0;
+  }
+  *off = cur_chunk_ * chunk_bytes_ + chunk_used_;
+  *ptr = chunks_[cur_chunk_] + chunk_used_;
+  chunk_used_ += bytes;
+  staged_bytes_ += bytes;
+  return Status::Ok();
+}
+
+Status RowStore::stage_write(uint32_t slot, const float *row, uint64_t label) {
+  size_t off;
+  char *p;
+  VK_TRY(staging_alloc(row_bytes(), &off, &p));
+  memcpy(p, row, (size_t)dim_ * 4);
+  if (stride_f_ > dim_) memset(p + (size_t)dim_ * 4, 0, (size_t)(stride_f_ - dim_) * 4);
+  ops_.push_back(Op{0, slot, 0, off});
+  stage_label(slot, label);
+  return Status::Ok();
+}
+
+void RowStore::stage_move(uint32_t dst, uint32_t src, uint64_t label) {
+  ops_.push_back(Op{1, dst, src, 0});
+  stage_label(dst, label);
+}
+
+void RowStore::stage_label(uint32_t slot, uint64_t label) {
+  if (h_labels_.size() <= slot) h_labels_.resize((size_t)slot + 1, ~0ull);
+  h_labels_[slot] = label;
+  label_dirty_lo_ = std::min<uint64_t>(label_dirty_lo_, slot);
+  label_dirty_hi_ = std::max<uint64_t>(label_dirty_hi_, (uint64_t)slot + 1);
+}
+
+Status RowStore::reserve(uint64_t rows) {
+  if (rows <= alloc_rows_) return Status::Ok();
+  (void)hipSetDevice(device_);
+  uint64_t want = std::max<uint64_t>(rows, alloc_rows_ + alloc_rows_ / 2);
+  want = std::max<uint64_t>(want, 1024);
+  float *nr = nullptr;
+  uint64_t *nl = nullptr;
+  VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nr), want * row_bytes()));
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&nl), want * 8);
+  if (e != hipSuccess) {
+    (void)hipFree(nr);
+    return Status::Err(4, std::string("hipMalloc labels: ") + hipGetErrorString(e));
+  }
+  if (alloc_rows_) {
+    VK_HIP_TRY(hipMemcpyAsync(nr, d_rows_, alloc_rows_ * row_bytes(), hipMemcpyDeviceToDevice, stream_));
+    VK_HIP_TRY(hipMemcpyAsync(nl, d_labels_, alloc_rows_ * 8, hipMemcpyDeviceToDevice, stream_));
+  }
+  VK_HIP_TRY(hipMemsetAsync(nl + alloc_rows_, 0xFF, (want - alloc_rows_) * 8, stream_));
+  VK_HIP_TRY(hipStreamSynchronize(stream_));
+  if (d_rows_) (void)hipFree(d_rows_);
+  if (d_labels_) (void)hipFree(d_labels_);
+  d_rows_ = nr;
+  d_labels_ = nl;
+  alloc_rows_ = want;
+  return Status::Ok();
+}
+
+Status RowStore::flush() {
+  if (!dirty()) return Status::Ok();
+  (void)hipSetDevice(device_);
+  uint64_t need = h_labels_.size();
+  for (const Op &op : ops_) need = std::max<uint64_t>(need, (uint64_t)op.slot + 1);
+  VK_TRY(reserve(need));
+  const size_t rb = row_bytes();
+  size_t i = 0;
+  while (i < ops_.size()) {
+    const Op &op = ops_[i];
+    if (op.kind == 0) {
+      // merge a run of writes that is contiguous both in slots and in staging
+      size_t jn = i + 1;
+      while (jn < ops_.size() && ops_[jn].kind == 0 && ops_[jn].slot == ops_[jn - 1].slot + 1 &&
+             ops_[jn].off == ops_[jn - 1].off + rb && (ops_[jn].off / chunk_bytes_) == (op.off / chunk_bytes_))
+        ++jn;
+      const char *src = chunks_[op.off / chunk_bytes_] + (op.off % chunk_bytes_);
+      VK_HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(d_rows_) + (size_t)op.slot * rb, src, (jn - i) * rb,
+                                hipMemcpyHostToDevice, stream_));
+      i = jn;
+    } else {
+      VK_HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(d_rows_) + (size_t)op.slot * rb,
+                                reinterpret_cast<char *>(d_rows_) + (size_t)op.src * rb, rb,
+                                hipMemcpyDeviceToDevice, stream_));
+      ++i;
+    }
+  }
+  if (label_dirty_lo_ < label_dirty_hi_) {
+    uint64_t hi = std::min<uint64_t>(label_dirty_hi_, h_labels_.size());
+    if (hi > label_dirty_lo_)
+      VK_HIP_TRY(hipMemcpyAsync(d_labels_ + label_dirty_lo_, h_labels_.data() + label_dirty_lo_,
+                                (hi - label_dirty_lo_) * 8, hipMemcpyHostToDevice, stream_));
+  }
+  VK_HIP_TRY(hipStreamSynchronize(stream_));
+  ops_.clear();
+  staged_bytes_ = 0;
+  chunk_used_ = 0;
+  cur_chunk_ = 0;
+  while (chunks_.size() > 8) {  // keep at most 8 pinned chunks around
+    (void)hipHostFree(chunks_.back());
+    chunks_.pop_back();
+  }
+  label_dirty_lo_ = ~0ull;
+  label_dirty_hi_ = 0;
+  return Status::Ok();
+}
+
+Status RowStore::read_row(uint32_t slot, float *out) {
+  VK_TRY(flush());
+  (void)hipSetDevice(device_);
+  if (slot >= alloc_rows_) return Status::Err(3, "slot out of range");
+  VK_HIP_TRY(hipMemcpy(out, reinterpret_cast<char *>(d_rows_) + (size_t)slot * row_bytes(), (size_t)dim_ * 4,
+                       hipMemcpyDeviceToHost));
+  return Status::Ok();
+}
+
+}  // namespace vk

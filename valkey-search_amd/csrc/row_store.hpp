@@ -1,0 +1,95 @@
+// row_store.hpp -- HBM-resident row table shared by the FLAT and HNSW device mirrors.
+//
+// Layout in HBM: rows[slot][stride_f] f32, row-contiguous, each row zero-padded to a
+// multiple of 16 floats (64 B) so a quad of lanes can stream it with aligned 16-B loads
+// and the padding reproduces SimSIMD's masked tail (device_common.hpp); labels[slot] u64.
+// Host mutations are appended to an op log with their row payload in pinned staging
+// memory and applied in order by flush() on the store's stream -- the "publish at the
+// write->read phase switch" model that replaces hnswlib storing raw host pointers
+// (bruteforce.h:81, hnswalg.h:1576-1577).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace vk {
+
+struct Status {
+  int code = 0;  // vk_status
+  std::string msg;
+  bool ok() const { return code == 0; }
+  static Status Ok() { return {}; }
+  static Status Err(int c, std::string m) { return Status{c, std::move(m)}; }
+};
+
+#define VK_HIP_TRY(expr)                                                                      \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return ::vk::Status::Err(4, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+  } while (0)
+
+#define VK_TRY(expr)                       \
+  do {                                     \
+    ::vk::Status _s = (expr);              \
+    if (!_s.ok()) return _s;               \
+  } while (0)
+
+inline uint32_t padded_dim(uint32_t dim) { return (dim + 15u) & ~15u; }
+
+class RowStore {
+ public:
+  RowStore(int device, uint32_t dim);
+  ~RowStore();
+  RowStore(const RowStore &) = delete;
+  RowStore &operator=(const RowStore &) = delete;
+
+  uint32_t dim() const { return dim_; }
+  uint32_t stride_f() const { return stride_f_; }
+  size_t row_bytes() const { return (size_t)stride_f_ * 4; }
+  int device() const { return device_; }
+  hipStream_t stream() const { return stream_; }
+  const float *d_rows() const { return d_rows_; }
+  float *d_rows_mut() { return d_rows_; }
+  const uint64_t *d_labels() const { return d_labels_; }
+  uint64_t alloc_rows() const { return alloc_rows_; }
+  size_t staged_ops() const { return ops_.size(); }
+  size_t staged_bytes() const { return staged_bytes_; }
+  bool dirty() const { return !ops_.empty() || label_dirty_lo_ < label_dirty_hi_; }
+  uint64_t device_bytes() const { return alloc_rows_ * (row_bytes() + 8); }
+  uint64_t host_bytes() const;
+
+  // host-side staging (caller serialises mutations)
+  Status stage_write(uint32_t slot, const float *row, uint64_t label);  // row: dim floats
+  void stage_move(uint32_t dst, uint32_t src, uint64_t label);          // row[dst] = row[src]
+  void stage_label(uint32_t slot, uint64_t label);
+  // make sure the device arrays can hold `rows` slots (keeps contents)
+  Status reserve(uint64_t rows);
+  // apply the log; blocks until the device copy is complete
+  Status flush();
+  // read one row back (dim floats); flushes first if needed
+  Status read_row(uint32_t slot, float *out);
+  // labels mirror (authoritative on the host)
+  std::vector<uint64_t> &host_labels() { return h_labels_; }
+
+ private:
+  struct Op { uint8_t kind; uint32_t slot; uint32_t src; size_t off; };  // kind 0 write, 1 move
+  Status staging_alloc(size_t bytes, size_t *off, char **ptr);
+
+  int device_;
+  uint32_t dim_, stride_f_;
+  hipStream_t stream_ = nullptr;
+  float *d_rows_ = nullptr;
+  uint64_t *d_labels_ = nullptr;
+  uint64_t alloc_rows_ = 0;
+  std::vector<uint64_t> h_labels_;
+  uint64_t label_dirty_lo_ = ~0ull, label_dirty_hi_ = 0;
+  std::vector<Op> ops_;
+  std::vector<char *> chunks_;   // pinned staging chunks
+  size_t chunk_bytes_ = 0, chunk_used_ = 0, cur_chunk_ = 0;
+  size_t staged_bytes_ = 0;
+};
+
+}  // namespace vk

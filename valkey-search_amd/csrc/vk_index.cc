@@ -1,0 +1,256 @@
+// vk_index.cc -- the C ABI declared in include/vk_index.h: argument checking, error
+// strings, and dispatch to FlatIndex / HnswIndex.  No exception leaves this file.
+#include "../../include/vk_index.h"
+
+#include <string.h>
+
+#include <exception>
+#include <memory>
+#include <string>
+
+#include "index.hpp"
+
+struct vk_index {
+  std::unique_ptr<vk::Index> impl;
+};
+
+namespace {
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+int done(const vk::Status &s) {
+  if (s.ok()) return VK_OK;
+  g_last_error = s.msg;
+  return s.code;
+}
+
+template <class F>
+int guarded(F &&f) {
+  try {
+    return done(f());
+  } catch (const std::exception &e) {
+    return fail(VK_ERR_INTERNAL, e.what());
+  } catch (...) {
+    return fail(VK_ERR_INTERNAL, "unknown exception");
+  }
+}
+
+vk::Status check_params(const vk_index_params *p) {
+  if (!p) return vk::Status::Err(VK_ERR_INVALID, "params is NULL");
+  if (p->struct_size != sizeof(vk_index_params)) return vk::Status::Err(VK_ERR_INVALID, "vk_index_params.struct_size mismatch");
+  if (p->algo > VK_ALGO_HNSW) return vk::Status::Err(VK_ERR_INVALID, "unknown algo");
+  if (p->metric > VK_METRIC_COSINE) return vk::Status::Err(VK_ERR_INVALID, "unknown metric");
+  if (p->dtype != VK_DTYPE_F32) return vk::Status::Err(VK_ERR_INVALID, "only FLOAT32 storage is implemented");
+  if (p->dim == 0 || p->dim > 64000) return vk::Status::Err(VK_ERR_INVALID, "dimension out of range");
+  if (p->initial_cap >= (1ull << 32)) return vk::Status::Err(VK_ERR_INVALID, "initial_cap out of range");
+  if (p->algo == VK_ALGO_HNSW && (p->m < 2 || p->m > 10000)) return vk::Status::Err(VK_ERR_INVALID, "M out of range");
+  return vk::Status::Ok();
+}
+}  // namespace
+
+extern "C" {
+
+const char *vk_last_error(void) { return g_last_error.c_str(); }
+
+int vk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int vk_index_create(const vk_index_params *params, vk_index **out) {
+  if (!out) return fail(VK_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  return guarded([&]() -> vk::Status {
+    VK_TRY(check_params(params));
+    std::unique_ptr<vk::Index> impl;
+    if (params->algo == VK_ALGO_FLAT) VK_TRY(vk::create_flat(*params, &impl));
+    else VK_TRY(vk::create_hnsw(*params, &impl));
+    *out = new vk_index{std::move(impl)};
+    return vk::Status::Ok();
+  });
+}
+
+void vk_index_destroy(vk_index *ix) {
+  try {
+    delete ix;
+  } catch (...) {
+  }
+}
+
+#define VK_NEED(ix)                                             \
+  if (!(ix) || !(ix)->impl) return fail(VK_ERR_INVALID, "index is NULL")
+
+int vk_index_add(vk_index *ix, uint64_t label, const void *row) {
+  VK_NEED(ix);
+  if (!row) return fail(VK_ERR_INVALID, "row is NULL");
+  return guarded([&] { return ix->impl->add(label, static_cast<const float *>(row)); });
+}
+
+int vk_index_add_batch(vk_index *ix, const uint64_t *labels, const void *rows, uint64_t n) {
+  VK_NEED(ix);
+  if (n && !rows) return fail(VK_ERR_INVALID, "rows is NULL");
+  return guarded([&] { return ix->impl->add_batch(labels, static_cast<const float *>(rows), n); });
+}
+
+int vk_index_remove(vk_index *ix, uint64_t label) {
+  VK_NEED(ix);
+  return guarded([&] { return ix->impl->remove(label); });
+}
+
+int vk_index_resize(vk_index *ix, uint64_t new_max_elements) {
+  VK_NEED(ix);
+  if (new_max_elements >= (1ull << 32)) return fail(VK_ERR_INVALID, "new_max_elements out of range");
+  return guarded([&] { return ix->impl->resize(new_max_elements); });
+}
+
+int vk_index_set_ef(vk_index *ix, uint32_t ef) {
+  VK_NEED(ix);
+  return guarded([&] { return ix->impl->set_ef(ef); });
+}
+
+int vk_index_flush(vk_index *ix) {
+  VK_NEED(ix);
+  return guarded([&] { return ix->impl->flush(); });
+}
+
+int vk_index_search_batch(vk_index *ix, const void *queries, uint64_t nq, uint64_t k, uint64_t ef_runtime,
+                          const uint64_t *allow_bits, uint64_t allow_nbits, const volatile int *cancel_flag,
+                          int partial_ok, float *out_dist, uint64_t *out_label, uint64_t *out_n) {
+  VK_NEED(ix);
+  if (nq && (!queries || !out_n)) return fail(VK_ERR_INVALID, "queries/out_n is NULL");
+  if (nq && k && (!out_dist || !out_label)) return fail(VK_ERR_INVALID, "output buffers are NULL");
+  return guarded([&] {
+    vk::SearchRequest rq;
+    rq.queries = static_cast<const float *>(queries);
+    rq.nq = nq;
+    rq.k = k;
+    rq.ef = ef_runtime;
+    rq.allow_bits = allow_bits;
+    rq.allow_nbits = allow_nbits;
+    rq.cancel_flag = cancel_flag;
+    rq.partial_ok = partial_ok != 0;
+    return ix->impl->search(rq, out_dist, out_label, out_n);
+  });
+}
+
+int vk_index_search(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, const uint64_t *allow_bits,
+                    uint64_t allow_nbits, const volatile int *cancel_flag, int partial_ok, float *out_dist,
+                    uint64_t *out_label, uint64_t *out_n) {
+  return vk_index_search_batch(ix, query, 1, k, ef_runtime, allow_bits, allow_nbits, cancel_flag, partial_ok,
+                               out_dist, out_label, out_n);
+}
+
+int vk_index_search_batch_device(vk_index *ix, const void *d_queries, uint64_t nq, uint64_t k, uint64_t ef_runtime,
+                                 const uint64_t *d_allow_bits, uint64_t allow_nbits, float *d_out_dist,
+                                 uint64_t *d_out_label, uint32_t *d_out_n, void *hip_stream) {
+  VK_NEED(ix);
+  if (nq && (!d_queries || !d_out_dist || !d_out_label || !d_out_n)) return fail(VK_ERR_INVALID, "device buffers are NULL");
+  return guarded([&] {
+    vk::SearchRequest rq;
+    rq.queries = static_cast<const float *>(d_queries);
+    rq.nq = nq;
+    rq.k = k;
+    rq.ef = ef_runtime;
+    rq.allow_bits = d_allow_bits;
+    rq.allow_nbits = allow_nbits;
+    return ix->impl->search_device(rq, d_out_dist, d_out_label, d_out_n, static_cast<hipStream_t>(hip_stream));
+  });
+}
+
+int vk_index_search_labels(vk_index *ix, const void *query, uint64_t k, const uint64_t *labels, uint64_t n_labels,
+                           float *out_dist, uint64_t *out_label, uint64_t *out_n) {
+  VK_NEED(ix);
+  if (!query || !out_n || (n_labels && !labels)) return fail(VK_ERR_INVALID, "NULL argument");
+  return guarded([&] {
+    return ix->impl->search_labels(static_cast<const float *>(query), k, labels, n_labels, out_dist, out_label, out_n);
+  });
+}
+
+int vk_index_distance(vk_index *ix, uint64_t label, const void *query, float *out) {
+  VK_NEED(ix);
+  if (!query || !out) return fail(VK_ERR_INVALID, "NULL argument");
+  return guarded([&] { return ix->impl->distance(label, static_cast<const float *>(query), out); });
+}
+
+int vk_index_get_row(vk_index *ix, uint64_t label, void *out_row) {
+  VK_NEED(ix);
+  if (!out_row) return fail(VK_ERR_INVALID, "out_row is NULL");
+  return guarded([&] { return ix->impl->get_row(label, static_cast<float *>(out_row)); });
+}
+
+int vk_index_contains(vk_index *ix, uint64_t label, int *out_found) {
+  VK_NEED(ix);
+  if (!out_found) return fail(VK_ERR_INVALID, "out_found is NULL");
+  return guarded([&] {
+    bool f = false;
+    vk::Status s = ix->impl->contains(label, &f);
+    *out_found = f ? 1 : 0;
+    return s;
+  });
+}
+
+int vk_index_get_stats(vk_index *ix, vk_index_stats *out) {
+  VK_NEED(ix);
+  if (!out) return fail(VK_ERR_INVALID, "out is NULL");
+  return guarded([&] { return ix->impl->stats(out); });
+}
+
+int vk_index_device_rows(vk_index *ix, uint64_t n_rows, void **d_rows, uint64_t *row_stride_bytes) {
+  VK_NEED(ix);
+  if (!d_rows || !row_stride_bytes) return fail(VK_ERR_INVALID, "NULL argument");
+  return guarded([&] { return ix->impl->device_rows(n_rows, d_rows, row_stride_bytes); });
+}
+
+int vk_index_commit_device_rows(vk_index *ix, uint64_t n_rows, const uint64_t *labels) {
+  VK_NEED(ix);
+  return guarded([&] { return ix->impl->commit_device_rows(n_rows, labels); });
+}
+
+int vk_merge_topk_device(const float *d_dist, const uint64_t *d_label, uint32_t parts, uint64_t nq, uint64_t k,
+                         float *d_out_dist, uint64_t *d_out_label, uint32_t *d_out_n, int device_id,
+                         void *hip_stream) {
+  if (!d_dist || !d_label || !d_out_dist || !d_out_label || !d_out_n) return fail(VK_ERR_INVALID, "NULL argument");
+  return guarded([&]() -> vk::Status {
+    int e = vk::flat_scan_slots_per_lane(k);
+    if (e == 0 || k == 0) return vk::Status::Err(VK_ERR_INVALID, "k out of range for the device merge");
+    if (device_id >= 0) VK_HIP_TRY(hipSetDevice(device_id));
+    vk::MergeArgs m{};
+    m.in_dist = d_dist;
+    m.in_label = d_label;
+    m.part_stride = nq * k;
+    m.q_stride = k;
+    m.parts = parts;
+    m.per_part = (uint32_t)k;
+    m.k = (uint32_t)k;
+    m.out_dist = d_out_dist;
+    m.out_label = d_out_label;
+    m.out_n = d_out_n;
+    VK_HIP_TRY(vk::launch_merge_topk(m, e, nq, static_cast<hipStream_t>(hip_stream)));
+    return vk::Status::Ok();
+  });
+}
+
+int vk_index_save(vk_index *ix, vk_write_chunk_fn write_chunk, void *user) {
+  VK_NEED(ix);
+  if (!write_chunk) return fail(VK_ERR_INVALID, "write_chunk is NULL");
+  return guarded([&] { return ix->impl->save(write_chunk, user); });
+}
+
+int vk_index_load(const vk_index_params *params, vk_read_chunk_fn read_chunk, void *user, vk_index **out) {
+  if (!out || !read_chunk) return fail(VK_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  return guarded([&]() -> vk::Status {
+    VK_TRY(check_params(params));
+    std::unique_ptr<vk::Index> impl;
+    if (params->algo == VK_ALGO_FLAT) VK_TRY(vk::load_flat(*params, read_chunk, user, &impl));
+    else VK_TRY(vk::load_hnsw(*params, read_chunk, user, &impl));
+    *out = new vk_index{std::move(impl)};
+    return vk::Status::Ok();
+  });
+}
+
+}  // extern "C"
