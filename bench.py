@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- kNN queries/sec on the FLAT path (BASELINE.json configs[1]):
+FLAT index, 10M x 768 fp32 COSINE, k=10, batch=256 queries per step.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  The index (fixed total size) is sharded by contiguous row ranges over
+the N ranks ("strong" scaling: total work fixed); a step = every rank scans its shard for
+the same 256 queries (rows resident in HBM, queries resident in HBM), one RCCL all-gather
+of the per-shard top-k, and the (distance,label) merge -- so the N-GPU answer is
+bit-identical to the 1-GPU answer.  Rank 0 prints ONE JSON line.
+
+PyTorch is plumbing here: synthetic data generation on the device, the RCCL process group,
+and HIP events.  The search itself is libvkindex.so called through its C ABI.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import _pkg  # noqa: E402
+
+vsa = _pkg.vsa
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
+
+
+class _DevMem:
+    """Expose a raw device allocation (the index's HBM row table) to torch without a copy."""
+
+    def __init__(self, ptr, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def device_view(ptr, shape, device):
+    return torch.as_tensor(_DevMem(ptr, shape), device=device)
+
+
+def gen_rows(n_begin, n_rows, dim, device, chunk=65536, latent=32, noise=0.05, seed=1234):
+    """Rank-32 latent model x = A z + 0.05 eps, L2-normalised;
+    chunk c is seeded by (seed, c) so any shard of any world size sees the same rows."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    A = torch.randn(dim, latent, generator=g, device=device, dtype=torch.float32)
+    c0, c1 = n_begin // chunk, (n_begin + n_rows + chunk - 1) // chunk
+    for c in range(c0, c1):
+        g.manual_seed(seed * 1000003 + c + 1)
+        z = torch.randn(chunk, latent, generator=g, device=device, dtype=torch.float32)
+        e = torch.randn(chunk, dim, generator=g, device=device, dtype=torch.float32)
+        x = z @ A.T + noise * e
+        x = torch.nn.functional.normalize(x, dim=1)
+        lo = max(n_begin, c * chunk)
+        hi = min(n_begin + n_rows, (c + 1) * chunk)
+        yield lo, x[lo - c * chunk: hi - c * chunk].contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-queries-per-thread", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-query-steps", type=int, default=5, help="extra: B=1 scan timing (HBM roofline)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    N, D, B, K = args.rows, args.dim, args.batch, args.k
+    r0 = rank * N // world
+    r1 = (rank + 1) * N // world
+    n_local = r1 - r0
+
+    # ---- build the shard: rows generated straight into the index's HBM row table ----
+    t_build = time.time()
+    ix = vsa.Index("FLAT", D, "COSINE", initial_cap=n_local, device_id=local_rank)
+    base_ptr, stride = ix.device_rows(n_local)
+    assert stride == ((D + 15) // 16) * 16 * 4
+    table = device_view(base_ptr, (n_local, stride // 4), device)   # [rows][padded dim] f32 in HBM
+    if stride != D * 4:
+        table[:, D:] = 0
+    for lo, x in gen_rows(r0, n_local, D, device):
+        table[lo - r0: lo - r0 + x.shape[0], :D] = x
+    torch.cuda.synchronize()
+    ix.commit_device_rows(n_local, np.arange(r0, r1, dtype=np.uint64))
+    t_build = time.time() - t_build
+
+    qg = torch.Generator(device=device)
+    qg.manual_seed(4242)
+    gA = torch.Generator(device=device)
+    gA.manual_seed(1234)
+    A = torch.randn(D, 32, generator=gA, device=device, dtype=torch.float32)
+    Q = torch.nn.functional.normalize(
+        torch.randn(B, 32, generator=qg, device=device) @ A.T + 0.05 * torch.randn(B, D, generator=qg, device=device),
+        dim=1).contiguous()
+
+    out_d = torch.empty(B, K, device=device, dtype=torch.float32)
+    out_l = torch.empty(B, K, device=device, dtype=torch.int64)
+    out_n = torch.empty(B, device=device, dtype=torch.int32)
+    if world > 1:
+        all_d = torch.empty(world, B, K, device=device, dtype=torch.float32)
+        all_l = torch.empty(world, B, K, device=device, dtype=torch.int64)
+        fin_d = torch.empty(B, K, device=device, dtype=torch.float32)
+        fin_l = torch.empty(B, K, device=device, dtype=torch.int64)
+        fin_n = torch.empty(B, device=device, dtype=torch.int32)
+
+    # a real (non-null) HIP stream: kernels, RCCL and the timing events all go on it
+    work_stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(work_stream)
+
+    def stream_ptr():
+        return work_stream.cuda_stream
+
+    def step(nq=B):
+        ix.search_batch_device(Q.data_ptr(), nq, K, out_d.data_ptr(), out_l.data_ptr(), out_n.data_ptr(),
+                               stream=stream_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(all_d, out_d)
+            dist.all_gather_into_tensor(all_l, out_l)
+            vsa.merge_topk_device(all_d.data_ptr(), all_l.data_ptr(), world, nq, K, fin_d.data_ptr(),
+                                  fin_l.data_ptr(), fin_n.data_ptr(), local_rank, stream_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- extra: single-query scan (the memory-bound formulation of the same path) ----
+    single = None
+    if args.single_query_steps > 0:
+        step(1)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.single_query_steps):
+            ix.search_batch_device(Q.data_ptr(), 1, K, out_d.data_ptr(), out_l.data_ptr(), out_n.data_ptr(),
+                                   stream=stream_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        ms1 = e0.elapsed_time(e1) / args.single_query_steps
+        gbs = n_local * stride / (ms1 * 1e-3) / 1e9
+        single = {"ms_per_query": round(ms1, 4), "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                  "bytes": n_local * stride}
+
+    result_d = (fin_d if world > 1 else out_d).cpu().numpy()
+    result_l = (fin_l if world > 1 else out_l).cpu().numpy().view(np.uint64)
+
+    # ---- CPU baseline + parity spot check on rank 0 (oracle = checker, never the product) ----
+    cpu = None
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        S = min(args.cpu_rows, n_local)
+        host_rows = np.ascontiguousarray(table[:S, :D].cpu().numpy())
+        flat = O.Flat(D, "COSINE", isa="skylake", max_elements=S)
+        flat.add_many(host_rows, np.arange(r0, r0 + S, dtype=np.uint64), borrowed=True)
+        hq = Q.cpu().numpy()
+        threads = len(os.sched_getaffinity(0))
+        nqt = threads * args.cpu_queries_per_thread
+        flat.search(hq[0], K)  # warm
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            res = list(ex.map(lambda i: flat.search(hq[i % B], K), range(nqt)))
+        cdt = time.perf_counter() - t1
+        qps_sample = nqt / cdt
+        cpu = {"value": round(qps_sample * S / N, 4), "unit": "queries/s", "cores": threads, "kind": "port",
+               "sample": f"oracle FLAT scan ({O.cpu_path()} clone of the SimSIMD skylake order), {nqt} queries over "
+                         f"the first {S} rows on {threads} threads ({qps_sample:.1f} q/s on the sample), scaled "
+                         f"linearly to {N} rows"}
+        # parity at full index size: the GPU answer restricted by a filter to the sampled rows must equal
+        # the oracle's answer on those rows, ids and distance bits
+        bits = O.allow_bitmap(np.arange(r0, r0 + S, dtype=np.uint64), r0 + S)
+        ok = True
+        for i in range(4):
+            gd, gl = ix.search(hq[i], K, allow=bits, allow_nbits=r0 + S)
+            od, ol = res[i] if i < len(res) else flat.search(hq[i], K)
+            ok = ok and gl.tolist() == ol.tolist() and gd.view(np.uint32).tolist() == od.view(np.uint32).tolist()
+        parity = "bit-exact" if ok else "MISMATCH"
+
+    if rank == 0:
+        qps = B * args.steps / dt
+        scan_bytes = n_local * stride                       # algorithmic bytes of one pass over the shard
+        flops = 2.0 * n_local * D * B                       # per step per GPU
+        out = {
+            "metric": "kNN queries/sec, FLAT 10Mx768 fp32 cosine k=10 batch=256",
+            "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"FLAT {N}x{D} fp32 COSINE k={K} batch={B} (BASELINE.json configs[1])",
+                       "rows_per_gpu": n_local, "sharding": f"rows/{world}", "recall_at_10": 1.0,
+                       "parity_vs_oracle": parity},
+            "roofline": {"bound": "hbm", "achieved": round(scan_bytes / (dev_ms * 1e-3) / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "flat_scan_kernel", "per_launch_ms": round(dev_ms, 4),
+                         "tflops_f32": round(flops / (dev_ms * 1e-3) / 1e12, 3)},
+            "cpu_baseline": cpu,
+            "single_query_scan": single,
+            "build_s": round(t_build, 2),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
