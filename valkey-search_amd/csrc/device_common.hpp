@@ -74,6 +74,23 @@ __device__ __forceinline__ float finish_distance(float sum) {
   return 1.0f - sum;               // == (float)(1.0 - (double)dot), see header comment
 }
 
+// One row against the query block in LDS, by one quad (all 4 lanes return the distance).
+// p = row base + lane-in-quad (float4 units); qs = padded query as float4[chunks*4].
+template <bool kL2>
+__device__ __forceinline__ float quad_row_distance(const float4 *__restrict__ p, const float4 *qs, uint32_t chunks, int j) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t c = 0;
+  for (; c + 8 <= chunks; c += 8) {
+    float4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = p[(c + u) * 4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) chunk_fma<kL2>(acc, x[u], qs[(c + u) * 4 + j]);
+  }
+  for (; c < chunks; ++c) chunk_fma<kL2>(acc, p[c * 4], qs[c * 4 + j]);
+  return finish_distance<kL2>(quad_reduce16(acc));
+}
+
 // ---- (distance,label) total order: std::pair<float,size_t> operator< ------------------
 __device__ __forceinline__ bool dl_less(float da, uint64_t la, float db, uint64_t lb) {
   return da < db || (da == db && la < lb);

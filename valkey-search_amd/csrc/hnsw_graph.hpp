@@ -1,0 +1,177 @@
+// hnsw_graph.hpp -- host-side HNSW graph: the authoritative copy of what
+// hnswlib::HierarchicalNSW<float> holds (third_party/hnswlib/hnswalg.h), built on the host
+// exactly as the reference builds it (concurrent addPoint from writer threads,
+// hnswalg.h:1523-1650) and mirrored to HBM for the device search (hnsw_search.hip).
+//
+// Same algorithmic steps and the same standard-library containers as the reference
+// (std::priority_queue with CompareByFirst, std::default_random_engine seeded 100,
+// std::unordered_set in updatePoint), so a single-threaded insert sequence produces the
+// graph hnswlib produces; storage is flat fixed-stride arrays instead of hnswlib's
+// ChunkedArray of {links | pointer | label} records so the level-0 table can be uploaded
+// as is: links0[id][0] = count (low 16 bits) | tombstone (bit 16, hnswalg.h:1259-1262),
+// links0[id][1..maxM0] = neighbour ids.
+#pragma once
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <random>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "host_dist.hpp"
+#include "row_store.hpp"
+
+namespace vk {
+
+class HnswGraph {
+ public:
+  static constexpr uint32_t kDeleteFlag = 0x00010000u;
+  static constexpr uint32_t kNone = 0xFFFFFFFFu;
+  enum Dirty : uint8_t { kDirtyL0 = 1, kDirtyUpper = 2 };
+
+  HnswGraph(uint32_t dim, bool l2, size_t max_elements, size_t M, size_t ef_construction, size_t seed,
+            bool allow_replace_deleted);
+  ~HnswGraph();
+
+  // addPoint(data, label, replace_deleted = allow_replace_deleted_) hnswalg.h:1278-1340.
+  // Thread safe.  *out_id = internal id that now holds the row; *row_changed = the
+  // device copy of that slot's row/label must be (re)written.
+  Status add(const float *row, uint64_t label, uint32_t *out_id);
+  Status mark_delete(uint64_t label);       // hnswalg.h:1173-1187
+  Status resize(size_t new_max);            // hnswalg.h:758-777; caller excludes other calls
+  void set_ef(size_t ef) { ef_ = ef; }
+
+  size_t dim() const { return dim_; }
+  size_t M() const { return M_; }
+  size_t maxM() const { return maxM_; }
+  size_t maxM0() const { return maxM0_; }
+  size_t ef() const { return ef_; }
+  size_t ef_construction() const { return efC_; }
+  size_t max_elements() const { return max_elements_; }
+  size_t count() const { return count_.load(std::memory_order_acquire); }
+  size_t deleted_count() const { return num_deleted_.load(); }
+  int max_level() const { return maxlevel_; }
+  uint32_t entry_point() const { return enterpoint_; }
+  double mult() const { return mult_; }
+
+  bool lookup(uint64_t label, uint32_t *id) const;      // label_lookup_
+  bool is_deleted(uint32_t id) const { return (links0(id)[0] & kDeleteFlag) != 0; }
+  uint64_t label_of(uint32_t id) const { return labels_[id]; }
+  int level_of(uint32_t id) const { return levels_[id]; }
+  const float *row(uint32_t id) const { return rows_[id >> kChunkShift] + (size_t)(id & kChunkMask) * dim_; }
+  const uint32_t *links0(uint32_t id) const { return l0_.get() + (size_t)id * (maxM0_ + 1); }
+  const uint32_t *upper(uint32_t id, int level) const { return upper_[id] + (size_t)(level - 1) * (maxM_ + 1); }
+  uint32_t upper_slot(uint32_t id) const { return upper_slot_[id]; }   // first device slot of id's upper lists
+  uint32_t upper_slots_used() const { return upper_slots_used_.load(); }
+  uint64_t max_label() const;                                          // VectorHNSW::GetMaxInternalLabel
+  uint64_t host_bytes() const;
+
+  // dirty tracking for the device mirror
+  uint8_t take_dirty(uint32_t id) { return dirty_[id].exchange(0, std::memory_order_acq_rel); }
+  bool any_dirty() const { return any_dirty_.load(std::memory_order_acquire); }
+  void clear_any_dirty() { any_dirty_.store(false, std::memory_order_release); }
+
+  // load path (persist): install a fully formed element
+  Status load_element(uint32_t id, const uint32_t *links0_words, const float *row, uint64_t label);
+  Status load_upper(uint32_t id, const uint32_t *words, size_t n_words);
+  Status load_labels(size_t count);   // rebuild label_lookup_ with the duplicate-label rule (:1033-1052)
+  void load_finish(size_t count, int maxlevel, uint32_t enterpoint);
+
+ private:
+  static constexpr uint32_t kChunkShift = 10, kChunkMask = (1u << kChunkShift) - 1;
+  using Pair = std::pair<float, uint32_t>;
+  struct CompareByFirst {
+    constexpr bool operator()(const Pair &a, const Pair &b) const noexcept { return a.first < b.first; }
+  };
+  using Heap = std::priority_queue<Pair, std::vector<Pair>, CompareByFirst>;
+
+  struct Spin {
+    std::atomic_flag &f;
+    explicit Spin(std::atomic_flag &fl) : f(fl) {
+      // an in-flight insert holds its own node lock for its whole duration (hnswalg.h:1561):
+      // back off to the scheduler instead of burning the core
+      for (unsigned spins = 0; f.test_and_set(std::memory_order_acquire); ++spins) {
+        if (spins < 64) __builtin_ia32_pause();
+        else std::this_thread::yield();
+      }
+    }
+    ~Spin() { f.clear(std::memory_order_release); }
+  };
+  struct VisitedList {
+    uint16_t curV = (uint16_t)-1;
+    std::vector<uint16_t> mass;
+    explicit VisitedList(size_t n) : mass(n) {}
+    uint16_t next() {
+      curV++;
+      if (curV == 0) { std::fill(mass.begin(), mass.end(), 0); curV++; }
+      return curV;
+    }
+  };
+
+  float dist(const float *a, const float *b) const { return dist_(a, b, dim_); }
+  uint32_t *links0_mut(uint32_t id) { return l0_.get() + (size_t)id * (maxM0_ + 1); }
+  uint32_t *upper_mut(uint32_t id, int level) { return upper_[id] + (size_t)(level - 1) * (maxM_ + 1); }
+  uint32_t *list_at(uint32_t id, int level) { return level == 0 ? links0_mut(id) : upper_mut(id, level); }
+  static unsigned list_count(const uint32_t *ll) { return *ll & 0xFFFFu; }
+  static void set_list_count(uint32_t *ll, unsigned n) { *ll = (*ll & 0xFFFF0000u) | (n & 0xFFFFu); }
+  float *row_mut(uint32_t id) { return rows_[id >> kChunkShift] + (size_t)(id & kChunkMask) * dim_; }
+  void ensure_row_chunk(uint32_t id);
+  void mark(uint32_t id, int level) {
+    dirty_[id].fetch_or(level == 0 ? kDirtyL0 : kDirtyUpper, std::memory_order_acq_rel);
+    any_dirty_.store(true, std::memory_order_release);
+  }
+  std::unique_ptr<VisitedList> get_visited();
+  void put_visited(std::unique_ptr<VisitedList> v);
+  int random_level();
+
+  Heap search_base_layer(uint32_t ep_id, const float *q, int layer);                 // :255-347
+  void neighbors_by_heuristic2(Heap &top, size_t M);                                 // :553-594
+  Status mutually_connect(const float *q, uint32_t cur_c, Heap &top, int level, bool is_update, uint32_t *next);  // :613-756
+  Status add_point_level(const float *row, uint64_t label, int level, uint32_t *out_id);   // :1523-1650
+  Status update_point(const float *row, uint32_t id, float prob);                   // :1342-1430
+  Status repair_connections(const float *q, uint32_t ep, uint32_t id, int level, int maxlevel);  // :1432-1511
+  Status mark_deleted_internal(uint32_t id);
+  Status unmark_deleted_internal(uint32_t id);
+  std::vector<uint32_t> connections_with_lock(uint32_t id, int level);
+  void alloc_tables(size_t n, size_t keep);
+
+  size_t dim_;
+  host_dist_fn dist_;
+  size_t max_elements_;
+  std::atomic<size_t> count_{0};
+  std::atomic<size_t> num_deleted_{0};
+  size_t M_, maxM_, maxM0_, efC_, ef_ = 10;
+  double mult_;
+  int maxlevel_ = -1;
+  uint32_t enterpoint_ = kNone;
+  bool allow_replace_deleted_;
+
+  std::unique_ptr<uint32_t[]> l0_;
+  std::unique_ptr<uint32_t *[]> upper_;
+  std::unique_ptr<uint32_t[]> upper_slot_;
+  std::atomic<uint32_t> upper_slots_used_{0};
+  std::unique_ptr<int[]> levels_;
+  std::unique_ptr<uint64_t[]> labels_;
+  std::vector<float *> rows_;
+  std::mutex rows_mu_;
+  std::unique_ptr<std::atomic_flag[]> link_locks_;
+  std::unique_ptr<std::atomic<uint8_t>[]> dirty_;
+  std::atomic<bool> any_dirty_{false};
+
+  std::mutex global_;
+  mutable std::mutex label_lookup_lock_;
+  std::unordered_map<uint64_t, uint32_t> label_lookup_;
+  static constexpr size_t kLabelLocks = 65536;
+  std::unique_ptr<std::mutex[]> label_op_locks_;
+  std::mutex deleted_lock_;
+  std::unordered_set<uint32_t> deleted_elements_;
+  std::mutex rng_mu_;
+  std::default_random_engine level_generator_, update_probability_generator_;
+  std::mutex visited_mu_;
+  std::vector<std::unique_ptr<VisitedList>> visited_pool_;
+};
+
+}  // namespace vk

@@ -1,6 +1,585 @@
-// placeholder until the HNSW mirror lands
+// hnsw_index.cc -- HnswIndex: hnswlib::HierarchicalNSW<float> semantics
+// (third_party/hnswlib/hnswalg.h) with the graph built on the host (hnsw_graph.cc) and
+// searched on the device (hnsw_search.hip).
+//
+//   addPoint / updatePoint / markDelete / resizeIndex -> HnswGraph (host, thread safe)
+//   searchKnn (hnswalg.h:1659-1725)                   -> one wave per query on the GPU
+//   SaveIndex / LoadIndex (hnswalg.h:808-1139)        -> same chunk stream, same load checks
+// Device mirror: the row table (row_store.hpp), the level-0 table links0[cap][2M+1] (the
+// reference's level-0 record without its pointer/label tail), and the upper-level lists
+// packed in a pool of (M+1)-word slots addressed by upper_slot[id] + level - 1.  Host
+// changes are tracked per node and published by flush().
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include "hnsw_graph.hpp"
 #include "index.hpp"
+
 namespace vk {
-Status create_hnsw(const vk_index_params &, std::unique_ptr<Index> *) { return Status::Err(VK_ERR_INTERNAL, "HNSW not built yet"); }
-Status load_hnsw(const vk_index_params &, vk_read_chunk_fn, void *, std::unique_ptr<Index> *) { return Status::Err(VK_ERR_INTERNAL, "HNSW not built yet"); }
+
+class HnswIndex final : public Index {
+ public:
+  HnswIndex(const vk_index_params &p, int device)
+      : Index(p), store_(device, p.dim), pool_(device),
+        graph_(std::make_unique<HnswGraph>(p.dim, p.metric == VK_METRIC_L2, p.initial_cap, p.m, p.ef_construction,
+                                           p.random_seed, p.allow_replace_deleted != 0)) {
+    graph_->set_ef(p.ef_runtime ? p.ef_runtime : 10);
+  }
+  ~HnswIndex() override {
+    (void)hipSetDevice(store_.device());
+    d_links0_.release();
+    d_upper_slot_.release();
+    d_upper_pool_.release();
+  }
+
+  Status add(uint64_t label, const float *row) override {
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    return add_one(label, row);
+  }
+
+  Status add_batch(const uint64_t *labels, const float *rows, uint64_t n) override {
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    unsigned threads = params_.build_threads ? params_.build_threads : std::thread::hardware_concurrency();
+    threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n / 16 + 1));
+    if (threads == 1) {
+      for (uint64_t i = 0; i < n; ++i) VK_TRY(add_one(labels ? labels[i] : i, rows + i * params_.dim));
+      return Status::Ok();
+    }
+    // the first element is inserted alone so every worker starts from a non-empty graph
+    uint64_t first = 0;
+    if (graph_->count() == 0 && n) {
+      VK_TRY(add_one(labels ? labels[0] : 0, rows));
+      first = 1;
+    }
+    std::atomic<uint64_t> next{first};
+    std::atomic<bool> failed{false};
+    Status err;
+    std::mutex err_mu;
+    auto work = [&]() {
+      for (;;) {
+        uint64_t i = next.fetch_add(1);
+        if (i >= n || failed.load()) return;
+        Status s = add_one(labels ? labels[i] : i, rows + i * params_.dim);
+        if (!s.ok()) {
+          std::lock_guard<std::mutex> g(err_mu);
+          if (!failed.exchange(true)) err = s;
+          return;
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work);
+    for (auto &t : pool) t.join();
+    return failed.load() ? err : Status::Ok();
+  }
+
+  Status remove(uint64_t label) override {
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    return graph_->mark_delete(label);
+  }
+
+  Status resize(uint64_t new_max) override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    return graph_->resize(new_max);
+  }
+
+  Status set_ef(uint32_t ef) override {
+    graph_->set_ef(ef);
+    return Status::Ok();
+  }
+
+  Status flush() override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    return flush_locked();
+  }
+
+  Status search(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) override {
+    VK_TRY(flush_if_dirty());
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    (void)hipSetDevice(store_.device());
+    if (rq.nq == 0) return Status::Ok();
+    if (graph_->count() == 0 || rq.k == 0) {
+      for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
+      return Status::Ok();
+    }
+    if (rq.cancel_flag && *rq.cancel_flag && !rq.partial_ok)
+      return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
+    CtxLease lease(pool_);
+    SearchCtx *ctx = lease.ctx;
+    VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f()));
+    const uint64_t *d_allow = nullptr;
+    VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
+    VK_TRY(ctx->d_out_d.ensure(rq.nq * rq.k * 4));
+    VK_TRY(ctx->d_out_l.ensure(rq.nq * rq.k * 8));
+    VK_TRY(ctx->d_out_n.ensure(rq.nq * 4));
+    VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, rq.allow_nbits, ctx->d_out_d.as<float>(),
+                  ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream, true));
+    VK_TRY(ctx->h_out_d.ensure(rq.nq * rq.k * 4));
+    VK_TRY(ctx->h_out_l.ensure(rq.nq * rq.k * 8));
+    VK_TRY(ctx->h_out_n.ensure(rq.nq * 4 + 32));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, ctx->d_out_d.p, rq.nq * rq.k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * rq.k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.as<char>() + rq.nq * 4, ctx->d_stats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
+      const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out_n.as<char>() + rq.nq * 4);
+      last_n_eval_ = st[0];
+      last_n_hops_ = st[1];
+      last_overflow_ = st[2];
+    }
+    if (rq.cancel_flag && *rq.cancel_flag && !rq.partial_ok)
+      return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
+    for (uint64_t q = 0; q < rq.nq; ++q) {
+      uint32_t n = ctx->h_out_n.as<uint32_t>()[q];
+      out_n[q] = n;
+      memcpy(out_dist + q * rq.k, ctx->h_out_d.as<float>() + q * rq.k, (size_t)n * 4);
+      memcpy(out_label + q * rq.k, ctx->h_out_l.as<uint64_t>() + q * rq.k, (size_t)n * 8);
+    }
+    return Status::Ok();
+  }
+
+  Status search_device(const SearchRequest &rq, float *d_out_dist, uint64_t *d_out_label, uint32_t *d_out_n,
+                       hipStream_t stream) override {
+    VK_TRY(flush_if_dirty());
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    (void)hipSetDevice(store_.device());
+    if (rq.nq == 0) return Status::Ok();
+    if (graph_->count() == 0 || rq.k == 0) return Status::Err(VK_ERR_INVALID, "empty index or k == 0");
+    if (!dev_ctx_) {
+      dev_ctx_ = std::make_unique<SearchCtx>();
+      VK_HIP_TRY(hipStreamCreateWithFlags(&dev_ctx_->stream, hipStreamNonBlocking));
+    }
+    hipStream_t s = stream ? stream : dev_ctx_->stream;
+    const float *dq = rq.queries;
+    if (store_.stride_f() != params_.dim) {
+      VK_TRY(dev_ctx_->d_q.ensure(rq.nq * store_.row_bytes()));
+      VK_HIP_TRY(hipMemsetAsync(dev_ctx_->d_q.p, 0, rq.nq * store_.row_bytes(), s));
+      VK_HIP_TRY(hipMemcpy2DAsync(dev_ctx_->d_q.p, store_.row_bytes(), rq.queries, (size_t)params_.dim * 4,
+                                  (size_t)params_.dim * 4, rq.nq, hipMemcpyDeviceToDevice, s));
+      dq = dev_ctx_->d_q.as<float>();
+    }
+    return launch(dev_ctx_.get(), dq, rq.nq, rq.k, rq.ef, rq.allow_bits, rq.allow_nbits, d_out_dist, d_out_label,
+                  d_out_n, s, false);
+  }
+
+  Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n, float *out_dist,
+                       uint64_t *out_label, uint64_t *out_n) override {
+    VK_TRY(flush_if_dirty());
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    (void)hipSetDevice(store_.device());
+    *out_n = 0;
+    if (n == 0 || k == 0) return Status::Ok();
+    CtxLease lease(pool_);
+    SearchCtx *ctx = lease.ctx;
+    VK_TRY(ctx->h_idx.ensure(n * 4));
+    VK_TRY(ctx->h_tmp.ensure(n * 4));
+    std::vector<uint64_t> found(n);
+    uint32_t *idx = ctx->h_idx.as<uint32_t>();
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      uint32_t id;
+      // tombstoned labels are "not found" (vector_hnsw.cc:55-64)
+      if (!graph_->lookup(labels[i], &id) || graph_->is_deleted(id)) continue;
+      idx[m] = id;
+      found[m++] = labels[i];
+    }
+    if (m == 0) return Status::Ok();
+    VK_TRY(upload_queries(ctx, query, 1, params_.dim, store_.stride_f()));
+    VK_TRY(ctx->d_idx.ensure(m * 4));
+    VK_TRY(ctx->d_tmp.ensure(m * 4));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->d_idx.p, idx, m * 4, hipMemcpyHostToDevice, ctx->stream));
+    GatherArgs ga{store_.d_rows(), ctx->d_q.as<float>(), ctx->d_idx.as<uint32_t>(), ctx->d_tmp.as<float>(),
+                  store_.stride_f(), store_.stride_f() / 16, (uint32_t)m};
+    VK_HIP_TRY(launch_gather_distance(ga, l2(), ctx->stream));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_tmp.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    prefilter_heap_select(ctx->h_tmp.as<float>(), found.data(), m, k, out_dist, out_label, out_n);
+    return Status::Ok();
+  }
+
+  Status distance(uint64_t label, const float *query, float *out) override {
+    float d;
+    uint64_t l, n = 0;
+    VK_TRY(search_labels(query, 1, &label, 1, &d, &l, &n));
+    if (n != 1) return Status::Err(VK_ERR_NOT_FOUND, "Couldn't find internal id");
+    *out = d;
+    return Status::Ok();
+  }
+
+  Status get_row(uint64_t label, float *out) override {
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    uint32_t id;
+    if (!graph_->lookup(label, &id)) return Status::Err(VK_ERR_NOT_FOUND, "label not found");
+    memcpy(out, graph_->row(id), (size_t)params_.dim * 4);
+    return Status::Ok();
+  }
+
+  Status contains(uint64_t label, bool *found) override {
+    uint32_t id;
+    *found = graph_->lookup(label, &id) && !graph_->is_deleted(id);
+    return Status::Ok();
+  }
+
+  Status stats(vk_index_stats *out) override {
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    memset(out, 0, sizeof(*out));
+    out->count = graph_->count();
+    out->deleted = graph_->deleted_count();
+    out->capacity = graph_->max_elements();
+    out->device_bytes = store_.device_bytes() + d_links0_.cap + d_upper_slot_.cap + d_upper_pool_.cap;
+    out->host_bytes = store_.host_bytes() + graph_->host_bytes();
+    out->staged_ops = store_.staged_ops();
+    out->max_level = graph_->max_level();
+    out->entry_point = graph_->entry_point();
+    out->last_n_eval = last_n_eval_;
+    out->last_n_hops = last_n_hops_;
+    return Status::Ok();
+  }
+
+  Status device_rows(uint64_t, void **, uint64_t *) override {
+    return Status::Err(VK_ERR_INVALID, "device bulk load is a FLAT-only path (the HNSW graph is built from host rows)");
+  }
+  Status commit_device_rows(uint64_t, const uint64_t *) override {
+    return Status::Err(VK_ERR_INVALID, "device bulk load is a FLAT-only path (the HNSW graph is built from host rows)");
+  }
+
+  Status save(vk_write_chunk_fn fn, void *user) override;
+  Status load_from(vk_read_chunk_fn fn, void *user);
+
+ private:
+  Status add_one(uint64_t label, const float *row) {
+    uint32_t id = 0;
+    VK_TRY(graph_->add(row, label, &id));
+    std::lock_guard<std::mutex> g(store_mu_);
+    return store_.stage_write(id, row, label);
+  }
+
+  Status flush_if_dirty() {
+    {
+      std::shared_lock<std::shared_mutex> lk(rw_);
+      if (!store_.dirty() && !graph_->any_dirty()) return Status::Ok();
+    }
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    return flush_locked();
+  }
+
+  Status flush_locked() {
+    (void)hipSetDevice(store_.device());
+    VK_TRY(store_.flush());
+    if (!graph_->any_dirty()) return Status::Ok();
+    graph_->clear_any_dirty();
+    const uint32_t count = (uint32_t)graph_->count();
+    const uint32_t l0s = (uint32_t)graph_->maxM0() + 1, ups = (uint32_t)graph_->maxM() + 1;
+    const uint64_t cap = std::max<uint64_t>(store_.alloc_rows(), count);
+    hipStream_t s = store_.stream();
+    bool full = false;
+    if (d_links0_.cap < cap * l0s * 4 || d_upper_slot_.cap < cap * 4) {
+      VK_TRY(d_links0_.ensure(cap * l0s * 4));       // DevBuf::ensure drops the old contents:
+      VK_TRY(d_upper_slot_.ensure(cap * 4));         // republish everything
+      full = true;
+    }
+    const uint64_t slots = graph_->upper_slots_used();
+    if (d_upper_pool_.cap < std::max<uint64_t>(slots, 1) * ups * 4) {
+      VK_TRY(d_upper_pool_.ensure(std::max<uint64_t>(slots + slots / 2, 64) * ups * 4));
+      full = true;
+    }
+    std::vector<uint32_t> dl0, dup;
+    for (uint32_t i = 0; i < count; ++i) {
+      uint8_t f = graph_->take_dirty(i);
+      if (full) continue;
+      if (f & HnswGraph::kDirtyL0) dl0.push_back(i);
+      if (f & HnswGraph::kDirtyUpper) dup.push_back(i);
+    }
+    if (full || dl0.size() > count / 8) {
+      VK_HIP_TRY(hipMemcpyAsync(d_links0_.p, graph_->links0(0), (size_t)count * l0s * 4, hipMemcpyHostToDevice, s));
+      dl0.clear();
+    }
+    if (full) {
+      dup.clear();
+      for (uint32_t i = 0; i < count; ++i)
+        if (graph_->level_of(i) > 0) dup.push_back(i);
+      std::vector<uint32_t> slots_host(count);
+      for (uint32_t i = 0; i < count; ++i) slots_host[i] = graph_->level_of(i) > 0 ? graph_->upper_slot(i) : HnswGraph::kNone;
+      VK_HIP_TRY(hipMemcpyAsync(d_upper_slot_.p, slots_host.data(), (size_t)count * 4, hipMemcpyHostToDevice, s));
+      VK_HIP_TRY(hipStreamSynchronize(s));
+    }
+    // staged scatter of the dirty lists
+    PinBuf h_pay, h_idx;
+    DevBuf d_pay, d_idx;
+    auto scatter = [&](uint32_t *dst, uint32_t stride, size_t n, auto fill) -> Status {
+      if (!n) return Status::Ok();
+      VK_TRY(h_pay.ensure(n * stride * 4));
+      VK_TRY(h_idx.ensure(n * 4));
+      VK_TRY(d_pay.ensure(n * stride * 4));
+      VK_TRY(d_idx.ensure(n * 4));
+      fill(h_pay.as<uint32_t>(), h_idx.as<uint32_t>());
+      VK_HIP_TRY(hipMemcpyAsync(d_pay.p, h_pay.p, n * stride * 4, hipMemcpyHostToDevice, s));
+      VK_HIP_TRY(hipMemcpyAsync(d_idx.p, h_idx.p, n * 4, hipMemcpyHostToDevice, s));
+      VK_HIP_TRY(launch_scatter_u32(dst, d_pay.as<uint32_t>(), d_idx.as<uint32_t>(), (uint32_t)n, stride, s));
+      VK_HIP_TRY(hipStreamSynchronize(s));
+      return Status::Ok();
+    };
+    Status st = scatter(d_links0_.as<uint32_t>(), l0s, dl0.size(), [&](uint32_t *pay, uint32_t *idx) {
+      for (size_t t = 0; t < dl0.size(); ++t) {
+        idx[t] = dl0[t];
+        memcpy(pay + t * l0s, graph_->links0(dl0[t]), (size_t)l0s * 4);
+      }
+    });
+    if (st.ok()) {
+      size_t nrec = 0;
+      for (uint32_t id : dup) nrec += (size_t)graph_->level_of(id);
+      st = scatter(d_upper_pool_.as<uint32_t>(), ups, nrec, [&](uint32_t *pay, uint32_t *idx) {
+        size_t t = 0;
+        for (uint32_t id : dup)
+          for (int lv = 1; lv <= graph_->level_of(id); ++lv, ++t) {
+            idx[t] = graph_->upper_slot(id) + (uint32_t)(lv - 1);
+            memcpy(pay + t * ups, graph_->upper(id, lv), (size_t)ups * 4);
+          }
+      });
+    }
+    if (st.ok() && !full)
+      st = scatter(d_upper_slot_.as<uint32_t>(), 1, dup.size(), [&](uint32_t *pay, uint32_t *idx) {
+        for (size_t t = 0; t < dup.size(); ++t) { idx[t] = dup[t]; pay[t] = graph_->upper_slot(dup[t]); }
+      });
+    h_pay.release();
+    h_idx.release();
+    d_pay.release();
+    d_idx.release();
+    VK_HIP_TRY(hipStreamSynchronize(s));
+    return st;
+  }
+
+  Status launch(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef_runtime, const uint64_t *d_allow,
+                uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
+                bool reset_stats) {
+    uint64_t ef = ef_runtime ? ef_runtime : graph_->ef();
+    ef = std::max<uint64_t>(ef, k);                       // hnswalg.h:1705,1710
+    const int e = hnsw_slots_per_lane(ef);
+    if (e == 0) return Status::Err(VK_ERR_INVALID, "ef (or k) > 512 is not served by this build of the HNSW search");
+    if (graph_->maxM0() > 256) return Status::Err(VK_ERR_INVALID, "M > 128 is not served by this build of the HNSW search");
+    const uint32_t count = (uint32_t)graph_->count();
+    HnswSearchArgs a{};
+    a.rows = store_.d_rows();
+    a.labels = store_.d_labels();
+    a.links0 = d_links0_.as<uint32_t>();
+    a.upper_slot = d_upper_slot_.as<uint32_t>();
+    a.upper_pool = d_upper_pool_.as<uint32_t>();
+    a.queries = d_q;
+    a.allow_bits = d_allow;
+    a.allow_nbits = allow_nbits;
+    a.out_dist = d_out_d;
+    a.out_label = d_out_l;
+    a.out_n = d_out_n;
+    a.row_stride_f = a.q_stride_f = store_.stride_f();
+    a.chunks = store_.stride_f() / 16;
+    a.l0_stride = (uint32_t)graph_->maxM0() + 1;
+    a.up_stride = (uint32_t)graph_->maxM() + 1;
+    a.entry_point = graph_->entry_point();
+    a.max_level = graph_->max_level();
+    a.n_nodes = count;
+    a.bitmap_words = (((count + 31) / 32) + 3) & ~3u;
+    a.nq = (uint32_t)nq;
+    a.k = (uint32_t)k;
+    a.ef = (uint32_t)ef;
+    a.cand_cap = (uint32_t)std::max<uint64_t>(1024, 2 * ef);
+    a.nbr_cap = (uint32_t)((graph_->maxM0() + 63) & ~(size_t)63);
+    a.check_deleted = graph_->deleted_count() ? 1 : 0;
+    if (hnsw_lds_bytes(a) > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
+    int max_blocks = 0;
+    VK_HIP_TRY(hnsw_max_blocks(a, l2(), e, &max_blocks));
+    // visited bitmaps: one per resident wave, bounded to 2 GiB per context
+    uint64_t blocks = std::min<uint64_t>((nq + 3) / 4, (uint64_t)max_blocks);
+    const uint64_t bm_bytes = (uint64_t)a.bitmap_words * 4;
+    blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)2 << 30) / (bm_bytes * 4)));
+    VK_TRY(ctx->d_tmp.ensure(blocks * 4 * bm_bytes));
+    a.visited = ctx->d_tmp.as<uint32_t>();
+    VK_TRY(ctx->d_stats.ensure(32));
+    if (reset_stats) VK_HIP_TRY(hipMemsetAsync(ctx->d_stats.p, 0, 32, s));
+    a.stats = ctx->d_stats.as<unsigned long long>();
+    VK_HIP_TRY(launch_hnsw_search(a, l2(), e, (uint32_t)blocks, s));
+    return Status::Ok();
+  }
+
+  RowStore store_;
+  CtxPool pool_;
+  std::unique_ptr<SearchCtx> dev_ctx_;
+  std::unique_ptr<HnswGraph> graph_;
+  std::shared_mutex rw_;
+  std::mutex store_mu_;
+  DevBuf d_links0_, d_upper_slot_, d_upper_pool_;
+  std::atomic<uint64_t> last_n_eval_{0}, last_n_hops_{0}, last_overflow_{0};
+};
+
+// ---- persistence: hnswalg.h:808-865 (SaveIndex), :887-1139 (LoadIndex + loadCheck) -----------------
+Status HnswIndex::save(vk_write_chunk_fn fn, void *user) {
+  std::shared_lock<std::shared_mutex> lk(rw_);
+  const HnswGraph &g = *graph_;
+  const size_t vec = (size_t)params_.dim * 4;
+  const size_t sl0 = g.maxM0() * 4 + 4, slu = g.maxM() * 4 + 4;
+  const size_t off_data = (sl0 + 7) & ~(size_t)7;
+  std::string hdr;
+  pb_put_varint_field(hdr, 2, g.max_elements());
+  pb_put_varint_field(hdr, 3, g.count());
+  pb_put_varint_field(hdr, 4, sl0 + vec + 8);
+  pb_put_varint_field(hdr, 5, off_data + 8);
+  pb_put_varint_field(hdr, 6, sl0);
+  pb_put_varint_field(hdr, 7, (uint64_t)(int64_t)g.max_level());   // int32: negatives are 10-byte varints
+  pb_put_varint_field(hdr, 8, g.count() ? g.entry_point() : 0xFFFFFFFFull);
+  pb_put_varint_field(hdr, 9, g.maxM());
+  pb_put_varint_field(hdr, 10, g.maxM0());
+  pb_put_varint_field(hdr, 11, g.M());
+  pb_put_double_field(hdr, 12, g.mult());
+  pb_put_varint_field(hdr, 13, g.ef_construction());
+  if (fn(user, hdr.data(), hdr.size())) return Status::Err(VK_ERR_INTERNAL, "write_chunk failed");
+  if (g.count() == 0) return Status::Ok();
+  std::vector<char> buf(sl0 + vec + 8);
+  for (uint32_t i = 0; i < g.count(); ++i) {
+    memcpy(buf.data(), g.links0(i), sl0);
+    memcpy(buf.data() + sl0, g.row(i), vec);
+    uint64_t lab = g.label_of(i);
+    memcpy(buf.data() + sl0 + vec, &lab, 8);
+    if (fn(user, buf.data(), buf.size())) return Status::Err(VK_ERR_INTERNAL, "write_chunk failed");
+  }
+  for (uint32_t i = 0; i < g.count(); ++i) {
+    uint64_t sz = g.level_of(i) > 0 ? slu * (size_t)g.level_of(i) : 0;
+    if (fn(user, &sz, 8)) return Status::Err(VK_ERR_INTERNAL, "write_chunk failed");
+    if (sz && fn(user, g.upper(i, 1), sz)) return Status::Err(VK_ERR_INTERNAL, "write_chunk failed");
+  }
+  return Status::Ok();
 }
+
+#define VK_LOAD_CHECK(ok, msg) \
+  if (!(ok)) return Status::Err(VK_ERR_INTERNAL, std::string("HNSW index load validation failed: ") + (msg))
+
+Status HnswIndex::load_from(vk_read_chunk_fn fn, void *user) {
+  const size_t vec = (size_t)params_.dim * 4;
+  std::vector<char> buf(std::max<size_t>(vec + 8 + 4 + 8 * 10000, 4096));
+  uint64_t len = 0;
+  if (fn(user, buf.data(), buf.size(), &len)) return Status::Err(VK_ERR_INTERNAL, "read_chunk failed");
+  uint64_t f[14] = {0};
+  double mult = 0;
+  int64_t max_level = 0;
+  {
+    PbReader r{reinterpret_cast<const uint8_t *>(buf.data()), reinterpret_cast<const uint8_t *>(buf.data()) + len};
+    uint32_t field, wire;
+    uint64_t val;
+    while (r.next(&field, &wire, &val)) {
+      if (field == 12 && wire == 1) memcpy(&mult, &val, 8);
+      else if (field == 7) max_level = (int32_t)(uint32_t)val;
+      else if (field < 14) f[field] = val;
+    }
+  }
+  const size_t M = f[11], maxM = f[9], maxM0 = f[10], cur = f[3];
+  const size_t exp_m = params_.m > 10000 ? 10000 : params_.m;
+  VK_LOAD_CHECK(exp_m >= 1, "M must be >= 1");
+  VK_LOAD_CHECK(M == exp_m, "header M does not match index definition");
+  VK_LOAD_CHECK(maxM == M, "header maxM does not equal M");
+  VK_LOAD_CHECK(maxM0 == 2 * M, "header maxM0 does not equal 2*M");
+  VK_LOAD_CHECK(maxM0 <= 0xFFFF, "maxM0 exceeds the 16-bit neighbor-count field");
+  const size_t sl0 = maxM0 * 4 + 4, slu = maxM * 4 + 4;
+  VK_LOAD_CHECK(f[4] == sl0 + vec + 8, "serialized element size is inconsistent with the geometry");
+  VK_LOAD_CHECK(f[1] == 0, "offset_level_0 must be 0");
+  if (M >= 2) {
+    const double expected = 1.0 / log((double)M);
+    VK_LOAD_CHECK(mult > 0.0 && fabs(mult - expected) <= 1e-6 * expected, "mult is inconsistent with M");
+  }
+  const size_t max_elements = std::max<size_t>(cur, std::max<size_t>(params_.initial_cap, f[2]));
+  VK_LOAD_CHECK(cur <= max_elements, "curr_element_count exceeds max_elements");
+  VK_LOAD_CHECK(max_elements < (1ull << 32), "max_elements out of range");
+  const uint32_t enterpoint = (uint32_t)f[8];
+  if (cur == 0) {
+    VK_LOAD_CHECK(max_level == -1 || max_level == 0, "empty index has a non-trivial max_level");
+  } else {
+    VK_LOAD_CHECK(max_level >= 0, "non-empty index has a negative max_level");
+    VK_LOAD_CHECK(max_level <= (int64_t)cur, "max_level exceeds the element count");
+    VK_LOAD_CHECK(enterpoint < cur, "enterpoint_node is out of range");
+  }
+  std::unique_lock<std::shared_mutex> lk(rw_);
+  graph_ = std::make_unique<HnswGraph>(params_.dim, params_.metric == VK_METRIC_L2, max_elements, M,
+                                       f[13] ? f[13] : params_.ef_construction, params_.random_seed,
+                                       params_.allow_replace_deleted != 0);
+  graph_->set_ef(params_.ef_runtime ? params_.ef_runtime : 10);   // ef_runtime is not persisted (vector_hnsw.cc:159-160)
+  if (buf.size() < sl0 + vec + 8 + slu * 64) buf.resize(sl0 + vec + 8 + slu * 64);
+  for (uint32_t i = 0; i < cur; ++i) {
+    if (fn(user, buf.data(), buf.size(), &len)) return Status::Err(VK_ERR_INTERNAL, "read_chunk failed");
+    VK_LOAD_CHECK(len == sl0 + vec + 8, "level-0 element chunk has the wrong size");
+    const uint32_t *ll = reinterpret_cast<const uint32_t *>(buf.data());
+    const size_t cnt = ll[0] & 0xFFFFu;
+    VK_LOAD_CHECK(cnt <= maxM0, "level-0 neighbor count exceeds 2*M");
+    for (size_t jn = 0; jn < cnt; ++jn) {
+      VK_LOAD_CHECK(ll[1 + jn] < cur, "level-0 neighbor id out of range");
+      VK_LOAD_CHECK(ll[1 + jn] != i, "level-0 self-loop");
+    }
+    uint64_t lab;
+    memcpy(&lab, buf.data() + sl0 + vec, 8);
+    VK_TRY(graph_->load_element(i, ll, reinterpret_cast<const float *>(buf.data() + sl0), lab));
+    VK_TRY(store_.stage_write(i, reinterpret_cast<const float *>(buf.data() + sl0), lab));
+    if (store_.staged_bytes() >= ((size_t)256 << 20)) VK_TRY(store_.flush());
+  }
+  for (uint32_t i = 0; i < cur; ++i) {
+    if (fn(user, buf.data(), buf.size(), &len)) return Status::Err(VK_ERR_INTERNAL, "read_chunk failed");
+    VK_LOAD_CHECK(len == 8, "link-list size chunk has the wrong size");
+    uint64_t sz;
+    memcpy(&sz, buf.data(), 8);
+    if (sz == 0) continue;
+    VK_LOAD_CHECK(sz % slu == 0, "upper-level link-list size is not a multiple of the stride");
+    const int64_t level = (int64_t)(sz / slu);
+    VK_LOAD_CHECK(level <= max_level, "element level exceeds max_level");
+    if (buf.size() < sz) buf.resize(sz);
+    if (fn(user, buf.data(), buf.size(), &len)) return Status::Err(VK_ERR_INTERNAL, "read_chunk failed");
+    VK_LOAD_CHECK(len == sz, "upper-level link-list chunk has the wrong size");
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(buf.data());
+    for (int64_t l = 0; l < level; ++l) VK_LOAD_CHECK((w[l * (maxM + 1)] & 0xFFFFu) <= maxM, "upper-level neighbor count exceeds M");
+    VK_TRY(graph_->load_upper(i, w, sz / 4));
+  }
+  if (cur > 0) VK_LOAD_CHECK(graph_->level_of(enterpoint) == max_level, "enterpoint node is not at max_level");
+  for (uint32_t i = 0; i < cur; ++i)
+    for (int level = 1; level <= graph_->level_of(i); ++level) {
+      const uint32_t *ll = graph_->upper(i, level);
+      const size_t cnt = ll[0] & 0xFFFFu;
+      for (size_t jn = 0; jn < cnt; ++jn) {
+        const uint32_t e = ll[1 + jn];
+        VK_LOAD_CHECK(e < cur, "upper-level neighbor id out of range");
+        VK_LOAD_CHECK(e != i, "upper-level self-loop");
+        VK_LOAD_CHECK(graph_->level_of(e) >= level, "upper-level neighbor is absent at that level");
+      }
+    }
+  Status dup = graph_->load_labels(cur);
+  if (!dup.ok()) return dup;
+  graph_->load_finish(cur, cur ? (int)max_level : -1, cur ? enterpoint : HnswGraph::kNone);
+  return flush_locked();
+}
+
+static Status pick_device_h(const vk_index_params &p, int *device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return Status::Err(VK_ERR_NO_DEVICE, "no HIP device: libvkindex needs a gfx950 GPU (no CPU fallback)");
+  int d = p.device_id;
+  if (d < 0 && hipGetDevice(&d) != hipSuccess) d = 0;
+  if (d >= n) return Status::Err(VK_ERR_INVALID, "device_id out of range");
+  *device = d;
+  return Status::Ok();
+}
+
+Status create_hnsw(const vk_index_params &p, std::unique_ptr<Index> *out) {
+  int device = 0;
+  VK_TRY(pick_device_h(p, &device));
+  *out = std::make_unique<HnswIndex>(p, device);
+  return Status::Ok();
+}
+
+Status load_hnsw(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std::unique_ptr<Index> *out) {
+  int device = 0;
+  VK_TRY(pick_device_h(p, &device));
+  auto ix = std::make_unique<HnswIndex>(p, device);
+  VK_TRY(ix->load_from(fn, user));
+  *out = std::move(ix);
+  return Status::Ok();
+}
+
+}  // namespace vk

@@ -1,0 +1,406 @@
+// hnsw_search.hip -- K5 + K6: HierarchicalNSW::searchKnn (third_party/hnswlib/hnswalg.h:1659-1725)
+// on CDNA4: the greedy descent over the upper layers (:1667-1697) fused in front of the
+// layer-0 best-first expansion searchBaseLayerST<false> (:351-551).  One 64-lane wave per
+// query; throughput comes from thousands of queries in flight, each hop from 16 row
+// gathers in flight per wave.
+//
+// What is kept from the reference, step for step:
+//   * the entry point enters the result list only if it is live and allowed (:373-388)
+//   * pop the closest frontier node; stop when it is farther than the worst result and the
+//     result list holds ef entries (:400-413)
+//   * its level-0 list is filtered against the visited set in list order (:453-464), every
+//     unvisited neighbour gets a distance (:496), and the neighbours are then CONSIDERED in
+//     list order with the bound updated after each one: consider = results.size() < ef ||
+//     lowerBound > dist (:502-503); a considered node always joins the frontier, and joins
+//     the results only if it is neither tombstoned nor filtered out (:506-524)
+//   * results are trimmed to k and reported ascending by (distance,label) (:1715-1723,
+//     vector_base.cc:258-277)
+// What is organised differently (same answers, different machinery):
+//   * distances: 16 neighbours at a time, one per quad of lanes, bit-identical to the
+//     reference's SimSIMD order (device_common.hpp)
+//   * visited set: a per-wave bitmap in HBM (one bit per node, atomicOr = test-and-set),
+//     cleared by the wave at the start of each query, instead of a u16 tag array
+//   * result list: sorted ascending in registers across the lanes (ef <= 64*kE); worst = last
+//   * frontier: unsorted pool in LDS with extract-min by a wave-wide scan; entries that can
+//     never be popped (farther than the bound once the result list is full -- the bound
+//     only shrinks from then on) are pruned when the pool fills
+// Equal distances: hnswlib's heaps compare the distance only, so which of two equidistant
+// nodes wins is decided by libstdc++'s sift order; here it is decided by arrival order.
+// Ids can therefore differ from the CPU path only between exactly equidistant nodes.
+#include <algorithm>
+
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace vk {
+
+namespace {
+
+constexpr uint32_t kDeleteFlag = 0x00010000u;
+constexpr uint32_t kNoneId = 0xFFFFFFFFu;
+constexpr float kFltMax = 3.402823466e+38F;
+
+// result list: rank r lives in slot r/64 of lane r%64, ascending by distance
+template <int kE>
+struct WaveSorted {
+  float d[kE];
+  uint32_t id[kE];
+  uint32_t cnt;
+
+  __device__ __forceinline__ void init() {
+    cnt = 0;
+#pragma unroll
+    for (int e = 0; e < kE; ++e) { d[e] = __builtin_inff(); id[e] = kNoneId; }
+  }
+  __device__ __forceinline__ float at_d(uint32_t r) const {
+    float v = 0.f;
+#pragma unroll
+    for (int e = 0; e < kE; ++e)
+      if ((r >> 6) == (uint32_t)e) v = readlane_f32(d[e], r & 63);
+    return v;
+  }
+  __device__ __forceinline__ uint32_t at_id(uint32_t r) const {
+    uint32_t v = 0;
+#pragma unroll
+    for (int e = 0; e < kE; ++e)
+      if ((r >> 6) == (uint32_t)e) v = __builtin_amdgcn_readlane((int)id[e], r & 63);
+    return v;
+  }
+  // insert (nd,nid) behind every entry with distance <= nd; the list keeps at most cap
+  __device__ __forceinline__ void insert(float nd, uint32_t nid, uint32_t cap, int lane) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (int e = 0; e < kE; ++e)
+      pos += __popcll(__ballot(((uint32_t)e * kWave + lane) < cnt && d[e] <= nd));
+    if (pos >= cap) return;
+#pragma unroll
+    for (int e = kE - 1; e >= 0; --e) {
+      if ((uint32_t)e * kWave + (kWave - 1) < pos) continue;  // whole slot row is in front of pos
+      float up_d = __shfl_up(d[e], 1);
+      uint32_t up_id = __shfl_up((int)id[e], 1);
+      float cd = 0.f;
+      uint32_t cid = 0;
+      if (e > 0) {
+        cd = readlane_f32(d[e - 1], kWave - 1);
+        cid = __builtin_amdgcn_readlane((int)id[e - 1], kWave - 1);
+      }
+      const uint32_t r = (uint32_t)e * kWave + lane;
+      const float src_d = lane == 0 ? cd : up_d;
+      const uint32_t src_id = lane == 0 ? cid : up_id;
+      if (r > pos) { d[e] = src_d; id[e] = src_id; }
+      else if (r == pos) { d[e] = nd; id[e] = nid; }
+    }
+    cnt = cnt + 1 < cap ? cnt + 1 : cap;
+  }
+};
+
+struct Pool {  // frontier in LDS
+  float *d;
+  uint32_t *id;
+  uint32_t cnt, cap;
+};
+
+// drop entries that can never be expanded: farther than `bound`
+__device__ __forceinline__ void pool_prune(Pool &c, float bound, int lane) {
+  uint32_t w = 0;
+  for (uint32_t base = 0; base < c.cnt; base += kWave) {
+    const uint32_t i = base + lane;
+    float dv = 0.f;
+    uint32_t iv = 0;
+    bool keep = false;
+    if (i < c.cnt) { dv = c.d[i]; iv = c.id[i]; keep = !(dv > bound); }
+    const uint64_t m = __ballot(keep);
+    const uint32_t pos = w + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) { c.d[pos] = dv; c.id[pos] = iv; }
+    w += __popcll(m);
+  }
+  c.cnt = w;
+}
+
+}  // namespace
+
+template <bool kL2, int kE>
+__global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
+  extern __shared__ float4 lds4[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 3;
+  const int rq = lane >> 2;
+  const uint32_t chunks = a.chunks;
+
+  // per-wave LDS carve: query | pool d | pool id | nbr id | nbr dist
+  const size_t per_wave_f4 = (size_t)chunks * 4 + (a.cand_cap * 2 + a.nbr_cap * 2 + 3) / 4;
+  float4 *qs = lds4 + wave * per_wave_f4;
+  float *pool_d = reinterpret_cast<float *>(qs + chunks * 4);
+  uint32_t *pool_id = reinterpret_cast<uint32_t *>(pool_d + a.cand_cap);
+  uint32_t *nbr_id = pool_id + a.cand_cap;
+  float *nbr_d = reinterpret_cast<float *>(nbr_id + a.nbr_cap);
+
+  const uint32_t wslot = blockIdx.x * 4 + wave;
+  const uint32_t wstride = gridDim.x * 4;
+  uint32_t *bitmap = a.visited + (size_t)wslot * a.bitmap_words;
+
+  unsigned long long st_eval = 0, st_hops = 0, st_over = 0, st_q = 0;
+
+  for (uint32_t q = wslot; q < a.nq; q += wstride) {
+    // ---- stage the query, clear this wave's visited bitmap --------------------------------
+    {
+      const float4 *src = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f);
+      for (uint32_t i = lane; i < chunks * 4; i += kWave) qs[i] = src[i];
+      uint4 *bm4 = reinterpret_cast<uint4 *>(bitmap);
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      for (uint32_t i = lane; i < a.bitmap_words / 4; i += kWave) bm4[i] = z;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+
+    auto row_dist = [&](uint32_t id) -> float {
+      const float4 *p = reinterpret_cast<const float4 *>(a.rows + (size_t)id * a.row_stride_f) + j;
+      return quad_row_distance<kL2>(p, qs, chunks, j);
+    };
+    auto visit = [&](uint32_t id) -> bool {  // true if it was NOT visited before
+      const uint32_t bit = 1u << (id & 31);
+      return (atomicOr(&bitmap[id >> 5], bit) & bit) == 0;
+    };
+
+    // ---- K6: greedy descent over the upper layers (:1667-1697) -------------------------------
+    uint32_t cur = a.entry_point;
+    float curdist = readlane_f32(row_dist(cur), 0);
+    for (int level = a.max_level; level > 0; --level) {
+      bool changed = true;
+      while (changed) {
+        changed = false;
+        const uint32_t *ll = a.upper_pool + (size_t)(a.upper_slot[cur] + (uint32_t)(level - 1)) * a.up_stride;
+        const uint32_t size = ll[0] & 0xFFFFu;
+        for (uint32_t base = 0; base < size; base += kRowsPerWave) {
+          const uint32_t i = base + rq;
+          const bool valid = i < size;
+          const uint32_t cid = valid ? ll[1 + i] : cur;
+          float dv = row_dist(cid);
+          // sequential "d < curdist" over the list == first occurrence of the minimum
+          float bd = valid ? dv : __builtin_inff();
+          uint32_t bi = i;
+#pragma unroll
+          for (int m = 4; m < kWave; m <<= 1) {
+            const float od = __shfl_xor(bd, m);
+            const uint32_t oi = __shfl_xor((int)bi, m);
+            if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+          }
+          if (bd < curdist) {
+            curdist = bd;
+            cur = ll[1 + bi];
+            changed = true;
+          }
+        }
+      }
+    }
+
+    // ---- K5: layer-0 best-first expansion (:351-551) --------------------------------------------
+    WaveSorted<kE> top;
+    top.init();
+    Pool c{pool_d, pool_id, 0, a.cand_cap};
+    float lowerBound;
+    {
+      bool ep_ok = true;
+      if (a.check_deleted && (a.links0[(size_t)cur * a.l0_stride] & kDeleteFlag)) ep_ok = false;
+      if (ep_ok && a.allow_bits && !allow_bit(a.allow_bits, a.allow_nbits, a.labels[cur])) ep_ok = false;
+      if (ep_ok) {
+        lowerBound = curdist;   // the reference recomputes the same distance (:378)
+        top.insert(curdist, cur, a.ef, lane);
+        if (lane == 0) { c.d[0] = curdist; c.id[0] = cur; }
+        st_eval += 1;
+      } else {
+        lowerBound = kFltMax;
+        if (lane == 0) { c.d[0] = kFltMax; c.id[0] = cur; }
+      }
+      c.cnt = 1;
+      if (lane == 0) (void)visit(cur);
+    }
+
+    for (;;) {
+      if (c.cnt == 0) break;
+      // extract-min over the pool
+      float bd = __builtin_inff();
+      uint32_t bi = kNoneId;
+      for (uint32_t i = lane; i < c.cnt; i += kWave) {
+        const float dv = c.d[i];
+        if (dv < bd || bi == kNoneId) { bd = dv; bi = i; }
+      }
+#pragma unroll
+      for (int m = 1; m < kWave; m <<= 1) {
+        const float od = __shfl_xor(bd, m);
+        const uint32_t oi = __shfl_xor((int)bi, m);
+        if (oi != kNoneId && (bi == kNoneId || od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
+      }
+      const float cand_dist = bd;
+      if (cand_dist > lowerBound && top.cnt == a.ef) break;
+      const uint32_t cur_id = c.id[bi];
+      // remove: move the last entry into the hole
+      if (lane == 0 && bi != c.cnt - 1) { c.d[bi] = c.d[c.cnt - 1]; c.id[bi] = c.id[c.cnt - 1]; }
+      c.cnt -= 1;
+      st_hops += 1;
+
+      // phase 1: unvisited neighbours, list order preserved
+      const uint32_t *ll = a.links0 + (size_t)cur_id * a.l0_stride;
+      const uint32_t size = ll[0] & 0xFFFFu;
+      uint32_t nn = 0;
+      for (uint32_t base = 0; base < size; base += kWave) {
+        const uint32_t i = base + lane;
+        bool unv = false;
+        uint32_t nid = 0;
+        if (i < size) { nid = ll[1 + i]; unv = visit(nid); }
+        const uint64_t m = __ballot(unv);
+        if (unv) nbr_id[nn + __popcll(m & ((1ull << lane) - 1ull))] = nid;
+        nn += __popcll(m);
+      }
+      // phase 3a: distances, 16 rows per round
+      for (uint32_t base = 0; base < nn; base += kRowsPerWave) {
+        const uint32_t u = base + rq;
+        const uint32_t nid = nbr_id[u < nn ? u : nn - 1];
+        const float dv = row_dist(nid);
+        if (u < nn && j == 0) nbr_d[u] = dv;
+      }
+      st_eval += nn;
+      // phase 3b: consider in list order, bound updated after each neighbour
+      for (uint32_t base = 0; base < nn; base += kWave) {
+        const uint32_t u = base + lane;
+        const float dv = u < nn ? nbr_d[u] : __builtin_inff();
+        const uint32_t nid = u < nn ? nbr_id[u] : 0;
+        // once the list is full the bound only shrinks: anything not below it now never will be
+        uint64_t m = __ballot(u < nn && (top.cnt < a.ef || lowerBound > dv));
+        while (m) {
+          const int b = __ffsll((unsigned long long)m) - 1;
+          m &= m - 1;
+          const float cd = readlane_f32(dv, b);
+          if (!(top.cnt < a.ef || lowerBound > cd)) continue;
+          const uint32_t cid = __builtin_amdgcn_readlane((int)nid, b);
+          // frontier
+          if (c.cnt == c.cap) {
+            if (top.cnt == a.ef) pool_prune(c, lowerBound, lane);
+            if (c.cnt == c.cap) st_over += 1;
+          }
+          if (c.cnt < c.cap) {
+            if (lane == 0) { c.d[c.cnt] = cd; c.id[c.cnt] = cid; }
+            c.cnt += 1;
+          }
+          // results
+          bool ok = true;
+          if (a.check_deleted && (a.links0[(size_t)cid * a.l0_stride] & kDeleteFlag)) ok = false;
+          if (ok && a.allow_bits && !allow_bit(a.allow_bits, a.allow_nbits, a.labels[cid])) ok = false;
+          if (ok) top.insert(cd, cid, a.ef, lane);
+          if (top.cnt) lowerBound = top.at_d(top.cnt - 1);
+        }
+      }
+    }
+
+    // ---- trim to k, label, order by (distance,label) ---------------------------------------------
+    const uint32_t kout = top.cnt < a.k ? top.cnt : a.k;
+    float *od = a.out_dist + (size_t)q * a.k;
+    uint64_t *ol = a.out_label + (size_t)q * a.k;
+    uint64_t lab[kE];
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+      const uint32_t r = (uint32_t)e * kWave + lane;
+      lab[e] = r < kout ? a.labels[top.id[e]] : kNoLabel;
+    }
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+      const uint32_t r = (uint32_t)e * kWave + lane;
+      uint32_t rank = 0;
+      for (uint32_t s = 0; s < kout; ++s) {
+        float sd = 0.f;
+        uint64_t sl = 0;
+#pragma unroll
+        for (int e2 = 0; e2 < kE; ++e2)
+          if ((s >> 6) == (uint32_t)e2) { sd = readlane_f32(top.d[e2], s & 63); sl = readlane_u64(lab[e2], s & 63); }
+        rank += dl_less(sd, sl, top.d[e], lab[e]) ? 1u : 0u;
+      }
+      if (r < kout) { od[rank] = top.d[e]; ol[rank] = lab[e]; }
+      else if (r < a.k) { od[r] = __builtin_inff(); ol[r] = kNoLabel; }
+    }
+    if (lane == 0) a.out_n[q] = kout;
+    st_q += 1;
+  }
+
+  if (lane == 0 && a.stats && st_q) {
+    atomicAdd(&a.stats[0], st_eval);
+    atomicAdd(&a.stats[1], st_hops);
+    atomicAdd(&a.stats[2], st_over);
+    atomicAdd(&a.stats[3], st_q);
+  }
+}
+
+__global__ void scatter_u32_kernel(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride) {
+  const uint64_t total = (uint64_t)n * stride;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t i = (uint32_t)(t / stride), w = (uint32_t)(t % stride);
+    dst[(size_t)idx[i] * stride + w] = src[t];
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------
+int hnsw_slots_per_lane(uint64_t ef) {
+  if (ef <= 64) return 1;
+  if (ef <= 128) return 2;
+  if (ef <= 256) return 4;
+  if (ef <= 512) return 8;
+  return 0;
+}
+
+size_t hnsw_lds_bytes(const HnswSearchArgs &a) {
+  const size_t per_wave_f4 = (size_t)a.chunks * 4 + (a.cand_cap * 2 + a.nbr_cap * 2 + 3) / 4;
+  return per_wave_f4 * 16 * 4;
+}
+
+template <bool kL2, int kE>
+static const void *hnsw_fn() { return reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE>); }
+
+static const void *hnsw_pick(bool l2, int e) {
+  switch (e) {
+    case 1: return l2 ? hnsw_fn<true, 1>() : hnsw_fn<false, 1>();
+    case 2: return l2 ? hnsw_fn<true, 2>() : hnsw_fn<false, 2>();
+    case 4: return l2 ? hnsw_fn<true, 4>() : hnsw_fn<false, 4>();
+    case 8: return l2 ? hnsw_fn<true, 8>() : hnsw_fn<false, 8>();
+  }
+  return nullptr;
+}
+
+hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, int e, int *blocks) {
+  const void *f = hnsw_pick(l2, e);
+  if (!f) return hipErrorInvalidValue;
+  const size_t lds = hnsw_lds_bytes(a);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    hipError_t er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (er != hipSuccess) return er;
+  }
+  int per_cu = 0;
+  hipError_t er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 256, lds);
+  if (er != hipSuccess) return er;
+  int dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (per_cu < 1) per_cu = 1;
+  *blocks = per_cu * (cus > 0 ? cus : 256);
+  return hipSuccess;
+}
+
+hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, int e, uint32_t blocks, hipStream_t s) {
+  const void *f = hnsw_pick(l2, e);
+  if (!f || blocks == 0) return hipErrorInvalidValue;
+  const size_t lds = hnsw_lds_bytes(a);
+  HnswSearchArgs args = a;
+  void *params[] = {&args};
+  return hipLaunchKernel(f, dim3(blocks), dim3(256), params, lds, s);
+}
+
+hipError_t launch_scatter_u32(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride,
+                              hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  uint64_t total = (uint64_t)n * stride;
+  uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(scatter_u32_kernel, dim3(blocks), dim3(256), 0, s, dst, src, idx, n, stride);
+  return hipGetLastError();
+}
+
+}  // namespace vk

@@ -41,6 +41,40 @@ struct GatherArgs {
   uint32_t row_stride_f, chunks, n;
 };
 
+// K5 + K6: HNSW search, one wave per query (hnsw_search.hip)
+struct HnswSearchArgs {
+  const float *rows;           // [cap][row_stride_f]
+  const uint64_t *labels;      // [cap]
+  const uint32_t *links0;      // [cap][l0_stride]: word0 = count | tombstone<<16, then neighbour ids
+  const uint32_t *upper_slot;  // [cap] first slot of the node's upper lists, 0xFFFFFFFF = level 0 only
+  const uint32_t *upper_pool;  // [slots][up_stride]: slot (upper_slot[id] + level-1) = list at `level`
+  const float *queries;        // [nq][q_stride_f] padded
+  const uint64_t *allow_bits;  // optional, by label
+  uint64_t allow_nbits;
+  uint32_t *visited;           // [wave slots][bitmap_words] scratch bitmaps
+  float *out_dist;             // [nq][k]
+  uint64_t *out_label;
+  uint32_t *out_n;
+  unsigned long long *stats;   // [4]: n_eval, n_hops, cand_overflow, queries
+  uint32_t row_stride_f, q_stride_f, chunks;
+  uint32_t l0_stride, up_stride;
+  uint32_t entry_point;
+  int32_t max_level;
+  uint32_t n_nodes, bitmap_words;
+  uint32_t nq, k, ef;
+  uint32_t cand_cap;           // candidate pool entries per wave (LDS)
+  uint32_t nbr_cap;            // >= maxM0
+  uint32_t check_deleted;      // any tombstones in the index
+};
+int hnsw_slots_per_lane(uint64_t ef);                      // 0 = ef too large for the in-register result list
+size_t hnsw_lds_bytes(const HnswSearchArgs &a);
+hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, int e, int *blocks);
+hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, int e, uint32_t blocks, hipStream_t s);
+
+// scatter rows of u32 words: dst[idx[i]*stride + w] = src[i*stride + w]
+hipError_t launch_scatter_u32(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride,
+                              hipStream_t s);
+
 int flat_scan_slots_per_lane(uint64_t k);                 // 0 = k too large for the in-register top-k
 int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e);
 hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, int qb, int e, hipStream_t s);
