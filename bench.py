@@ -46,6 +46,24 @@ def device_view(ptr, shape, device):
     return torch.as_tensor(_DevMem(ptr, shape), device=device)
 
 
+def effective_cpus() -> int:
+    """CPUs this process may really use: affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, round(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, round(q / p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def gen_rows(n_begin, n_rows, dim, device, chunk=65536, latent=32, noise=0.05, seed=1234):
     """Rank-32 latent model x = A z + 0.05 eps, L2-normalised (SURVEY.md 8d config 2);
     chunk c is seeded by (seed, c) so any shard of any world size sees the same rows."""
@@ -99,7 +117,7 @@ def main():
     t_build = time.time()
     ix = vsa.Index("FLAT", D, "COSINE", initial_cap=n_local, device_id=local_rank)
     base_ptr, stride = ix.device_rows(n_local)
-    assert stride == ((D + 15) // 16) * 16 * 4
+    assert stride == ((D + 63) // 64) * 64 * 4   # rows are zero padded to 256-B multiples
     table = device_view(base_ptr, (n_local, stride // 4), device)   # [rows][padded dim] f32 in HBM
     if stride != D * 4:
         table[:, D:] = 0
@@ -196,7 +214,7 @@ def main():
         flat = O.Flat(D, "COSINE", isa="skylake", max_elements=S)
         flat.add_many(host_rows, np.arange(r0, r0 + S, dtype=np.uint64), borrowed=True)
         hq = Q.cpu().numpy()
-        threads = len(os.sched_getaffinity(0))
+        threads = effective_cpus()
         nqt = threads * args.cpu_queries_per_thread
         flat.search(hq[0], K)  # warm
         t1 = time.perf_counter()
@@ -230,11 +248,19 @@ def main():
             "config": {"workload": f"FLAT {N}x{D} fp32 COSINE k={K} batch={B} (BASELINE.json configs[1])",
                        "rows_per_gpu": n_local, "sharding": f"rows/{world}", "recall_at_10": 1.0,
                        "parity_vs_oracle": parity},
-            "roofline": {"bound": "hbm", "achieved": round(scan_bytes / (dev_ms * 1e-3) / 1e9, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "flat_scan_kernel", "per_launch_ms": round(dev_ms, 4),
-                         "tflops_f32": round(flops / (dev_ms * 1e-3) / 1e12, 3)},
+            # B >= 16 in the inner-product space runs on the f32 matrix cores (flat_gemm_kernel, K4):
+            # algorithmic FLOPs per launch = 2 * rows * D * B against the 157.3 TFLOP/s f32 MFMA peak
+            "roofline": ({"bound": "mfma", "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 3),
+                          "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                          "frac": round(flops / (dev_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 5), "traffic": None,
+                          "kernel": "flat_gemm_kernel", "per_launch_ms": round(dev_ms, 4),
+                          "hbm_gbs_algorithmic": round(scan_bytes / (dev_ms * 1e-3) / 1e9, 2)}
+                         if B >= 16 and not os.environ.get("VK_FLAT_FORCE_SCAN") else
+                         {"bound": "hbm", "achieved": round(scan_bytes / (dev_ms * 1e-3) / 1e9, 2),
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                          "kernel": "flat_scan_kernel", "per_launch_ms": round(dev_ms, 4),
+                          "tflops_f32": round(flops / (dev_ms * 1e-3) / 1e12, 3)}),
             "cpu_baseline": cpu,
             "single_query_scan": single,
             "build_s": round(t_build, 2),

@@ -29,6 +29,10 @@ size_t gs_links(void *g, uint32_t id, int level, uint32_t *out) {
   for (size_t i = 0; i < n; ++i) out[i] = ll[1 + i];
   return n;
 }
+#ifdef VK_PROFILE_LOCKS
+uint64_t gs_spin_cycles() { return vk::g_spin_wait_cycles.load(); }
+uint64_t gs_spin_waits() { return vk::g_spin_waits.load(); }
+#endif
 const char *gs_dist_path() { return vk::host_distance_path(); }
 float gs_distance(int l2, const float *a, const float *b, size_t n) {
   return (l2 ? vk::host_distance_l2() : vk::host_distance_ip())(a, b, n);

@@ -240,3 +240,38 @@ def test_save_load_round_trip(vsa, oracle):
     assert g2.stats().count == 1234 and g2.stats().capacity == 2000
     q = _data(1, 40, 20)[0]
     _assert_same(*g2.search(q, 10), *o.search(q, 10))
+
+
+@pytest.mark.parametrize("metric", ["IP", "COSINE"])
+@pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 256, 10), (5000, 100, 33, 10), (9000, 768, 64, 10), (4097, 16, 16, 5),
+                                        (3000, 48, 100, 64), (300, 7, 40, 10)])
+def test_mfma_batched_path_bit_exact(vsa, oracle, metric, n, dim, nq, k):
+    """K4 (flat_gemm.hip): >= 16 queries in the inner-product space go through the f32 MFMA kernel; one
+    accumulator tile per SimSIMD lane class keeps the result bit-identical to the CPU reference."""
+    x = _prep(oracle, _data(n, dim, 31), metric)
+    g, o = _both(vsa, oracle, x, metric)
+    Q = _prep(oracle, _data(nq, dim, 32), metric)
+    D, L, N = g.search_batch(Q, k)
+    for i in range(nq):
+        od, ol = o.search(Q[i], k)
+        assert N[i] == len(ol)
+        _assert_same(D[i, :N[i]], L[i, :N[i]], od, ol)
+
+
+def test_mfma_path_ties_and_filter(vsa, oracle):
+    base = _data(400, 64, 33)
+    x = np.concatenate([base, base, base])
+    labels = np.random.default_rng(34).permutation(5000)[:1200].astype(np.uint64)
+    g, o = _both(vsa, oracle, x, "IP", labels=labels)
+    Q = base[:32]
+    D, L, N = g.search_batch(Q, 6)
+    for i in range(32):
+        _assert_same(D[i, :N[i]], L[i, :N[i]], *o.search(Q[i], 6))
+    # with a filter the batched answer must equal the single-query scan answer (K3), itself checked above
+    allowed = np.sort(np.random.default_rng(35).choice(labels, 300, replace=False))
+    bits = oracle.allow_bitmap(allowed, 5000)
+    D, L, N = g.search_batch(Q, 6, allow=bits, allow_nbits=5000)
+    for i in range(32):
+        sd, sl = g.search(Q[i], 6, allow=bits, allow_nbits=5000)
+        _assert_same(D[i, :N[i]], L[i, :N[i]], sd, sl)
+        assert set(L[i, :N[i]].tolist()) <= set(allowed.tolist())

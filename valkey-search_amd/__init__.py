@@ -128,9 +128,12 @@ class Index:
         return self
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().vk_index_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:          # at interpreter shutdown the module globals may be gone
+            try:
+                _lib.vk_index_destroy(h)
+            except Exception:
+                pass
 
     __del__ = close
 

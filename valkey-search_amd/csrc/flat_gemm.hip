@@ -1,0 +1,296 @@
+// flat_gemm.hip -- K4: batched FLAT search for the inner-product space (IP / COSINE) on the
+// gfx950 matrix cores: 1 - Q.X^T with v_mfma_f32_32x32x2_f32 and a fused per-lane top-k,
+// BIT-IDENTICAL to the reference CPU distance.
+//
+// Why it can be exact.  The reference distance is SimSIMD's AVX-512 dot (dot.h:1183-1204): 16
+// lane-class accumulators, class l = element index mod 16, each an in-order fmaf chain over the
+// chunks c = 0,1,..., then a fixed add tree, then 1.0f - dot (hnswlib/simsimd.h:16-24).  The
+// f32-input MFMA is bit-for-bit a k-ordered fmaf chain (no wider internal accumulation), so one
+// accumulator tile PER LANE CLASS, fed only (chunk c, class l), (chunk c+1, class l), ... in order,
+// reproduces chain l for all 32x32 (row,query) pairs of the tile at once; the 16 tiles are then
+// combined elementwise with the same tree.  Cost = the FLOPs of one K=D GEMM.  (L2 is not a
+// product of the inputs and stays on the scan kernel.)
+//
+// Tiling (one 256-thread block per CU, 4 waves = one per SIMD, ~400 VGPR+AGPR per lane):
+//   block tile  = 128 rows x 32 queries; wave w owns rows [32w,32w+32) x all 32 queries
+//   accumulators= 16 classes x f32x16 = 256 registers per lane
+//   Q tile      : resident in LDS for the whole block, [32][Dp+4] f32 (pad 4 => ds_read_b128 hits
+//                 64 distinct banks per 16-lane group)
+//   X rows      : streamed HBM -> registers -> LDS, 3-deep ring of [128 rows][2 chunks] stages
+//                 (row stride 36 dwords, conflict free), one barrier per stage (= 16 MFMAs/wave)
+//   per stage   : for each class group p (classes 4p..4p+3): one ds_read_b128 of X, one of Q
+//                 (lane = (row or query i = lane&31, chunk kk = lane>>5)), then 4 MFMAs
+//   per tile    : tree-reduce the 16 tiles, 1-dot, compare the lane's 16 (row) values for its query
+//                 against the lane's running threshold; the rare insert goes to the lane's private
+//                 k-list in HBM scratch ((distance,label) order, ties by label)
+// Grid: persistent, nrp x nqt blocks, XCD-aware decode (blocks that stream the same rows for
+// different query tiles sit on one XCD and share its L2).
+// Roofline: MFMA-bound, 2*rows*D*B FLOPs per launch against the 157.3 TFLOP/s f32 matrix peak.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace vk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int kTileRows = 128;
+constexpr int kTileQ = 32;
+constexpr int kXStride = 36;     // dwords per staged row: 2 chunks (32 floats) + 4 pad
+constexpr int kXBufs = 3;
+}  // namespace
+
+struct LaneTop {          // one lane's running top-k state; the list itself lives in HBM scratch
+  float thr_d;            // worst kept distance, +inf while the list is not full
+  uint64_t thr_l;
+  uint32_t thr_i, cnt;
+};
+
+// rare path: a (distance,row) that passed the lane's distance gate
+__device__ __noinline__ LaneTop topk_insert(const uint64_t *__restrict__ labels, const uint64_t *__restrict__ allow_bits,
+                                            uint64_t allow_nbits, uint32_t k, float dist, uint32_t row, float *list_d,
+                                            uint64_t *list_l, LaneTop t) {
+  const uint64_t lab = labels[row];
+  if (!allow_bit(allow_bits, allow_nbits, lab)) return t;
+  if (t.cnt >= k && !dl_less(dist, lab, t.thr_d, t.thr_l)) return t;
+  const uint32_t at = t.cnt < k ? t.cnt++ : t.thr_i;
+  list_d[at] = dist;
+  list_l[at] = lab;
+  if (t.cnt == k) {   // recompute this lane's worst entry
+    float wd = list_d[0];
+    uint64_t wl = list_l[0];
+    uint32_t wi = 0;
+    for (uint32_t i = 1; i < k; ++i) {
+      const float di = list_d[i];
+      const uint64_t lv = list_l[i];
+      if (dl_less(wd, wl, di, lv)) { wd = di; wl = lv; wi = i; }
+    }
+    t.thr_d = wd;
+    t.thr_l = wl;
+    t.thr_i = wi;
+  }
+  return t;
+}
+
+// Position in this block's flattened (tile, stage) stream, kept incrementally (no divisions).
+struct StreamPos {
+  uint32_t tile_row0;   // first row of the tile
+  uint32_t st;          // stage inside the tile
+  uint32_t left;        // stages still to come, this one included
+};
+__device__ __forceinline__ void stream_advance(StreamPos &p, uint32_t stages, uint32_t tile_step_rows) {
+  p.left -= 1;
+  p.st += 1;
+  if (p.st == stages) { p.st = 0; p.tile_row0 += tile_step_rows; }
+}
+
+// Register-resident staging sets are plain structs handled BY VALUE (arrays passed by reference
+// end up in scratch memory once the kernel is at its VGPR budget, and every load is then waited
+// for immediately).
+struct Stg { float4 v0, v1, v2, v3; };
+struct Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
+
+// global -> registers for one stage: 1024 float4 per stage, 4 per thread:
+// idx = tid + 256*u -> row idx/8, 16-B column idx%8 of the 2-chunk slab
+__device__ __forceinline__ float4 stage_load1(const FlatGemmArgs &a, uint32_t idx, const StreamPos &p) {
+  const uint32_t r = idx >> 3, c4 = idx & 7;
+  uint32_t row = p.tile_row0 + r;
+  row = row < a.n_rows ? row : a.n_rows - 1;
+  // chunk = st*2 + c4/4, 16-B piece c4%4 of it == float4 index st*8 + c4 (rows are zero padded
+  // to whole stages, so there is no tail)
+  return reinterpret_cast<const float4 *>(a.rows + (size_t)row * a.row_stride_f)[p.st * 8 + c4];
+}
+__device__ __forceinline__ Stg stage_load(const FlatGemmArgs &a, uint32_t tid, const StreamPos &p) {
+  Stg s;
+  s.v0 = stage_load1(a, tid, p);
+  s.v1 = stage_load1(a, tid + 256, p);
+  s.v2 = stage_load1(a, tid + 512, p);
+  s.v3 = stage_load1(a, tid + 768, p);
+  return s;
+}
+
+__device__ __forceinline__ void stage_store(float *buf, uint32_t tid, const Stg s) {
+  *reinterpret_cast<float4 *>(buf + ((tid) >> 3) * kXStride + ((tid) & 7) * 4) = s.v0;
+  *reinterpret_cast<float4 *>(buf + ((tid + 256) >> 3) * kXStride + ((tid + 256) & 7) * 4) = s.v1;
+  *reinterpret_cast<float4 *>(buf + ((tid + 512) >> 3) * kXStride + ((tid + 512) & 7) * 4) = s.v2;
+  *reinterpret_cast<float4 *>(buf + ((tid + 768) >> 3) * kXStride + ((tid + 768) & 7) * 4) = s.v3;
+}
+
+// LDS -> registers: this lane's A (row) and B (query) operands of one stage, 4 class groups each
+__device__ __forceinline__ Frag frag_load(const float *xb, const float *q_row, uint32_t st, uint32_t kk) {
+  const float *qb = q_row + (st * 2 + kk) * 16;
+  Frag f;
+  f.a0 = *reinterpret_cast<const float4 *>(xb);
+  f.a1 = *reinterpret_cast<const float4 *>(xb + 4);
+  f.a2 = *reinterpret_cast<const float4 *>(xb + 8);
+  f.a3 = *reinterpret_cast<const float4 *>(xb + 12);
+  f.b0 = *reinterpret_cast<const float4 *>(qb);
+  f.b1 = *reinterpret_cast<const float4 *>(qb + 4);
+  f.b2 = *reinterpret_cast<const float4 *>(qb + 8);
+  f.b3 = *reinterpret_cast<const float4 *>(qb + 12);
+  return f;
+}
+
+#define VK_MFMA4(P, AV, BV)                                                                                      \
+  acc[4 * P + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, BV.x, kZeroC ? zero : acc[4 * P + 0], 0, 0, 0);  \
+  acc[4 * P + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, BV.y, kZeroC ? zero : acc[4 * P + 1], 0, 0, 0);  \
+  acc[4 * P + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, BV.z, kZeroC ? zero : acc[4 * P + 2], 0, 0, 0);  \
+  acc[4 * P + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, BV.w, kZeroC ? zero : acc[4 * P + 3], 0, 0, 0);
+
+template <bool kZeroC>
+__device__ __forceinline__ void stage_mfma(f32x16 (&acc)[16], const Frag f) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  VK_MFMA4(0, f.a0, f.b0)
+  VK_MFMA4(1, f.a1, f.b1)
+  VK_MFMA4(2, f.a2, f.b2)
+  VK_MFMA4(3, f.a3, f.b3)
+}
+#undef VK_MFMA4
+
+__global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
+  extern __shared__ float lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63;
+  const uint32_t wave = tid >> 6;
+  const uint32_t li = lane & 31;   // row (A) / query (B) index inside the 32-wide MFMA tile
+  const uint32_t kk = lane >> 5;   // which of the two chunks of the stage this lane feeds
+  const uint32_t chunks = a.chunks;
+  // stages of 2 chunks each; the row stride is a multiple of 4 chunks, so the count is even and the
+  // ping-pong register sets keep their parity from tile to tile (padding chunks are zeros)
+  const uint32_t stages = chunks / 2;
+  const uint32_t qstride = a.row_stride_f + 4;
+
+  float *lds_q = lds;                                   // [32][qstride]
+  float *lds_x = lds + (size_t)kTileQ * qstride;        // [kXBufs][128][kXStride]
+  constexpr uint32_t kBufFloats = kTileRows * kXStride;
+
+  const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+  const uint32_t rp = (seq / a.nqt) * 8u + xcd;
+  const uint32_t qt = seq % a.nqt;
+  const uint32_t q0 = qt * kTileQ;
+
+  // ---- Q tile -> LDS (queries past nq replicate the last one; their results are discarded)
+  for (uint32_t i = tid; i < (uint32_t)kTileQ * (a.row_stride_f / 4); i += 256) {
+    const uint32_t q = i / (a.row_stride_f / 4), c4 = i % (a.row_stride_f / 4);
+    const uint32_t gq = q0 + q < a.nq ? q0 + q : a.nq - 1;
+    const float4 v = reinterpret_cast<const float4 *>(a.queries + (size_t)gq * a.q_stride_f)[c4];
+    *reinterpret_cast<float4 *>(lds_q + (size_t)q * qstride + c4 * 4) = v;
+  }
+
+  // ---- this lane's private top-k list (HBM scratch) and threshold
+  const uint32_t my_q = q0 + li;
+  const bool q_valid = my_q < a.nq;
+  const uint32_t slot = wave * 2 + kk;
+  const size_t list_base = (((size_t)(q_valid ? my_q : 0) * a.nrp + rp) * 8 + slot) * a.k;
+  float *list_d = a.part_dist + list_base;
+  uint64_t *list_l = a.part_label + list_base;
+  if (q_valid)
+    for (uint32_t i = 0; i < a.k; ++i) { list_d[i] = __builtin_inff(); list_l[i] = kNoLabel; }
+  LaneTop top{__builtin_inff(), kNoLabel, 0u, 0u};
+
+  const uint32_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
+  const uint32_t my_tiles = rp < n_tiles ? (n_tiles - rp + a.nrp - 1) / a.nrp : 0;
+  const uint32_t total = my_tiles * stages;             // stages in this block's stream (< 2^32: <= 2^25 tiles)
+  const uint32_t tile_step_rows = a.nrp * kTileRows;
+  if (total == 0) return;
+  (void)total;
+
+  // Software pipeline over the stream, iteration i = stage i:
+  //   global loads for stage i+3 are issued at the top of i, written to LDS at the bottom of i+1
+  //   (two iterations of cover), read LDS->registers during i+2, multiplied during i+3.
+  // LDS ring: stage s lives in buffer s % 3; the buffer written at the bottom of i (stage i+2)
+  // last held stage i-1, whose fragments were fetched during i-2.  One barrier per iteration.
+  // The loop is unrolled by two with ping-pong register sets (no register rotation: a move of
+  // a register that is the target of an in-flight load would wait for the load).
+  StreamPos ld{rp * kTileRows, 0, total};               // next stage to fetch from HBM
+  Stg stg_a, stg_b;
+  // prologue: stages 0 and 1 straight to LDS, stage 2 left in registers (set a).  A stream has at
+  // least two stages (stages is even); loads past its end re-read the last stage and are unused.
+  stg_a = stage_load(a, tid, ld);
+  stage_store(lds_x, tid, stg_a);
+  stream_advance(ld, stages, tile_step_rows);
+  stg_a = stage_load(a, tid, ld);
+  stage_store(lds_x + kBufFloats, tid, stg_a);
+  stream_advance(ld, stages, tile_step_rows);
+  stg_a = stage_load(a, tid, ld);
+  stg_b = stg_a;
+  if (ld.left) stream_advance(ld, stages, tile_step_rows);
+  __syncthreads();
+
+  const uint32_t x_off = (wave * 32 + li) * kXStride + kk * 16;
+  const float *q_row = lds_q + (size_t)li * qstride;
+  Frag f0 = frag_load(lds_x + x_off, q_row, 0, kk), f1 = f0;
+
+  uint32_t rbuf = 1;            // buffer of stage done+1
+  uint32_t wbuf = 2;            // buffer of stage done+2
+  uint32_t tile_row0 = rp * kTileRows;
+
+  // one pipeline iteration: F = fragments of stage ST, NF receives the next stage's, SNEW receives
+  // the loads of stage done+3, SOLD (loads of stage done+2) goes to LDS.  Past the end of the
+  // stream the prefetches are harmless re-reads (ld stops advancing, results unused).
+#define VK_GEMM_STAGE(ZERO, ST, F, NF, SNEW, SOLD)                                                \
+  {                                                                                               \
+    SNEW = stage_load(a, tid, ld);                                                                \
+    if (ld.left) stream_advance(ld, stages, tile_step_rows);                                      \
+    stage_mfma<ZERO>(acc, F);                                                                     \
+    const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
+    NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk);                            \
+    stage_store(lds_x + wbuf * kBufFloats, tid, SOLD);                                            \
+    __syncthreads();                                                                              \
+    rbuf = rbuf == 2 ? 0u : rbuf + 1;                                                             \
+    wbuf = wbuf == 2 ? 0u : wbuf + 1;                                                             \
+  }
+
+  for (uint32_t t = 0; t < my_tiles; ++t) {
+    f32x16 acc[16];
+    VK_GEMM_STAGE(true, 0u, f0, f1, stg_b, stg_a)    // accumulators are born from a zero C operand
+    VK_GEMM_STAGE(false, 1u, f1, f0, stg_a, stg_b)
+    for (uint32_t st = 2; st < stages; st += 2) {
+      VK_GEMM_STAGE(false, st, f0, f1, stg_b, stg_a)
+      VK_GEMM_STAGE(false, st + 1, f1, f0, stg_a, stg_b)
+    }
+    // ---- tile done.  Per output register r: gather the 16 class sums, combine them with
+    // _mm512_reduce_add_ps's pairing (l,l+8) -> (l,l+4) -> (l,l+2) -> (0,1), 1 - dot, gate
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v[16];
+#pragma unroll
+      for (int l = 0; l < 16; ++l) v[l] = acc[l][r];
+#pragma unroll
+      for (int l = 0; l < 8; ++l) v[l] = v[l + 8] + v[l];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) v[l] = v[l + 4] + v[l];
+      const float dot = (v[0] + v[2]) + (v[1] + v[3]);
+      const float dist = 1.0f - dot;
+      const uint32_t row = tile_row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (q_valid && row < a.n_rows && dist <= top.thr_d)
+        top = topk_insert(a.labels, a.allow_bits, a.allow_nbits, a.k, dist, row, list_d, list_l, top);
+      // keep the 16 gathers of one output register together: hoisting all 256 accumulator reads
+      // ahead of the adds would need 256 VGPRs and spill into the pipelined loop
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    tile_row0 += tile_step_rows;
+  }
+#undef VK_GEMM_STAGE
+}
+
+size_t flat_gemm_lds_bytes(uint32_t row_stride_f) {
+  return ((size_t)kTileQ * (row_stride_f + 4) + (size_t)kXBufs * kTileRows * kXStride) * 4;
+}
+
+bool flat_gemm_supported(uint32_t row_stride_f, uint64_t k) {
+  return (row_stride_f % 64) == 0 && flat_gemm_lds_bytes(row_stride_f) <= 160 * 1024 && k >= 1 && k <= 64;
+}
+
+hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
+  if (a.nrp == 0 || (a.nrp & 7u) || a.nqt != (a.nq + kTileQ - 1) / kTileQ) return hipErrorInvalidValue;
+  const size_t lds = flat_gemm_lds_bytes(a.row_stride_f);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_gemm_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(flat_gemm_kernel, dim3(a.nrp * a.nqt), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace vk

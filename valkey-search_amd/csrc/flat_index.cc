@@ -12,6 +12,7 @@
 // those that passed).  That corner is unreachable through FT.SEARCH (FLAT + filter always
 // takes the pre-filter path, src/query/planner.cc:23-29); here a filtered scan returns
 // the exact k best allowed rows.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -393,6 +394,9 @@ class FlatIndex final : public Index {
     const int e = flat_scan_slots_per_lane(k);
     if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 is not served by this build of the FLAT scan");
     const uint32_t chunks = store_.stride_f() / 16;
+    // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
+    if (!l2() && nq >= kGemmMinQueries && !cancel && flat_gemm_supported(store_.stride_f(), k) && !force_scan_)
+      return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     const int qb = flat_scan_pick_qb(nq, chunks, e);
     const uint32_t nqg = (uint32_t)((nq + qb - 1) / qb);
@@ -449,10 +453,52 @@ class FlatIndex final : public Index {
     return Status::Ok();
   }
 
+  // K4 launch: persistent grid of ~one block per CU, nrp row partitions x nqt query tiles of 32
+  Status scan_gemm(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
+                   uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s) {
+    FlatGemmArgs g{};
+    g.rows = store_.d_rows();
+    g.labels = store_.d_labels();
+    g.queries = d_q;
+    g.allow_bits = d_allow;
+    g.allow_nbits = allow_nbits;
+    g.row_stride_f = g.q_stride_f = store_.stride_f();
+    g.chunks = store_.stride_f() / 16;
+    g.n_rows = (uint32_t)count;
+    g.nq = (uint32_t)nq;
+    g.k = (uint32_t)k;
+    g.nqt = (uint32_t)((nq + 31) / 32);
+    const uint32_t tiles = (uint32_t)((count + 127) / 128);
+    uint32_t nrp = std::max<uint32_t>(8, (256 / g.nqt) & ~7u);
+    nrp = std::min<uint32_t>(nrp, std::max<uint32_t>(8, (tiles + 7) & ~7u));
+    g.nrp = nrp;
+    const uint64_t per_q = (uint64_t)nrp * 8 * k;
+    VK_TRY(ctx->d_part_d.ensure((size_t)nq * per_q * 4));
+    VK_TRY(ctx->d_part_l.ensure((size_t)nq * per_q * 8));
+    g.part_dist = ctx->d_part_d.as<float>();
+    g.part_label = ctx->d_part_l.as<uint64_t>();
+    VK_HIP_TRY(launch_flat_gemm(g, s));
+    MergeArgs m{};
+    m.in_dist = g.part_dist;
+    m.in_label = g.part_label;
+    m.part_stride = nq * per_q;
+    m.q_stride = per_q;
+    m.parts = 1;
+    m.per_part = (uint32_t)per_q;
+    m.k = (uint32_t)k;
+    m.out_dist = d_out_d;
+    m.out_label = d_out_l;
+    m.out_n = d_out_n;
+    VK_HIP_TRY(launch_merge_topk(m, 1, nq, s));
+    return Status::Ok();
+  }
+
+  static constexpr uint64_t kGemmMinQueries = 16;
   RowStore store_;
   CtxPool pool_;
   std::unique_ptr<SearchCtx> dev_ctx_;
   std::shared_mutex rw_;
+  bool force_scan_ = getenv("VK_FLAT_FORCE_SCAN") != nullptr;   // A/B switch for benchmarks: VALU scan for every batch size
   std::unordered_map<uint64_t, uint32_t> slot_of_;  // dict_external_to_internal
   uint64_t count_ = 0;                               // cur_element_count_
   uint64_t capacity_;                                // data_->getCapacity()

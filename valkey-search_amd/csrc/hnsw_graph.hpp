@@ -26,6 +26,10 @@
 
 namespace vk {
 
+#ifdef VK_PROFILE_LOCKS
+inline std::atomic<uint64_t> g_spin_wait_cycles{0}, g_spin_waits{0};
+#endif
+
 class HnswGraph {
  public:
   static constexpr uint32_t kDeleteFlag = 0x00010000u;
@@ -93,10 +97,21 @@ class HnswGraph {
     explicit Spin(std::atomic_flag &fl) : f(fl) {
       // an in-flight insert holds its own node lock for its whole duration (hnswalg.h:1561):
       // back off to the scheduler instead of burning the core
+#ifdef VK_PROFILE_LOCKS
+      if (!f.test_and_set(std::memory_order_acquire)) return;
+      const uint64_t t0 = __builtin_ia32_rdtsc();
       for (unsigned spins = 0; f.test_and_set(std::memory_order_acquire); ++spins) {
         if (spins < 64) __builtin_ia32_pause();
         else std::this_thread::yield();
       }
+      g_spin_wait_cycles.fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+      g_spin_waits.fetch_add(1, std::memory_order_relaxed);
+#else
+      for (unsigned spins = 0; f.test_and_set(std::memory_order_acquire); ++spins) {
+        if (spins < 64) __builtin_ia32_pause();
+        else std::this_thread::yield();
+      }
+#endif
     }
     ~Spin() { f.clear(std::memory_order_release); }
   };

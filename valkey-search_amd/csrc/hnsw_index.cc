@@ -10,6 +10,8 @@
 // packed in a pool of (M+1)-word slots addressed by upper_slot[id] + level - 1.  Host
 // changes are tracked per node and published by flush().
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -20,6 +22,29 @@
 #include "index.hpp"
 
 namespace vk {
+
+// CPUs this process may actually use: hardware threads capped by the cgroup CPU quota
+// (a container can expose 256 hardware threads with a 16-CPU quota; oversubscribing the quota
+// throttles lock holders and collapses the build rate).
+static unsigned effective_cpus() {
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  auto apply = [&](double quota, double period) {
+    if (quota > 0 && period > 0) n = (unsigned)std::max(1.0, std::min((double)n, floor(quota / period + 0.5)));
+  };
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {          // cgroup v2: "<quota|max> <period>"
+    char q[32];
+    double period = 0;
+    if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0) apply(atof(q), period);
+    fclose(f);
+  } else {
+    double quota = -1, period = 0;                                // cgroup v1
+    if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lf", &quota) != 1) quota = -1; fclose(fq); }
+    if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lf", &period) != 1) period = 0; fclose(fp); }
+    apply(quota, period);
+  }
+  return n;
+}
 
 class HnswIndex final : public Index {
  public:
@@ -43,7 +68,7 @@ class HnswIndex final : public Index {
 
   Status add_batch(const uint64_t *labels, const float *rows, uint64_t n) override {
     std::shared_lock<std::shared_mutex> lk(rw_);
-    unsigned threads = params_.build_threads ? params_.build_threads : std::thread::hardware_concurrency();
+    unsigned threads = params_.build_threads ? params_.build_threads : effective_cpus();
     threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n / 16 + 1));
     if (threads == 1) {
       for (uint64_t i = 0; i < n; ++i) VK_TRY(add_one(labels ? labels[i] : i, rows + i * params_.dim));

@@ -22,6 +22,24 @@ struct FlatScanArgs {
   uint32_t nqg;               // query groups = ceil(nq / kQB); grid = nrp * nqg blocks
 };
 
+// K4: batched FLAT (inner-product space) on the matrix cores, fused per-lane top-k
+struct FlatGemmArgs {
+  const float *rows;
+  const uint64_t *labels;
+  const float *queries;       // [nq][q_stride_f] padded
+  const uint64_t *allow_bits;
+  uint64_t allow_nbits;
+  float *part_dist;           // [nq][nrp][8][k] per-lane partial lists
+  uint64_t *part_label;
+  uint32_t row_stride_f, q_stride_f, chunks;
+  uint32_t n_rows, nq, k;
+  uint32_t nrp;               // row partitions, multiple of 8
+  uint32_t nqt;               // query tiles of 32
+};
+size_t flat_gemm_lds_bytes(uint32_t row_stride_f);
+bool flat_gemm_supported(uint32_t row_stride_f, uint64_t k);
+hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s);
+
 struct MergeArgs {
   const float *in_dist;       // entry (part, q, i) at part*part_stride + q*q_stride + i
   const uint64_t *in_label;

@@ -1,7 +1,7 @@
 // row_store.hpp -- HBM-resident row table shared by the FLAT and HNSW device mirrors.
 //
 // Layout in HBM: rows[slot][stride_f] f32, row-contiguous, each row zero-padded to a
-// multiple of 16 floats (64 B) so a quad of lanes can stream it with aligned 16-B loads
+// multiple of 64 floats (256 B) so a quad of lanes can stream it with aligned 16-B loads
 // and the padding reproduces SimSIMD's masked tail (device_common.hpp); labels[slot] u64.
 // Host mutations are appended to an op log with their row payload in pinned staging
 // memory and applied in order by flush() on the store's stream -- the "publish at the
@@ -37,7 +37,10 @@ struct Status {
     if (!_s.ok()) return _s;               \
   } while (0)
 
-inline uint32_t padded_dim(uint32_t dim) { return (dim + 15u) & ~15u; }
+// Row stride in floats: a multiple of 64 (256 B).  16 would be enough for the quad-per-row kernels
+// (one SimSIMD chunk); 64 = two MFMA stages of two chunks, so the matrix-core kernel needs no tail
+// handling.  Padding is zero: fma(0,0,x) == x, distances are unchanged.
+inline uint32_t padded_dim(uint32_t dim) { return (dim + 63u) & ~63u; }
 
 class RowStore {
  public:
