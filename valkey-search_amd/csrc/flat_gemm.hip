@@ -16,8 +16,9 @@
 //   accumulators= 16 classes x f32x16 = 256 registers per lane
 //   Q tile      : resident in LDS for the whole block, [32][Dp+4] f32 (pad 4 => ds_read_b128 hits
 //                 64 distinct banks per 16-lane group)
-//   X rows      : streamed HBM -> registers -> LDS, 3-deep ring of [128 rows][2 chunks] stages
-//                 (row stride 36 dwords, conflict free), one barrier per stage (= 16 MFMAs/wave)
+//   X rows      : each wave streams ITS 32 rows HBM -> registers -> its private LDS ring (3 stages of
+//                 [32 rows][2 chunks], row stride 36 dwords, conflict free) -> MFMA operands; no
+//                 block barrier in the main loop, the waves run free
 //   per stage   : for each class group p (classes 4p..4p+3): one ds_read_b128 of X, one of Q
 //                 (lane = (row or query i = lane&31, chunk kk = lane>>5)), then 4 MFMAs
 //   per tile    : tree-reduce the 16 tiles, 1-dot, compare the lane's 16 (row) values for its query
@@ -26,6 +27,8 @@
 // Grid: persistent, nrp x nqt blocks, XCD-aware decode (blocks that stream the same rows for
 // different query tiles sit on one XCD and share its L2).
 // Roofline: MFMA-bound, 2*rows*D*B FLOPs per launch against the 157.3 TFLOP/s f32 matrix peak.
+#include <stdlib.h>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -47,7 +50,7 @@ struct LaneTop {          // one lane's running top-k state; the list itself liv
 };
 
 // rare path: a (distance,row) that passed the lane's distance gate
-__device__ __noinline__ LaneTop topk_insert(const uint64_t *__restrict__ labels, const uint64_t *__restrict__ allow_bits,
+__device__ __forceinline__ LaneTop topk_insert(const uint64_t *__restrict__ labels, const uint64_t *__restrict__ allow_bits,
                                             uint64_t allow_nbits, uint32_t k, float dist, uint32_t row, float *list_d,
                                             uint64_t *list_l, LaneTop t) {
   const uint64_t lab = labels[row];
@@ -79,9 +82,13 @@ struct StreamPos {
   uint32_t left;        // stages still to come, this one included
 };
 __device__ __forceinline__ void stream_advance(StreamPos &p, uint32_t stages, uint32_t tile_step_rows) {
-  p.left -= 1;
-  p.st += 1;
-  if (p.st == stages) { p.st = 0; p.tile_row0 += tile_step_rows; }
+  // branch-free (a stage of the main loop must stay one basic block for the instruction interleave),
+  // and a no-op once the stream is exhausted
+  const bool go = p.left != 0;
+  const bool wrap = go && p.st + 1 == stages;
+  p.left -= go ? 1u : 0u;
+  p.st = wrap ? 0u : p.st + (go ? 1u : 0u);
+  p.tile_row0 += wrap ? tile_step_rows : 0u;
 }
 
 // Register-resident staging sets are plain structs handled BY VALUE (arrays passed by reference
@@ -90,8 +97,9 @@ __device__ __forceinline__ void stream_advance(StreamPos &p, uint32_t stages, ui
 struct Stg { float4 v0, v1, v2, v3; };
 struct Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
 
-// global -> registers for one stage: 1024 float4 per stage, 4 per thread:
-// idx = tid + 256*u -> row idx/8, 16-B column idx%8 of the 2-chunk slab
+// global -> registers for one stage of ONE WAVE: its 32 rows x 2 chunks = 256 float4, 4 per lane:
+// idx = lane + 64*u -> row idx/8 (of the wave's 32), 16-B column idx%8 of the 2-chunk slab.
+// p.tile_row0 already includes the wave's row offset.
 __device__ __forceinline__ float4 stage_load1(const FlatGemmArgs &a, uint32_t idx, const StreamPos &p) {
   const uint32_t r = idx >> 3, c4 = idx & 7;
   uint32_t row = p.tile_row0 + r;
@@ -100,20 +108,20 @@ __device__ __forceinline__ float4 stage_load1(const FlatGemmArgs &a, uint32_t id
   // to whole stages, so there is no tail)
   return reinterpret_cast<const float4 *>(a.rows + (size_t)row * a.row_stride_f)[p.st * 8 + c4];
 }
-__device__ __forceinline__ Stg stage_load(const FlatGemmArgs &a, uint32_t tid, const StreamPos &p) {
+__device__ __forceinline__ Stg stage_load(const FlatGemmArgs &a, uint32_t lane, const StreamPos &p) {
   Stg s;
-  s.v0 = stage_load1(a, tid, p);
-  s.v1 = stage_load1(a, tid + 256, p);
-  s.v2 = stage_load1(a, tid + 512, p);
-  s.v3 = stage_load1(a, tid + 768, p);
+  s.v0 = stage_load1(a, lane, p);
+  s.v1 = stage_load1(a, lane + 64, p);
+  s.v2 = stage_load1(a, lane + 128, p);
+  s.v3 = stage_load1(a, lane + 192, p);
   return s;
 }
 
-__device__ __forceinline__ void stage_store(float *buf, uint32_t tid, const Stg s) {
-  *reinterpret_cast<float4 *>(buf + ((tid) >> 3) * kXStride + ((tid) & 7) * 4) = s.v0;
-  *reinterpret_cast<float4 *>(buf + ((tid + 256) >> 3) * kXStride + ((tid + 256) & 7) * 4) = s.v1;
-  *reinterpret_cast<float4 *>(buf + ((tid + 512) >> 3) * kXStride + ((tid + 512) & 7) * 4) = s.v2;
-  *reinterpret_cast<float4 *>(buf + ((tid + 768) >> 3) * kXStride + ((tid + 768) & 7) * 4) = s.v3;
+__device__ __forceinline__ void stage_store(float *buf, uint32_t lane, const Stg s) {
+  *reinterpret_cast<float4 *>(buf + ((lane) >> 3) * kXStride + ((lane) & 7) * 4) = s.v0;
+  *reinterpret_cast<float4 *>(buf + ((lane + 64) >> 3) * kXStride + ((lane + 64) & 7) * 4) = s.v1;
+  *reinterpret_cast<float4 *>(buf + ((lane + 128) >> 3) * kXStride + ((lane + 128) & 7) * 4) = s.v2;
+  *reinterpret_cast<float4 *>(buf + ((lane + 192) >> 3) * kXStride + ((lane + 192) & 7) * 4) = s.v3;
 }
 
 // LDS -> registers: this lane's A (row) and B (query) operands of one stage, 4 class groups each
@@ -147,6 +155,9 @@ __device__ __forceinline__ void stage_mfma(f32x16 (&acc)[16], const Frag f) {
 }
 #undef VK_MFMA4
 
+// kAblate (timing experiments only, results invalid when != 0): 1 = no HBM loads, 2 = also no LDS
+// stores / barriers, 3 = also no LDS fragment reads (pure MFMA issue)
+template <int kAblate>
 __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   extern __shared__ float lds[];
   const uint32_t tid = threadIdx.x;
@@ -160,9 +171,11 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   const uint32_t stages = chunks / 2;
   const uint32_t qstride = a.row_stride_f + 4;
 
-  float *lds_q = lds;                                   // [32][qstride]
-  float *lds_x = lds + (size_t)kTileQ * qstride;        // [kXBufs][128][kXStride]
-  constexpr uint32_t kBufFloats = kTileRows * kXStride;
+  float *lds_q = lds;                                   // [32][qstride], shared, read-only after the first barrier
+  constexpr uint32_t kBufFloats = 32 * kXStride;        // one stage of one wave: 32 rows x 36 dwords
+  // each wave stages ITS OWN 32 rows through a private ring of kXBufs buffers: no block barrier in
+  // the main loop (a barrier idles the matrix pipe of a one-wave-per-SIMD kernel every stage)
+  float *lds_x = lds + (size_t)kTileQ * qstride + (size_t)wave * kXBufs * kBufFloats;
 
   const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
   const uint32_t rp = (seq / a.nqt) * 8u + xcd;
@@ -202,22 +215,22 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   // last held stage i-1, whose fragments were fetched during i-2.  One barrier per iteration.
   // The loop is unrolled by two with ping-pong register sets (no register rotation: a move of
   // a register that is the target of an in-flight load would wait for the load).
-  StreamPos ld{rp * kTileRows, 0, total};               // next stage to fetch from HBM
+  StreamPos ld{rp * kTileRows + wave * 32, 0, total};   // next stage to fetch from HBM (this wave's rows)
   Stg stg_a, stg_b;
   // prologue: stages 0 and 1 straight to LDS, stage 2 left in registers (set a).  A stream has at
   // least two stages (stages is even); loads past its end re-read the last stage and are unused.
-  stg_a = stage_load(a, tid, ld);
-  stage_store(lds_x, tid, stg_a);
+  stg_a = stage_load(a, lane, ld);
+  stage_store(lds_x, lane, stg_a);
   stream_advance(ld, stages, tile_step_rows);
-  stg_a = stage_load(a, tid, ld);
-  stage_store(lds_x + kBufFloats, tid, stg_a);
+  stg_a = stage_load(a, lane, ld);
+  stage_store(lds_x + kBufFloats, lane, stg_a);
   stream_advance(ld, stages, tile_step_rows);
-  stg_a = stage_load(a, tid, ld);
+  stg_a = stage_load(a, lane, ld);
   stg_b = stg_a;
-  if (ld.left) stream_advance(ld, stages, tile_step_rows);
-  __syncthreads();
+  stream_advance(ld, stages, tile_step_rows);
+  __syncthreads();                                       // the shared Q tile is in place
 
-  const uint32_t x_off = (wave * 32 + li) * kXStride + kk * 16;
+  const uint32_t x_off = li * kXStride + kk * 16;
   const float *q_row = lds_q + (size_t)li * qstride;
   Frag f0 = frag_load(lds_x + x_off, q_row, 0, kk), f1 = f0;
 
@@ -230,15 +243,26 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   // stream the prefetches are harmless re-reads (ld stops advancing, results unused).
 #define VK_GEMM_STAGE(ZERO, ST, F, NF, SNEW, SOLD)                                                \
   {                                                                                               \
-    SNEW = stage_load(a, tid, ld);                                                                \
-    if (ld.left) stream_advance(ld, stages, tile_step_rows);                                      \
+    if constexpr (kAblate < 1) SNEW = stage_load(a, lane, ld);                                    \
+    if constexpr (kAblate == 4) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load(a, lane, hot); } /* L1/L2-hot loads */ \
+    stream_advance(ld, stages, tile_step_rows);                                                   \
     stage_mfma<ZERO>(acc, F);                                                                     \
     const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
-    NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk);                            \
-    stage_store(lds_x + wbuf * kBufFloats, tid, SOLD);                                            \
-    __syncthreads();                                                                              \
+    if constexpr (kAblate < 3 || kAblate == 4) NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk); \
+    if constexpr (kAblate < 2 || kAblate == 4) stage_store(lds_x + wbuf * kBufFloats, lane, SOLD); \
     rbuf = rbuf == 2 ? 0u : rbuf + 1;                                                             \
     wbuf = wbuf == 2 ? 0u : wbuf + 1;                                                             \
+    /* One wave per SIMD: whatever the wave issues between two MFMAs must fit in the 64 cycles */ \
+    /* the matrix pipe is busy, or the pipe idles.  Spread the stage's other work over the 16  */ \
+    /* MFMA gaps: the 4 new HBM loads first, then the 8 fragment reads, and last the LDS stores */ \
+    /* of the loads issued at the top of the PREVIOUS stage (28 gaps ~ 1800 cycles of cover).   */ \
+    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                              \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 /* 1 MFMA     */         \
+      __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);                 /* VALU+SALU  */         \
+      if (g < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      /* 1 VMEM read */        \
+      else if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* 1 DS read  */        \
+      else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);            /* 1 DS write */         \
+    }                                                                                             \
   }
 
   for (uint32_t t = 0; t < my_tiles; ++t) {
@@ -286,11 +310,17 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
   if (a.nrp == 0 || (a.nrp & 7u) || a.nqt != (a.nq + kTileQ - 1) / kTileQ) return hipErrorInvalidValue;
   const size_t lds = flat_gemm_lds_bytes(a.row_stride_f);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_gemm_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const int ablate = getenv("VK_GEMM_ABLATE") ? atoi(getenv("VK_GEMM_ABLATE")) : 0;
+  const void *fn = ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1>)
+                 : ablate == 2 ? reinterpret_cast<const void *>(&flat_gemm_kernel<2>)
+                 : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3>)
+                 : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4>)
+                               : reinterpret_cast<const void *>(&flat_gemm_kernel<0>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(flat_gemm_kernel, dim3(a.nrp * a.nqt), dim3(256), lds, s, a);
-  return hipGetLastError();
+  FlatGemmArgs args = a;
+  void *params[] = {&args};
+  return hipLaunchKernel(fn, dim3(a.nrp * a.nqt), dim3(256), params, lds, s);
 }
 
 }  // namespace vk
