@@ -140,8 +140,8 @@ def main():
     out_l = torch.empty(B, K, device=device, dtype=torch.int64)
     out_n = torch.empty(B, device=device, dtype=torch.int32)
     if world > 1:
-        all_d = torch.empty(world, B, K, device=device, dtype=torch.float32)
-        all_l = torch.empty(world, B, K, device=device, dtype=torch.int64)
+        all_d = torch.empty(world * B, K, device=device, dtype=torch.float32)   # rank-major == [world][B][K]
+        all_l = torch.empty(world * B, K, device=device, dtype=torch.int64)
         fin_d = torch.empty(B, K, device=device, dtype=torch.float32)
         fin_l = torch.empty(B, K, device=device, dtype=torch.int64)
         fin_n = torch.empty(B, device=device, dtype=torch.int32)

@@ -243,8 +243,13 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   // stream the prefetches are harmless re-reads (ld stops advancing, results unused).
 #define VK_GEMM_STAGE(ZERO, ST, F, NF, SNEW, SOLD)                                                \
   {                                                                                               \
+    /* HBM loads for stage +3, this stage's 16 MFMAs (operands fetched one stage ago), LDS      */ \
+    /* fragment reads for stage +1, LDS store of the loads issued one stage ago.  Placement of  */ \
+    /* the independent pieces is left to the compiler: measured on MI355X (10Mx768, B=256) its  */ \
+    /* own schedule (51.0 ms) beat pinning the store behind the MFMAs (53-54 ms) and spreading  */ \
+    /* the other work over the MFMA gaps with sched_group_barrier (55-59 ms).                   */ \
     if constexpr (kAblate < 1) SNEW = stage_load(a, lane, ld);                                    \
-    if constexpr (kAblate == 4) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load(a, lane, hot); } /* L1/L2-hot loads */ \
+    if constexpr (kAblate == 4) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load(a, lane, hot); } \
     stream_advance(ld, stages, tile_step_rows);                                                   \
     stage_mfma<ZERO>(acc, F);                                                                     \
     const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
@@ -252,17 +257,6 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
     if constexpr (kAblate < 2 || kAblate == 4) stage_store(lds_x + wbuf * kBufFloats, lane, SOLD); \
     rbuf = rbuf == 2 ? 0u : rbuf + 1;                                                             \
     wbuf = wbuf == 2 ? 0u : wbuf + 1;                                                             \
-    /* One wave per SIMD: whatever the wave issues between two MFMAs must fit in the 64 cycles */ \
-    /* the matrix pipe is busy, or the pipe idles.  Spread the stage's other work over the 16  */ \
-    /* MFMA gaps: the 4 new HBM loads first, then the 8 fragment reads, and last the LDS stores */ \
-    /* of the loads issued at the top of the PREVIOUS stage (28 gaps ~ 1800 cycles of cover).   */ \
-    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                              \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 /* 1 MFMA     */         \
-      __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);                 /* VALU+SALU  */         \
-      if (g < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      /* 1 VMEM read */        \
-      else if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* 1 DS read  */        \
-      else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);            /* 1 DS write */         \
-    }                                                                                             \
   }
 
   for (uint32_t t = 0; t < my_tiles; ++t) {

@@ -410,7 +410,7 @@ class FlatIndex final : public Index {
     const uint64_t tiles = (std::min<uint64_t>(seg_rows, row_end) + 15) / 16;
     uint32_t nrp = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, std::max<uint32_t>(2048 / nqg, 256));
     nrp = std::max<uint32_t>(8, (nrp + 7) & ~7u);
-    const uint64_t per_q = (uint64_t)nrp * 4 * k;
+    const uint64_t per_q = (uint64_t)nrp * (e == 1 ? 1 : 4) * k;   // e == 1: one list per block (merged in LDS)
     VK_TRY(ctx->d_part_d.ensure((size_t)nseg * nq * per_q * 4));
     VK_TRY(ctx->d_part_l.ensure((size_t)nseg * nq * per_q * 8));
     uint32_t done = 0;

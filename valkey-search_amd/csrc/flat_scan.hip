@@ -13,6 +13,8 @@
 // consumed exactly once.  The query block lives in LDS and is read with quad-broadcast
 // ds_read_b128.  Distances come out bit-identical to the reference CPU path, ties are
 // resolved by (distance,label) exactly like the std::pair heap of bruteforce.h.
+#include <algorithm>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -100,12 +102,52 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
     }
   }
 
+  if constexpr (kE == 1) {
+    // Block-level merge (k <= 64): waves 1..3 hand their lists to wave 0 through LDS, so the
+    // grid leaves one partial list per BLOCK and the final merge kernel reads 4x fewer entries.
+    __syncthreads();                                   // everyone is done with the query block in LDS
+    float *md = reinterpret_cast<float *>(qs);         // reuse it: [kQB][3][k] distances, then labels
+    uint64_t *ml = reinterpret_cast<uint64_t *>(md + ((kQB * 3 * a.k + 1) & ~1u));
+    if (wave > 0) {
 #pragma unroll
-  for (int qi = 0; qi < kQB; ++qi) {
-    const uint32_t q = qbase + qi;
-    if (q < a.nq) {
-      const size_t base = ((size_t)q * total_waves + wave_gid) * a.k;
-      top[qi].store(a.part_dist + base, a.part_label + base, lane);
+      for (int qi = 0; qi < kQB; ++qi)
+        if ((uint32_t)lane < a.k) {
+          md[(qi * 3 + wave - 1) * a.k + lane] = top[qi].d[0];
+          ml[(qi * 3 + wave - 1) * a.k + lane] = top[qi].lab[0];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int qi = 0; qi < kQB; ++qi) {
+        for (int w = 0; w < 3; ++w) {
+          float dist = __builtin_inff();
+          uint64_t lab = kNoLabel;
+          if ((uint32_t)lane < a.k) { dist = md[(qi * 3 + w) * a.k + lane]; lab = ml[(qi * 3 + w) * a.k + lane]; }
+          uint64_t mask = __ballot(lab != kNoLabel && dist <= top[qi].thr_d);
+          while (mask) {
+            const int b = __ffsll((unsigned long long)mask) - 1;
+            mask &= mask - 1;
+            const float cd = readlane_f32(dist, b);
+            if (!(cd <= top[qi].thr_d)) continue;
+            top[qi].insert(cd, readlane_u64(lab, b), lane);
+          }
+        }
+        const uint32_t q = qbase + qi;
+        if (q < a.nq) {
+          const size_t base = ((size_t)q * a.nrp + rp) * a.k;
+          top[qi].store(a.part_dist + base, a.part_label + base, lane);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int qi = 0; qi < kQB; ++qi) {
+      const uint32_t q = qbase + qi;
+      if (q < a.nq) {
+        const size_t base = ((size_t)q * total_waves + wave_gid) * a.k;
+        top[qi].store(a.part_dist + base, a.part_label + base, lane);
+      }
     }
   }
 }
@@ -237,6 +279,7 @@ hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, int qb, int e, hipSt
   if (a.nrp == 0 || (a.nrp & 7u) || a.nqg != (a.nq + qb - 1) / qb) return hipErrorInvalidValue;
   dim3 grid(a.nrp * a.nqg);
   size_t lds = (size_t)qb * a.chunks * 64;
+  if (e == 1) lds = std::max<size_t>(lds, ((size_t)qb * 3 * a.k + 2) * 12);   // block-level merge buffers reuse it
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (e == 1) return l2 ? launch_scan_qb<true, 1>(qb, a, grid, lds, s) : launch_scan_qb<false, 1>(qb, a, grid, lds, s);
   if (e == 4) return l2 ? launch_scan_qb<true, 4>(qb, a, grid, lds, s) : launch_scan_qb<false, 4>(qb, a, grid, lds, s);

@@ -12,7 +12,7 @@ struct FlatScanArgs {
   const float *queries;       // [nq][q_stride_f], padded like rows
   const uint64_t *allow_bits; // optional bitmap by label
   uint64_t allow_nbits;
-  float *part_dist;           // [nq][nrp*4][k] per-wave partial top-k
+  float *part_dist;           // partial top-k lists: [nq][nrp][k] per block when k <= 64, else [nq][nrp*4][k] per wave
   uint64_t *part_label;
   uint32_t row_stride_f, q_stride_f;
   uint32_t chunks;            // row_stride_f / 16
