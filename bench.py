@@ -82,6 +82,74 @@ def gen_rows(n_begin, n_rows, dim, device, chunk=65536, latent=32, noise=0.05, s
         yield lo, x[lo - c * chunk: hi - c * chunk].contiguous()
 
 
+def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
+    """HNSW over the first --hnsw-rows rows: host build (quota-aware threads), device search, recall vs
+    the exact FLAT answer on the same rows, and the CPU oracle searching the SAME graph."""
+    from oracle import oracle as O
+    Nh, D, K, ef = min(args.hnsw_rows, table.shape[0]), args.dim, args.k, args.hnsw_ef
+    host_rows = np.ascontiguousarray(table[:Nh, :D].cpu().numpy())
+    t0 = time.perf_counter()
+    h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=ef)
+    h.add_batch(host_rows)
+    h.flush()
+    build_s = time.perf_counter() - t0
+    nq = args.hnsw_queries
+    qg = torch.Generator(device=device)
+    qg.manual_seed(9090)
+    Qh = torch.nn.functional.normalize(torch.randn(nq, 32, generator=qg, device=device) @ A.T +
+                                       0.05 * torch.randn(nq, D, generator=qg, device=device), dim=1).contiguous()
+    hq = Qh.cpu().numpy()
+    # exact ground truth from the FLAT index restricted to the same rows (labels < Nh)
+    bits = O.allow_bitmap(np.arange(Nh, dtype=np.uint64), Nh)
+    _, gt, _ = flat_ix.search_batch(hq, K, allow=bits, allow_nbits=Nh)
+    od = torch.empty(nq, K, device=device, dtype=torch.float32)
+    ol = torch.empty(nq, K, device=device, dtype=torch.int64)
+    on = torch.empty(nq, device=device, dtype=torch.int32)
+
+    def run():
+        h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef, stream=stream_ptr())
+
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gl = ol.cpu().numpy().view(np.uint64)
+    recall = float(np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gl, gt)])) / K
+    _D, _L, _N = h.search_batch(hq[:1024], K, ef=ef)        # host path once: fills the work counters
+    st = h.stats()
+    useful = (st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132) / 1024.0 * nq
+    # CPU: the oracle searches the very same graph (SaveIndex chunk stream), one query per thread
+    t1 = time.perf_counter()
+    o = O.HNSW.from_saved_chunks(h.save(), D, "COSINE", 16, ef_construction=200)
+    export_s = time.perf_counter() - t1
+    threads = effective_cpus()
+    ncq = min(nq, threads * 64)
+    o.search(hq[0], K, ef=ef)
+    t1 = time.perf_counter()
+    # the oracle's visited list is per index object: searches are serialised per object, so give each
+    # thread its own view of the graph?  No -- hnswlib hands out one visited list per concurrent search;
+    # the oracle is single-threaded by design, so time it on one thread and report that honestly.
+    cpu_res = [o.search(hq[i], K, ef=ef) for i in range(min(ncq, 512))]
+    cdt = time.perf_counter() - t1
+    n_cpu = len(cpu_res)
+    cpu_recall = float(np.mean([len(set(r[1].tolist()) & set(gt[i].tolist())) for i, r in enumerate(cpu_res)])) / K
+    same = sum(int(cpu_res[i][1].tolist() == gl[i][:len(cpu_res[i][1])].tolist()) for i in range(n_cpu))
+    return {"rows": Nh, "M": 16, "ef_construction": 200, "ef": ef, "k": K, "queries_per_batch": nq,
+            "build_s": round(build_s, 2), "build_inserts_per_s": round(Nh / build_s, 1), "build_threads": threads,
+            "gpu_qps": round(nq / (ms * 1e-3), 1), "ms_per_batch": round(ms, 3), "recall_at_10": round(recall, 4),
+            "n_eval_per_query": round(st.last_n_eval / 1024.0, 1), "n_hops_per_query": round(st.last_n_hops / 1024.0, 1),
+            "useful_gbs": round(useful / (ms * 1e-3) / 1e9, 1),
+            "cpu": {"kind": "port", "threads": 1, "qps_per_thread": round(n_cpu / cdt, 1), "queries": n_cpu,
+                    "recall_at_10": round(cpu_recall, 4), "same_graph": True,
+                    "ids_identical_to_gpu": f"{same}/{n_cpu}", "graph_export_s": round(export_s, 2)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +163,9 @@ def main():
     ap.add_argument("--cpu-queries-per-thread", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-query-steps", type=int, default=5, help="extra: B=1 scan timing (HBM roofline)")
+    ap.add_argument("--hnsw-rows", type=int, default=200_000, help="extra: HNSW leg over the first rows (0 = skip)")
+    ap.add_argument("--hnsw-ef", type=int, default=128)
+    ap.add_argument("--hnsw-queries", type=int, default=4096)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,6 +307,11 @@ def main():
             ok = ok and gl.tolist() == ol.tolist() and gd.view(np.uint32).tolist() == od.view(np.uint32).tolist()
         parity = "bit-exact" if ok else "MISMATCH"
 
+    # ---- extra: HNSW (BASELINE.json configs[2] shape: M=16 efC=200, cosine, ef=128, k=10) on rank 0 ----
+    hnsw = None
+    if rank == 0 and world == 1 and args.hnsw_rows > 0:
+        hnsw = hnsw_leg(args, ix, table, A, device, stream_ptr)
+
     if rank == 0:
         qps = B * args.steps / dt
         scan_bytes = n_local * stride                       # algorithmic bytes of one pass over the shard
@@ -263,6 +339,7 @@ def main():
                           "tflops_f32": round(flops / (dev_ms * 1e-3) / 1e12, 3)}),
             "cpu_baseline": cpu,
             "single_query_scan": single,
+            "hnsw": hnsw,
             "build_s": round(t_build, 2),
         }
         print(json.dumps(out))

@@ -640,3 +640,33 @@ int vko_hnsw_distance(const vko_hnsw *h, uint64_t label, const float *q, float *
     *out = h_dist(h, q, h->rows[id]);
     return 0;
 }
+
+/* ---- bulk load of an existing graph (test infrastructure: lets the oracle SEARCH a graph that
+ * was built elsewhere, e.g. by the product's multi-threaded host builder, so GPU and CPU answers
+ * can be compared on the very same graph).  Layout mirrors the chunk stream of SaveIndex
+ * (hnswalg.h:808-865): per element a level-0 word block [1+2M], a row, a label; then the
+ * concatenated upper-level blocks, element i owning words [upper_off[i], upper_off[i+1]). */
+int vko_hnsw_load_graph(vko_hnsw *h, size_t n, const float *rows, const uint64_t *labels,
+                        const uint32_t *l0_words, const uint64_t *upper_off, const uint32_t *upper_words,
+                        int max_level, uint32_t entry_point) {
+    if (n > h->max_elements || h->count != 0) { vko_set_error("load_graph: index must be empty and large enough"); return 2; }
+    for (size_t i = 0; i < n; ++i) {
+        memcpy(ll0(h, (uint32_t)i), l0_words + i * (h->maxM0 + 1), (h->maxM0 + 1) * sizeof(uint32_t));
+        h->rows[i] = (float *)malloc(h->dim * sizeof(float));
+        memcpy(h->rows[i], rows + i * h->dim, h->dim * sizeof(float));
+        h->labels[i] = labels[i];
+        size_t nw = (size_t)(upper_off[i + 1] - upper_off[i]);
+        if (nw % (h->maxM + 1)) { vko_set_error("load_graph: bad upper block size"); return 2; }
+        h->levels[i] = (int)(nw / (h->maxM + 1));
+        if (nw) {
+            h->upper[i] = (uint32_t *)malloc(nw * sizeof(uint32_t));
+            memcpy(h->upper[i], upper_words + upper_off[i], nw * sizeof(uint32_t));
+        }
+        if (is_deleted(h, (uint32_t)i)) h->num_deleted++;
+        else vko_map_put(&h->label_lookup, labels[i], (uint32_t)i);
+    }
+    h->count = n;
+    h->maxlevel = max_level;
+    h->enterpoint = entry_point;
+    return 0;
+}

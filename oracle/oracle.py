@@ -98,6 +98,8 @@ def _load():
     lib.vko_hnsw_links.argtypes = [C.c_void_p, C.c_uint32, C.c_int, _u32p, C.c_size_t]
     lib.vko_hnsw_row.restype = _f32p
     lib.vko_hnsw_row.argtypes = [C.c_void_p, C.c_uint32]
+    lib.vko_hnsw_load_graph.restype = C.c_int
+    lib.vko_hnsw_load_graph.argtypes = [C.c_void_p, C.c_size_t, _f32p, _u64p, _u32p, _u64p, _u32p, C.c_int, C.c_uint32]
     lib.vko_merge_topk.restype = C.c_size_t
     lib.vko_merge_topk.argtypes = [_f32p, _u64p, _u32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p, _u64p]
     return lib
@@ -277,6 +279,58 @@ class HNSW:
         out = C.c_float()
         rc = LIB.vko_hnsw_distance(self._h, int(label), _fp(q), C.byref(out))
         return None if rc else np.float32(out.value)
+
+    @classmethod
+    def from_saved_chunks(cls, chunks, dim, space, M, ef_construction=200, isa="skylake", ef=10):
+        """Oracle index over a graph serialised in hnswlib's SaveIndex chunk layout (hnswalg.h:808-865):
+        chunks[0] header, then n element chunks [level-0 words | row | label], then per element a u64
+        size chunk and (if non-zero) the upper-level link block."""
+        sl0 = (2 * M + 1) * 4
+        esz = sl0 + dim * 4 + 8
+        n = 0
+        while 1 + n < len(chunks) and len(chunks[1 + n]) == esz and not (len(chunks[1 + n]) == 8):
+            n += 1
+        # the element section ends where the size chunks (8 bytes) begin; esz == 8 is impossible
+        body = np.frombuffer(b"".join(chunks[1:1 + n]), dtype=np.uint8).reshape(n, esz) if n else np.zeros((0, esz), np.uint8)
+        l0 = np.ascontiguousarray(body[:, :sl0]).view(np.uint32).reshape(n, 2 * M + 1)
+        rows = np.ascontiguousarray(body[:, sl0:sl0 + dim * 4]).view(np.float32).reshape(n, dim)
+        labels = np.ascontiguousarray(body[:, sl0 + dim * 4:]).view(np.uint64).reshape(n)
+        off = np.zeros(n + 1, np.uint64)
+        ups = []
+        pos = 1 + n
+        for i in range(n):
+            sz = int(np.frombuffer(chunks[pos], dtype=np.uint64)[0])
+            pos += 1
+            if sz:
+                ups.append(np.frombuffer(chunks[pos], dtype=np.uint32))
+                pos += 1
+            off[i + 1] = off[i] + sz // 4
+        up = np.ascontiguousarray(np.concatenate(ups)) if ups else np.zeros(1, np.uint32)
+        levels = ((off[1:] - off[:-1]) // np.uint64(M + 1)).astype(np.int64)
+        max_level = int(levels.max()) if n else -1
+        # entry point: the header's field 8 (varint); parse the few fields we need
+        hdr = chunks[0]
+        fields, p = {}, 0
+        while p < len(hdr):
+            key = hdr[p]; p += 1
+            f, w = key >> 3, key & 7
+            if w == 0:
+                v, sh = 0, 0
+                while True:
+                    b = hdr[p]; p += 1
+                    v |= (b & 0x7F) << sh; sh += 7
+                    if not b & 0x80:
+                        break
+                fields[f] = v
+            elif w == 1:
+                p += 8
+        self = cls(dim, space, isa=isa, max_elements=max(n, 1), M=M, ef_construction=ef_construction, ef=ef)
+        rc = LIB.vko_hnsw_load_graph(self._h, n, _fp(rows), labels.ctypes.data_as(_u64p), l0.ctypes.data_as(_u32p),
+                                     off.ctypes.data_as(_u64p), up.ctypes.data_as(_u32p), max_level,
+                                     int(fields.get(8, 0)) & 0xFFFFFFFF)
+        if rc:
+            raise RuntimeError(last_error())
+        return self
 
     def export_graph(self):
         """Dense arrays describing the graph (for feeding the device path the same graph)."""

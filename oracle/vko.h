@@ -108,6 +108,10 @@ int vko_hnsw_is_deleted(const vko_hnsw *h, uint32_t id);
 /* copies the link list of `id` at `level` into out (capacity cap); returns count */
 size_t vko_hnsw_links(const vko_hnsw *h, uint32_t id, int level, uint32_t *out, size_t cap);
 const float *vko_hnsw_row(const vko_hnsw *h, uint32_t id);
+/* install a graph built elsewhere (see hnsw.c); the index must be empty */
+int vko_hnsw_load_graph(vko_hnsw *h, size_t n, const float *rows, const uint64_t *labels,
+                        const uint32_t *l0_words, const uint64_t *upper_off, const uint32_t *upper_words,
+                        int max_level, uint32_t entry_point);
 
 /* ---- cluster / shard merge (fanout.cc:162-175 semantics, made total) ------- */
 /* k smallest by (dist,label) over `parts` lists of `per` entries each */

@@ -216,3 +216,20 @@ def test_save_load_round_trip_and_validation(vsa, oracle):
     assert "neighbor id out of range" in ei.value.msg
     with pytest.raises(vsa.VkError):
         vsa.Index.load(chunks[:100], "HNSW", dim, "L2", m=M, ef_construction=60)    # truncated stream
+
+
+def test_multithreaded_build_same_graph_same_answers(vsa, oracle):
+    """Build with 8 host threads (graph differs from any single-threaded build), hand the SAME graph to the
+    oracle through the SaveIndex chunk stream, and require identical neighbours from GPU and CPU."""
+    rng = np.random.default_rng(26)
+    n, dim, M = 12000, 96, 16
+    A = rng.standard_normal((dim, 24)).astype(np.float32)
+    x = (rng.standard_normal((n, 24)).astype(np.float32) @ A.T + 0.1 * rng.standard_normal((n, dim)).astype(np.float32))
+    g = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=M, ef_construction=100, build_threads=8)
+    g.add_batch(x)
+    o = oracle.HNSW.from_saved_chunks(g.save(), dim, "L2", M, ef_construction=100)
+    assert o.count == n and o.max_level == g.stats().max_level and o.entry_point == g.stats().entry_point
+    Q = (rng.standard_normal((40, 24)).astype(np.float32) @ A.T).astype(np.float32)
+    D, L, N = g.search_batch(Q, 10, ef=128)
+    for i in range(len(Q)):
+        _same(D[i, :N[i]], L[i, :N[i]], *o.search(Q[i], 10, ef=128))
