@@ -56,7 +56,11 @@ typedef enum {
 
 typedef enum { VK_ALGO_FLAT = 0, VK_ALGO_HNSW = 1 } vk_algo;          /* IndexerType kFlat / kHNSW */
 typedef enum { VK_METRIC_L2 = 0, VK_METRIC_IP = 1, VK_METRIC_COSINE = 2 } vk_metric; /* index_schema.proto DistanceMetric */
-typedef enum { VK_DTYPE_F32 = 0, VK_DTYPE_BF16 = 1 } vk_dtype;         /* FLOAT32 is the only reference type (vector_base.h:112-114) */
+/* Storage type of the rows in HBM.  FLOAT32 is the only reference type (vector_base.h:112-114).
+ * BF16 is an extension (BASELINE config 4): rows still ARRIVE as f32 and are rounded to nearest-even
+ * at ingest; queries stay f32; distances are the same f32 arithmetic on the widened values, so a bf16
+ * index answers exactly like an f32 index holding the rounded rows.  get_row / save return f32. */
+typedef enum { VK_DTYPE_F32 = 0, VK_DTYPE_BF16 = 1 } vk_dtype;
 
 typedef struct vk_index_params {
   uint32_t struct_size;       /* = sizeof(vk_index_params) */
@@ -88,6 +92,9 @@ typedef struct vk_index_stats {
    * upper layers, hnswalg.h:1679-1680): */
   uint64_t last_n_eval;       /* distance evaluations */
   uint64_t last_n_hops;       /* expanded nodes */
+  /* query coalescer (vk_index_set_coalescing): device batches run / single queries they carried */
+  uint64_t coalesced_batches;
+  uint64_t coalesced_queries;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------
@@ -158,6 +165,13 @@ int vk_index_search_labels(vk_index *ix, const void *query, uint64_t k, const ui
  * (ComputeDistanceFromRecordImpl: vector_flat.cc:256-271, vector_hnsw.cc:369-383) */
 int vk_index_distance(vk_index *ix, uint64_t label, const void *query, float *out);
 /* the stored row (GetValueImpl -> getPoint bruteforce.h:85-90 / getDataByInternalId) */
+/* Query coalescing for vk_index_search.  The reference issues ONE query per call from up to
+ * `reader-threads` pool threads (search.cc:886-910 -> :135-170); with max_batch > 1, concurrent
+ * vk_index_search calls that carry no filter and no cancel flag and agree on (k, ef_runtime) are
+ * merged into one device batch: the first caller waits until max_batch calls are queued or
+ * max_wait_us elapsed, runs the batch and hands each caller its own answer (identical to the
+ * answer it would have got alone).  max_batch <= 1 turns it off (the default). */
+int vk_index_set_coalescing(vk_index *ix, uint32_t max_batch, uint32_t max_wait_us);
 int vk_index_get_row(vk_index *ix, uint64_t label, void *out_row);
 int vk_index_contains(vk_index *ix, uint64_t label, int *out_found);
 int vk_index_get_stats(vk_index *ix, vk_index_stats *out);

@@ -39,10 +39,27 @@ def test_library_exports_every_declared_symbol(vsa):
     assert not missing, missing
 
 
-def test_struct_layouts_match_header(vsa):
-    # vk_index_params: 9 u32 + padding-free u64s; keep the ctypes mirror honest
+def test_struct_layouts_match_header(vsa, tmp_path):
+    """The ctypes mirrors against what a C compiler makes of include/vk_index.h: size and the
+    offset of every field (gcc compiles a probe that prints them)."""
+    import subprocess
     assert C.sizeof(vsa.Params) == 64
-    assert C.sizeof(vsa.Stats) == 72
+    assert C.sizeof(vsa.Stats) == 88
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vk_index.h"', 'int main(void){']
+    for cname, mirror in (("vk_index_params", vsa.Params), ("vk_index_stats", vsa.Stats)):
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append('return 0;}')
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, mirror in (("vk_index_params", vsa.Params), ("vk_index_stats", vsa.Stats)):
+        assert int(got[cname]) == C.sizeof(mirror)
+        for fname, _ in mirror._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(mirror, fname).offset, fname
 
 
 def test_fails_loudly_without_device(vsa):

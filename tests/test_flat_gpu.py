@@ -67,7 +67,7 @@ def test_batch_queries_bit_exact(vsa, oracle, nq):
         _assert_same(D[i], L[i], od, ol)
 
 
-@pytest.mark.parametrize("k", [1, 10, 64, 65, 100, 256, 300, 1000])
+@pytest.mark.parametrize("k", [1, 10, 64, 65, 100, 256, 300, 1000, 1024, 1025, 2500, 5000])
 def test_k_values(vsa, oracle, k):
     x = _data(5000, 64, 5)
     g, o = _both(vsa, oracle, x, "L2")
@@ -275,3 +275,19 @@ def test_mfma_path_ties_and_filter(vsa, oracle):
         sd, sl = g.search(Q[i], 6, allow=bits, allow_nbits=5000)
         _assert_same(D[i, :N[i]], L[i, :N[i]], sd, sl)
         assert set(L[i, :N[i]].tolist()) <= set(allowed.tolist())
+
+
+def test_large_k_pages_through_ties_and_filter(vsa, oracle):
+    """k > 1024 is served in passes bounded by the previous pass's last (distance,label): duplicates that
+    straddle a pass boundary must not be lost or repeated."""
+    base = _data(900, 32, 51)
+    x = np.concatenate([base, base, base])          # every distance occurs three times
+    g, o = _both(vsa, oracle, x, "L2")
+    q = _data(1, 32, 52)[0]
+    gd, gl = g.search(q, 2600)
+    od, ol = o.search(q, 2600)
+    _assert_same(gd, gl, od, ol)
+    D, L, N = g.search_batch(_data(3, 32, 53), 1500)
+    for i in range(3):
+        od, ol = o.search(_data(3, 32, 53)[i], 1500)
+        _assert_same(D[i, :N[i]], L[i, :N[i]], od, ol)

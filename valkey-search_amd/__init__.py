@@ -40,7 +40,7 @@ class Stats(C.Structure):
     _fields_ = [("count", C.c_uint64), ("deleted", C.c_uint64), ("capacity", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("host_bytes", C.c_uint64), ("staged_ops", C.c_uint64),
                 ("max_level", C.c_int32), ("entry_point", C.c_uint32), ("last_n_eval", C.c_uint64),
-                ("last_n_hops", C.c_uint64)]
+                ("last_n_hops", C.c_uint64), ("coalesced_batches", C.c_uint64), ("coalesced_queries", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
     L.vk_index_resize.argtypes = [vp, u64]
     L.vk_index_set_ef.argtypes = [vp, u32]
     L.vk_index_flush.argtypes = [vp]
+    L.vk_index_set_coalescing.argtypes = [vp, u32, u32]
     L.vk_index_search.argtypes = [vp, vp, u64, u64, vp, u64, vp, i32, vp, vp, u64p]
     L.vk_index_search_batch.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, i32, vp, vp, vp]
     L.vk_index_search_batch_device.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, vp, vp, vp]
@@ -105,9 +106,12 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+DTYPE = {"f32": 0, "bf16": 1}
+
+
 def make_params(algo, dim, metric, initial_cap, block_size=1024, m=16, ef_construction=200, ef_runtime=10,
-                seed=100, allow_replace_deleted=False, device_id=-1, build_threads=0) -> Params:
-    return Params(C.sizeof(Params), ALGO[algo], METRIC[metric], 0, dim, block_size, initial_cap, m, ef_construction,
+                seed=100, allow_replace_deleted=False, device_id=-1, build_threads=0, dtype="f32") -> Params:
+    return Params(C.sizeof(Params), ALGO[algo], METRIC[metric], DTYPE[dtype], dim, block_size, initial_cap, m, ef_construction,
                   ef_runtime, int(allow_replace_deleted), seed, device_id, build_threads)
 
 
@@ -160,6 +164,20 @@ class Index:
 
     def flush(self):
         _check(lib().vk_index_flush(self._h))
+
+    def set_coalescing(self, max_batch, max_wait_us):
+        """Merge concurrent single-query searches into device batches (vk_index_set_coalescing)."""
+        _check(lib().vk_index_set_coalescing(self._h, int(max_batch), int(max_wait_us)))
+
+    def search_one(self, q, k, ef=0):
+        """vk_index_search itself (the per-FT.SEARCH entry point; ctypes drops the GIL around it)."""
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
+        d = np.empty(k, np.float32)
+        l = np.empty(k, np.uint64)
+        n = C.c_uint64(0)
+        _check(lib().vk_index_search(self._h, q.ctypes.data, int(k), int(ef), None, 0, None, 1, d.ctypes.data,
+                                     l.ctypes.data, C.byref(n)))
+        return d[:n.value], l[:n.value]
 
     # ---- queries
     def search(self, q, k, ef=0, allow=None, allow_nbits=None, cancel=None, partial_ok=True):

@@ -1,0 +1,122 @@
+// coalescer.hpp -- N1: query coalescing between the reader pool and the device.
+//
+// valkey-search has no batch API: every FT.SEARCH is one query vector and one call to
+// VectorFlat/VectorHNSW::Search on a reader-pool thread (src/query/search.cc:135-170, :886-910),
+// up to `reader-threads` of them concurrently.  One query cannot feed an MI355X (a FLAT scan is
+// HBM-bound at any batch size up to ~dozens, the MFMA path wants >= 16 queries), so concurrent
+// single-query calls that are compatible (same k, same ef, no filter, no cancel flag) are merged
+// into one vk_index_search_batch: the first caller to arrive becomes the leader, waits until
+// `max_batch` requests are queued or `max_wait_us` elapsed, runs the batch, and hands every
+// follower its slice.  Latency/throughput knob, off by default (max_batch <= 1).
+#pragma once
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+
+#include "index.hpp"
+
+namespace vk {
+
+class Coalescer {
+ public:
+  void configure(uint32_t max_batch, uint32_t max_wait_us) {
+    std::lock_guard<std::mutex> lk(mu_);
+    max_batch_ = max_batch;
+    max_wait_us_ = max_wait_us;
+  }
+  bool enabled() const { return max_batch_ > 1; }
+  uint64_t batches() const { return batches_; }
+  uint64_t queries() const { return queries_; }
+
+  // one single-query request; returns the status of the batch it travelled in
+  Status search(Index *ix, const float *query, uint64_t k, uint64_t ef, float *out_dist, uint64_t *out_label,
+                uint64_t *out_n) {
+    Req me{query, out_dist, out_label, out_n, Status::Ok(), false};
+    std::unique_lock<std::mutex> lk(mu_);
+    Lane &lane = lanes_[std::make_pair(k, ef)];
+    lane.q.push_back(&me);
+    if (lane.leader_active && lane.q.size() >= max_batch_) cv_.notify_all();  // batch full: wake the leader
+    while (!me.done) {
+      if (lane.leader_active) {
+        cv_.wait(lk);
+        continue;
+      }
+      // nobody is driving this lane: lead one batch (ours is in it unless the queue is longer
+      // than max_batch, in which case the loop leads or follows again)
+      lane.leader_active = true;
+      lead_one_batch(ix, lane, k, ef, lk);
+      lane.leader_active = false;
+      cv_.notify_all();
+    }
+    return me.st;
+  }
+
+ private:
+  struct Req {
+    const float *q;
+    float *od;
+    uint64_t *ol;
+    uint64_t *on;
+    Status st;
+    bool done;
+  };
+  struct Lane {
+    std::deque<Req *> q;
+    bool leader_active = false;
+  };
+  void lead_one_batch(Index *ix, Lane &lane, uint64_t k, uint64_t ef, std::unique_lock<std::mutex> &lk) {
+    const uint32_t dim = ix->params().dim;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us_);
+    cv_.wait_until(lk, deadline, [&] { return lane.q.size() >= max_batch_; });
+    std::vector<Req *> batch;
+    while (!lane.q.empty() && batch.size() < max_batch_) {
+      batch.push_back(lane.q.front());
+      lane.q.pop_front();
+    }
+    lk.unlock();
+    const uint64_t nq = batch.size();
+    Status st = Status::Ok();
+    std::vector<float> Q, D;
+    std::vector<uint64_t> L, N;
+    try {
+      Q.resize(nq * dim);
+      D.resize(nq * k);
+      L.resize(nq * k);
+      N.resize(nq);
+      for (uint64_t i = 0; i < nq; ++i) memcpy(Q.data() + i * dim, batch[i]->q, (size_t)dim * 4);
+      SearchRequest rq;
+      rq.queries = Q.data();
+      rq.nq = nq;
+      rq.k = k;
+      rq.ef = ef;
+      st = ix->search(rq, D.data(), L.data(), N.data());
+    } catch (const std::exception &e) {
+      st = Status::Err(VK_ERR_INTERNAL, e.what());
+    }
+    lk.lock();
+    batches_ += 1;
+    queries_ += nq;
+    for (uint64_t i = 0; i < nq; ++i) {
+      Req *r = batch[i];
+      r->st = st;
+      if (st.ok()) {
+        *r->on = N[i];
+        if (N[i]) {
+          memcpy(r->od, D.data() + i * k, (size_t)N[i] * 4);
+          memcpy(r->ol, L.data() + i * k, (size_t)N[i] * 8);
+        }
+      }
+      r->done = true;
+    }
+  }
+
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::map<std::pair<uint64_t, uint64_t>, Lane> lanes_;
+  uint32_t max_batch_ = 0, max_wait_us_ = 0;
+  uint64_t batches_ = 0, queries_ = 0;
+};
+
+}  // namespace vk

@@ -74,20 +74,41 @@ __device__ __forceinline__ float finish_distance(float sum) {
   return 1.0f - sum;               // == (float)(1.0 - (double)dot), see header comment
 }
 
+// ---- row storage type ------------------------------------------------------------------------
+// Rows are f32 (the only type the reference has, vector_base.h:112-114) or bf16 (extension, config 4):
+// bf16 rows are the f32 input rounded to nearest-even at ingest; the arithmetic stays the f32
+// lane-exact chain on the widened values (bf16 -> f32 is a 16-bit shift, exact), so a bf16 index
+// answers exactly like an f32 index over the rounded rows.  4-element "pieces": piece i of a row
+// is elements 4i..4i+3 (16 B of f32, 8 B of bf16).
+template <bool kBf16>
+__device__ __forceinline__ const char *row_base(const void *rows, size_t row, uint32_t stride_e) {
+  return static_cast<const char *>(rows) + row * (size_t)stride_e * (kBf16 ? 2 : 4);
+}
+template <bool kBf16>
+__device__ __forceinline__ float4 row_piece(const char *base, uint32_t piece) {
+  if constexpr (kBf16) {
+    const uint2 u = reinterpret_cast<const uint2 *>(base)[piece];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+  } else {
+    return reinterpret_cast<const float4 *>(base)[piece];
+  }
+}
+
 // One row against the query block in LDS, by one quad (all 4 lanes return the distance).
-// p = row base + lane-in-quad (float4 units); qs = padded query as float4[chunks*4].
-template <bool kL2>
-__device__ __forceinline__ float quad_row_distance(const float4 *__restrict__ p, const float4 *qs, uint32_t chunks, int j) {
+// base = start of the row; qs = padded query as float4[chunks*4]; j = lane inside the quad.
+template <bool kL2, bool kBf16>
+__device__ __forceinline__ float quad_row_distance(const char *__restrict__ base, const float4 *qs, uint32_t chunks, int j) {
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t c = 0;
   for (; c + 8 <= chunks; c += 8) {
     float4 x[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = p[(c + u) * 4];
+    for (int u = 0; u < 8; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
 #pragma unroll
     for (int u = 0; u < 8; ++u) chunk_fma<kL2>(acc, x[u], qs[(c + u) * 4 + j]);
   }
-  for (; c < chunks; ++c) chunk_fma<kL2>(acc, p[c * 4], qs[c * 4 + j]);
+  for (; c < chunks; ++c) chunk_fma<kL2>(acc, row_piece<kBf16>(base, c * 4 + j), qs[c * 4 + j]);
   return finish_distance<kL2>(quad_reduce16(acc));
 }
 

@@ -259,7 +259,18 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
     wbuf = wbuf == 2 ? 0u : wbuf + 1;                                                             \
   }
 
+  // Lockstep with the other query-tile blocks that stream the same rows (same rp, same wave index,
+  // all on this XCD): each wave publishes the tile it has started and does not start tile t before
+  // every sharer has started tile t-W.  Without it the sharers drift further apart than the XCD's
+  // 4 MB L2 holds (4 panels x 393 KB per tile generation) and every one of them misses to HBM.
+  // A performance hint only: after kMaxSpins polls the wave stops waiting for good (a grid that is
+  // not fully co-resident must not hang).
+  uint32_t lockstep = a.lockstep;
+  uint32_t *sync_grp = a.sync + ((size_t)rp * 4 + wave) * 32;
+  constexpr uint32_t kMaxSpins = 4096;
+
   for (uint32_t t = 0; t < my_tiles; ++t) {
+    if (lockstep && lane == 0) __hip_atomic_store(sync_grp + qt, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f32x16 acc[16];
     VK_GEMM_STAGE(true, 0u, f0, f1, stg_b, stg_a)    // accumulators are born from a zero C operand
     VK_GEMM_STAGE(false, 1u, f1, f0, stg_a, stg_b)
@@ -267,6 +278,9 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
       VK_GEMM_STAGE(false, st, f0, f1, stg_b, stg_a)
       VK_GEMM_STAGE(false, st + 1, f1, f0, stg_a, stg_b)
     }
+    // progress of the sharers, fetched behind the epilogue and looked at after it
+    uint32_t seen = 0xffffffffu;
+    if (lockstep && lane < a.nqt) seen = __hip_atomic_load(sync_grp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- tile done.  Per output register r: gather the 16 class sums, combine them with
     // _mm512_reduce_add_ps's pairing (l,l+8) -> (l,l+4) -> (l,l+2) -> (0,1), 1 - dot, gate
 #pragma unroll
@@ -288,6 +302,16 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     tile_row0 += tile_step_rows;
+    if (lockstep && t + 1 < my_tiles) {
+      // about to start tile t+1: everyone must have started tile t+1-W, i.e. published >= t+2-W
+      const uint32_t need = t + 2 > lockstep ? t + 2 - lockstep : 0;
+      uint32_t spins = 0;
+      while (__builtin_amdgcn_ballot_w64(seen < need) != 0) {
+        if (++spins > kMaxSpins) { lockstep = 0; break; }
+        __builtin_amdgcn_s_sleep(4);
+        if (lane < a.nqt) seen = __hip_atomic_load(sync_grp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 #undef VK_GEMM_STAGE
 }

@@ -151,7 +151,7 @@ void prefilter_heap_select(const float *dist, const uint64_t *labels, uint64_t n
 class FlatIndex final : public Index {
  public:
   explicit FlatIndex(const vk_index_params &p, int device)
-      : Index(p), store_(device, p.dim), pool_(device), capacity_(p.initial_cap) {}
+      : Index(p), store_(device, p.dim, p.dtype == VK_DTYPE_BF16), pool_(device), capacity_(p.initial_cap) {}
 
   Status add(uint64_t label, const float *row) override {
     std::unique_lock<std::shared_mutex> lk(rw_);
@@ -211,6 +211,7 @@ class FlatIndex final : public Index {
     VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f()));
     const uint64_t *d_allow = nullptr;
     VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
+    if (k > kMaxPassK) return search_in_passes(ctx, rq, k, count, d_allow, out_dist, out_label, out_n);
     VK_TRY(ctx->d_out_d.ensure(rq.nq * k * 4));
     VK_TRY(ctx->d_out_l.ensure(rq.nq * k * 8));
     VK_TRY(ctx->d_out_n.ensure(rq.nq * 4));
@@ -249,9 +250,10 @@ class FlatIndex final : public Index {
       return Status::Err(VK_ERR_INVALID, "search_batch_device needs 0 < k <= element count");
     const float *dq = rq.queries;
     if (store_.stride_f() != params_.dim) {
-      VK_TRY(dev_ctx_->d_q.ensure(rq.nq * store_.row_bytes()));
-      VK_HIP_TRY(hipMemsetAsync(dev_ctx_->d_q.p, 0, rq.nq * store_.row_bytes(), s));
-      VK_HIP_TRY(hipMemcpy2DAsync(dev_ctx_->d_q.p, store_.row_bytes(), rq.queries, (size_t)params_.dim * 4,
+      const size_t q_pitch = (size_t)store_.stride_f() * 4;   // queries are always f32
+      VK_TRY(dev_ctx_->d_q.ensure(rq.nq * q_pitch));
+      VK_HIP_TRY(hipMemsetAsync(dev_ctx_->d_q.p, 0, rq.nq * q_pitch, s));
+      VK_HIP_TRY(hipMemcpy2DAsync(dev_ctx_->d_q.p, q_pitch, rq.queries, (size_t)params_.dim * 4,
                                   (size_t)params_.dim * 4, rq.nq, hipMemcpyDeviceToDevice, s));
       dq = dev_ctx_->d_q.as<float>();
     }
@@ -287,7 +289,7 @@ class FlatIndex final : public Index {
     VK_HIP_TRY(hipMemcpyAsync(ctx->d_idx.p, idx, m * 4, hipMemcpyHostToDevice, ctx->stream));
     GatherArgs ga{store_.d_rows(), ctx->d_q.as<float>(), ctx->d_idx.as<uint32_t>(), ctx->d_tmp.as<float>(),
                   store_.stride_f(), store_.stride_f() / 16, (uint32_t)m};
-    VK_HIP_TRY(launch_gather_distance(ga, l2(), ctx->stream));
+    VK_HIP_TRY(launch_gather_distance(ga, l2(), store_.bf16(), ctx->stream));
     VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_tmp.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
     VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
     prefilter_heap_select(ctx->h_tmp.as<float>(), found.data(), m, k, out_dist, out_label, out_n);
@@ -392,10 +394,10 @@ class FlatIndex final : public Index {
               uint64_t allow_nbits, const volatile int *cancel, float *d_out_d, uint64_t *d_out_l,
               uint32_t *d_out_n, hipStream_t s) {
     const int e = flat_scan_slots_per_lane(k);
-    if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 is not served by this build of the FLAT scan");
+    if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 needs the host entry points (vk_index_search / _batch), which page through the result in passes");
     const uint32_t chunks = store_.stride_f() / 16;
     // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
-    if (!l2() && nq >= kGemmMinQueries && !cancel && flat_gemm_supported(store_.stride_f(), k) && !force_scan_)
+    if (!l2() && !store_.bf16() && !lb_dist_ && nq >= kGemmMinQueries && !cancel && flat_gemm_supported(store_.stride_f(), k) && !force_scan_)
       return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     const int qb = flat_scan_pick_qb(nq, chunks, e);
@@ -425,6 +427,8 @@ class FlatIndex final : public Index {
       a.queries = d_q;
       a.allow_bits = d_allow;
       a.allow_nbits = allow_nbits;
+      a.lb_dist = lb_dist_;
+      a.lb_label = lb_label_;
       a.part_dist = ctx->d_part_d.as<float>() + (size_t)sgi * nq * per_q;
       a.part_label = ctx->d_part_l.as<uint64_t>() + (size_t)sgi * nq * per_q;
       a.row_stride_f = a.q_stride_f = store_.stride_f();
@@ -435,7 +439,7 @@ class FlatIndex final : public Index {
       a.k = (uint32_t)k;
       a.nrp = nrp;
       a.nqg = nqg;
-      VK_HIP_TRY(launch_flat_scan(a, l2(), qb, e, s));
+      VK_HIP_TRY(launch_flat_scan(a, l2(), store_.bf16(), qb, e, s));
       ++done;
     }
     MergeArgs m{};
@@ -453,11 +457,64 @@ class FlatIndex final : public Index {
     return Status::Ok();
   }
 
+  // k > 1024 (max-vector-knn allows up to 100000, ft_search_parser.cc:34-45): passes of <= 1024, each pass
+  // restricted to entries strictly beyond the last (distance,label) of the previous one.  Exact; one
+  // full scan per pass.
+  Status search_in_passes(SearchCtx *ctx, const SearchRequest &rq, uint64_t k, uint64_t count, const uint64_t *d_allow,
+                          float *out_dist, uint64_t *out_label, uint64_t *out_n) {
+    const uint64_t nq = rq.nq;
+    VK_TRY(ctx->d_out_d.ensure(nq * kMaxPassK * 4));
+    VK_TRY(ctx->d_out_l.ensure(nq * kMaxPassK * 8));
+    VK_TRY(ctx->d_out_n.ensure(nq * 4));
+    VK_TRY(ctx->h_out_d.ensure(nq * kMaxPassK * 4));
+    VK_TRY(ctx->h_out_l.ensure(nq * kMaxPassK * 8));
+    VK_TRY(ctx->h_out_n.ensure(nq * 4));
+    VK_TRY(ctx->d_idx.ensure(nq * 4));    // lower-bound distances
+    VK_TRY(ctx->d_stats.ensure(nq * 8));  // lower-bound labels
+    std::vector<float> lbd(nq, -__builtin_inff());
+    std::vector<uint64_t> lbl(nq, 0);
+    std::vector<uint64_t> got(nq, 0);
+    bool first = true, more = true;
+    while (more) {
+      uint64_t kp = 0;
+      for (uint64_t q = 0; q < nq; ++q) kp = std::max(kp, std::min<uint64_t>(kMaxPassK, k - got[q]));
+      if (kp == 0) break;
+      if (!first) {
+        VK_HIP_TRY(hipMemcpyAsync(ctx->d_idx.p, lbd.data(), nq * 4, hipMemcpyHostToDevice, ctx->stream));
+        VK_HIP_TRY(hipMemcpyAsync(ctx->d_stats.p, lbl.data(), nq * 8, hipMemcpyHostToDevice, ctx->stream));
+      }
+      lb_dist_ = first ? nullptr : ctx->d_idx.as<float>();
+      lb_label_ = first ? nullptr : ctx->d_stats.as<uint64_t>();
+      Status st = scan(ctx, ctx->d_q.as<float>(), nq, kp, count, d_allow, rq.allow_nbits, nullptr, ctx->d_out_d.as<float>(),
+                       ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream);
+      lb_dist_ = nullptr;
+      lb_label_ = nullptr;
+      VK_TRY(st);
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, ctx->d_out_d.p, nq * kp * 4, hipMemcpyDeviceToHost, ctx->stream));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, nq * kp * 8, hipMemcpyDeviceToHost, ctx->stream));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+      VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      more = false;
+      for (uint64_t q = 0; q < nq; ++q) {
+        const uint64_t want = std::min<uint64_t>(kp, k - got[q]);
+        const uint64_t n = std::min<uint64_t>(ctx->h_out_n.as<uint32_t>()[q], want);
+        memcpy(out_dist + q * rq.k + got[q], ctx->h_out_d.as<float>() + q * kp, n * 4);
+        memcpy(out_label + q * rq.k + got[q], ctx->h_out_l.as<uint64_t>() + q * kp, n * 8);
+        got[q] += n;
+        if (n) { lbd[q] = out_dist[q * rq.k + got[q] - 1]; lbl[q] = out_label[q * rq.k + got[q] - 1]; }
+        if (n == kp && got[q] < k) more = true;   // a full pass: there may be more beyond it
+      }
+      first = false;
+    }
+    for (uint64_t q = 0; q < nq; ++q) out_n[q] = got[q];
+    return Status::Ok();
+  }
+
   // K4 launch: persistent grid of ~one block per CU, nrp row partitions x nqt query tiles of 32
   Status scan_gemm(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
                    uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s) {
     FlatGemmArgs g{};
-    g.rows = store_.d_rows();
+    g.rows = static_cast<const float *>(store_.d_rows());
     g.labels = store_.d_labels();
     g.queries = d_q;
     g.allow_bits = d_allow;
@@ -477,6 +534,13 @@ class FlatIndex final : public Index {
     VK_TRY(ctx->d_part_l.ensure((size_t)nq * per_q * 8));
     g.part_dist = ctx->d_part_d.as<float>();
     g.part_label = ctx->d_part_l.as<uint64_t>();
+    g.lockstep = g.nqt > 1 && g.nqt <= 32 ? gemm_lockstep_ : 0;
+    if (g.lockstep) {
+      const size_t sync_bytes = (size_t)nrp * 4 * 32 * 4;
+      VK_TRY(ctx->d_sync.ensure(sync_bytes));
+      g.sync = ctx->d_sync.as<uint32_t>();
+      VK_HIP_TRY(hipMemsetAsync(g.sync, 0, sync_bytes, s));
+    }
     VK_HIP_TRY(launch_flat_gemm(g, s));
     MergeArgs m{};
     m.in_dist = g.part_dist;
@@ -494,15 +558,24 @@ class FlatIndex final : public Index {
   }
 
   static constexpr uint64_t kGemmMinQueries = 16;
+  static constexpr uint64_t kMaxPassK = 1024;
+  // per-call lower bounds of search_in_passes (set only around its scan() calls, under the ctx lease)
+  static thread_local const float *lb_dist_;
+  static thread_local const uint64_t *lb_label_;
   RowStore store_;
   CtxPool pool_;
   std::unique_ptr<SearchCtx> dev_ctx_;
   std::shared_mutex rw_;
+  // K4 lockstep window in row tiles (see FlatGemmArgs::lockstep); VK_GEMM_LOCKSTEP=0 turns it off
+  uint32_t gemm_lockstep_ = getenv("VK_GEMM_LOCKSTEP") ? (uint32_t)atoi(getenv("VK_GEMM_LOCKSTEP")) : 1;
   bool force_scan_ = getenv("VK_FLAT_FORCE_SCAN") != nullptr;   // A/B switch for benchmarks: VALU scan for every batch size
   std::unordered_map<uint64_t, uint32_t> slot_of_;  // dict_external_to_internal
   uint64_t count_ = 0;                               // cur_element_count_
   uint64_t capacity_;                                // data_->getCapacity()
 };
+
+thread_local const float *FlatIndex::lb_dist_ = nullptr;
+thread_local const uint64_t *FlatIndex::lb_label_ = nullptr;
 
 // ---- persistence: bruteforce.h:147-207 --------------------------------------------------------
 // chunk 0: BruteForceIndexHeader{max_elements=1, size_per_element=2, curr_element_count=3}
@@ -525,6 +598,13 @@ Status FlatIndex::save(vk_write_chunk_fn fn, void *user) {
     VK_HIP_TRY(hipMemcpy(rows.data(), reinterpret_cast<const char *>(store_.d_rows()) + i0 * rb, nb * rb,
                          hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < nb; ++i) {
+      if (store_.bf16()) {   // the stream carries f32 vectors (the widened, already rounded values)
+        const uint16_t *h = reinterpret_cast<const uint16_t *>(rows.data() + i * rb);
+        for (uint32_t d = 0; d < params_.dim; ++d) {
+          uint32_t u = (uint32_t)h[d] << 16;
+          memcpy(buf.data() + (size_t)d * 4, &u, 4);
+        }
+      } else
       memcpy(buf.data(), rows.data() + i * rb, vec_bytes);
       uint64_t lab = store_.host_labels()[i0 + i];
       memcpy(buf.data() + vec_bytes, &lab, 8);

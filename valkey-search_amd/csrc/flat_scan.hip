@@ -20,7 +20,7 @@
 
 namespace vk {
 
-template <int kQB, bool kL2, int kE>
+template <int kQB, bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   extern __shared__ float4 qs[];  // [kQB][chunks][4] float4 == kQB padded queries
   const int lane = threadIdx.x & 63;
@@ -48,8 +48,15 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   __syncthreads();
 
   WaveTopK<kE> top[kQB];
+  float lbd[kQB];
+  uint64_t lbl[kQB];
 #pragma unroll
-  for (int qi = 0; qi < kQB; ++qi) top[qi].init(a.k);
+  for (int qi = 0; qi < kQB; ++qi) {
+    top[qi].init(a.k);
+    const uint32_t q = qbase + qi < a.nq ? qbase + qi : a.nq - 1;
+    lbd[qi] = a.lb_dist ? a.lb_dist[q] : -__builtin_inff();
+    lbl[qi] = a.lb_dist ? a.lb_label[q] : 0;
+  }
 
   const uint32_t total_waves = a.nrp * 4;   // nrp is a multiple of 8
   const uint32_t wave_gid = rp * 4 + wave;
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
     const uint32_t row = a.row_begin + tile * kRowsPerWave + rq;
     const bool valid = row < a.row_end;
     const uint32_t lrow = valid ? row : a.row_end - 1;
-    const float4 *__restrict__ p = reinterpret_cast<const float4 *>(a.rows + (size_t)lrow * a.row_stride_f) + j;
+    const char *__restrict__ base = row_base<kBf16>(a.rows, lrow, a.row_stride_f);
 
     float4 acc[kQB];
 #pragma unroll
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
     for (; c + 8 <= chunks; c += 8) {
       float4 x[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = p[(c + u) * 4];
+      for (int u = 0; u < 8; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
 #pragma unroll
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
       }
     }
     for (; c < chunks; ++c) {
-      float4 x = p[c * 4];
+      float4 x = row_piece<kBf16>(base, c * 4 + j);
 #pragma unroll
       for (int qi = 0; qi < kQB; ++qi) chunk_fma<kL2>(acc[qi], x, qs[(qi * chunks + c) * 4 + j]);
     }
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
     for (int qi = 0; qi < kQB; ++qi) {
       const float dist = finish_distance<kL2>(quad_reduce16(acc[qi]));
       // distance gate first, filter second -- the order of bruteforce.h:131-135
-      const bool cand = valid && j == 0 && dist <= top[qi].thr_d;
+      const bool cand = valid && j == 0 && dist <= top[qi].thr_d && dist >= lbd[qi];
       uint64_t mask = __ballot(cand);
       while (mask) {
         const int b = __ffsll((unsigned long long)mask) - 1;
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
         if (!(cd <= top[qi].thr_d)) continue;
         const uint32_t crow = __builtin_amdgcn_readlane((int)row, b);
         const uint64_t cl = a.labels[crow];
+        if (a.lb_dist && !dl_less(lbd[qi], lbl[qi], cd, cl)) continue;   // not beyond the previous pass
         if (!allow_bit(a.allow_bits, a.allow_nbits, cl)) continue;
         top[qi].insert(cd, cl, lane);
       }
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs a) {
 }
 
 // Distances of an explicit row list (K8).  out[i] = distance(query, rows[idx[i]]).
-template <bool kL2>
+template <bool kL2, bool kBf16>
 __global__ __launch_bounds__(256) void gather_distance_kernel(GatherArgs a) {
   extern __shared__ float4 qs[];
   const int lane = threadIdx.x & 63;
@@ -220,42 +228,36 @@ __global__ __launch_bounds__(256) void gather_distance_kernel(GatherArgs a) {
     const uint32_t i = tile * kRowsPerWave + rq;
     const bool valid = i < a.n;
     const uint32_t row = a.idx[valid ? i : a.n - 1];
-    const float4 *__restrict__ p = reinterpret_cast<const float4 *>(a.rows + (size_t)row * a.row_stride_f) + j;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t c = 0;
-    for (; c + 8 <= chunks; c += 8) {
-      float4 x[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = p[(c + u) * 4];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) chunk_fma<kL2>(acc, x[u], qs[(c + u) * 4 + j]);
-    }
-    for (; c < chunks; ++c) chunk_fma<kL2>(acc, p[c * 4], qs[c * 4 + j]);
-    const float dist = finish_distance<kL2>(quad_reduce16(acc));
+    const float dist = quad_row_distance<kL2, kBf16>(row_base<kBf16>(a.rows, row, a.row_stride_f), qs, chunks, j);
     if (valid && j == 0) a.out[i] = dist;
   }
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
-template <int kQB, bool kL2, int kE>
+template <int kQB, bool kL2, int kE, bool kBf16>
 static hipError_t launch_scan_t(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<kQB, kL2, kE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<kQB, kL2, kE, kBf16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((flat_scan_kernel<kQB, kL2, kE>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((flat_scan_kernel<kQB, kL2, kE, kBf16>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
-template <bool kL2, int kE>
+template <bool kL2, int kE, bool kBf16>
 static hipError_t launch_scan_qb(int qb, const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
   switch (qb) {
-    case 1: return launch_scan_t<1, kL2, kE>(a, grid, lds, s);
-    case 2: return launch_scan_t<2, kL2, kE>(a, grid, lds, s);
-    case 4: return launch_scan_t<4, kL2, kE>(a, grid, lds, s);
-    default: return launch_scan_t<8, kL2, kE>(a, grid, lds, s);
+    case 1: return launch_scan_t<1, kL2, kE, kBf16>(a, grid, lds, s);
+    case 2: return launch_scan_t<2, kL2, kE, kBf16>(a, grid, lds, s);
+    case 4: return launch_scan_t<4, kL2, kE, kBf16>(a, grid, lds, s);
+    default: return launch_scan_t<8, kL2, kE, kBf16>(a, grid, lds, s);
   }
+}
+
+template <int kE, bool kBf16>
+static hipError_t launch_scan_l2(bool l2, int qb, const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+  return l2 ? launch_scan_qb<true, kE, kBf16>(qb, a, grid, lds, s) : launch_scan_qb<false, kE, kBf16>(qb, a, grid, lds, s);
 }
 
 int flat_scan_slots_per_lane(uint64_t k) {
@@ -275,15 +277,15 @@ int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e) {
   return qb;
 }
 
-hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, int qb, int e, hipStream_t s) {
+hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, int e, hipStream_t s) {
   if (a.nrp == 0 || (a.nrp & 7u) || a.nqg != (a.nq + qb - 1) / qb) return hipErrorInvalidValue;
   dim3 grid(a.nrp * a.nqg);
   size_t lds = (size_t)qb * a.chunks * 64;
   if (e == 1) lds = std::max<size_t>(lds, ((size_t)qb * 3 * a.k + 2) * 12);   // block-level merge buffers reuse it
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (e == 1) return l2 ? launch_scan_qb<true, 1>(qb, a, grid, lds, s) : launch_scan_qb<false, 1>(qb, a, grid, lds, s);
-  if (e == 4) return l2 ? launch_scan_qb<true, 4>(qb, a, grid, lds, s) : launch_scan_qb<false, 4>(qb, a, grid, lds, s);
-  if (e == 16) return l2 ? launch_scan_qb<true, 16>(qb, a, grid, lds, s) : launch_scan_qb<false, 16>(qb, a, grid, lds, s);
+  if (e == 1) return bf16 ? launch_scan_l2<1, true>(l2, qb, a, grid, lds, s) : launch_scan_l2<1, false>(l2, qb, a, grid, lds, s);
+  if (e == 4) return bf16 ? launch_scan_l2<4, true>(l2, qb, a, grid, lds, s) : launch_scan_l2<4, false>(l2, qb, a, grid, lds, s);
+  if (e == 16) return bf16 ? launch_scan_l2<16, true>(l2, qb, a, grid, lds, s) : launch_scan_l2<16, false>(l2, qb, a, grid, lds, s);
   return hipErrorInvalidValue;
 }
 
@@ -297,22 +299,24 @@ hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t
   return hipGetLastError();
 }
 
-hipError_t launch_gather_distance(const GatherArgs &a, bool l2, hipStream_t s) {
+hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipStream_t s) {
   if (a.n == 0) return hipSuccess;
   uint32_t tiles = (a.n + kRowsPerWave - 1) / kRowsPerWave;
   uint32_t blocks = (tiles + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   size_t lds = (size_t)a.chunks * 64;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const void *f = l2 ? (bf16 ? reinterpret_cast<const void *>(&gather_distance_kernel<true, true>)
+                             : reinterpret_cast<const void *>(&gather_distance_kernel<true, false>))
+                     : (bf16 ? reinterpret_cast<const void *>(&gather_distance_kernel<false, true>)
+                             : reinterpret_cast<const void *>(&gather_distance_kernel<false, false>));
   if (lds > 48 * 1024) {
-    const void *f = l2 ? reinterpret_cast<const void *>(&gather_distance_kernel<true>)
-                       : reinterpret_cast<const void *>(&gather_distance_kernel<false>);
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  if (l2) hipLaunchKernelGGL((gather_distance_kernel<true>), dim3(blocks), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((gather_distance_kernel<false>), dim3(blocks), dim3(256), lds, s, a);
-  return hipGetLastError();
+  GatherArgs args = a;
+  void *params[] = {&args};
+  return hipLaunchKernel(f, dim3(blocks), dim3(256), params, lds, s);
 }
 
 }  // namespace vk

@@ -49,7 +49,7 @@ static unsigned effective_cpus() {
 class HnswIndex final : public Index {
  public:
   HnswIndex(const vk_index_params &p, int device)
-      : Index(p), store_(device, p.dim), pool_(device),
+      : Index(p), store_(device, p.dim, p.dtype == VK_DTYPE_BF16), pool_(device),
         graph_(std::make_unique<HnswGraph>(p.dim, p.metric == VK_METRIC_L2, p.initial_cap, p.m, p.ef_construction,
                                            p.random_seed, p.allow_replace_deleted != 0)) {
     graph_->set_ef(p.ef_runtime ? p.ef_runtime : 10);
@@ -182,9 +182,10 @@ class HnswIndex final : public Index {
     hipStream_t s = stream ? stream : dev_ctx_->stream;
     const float *dq = rq.queries;
     if (store_.stride_f() != params_.dim) {
-      VK_TRY(dev_ctx_->d_q.ensure(rq.nq * store_.row_bytes()));
-      VK_HIP_TRY(hipMemsetAsync(dev_ctx_->d_q.p, 0, rq.nq * store_.row_bytes(), s));
-      VK_HIP_TRY(hipMemcpy2DAsync(dev_ctx_->d_q.p, store_.row_bytes(), rq.queries, (size_t)params_.dim * 4,
+      const size_t q_pitch = (size_t)store_.stride_f() * 4;   // queries are always f32
+      VK_TRY(dev_ctx_->d_q.ensure(rq.nq * q_pitch));
+      VK_HIP_TRY(hipMemsetAsync(dev_ctx_->d_q.p, 0, rq.nq * q_pitch, s));
+      VK_HIP_TRY(hipMemcpy2DAsync(dev_ctx_->d_q.p, q_pitch, rq.queries, (size_t)params_.dim * 4,
                                   (size_t)params_.dim * 4, rq.nq, hipMemcpyDeviceToDevice, s));
       dq = dev_ctx_->d_q.as<float>();
     }
@@ -220,7 +221,7 @@ class HnswIndex final : public Index {
     VK_HIP_TRY(hipMemcpyAsync(ctx->d_idx.p, idx, m * 4, hipMemcpyHostToDevice, ctx->stream));
     GatherArgs ga{store_.d_rows(), ctx->d_q.as<float>(), ctx->d_idx.as<uint32_t>(), ctx->d_tmp.as<float>(),
                   store_.stride_f(), store_.stride_f() / 16, (uint32_t)m};
-    VK_HIP_TRY(launch_gather_distance(ga, l2(), ctx->stream));
+    VK_HIP_TRY(launch_gather_distance(ga, l2(), store_.bf16(), ctx->stream));
     VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_tmp.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
     VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
     prefilter_heap_select(ctx->h_tmp.as<float>(), found.data(), m, k, out_dist, out_label, out_n);
@@ -279,6 +280,18 @@ class HnswIndex final : public Index {
  private:
   Status add_one(uint64_t label, const float *row) {
     uint32_t id = 0;
+    std::vector<float> rounded;
+    if (store_.bf16()) {   // the host graph must see what the device will see: rows rounded to bf16
+      rounded.resize(params_.dim);
+      for (uint32_t i = 0; i < params_.dim; ++i) {
+        uint32_t u;
+        memcpy(&u, row + i, 4);
+        if (!((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu))) u += 0x7FFFu + ((u >> 16) & 1u);
+        u &= 0xFFFF0000u;
+        memcpy(&rounded[i], &u, 4);
+      }
+      row = rounded.data();
+    }
     VK_TRY(graph_->add(row, label, &id));
     std::lock_guard<std::mutex> g(store_mu_);
     return store_.stage_write(id, row, label);
@@ -416,7 +429,7 @@ class HnswIndex final : public Index {
     a.check_deleted = graph_->deleted_count() ? 1 : 0;
     if (hnsw_lds_bytes(a) > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     int max_blocks = 0;
-    VK_HIP_TRY(hnsw_max_blocks(a, l2(), e, &max_blocks));
+    VK_HIP_TRY(hnsw_max_blocks(a, l2(), store_.bf16(), e, &max_blocks));
     // visited bitmaps: one per resident wave, bounded to 2 GiB per context
     uint64_t blocks = std::min<uint64_t>((nq + 3) / 4, (uint64_t)max_blocks);
     const uint64_t bm_bytes = (uint64_t)a.bitmap_words * 4;
@@ -426,7 +439,7 @@ class HnswIndex final : public Index {
     VK_TRY(ctx->d_stats.ensure(32));
     if (reset_stats) VK_HIP_TRY(hipMemsetAsync(ctx->d_stats.p, 0, 32, s));
     a.stats = ctx->d_stats.as<unsigned long long>();
-    VK_HIP_TRY(launch_hnsw_search(a, l2(), e, (uint32_t)blocks, s));
+    VK_HIP_TRY(launch_hnsw_search(a, l2(), store_.bf16(), e, (uint32_t)blocks, s));
     return Status::Ok();
   }
 

@@ -119,7 +119,7 @@ __device__ __forceinline__ void pool_prune(Pool &c, float bound, int lane) {
 
 }  // namespace
 
-template <bool kL2, int kE>
+template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63;
@@ -155,8 +155,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     }
 
     auto row_dist = [&](uint32_t id) -> float {
-      const float4 *p = reinterpret_cast<const float4 *>(a.rows + (size_t)id * a.row_stride_f) + j;
-      return quad_row_distance<kL2>(p, qs, chunks, j);
+      return quad_row_distance<kL2, kBf16>(row_base<kBf16>(a.rows, id, a.row_stride_f), qs, chunks, j);
     };
     auto visit = [&](uint32_t id) -> bool {  // true if it was NOT visited before
       const uint32_t bit = 1u << (id & 31);
@@ -352,21 +351,27 @@ size_t hnsw_lds_bytes(const HnswSearchArgs &a) {
   return per_wave_f4 * 16 * 4;
 }
 
-template <bool kL2, int kE>
-static const void *hnsw_fn() { return reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE>); }
+template <bool kL2, int kE, bool kBf16>
+static const void *hnsw_fn() { return reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE, kBf16>); }
 
-static const void *hnsw_pick(bool l2, int e) {
+template <int kE>
+static const void *hnsw_pick_e(bool l2, bool bf16) {
+  return l2 ? (bf16 ? hnsw_fn<true, kE, true>() : hnsw_fn<true, kE, false>())
+            : (bf16 ? hnsw_fn<false, kE, true>() : hnsw_fn<false, kE, false>());
+}
+
+static const void *hnsw_pick(bool l2, bool bf16, int e) {
   switch (e) {
-    case 1: return l2 ? hnsw_fn<true, 1>() : hnsw_fn<false, 1>();
-    case 2: return l2 ? hnsw_fn<true, 2>() : hnsw_fn<false, 2>();
-    case 4: return l2 ? hnsw_fn<true, 4>() : hnsw_fn<false, 4>();
-    case 8: return l2 ? hnsw_fn<true, 8>() : hnsw_fn<false, 8>();
+    case 1: return hnsw_pick_e<1>(l2, bf16);
+    case 2: return hnsw_pick_e<2>(l2, bf16);
+    case 4: return hnsw_pick_e<4>(l2, bf16);
+    case 8: return hnsw_pick_e<8>(l2, bf16);
   }
   return nullptr;
 }
 
-hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, int e, int *blocks) {
-  const void *f = hnsw_pick(l2, e);
+hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks) {
+  const void *f = hnsw_pick(l2, bf16, e);
   if (!f) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -385,8 +390,8 @@ hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, int e, int *blocks)
   return hipSuccess;
 }
 
-hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, int e, uint32_t blocks, hipStream_t s) {
-  const void *f = hnsw_pick(l2, e);
+hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s) {
+  const void *f = hnsw_pick(l2, bf16, e);
   if (!f || blocks == 0) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   HnswSearchArgs args = a;

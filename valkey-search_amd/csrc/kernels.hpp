@@ -7,11 +7,13 @@ namespace vk {
 
 // K3: FLAT scan over rows [row_begin,row_end) for nq queries.
 struct FlatScanArgs {
-  const float *rows;          // [cap][row_stride_f], zero padded to a multiple of 16 floats
+  const void *rows;           // [cap][row_stride_f] f32 or bf16 elements, zero padded to a multiple of 64 elements
   const uint64_t *labels;     // [cap]
   const float *queries;       // [nq][q_stride_f], padded like rows
   const uint64_t *allow_bits; // optional bitmap by label
   uint64_t allow_nbits;
+  const float *lb_dist;       // optional per-query EXCLUSIVE lower bound (dist,label): only entries
+  const uint64_t *lb_label;   // strictly greater are eligible (k > 1024 is served in passes of <= 1024)
   float *part_dist;           // partial top-k lists: [nq][nrp][k] per block when k <= 64, else [nq][nrp*4][k] per wave
   uint64_t *part_label;
   uint32_t row_stride_f, q_stride_f;
@@ -35,6 +37,10 @@ struct FlatGemmArgs {
   uint32_t n_rows, nq, k;
   uint32_t nrp;               // row partitions, multiple of 8
   uint32_t nqt;               // query tiles of 32
+  // lockstep window W among the nqt blocks that stream the same row panel through one XCD's L2
+  // (0 = off): a wave starts row tile t only after every sharer has started tile t-W
+  uint32_t lockstep;
+  uint32_t *sync;             // [nrp][4 waves][32] progress words, zeroed before the launch
 };
 size_t flat_gemm_lds_bytes(uint32_t row_stride_f);
 bool flat_gemm_supported(uint32_t row_stride_f, uint64_t k);
@@ -52,7 +58,7 @@ struct MergeArgs {
 };
 
 struct GatherArgs {
-  const float *rows;
+  const void *rows;
   const float *query;         // padded
   const uint32_t *idx;        // [n] row slots
   float *out;                 // [n]
@@ -61,7 +67,7 @@ struct GatherArgs {
 
 // K5 + K6: HNSW search, one wave per query (hnsw_search.hip)
 struct HnswSearchArgs {
-  const float *rows;           // [cap][row_stride_f]
+  const void *rows;            // [cap][row_stride_f] f32 or bf16 elements
   const uint64_t *labels;      // [cap]
   const uint32_t *links0;      // [cap][l0_stride]: word0 = count | tombstone<<16, then neighbour ids
   const uint32_t *upper_slot;  // [cap] first slot of the node's upper lists, 0xFFFFFFFF = level 0 only
@@ -86,8 +92,8 @@ struct HnswSearchArgs {
 };
 int hnsw_slots_per_lane(uint64_t ef);                      // 0 = ef too large for the in-register result list
 size_t hnsw_lds_bytes(const HnswSearchArgs &a);
-hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, int e, int *blocks);
-hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, int e, uint32_t blocks, hipStream_t s);
+hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks);
+hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s);
 
 // scatter rows of u32 words: dst[idx[i]*stride + w] = src[i*stride + w]
 hipError_t launch_scatter_u32(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride,
@@ -95,8 +101,8 @@ hipError_t launch_scatter_u32(uint32_t *dst, const uint32_t *src, const uint32_t
 
 int flat_scan_slots_per_lane(uint64_t k);                 // 0 = k too large for the in-register top-k
 int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e);
-hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, int qb, int e, hipStream_t s);
+hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, int e, hipStream_t s);
 hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s);
-hipError_t launch_gather_distance(const GatherArgs &a, bool l2, hipStream_t s);
+hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipStream_t s);
 
 }  // namespace vk

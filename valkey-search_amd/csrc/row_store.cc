@@ -7,7 +7,19 @@
 
 namespace vk {
 
-RowStore::RowStore(int device, uint32_t dim) : device_(device), dim_(dim), stride_f_(padded_dim(dim)) {
+namespace {
+// f32 -> bf16, round to nearest even (NaN stays NaN): the ingest rule of a bf16 index
+inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x0040u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+}  // namespace
+
+RowStore::RowStore(int device, uint32_t dim, bool bf16)
+    : device_(device), dim_(dim), stride_f_(padded_dim(dim)), elem_(bf16 ? 2u : 4u) {
   (void)hipSetDevice(device_);
   (void)hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
   size_t rb = row_bytes();
@@ -51,8 +63,13 @@ Status RowStore::stage_write(uint32_t slot, const float *row, uint64_t label) {
   size_t off;
   char *p;
   VK_TRY(staging_alloc(row_bytes(), &off, &p));
-  memcpy(p, row, (size_t)dim_ * 4);
-  if (stride_f_ > dim_) memset(p + (size_t)dim_ * 4, 0, (size_t)(stride_f_ - dim_) * 4);
+  if (elem_ == 4) {
+    memcpy(p, row, (size_t)dim_ * 4);
+  } else {
+    uint16_t *h = reinterpret_cast<uint16_t *>(p);
+    for (uint32_t i = 0; i < dim_; ++i) h[i] = f32_to_bf16_rne(row[i]);
+  }
+  if (stride_f_ > dim_) memset(p + (size_t)dim_ * elem_, 0, (size_t)(stride_f_ - dim_) * elem_);
   ops_.push_back(Op{0, slot, 0, off});
   stage_label(slot, label);
   return Status::Ok();
@@ -75,9 +92,9 @@ Status RowStore::reserve(uint64_t rows) {
   (void)hipSetDevice(device_);
   uint64_t want = std::max<uint64_t>(rows, alloc_rows_ + alloc_rows_ / 2);
   want = std::max<uint64_t>(want, 1024);
-  float *nr = nullptr;
+  void *nr = nullptr;
   uint64_t *nl = nullptr;
-  VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nr), want * row_bytes()));
+  VK_HIP_TRY(hipMalloc(&nr, want * row_bytes()));
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&nl), want * 8);
   if (e != hipSuccess) {
     (void)hipFree(nr);
@@ -148,8 +165,18 @@ Status RowStore::read_row(uint32_t slot, float *out) {
   VK_TRY(flush());
   (void)hipSetDevice(device_);
   if (slot >= alloc_rows_) return Status::Err(3, "slot out of range");
-  VK_HIP_TRY(hipMemcpy(out, reinterpret_cast<char *>(d_rows_) + (size_t)slot * row_bytes(), (size_t)dim_ * 4,
-                       hipMemcpyDeviceToHost));
+  if (elem_ == 4) {
+    VK_HIP_TRY(hipMemcpy(out, reinterpret_cast<char *>(d_rows_) + (size_t)slot * row_bytes(), (size_t)dim_ * 4,
+                         hipMemcpyDeviceToHost));
+  } else {
+    std::vector<uint16_t> h(dim_);
+    VK_HIP_TRY(hipMemcpy(h.data(), reinterpret_cast<char *>(d_rows_) + (size_t)slot * row_bytes(), (size_t)dim_ * 2,
+                         hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < dim_; ++i) {
+      uint32_t u = (uint32_t)h[i] << 16;
+      memcpy(out + i, &u, 4);
+    }
+  }
   return Status::Ok();
 }
 

@@ -44,18 +44,19 @@ inline uint32_t padded_dim(uint32_t dim) { return (dim + 63u) & ~63u; }
 
 class RowStore {
  public:
-  RowStore(int device, uint32_t dim);
+  RowStore(int device, uint32_t dim, bool bf16 = false);
   ~RowStore();
   RowStore(const RowStore &) = delete;
   RowStore &operator=(const RowStore &) = delete;
 
   uint32_t dim() const { return dim_; }
   uint32_t stride_f() const { return stride_f_; }
-  size_t row_bytes() const { return (size_t)stride_f_ * 4; }
+  size_t row_bytes() const { return (size_t)stride_f_ * elem_; }   // stride_f_ counts ELEMENTS (f32 or bf16)
+  bool bf16() const { return elem_ == 2; }
   int device() const { return device_; }
   hipStream_t stream() const { return stream_; }
-  const float *d_rows() const { return d_rows_; }
-  float *d_rows_mut() { return d_rows_; }
+  const void *d_rows() const { return d_rows_; }
+  void *d_rows_mut() { return d_rows_; }
   const uint64_t *d_labels() const { return d_labels_; }
   uint64_t alloc_rows() const { return alloc_rows_; }
   size_t staged_ops() const { return ops_.size(); }
@@ -82,9 +83,9 @@ class RowStore {
   Status staging_alloc(size_t bytes, size_t *off, char **ptr);
 
   int device_;
-  uint32_t dim_, stride_f_;
+  uint32_t dim_, stride_f_, elem_;
   hipStream_t stream_ = nullptr;
-  float *d_rows_ = nullptr;
+  void *d_rows_ = nullptr;
   uint64_t *d_labels_ = nullptr;
   uint64_t alloc_rows_ = 0;
   std::vector<uint64_t> h_labels_;

@@ -8,10 +8,12 @@
 #include <memory>
 #include <string>
 
+#include "coalescer.hpp"
 #include "index.hpp"
 
 struct vk_index {
   std::unique_ptr<vk::Index> impl;
+  vk::Coalescer coalescer;
 };
 
 namespace {
@@ -43,7 +45,7 @@ vk::Status check_params(const vk_index_params *p) {
   if (p->struct_size != sizeof(vk_index_params)) return vk::Status::Err(VK_ERR_INVALID, "vk_index_params.struct_size mismatch");
   if (p->algo > VK_ALGO_HNSW) return vk::Status::Err(VK_ERR_INVALID, "unknown algo");
   if (p->metric > VK_METRIC_COSINE) return vk::Status::Err(VK_ERR_INVALID, "unknown metric");
-  if (p->dtype != VK_DTYPE_F32) return vk::Status::Err(VK_ERR_INVALID, "only FLOAT32 storage is implemented");
+  if (p->dtype > VK_DTYPE_BF16) return vk::Status::Err(VK_ERR_INVALID, "unknown dtype");
   if (p->dim == 0 || p->dim > 64000) return vk::Status::Err(VK_ERR_INVALID, "dimension out of range");
   if (p->initial_cap >= (1ull << 32)) return vk::Status::Err(VK_ERR_INVALID, "initial_cap out of range");
   if (p->algo == VK_ALGO_HNSW && (p->m < 2 || p->m > 10000)) return vk::Status::Err(VK_ERR_INVALID, "M out of range");
@@ -69,7 +71,8 @@ int vk_index_create(const vk_index_params *params, vk_index **out) {
     std::unique_ptr<vk::Index> impl;
     if (params->algo == VK_ALGO_FLAT) VK_TRY(vk::create_flat(*params, &impl));
     else VK_TRY(vk::create_hnsw(*params, &impl));
-    *out = new vk_index{std::move(impl)};
+    *out = new vk_index;
+    (*out)->impl = std::move(impl);
     return vk::Status::Ok();
   });
 }
@@ -140,6 +143,13 @@ int vk_index_search_batch(vk_index *ix, const void *queries, uint64_t nq, uint64
 int vk_index_search(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, const uint64_t *allow_bits,
                     uint64_t allow_nbits, const volatile int *cancel_flag, int partial_ok, float *out_dist,
                     uint64_t *out_label, uint64_t *out_n) {
+  if (ix && ix->impl && ix->coalescer.enabled() && !allow_bits && !cancel_flag && k) {
+    if (!query || !out_n || !out_dist || !out_label) return fail(VK_ERR_INVALID, "NULL argument");
+    return guarded([&] {
+      return ix->coalescer.search(ix->impl.get(), static_cast<const float *>(query), k, ef_runtime, out_dist,
+                                  out_label, out_n);
+    });
+  }
   return vk_index_search_batch(ix, query, 1, k, ef_runtime, allow_bits, allow_nbits, cancel_flag, partial_ok,
                                out_dist, out_label, out_n);
 }
@@ -196,7 +206,19 @@ int vk_index_contains(vk_index *ix, uint64_t label, int *out_found) {
 int vk_index_get_stats(vk_index *ix, vk_index_stats *out) {
   VK_NEED(ix);
   if (!out) return fail(VK_ERR_INVALID, "out is NULL");
-  return guarded([&] { return ix->impl->stats(out); });
+  return guarded([&] {
+    vk::Status s = ix->impl->stats(out);
+    out->coalesced_batches = ix->coalescer.batches();
+    out->coalesced_queries = ix->coalescer.queries();
+    return s;
+  });
+}
+
+int vk_index_set_coalescing(vk_index *ix, uint32_t max_batch, uint32_t max_wait_us) {
+  VK_NEED(ix);
+  if (max_batch > 4096) return fail(VK_ERR_INVALID, "max_batch out of range");
+  ix->coalescer.configure(max_batch, max_wait_us);
+  return VK_OK;
 }
 
 int vk_index_device_rows(vk_index *ix, uint64_t n_rows, void **d_rows, uint64_t *row_stride_bytes) {
@@ -248,7 +270,8 @@ int vk_index_load(const vk_index_params *params, vk_read_chunk_fn read_chunk, vo
     std::unique_ptr<vk::Index> impl;
     if (params->algo == VK_ALGO_FLAT) VK_TRY(vk::load_flat(*params, read_chunk, user, &impl));
     else VK_TRY(vk::load_hnsw(*params, read_chunk, user, &impl));
-    *out = new vk_index{std::move(impl)};
+    *out = new vk_index;
+    (*out)->impl = std::move(impl);
     return vk::Status::Ok();
   });
 }
