@@ -49,10 +49,19 @@ struct LaneTop {          // one lane's running top-k state; the list itself liv
   uint32_t thr_i, cnt;
 };
 
+// order-preserving f32 <-> u32 (larger float = larger key), for atomicMin on the shared bound
+__device__ __forceinline__ uint32_t f32_key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 // rare path: a (distance,row) that passed the lane's distance gate
 __device__ __forceinline__ LaneTop topk_insert(const uint64_t *__restrict__ labels, const uint64_t *__restrict__ allow_bits,
                                             uint64_t allow_nbits, uint32_t k, float dist, uint32_t row, float *list_d,
-                                            uint64_t *list_l, LaneTop t) {
+                                            uint64_t *list_l, uint32_t *qbound_q, LaneTop t) {
   const uint64_t lab = labels[row];
   if (!allow_bit(allow_bits, allow_nbits, lab)) return t;
   if (t.cnt >= k && !dl_less(dist, lab, t.thr_d, t.thr_l)) return t;
@@ -71,8 +80,54 @@ __device__ __forceinline__ LaneTop topk_insert(const uint64_t *__restrict__ labe
     t.thr_d = wd;
     t.thr_l = wl;
     t.thr_i = wi;
+    // k kept entries are all <= wd: nothing beyond wd can reach this query's final top-k, whichever
+    // list it would land in -- publish it for every other lane working on the query
+    __hip_atomic_fetch_min(qbound_q, f32_key(wd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return t;
+}
+
+// k <= kRegCap: the lane's list lives in registers (distance + row index; labels are looked up only to
+// break distance ties, to apply the filter, and when the list is written out).  An insert is ~50
+// VALU operations and no memory round trip; with the HBM-resident list every insert of any lane
+// stalled the whole wave -- and its matrix pipe -- for about a microsecond, ~6000 times per wave at
+// 10M rows.
+constexpr int kRegCap = 10;
+struct RegTop {
+  float d[kRegCap];
+  uint32_t r[kRegCap];
+  float thr_d;            // worst kept distance, +inf while the list is not full
+  uint32_t thr_r, thr_i, cnt;
+};
+__device__ __forceinline__ RegTop reg_insert(const uint64_t *__restrict__ labels, const uint64_t *__restrict__ allow_bits,
+                                          uint64_t allow_nbits, uint32_t k, float dist, uint32_t row, RegTop s) {
+  if (allow_bits != nullptr && !allow_bit(allow_bits, allow_nbits, labels[row])) return s;
+  if (s.cnt >= k && dist == s.thr_d && !(labels[row] < labels[s.thr_r])) return s;   // tie: label decides
+  const uint32_t at = s.cnt < k ? s.cnt++ : s.thr_i;
+#pragma unroll
+  for (int i = 0; i < kRegCap; ++i) {
+    s.d[i] = (uint32_t)i == at ? dist : s.d[i];
+    s.r[i] = (uint32_t)i == at ? row : s.r[i];
+  }
+  if (s.cnt == k) {   // recompute the worst entry: largest (distance, label)
+    float wd = s.d[0];
+    uint32_t wr = s.r[0], wi = 0;
+#pragma unroll
+    for (int i = 1; i < kRegCap; ++i) {
+      if ((uint32_t)i < k) {
+        const float di = s.d[i];
+        bool worse = di > wd;
+        if (di == wd) worse = labels[s.r[i]] > labels[wr];
+        wd = worse ? di : wd;
+        wr = worse ? s.r[i] : wr;
+        wi = worse ? (uint32_t)i : wi;
+      }
+    }
+    s.thr_d = wd;
+    s.thr_r = wr;
+    s.thr_i = wi;
+  }
+  return s;
 }
 
 // Position in this block's flattened (tile, stage) stream, kept incrementally (no divisions).
@@ -155,10 +210,16 @@ __device__ __forceinline__ void stage_mfma(f32x16 (&acc)[16], const Frag f) {
 }
 #undef VK_MFMA4
 
-// kAblate (timing experiments only, results invalid when != 0): 1 = no HBM loads, 2 = also no LDS
-// stores / barriers, 3 = also no LDS fragment reads (pure MFMA issue)
-template <int kAblate>
+// kAblate (timing experiments only, results invalid when != 0), cumulative: 1 = the top-k insert is
+// replaced by a running minimum (no divergent path), 2 = and the HBM loads re-read one hot tile (L2
+// hits only), 3 = no global loads at all, 4 = no LDS stores, 5 = no LDS fragment reads (MFMA +
+// epilogue arithmetic only)
+// kMode: 0 = two register staging sets (HBM loads in flight for ~2 stages); 1, 2 = four sets (~4
+// stages; needs stages % 4 == 0, i.e. a row stride that is a multiple of 128 floats) with two ways
+// of placing the loads; 3 = two sets with the hand placement of 2
+template <int kAblate, int kMode, bool kRegList>
 __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
+  constexpr bool kDeep = kMode == 1 || kMode == 2;
   extern __shared__ float lds[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
@@ -197,16 +258,31 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   const size_t list_base = (((size_t)(q_valid ? my_q : 0) * a.nrp + rp) * 8 + slot) * a.k;
   float *list_d = a.part_dist + list_base;
   uint64_t *list_l = a.part_label + list_base;
-  if (q_valid)
+  if (q_valid && !kRegList)
     for (uint32_t i = 0; i < a.k; ++i) { list_d[i] = __builtin_inff(); list_l[i] = kNoLabel; }
   LaneTop top{__builtin_inff(), kNoLabel, 0u, 0u};
+  RegTop rtop;
+#pragma unroll
+  for (int i = 0; i < kRegCap; ++i) { rtop.d[i] = __builtin_inff(); rtop.r[i] = 0xffffffffu; }
+  rtop.thr_d = __builtin_inff();
+  rtop.thr_r = 0xffffffffu;
+  rtop.thr_i = 0;
+  rtop.cnt = 0;
+  uint32_t *qbound_q = a.qbound + (q_valid ? my_q : 0);
 
+  // row tiles of this partition: a contiguous range (consecutive tiles are adjacent in memory: fewer
+  // TLB fills and DRAM page changes than the strided assignment rp, rp+nrp, ...)
   const uint32_t n_tiles = (a.n_rows + kTileRows - 1) / kTileRows;
-  const uint32_t my_tiles = rp < n_tiles ? (n_tiles - rp + a.nrp - 1) / a.nrp : 0;
+  const uint32_t t_base = n_tiles / a.nrp, t_rem = n_tiles % a.nrp;
+  const uint32_t first_tile = a.contig ? rp * t_base + (rp < t_rem ? rp : t_rem) : rp;
+  const uint32_t my_tiles = a.contig ? t_base + (rp < t_rem ? 1u : 0u) : (rp < n_tiles ? (n_tiles - rp + a.nrp - 1) / a.nrp : 0);
   const uint32_t total = my_tiles * stages;             // stages in this block's stream (< 2^32: <= 2^25 tiles)
-  const uint32_t tile_step_rows = a.nrp * kTileRows;
-  if (total == 0) return;
-  (void)total;
+  const uint32_t tile_step_rows = a.contig ? kTileRows : a.nrp * kTileRows;
+  if (total == 0) {   // more partitions than tiles: this block only owes the merge its empty lists
+    if (q_valid && kRegList)
+      for (uint32_t i = 0; i < a.k; ++i) { list_d[i] = __builtin_inff(); list_l[i] = kNoLabel; }
+    return;
+  }
 
   // Software pipeline over the stream, iteration i = stage i:
   //   global loads for stage i+3 are issued at the top of i, written to LDS at the bottom of i+1
@@ -215,19 +291,31 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   // last held stage i-1, whose fragments were fetched during i-2.  One barrier per iteration.
   // The loop is unrolled by two with ping-pong register sets (no register rotation: a move of
   // a register that is the target of an in-flight load would wait for the load).
-  StreamPos ld{rp * kTileRows + wave * 32, 0, total};   // next stage to fetch from HBM (this wave's rows)
-  Stg stg_a, stg_b;
-  // prologue: stages 0 and 1 straight to LDS, stage 2 left in registers (set a).  A stream has at
-  // least two stages (stages is even); loads past its end re-read the last stage and are unused.
+  StreamPos ld{first_tile * kTileRows + wave * 32, 0, total};   // next stage to fetch from HBM (this wave's rows)
+  Stg stg_a, stg_b, stg_c, stg_d;
+  // prologue: stages 0 and 1 straight to LDS, the next one (kDeep: three) left in registers.  A
+  // stream has at least two stages; loads past its end re-read the last stage and are unused.
   stg_a = stage_load(a, lane, ld);
   stage_store(lds_x, lane, stg_a);
   stream_advance(ld, stages, tile_step_rows);
   stg_a = stage_load(a, lane, ld);
   stage_store(lds_x + kBufFloats, lane, stg_a);
   stream_advance(ld, stages, tile_step_rows);
-  stg_a = stage_load(a, lane, ld);
-  stg_b = stg_a;
-  stream_advance(ld, stages, tile_step_rows);
+  if constexpr (kDeep) {
+    // iteration i loads into set i%4 and stores set (i+1)%4: sets b, c, d hold stages 2, 3, 4
+    stg_b = stage_load(a, lane, ld);
+    stream_advance(ld, stages, tile_step_rows);
+    stg_c = stage_load(a, lane, ld);
+    stream_advance(ld, stages, tile_step_rows);
+    stg_d = stage_load(a, lane, ld);
+    stream_advance(ld, stages, tile_step_rows);
+    stg_a = stg_d;
+  } else {
+    stg_a = stage_load(a, lane, ld);
+    stg_b = stg_a;
+    stg_c = stg_d = stg_a;
+    stream_advance(ld, stages, tile_step_rows);
+  }
   __syncthreads();                                       // the shared Q tile is in place
 
   const uint32_t x_off = li * kXStride + kk * 16;
@@ -236,25 +324,49 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
 
   uint32_t rbuf = 1;            // buffer of stage done+1
   uint32_t wbuf = 2;            // buffer of stage done+2
-  uint32_t tile_row0 = rp * kTileRows;
+  uint32_t tile_row0 = first_tile * kTileRows;
 
   // one pipeline iteration: F = fragments of stage ST, NF receives the next stage's, SNEW receives
   // the loads of stage done+3, SOLD (loads of stage done+2) goes to LDS.  Past the end of the
   // stream the prefetches are harmless re-reads (ld stops advancing, results unused).
 #define VK_GEMM_STAGE(ZERO, ST, F, NF, SNEW, SOLD)                                                \
   {                                                                                               \
-    /* HBM loads for stage +3, this stage's 16 MFMAs (operands fetched one stage ago), LDS      */ \
-    /* fragment reads for stage +1, LDS store of the loads issued one stage ago.  Placement of  */ \
-    /* the independent pieces is left to the compiler: measured on MI355X (10Mx768, B=256) its  */ \
-    /* own schedule (51.0 ms) beat pinning the store behind the MFMAs (53-54 ms) and spreading  */ \
-    /* the other work over the MFMA gaps with sched_group_barrier (55-59 ms).                   */ \
-    if constexpr (kAblate < 1) SNEW = stage_load(a, lane, ld);                                    \
-    if constexpr (kAblate == 4) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load(a, lane, hot); } \
-    stream_advance(ld, stages, tile_step_rows);                                                   \
-    stage_mfma<ZERO>(acc, F);                                                                     \
+    /* HBM loads for a later stage, LDS fragment reads for stage +1, this stage's 16 MFMAs        */ \
+    /* (operands fetched one stage ago), LDS store of the oldest loads in flight.                 */ \
+    /* kMode 0: placement left to the compiler (its own schedule beat hand placement for the      */ \
+    /* two-set pipeline).  kMode 1/2: four staging sets; at the VGPR limit the scheduler sinks    */ \
+    /* the loads towards their use, so they are pinned at the top of the stage.                   */ \
     const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
-    if constexpr (kAblate < 3 || kAblate == 4) NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk); \
-    if constexpr (kAblate < 2 || kAblate == 4) stage_store(lds_x + wbuf * kBufFloats, lane, SOLD); \
+    if constexpr (kAblate < 2) SNEW = stage_load(a, lane, ld);                                    \
+    if constexpr (kAblate == 2) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load(a, lane, hot); } \
+    stream_advance(ld, stages, tile_step_rows);                                                   \
+    if constexpr (kMode == 1) {                                                                   \
+      NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk);                          \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      stage_mfma<ZERO>(acc, F);                                                                   \
+      stage_store(lds_x + wbuf * kBufFloats, lane, SOLD);                                         \
+    } else {                                                                                      \
+      stage_mfma<ZERO>(acc, F);                                                                   \
+      if constexpr (kAblate < 5) NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk); \
+      if constexpr (kAblate < 4) stage_store(lds_x + wbuf * kBufFloats, lane, SOLD);              \
+    }                                                                                             \
+    if constexpr (kMode >= 2) {                                                                   \
+      /* MFMA k followed by: a global load (k < 4), an LDS fragment read (4 <= k < 12), an LDS    */ \
+      /* store (k >= 12) */                                                                       \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                        \
+      }                                                                                           \
+      _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+      }                                                                                           \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                        \
+      }                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    }                                                                                             \
     rbuf = rbuf == 2 ? 0u : rbuf + 1;                                                             \
     wbuf = wbuf == 2 ? 0u : wbuf + 1;                                                             \
   }
@@ -271,16 +383,33 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
 
   for (uint32_t t = 0; t < my_tiles; ++t) {
     if (lockstep && lane == 0) __hip_atomic_store(sync_grp + qt, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the query's shared pruning bound, fetched now and used a whole tile later in the epilogue
+    uint32_t bkey = 0xFF800000u;
+    if constexpr (!kRegList) bkey = __hip_atomic_load(qbound_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f32x16 acc[16];
-    VK_GEMM_STAGE(true, 0u, f0, f1, stg_b, stg_a)    // accumulators are born from a zero C operand
-    VK_GEMM_STAGE(false, 1u, f1, f0, stg_a, stg_b)
-    for (uint32_t st = 2; st < stages; st += 2) {
-      VK_GEMM_STAGE(false, st, f0, f1, stg_b, stg_a)
-      VK_GEMM_STAGE(false, st + 1, f1, f0, stg_a, stg_b)
+    if constexpr (kDeep) {
+      VK_GEMM_STAGE(true, 0u, f0, f1, stg_a, stg_b)    // accumulators are born from a zero C operand
+      VK_GEMM_STAGE(false, 1u, f1, f0, stg_b, stg_c)
+      VK_GEMM_STAGE(false, 2u, f0, f1, stg_c, stg_d)
+      VK_GEMM_STAGE(false, 3u, f1, f0, stg_d, stg_a)
+      for (uint32_t st = 4; st < stages; st += 4) {
+        VK_GEMM_STAGE(false, st, f0, f1, stg_a, stg_b)
+        VK_GEMM_STAGE(false, st + 1, f1, f0, stg_b, stg_c)
+        VK_GEMM_STAGE(false, st + 2, f0, f1, stg_c, stg_d)
+        VK_GEMM_STAGE(false, st + 3, f1, f0, stg_d, stg_a)
+      }
+    } else {
+      VK_GEMM_STAGE(true, 0u, f0, f1, stg_b, stg_a)    // accumulators are born from a zero C operand
+      VK_GEMM_STAGE(false, 1u, f1, f0, stg_a, stg_b)
+      for (uint32_t st = 2; st < stages; st += 2) {
+        VK_GEMM_STAGE(false, st, f0, f1, stg_b, stg_a)
+        VK_GEMM_STAGE(false, st + 1, f1, f0, stg_a, stg_b)
+      }
     }
     // progress of the sharers, fetched behind the epilogue and looked at after it
     uint32_t seen = 0xffffffffu;
     if (lockstep && lane < a.nqt) seen = __hip_atomic_load(sync_grp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float gate_b = key_f32(bkey);
     // ---- tile done.  Per output register r: gather the 16 class sums, combine them with
     // _mm512_reduce_add_ps's pairing (l,l+8) -> (l,l+4) -> (l,l+2) -> (0,1), 1 - dot, gate
 #pragma unroll
@@ -295,8 +424,15 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
       const float dot = (v[0] + v[2]) + (v[1] + v[3]);
       const float dist = 1.0f - dot;
       const uint32_t row = tile_row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-      if (q_valid && row < a.n_rows && dist <= top.thr_d)
-        top = topk_insert(a.labels, a.allow_bits, a.allow_nbits, a.k, dist, row, list_d, list_l, top);
+      if constexpr (kAblate >= 1) {
+        top.thr_d = dist < top.thr_d ? dist : top.thr_d;
+        top.thr_i = row;
+      } else if constexpr (kRegList) {
+        if (q_valid && row < a.n_rows && dist <= rtop.thr_d)
+          rtop = reg_insert(a.labels, a.allow_bits, a.allow_nbits, a.k, dist, row, rtop);
+      } else if (q_valid && row < a.n_rows && dist <= top.thr_d && dist <= gate_b) {
+        top = topk_insert(a.labels, a.allow_bits, a.allow_nbits, a.k, dist, row, list_d, list_l, qbound_q, top);
+      }
       // keep the 16 gathers of one output register together: hoisting all 256 accumulator reads
       // ahead of the adds would need 256 VGPRs and spill into the pipelined loop
       __builtin_amdgcn_sched_barrier(0);
@@ -311,6 +447,18 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
         __builtin_amdgcn_s_sleep(4);
         if (lane < a.nqt) seen = __hip_atomic_load(sync_grp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+    }
+  }
+  if constexpr (kAblate >= 1) {   // keep the arithmetic alive
+    if (q_valid) { list_d[0] = top.thr_d; list_l[0] = top.thr_i; }
+  } else if constexpr (kRegList) {
+    if (q_valid) {
+#pragma unroll
+      for (int i = 0; i < kRegCap; ++i)
+        if ((uint32_t)i < a.k) {
+          list_d[i] = rtop.d[i];
+          list_l[i] = rtop.r[i] == 0xffffffffu ? kNoLabel : a.labels[rtop.r[i]];
+        }
     }
   }
 #undef VK_GEMM_STAGE
@@ -329,11 +477,19 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
   const size_t lds = flat_gemm_lds_bytes(a.row_stride_f);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static const int ablate = getenv("VK_GEMM_ABLATE") ? atoi(getenv("VK_GEMM_ABLATE")) : 0;
-  const void *fn = ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1>)
-                 : ablate == 2 ? reinterpret_cast<const void *>(&flat_gemm_kernel<2>)
-                 : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3>)
-                 : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4>)
-                               : reinterpret_cast<const void *>(&flat_gemm_kernel<0>);
+  static const int mode_env = getenv("VK_GEMM_MODE") ? atoi(getenv("VK_GEMM_MODE")) : 0;
+  const int mode = mode_env == 2 && (a.chunks % 8) == 0 ? 2 : 0;
+  static const int reg_env = getenv("VK_GEMM_REGLIST") ? atoi(getenv("VK_GEMM_REGLIST")) : 1;
+  const bool reg = reg_env && a.k <= (uint32_t)kRegCap;
+  const void *fn = ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1, 0, false>)
+                 : ablate == 2 ? reinterpret_cast<const void *>(&flat_gemm_kernel<2, 0, false>)
+                 : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3, 0, false>)
+                 : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4, 0, false>)
+                 : ablate == 5 ? reinterpret_cast<const void *>(&flat_gemm_kernel<5, 0, false>)
+                 : mode == 2   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 2, true>)
+                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 2, false>))
+                               : (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, true>)
+                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, false>));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   FlatGemmArgs args = a;

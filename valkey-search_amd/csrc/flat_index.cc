@@ -535,12 +535,14 @@ class FlatIndex final : public Index {
     g.part_dist = ctx->d_part_d.as<float>();
     g.part_label = ctx->d_part_l.as<uint64_t>();
     g.lockstep = g.nqt > 1 && g.nqt <= 32 ? gemm_lockstep_ : 0;
-    if (g.lockstep) {
-      const size_t sync_bytes = (size_t)nrp * 4 * 32 * 4;
-      VK_TRY(ctx->d_sync.ensure(sync_bytes));
-      g.sync = ctx->d_sync.as<uint32_t>();
-      VK_HIP_TRY(hipMemsetAsync(g.sync, 0, sync_bytes, s));
-    }
+    g.contig = gemm_contig_;
+    // [ progress words | per-query bounds ]
+    const size_t sync_bytes = (size_t)nrp * 4 * 32 * 4;
+    VK_TRY(ctx->d_sync.ensure(sync_bytes + nq * 4));
+    g.sync = ctx->d_sync.as<uint32_t>();
+    g.qbound = g.sync + sync_bytes / 4;
+    VK_HIP_TRY(hipMemsetAsync(g.sync, 0, sync_bytes, s));
+    VK_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g.qbound), (int)0xFF800000u, nq, s));   // key of +inf
     VK_HIP_TRY(launch_flat_gemm(g, s));
     MergeArgs m{};
     m.in_dist = g.part_dist;
@@ -568,6 +570,7 @@ class FlatIndex final : public Index {
   std::shared_mutex rw_;
   // K4 lockstep window in row tiles (see FlatGemmArgs::lockstep); VK_GEMM_LOCKSTEP=0 turns it off
   uint32_t gemm_lockstep_ = getenv("VK_GEMM_LOCKSTEP") ? (uint32_t)atoi(getenv("VK_GEMM_LOCKSTEP")) : 1;
+  uint32_t gemm_contig_ = getenv("VK_GEMM_CONTIG") ? (uint32_t)atoi(getenv("VK_GEMM_CONTIG")) : 1;
   bool force_scan_ = getenv("VK_FLAT_FORCE_SCAN") != nullptr;   // A/B switch for benchmarks: VALU scan for every batch size
   std::unordered_map<uint64_t, uint32_t> slot_of_;  // dict_external_to_internal
   uint64_t count_ = 0;                               // cur_element_count_

@@ -41,6 +41,10 @@ struct FlatGemmArgs {
   // (0 = off): a wave starts row tile t only after every sharer has started tile t-W
   uint32_t lockstep;
   uint32_t *sync;             // [nrp][4 waves][32] progress words, zeroed before the launch
+  // per-query pruning bound shared by every list of the launch: order-preserving key of the
+  // smallest k-th-best distance any FULL list has reached (0xFF800000 = +inf before the launch)
+  uint32_t *qbound;           // [nq]
+  uint32_t contig;            // 1: a row partition owns a contiguous range of tiles, 0: tiles rp, rp+nrp, ...
 };
 size_t flat_gemm_lds_bytes(uint32_t row_stride_f);
 bool flat_gemm_supported(uint32_t row_stride_f, uint64_t k);
