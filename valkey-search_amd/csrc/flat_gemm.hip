@@ -154,21 +154,24 @@ struct Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
 
 // global -> registers for one stage of ONE WAVE: its 32 rows x 2 chunks = 256 float4, 4 per lane:
 // idx = lane + 64*u -> row idx/8 (of the wave's 32), 16-B column idx%8 of the 2-chunk slab.
-// p.tile_row0 already includes the wave's row offset.
-__device__ __forceinline__ float4 stage_load1(const FlatGemmArgs &a, uint32_t idx, const StreamPos &p) {
-  const uint32_t r = idx >> 3, c4 = idx & 7;
-  uint32_t row = p.tile_row0 + r;
-  row = row < a.n_rows ? row : a.n_rows - 1;
-  // chunk = st*2 + c4/4, 16-B piece c4%4 of it == float4 index st*8 + c4 (rows are zero padded
-  // to whole stages, so there is no tail)
-  return reinterpret_cast<const float4 *>(a.rows + (size_t)row * a.row_stride_f)[p.st * 8 + c4];
+// Address = wave-uniform base (tile row, stage: scalar registers) + a per-lane offset that never
+// changes (LaneOff, computed once), so a stage issues its four loads without any vector address
+// arithmetic.  No clamping: the row store keeps RowStore::kRowSlack readable rows past its capacity,
+// rows past n_rows are masked in the epilogue.  p.tile_row0 already includes the wave's row offset.
+struct LaneOff { uint32_t o0, o1, o2, o3; };   // in floats
+__device__ __forceinline__ LaneOff lane_offsets(uint32_t lane, uint32_t row_stride_f) {
+  const uint32_t o = (lane >> 3) * row_stride_f + (lane & 7) * 4;
+  return LaneOff{o, o + 8 * row_stride_f, o + 16 * row_stride_f, o + 24 * row_stride_f};
 }
-__device__ __forceinline__ Stg stage_load(const FlatGemmArgs &a, uint32_t lane, const StreamPos &p) {
+__device__ __forceinline__ Stg stage_load(const FlatGemmArgs &a, const LaneOff lo, const StreamPos &p) {
+  // chunk = st*2 + c4/4, 16-B piece c4%4 of it == float offset st*32 + c4*4 (rows are zero padded
+  // to whole stages, so there is no tail)
+  const float *base = a.rows + (size_t)p.tile_row0 * a.row_stride_f + p.st * 32;
   Stg s;
-  s.v0 = stage_load1(a, lane, p);
-  s.v1 = stage_load1(a, lane + 64, p);
-  s.v2 = stage_load1(a, lane + 128, p);
-  s.v3 = stage_load1(a, lane + 192, p);
+  s.v0 = *reinterpret_cast<const float4 *>(base + lo.o0);
+  s.v1 = *reinterpret_cast<const float4 *>(base + lo.o1);
+  s.v2 = *reinterpret_cast<const float4 *>(base + lo.o2);
+  s.v3 = *reinterpret_cast<const float4 *>(base + lo.o3);
   return s;
 }
 
@@ -208,7 +211,6 @@ __device__ __forceinline__ void stage_mfma(f32x16 (&acc)[16], const Frag f) {
   VK_MFMA4(2, f.a2, f.b2)
   VK_MFMA4(3, f.a3, f.b3)
 }
-#undef VK_MFMA4
 
 // kAblate (timing experiments only, results invalid when != 0), cumulative: 1 = the top-k insert is
 // replaced by a running minimum (no divergent path), 2 = and the HBM loads re-read one hot tile (L2
@@ -219,11 +221,12 @@ __device__ __forceinline__ void stage_mfma(f32x16 (&acc)[16], const Frag f) {
 // of placing the loads; 3 = two sets with the hand placement of 2
 template <int kAblate, int kMode, bool kRegList>
 __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
-  constexpr bool kDeep = kMode == 1 || kMode == 2;
+  constexpr bool kDeep = kMode == 1 || kMode == 2 || kMode == 4;
+  constexpr bool kInPlace = kMode >= 4 && kMode <= 6;
   extern __shared__ float lds[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
-  const uint32_t wave = tid >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it in a scalar register
   const uint32_t li = lane & 31;   // row (A) / query (B) index inside the 32-wide MFMA tile
   const uint32_t kk = lane >> 5;   // which of the two chunks of the stage this lane feeds
   const uint32_t chunks = a.chunks;
@@ -291,27 +294,28 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   // last held stage i-1, whose fragments were fetched during i-2.  One barrier per iteration.
   // The loop is unrolled by two with ping-pong register sets (no register rotation: a move of
   // a register that is the target of an in-flight load would wait for the load).
+  const LaneOff loff = lane_offsets(lane, a.row_stride_f);
   StreamPos ld{first_tile * kTileRows + wave * 32, 0, total};   // next stage to fetch from HBM (this wave's rows)
   Stg stg_a, stg_b, stg_c, stg_d;
   // prologue: stages 0 and 1 straight to LDS, the next one (kDeep: three) left in registers.  A
   // stream has at least two stages; loads past its end re-read the last stage and are unused.
-  stg_a = stage_load(a, lane, ld);
+  stg_a = stage_load(a, loff, ld);
   stage_store(lds_x, lane, stg_a);
   stream_advance(ld, stages, tile_step_rows);
-  stg_a = stage_load(a, lane, ld);
+  stg_a = stage_load(a, loff, ld);
   stage_store(lds_x + kBufFloats, lane, stg_a);
   stream_advance(ld, stages, tile_step_rows);
   if constexpr (kDeep) {
     // iteration i loads into set i%4 and stores set (i+1)%4: sets b, c, d hold stages 2, 3, 4
-    stg_b = stage_load(a, lane, ld);
+    stg_b = stage_load(a, loff, ld);
     stream_advance(ld, stages, tile_step_rows);
-    stg_c = stage_load(a, lane, ld);
+    stg_c = stage_load(a, loff, ld);
     stream_advance(ld, stages, tile_step_rows);
-    stg_d = stage_load(a, lane, ld);
+    stg_d = stage_load(a, loff, ld);
     stream_advance(ld, stages, tile_step_rows);
     stg_a = stg_d;
   } else {
-    stg_a = stage_load(a, lane, ld);
+    stg_a = stage_load(a, loff, ld);
     stg_b = stg_a;
     stg_c = stg_d = stg_a;
     stream_advance(ld, stages, tile_step_rows);
@@ -337,8 +341,8 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
     /* two-set pipeline).  kMode 1/2: four staging sets; at the VGPR limit the scheduler sinks    */ \
     /* the loads towards their use, so they are pinned at the top of the stage.                   */ \
     const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
-    if constexpr (kAblate < 2) SNEW = stage_load(a, lane, ld);                                    \
-    if constexpr (kAblate == 2) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load(a, lane, hot); } \
+    if constexpr (kAblate < 2) SNEW = stage_load(a, loff, ld);                                    \
+    if constexpr (kAblate == 2) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load(a, loff, hot); } \
     stream_advance(ld, stages, tile_step_rows);                                                   \
     if constexpr (kMode == 1) {                                                                   \
       NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk);                          \
@@ -350,7 +354,24 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
       if constexpr (kAblate < 5) NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk); \
       if constexpr (kAblate < 4) stage_store(lds_x + wbuf * kBufFloats, lane, SOLD);              \
     }                                                                                             \
-    if constexpr (kMode >= 2) {                                                                   \
+    if constexpr (kMode == 7) {                                                                   \
+      /* M V M V M V M V | R R R R | M M M M | R R | M W M W M W M W | R R | M M M M: every       */ \
+      /* fragment of the next stage is requested >= 4 MFMAs before this stage ends                 */ \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                        \
+      }                                                                                           \
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                        \
+      }                                                                                           \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    } else if constexpr (kMode >= 2) {                                                            \
       /* MFMA k followed by: a global load (k < 4), an LDS fragment read (4 <= k < 12), an LDS    */ \
       /* store (k >= 12) */                                                                       \
       _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
@@ -371,6 +392,60 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
     wbuf = wbuf == 2 ? 0u : wbuf + 1;                                                             \
   }
 
+  // kMode 4/5/6: ONE fragment set, refreshed in place -- the operands of class group p are re-read
+  // from LDS for the next stage right after the four MFMAs that consumed them, which frees VGPRs
+  // (kMode 4 spends them on two extra staging sets).  Issue order asked of the scheduler:
+  //   M V M V M V M V | R.. | M M M M | R R | M W M W M W M W | R R | M M M M | (R R)
+  // sched_group_barrier takes ANY MFMA of the region, so a group-3 MFMA may be pulled to the front
+  // of the stage: kMode 6 therefore double-buffers group 3 (F3 = this stage, NF3 = next stage, read
+  // early), so that every operand of a stage is in flight well before the stage begins.
+#define VK_GEMM_STAGE_IP(ZERO, ST, SNEW, SOLD, F3A, F3B, NF3A, NF3B)                              \
+  {                                                                                               \
+    constexpr bool kZeroC = ZERO;                                                                 \
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+    const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
+    const float *xn = lds_x + rbuf * kBufFloats + x_off;                                          \
+    const float *qn = q_row + (nst * 2 + kk) * 16;                                                \
+    SNEW = stage_load(a, loff, ld);                                                               \
+    stream_advance(ld, stages, tile_step_rows);                                                   \
+    VK_MFMA4(0, f0.a0, f0.b0)                                                                     \
+    f0.a0 = *reinterpret_cast<const float4 *>(xn);                                                \
+    f0.b0 = *reinterpret_cast<const float4 *>(qn);                                                \
+    if constexpr (kMode == 6) {                                                                   \
+      NF3A = *reinterpret_cast<const float4 *>(xn + 12);                                          \
+      NF3B = *reinterpret_cast<const float4 *>(qn + 12);                                          \
+    }                                                                                             \
+    VK_MFMA4(1, f0.a1, f0.b1)                                                                     \
+    f0.a1 = *reinterpret_cast<const float4 *>(xn + 4);                                            \
+    f0.b1 = *reinterpret_cast<const float4 *>(qn + 4);                                            \
+    VK_MFMA4(2, f0.a2, f0.b2)                                                                     \
+    stage_store(lds_x + wbuf * kBufFloats, lane, SOLD);                                           \
+    f0.a2 = *reinterpret_cast<const float4 *>(xn + 8);                                            \
+    f0.b2 = *reinterpret_cast<const float4 *>(qn + 8);                                            \
+    VK_MFMA4(3, F3A, F3B)                                                                         \
+    if constexpr (kMode != 6) {                                                                   \
+      F3A = *reinterpret_cast<const float4 *>(xn + 12);                                           \
+      F3B = *reinterpret_cast<const float4 *>(qn + 12);                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                          \
+    }                                                                                             \
+    __builtin_amdgcn_sched_group_barrier(0x100, kMode == 6 ? 4 : 2, 0);                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                            \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                          \
+    }                                                                                             \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                            \
+    if constexpr (kMode != 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    rbuf = rbuf == 2 ? 0u : rbuf + 1;                                                             \
+    wbuf = wbuf == 2 ? 0u : wbuf + 1;                                                             \
+  }
+
   // Lockstep with the other query-tile blocks that stream the same rows (same rp, same wave index,
   // all on this XCD): each wave publishes the tile it has started and does not start tile t before
   // every sharer has started tile t-W.  Without it the sharers drift further apart than the XCD's
@@ -387,7 +462,26 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
     uint32_t bkey = 0xFF800000u;
     if constexpr (!kRegList) bkey = __hip_atomic_load(qbound_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f32x16 acc[16];
-    if constexpr (kDeep) {
+    if constexpr (kInPlace && kDeep) {
+      VK_GEMM_STAGE_IP(true, 0u, stg_a, stg_b, f0.a3, f0.b3, f1.a3, f1.b3)   // accumulators are born from a zero C operand
+      VK_GEMM_STAGE_IP(false, 1u, stg_b, stg_c, f0.a3, f0.b3, f1.a3, f1.b3)
+      VK_GEMM_STAGE_IP(false, 2u, stg_c, stg_d, f0.a3, f0.b3, f1.a3, f1.b3)
+      VK_GEMM_STAGE_IP(false, 3u, stg_d, stg_a, f0.a3, f0.b3, f1.a3, f1.b3)
+      for (uint32_t st = 4; st < stages; st += 4) {
+        VK_GEMM_STAGE_IP(false, st, stg_a, stg_b, f0.a3, f0.b3, f1.a3, f1.b3)
+        VK_GEMM_STAGE_IP(false, st + 1, stg_b, stg_c, f0.a3, f0.b3, f1.a3, f1.b3)
+        VK_GEMM_STAGE_IP(false, st + 2, stg_c, stg_d, f0.a3, f0.b3, f1.a3, f1.b3)
+        VK_GEMM_STAGE_IP(false, st + 3, stg_d, stg_a, f0.a3, f0.b3, f1.a3, f1.b3)
+      }
+    } else if constexpr (kInPlace) {
+      // group 3 ping-pongs between f0.a3/b3 and f1.a3/b3 in kMode 6 (in place in kMode 5)
+      VK_GEMM_STAGE_IP(true, 0u, stg_b, stg_a, f0.a3, f0.b3, f1.a3, f1.b3)
+      VK_GEMM_STAGE_IP(false, 1u, stg_a, stg_b, f1.a3, f1.b3, f0.a3, f0.b3)
+      for (uint32_t st = 2; st < stages; st += 2) {
+        VK_GEMM_STAGE_IP(false, st, stg_b, stg_a, f0.a3, f0.b3, f1.a3, f1.b3)
+        VK_GEMM_STAGE_IP(false, st + 1, stg_a, stg_b, f1.a3, f1.b3, f0.a3, f0.b3)
+      }
+    } else     if constexpr (kDeep) {
       VK_GEMM_STAGE(true, 0u, f0, f1, stg_a, stg_b)    // accumulators are born from a zero C operand
       VK_GEMM_STAGE(false, 1u, f1, f0, stg_b, stg_c)
       VK_GEMM_STAGE(false, 2u, f0, f1, stg_c, stg_d)
@@ -462,6 +556,8 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
     }
   }
 #undef VK_GEMM_STAGE
+#undef VK_GEMM_STAGE_IP
+#undef VK_MFMA4
 }
 
 size_t flat_gemm_lds_bytes(uint32_t row_stride_f) {
@@ -477,17 +573,18 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
   const size_t lds = flat_gemm_lds_bytes(a.row_stride_f);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static const int ablate = getenv("VK_GEMM_ABLATE") ? atoi(getenv("VK_GEMM_ABLATE")) : 0;
-  static const int mode_env = getenv("VK_GEMM_MODE") ? atoi(getenv("VK_GEMM_MODE")) : 0;
-  const int mode = mode_env == 2 && (a.chunks % 8) == 0 ? 2 : 0;
+  // VK_GEMM_MODE=0: the compiler's own placement of the stage's memory operations (A/B switch)
+  static const int mode_env = getenv("VK_GEMM_MODE") ? atoi(getenv("VK_GEMM_MODE")) : 7;
+  const int mode = mode_env == 7 ? 7 : 0;
   static const int reg_env = getenv("VK_GEMM_REGLIST") ? atoi(getenv("VK_GEMM_REGLIST")) : 1;
   const bool reg = reg_env && a.k <= (uint32_t)kRegCap;
-  const void *fn = ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1, 0, false>)
-                 : ablate == 2 ? reinterpret_cast<const void *>(&flat_gemm_kernel<2, 0, false>)
-                 : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3, 0, false>)
-                 : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4, 0, false>)
-                 : ablate == 5 ? reinterpret_cast<const void *>(&flat_gemm_kernel<5, 0, false>)
-                 : mode == 2   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 2, true>)
-                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 2, false>))
+  const void *fn = ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1, 7, false>)
+                 : ablate == 2 ? reinterpret_cast<const void *>(&flat_gemm_kernel<2, 7, false>)
+                 : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3, 7, false>)
+                 : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4, 7, false>)
+                 : ablate == 5 ? reinterpret_cast<const void *>(&flat_gemm_kernel<5, 7, false>)
+                 : mode == 7   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true>)
+                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false>))
                                : (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, true>)
                                       : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, false>));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

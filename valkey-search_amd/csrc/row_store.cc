@@ -94,7 +94,10 @@ Status RowStore::reserve(uint64_t rows) {
   want = std::max<uint64_t>(want, 1024);
   void *nr = nullptr;
   uint64_t *nl = nullptr;
-  VK_HIP_TRY(hipMalloc(&nr, want * row_bytes()));
+  // kRowSlack rows beyond the capacity stay allocated (and zero): the tiled kernels read whole
+  // 128-row tiles and mask the rows past the count afterwards, instead of clamping every address
+  VK_HIP_TRY(hipMalloc(&nr, (want + kRowSlack) * row_bytes()));
+  VK_HIP_TRY(hipMemsetAsync(static_cast<char *>(nr) + want * row_bytes(), 0, kRowSlack * row_bytes(), stream_));
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&nl), want * 8);
   if (e != hipSuccess) {
     (void)hipFree(nr);
