@@ -150,6 +150,20 @@ def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
                     "ids_identical_to_gpu": f"{same}/{n_cpu}", "graph_export_s": round(export_s, 2)}}
 
 
+def pmc_traffic(N, D, B, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE
+    is a separate run by rule, so bench.py cannot collect it live): profiles/r01_pmc_fetch_size_k4.json,
+    valid for the default single-GPU workload only."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_fetch_size_k4.json")
+    if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not os.path.exists(path):
+        return None, None
+    if os.environ.get("VK_FLAT_FORCE_SCAN") or os.environ.get("VK_GEMM_MODE") or os.environ.get("VK_GEMM_ABLATE"):
+        return None, None
+    j = json.load(open(path))
+    key = "lockstep_off" if os.environ.get("VK_GEMM_LOCKSTEP") == "0" else "lockstep_on"
+    return round(j[key]["hbm_bytes_per_launch"]), "profiles/r01_pmc_fetch_size_k4.json (rocprofv3 --pmc FETCH_SIZE, separate pass)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +327,7 @@ def main():
         hnsw = hnsw_leg(args, ix, table, A, device, stream_ptr)
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic(N, D, B, world)
         qps = B * args.steps / dt
         scan_bytes = n_local * stride                       # algorithmic bytes of one pass over the shard
         flops = 2.0 * n_local * D * B                       # per step per GPU
@@ -328,7 +343,9 @@ def main():
             # algorithmic FLOPs per launch = 2 * rows * D * B against the 157.3 TFLOP/s f32 MFMA peak
             "roofline": ({"bound": "mfma", "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 3),
                           "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                          "frac": round(flops / (dev_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 5), "traffic": None,
+                          "frac": round(flops / (dev_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 5), "traffic": traffic,
+                          "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                          "algorithmic_bytes": scan_bytes,
                           "kernel": "flat_gemm_kernel", "per_launch_ms": round(dev_ms, 4),
                           "hbm_gbs_algorithmic": round(scan_bytes / (dev_ms * 1e-3) / 1e9, 2)}
                          if B >= 16 and not os.environ.get("VK_FLAT_FORCE_SCAN") else

@@ -8,13 +8,15 @@ library is missing, or there is no gfx950 device, calls fail loudly.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libvkindex.so"
+# VKINDEX_LIB: load another build of the same ABI (A/B timing of kernel variants on one GPU box)
+LIB_PATH = Path(os.environ["VKINDEX_LIB"]) if os.environ.get("VKINDEX_LIB") else PKG_DIR / "libvkindex.so"
 HOST_LIB_PATH = PKG_DIR / "libvkhost.so"
 
 VK_OK, VK_ERR_INVALID, VK_ERR_CAPACITY, VK_ERR_NOT_FOUND, VK_ERR_INTERNAL, VK_ERR_CANCELLED, VK_ERR_NO_DEVICE = range(7)

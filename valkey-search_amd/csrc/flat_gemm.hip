@@ -354,7 +354,24 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
       if constexpr (kAblate < 5) NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk); \
       if constexpr (kAblate < 4) stage_store(lds_x + wbuf * kBufFloats, lane, SOLD);              \
     }                                                                                             \
-    if constexpr (kMode == 7) {                                                                   \
+    if constexpr (kMode == 8) {                                                                   \
+      /* as 7, but the LDS stores go last (M V x4 | R R R R | M x4 | R R | M x4 | R R | M W x4):   */ \
+      /* the staged loads get 2.0 instead of 1.6 stages to arrive                                  */ \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                        \
+      }                                                                                           \
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                        \
+      }                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+    } else if constexpr (kMode == 7) {                                                            \
       /* M V M V M V M V | R R R R | M M M M | R R | M W M W M W M W | R R | M M M M: every       */ \
       /* fragment of the next stage is requested >= 4 MFMAs before this stage ends                 */ \
       _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
@@ -575,7 +592,7 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
   static const int ablate = getenv("VK_GEMM_ABLATE") ? atoi(getenv("VK_GEMM_ABLATE")) : 0;
   // VK_GEMM_MODE=0: the compiler's own placement of the stage's memory operations (A/B switch)
   static const int mode_env = getenv("VK_GEMM_MODE") ? atoi(getenv("VK_GEMM_MODE")) : 7;
-  const int mode = mode_env == 7 ? 7 : 0;
+  const int mode = mode_env == 7 || mode_env == 8 ? mode_env : 0;
   static const int reg_env = getenv("VK_GEMM_REGLIST") ? atoi(getenv("VK_GEMM_REGLIST")) : 1;
   const bool reg = reg_env && a.k <= (uint32_t)kRegCap;
   const void *fn = ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1, 7, false>)
@@ -583,6 +600,8 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
                  : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3, 7, false>)
                  : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4, 7, false>)
                  : ablate == 5 ? reinterpret_cast<const void *>(&flat_gemm_kernel<5, 7, false>)
+                 : mode == 8   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 8, true>)
+                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 8, false>))
                  : mode == 7   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true>)
                                       : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false>))
                                : (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, true>)

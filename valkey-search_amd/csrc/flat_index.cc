@@ -569,7 +569,7 @@ class FlatIndex final : public Index {
   std::unique_ptr<SearchCtx> dev_ctx_;
   std::shared_mutex rw_;
   // K4 lockstep window in row tiles (see FlatGemmArgs::lockstep); VK_GEMM_LOCKSTEP=0 turns it off
-  uint32_t gemm_lockstep_ = getenv("VK_GEMM_LOCKSTEP") ? (uint32_t)atoi(getenv("VK_GEMM_LOCKSTEP")) : 0;
+  uint32_t gemm_lockstep_ = getenv("VK_GEMM_LOCKSTEP") ? (uint32_t)atoi(getenv("VK_GEMM_LOCKSTEP")) : 1;
   uint32_t gemm_contig_ = getenv("VK_GEMM_CONTIG") ? (uint32_t)atoi(getenv("VK_GEMM_CONTIG")) : 1;
   bool force_scan_ = getenv("VK_FLAT_FORCE_SCAN") != nullptr;   // A/B switch for benchmarks: VALU scan for every batch size
   std::unordered_map<uint64_t, uint32_t> slot_of_;  // dict_external_to_internal
