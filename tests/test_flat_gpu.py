@@ -291,3 +291,18 @@ def test_large_k_pages_through_ties_and_filter(vsa, oracle):
     for i in range(3):
         od, ol = o.search(_data(3, 32, 53)[i], 1500)
         _assert_same(D[i, :N[i]], L[i, :N[i]], od, ol)
+
+
+def test_baseline_config1_shape(vsa, oracle):
+    """BASELINE.json configs[0]: FLAT 100k x 128 f32 L2 k=10, one query per call -- ids and distance
+    bits of every answer against the oracle (the reference's own CPU-runnable case)."""
+    n, dim, k = 100_000, 128, 10
+    x = _data(n, dim, 1234)
+    g, o = _both(vsa, oracle, x, "L2")
+    Q = _data(64, dim, 1235)
+    for q in Q:
+        _assert_same(*g.search(q, k), *o.search(q, k))
+    # the same queries as one batch
+    D, L, Nn = g.search_batch(Q, k)
+    for i, q in enumerate(Q):
+        _assert_same(D[i, :Nn[i]], L[i, :Nn[i]], *o.search(q, k))
