@@ -46,6 +46,10 @@ def device_view(ptr, shape, device):
     return torch.as_tensor(_DevMem(ptr, shape), device=device)
 
 
+def device_view_typed(ptr, shape, device, typestr):
+    return torch.as_tensor(_DevMem(ptr, shape, typestr), device=device)
+
+
 def effective_cpus() -> int:
     """CPUs this process may really use: affinity capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -155,7 +159,7 @@ def pmc_traffic(N, D, B, world):
     is a separate run by rule, so bench.py cannot collect it live): profiles/r01_pmc_fetch_size_k4.json,
     valid for the default single-GPU workload only."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_fetch_size_k4.json")
-    if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not os.path.exists(path):
+    if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not os.path.exists(path) or "bf16" in sys.argv:
         return None, None
     if os.environ.get("VK_FLAT_FORCE_SCAN") or os.environ.get("VK_GEMM_MODE") or os.environ.get("VK_GEMM_ABLATE"):
         return None, None
@@ -173,6 +177,8 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="row storage (bf16 = BASELINE.json configs[3] storage; queries and arithmetic stay f32)")
     ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--cpu-queries-per-thread", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -200,14 +206,19 @@ def main():
 
     # ---- build the shard: rows generated straight into the index's HBM row table ----
     t_build = time.time()
-    ix = vsa.Index("FLAT", D, "COSINE", initial_cap=n_local, device_id=local_rank)
+    bf16 = args.dtype == "bf16"
+    esz = 2 if bf16 else 4
+    ix = vsa.Index("FLAT", D, "COSINE", initial_cap=n_local, device_id=local_rank, dtype=args.dtype)
     base_ptr, stride = ix.device_rows(n_local)
-    assert stride == ((D + 63) // 64) * 64 * 4   # rows are zero padded to 256-B multiples
-    table = device_view(base_ptr, (n_local, stride // 4), device)   # [rows][padded dim] f32 in HBM
-    if stride != D * 4:
+    assert stride == ((D + 63) // 64) * 64 * esz   # rows are zero padded to whole 64-element groups
+    if bf16:   # torch cannot import bf16 through __cuda_array_interface__: map as int16 and reinterpret
+        table = device_view_typed(base_ptr, (n_local, stride // 2), device, "<i2").view(torch.bfloat16)
+    else:
+        table = device_view(base_ptr, (n_local, stride // 4), device)   # [rows][padded dim] in HBM
+    if stride != D * esz:
         table[:, D:] = 0
     for lo, x in gen_rows(r0, n_local, D, device):
-        table[lo - r0: lo - r0 + x.shape[0], :D] = x
+        table[lo - r0: lo - r0 + x.shape[0], :D] = x     # bf16: round to nearest even, as the library's ingest does
     torch.cuda.synchronize()
     ix.commit_device_rows(n_local, np.arange(r0, r1, dtype=np.uint64))
     t_build = time.time() - t_build
@@ -295,7 +306,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as O
         S = min(args.cpu_rows, n_local)
-        host_rows = np.ascontiguousarray(table[:S, :D].cpu().numpy())
+        host_rows = np.ascontiguousarray(table[:S, :D].float().cpu().numpy())   # bf16: the widened stored values
         flat = O.Flat(D, "COSINE", isa="skylake", max_elements=S)
         flat.add_many(host_rows, np.arange(r0, r0 + S, dtype=np.uint64), borrowed=True)
         hq = Q.cpu().numpy()
@@ -319,11 +330,17 @@ def main():
             gd, gl = ix.search(hq[i], K, allow=bits, allow_nbits=r0 + S)
             od, ol = res[i] if i < len(res) else flat.search(hq[i], K)
             ok = ok and gl.tolist() == ol.tolist() and gd.view(np.uint32).tolist() == od.view(np.uint32).tolist()
+        # ... and the same through the timed path (batched: K4 on the matrix cores)
+        nb = min(B, 32)
+        bd, bl, bn = ix.search_batch(hq[:nb], K, allow=bits, allow_nbits=r0 + S)
+        for i in range(nb):
+            od, ol = res[i] if i < len(res) else flat.search(hq[i], K)
+            ok = ok and bl[i, :bn[i]].tolist() == ol.tolist() and bd[i, :bn[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist()
         parity = "bit-exact" if ok else "MISMATCH"
 
     # ---- extra: HNSW (BASELINE.json configs[2] shape: M=16 efC=200, cosine, ef=128, k=10) on rank 0 ----
     hnsw = None
-    if rank == 0 and world == 1 and args.hnsw_rows > 0:
+    if rank == 0 and world == 1 and args.hnsw_rows > 0 and not bf16:
         hnsw = hnsw_leg(args, ix, table, A, device, stream_ptr)
 
     if rank == 0:
@@ -332,11 +349,14 @@ def main():
         scan_bytes = n_local * stride                       # algorithmic bytes of one pass over the shard
         flops = 2.0 * n_local * D * B                       # per step per GPU
         out = {
-            "metric": "kNN queries/sec, FLAT 10Mx768 fp32 cosine k=10 batch=256",
+            "metric": "kNN queries/sec, FLAT 10Mx768 fp32 cosine k=10 batch=256" if not bf16 else
+                      "kNN queries/sec, FLAT 10Mx768 bf16-stored cosine k=10 batch=256",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"FLAT {N}x{D} fp32 COSINE k={K} batch={B} (BASELINE.json configs[1])",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "row_storage": args.dtype, "data": "synthetic",
+            "config": {"workload": (f"FLAT {N}x{D} fp32 COSINE k={K} batch={B} (BASELINE.json configs[1])" if not bf16 else
+                                    f"FLAT {N}x{D} bf16 rows, f32 queries/arithmetic, COSINE k={K} batch={B} "
+                                    f"(per-GPU shard of BASELINE.json configs[3])"),
                        "rows_per_gpu": n_local, "sharding": f"rows/{world}", "recall_at_10": 1.0,
                        "parity_vs_oracle": parity},
             # B >= 16 in the inner-product space runs on the f32 matrix cores (flat_gemm_kernel, K4):

@@ -61,3 +61,20 @@ def test_hnsw_bf16_equals_f32_on_rounded_rows(vsa, oracle):
     Q = rng.standard_normal((8, dim)).astype(np.float32)
     for q in Q:
         _same(*g.search(q, 10, ef=64), *o.search(q, 10, ef=64))
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 64, 10), (6000, 768, 32, 10), (3000, 100, 40, 30)])
+def test_flat_bf16_batched_mfma_path(vsa, oracle, n, dim, nq, k):
+    """>= 16 queries in the inner-product space over bf16 rows: K4 widens the rows on their way into LDS;
+    the answer must equal the f32 oracle over the rounded rows, ids and distance bits."""
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g = vsa.Index("FLAT", dim, "IP", initial_cap=n, dtype="bf16")
+    g.add_batch(x)
+    o = oracle.Flat(dim, "IP", max_elements=n)
+    o.add_many(bf16_round(x))
+    Q = rng.standard_normal((nq, dim)).astype(np.float32)
+    D, L, N = g.search_batch(Q, k)
+    for i in range(nq):
+        od, ol = o.search(Q[i], k)
+        _same(D[i, :N[i]], L[i, :N[i]], od, ol)

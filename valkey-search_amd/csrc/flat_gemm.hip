@@ -158,28 +158,69 @@ struct Frag { float4 a0, a1, a2, a3, b0, b1, b2, b3; };
 // changes (LaneOff, computed once), so a stage issues its four loads without any vector address
 // arithmetic.  No clamping: the row store keeps RowStore::kRowSlack readable rows past its capacity,
 // rows past n_rows are masked in the epilogue.  p.tile_row0 already includes the wave's row offset.
-struct LaneOff { uint32_t o0, o1, o2, o3; };   // in floats
-__device__ __forceinline__ LaneOff lane_offsets(uint32_t lane, uint32_t row_stride_f) {
-  const uint32_t o = (lane >> 3) * row_stride_f + (lane & 7) * 4;
-  return LaneOff{o, o + 8 * row_stride_f, o + 16 * row_stride_f, o + 24 * row_stride_f};
+struct LaneOff { uint32_t o0, o1, o2, o3; };   // in elements
+// bf16 rows (kBf16): a stage of a row is 32 elements = 64 B, so the wave's 32 x 64 B are 128 16-B
+// pieces, 2 per lane: idx = lane + 64*u -> row idx/4, piece idx%4 (8 elements each); they are widened
+// to f32 (<< 16, exact) on the way into LDS, so everything behind the staging ring is the f32 kernel.
+template <bool kBf16>
+__device__ __forceinline__ LaneOff lane_offsets(uint32_t lane, uint32_t row_stride_e) {
+  if constexpr (kBf16) {
+    const uint32_t o = (lane >> 2) * row_stride_e + (lane & 3) * 8;
+    return LaneOff{o, o + 16 * row_stride_e, 0, 0};
+  } else {
+    const uint32_t o = (lane >> 3) * row_stride_e + (lane & 7) * 4;
+    return LaneOff{o, o + 8 * row_stride_e, o + 16 * row_stride_e, o + 24 * row_stride_e};
+  }
 }
+template <bool kBf16>
 __device__ __forceinline__ Stg stage_load(const FlatGemmArgs &a, const LaneOff lo, const StreamPos &p) {
-  // chunk = st*2 + c4/4, 16-B piece c4%4 of it == float offset st*32 + c4*4 (rows are zero padded
-  // to whole stages, so there is no tail)
-  const float *base = a.rows + (size_t)p.tile_row0 * a.row_stride_f + p.st * 32;
   Stg s;
-  s.v0 = *reinterpret_cast<const float4 *>(base + lo.o0);
-  s.v1 = *reinterpret_cast<const float4 *>(base + lo.o1);
-  s.v2 = *reinterpret_cast<const float4 *>(base + lo.o2);
-  s.v3 = *reinterpret_cast<const float4 *>(base + lo.o3);
+  if constexpr (kBf16) {
+    const uint16_t *base = static_cast<const uint16_t *>(a.rows) + (size_t)p.tile_row0 * a.row_stride_f + p.st * 32;
+    s.v0 = *reinterpret_cast<const float4 *>(base + lo.o0);
+    s.v1 = *reinterpret_cast<const float4 *>(base + lo.o1);
+    s.v2 = s.v0;
+    s.v3 = s.v0;
+  } else {
+    // chunk = st*2 + c4/4, 16-B piece c4%4 of it == float offset st*32 + c4*4 (rows are zero padded
+    // to whole stages, so there is no tail)
+    const float *base = static_cast<const float *>(a.rows) + (size_t)p.tile_row0 * a.row_stride_f + p.st * 32;
+    s.v0 = *reinterpret_cast<const float4 *>(base + lo.o0);
+    s.v1 = *reinterpret_cast<const float4 *>(base + lo.o1);
+    s.v2 = *reinterpret_cast<const float4 *>(base + lo.o2);
+    s.v3 = *reinterpret_cast<const float4 *>(base + lo.o3);
+  }
   return s;
 }
 
+// eight bf16 (one 16-B piece) -> two float4
+__device__ __forceinline__ void widen8(const float4 raw, float4 &lo, float4 &hi) {
+  const uint32_t w0 = __float_as_uint(raw.x), w1 = __float_as_uint(raw.y), w2 = __float_as_uint(raw.z),
+                 w3 = __float_as_uint(raw.w);
+  lo = float4{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16),
+              __uint_as_float(w1 & 0xffff0000u)};
+  hi = float4{__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u), __uint_as_float(w3 << 16),
+              __uint_as_float(w3 & 0xffff0000u)};
+}
+
+template <bool kBf16>
 __device__ __forceinline__ void stage_store(float *buf, uint32_t lane, const Stg s) {
-  *reinterpret_cast<float4 *>(buf + ((lane) >> 3) * kXStride + ((lane) & 7) * 4) = s.v0;
-  *reinterpret_cast<float4 *>(buf + ((lane + 64) >> 3) * kXStride + ((lane + 64) & 7) * 4) = s.v1;
-  *reinterpret_cast<float4 *>(buf + ((lane + 128) >> 3) * kXStride + ((lane + 128) & 7) * 4) = s.v2;
-  *reinterpret_cast<float4 *>(buf + ((lane + 192) >> 3) * kXStride + ((lane + 192) & 7) * 4) = s.v3;
+  if constexpr (kBf16) {
+    float4 a0, a1, b0, b1;
+    widen8(s.v0, a0, a1);
+    widen8(s.v1, b0, b1);
+    float *p0 = buf + (lane >> 2) * kXStride + (lane & 3) * 8;
+    float *p1 = p0 + 16 * kXStride;
+    *reinterpret_cast<float4 *>(p0) = a0;
+    *reinterpret_cast<float4 *>(p0 + 4) = a1;
+    *reinterpret_cast<float4 *>(p1) = b0;
+    *reinterpret_cast<float4 *>(p1 + 4) = b1;
+  } else {
+    *reinterpret_cast<float4 *>(buf + ((lane) >> 3) * kXStride + ((lane) & 7) * 4) = s.v0;
+    *reinterpret_cast<float4 *>(buf + ((lane + 64) >> 3) * kXStride + ((lane + 64) & 7) * 4) = s.v1;
+    *reinterpret_cast<float4 *>(buf + ((lane + 128) >> 3) * kXStride + ((lane + 128) & 7) * 4) = s.v2;
+    *reinterpret_cast<float4 *>(buf + ((lane + 192) >> 3) * kXStride + ((lane + 192) & 7) * 4) = s.v3;
+  }
 }
 
 // LDS -> registers: this lane's A (row) and B (query) operands of one stage, 4 class groups each
@@ -219,7 +260,7 @@ __device__ __forceinline__ void stage_mfma(f32x16 (&acc)[16], const Frag f) {
 // kMode: 0 = two register staging sets (HBM loads in flight for ~2 stages); 1, 2 = four sets (~4
 // stages; needs stages % 4 == 0, i.e. a row stride that is a multiple of 128 floats) with two ways
 // of placing the loads; 3 = two sets with the hand placement of 2
-template <int kAblate, int kMode, bool kRegList>
+template <int kAblate, int kMode, bool kRegList, bool kBf16>
 __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   constexpr bool kDeep = kMode == 1 || kMode == 2 || kMode == 4;
   constexpr bool kInPlace = kMode >= 4 && kMode <= 6;
@@ -294,28 +335,28 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
   // last held stage i-1, whose fragments were fetched during i-2.  One barrier per iteration.
   // The loop is unrolled by two with ping-pong register sets (no register rotation: a move of
   // a register that is the target of an in-flight load would wait for the load).
-  const LaneOff loff = lane_offsets(lane, a.row_stride_f);
+  const LaneOff loff = lane_offsets<kBf16>(lane, a.row_stride_f);
   StreamPos ld{first_tile * kTileRows + wave * 32, 0, total};   // next stage to fetch from HBM (this wave's rows)
   Stg stg_a, stg_b, stg_c, stg_d;
   // prologue: stages 0 and 1 straight to LDS, the next one (kDeep: three) left in registers.  A
   // stream has at least two stages; loads past its end re-read the last stage and are unused.
-  stg_a = stage_load(a, loff, ld);
-  stage_store(lds_x, lane, stg_a);
+  stg_a = stage_load<kBf16>(a, loff, ld);
+  stage_store<kBf16>(lds_x, lane, stg_a);
   stream_advance(ld, stages, tile_step_rows);
-  stg_a = stage_load(a, loff, ld);
-  stage_store(lds_x + kBufFloats, lane, stg_a);
+  stg_a = stage_load<kBf16>(a, loff, ld);
+  stage_store<kBf16>(lds_x + kBufFloats, lane, stg_a);
   stream_advance(ld, stages, tile_step_rows);
   if constexpr (kDeep) {
     // iteration i loads into set i%4 and stores set (i+1)%4: sets b, c, d hold stages 2, 3, 4
-    stg_b = stage_load(a, loff, ld);
+    stg_b = stage_load<kBf16>(a, loff, ld);
     stream_advance(ld, stages, tile_step_rows);
-    stg_c = stage_load(a, loff, ld);
+    stg_c = stage_load<kBf16>(a, loff, ld);
     stream_advance(ld, stages, tile_step_rows);
-    stg_d = stage_load(a, loff, ld);
+    stg_d = stage_load<kBf16>(a, loff, ld);
     stream_advance(ld, stages, tile_step_rows);
     stg_a = stg_d;
   } else {
-    stg_a = stage_load(a, loff, ld);
+    stg_a = stage_load<kBf16>(a, loff, ld);
     stg_b = stg_a;
     stg_c = stg_d = stg_a;
     stream_advance(ld, stages, tile_step_rows);
@@ -341,18 +382,18 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
     /* two-set pipeline).  kMode 1/2: four staging sets; at the VGPR limit the scheduler sinks    */ \
     /* the loads towards their use, so they are pinned at the top of the stage.                   */ \
     const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
-    if constexpr (kAblate < 2) SNEW = stage_load(a, loff, ld);                                    \
-    if constexpr (kAblate == 2) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load(a, loff, hot); } \
+    if constexpr (kAblate < 2) SNEW = stage_load<kBf16>(a, loff, ld);                                    \
+    if constexpr (kAblate == 2) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load<kBf16>(a, loff, hot); } \
     stream_advance(ld, stages, tile_step_rows);                                                   \
     if constexpr (kMode == 1) {                                                                   \
       NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk);                          \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       stage_mfma<ZERO>(acc, F);                                                                   \
-      stage_store(lds_x + wbuf * kBufFloats, lane, SOLD);                                         \
+      stage_store<kBf16>(lds_x + wbuf * kBufFloats, lane, SOLD);                                         \
     } else {                                                                                      \
       stage_mfma<ZERO>(acc, F);                                                                   \
       if constexpr (kAblate < 5) NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk); \
-      if constexpr (kAblate < 4) stage_store(lds_x + wbuf * kBufFloats, lane, SOLD);              \
+      if constexpr (kAblate < 4) stage_store<kBf16>(lds_x + wbuf * kBufFloats, lane, SOLD);              \
     }                                                                                             \
     if constexpr (kMode == 8) {                                                                   \
       /* as 7, but the LDS stores go last (M V x4 | R R R R | M x4 | R R | M x4 | R R | M W x4):   */ \
@@ -423,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
     const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
     const float *xn = lds_x + rbuf * kBufFloats + x_off;                                          \
     const float *qn = q_row + (nst * 2 + kk) * 16;                                                \
-    SNEW = stage_load(a, loff, ld);                                                               \
+    SNEW = stage_load<kBf16>(a, loff, ld);                                                               \
     stream_advance(ld, stages, tile_step_rows);                                                   \
     VK_MFMA4(0, f0.a0, f0.b0)                                                                     \
     f0.a0 = *reinterpret_cast<const float4 *>(xn);                                                \
@@ -436,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
     f0.a1 = *reinterpret_cast<const float4 *>(xn + 4);                                            \
     f0.b1 = *reinterpret_cast<const float4 *>(qn + 4);                                            \
     VK_MFMA4(2, f0.a2, f0.b2)                                                                     \
-    stage_store(lds_x + wbuf * kBufFloats, lane, SOLD);                                           \
+    stage_store<kBf16>(lds_x + wbuf * kBufFloats, lane, SOLD);                                           \
     f0.a2 = *reinterpret_cast<const float4 *>(xn + 8);                                            \
     f0.b2 = *reinterpret_cast<const float4 *>(qn + 8);                                            \
     VK_MFMA4(3, F3A, F3B)                                                                         \
@@ -595,17 +636,19 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
   const int mode = mode_env == 7 || mode_env == 8 ? mode_env : 0;
   static const int reg_env = getenv("VK_GEMM_REGLIST") ? atoi(getenv("VK_GEMM_REGLIST")) : 1;
   const bool reg = reg_env && a.k <= (uint32_t)kRegCap;
-  const void *fn = ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1, 7, false>)
-                 : ablate == 2 ? reinterpret_cast<const void *>(&flat_gemm_kernel<2, 7, false>)
-                 : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3, 7, false>)
-                 : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4, 7, false>)
-                 : ablate == 5 ? reinterpret_cast<const void *>(&flat_gemm_kernel<5, 7, false>)
-                 : mode == 8   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 8, true>)
-                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 8, false>))
-                 : mode == 7   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true>)
-                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false>))
-                               : (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, true>)
-                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, false>));
+  const void *fn = ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1, 7, false, false>)
+                 : ablate == 2 ? reinterpret_cast<const void *>(&flat_gemm_kernel<2, 7, false, false>)
+                 : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3, 7, false, false>)
+                 : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4, 7, false, false>)
+                 : ablate == 5 ? reinterpret_cast<const void *>(&flat_gemm_kernel<5, 7, false, false>)
+                 : mode == 8   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 8, true, false>)
+                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 8, false, false>))
+                 : a.bf16      ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true, true>)
+                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false, true>))
+                 : mode == 7   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true, false>)
+                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false, false>))
+                               : (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, true, false>)
+                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, false, false>));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   FlatGemmArgs args = a;

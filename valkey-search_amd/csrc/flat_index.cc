@@ -397,7 +397,7 @@ class FlatIndex final : public Index {
     if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 needs the host entry points (vk_index_search / _batch), which page through the result in passes");
     const uint32_t chunks = store_.stride_f() / 16;
     // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
-    if (!l2() && !store_.bf16() && !lb_dist_ && nq >= kGemmMinQueries && !cancel && flat_gemm_supported(store_.stride_f(), k) && !force_scan_)
+    if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !cancel && flat_gemm_supported(store_.stride_f(), k) && !force_scan_)
       return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     const int qb = flat_scan_pick_qb(nq, chunks, e);
@@ -514,7 +514,8 @@ class FlatIndex final : public Index {
   Status scan_gemm(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
                    uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s) {
     FlatGemmArgs g{};
-    g.rows = static_cast<const float *>(store_.d_rows());
+    g.rows = store_.d_rows();
+    g.bf16 = store_.bf16() ? 1 : 0;
     g.labels = store_.d_labels();
     g.queries = d_q;
     g.allow_bits = d_allow;

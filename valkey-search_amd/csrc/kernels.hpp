@@ -26,7 +26,8 @@ struct FlatScanArgs {
 
 // K4: batched FLAT (inner-product space) on the matrix cores, fused per-lane top-k
 struct FlatGemmArgs {
-  const float *rows;
+  const void *rows;           // f32 or (bf16 = 1) bf16 rows, row_stride_f ELEMENTS apart
+  uint32_t bf16;
   const uint64_t *labels;
   const float *queries;       // [nq][q_stride_f] padded
   const uint64_t *allow_bits;
