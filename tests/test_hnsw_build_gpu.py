@@ -1,0 +1,113 @@
+"""K9 -- device-assisted HNSW construction (hnsw_build.hip): add_batch of >= 4096 new points links
+level 0 on the GPU.  The graph is not the sequential hnswlib graph (no multi-threaded build is), so
+what is pinned is what the reference pins for its own builds (vector_test.cc:461-500): recall, plus
+the structural invariants LoadIndex validates, plus host/device consistency of the mirror."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vsa():
+    import _pkg
+    return _pkg.vsa
+
+
+def latent(n, dim, seed, rank=16):
+    rng = np.random.default_rng(1000)
+    A = rng.standard_normal((dim, rank)).astype(np.float32)
+    r = np.random.default_rng(seed)
+    x = r.standard_normal((n, rank)).astype(np.float32) @ A.T + 0.05 * r.standard_normal((n, dim)).astype(np.float32)
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+def build(vsa, x, device, metric="IP", M=16, efc=100, cap=None):
+    old = os.environ.get("VK_HNSW_DEVICE_BUILD")
+    os.environ["VK_HNSW_DEVICE_BUILD"] = "1" if device else "0"
+    try:
+        g = vsa.Index("HNSW", x.shape[1], metric, initial_cap=cap or len(x), m=M, ef_construction=efc, ef_runtime=64)
+        g.add_batch(x)
+    finally:
+        if old is None:
+            os.environ.pop("VK_HNSW_DEVICE_BUILD", None)
+        else:
+            os.environ["VK_HNSW_DEVICE_BUILD"] = old
+    return g
+
+
+def recall(g, flat, Q, k=10, ef=64):
+    D, L, N = g.search_batch(Q, k, ef=ef)
+    Dt, Lt, Nt = flat.search_batch(Q, k)
+    return float(np.mean([len(set(L[i, :N[i]].tolist()) & set(Lt[i].tolist())) / k for i in range(len(Q))]))
+
+
+@pytest.mark.parametrize("metric", ["IP", "L2"])
+def test_device_build_recall_and_invariants(vsa, oracle, metric):
+    n, dim = 30000, 64
+    x = latent(n, dim, 1)
+    Q = latent(400, dim, 2)
+    flat = vsa.Index("FLAT", dim, metric, initial_cap=n)
+    flat.add_batch(x)
+    gd = build(vsa, x, True, metric)
+    gh = build(vsa, x, False, metric)
+    assert gd.stats().count == n and gd.stats().max_level >= 2
+    rd, rh = recall(gd, flat, Q), recall(gh, flat, Q)
+    assert rd >= rh - 0.02, (rd, rh)           # no worse than the host (hnswlib-order) build
+    assert rd >= 0.9, rd
+    # every structural rule LoadIndex checks (counts, id ranges, levels, entry point) holds, and the
+    # host mirror the chunks are written from equals the device graph: the CPU oracle walking the saved
+    # graph must give the device's answers
+    chunks = gd.save()
+    g2 = vsa.Index.load(chunks, "HNSW", dim, metric, initial_cap=n, m=16, ef_construction=100)
+    assert g2.stats().count == n
+    o = oracle.HNSW.from_saved_chunks(chunks, dim, metric, 16, ef_construction=100)
+    for q in Q[:25]:
+        d0, l0 = gd.search(q, 10, ef=64)
+        d1, l1 = o.search(q, 10, ef=64)
+        assert l0.tolist() == l1.tolist() and d0.view(np.uint32).tolist() == d1.view(np.uint32).tolist()
+    # level-0 degree: nobody above 2M, almost nobody isolated
+    M0 = 32
+    deg = np.array([int(np.frombuffer(c[:4], np.uint32)[0] & 0xFFFF) for c in chunks[1:1 + n]])
+    assert deg.max() <= M0 and (deg == 0).sum() == 0 and deg.mean() > 8
+
+
+def test_self_retrieval_and_mutations_after_device_build(vsa):
+    n, dim = 12000, 48
+    x = latent(n, dim, 3)
+    g = build(vsa, x, True, "L2", cap=n + 8000)
+    D, L, N = g.search_batch(x[:500], 1, ef=64)
+    assert (L[:, 0] == np.arange(500)).mean() >= 0.99         # TestIndex-style self retrieval
+    # the index keeps working through the ordinary (host) mutation path afterwards
+    y = latent(50, dim, 4)
+    for i in range(50):
+        assert g.add(n + i, y[i]) == 0
+    for i in range(0, 100, 2):
+        assert g.remove(i) == 0
+    st = g.stats()
+    assert st.count == n + 50 and st.deleted == 50
+    d, l = g.search(y[7], 1, ef=64)
+    assert l[0] == n + 7 and d[0] <= 1e-5
+    d, l = g.search(x[0], 5, ef=64)
+    assert 0 not in l.tolist()
+    # a second bulk batch on top of a graph that already has tombstones
+    z = latent(6000, dim, 5)
+    g.add_batch(z, np.arange(100000, 106000, dtype=np.uint64))
+    D, L, N = g.search_batch(z[:200], 1, ef=64)
+    assert (L[:, 0] == np.arange(100000, 100200)).mean() >= 0.98
+
+
+def test_small_batches_take_the_host_path_unchanged(vsa, oracle):
+    """Below the batch threshold nothing changes: a single-threaded build still equals the oracle's."""
+    n, dim = 1500, 32
+    x = latent(n, dim, 6)
+    g = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=8, ef_construction=60, build_threads=1)
+    g.add_batch(x)
+    o = oracle.HNSW(dim, "L2", max_elements=n, M=8, ef_construction=60)
+    o.add_many(x)
+    for q in latent(20, dim, 7):
+        d0, l0 = g.search(q, 10, ef=50)
+        d1, l1 = o.search(q, 10, ef=50)
+        assert l0.tolist() == l1.tolist()

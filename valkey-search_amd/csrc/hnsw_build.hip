@@ -1,0 +1,203 @@
+// hnsw_build.hip -- K9: the level-0 part of HierarchicalNSW::addPoint for a BATCH of new points on
+// the device (third_party/hnswlib/hnswalg.h:1523-1650), i.e. the steps that dominate graph
+// construction: the efConstruction beam search (searchBaseLayer :255-347 -- served by
+// hnsw_search_kernel with k = ef = efConstruction), the neighbour-selection heuristic
+// (getNeighborsByHeuristic2 :553-594) and the reverse links with re-pruning of full lists
+// (mutuallyConnectNewElement :613-756).
+//
+// Batch semantics: the points of one batch search the graph as it was before the batch (they do
+// not see one another), like concurrent addPoint calls that started at the same moment; a node that
+// several new points selected gets ONE re-prune over its old list plus all of them.  The host keeps
+// batches small relative to the graph (hnsw_index.cc).  The graph therefore differs from a
+// sequential build the same way any multi-threaded hnswlib build does -- recall, not ids, is what
+// is pinned (tests/test_hnsw_build_gpu.py).  Upper levels (1/M of the points) stay on the host.
+//
+// Both kernels: one wave per node, distances 16 rows at a time (one row per quad of lanes) against a
+// "query" row staged in LDS, the same lane-exact f32 arithmetic as everywhere else.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+namespace vk {
+
+namespace {
+constexpr uint32_t kFlagMask = 0xFFFF0000u;
+
+// stage row `id` as the wave's LDS query
+__device__ __forceinline__ void stage_query(const HnswBuildArgs &a, float4 *qs, uint32_t id, int lane) {
+  const float4 *src = reinterpret_cast<const float4 *>(a.rows + (size_t)id * a.row_stride_f);
+  for (uint32_t i = lane; i < a.chunks * 4; i += kWave) qs[i] = src[i];
+}
+
+// getNeighborsByHeuristic2's inner test for one candidate c (already staged in qs): is any kept
+// node closer to c than c is to the base point?  kept ids live in LDS.
+template <bool kL2>
+__device__ __forceinline__ bool dominated(const HnswBuildArgs &a, const float4 *qs, const uint32_t *kept, uint32_t nkept,
+                                          float dist_to_base, int lane) {
+  const int j = lane & 3, rq = lane >> 2;
+  for (uint32_t base = 0; base < nkept; base += kRowsPerWave) {
+    const uint32_t i = base + rq;
+    const bool valid = i < nkept;
+    const uint32_t sid = kept[valid ? i : 0];
+    const float d = quad_row_distance<kL2, false>(reinterpret_cast<const char *>(a.rows + (size_t)sid * a.row_stride_f), qs,
+                                                  a.chunks, j);
+    if (__ballot(valid && d < dist_to_base) != 0) return true;     // hnswalg.h:583-586
+  }
+  return false;
+}
+}  // namespace
+
+// ---- selection for the new points --------------------------------------------------------------
+// in : cand_id/cand_dist [n_new][ld] ascending by distance (hnsw_search_kernel, ids as u64), cand_n
+// out: links0[first_id + p] = the selected neighbours; sel_* = the same, for the reverse links
+template <bool kL2>
+__global__ __launch_bounds__(256) void hnsw_select_kernel(HnswBuildArgs a) {
+  extern __shared__ float4 lds4[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t per_wave_f4 = (size_t)a.chunks * 4 + (a.max_keep + 3) / 4;
+  float4 *qs = lds4 + wave * per_wave_f4;
+  uint32_t *kept = reinterpret_cast<uint32_t *>(qs + a.chunks * 4);
+
+  const uint32_t p = blockIdx.x * 4 + wave;
+  if (p >= a.n_new) return;
+  const uint32_t n = a.cand_n[p] < a.cand_ld ? a.cand_n[p] : a.cand_ld;
+  const uint64_t *cid = a.cand_id + (size_t)p * a.cand_ld;
+  const float *cd = a.cand_dist + (size_t)p * a.cand_ld;
+  uint32_t *sel_id = a.sel_id + (size_t)p * a.max_keep;
+  float *sel_d = a.sel_dist + (size_t)p * a.max_keep;
+
+  uint32_t nk = 0;
+  if (n < a.max_keep) {                                    // hnswalg.h:555-557: fewer than M -> keep all
+    for (uint32_t i = lane; i < n; i += kWave) { kept[i] = (uint32_t)cid[i]; sel_d[i] = cd[i]; }
+    nk = n;
+  } else {
+    for (uint32_t ci = 0; ci < n && nk < a.max_keep; ++ci) {
+      const uint32_t c = (uint32_t)cid[ci];
+      const float dq = cd[ci];
+      bool good = true;
+      if (nk) {
+        stage_query(a, qs, c, lane);
+        good = !dominated<kL2>(a, qs, kept, nk, dq, lane);
+      }
+      if (good) {
+        if (lane == 0) { kept[nk] = c; sel_d[nk] = dq; }
+        ++nk;
+      }
+    }
+  }
+  uint32_t *ll = a.links0 + (size_t)(a.first_id + p) * a.l0_stride;
+  for (uint32_t i = lane; i < nk; i += kWave) {
+    const uint32_t v = kept[i];
+    ll[1 + i] = v;
+    sel_id[i] = v;
+  }
+  if (lane == 0) {
+    ll[0] = (ll[0] & kFlagMask) | nk;
+    a.sel_n[p] = nk;
+  }
+}
+
+// ---- reverse links ---------------------------------------------------------------------------------
+// touched node t: s = node[t]; new points add_p[off[t]..off[t+1]) at distances add_d (ascending).
+// Room left: append.  Otherwise the old list (distances to s computed here) and the new points go
+// through the heuristic together with capacity maxM0 (hnswalg.h:706-738).
+template <bool kL2>
+__global__ __launch_bounds__(256) void hnsw_relink_kernel(HnswBuildArgs a) {
+  extern __shared__ float4 lds4[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 3, rq = lane >> 2;
+  constexpr uint32_t kCap = 256;                            // candidates per node (old list + additions)
+  const size_t per_wave_f4 = (size_t)a.chunks * 4 + (kCap * 4 + a.max_keep + 3) / 4;
+  float4 *qs = lds4 + wave * per_wave_f4;
+  float *c_d = reinterpret_cast<float *>(qs + a.chunks * 4);
+  uint32_t *c_id = reinterpret_cast<uint32_t *>(c_d + kCap);
+  float *s_d = reinterpret_cast<float *>(c_id + kCap);      // sorted copies
+  uint32_t *s_id = reinterpret_cast<uint32_t *>(s_d + kCap);
+  uint32_t *kept = s_id + kCap;
+
+  const uint32_t t = blockIdx.x * 4 + wave;
+  if (t >= a.n_touched) return;
+  const uint32_t s = a.node[t];
+  uint32_t *ll = a.links0 + (size_t)s * a.l0_stride;
+  const uint32_t w0 = ll[0];
+  const uint32_t cnt = w0 & 0xFFFFu;
+  const uint32_t a0 = a.off[t];
+  uint32_t nadd = a.off[t + 1] - a0;
+  if (cnt + nadd <= a.max_keep) {                           // hnswalg.h:688-704
+    for (uint32_t i = lane; i < nadd; i += kWave) ll[1 + cnt + i] = a.add_p[a0 + i];
+    if (lane == 0) ll[0] = (w0 & kFlagMask) | (cnt + nadd);
+    return;
+  }
+  if (cnt + nadd > kCap) nadd = kCap - cnt;                 // additions are sorted: the farthest are dropped
+
+  // candidates: old neighbours with their distance to s, then the new points
+  stage_query(a, qs, s, lane);
+  for (uint32_t base = 0; base < cnt; base += kRowsPerWave) {
+    const uint32_t i = base + rq;
+    const bool valid = i < cnt;
+    const uint32_t e = ll[1 + (valid ? i : 0)];
+    const float d = quad_row_distance<kL2, false>(reinterpret_cast<const char *>(a.rows + (size_t)e * a.row_stride_f), qs,
+                                                  a.chunks, j);
+    if (valid && j == 0) { c_d[i] = d; c_id[i] = e; }
+  }
+  for (uint32_t i = lane; i < nadd; i += kWave) { c_d[cnt + i] = a.add_d[a0 + i]; c_id[cnt + i] = a.add_p[a0 + i]; }
+  const uint32_t total = cnt + nadd;
+  // ascending by (distance, id): rank by counting
+  for (uint32_t i = lane; i < total; i += kWave) {
+    const float di = c_d[i];
+    const uint32_t ii = c_id[i];
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < total; ++o) {
+      const float dO = c_d[o];
+      const uint32_t io = c_id[o];
+      rank += (dO < di || (dO == di && io < ii)) ? 1u : 0u;
+    }
+    s_d[rank] = di;
+    s_id[rank] = ii;
+  }
+  uint32_t nk = 0;
+  for (uint32_t ci = 0; ci < total && nk < a.max_keep; ++ci) {
+    const uint32_t c = s_id[ci];
+    const float dq = s_d[ci];
+    bool good = true;
+    if (nk) {
+      stage_query(a, qs, c, lane);
+      good = !dominated<kL2>(a, qs, kept, nk, dq, lane);
+    }
+    if (good) {
+      if (lane == 0) kept[nk] = c;
+      ++nk;
+    }
+  }
+  for (uint32_t i = lane; i < nk; i += kWave) ll[1 + i] = kept[i];
+  if (lane == 0) ll[0] = (w0 & kFlagMask) | nk;
+}
+
+size_t hnsw_build_lds_bytes(const HnswBuildArgs &a, bool relink) {
+  const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((relink ? 256 * 4 : 0) + a.max_keep + 3) / 4;
+  return per_wave_f4 * 16 * 4;
+}
+
+hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, hipStream_t s) {
+  const size_t lds = hnsw_build_lds_bytes(a, false);
+  const void *fn = l2 ? reinterpret_cast<const void *>(&hnsw_select_kernel<true>)
+                      : reinterpret_cast<const void *>(&hnsw_select_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  HnswBuildArgs args = a;
+  void *params[] = {&args};
+  return hipLaunchKernel(fn, dim3((a.n_new + 3) / 4), dim3(256), params, lds, s);
+}
+
+hipError_t launch_hnsw_relink(const HnswBuildArgs &a, bool l2, hipStream_t s) {
+  if (a.n_touched == 0) return hipSuccess;
+  const size_t lds = hnsw_build_lds_bytes(a, true);
+  const void *fn = l2 ? reinterpret_cast<const void *>(&hnsw_relink_kernel<true>)
+                      : reinterpret_cast<const void *>(&hnsw_relink_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  HnswBuildArgs args = a;
+  void *params[] = {&args};
+  return hipLaunchKernel(fn, dim3((a.n_touched + 3) / 4), dim3(256), params, lds, s);
+}
+
+}  // namespace vk

@@ -509,6 +509,88 @@ Status HnswGraph::add(const float *new_row, uint64_t label, uint32_t *out_id) {
   return update_point(new_row, replaced, 1.0f);
 }
 
+// ---- device-assisted bulk insert -----------------------------------------------------------------
+bool HnswGraph::bulk_possible(const uint64_t *labels, size_t n) const {
+  if (count_.load() + n > max_elements_) return false;
+  if (allow_replace_deleted_ && num_deleted_.load()) return false;   // those inserts reuse tombstoned slots
+  std::lock_guard<std::mutex> lk(label_lookup_lock_);
+  for (size_t i = 0; i < n; ++i)
+    if (label_lookup_.count(labels ? labels[i] : (uint64_t)i)) return false;   // an update, not an insert
+  return true;
+}
+
+Status HnswGraph::bulk_register(const float *rows, const uint64_t *labels, size_t n, uint32_t *first_id) {
+  std::lock_guard<std::mutex> lock_table(label_lookup_lock_);
+  if (count_.load() + n > max_elements_)
+    return Status::Err(kErrCapacity, "The number of elements exceeds the specified limit");
+  const uint32_t first = (uint32_t)count_.load();
+  *first_id = first;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t id = first + (uint32_t)i;
+    ensure_row_chunk(id);
+    memset(links0_mut(id), 0, (maxM0_ + 1) * sizeof(uint32_t));
+    labels_[id] = labels[i];
+    memcpy(row_mut(id), rows + i * dim_, dim_ * sizeof(float));
+    const int lv = random_level();
+    levels_[id] = lv;
+    delete[] upper_[id];
+    upper_[id] = nullptr;
+    if (lv) {
+      upper_[id] = new uint32_t[(size_t)lv * (maxM_ + 1)]();
+      upper_slot_[id] = upper_slots_used_.fetch_add((uint32_t)lv);
+      mark(id, 1);
+    }
+    mark(id, 0);
+    label_lookup_[labels[i]] = id;
+  }
+  count_.fetch_add(n, std::memory_order_release);
+  return Status::Ok();
+}
+
+Status HnswGraph::bulk_link_upper(uint32_t id) {
+  const int curlevel = levels_[id];
+  if (curlevel <= 0) return Status::Ok();
+  const float *q = row(id);
+  std::unique_lock<std::mutex> templock(global_);
+  const int maxlevelcopy = maxlevel_;
+  Spin lock_el(link_locks_[id]);
+  if (curlevel <= maxlevelcopy) templock.unlock();
+  uint32_t currObj = enterpoint_;
+  const uint32_t enterpoint_copy = enterpoint_;
+  if (currObj == kNone) return Status::Err(kErrInternal, "bulk insert into an empty graph");
+  if (curlevel < maxlevelcopy) {
+    float curdist = dist(q, row(currObj));
+    for (int level = maxlevelcopy; level > curlevel; level--) {
+      bool changed = true;
+      while (changed) {
+        changed = false;
+        Spin lock(link_locks_[currObj]);
+        const uint32_t *ll = upper(currObj, level);
+        const int size = (int)list_count(ll);
+        for (int i = 0; i < size; i++) {
+          const uint32_t cand = ll[1 + i];
+          float d = dist(q, row(cand));
+          if (d < curdist) { curdist = d; currObj = cand; changed = true; }
+        }
+      }
+    }
+  }
+  const bool epDeleted = is_deleted(enterpoint_copy);
+  for (int level = std::min(curlevel, maxlevelcopy); level >= 1; level--) {
+    Heap top = search_base_layer(currObj, q, level);
+    if (epDeleted) {
+      top.emplace(dist(q, row(enterpoint_copy)), enterpoint_copy);
+      if (top.size() > efC_) top.pop();
+    }
+    VK_TRY(mutually_connect(q, id, top, level, false, &currObj));
+  }
+  if (curlevel > maxlevelcopy) {
+    enterpoint_ = id;
+    maxlevel_ = curlevel;
+  }
+  return Status::Ok();
+}
+
 // ---- load path ----------------------------------------------------------------------------------
 Status HnswGraph::load_element(uint32_t id, const uint32_t *links0_words, const float *new_row, uint64_t label) {
   if (id >= max_elements_) return Status::Err(kErrInternal, "element id beyond max_elements");

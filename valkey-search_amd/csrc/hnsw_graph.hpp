@@ -78,6 +78,15 @@ class HnswGraph {
   bool any_dirty() const { return any_dirty_.load(std::memory_order_acquire); }
   void clear_any_dirty() { any_dirty_.store(false, std::memory_order_release); }
 
+  // device-assisted bulk insert (hnsw_build.hip drives level 0): the caller holds the index
+  // exclusively.  bulk_register = the slot/label/level bookkeeping of addPoint (:1523-1583) for n new
+  // labels (levels drawn in order from the same generator); bulk_link_upper = the rest of addPoint
+  // restricted to levels >= 1, thread safe like add().
+  bool bulk_possible(const uint64_t *labels, size_t n) const;
+  Status bulk_register(const float *rows, const uint64_t *labels, size_t n, uint32_t *first_id);
+  Status bulk_link_upper(uint32_t id);
+  uint32_t *links0_table() { return l0_.get(); }
+
   // load path (persist): install a fully formed element
   Status load_element(uint32_t id, const uint32_t *links0_words, const float *row, uint64_t label);
   Status load_upper(uint32_t id, const uint32_t *words, size_t n_words);

@@ -67,6 +67,15 @@ class HnswIndex final : public Index {
   }
 
   Status add_batch(const uint64_t *labels, const float *rows, uint64_t n) override {
+    if (device_build_ && n >= kDeviceBuildMinBatch) {
+      bool handled = false;
+      Status s = add_batch_device(labels, rows, n, &handled);
+      if (handled || !s.ok()) return s;
+    }
+    return add_batch_host(labels, rows, n);
+  }
+
+  Status add_batch_host(const uint64_t *labels, const float *rows, uint64_t n) {
     std::shared_lock<std::shared_mutex> lk(rw_);
     unsigned threads = params_.build_threads ? params_.build_threads : effective_cpus();
     threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n / 16 + 1));
@@ -394,7 +403,7 @@ class HnswIndex final : public Index {
 
   Status launch(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef_runtime, const uint64_t *d_allow,
                 uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
-                bool reset_stats) {
+                bool reset_stats, bool out_ids = false) {
     uint64_t ef = ef_runtime ? ef_runtime : graph_->ef();
     ef = std::max<uint64_t>(ef, k);                       // hnswalg.h:1705,1710
     const int e = hnsw_slots_per_lane(ef);
@@ -427,6 +436,7 @@ class HnswIndex final : public Index {
     a.cand_cap = (uint32_t)std::max<uint64_t>(1024, 2 * ef);
     a.nbr_cap = (uint32_t)((graph_->maxM0() + 63) & ~(size_t)63);
     a.check_deleted = graph_->deleted_count() ? 1 : 0;
+    a.out_ids = out_ids ? 1 : 0;
     if (hnsw_lds_bytes(a) > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     int max_blocks = 0;
     VK_HIP_TRY(hnsw_max_blocks(a, l2(), store_.bf16(), e, &max_blocks));
@@ -443,6 +453,183 @@ class HnswIndex final : public Index {
     return Status::Ok();
   }
 
+  // ---- K9: device-assisted bulk insert (hnsw_build.hip) ---------------------------------------------
+  // Level 0 of a batch of NEW points is linked on the device: efConstruction beam search
+  // (hnsw_search_kernel, ids out), neighbour selection, reverse links with re-pruning; the host
+  // registers the points, links their upper levels (1/M of them) and keeps its level-0 table in
+  // step by reading back the lists the batch touched.  *handled = false: preconditions not met,
+  // nothing was changed, the caller takes the host path.
+  static constexpr uint64_t kDeviceBuildMinBatch = 4096;
+  static constexpr uint64_t kDeviceBuildMinGraph = 2048;   // the first points are inserted one by one
+  static constexpr uint64_t kDeviceBuildMaxBatch = 8192;
+
+  Status add_batch_device(const uint64_t *labels_in, const float *rows, uint64_t n, bool *handled) {
+    *handled = false;
+    if (store_.bf16() || graph_->ef_construction() > 512 || graph_->maxM0() > 192) return Status::Ok();
+    if ((size_t)store_.stride_f() * 4 * 4 + 8192 > 160 * 1024) return Status::Ok();
+    std::vector<uint64_t> iota;
+    const uint64_t *labels = labels_in;
+    if (!labels) {
+      iota.resize(n);
+      for (uint64_t i = 0; i < n; ++i) iota[i] = i;
+      labels = iota.data();
+    }
+    {
+      std::shared_lock<std::shared_mutex> lk(rw_);
+      if (!graph_->bulk_possible(labels, n)) return Status::Ok();
+    }
+    *handled = true;
+    uint64_t pos = 0;
+    if (graph_->count() < kDeviceBuildMinGraph) {
+      pos = std::min<uint64_t>(n, kDeviceBuildMinGraph - graph_->count());
+      VK_TRY(add_batch_host(labels, rows, pos));
+    }
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    (void)hipSetDevice(store_.device());
+    while (pos < n) {
+      const uint64_t count = graph_->count();
+      const uint64_t P = std::min<uint64_t>(n - pos, std::max<uint64_t>(256, std::min<uint64_t>(count / 8, kDeviceBuildMaxBatch)));
+      VK_TRY(device_batch(labels + pos, rows + pos * params_.dim, (uint32_t)P));
+      pos += P;
+    }
+    return Status::Ok();
+  }
+
+  Status device_batch(const uint64_t *labels, const float *rows, uint32_t P) {
+    const uint32_t dim = params_.dim, M = (uint32_t)graph_->M(), maxM0 = (uint32_t)graph_->maxM0();
+    const uint32_t l0s = maxM0 + 1;
+    uint32_t first = 0;
+    VK_TRY(graph_->bulk_register(rows, labels, P, &first));
+    for (uint32_t i = 0; i < P; ++i) VK_TRY(store_.stage_write(first + i, rows + (size_t)i * dim, labels[i]));
+    VK_TRY(flush_locked());          // rows, labels, the new (empty) lists, upper lists of earlier batches
+    CtxLease lease(pool_);
+    SearchCtx *ctx = lease.ctx;
+    hipStream_t s = ctx->stream;
+    // A: candidates = efConstruction nearest live nodes of every new point, ascending
+    const uint32_t efc = (uint32_t)graph_->ef_construction();
+    VK_TRY(ctx->d_out_d.ensure((size_t)P * efc * 4));
+    VK_TRY(ctx->d_out_l.ensure((size_t)P * efc * 8));
+    VK_TRY(ctx->d_out_n.ensure((size_t)P * 4));
+    const float *d_new = static_cast<const float *>(store_.d_rows()) + (size_t)first * store_.stride_f();
+    VK_TRY(launch(ctx, d_new, P, efc, efc, nullptr, 0, ctx->d_out_d.as<float>(), ctx->d_out_l.as<uint64_t>(),
+                  ctx->d_out_n.as<uint32_t>(), s, true, true));
+    // B: neighbour selection, writes the new points' own lists
+    HnswBuildArgs b{};
+    b.rows = static_cast<const float *>(store_.d_rows());
+    b.row_stride_f = store_.stride_f();
+    b.chunks = store_.stride_f() / 16;
+    b.links0 = d_links0_.as<uint32_t>();
+    b.l0_stride = l0s;
+    b.max_keep = M;
+    b.cand_id = ctx->d_out_l.as<uint64_t>();
+    b.cand_dist = ctx->d_out_d.as<float>();
+    b.cand_n = ctx->d_out_n.as<uint32_t>();
+    b.cand_ld = efc;
+    b.n_new = P;
+    b.first_id = first;
+    VK_TRY(ctx->d_part_d.ensure((size_t)P * M * 4));
+    VK_TRY(ctx->d_part_l.ensure((size_t)P * M * 4 + (size_t)P * 4));
+    b.sel_dist = ctx->d_part_d.as<float>();
+    b.sel_id = ctx->d_part_l.as<uint32_t>();
+    b.sel_n = b.sel_id + (size_t)P * M;
+    VK_HIP_TRY(launch_hnsw_select(b, l2(), s));
+    VK_TRY(ctx->h_out_d.ensure((size_t)P * M * 4));
+    VK_TRY(ctx->h_out_l.ensure((size_t)P * M * 4 + (size_t)P * 4));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, b.sel_dist, (size_t)P * M * 4, hipMemcpyDeviceToHost, s));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, b.sel_id, (size_t)P * M * 4 + (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    VK_HIP_TRY(hipStreamSynchronize(s));
+    // C: reverse links, grouped by the selected node
+    struct Rev { uint32_t s; float d; uint32_t p; };
+    std::vector<Rev> rev;
+    rev.reserve((size_t)P * M);
+    {
+      const float *sd = ctx->h_out_d.as<float>();
+      const uint32_t *si = ctx->h_out_l.as<uint32_t>();
+      const uint32_t *sn = si + (size_t)P * M;
+      for (uint32_t p = 0; p < P; ++p)
+        for (uint32_t t = 0; t < sn[p]; ++t) rev.push_back(Rev{si[(size_t)p * M + t], sd[(size_t)p * M + t], first + p});
+    }
+    std::sort(rev.begin(), rev.end(), [](const Rev &x, const Rev &y) {
+      return x.s != y.s ? x.s < y.s : (x.d != y.d ? x.d < y.d : x.p < y.p);
+    });
+    std::vector<uint32_t> node, off;
+    for (size_t i = 0; i < rev.size(); ++i)
+      if (i == 0 || rev[i].s != rev[i - 1].s) { node.push_back(rev[i].s); off.push_back((uint32_t)i); }
+    off.push_back((uint32_t)rev.size());
+    const uint32_t T = (uint32_t)node.size();
+    if (T) {
+      // [node T | off T+1 | add_p R | add_d R]
+      const size_t R = rev.size(), words = (size_t)T + T + 1 + 2 * R;
+      VK_TRY(ctx->h_tmp.ensure(words * 4));
+      VK_TRY(ctx->d_idx.ensure(words * 4));
+      uint32_t *h = ctx->h_tmp.as<uint32_t>();
+      memcpy(h, node.data(), (size_t)T * 4);
+      memcpy(h + T, off.data(), (size_t)(T + 1) * 4);
+      uint32_t *hp = h + 2 * T + 1;
+      float *hd = reinterpret_cast<float *>(hp + R);
+      for (size_t i = 0; i < R; ++i) { hp[i] = rev[i].p; hd[i] = rev[i].d; }
+      VK_HIP_TRY(hipMemcpyAsync(ctx->d_idx.p, h, words * 4, hipMemcpyHostToDevice, s));
+      const uint32_t *d = ctx->d_idx.as<uint32_t>();
+      b.node = d;
+      b.off = d + T;
+      b.add_p = d + 2 * T + 1;
+      b.add_d = reinterpret_cast<const float *>(d + 2 * T + 1 + R);
+      b.n_touched = T;
+      b.max_keep = maxM0;
+      VK_HIP_TRY(launch_hnsw_relink(b, l2(), s));
+    }
+    // keep the host table in step: read back the lists this batch wrote (new points + touched nodes)
+    {
+      const size_t nsync = (size_t)P + T;
+      VK_TRY(ctx->h_idx.ensure(nsync * 4));
+      uint32_t *hi = ctx->h_idx.as<uint32_t>();
+      for (uint32_t i = 0; i < P; ++i) hi[i] = first + i;
+      for (uint32_t i = 0; i < T; ++i) hi[P + i] = node[i];
+      VK_TRY(ctx->d_allow.ensure(nsync * 4));
+      VK_TRY(ctx->d_q.ensure(nsync * l0s * 4));
+      VK_TRY(ctx->h_q.ensure(nsync * l0s * 4));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->d_allow.p, hi, nsync * 4, hipMemcpyHostToDevice, s));
+      VK_HIP_TRY(launch_gather_u32(ctx->d_q.as<uint32_t>(), d_links0_.as<uint32_t>(), ctx->d_allow.as<uint32_t>(),
+                                   (uint32_t)nsync, l0s, s));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_q.p, ctx->d_q.p, nsync * l0s * 4, hipMemcpyDeviceToHost, s));
+      VK_HIP_TRY(hipStreamSynchronize(s));
+      uint32_t *tab = graph_->links0_table();
+      const uint32_t *src = ctx->h_q.as<uint32_t>();
+      for (size_t i = 0; i < nsync; ++i) memcpy(tab + (size_t)hi[i] * l0s, src + i * l0s, (size_t)l0s * 4);
+    }
+    // upper levels of the batch's points on the host, in parallel like concurrent addPoint calls
+    std::vector<uint32_t> ups;
+    for (uint32_t i = 0; i < P; ++i)
+      if (graph_->level_of(first + i) > 0) ups.push_back(first + i);
+    if (!ups.empty()) {
+      const unsigned threads = (unsigned)std::min<size_t>(ups.size(), params_.build_threads ? params_.build_threads : effective_cpus());
+      std::atomic<size_t> next{0};
+      std::atomic<bool> failed{false};
+      Status err;
+      std::mutex err_mu;
+      auto work = [&]() {
+        for (;;) {
+          size_t i = next.fetch_add(1);
+          if (i >= ups.size() || failed.load()) return;
+          Status st = graph_->bulk_link_upper(ups[i]);
+          if (!st.ok()) {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (!failed.exchange(true)) err = st;
+          }
+        }
+      };
+      if (threads <= 1) work();
+      else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+      }
+      if (failed.load()) return err;
+    }
+    return Status::Ok();
+  }
+
+  bool device_build_ = !(getenv("VK_HNSW_DEVICE_BUILD") && atoi(getenv("VK_HNSW_DEVICE_BUILD")) == 0);
   RowStore store_;
   CtxPool pool_;
   std::unique_ptr<SearchCtx> dev_ctx_;

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
 #pragma unroll
     for (int e = 0; e < kE; ++e) {
       const uint32_t r = (uint32_t)e * kWave + lane;
-      lab[e] = r < kout ? a.labels[top.id[e]] : kNoLabel;
+      lab[e] = r < kout ? (a.out_ids ? (uint64_t)top.id[e] : a.labels[top.id[e]]) : kNoLabel;
     }
 #pragma unroll
     for (int e = 0; e < kE; ++e) {
@@ -334,6 +334,14 @@ __global__ void scatter_u32_kernel(uint32_t *dst, const uint32_t *src, const uin
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t i = (uint32_t)(t / stride), w = (uint32_t)(t % stride);
     dst[(size_t)idx[i] * stride + w] = src[t];
+  }
+}
+
+__global__ void gather_u32_kernel(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride) {
+  const uint64_t total = (uint64_t)n * stride;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t i = (uint32_t)(t / stride), w = (uint32_t)(t % stride);
+    dst[t] = src[(size_t)idx[i] * stride + w];
   }
 }
 
@@ -405,6 +413,15 @@ hipError_t launch_scatter_u32(uint32_t *dst, const uint32_t *src, const uint32_t
   uint64_t total = (uint64_t)n * stride;
   uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(scatter_u32_kernel, dim3(blocks), dim3(256), 0, s, dst, src, idx, n, stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_u32(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride,
+                             hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  uint64_t total = (uint64_t)n * stride;
+  uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(gather_u32_kernel, dim3(blocks), dim3(256), 0, s, dst, src, idx, n, stride);
   return hipGetLastError();
 }
 

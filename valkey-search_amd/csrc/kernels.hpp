@@ -94,15 +94,46 @@ struct HnswSearchArgs {
   uint32_t cand_cap;           // candidate pool entries per wave (LDS)
   uint32_t nbr_cap;            // >= maxM0
   uint32_t check_deleted;      // any tombstones in the index
+  uint32_t out_ids;            // 1: out_label receives internal ids (device-side graph construction)
 };
 int hnsw_slots_per_lane(uint64_t ef);                      // 0 = ef too large for the in-register result list
 size_t hnsw_lds_bytes(const HnswSearchArgs &a);
 hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks);
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s);
 
+// K9 (hnsw_build.hip): level-0 neighbour selection and reverse links for a batch of new points
+struct HnswBuildArgs {
+  const float *rows;           // f32 rows
+  uint32_t row_stride_f, chunks;
+  uint32_t *links0;            // [cap][l0_stride], updated in place
+  uint32_t l0_stride;
+  uint32_t max_keep;           // select: M; relink: maxM0
+  // select: candidates of the new points first_id .. first_id + n_new - 1
+  const uint64_t *cand_id;     // [n_new][cand_ld] ascending by distance (ids)
+  const float *cand_dist;
+  const uint32_t *cand_n;
+  uint32_t cand_ld, n_new, first_id;
+  uint32_t *sel_id;            // [n_new][max_keep]
+  float *sel_dist;
+  uint32_t *sel_n;
+  // relink: CSR over the touched nodes
+  const uint32_t *node;        // [n_touched]
+  const uint32_t *off;         // [n_touched + 1]
+  const uint32_t *add_p;       // new point ids, per node ascending by distance
+  const float *add_d;
+  uint32_t n_touched;
+};
+size_t hnsw_build_lds_bytes(const HnswBuildArgs &a, bool relink);
+hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, hipStream_t s);
+hipError_t launch_hnsw_relink(const HnswBuildArgs &a, bool l2, hipStream_t s);
+
 // scatter rows of u32 words: dst[idx[i]*stride + w] = src[i*stride + w]
 hipError_t launch_scatter_u32(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride,
                               hipStream_t s);
+
+// gather rows of u32 words: dst[i*stride + w] = src[idx[i]*stride + w]
+hipError_t launch_gather_u32(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride,
+                             hipStream_t s);
 
 int flat_scan_slots_per_lane(uint64_t k);                 // 0 = k too large for the in-register top-k
 int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e);
