@@ -46,6 +46,10 @@ def run(tag, device, n):
             D, L, N = g.search_batch(Q, 10, ef=ef)
             rec = np.mean([len(set(L[i, :N[i]].tolist()) & set(Lt[i].tolist())) / 10 for i in range(len(Q))])
             line += f" | recall@10 ef={ef}: {rec:.4f}"
+    if os.environ.get("BUILD_PROBE_DEGREES"):
+        chunks = g.save()
+        deg = np.array([int(np.frombuffer(c[:4], np.uint32)[0] & 0xFFFF) for c in chunks[1:1 + n]])
+        line += f" | level-0 degree mean {deg.mean():.2f} p10 {np.percentile(deg, 10):.0f} p50 {np.percentile(deg, 50):.0f} max {deg.max()} full {(deg == 32).mean():.3f}"
     print(line, flush=True)
 
 run("device-assisted build", True, a.rows)

@@ -77,6 +77,14 @@ class HnswGraph {
   uint8_t take_dirty(uint32_t id) { return dirty_[id].exchange(0, std::memory_order_acq_rel); }
   bool any_dirty() const { return any_dirty_.load(std::memory_order_acquire); }
   void clear_any_dirty() { any_dirty_.store(false, std::memory_order_release); }
+  // ids whose dirty byte went from 0 to non-zero since the last call (flush walks these, not the
+  // whole table: a scan of 10M atomics per flush was most of the cost of a bulk build)
+  std::vector<uint32_t> take_dirty_ids() {
+    std::lock_guard<std::mutex> g(dirty_mu_);
+    std::vector<uint32_t> out;
+    out.swap(dirty_ids_);
+    return out;
+  }
 
   // device-assisted bulk insert (hnsw_build.hip drives level 0): the caller holds the index
   // exclusively.  bulk_register = the slot/label/level bookkeeping of addPoint (:1523-1583) for n new
@@ -144,7 +152,11 @@ class HnswGraph {
   float *row_mut(uint32_t id) { return rows_[id >> kChunkShift] + (size_t)(id & kChunkMask) * dim_; }
   void ensure_row_chunk(uint32_t id);
   void mark(uint32_t id, int level) {
-    dirty_[id].fetch_or(level == 0 ? kDirtyL0 : kDirtyUpper, std::memory_order_acq_rel);
+    const uint8_t prev = dirty_[id].fetch_or(level == 0 ? kDirtyL0 : kDirtyUpper, std::memory_order_acq_rel);
+    if (prev == 0) {
+      std::lock_guard<std::mutex> g(dirty_mu_);
+      dirty_ids_.push_back(id);
+    }
     any_dirty_.store(true, std::memory_order_release);
   }
   std::unique_ptr<VisitedList> get_visited();
@@ -184,6 +196,8 @@ class HnswGraph {
   std::unique_ptr<std::atomic_flag[]> link_locks_;
   std::unique_ptr<std::atomic<uint8_t>[]> dirty_;
   std::atomic<bool> any_dirty_{false};
+  std::mutex dirty_mu_;
+  std::vector<uint32_t> dirty_ids_;
 
   std::mutex global_;
   mutable std::mutex label_lookup_lock_;
