@@ -87,8 +87,9 @@ def gen_rows(n_begin, n_rows, dim, device, chunk=65536, latent=32, noise=0.05, s
 
 
 def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
-    """HNSW over the first --hnsw-rows rows: host build (quota-aware threads), device search, recall vs
-    the exact FLAT answer on the same rows, and the CPU oracle searching the SAME graph."""
+    """HNSW over the first --hnsw-rows rows: device-assisted bulk build (K9), device search, recall vs the
+    exact FLAT answer on the same rows, the CPU oracle searching the SAME graph, and the two hybrid paths
+    of BASELINE.json configs[4] (inline filter at 10 % selectivity, pre-filter below 0.1 %)."""
     from oracle import oracle as O
     Nh, D, K, ef = min(args.hnsw_rows, table.shape[0]), args.dim, args.k, args.hnsw_ef
     host_rows = np.ascontiguousarray(table[:Nh, :D].cpu().numpy())
@@ -144,8 +145,38 @@ def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
     n_cpu = len(cpu_res)
     cpu_recall = float(np.mean([len(set(r[1].tolist()) & set(gt[i].tolist())) for i, r in enumerate(cpu_res)])) / K
     same = sum(int(cpu_res[i][1].tolist() == gl[i][:len(cpu_res[i][1])].tolist()) for i in range(n_cpu))
-    return {"rows": Nh, "M": 16, "ef_construction": 200, "ef": ef, "k": K, "queries_per_batch": nq,
-            "build_s": round(build_s, 2), "build_inserts_per_s": round(Nh / build_s, 1), "build_threads": threads,
+    # ---- hybrid: TAG-like filters as allow-bitmaps over labels (planner.cc:21-45 picks the path) ----
+    tag_bits = O.allow_bitmap(np.arange(3, Nh, 10, dtype=np.uint64), Nh)           # 10 % of the rows: inline
+    d_bits = torch.from_numpy(tag_bits.view(np.int64)).to(device)
+    _, gt_f, _ = flat_ix.search_batch(hq[:1024], K, allow=tag_bits, allow_nbits=Nh)
+
+    def run_f():
+        h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef,
+                              d_allow=d_bits.data_ptr(), allow_nbits=Nh, stream=stream_ptr())
+
+    run_f()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        run_f()
+    e1.record()
+    torch.cuda.synchronize()
+    ms_f = e0.elapsed_time(e1) / reps
+    glf = ol.cpu().numpy().view(np.uint64)[:1024]
+    recall_f = float(np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(glf, gt_f)])) / K
+    # pre-filter (<= 0.001 * N keys): exact kNN over the key list, one call per query like CalcBestMatchingPrefilteredKeys
+    keys = np.sort(np.random.default_rng(77).choice(Nh, max(1, Nh // 2000), replace=False)).astype(np.uint64)
+    key_bits = O.allow_bitmap(keys, Nh)
+    t1 = time.perf_counter()
+    pre = [h.search_labels(hq[i], K, keys) for i in range(256)]
+    pre_dt = time.perf_counter() - t1
+    _, gt_p, ngt = flat_ix.search_batch(hq[:256], K, allow=key_bits, allow_nbits=Nh)
+    pre_ok = all(set(pre[i][1].tolist()) == set(gt_p[i, :ngt[i]].tolist()) for i in range(256))
+    hybrid = {"inline_filter": {"selectivity": 0.1, "gpu_qps": round(nq / (ms_f * 1e-3), 1), "recall_at_10": round(recall_f, 4)},
+              "pre_filter": {"keys": int(len(keys)), "selectivity": round(len(keys) / Nh, 5),
+                             "qps_single_caller": round(256 / pre_dt, 1), "exact": bool(pre_ok)}}
+    return {"rows": Nh, "M": 16, "ef_construction": 200, "ef": ef, "k": K, "queries_per_batch": nq, "hybrid": hybrid,
+            "build_s": round(build_s, 2), "build_inserts_per_s": round(Nh / build_s, 1), "build": "device-assisted (K9)", "host_threads": threads,
             "gpu_qps": round(nq / (ms * 1e-3), 1), "ms_per_batch": round(ms, 3), "recall_at_10": round(recall, 4),
             "n_eval_per_query": round(st.last_n_eval / 1024.0, 1), "n_hops_per_query": round(st.last_n_hops / 1024.0, 1),
             "useful_gbs": round(useful / (ms * 1e-3) / 1e9, 1),
