@@ -185,6 +185,42 @@ def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
                     "ids_identical_to_gpu": f"{same}/{n_cpu}", "graph_export_s": round(export_s, 2)}}
 
 
+def coalescer_leg(ix, hq, K, threads=64, per_thread=4):
+    """N1: the reference issues one query per FT.SEARCH from a pool of reader threads (search.cc:886-910).
+    `threads` callers each issue `per_thread` single-query vk_index_search calls, first one at a time per
+    call (a device pass each), then with vk_index_set_coalescing merging concurrent calls into batches."""
+    import threading
+
+    def drive(n_threads):
+        out = [None] * (n_threads * per_thread)
+
+        def worker(t):
+            for r in range(per_thread):
+                i = t * per_thread + r
+                out[i] = ix.search_one(hq[i % len(hq)], K)
+
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        t0 = time.perf_counter()
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        return time.perf_counter() - t0, out
+
+    ix.set_coalescing(0, 0)
+    dt0, ref = drive(threads)
+    before = ix.stats()
+    ix.set_coalescing(threads, 300)
+    dt1, got = drive(threads)
+    after = ix.stats()
+    ix.set_coalescing(0, 0)
+    same = all(a[1].tolist() == b[1].tolist() and a[0].view(np.uint32).tolist() == b[0].view(np.uint32).tolist()
+               for a, b in zip(ref, got))
+    nq = threads * per_thread
+    batches = after.coalesced_batches - before.coalesced_batches
+    return {"callers": threads, "queries": nq, "uncoalesced_qps": round(nq / dt0, 1), "coalesced_qps": round(nq / dt1, 1),
+            "device_batches": int(batches), "mean_batch": round(nq / max(1, batches), 1), "max_wait_us": 300,
+            "answers_identical": bool(same)}
+
+
 def pmc_traffic(N, D, B, world):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE
     is a separate run by rule, so bench.py cannot collect it live): profiles/r01_pmc_fetch_size_k4.json,
@@ -374,6 +410,10 @@ def main():
     if rank == 0 and world == 1 and args.hnsw_rows > 0 and not bf16:
         hnsw = hnsw_leg(args, ix, table, A, device, stream_ptr)
 
+    coalescer = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        coalescer = coalescer_leg(ix, Q.cpu().numpy(), K)
+
     if rank == 0:
         traffic, traffic_src = pmc_traffic(N, D, B, world)
         qps = B * args.steps / dt
@@ -407,6 +447,7 @@ def main():
                           "tflops_f32": round(flops / (dev_ms * 1e-3) / 1e12, 3)}),
             "cpu_baseline": cpu,
             "single_query_scan": single,
+            "coalescer": coalescer,
             "hnsw": hnsw,
             "build_s": round(t_build, 2),
         }
