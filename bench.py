@@ -370,7 +370,7 @@ def main():
     # ---- CPU baseline + parity spot check on rank 0 (oracle = checker, never the product) ----
     cpu = None
     parity = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (bench contract)
         from oracle import oracle as O
         S = min(args.cpu_rows, n_local)
         host_rows = np.ascontiguousarray(table[:S, :D].float().cpu().numpy())   # bf16: the widened stored values
