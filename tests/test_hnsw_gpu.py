@@ -233,3 +233,27 @@ def test_multithreaded_build_same_graph_same_answers(vsa, oracle):
     D, L, N = g.search_batch(Q, 10, ef=128)
     for i in range(len(Q)):
         _same(D[i, :N[i]], L[i, :N[i]], *o.search(Q[i], 10, ef=128))
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_large_ef_uses_the_lds_result_list(vsa, oracle, metric):
+    """512 < ef <= 4096: the result list moves from the lanes' registers to LDS (one wave per block); the
+    answers must still be the oracle's on the same graph -- including k > 512 and a filter."""
+    rng = np.random.default_rng(61)
+    n, dim = 6000, 40
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g, o = _pair(vsa, oracle, x, metric, M=12, efc=80)
+    Q = rng.standard_normal((12, dim)).astype(np.float32)
+    for q in Q:
+        for k, ef in ((10, 600), (10, 1500), (700, 1000), (2000, 4096)):
+            _same(*g.search(q, k, ef=ef), *o.search(q, k, ef=ef))
+    allowed = np.sort(rng.choice(n, 2500, replace=False)).astype(np.uint64)
+    bits = oracle.allow_bitmap(allowed, n)
+    for q in Q[:4]:
+        _same(*g.search(q, 50, ef=900, allow=bits, allow_nbits=n), *o.search(q, 50, ef=900, allow=bits, allow_nbits=n))
+    # batched, and the documented ceiling
+    D, L, N = g.search_batch(Q, 20, ef=800)
+    for i, q in enumerate(Q):
+        _same(D[i, :N[i]], L[i, :N[i]], *o.search(q, 20, ef=800))
+    with pytest.raises(vsa.VkError):
+        g.search(Q[0], 10, ef=5000)

@@ -409,7 +409,7 @@ class HnswIndex final : public Index {
     uint64_t ef = ef_runtime ? ef_runtime : graph_->ef();
     ef = std::max<uint64_t>(ef, k);                       // hnswalg.h:1705,1710
     const int e = hnsw_slots_per_lane(ef);
-    if (e == 0) return Status::Err(VK_ERR_INVALID, "ef (or k) > 512 is not served by this build of the HNSW search");
+    if (e == 0) return Status::Err(VK_ERR_INVALID, "ef (or k) > 4096 is not served by this build of the HNSW search");
     if (graph_->maxM0() > 256) return Status::Err(VK_ERR_INVALID, "M > 128 is not served by this build of the HNSW search");
     const uint32_t count = (uint32_t)graph_->count();
     HnswSearchArgs a{};
@@ -443,10 +443,11 @@ class HnswIndex final : public Index {
     int max_blocks = 0;
     VK_HIP_TRY(hnsw_max_blocks(a, l2(), store_.bf16(), e, &max_blocks));
     // visited bitmaps: one per resident wave, bounded to 2 GiB per context
-    uint64_t blocks = std::min<uint64_t>((nq + 3) / 4, (uint64_t)max_blocks);
+    const uint64_t wpb = (uint64_t)hnsw_waves_per_block(e);
+    uint64_t blocks = std::min<uint64_t>((nq + wpb - 1) / wpb, (uint64_t)max_blocks);
     const uint64_t bm_bytes = (uint64_t)a.bitmap_words * 4;
-    blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)2 << 30) / (bm_bytes * 4)));
-    VK_TRY(ctx->d_tmp.ensure(blocks * 4 * bm_bytes));
+    blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)2 << 30) / (bm_bytes * wpb)));
+    VK_TRY(ctx->d_tmp.ensure(blocks * wpb * bm_bytes));
     a.visited = ctx->d_tmp.as<uint32_t>();
     VK_TRY(ctx->d_stats.ensure(32));
     if (reset_stats) VK_HIP_TRY(hipMemsetAsync(ctx->d_stats.p, 0, 32, s));

@@ -28,6 +28,7 @@
 // nodes wins is decided by libstdc++'s sift order; here it is decided by arrival order.
 // Ids can therefore differ from the CPU path only between exactly equidistant nodes.
 #include <algorithm>
+#include <type_traits>
 
 #include "device_common.hpp"
 #include "kernels.hpp"
@@ -94,6 +95,41 @@ struct WaveSorted {
   }
 };
 
+// ef > 512: the result list does not fit the lanes' registers; it lives in LDS (one wave per block),
+// sorted ascending like WaveSorted, insertion = parallel shift.  Same interface, lower throughput.
+struct LdsSorted {
+  float *d;
+  uint32_t *id;
+  uint32_t cnt;
+  __device__ __forceinline__ void init() { cnt = 0; }
+  __device__ __forceinline__ float at_d(uint32_t r) const { return d[r]; }
+  __device__ __forceinline__ uint32_t at_id(uint32_t r) const { return id[r]; }
+  __device__ __forceinline__ void insert(float nd, uint32_t nid, uint32_t cap, int lane) {
+    uint32_t pos = 0;
+    for (uint32_t base = 0; base < cnt; base += kWave) {
+      const uint32_t i = base + lane;
+      pos += __popcll(__ballot(i < cnt && d[i] <= nd));
+    }
+    if (pos >= cap) return;
+    const uint32_t last = cnt < cap ? cnt : cap - 1;     // entries pos..last-1 move up by one
+    for (uint32_t hi = last; hi > pos;) {
+      const uint32_t i = hi - (uint32_t)lane;             // this lane's destination index
+      const bool mv = hi >= (uint32_t)lane && i > pos;
+      float v = 0.f;
+      uint32_t w = 0;
+      if (mv) { v = d[i - 1]; w = id[i - 1]; }
+      __builtin_amdgcn_wave_barrier();
+      if (mv) { d[i] = v; id[i] = w; }
+      __builtin_amdgcn_wave_barrier();
+      hi = hi > (uint32_t)kWave ? hi - kWave : 0;
+      if (hi <= pos) break;
+    }
+    if (lane == 0) { d[pos] = nd; id[pos] = nid; }
+    __builtin_amdgcn_wave_barrier();
+    cnt = cnt + 1 < cap ? cnt + 1 : cap;
+  }
+};
+
 struct Pool {  // frontier in LDS
   float *d;
   uint32_t *id;
@@ -128,16 +164,20 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
   const int rq = lane >> 2;
   const uint32_t chunks = a.chunks;
 
-  // per-wave LDS carve: query | pool d | pool id | nbr id | nbr dist
-  const size_t per_wave_f4 = (size_t)chunks * 4 + (a.cand_cap * 2 + a.nbr_cap * 2 + 3) / 4;
+  // per-wave LDS carve: query | [result list d | id (kE == 0 only)] | pool d | pool id | nbr id | nbr dist
+  constexpr bool kLdsList = kE == 0;
+  const uint32_t list_words = kLdsList ? 2 * a.ef : 0;
+  const size_t per_wave_f4 = (size_t)chunks * 4 + (list_words + a.cand_cap * 2 + a.nbr_cap * 2 + 3) / 4;
   float4 *qs = lds4 + wave * per_wave_f4;
-  float *pool_d = reinterpret_cast<float *>(qs + chunks * 4);
+  float *list_d = reinterpret_cast<float *>(qs + chunks * 4);
+  float *pool_d = list_d + list_words;
   uint32_t *pool_id = reinterpret_cast<uint32_t *>(pool_d + a.cand_cap);
   uint32_t *nbr_id = pool_id + a.cand_cap;
   float *nbr_d = reinterpret_cast<float *>(nbr_id + a.nbr_cap);
 
-  const uint32_t wslot = blockIdx.x * 4 + wave;
-  const uint32_t wstride = gridDim.x * 4;
+  const uint32_t wpb = blockDim.x >> 6;                  // 4 waves per block, 1 with the LDS result list
+  const uint32_t wslot = blockIdx.x * wpb + wave;
+  const uint32_t wstride = gridDim.x * wpb;
   uint32_t *bitmap = a.visited + (size_t)wslot * a.bitmap_words;
 
   unsigned long long st_eval = 0, st_hops = 0, st_over = 0, st_q = 0;
@@ -195,7 +235,8 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     }
 
     // ---- K5: layer-0 best-first expansion (:351-551) --------------------------------------------
-    WaveSorted<kE> top;
+    typename std::conditional<kLdsList, LdsSorted, WaveSorted<(kE > 0 ? kE : 1)>>::type top;
+    if constexpr (kLdsList) { top.d = list_d; top.id = reinterpret_cast<uint32_t *>(list_d + a.ef); }
     top.init();
     Pool c{pool_d, pool_id, 0, a.cand_cap};
     float lowerBound;
@@ -296,7 +337,30 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     const uint32_t kout = top.cnt < a.k ? top.cnt : a.k;
     float *od = a.out_dist + (size_t)q * a.k;
     uint64_t *ol = a.out_label + (size_t)q * a.k;
-    uint64_t lab[kE];
+    if constexpr (kLdsList) {
+      // the list is ascending by distance; equal distances form runs that are ordered by label
+      for (uint32_t r = lane; r < a.k; r += kWave) {
+        if (r < kout) {
+          const float dr = top.d[r];
+          const uint64_t lr = a.out_ids ? (uint64_t)top.id[r] : a.labels[top.id[r]];
+          uint32_t lo = r, rank_in_run = 0;
+          while (lo > 0 && top.d[lo - 1] == dr) --lo;
+          for (uint32_t t = lo; t < kout && top.d[t] == dr; ++t) {
+            if (t == r) continue;
+            const uint64_t lt = a.out_ids ? (uint64_t)top.id[t] : a.labels[top.id[t]];
+            rank_in_run += lt < lr ? 1u : 0u;
+          }
+          // (like the register path, only the first kout entries are ranked among themselves)
+          const uint32_t pos = lo + rank_in_run;
+          od[pos] = dr;
+          ol[pos] = lr;
+        } else {
+          od[r] = __builtin_inff();
+          ol[r] = kNoLabel;
+        }
+      }
+    } else {
+    uint64_t lab[kE > 0 ? kE : 1];
 #pragma unroll
     for (int e = 0; e < kE; ++e) {
       const uint32_t r = (uint32_t)e * kWave + lane;
@@ -316,6 +380,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
       }
       if (r < kout) { od[rank] = top.d[e]; ol[rank] = lab[e]; }
       else if (r < a.k) { od[r] = __builtin_inff(); ol[r] = kNoLabel; }
+    }
     }
     if (lane == 0) a.out_n[q] = kout;
     st_q += 1;
@@ -351,12 +416,16 @@ int hnsw_slots_per_lane(uint64_t ef) {
   if (ef <= 128) return 2;
   if (ef <= 256) return 4;
   if (ef <= 512) return 8;
+  if (ef <= kHnswMaxEf) return kHnswLdsList;   // result list in LDS, one wave per block
   return 0;
 }
 
+int hnsw_waves_per_block(int e) { return e == kHnswLdsList ? 1 : 4; }
+
 size_t hnsw_lds_bytes(const HnswSearchArgs &a) {
-  const size_t per_wave_f4 = (size_t)a.chunks * 4 + (a.cand_cap * 2 + a.nbr_cap * 2 + 3) / 4;
-  return per_wave_f4 * 16 * 4;
+  const bool lds_list = a.ef > 512;
+  const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + a.cand_cap * 2 + a.nbr_cap * 2 + 3) / 4;
+  return per_wave_f4 * 16 * (lds_list ? 1 : 4);
 }
 
 template <bool kL2, int kE, bool kBf16>
@@ -374,6 +443,7 @@ static const void *hnsw_pick(bool l2, bool bf16, int e) {
     case 2: return hnsw_pick_e<2>(l2, bf16);
     case 4: return hnsw_pick_e<4>(l2, bf16);
     case 8: return hnsw_pick_e<8>(l2, bf16);
+    case kHnswLdsList: return hnsw_pick_e<0>(l2, bf16);
   }
   return nullptr;
 }
@@ -388,7 +458,7 @@ hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, i
     if (er != hipSuccess) return er;
   }
   int per_cu = 0;
-  hipError_t er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 256, lds);
+  hipError_t er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64 * hnsw_waves_per_block(e), lds);
   if (er != hipSuccess) return er;
   int dev = 0, cus = 0;
   (void)hipGetDevice(&dev);
@@ -402,9 +472,13 @@ hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e
   const void *f = hnsw_pick(l2, bf16, e);
   if (!f || blocks == 0) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
+  if (lds > 48 * 1024) {
+    hipError_t er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (er != hipSuccess) return er;
+  }
   HnswSearchArgs args = a;
   void *params[] = {&args};
-  return hipLaunchKernel(f, dim3(blocks), dim3(256), params, lds, s);
+  return hipLaunchKernel(f, dim3(blocks), dim3(64 * hnsw_waves_per_block(e)), params, lds, s);
 }
 
 hipError_t launch_scatter_u32(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride,

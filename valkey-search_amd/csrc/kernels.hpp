@@ -96,7 +96,10 @@ struct HnswSearchArgs {
   uint32_t check_deleted;      // any tombstones in the index
   uint32_t out_ids;            // 1: out_label receives internal ids (device-side graph construction)
 };
-int hnsw_slots_per_lane(uint64_t ef);                      // 0 = ef too large for the in-register result list
+constexpr int kHnswLdsList = 16;      // hnsw_slots_per_lane(): 512 < ef <= kHnswMaxEf, result list in LDS
+constexpr uint64_t kHnswMaxEf = 4096;
+int hnsw_slots_per_lane(uint64_t ef);                      // 0 = ef beyond kHnswMaxEf
+int hnsw_waves_per_block(int e);
 size_t hnsw_lds_bytes(const HnswSearchArgs &a);
 hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks);
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s);
