@@ -435,7 +435,7 @@ class HnswIndex final : public Index {
     a.nq = (uint32_t)nq;
     a.k = (uint32_t)k;
     a.ef = (uint32_t)ef;
-    a.cand_cap = (uint32_t)std::max<uint64_t>(1024, 2 * ef);
+    a.cand_cap = (uint32_t)std::max<uint64_t>(cand_floor_, 2 * ef);   // frontier pool (LDS); overflow is counted in stats
     a.nbr_cap = (uint32_t)((graph_->maxM0() + 63) & ~(size_t)63);
     a.check_deleted = graph_->deleted_count() ? 1 : 0;
     a.out_ids = out_ids ? 1 : 0;
@@ -683,6 +683,7 @@ class HnswIndex final : public Index {
   uint64_t build_min_graph_ = getenv("VK_HNSW_BUILD_MIN_GRAPH") ? (uint64_t)atoll(getenv("VK_HNSW_BUILD_MIN_GRAPH")) : kDeviceBuildMinGraph;
   uint64_t build_min_batch_ = getenv("VK_HNSW_BUILD_MIN_BATCH") ? (uint64_t)atoll(getenv("VK_HNSW_BUILD_MIN_BATCH")) : 64;
   uint64_t build_frac_ = getenv("VK_HNSW_BUILD_FRAC") ? (uint64_t)std::max(1, atoi(getenv("VK_HNSW_BUILD_FRAC"))) : 32;
+  uint64_t cand_floor_ = getenv("VK_HNSW_POOL_FLOOR") ? (uint64_t)atoll(getenv("VK_HNSW_POOL_FLOOR")) : 512;
   bool device_build_ = !(getenv("VK_HNSW_DEVICE_BUILD") && atoi(getenv("VK_HNSW_DEVICE_BUILD")) == 0);
   RowStore store_;
   CtxPool pool_;

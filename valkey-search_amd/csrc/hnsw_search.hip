@@ -155,8 +155,9 @@ __device__ __forceinline__ void pool_prune(Pool &c, float bound, int lane) {
 
 }  // namespace
 
+// 4 waves per SIMD (<= 128 VGPRs): the search is bound by gathers in flight, i.e. by resident waves
 template <bool kL2, int kE, bool kBf16>
-__global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
+__global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
