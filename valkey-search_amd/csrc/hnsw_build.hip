@@ -14,6 +14,8 @@
 //
 // Both kernels: one wave per node, distances 16 rows at a time (one row per quad of lanes) against a
 // "query" row staged in LDS, the same lane-exact f32 arithmetic as everywhere else.
+#include <hipcub/hipcub.hpp>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void hnsw_relink_kernel(HnswBuildArgs a) {
   uint32_t *kept = s_id + kCap;
 
   const uint32_t t = blockIdx.x * 4 + wave;
-  if (t >= a.n_touched) return;
+  if (t >= (a.counts ? a.counts[0] : a.n_touched)) return;
   const uint32_t s = a.node[t];
   uint32_t *ll = a.links0 + (size_t)s * a.l0_stride;
   const uint32_t w0 = ll[0];
@@ -172,6 +174,96 @@ __global__ __launch_bounds__(256) void hnsw_relink_kernel(HnswBuildArgs a) {
   if (lane == 0) ll[0] = (w0 & kFlagMask) | nk;
 }
 
+// ---- grouping the (new point -> selected neighbour) pairs by neighbour, on the device ---------------
+namespace {
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ void hnsw_pairs_kernel(const uint32_t *sel_id, const float *sel_dist, const uint32_t *sel_n, uint32_t n_new,
+                                  uint32_t m, uint32_t first, uint64_t *keys, uint32_t *vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_new * m) return;
+  const uint32_t p = i / m, t = i % m;
+  const bool valid = t < sel_n[p];
+  keys[i] = valid ? (((uint64_t)sel_id[i] << 32) | f32_order_key(sel_dist[i])) : ~0ull;
+  vals[i] = first + p;
+}
+__global__ void hnsw_heads_kernel(const uint64_t *keys, uint32_t n, uint32_t *flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  flags[i] = (k != ~0ull && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != (uint32_t)(k >> 32))) ? 1u : 0u;
+}
+// node[t], off[t] for the heads; add_d for every pair; counts = {touched nodes, pairs}
+__global__ void hnsw_csr_kernel(const uint64_t *keys, const uint32_t *flags, const uint32_t *pos, uint32_t n,
+                                uint32_t *node, uint32_t *off, float *add_d, uint32_t *counts) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  const bool valid = k != ~0ull;
+  if (i == 0 && !valid) { counts[0] = 0; counts[1] = 0; off[0] = 0; }
+  if (!valid) return;
+  add_d[i] = f32_from_order_key((uint32_t)k);
+  if (flags[i]) { node[pos[i]] = (uint32_t)(k >> 32); off[pos[i]] = i; }
+  if (i == n - 1 || keys[i + 1] == ~0ull) {        // the last pair
+    const uint32_t T = pos[i] + flags[i];
+    counts[0] = T;
+    counts[1] = i + 1;
+    off[T] = i + 1;
+  }
+}
+// the lists a batch wrote, compacted for the host: rows 0..n_new-1 = the new points, then the touched nodes
+__global__ void hnsw_gather_lists_kernel(uint32_t *dst, const uint32_t *links0, uint32_t stride, uint32_t first,
+                                         uint32_t n_new, const uint32_t *node, const uint32_t *counts) {
+  const uint64_t rows = (uint64_t)n_new + counts[0];
+  const uint64_t total = rows * stride;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t r = (uint32_t)(t / stride), w = (uint32_t)(t % stride);
+    const uint32_t id = r < n_new ? first + r : node[r - n_new];
+    dst[t] = links0[(size_t)id * stride + w];
+  }
+}
+}  // namespace
+
+size_t hnsw_group_tmp_bytes(uint32_t n_pairs) {
+  size_t sort_b = 0, scan_b = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_b, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_pairs, 0, 64, nullptr);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_pairs,
+                                         nullptr);
+  return std::max(sort_b, scan_b) + 256;
+}
+
+// sel_* -> CSR {node, off, add_p, add_d, counts}; everything on stream s, no host round trip
+hipError_t launch_hnsw_group(const HnswGroupArgs &g, hipStream_t s) {
+  const uint32_t n = g.n_new * g.m;
+  if (n == 0) return hipSuccess;
+  const uint32_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(hnsw_pairs_kernel, dim3(blocks), dim3(256), 0, s, g.sel_id, g.sel_dist, g.sel_n, g.n_new, g.m,
+                     g.first_id, g.keys_a, g.vals_a);
+  size_t tb = g.tmp_bytes;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(g.tmp, tb, g.keys_a, g.keys_b, g.vals_a, g.add_p, (int)n, 0, 64, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(hnsw_heads_kernel, dim3(blocks), dim3(256), 0, s, g.keys_b, n, g.flags);
+  tb = g.tmp_bytes;
+  e = hipcub::DeviceScan::ExclusiveSum(g.tmp, tb, g.flags, g.pos, (int)n, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(hnsw_csr_kernel, dim3(blocks), dim3(256), 0, s, g.keys_b, g.flags, g.pos, n, g.node, g.off, g.add_d,
+                     g.counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_hnsw_gather_lists(uint32_t *dst, const uint32_t *links0, uint32_t stride, uint32_t first, uint32_t n_new,
+                                    const uint32_t *node, const uint32_t *counts, hipStream_t s) {
+  hipLaunchKernelGGL(hnsw_gather_lists_kernel, dim3(2048), dim3(256), 0, s, dst, links0, stride, first, n_new, node, counts);
+  return hipGetLastError();
+}
+
 size_t hnsw_build_lds_bytes(const HnswBuildArgs &a, bool relink) {
   const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((relink ? 256 * 4 : 0) + a.max_keep + 3) / 4;
   return per_wave_f4 * 16 * 4;
@@ -189,7 +281,7 @@ hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, hipStream_t s) {
 }
 
 hipError_t launch_hnsw_relink(const HnswBuildArgs &a, bool l2, hipStream_t s) {
-  if (a.n_touched == 0) return hipSuccess;
+  if (a.n_touched == 0) return hipSuccess;    // with a.counts: n_touched is the upper bound (n_new * M)
   const size_t lds = hnsw_build_lds_bytes(a, true);
   const void *fn = l2 ? reinterpret_cast<const void *>(&hnsw_relink_kernel<true>)
                       : reinterpret_cast<const void *>(&hnsw_relink_kernel<false>);

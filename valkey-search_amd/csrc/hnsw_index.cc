@@ -498,9 +498,10 @@ class HnswIndex final : public Index {
     }
     if (getenv("VK_HNSW_BUILD_VERBOSE"))
       fprintf(stderr,
-              "[vk] device build: %llu batches; register+flush %.2fs, search %.2fs, select %.2fs, group %.2fs, relink+sync %.2fs, "
-              "upper levels (host) %.2fs; beam-search pool overflows %llu, evals/point %.0f\n",
-              (unsigned long long)bt_.batches, bt_.reg, bt_.search, bt_.select, bt_.group, bt_.relink, bt_.upper,
+              "[vk] device build: %llu batches; register+flush %.2fs, beam search %.2fs, select+group+relink+gather %.2fs, "
+              "host table update %.2fs, waiting for the host's upper-level linking %.2fs; beam-search pool overflows %llu, "
+              "evals/point %.0f\n",
+              (unsigned long long)bt_.batches, bt_.reg, bt_.search, bt_.select, bt_.relink, bt_.upper,
               (unsigned long long)bt_.overflow, bt_.points ? (double)bt_.evals / bt_.points : 0.0);
     return Status::Ok();
   }
@@ -545,7 +546,24 @@ class HnswIndex final : public Index {
       bt_.search += now_s() - t0;
       t0 = now_s();
     }
-    // B: neighbour selection, writes the new points' own lists
+    // B..E on the device without a host round trip: neighbour selection (writes the new points' own
+    // lists), grouping of the (new point, neighbour) pairs by neighbour (radix sort), reverse links,
+    // and a compact copy of every list the batch wrote for the host's table
+    const size_t np = (size_t)P * M;                       // pairs, upper bound
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t tmp_bytes = hnsw_group_tmp_bytes((uint32_t)np);
+    const size_t lists_words = ((size_t)P + np) * l0s;
+    size_t o_sel_id = 0, o_sel_d = o_sel_id + al(np * 4), o_sel_n = o_sel_d + al(np * 4), o_keys_a = o_sel_n + al((size_t)P * 4),
+           o_keys_b = o_keys_a + al(np * 8), o_vals_a = o_keys_b + al(np * 8), o_add_p = o_vals_a + al(np * 4),
+           o_add_d = o_add_p + al(np * 4), o_flags = o_add_d + al(np * 4), o_pos = o_flags + al(np * 4),
+           o_off = o_pos + al(np * 4), o_tmp = o_off + al((np + 1) * 4), o_ret = o_tmp + al(tmp_bytes);
+    // returned to the host in one copy: [counts 2 | node np | lists]
+    const size_t ret_bytes = al(8) + al(np * 4) + lists_words * 4;
+    VK_TRY(ctx->d_part_d.ensure(o_ret + ret_bytes));
+    char *db = ctx->d_part_d.as<char>();
+    uint32_t *d_counts = reinterpret_cast<uint32_t *>(db + o_ret);
+    uint32_t *d_node = reinterpret_cast<uint32_t *>(db + o_ret + al(8));
+    uint32_t *d_lists = reinterpret_cast<uint32_t *>(db + o_ret + al(8) + al(np * 4));
     HnswBuildArgs b{};
     b.rows = static_cast<const float *>(store_.d_rows());
     b.row_stride_f = store_.stride_f();
@@ -559,16 +577,41 @@ class HnswIndex final : public Index {
     b.cand_ld = efc;
     b.n_new = P;
     b.first_id = first;
-    VK_TRY(ctx->d_part_d.ensure((size_t)P * M * 4));
-    VK_TRY(ctx->d_part_l.ensure((size_t)P * M * 4 + (size_t)P * 4));
-    b.sel_dist = ctx->d_part_d.as<float>();
-    b.sel_id = ctx->d_part_l.as<uint32_t>();
-    b.sel_n = b.sel_id + (size_t)P * M;
+    b.sel_id = reinterpret_cast<uint32_t *>(db + o_sel_id);
+    b.sel_dist = reinterpret_cast<float *>(db + o_sel_d);
+    b.sel_n = reinterpret_cast<uint32_t *>(db + o_sel_n);
     VK_HIP_TRY(launch_hnsw_select(b, l2(), s));
-    VK_TRY(ctx->h_out_d.ensure((size_t)P * M * 4));
-    VK_TRY(ctx->h_out_l.ensure((size_t)P * M * 4 + (size_t)P * 4));
-    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, b.sel_dist, (size_t)P * M * 4, hipMemcpyDeviceToHost, s));
-    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, b.sel_id, (size_t)P * M * 4 + (size_t)P * 4, hipMemcpyDeviceToHost, s));
+    HnswGroupArgs g{};
+    g.sel_id = b.sel_id;
+    g.sel_dist = b.sel_dist;
+    g.sel_n = b.sel_n;
+    g.n_new = P;
+    g.m = M;
+    g.first_id = first;
+    g.keys_a = reinterpret_cast<uint64_t *>(db + o_keys_a);
+    g.keys_b = reinterpret_cast<uint64_t *>(db + o_keys_b);
+    g.vals_a = reinterpret_cast<uint32_t *>(db + o_vals_a);
+    g.add_p = reinterpret_cast<uint32_t *>(db + o_add_p);
+    g.add_d = reinterpret_cast<float *>(db + o_add_d);
+    g.flags = reinterpret_cast<uint32_t *>(db + o_flags);
+    g.pos = reinterpret_cast<uint32_t *>(db + o_pos);
+    g.off = reinterpret_cast<uint32_t *>(db + o_off);
+    g.node = d_node;
+    g.counts = d_counts;
+    g.tmp = db + o_tmp;
+    g.tmp_bytes = tmp_bytes;
+    VK_HIP_TRY(launch_hnsw_group(g, s));
+    b.node = g.node;
+    b.off = g.off;
+    b.add_p = g.add_p;
+    b.add_d = g.add_d;
+    b.counts = g.counts;
+    b.n_touched = (uint32_t)np;
+    b.max_keep = maxM0;
+    VK_HIP_TRY(launch_hnsw_relink(b, l2(), s));
+    VK_HIP_TRY(launch_hnsw_gather_lists(d_lists, d_links0_.as<uint32_t>(), l0s, first, P, d_node, d_counts, s));
+    VK_TRY(ctx->h_q.ensure(ret_bytes));
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_q.p, db + o_ret, ret_bytes, hipMemcpyDeviceToHost, s));
     // while the device works on level 0: the upper levels of the batch's points on the host, in
     // parallel like concurrent addPoint calls (the kernels above were enqueued with the entry point
     // and level of the graph as flushed, so a new entry point made here is seen from the next batch on)
@@ -585,7 +628,7 @@ class HnswIndex final : public Index {
         if (i >= ups.size() || failed.load()) return;
         Status st = graph_->bulk_link_upper(ups[i]);
         if (!st.ok()) {
-          std::lock_guard<std::mutex> g(err_mu);
+          std::lock_guard<std::mutex> g2(err_mu);
           if (!failed.exchange(true)) err = st;
         }
       }
@@ -602,71 +645,19 @@ class HnswIndex final : public Index {
     VK_HIP_TRY(hipStreamSynchronize(s));
     bt_.select += now_s() - t0;
     t0 = now_s();
-    // C: reverse links, grouped by the selected node
-    struct Rev { uint64_t key; uint32_t p; uint32_t s; float d; };   // key = node | order-preserving distance
-    std::vector<Rev> rev;
-    rev.reserve((size_t)P * M);
-    {
-      const float *sd = ctx->h_out_d.as<float>();
-      const uint32_t *si = ctx->h_out_l.as<uint32_t>();
-      const uint32_t *sn = si + (size_t)P * M;
-      for (uint32_t p = 0; p < P; ++p)
-        for (uint32_t t = 0; t < sn[p]; ++t) {
-          const float d = sd[(size_t)p * M + t];
-          uint32_t u;
-          memcpy(&u, &d, 4);
-          u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-          const uint32_t sid = si[(size_t)p * M + t];
-          rev.push_back(Rev{((uint64_t)sid << 32) | u, first + p, sid, d});
-        }
-    }
-    std::sort(rev.begin(), rev.end(), [](const Rev &x, const Rev &y) { return x.key != y.key ? x.key < y.key : x.p < y.p; });
-    std::vector<uint32_t> node, off;
-    for (size_t i = 0; i < rev.size(); ++i)
-      if (i == 0 || rev[i].s != rev[i - 1].s) { node.push_back(rev[i].s); off.push_back((uint32_t)i); }
-    off.push_back((uint32_t)rev.size());
-    const uint32_t T = (uint32_t)node.size();
-    bt_.group += now_s() - t0;
-    t0 = now_s();
-    if (T) {
-      // [node T | off T+1 | add_p R | add_d R]
-      const size_t R = rev.size(), words = (size_t)T + T + 1 + 2 * R;
-      VK_TRY(ctx->h_tmp.ensure(words * 4));
-      VK_TRY(ctx->d_idx.ensure(words * 4));
-      uint32_t *h = ctx->h_tmp.as<uint32_t>();
-      memcpy(h, node.data(), (size_t)T * 4);
-      memcpy(h + T, off.data(), (size_t)(T + 1) * 4);
-      uint32_t *hp = h + 2 * T + 1;
-      float *hd = reinterpret_cast<float *>(hp + R);
-      for (size_t i = 0; i < R; ++i) { hp[i] = rev[i].p; hd[i] = rev[i].d; }
-      VK_HIP_TRY(hipMemcpyAsync(ctx->d_idx.p, h, words * 4, hipMemcpyHostToDevice, s));
-      const uint32_t *d = ctx->d_idx.as<uint32_t>();
-      b.node = d;
-      b.off = d + T;
-      b.add_p = d + 2 * T + 1;
-      b.add_d = reinterpret_cast<const float *>(d + 2 * T + 1 + R);
-      b.n_touched = T;
-      b.max_keep = maxM0;
-      VK_HIP_TRY(launch_hnsw_relink(b, l2(), s));
-    }
-    // keep the host table in step: read back the lists this batch wrote (new points + touched nodes)
-    {
-      const size_t nsync = (size_t)P + T;
-      VK_TRY(ctx->h_idx.ensure(nsync * 4));
-      uint32_t *hi = ctx->h_idx.as<uint32_t>();
-      for (uint32_t i = 0; i < P; ++i) hi[i] = first + i;
-      for (uint32_t i = 0; i < T; ++i) hi[P + i] = node[i];
-      VK_TRY(ctx->d_allow.ensure(nsync * 4));
-      VK_TRY(ctx->d_q.ensure(nsync * l0s * 4));
-      VK_TRY(ctx->h_q.ensure(nsync * l0s * 4));
-      VK_HIP_TRY(hipMemcpyAsync(ctx->d_allow.p, hi, nsync * 4, hipMemcpyHostToDevice, s));
-      VK_HIP_TRY(launch_gather_u32(ctx->d_q.as<uint32_t>(), d_links0_.as<uint32_t>(), ctx->d_allow.as<uint32_t>(),
-                                   (uint32_t)nsync, l0s, s));
-      VK_HIP_TRY(hipMemcpyAsync(ctx->h_q.p, ctx->d_q.p, nsync * l0s * 4, hipMemcpyDeviceToHost, s));
-      VK_HIP_TRY(hipStreamSynchronize(s));
+    {   // keep the host table in step with what the batch wrote
+      const char *hb = ctx->h_q.as<char>();
+      const uint32_t T = reinterpret_cast<const uint32_t *>(hb)[0];
+      const uint32_t *node = reinterpret_cast<const uint32_t *>(hb + al(8));
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(hb + al(8) + al(np * 4));
       uint32_t *tab = graph_->links0_table();
-      const uint32_t *src = ctx->h_q.as<uint32_t>();
-      for (size_t i = 0; i < nsync; ++i) memcpy(tab + (size_t)hi[i] * l0s, src + i * l0s, (size_t)l0s * 4);
+      const size_t count_now = graph_->count();
+      if (T > np) return Status::Err(VK_ERR_INTERNAL, "device build: inconsistent group count");
+      for (size_t i = 0; i < (size_t)P + T; ++i) {
+        const uint32_t id = i < P ? first + (uint32_t)i : node[i - P];
+        if (id >= count_now) return Status::Err(VK_ERR_INTERNAL, "device build: node id out of range");
+        memcpy(tab + (size_t)id * l0s, src + i * l0s, (size_t)l0s * 4);
+      }
     }
     bt_.relink += now_s() - t0;
     t0 = now_s();

@@ -124,8 +124,29 @@ struct HnswBuildArgs {
   const uint32_t *off;         // [n_touched + 1]
   const uint32_t *add_p;       // new point ids, per node ascending by distance
   const float *add_d;
-  uint32_t n_touched;
+  uint32_t n_touched;          // number of touched nodes, or its upper bound when counts != nullptr
+  const uint32_t *counts;      // optional device-side {touched nodes, pairs} (launch_hnsw_group)
 };
+// grouping of the selection output into that CSR on the device (radix sort by (node, distance))
+struct HnswGroupArgs {
+  const uint32_t *sel_id;      // [n_new][m]
+  const float *sel_dist;
+  const uint32_t *sel_n;
+  uint32_t n_new, m, first_id;
+  uint64_t *keys_a, *keys_b;   // [n_new * m] each
+  uint32_t *vals_a;            // [n_new * m]
+  uint32_t *flags, *pos;       // [n_new * m] each
+  void *tmp;                   // hnsw_group_tmp_bytes(n_new * m)
+  size_t tmp_bytes;
+  uint32_t *node, *off;        // out: [n_new * m], [n_new * m + 1]
+  uint32_t *add_p;             // out: [n_new * m]
+  float *add_d;                // out: [n_new * m]
+  uint32_t *counts;            // out: [2]
+};
+size_t hnsw_group_tmp_bytes(uint32_t n_pairs);
+hipError_t launch_hnsw_group(const HnswGroupArgs &g, hipStream_t s);
+hipError_t launch_hnsw_gather_lists(uint32_t *dst, const uint32_t *links0, uint32_t stride, uint32_t first, uint32_t n_new,
+                                    const uint32_t *node, const uint32_t *counts, hipStream_t s);
 size_t hnsw_build_lds_bytes(const HnswBuildArgs &a, bool relink);
 hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, hipStream_t s);
 hipError_t launch_hnsw_relink(const HnswBuildArgs &a, bool l2, hipStream_t s);
