@@ -513,7 +513,20 @@ class FlatIndex final : public Index {
   // K4 launch: persistent grid of ~one block per CU, nrp row partitions x nqt query tiles of 32
   Status scan_gemm(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
                    uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s) {
+    // pre-pass (this kernel over the first rows): a valid bound on every query's k-th best distance, so the per-lane
+    // lists of K4 start gated instead of accepting everything until they have filled
+    const float *init_bound = nullptr;
+    if (gemm_prepass_rows_ && count >= 8 * gemm_prepass_rows_ && k <= 10 && !in_prepass_) {
+      in_prepass_ = true;   // the same kernel over the first rows only
+      Status ps = scan_gemm(ctx, d_q, nq, k, gemm_prepass_rows_, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
+      in_prepass_ = false;
+      VK_TRY(ps);
+      VK_TRY(ctx->d_stats.ensure(std::max<size_t>(32, nq * 4)));
+      VK_HIP_TRY(launch_kth_bound(d_out_d, d_out_n, (uint32_t)k, (uint32_t)nq, ctx->d_stats.as<float>(), s));
+      init_bound = ctx->d_stats.as<float>();
+    }
     FlatGemmArgs g{};
+    g.init_bound = init_bound;
     g.rows = store_.d_rows();
     g.bf16 = store_.bf16() ? 1 : 0;
     g.labels = store_.d_labels();
@@ -571,6 +584,8 @@ class FlatIndex final : public Index {
   std::shared_mutex rw_;
   // K4 lockstep window in row tiles (see FlatGemmArgs::lockstep); VK_GEMM_LOCKSTEP=0 turns it off
   uint32_t gemm_lockstep_ = getenv("VK_GEMM_LOCKSTEP") ? (uint32_t)atoi(getenv("VK_GEMM_LOCKSTEP")) : 1;
+  uint64_t gemm_prepass_rows_ = getenv("VK_GEMM_PREPASS") ? (uint64_t)atoll(getenv("VK_GEMM_PREPASS")) : 16384;
+  static thread_local bool in_prepass_;
   uint32_t gemm_contig_ = getenv("VK_GEMM_CONTIG") ? (uint32_t)atoi(getenv("VK_GEMM_CONTIG")) : 1;
   bool force_scan_ = getenv("VK_FLAT_FORCE_SCAN") != nullptr;   // A/B switch for benchmarks: VALU scan for every batch size
   std::unordered_map<uint64_t, uint32_t> slot_of_;  // dict_external_to_internal
@@ -578,6 +593,7 @@ class FlatIndex final : public Index {
   uint64_t capacity_;                                // data_->getCapacity()
 };
 
+thread_local bool FlatIndex::in_prepass_ = false;
 thread_local const float *FlatIndex::lb_dist_ = nullptr;
 thread_local const uint64_t *FlatIndex::lb_label_ = nullptr;
 

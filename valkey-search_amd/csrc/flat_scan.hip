@@ -319,4 +319,14 @@ hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipSt
   return hipLaunchKernel(f, dim3(blocks), dim3(256), params, lds, s);
 }
 
+__global__ void kth_bound_kernel(const float *out_dist, const uint32_t *out_n, uint32_t k, uint32_t nq, float *bound) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq) bound[q] = out_n[q] >= k ? out_dist[(size_t)q * k + k - 1] : __builtin_inff();
+}
+hipError_t launch_kth_bound(const float *out_dist, const uint32_t *out_n, uint32_t k, uint32_t nq, float *bound, hipStream_t s) {
+  if (nq == 0) return hipSuccess;
+  hipLaunchKernelGGL(kth_bound_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, out_dist, out_n, k, nq, bound);
+  return hipGetLastError();
+}
+
 }  // namespace vk

@@ -45,6 +45,7 @@ struct FlatGemmArgs {
   // per-query pruning bound shared by every list of the launch: order-preserving key of the
   // smallest k-th-best distance any FULL list has reached (0xFF800000 = +inf before the launch)
   uint32_t *qbound;           // [nq]
+  const float *init_bound;    // optional [nq]: a valid upper bound of each query's k-th best distance (pre-pass)
   uint32_t contig;            // 1: a row partition owns a contiguous range of tiles, 0: tiles rp, rp+nrp, ...
 };
 size_t flat_gemm_lds_bytes(uint32_t row_stride_f);
@@ -164,5 +165,7 @@ int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e);
 hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, int e, hipStream_t s);
 hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s);
 hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipStream_t s);
+// bound[q] = out_dist[q][k-1] if the query found k entries, +inf otherwise
+hipError_t launch_kth_bound(const float *out_dist, const uint32_t *out_n, uint32_t k, uint32_t nq, float *bound, hipStream_t s);
 
 }  // namespace vk
