@@ -261,7 +261,7 @@ __device__ __forceinline__ void stage_mfma(f32x16 (&acc)[16], const Frag f) {
 // stages; needs stages % 4 == 0, i.e. a row stride that is a multiple of 128 floats) with two ways
 // of placing the loads; 3 = two sets with the hand placement of 2
 template <int kAblate, int kMode, bool kRegList, bool kBf16>
-__global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
+__device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
   constexpr bool kDeep = kMode == 1 || kMode == 2 || kMode == 4;
   constexpr bool kInPlace = kMode >= 4 && kMode <= 6;
   extern __shared__ float lds[];
@@ -620,6 +620,17 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
 #undef VK_MFMA4
 }
 
+template <int kAblate, int kMode, bool kRegList, bool kBf16>
+__global__ __launch_bounds__(256, 1) void flat_gemm_kernel(FlatGemmArgs a) {
+  flat_gemm_body<kAblate, kMode, kRegList, kBf16>(a);
+}
+// the same code under its own name for the pre-pass over the first rows (FlatIndex::scan_gemm), so that
+// per-kernel profiles do not average a 0.1 ms launch into the 37 ms one
+template <bool kRegList, bool kBf16>
+__global__ __launch_bounds__(256, 1) void flat_gemm_prepass_kernel(FlatGemmArgs a) {
+  flat_gemm_body<0, 7, kRegList, kBf16>(a);
+}
+
 size_t flat_gemm_lds_bytes(uint32_t row_stride_f) {
   return ((size_t)kTileQ * (row_stride_f + 4) + (size_t)kXBufs * kTileRows * kXStride) * 4;
 }
@@ -638,7 +649,11 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
   const int mode = mode_env == 7 || mode_env == 8 ? mode_env : 0;
   static const int reg_env = getenv("VK_GEMM_REGLIST") ? atoi(getenv("VK_GEMM_REGLIST")) : 1;
   const bool reg = reg_env && a.k <= (uint32_t)kRegCap;
-  const void *fn = ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1, 7, false, false>)
+  const void *fn = a.prepass && !ablate ? (a.bf16 ? (reg ? reinterpret_cast<const void *>(&flat_gemm_prepass_kernel<true, true>)
+                                                          : reinterpret_cast<const void *>(&flat_gemm_prepass_kernel<false, true>))
+                                                  : (reg ? reinterpret_cast<const void *>(&flat_gemm_prepass_kernel<true, false>)
+                                                          : reinterpret_cast<const void *>(&flat_gemm_prepass_kernel<false, false>)))
+                 : ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1, 7, false, false>)
                  : ablate == 2 ? reinterpret_cast<const void *>(&flat_gemm_kernel<2, 7, false, false>)
                  : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3, 7, false, false>)
                  : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4, 7, false, false>)

@@ -527,6 +527,7 @@ class FlatIndex final : public Index {
     }
     FlatGemmArgs g{};
     g.init_bound = init_bound;
+    g.prepass = in_prepass_ ? 1 : 0;
     g.rows = store_.d_rows();
     g.bf16 = store_.bf16() ? 1 : 0;
     g.labels = store_.d_labels();

@@ -45,6 +45,7 @@ struct FlatGemmArgs {
   // per-query pruning bound shared by every list of the launch: order-preserving key of the
   // smallest k-th-best distance any FULL list has reached (0xFF800000 = +inf before the launch)
   uint32_t *qbound;           // [nq]
+  uint32_t prepass;           // 1: this launch is the pre-pass (same code, separate kernel name)
   const float *init_bound;    // optional [nq]: a valid upper bound of each query's k-th best distance (pre-pass)
   uint32_t contig;            // 1: a row partition owns a contiguous range of tiles, 0: tiles rp, rp+nrp, ...
 };
