@@ -162,10 +162,17 @@ struct LaneOff { uint32_t o0, o1, o2, o3; };   // in elements
 // bf16 rows (kBf16): a stage of a row is 32 elements = 64 B, so the wave's 32 x 64 B are 128 16-B
 // pieces, 2 per lane: idx = lane + 64*u -> row idx/4, piece idx%4 (8 elements each); they are widened
 // to f32 (<< 16, exact) on the way into LDS, so everything behind the staging ring is the f32 kernel.
+// which of the first 16 rows a lane stages (4 lanes per row): the 16 lanes that share an LDS store pass
+// take rows {2G, 2G+1, 2G+8, 2G+9}, so their 16-B stores land in 16 different bank groups with the
+// 36-dword row stride ((9*row + 2*piece) mod 16 is then a permutation) -- rows in plain order conflict 2-way
+__device__ __forceinline__ uint32_t bf16_lane_row(uint32_t lane) {
+  const uint32_t G = lane >> 4, rr = (lane >> 2) & 3;
+  return 2 * G + (rr & 1) + 8 * (rr >> 1);
+}
 template <bool kBf16>
 __device__ __forceinline__ LaneOff lane_offsets(uint32_t lane, uint32_t row_stride_e) {
   if constexpr (kBf16) {
-    const uint32_t o = (lane >> 2) * row_stride_e + (lane & 3) * 8;
+    const uint32_t o = bf16_lane_row(lane) * row_stride_e + (lane & 3) * 8;
     return LaneOff{o, o + 16 * row_stride_e, 0, 0};
   } else {
     const uint32_t o = (lane >> 3) * row_stride_e + (lane & 7) * 4;
@@ -209,7 +216,7 @@ __device__ __forceinline__ void stage_store(float *buf, uint32_t lane, const Stg
     float4 a0, a1, b0, b1;
     widen8(s.v0, a0, a1);
     widen8(s.v1, b0, b1);
-    float *p0 = buf + (lane >> 2) * kXStride + (lane & 3) * 8;
+    float *p0 = buf + bf16_lane_row(lane) * kXStride + (lane & 3) * 8;
     float *p1 = p0 + 16 * kXStride;
     *reinterpret_cast<float4 *>(p0) = a0;
     *reinterpret_cast<float4 *>(p0 + 4) = a1;
