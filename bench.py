@@ -253,18 +253,26 @@ def main():
     ap.add_argument("--hnsw-rows", type=int, default=200_000, help="extra: HNSW leg over the first rows (0 = skip)")
     ap.add_argument("--hnsw-ef", type=int, default=128)
     ap.add_argument("--hnsw-queries", type=int, default=4096)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="test aid: every rank uses cuda:0 (with --backend gloo, two ranks can exercise the sharded path on one GPU)")
+    ap.add_argument("--verify-merge", action="store_true",
+                    help="test aid (N > 1, small --rows): rank 0 also builds the unsharded index and checks the merged answer against it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     N, D, B, K = args.rows, args.dim, args.batch, args.k
     r0 = rank * N // world
@@ -316,13 +324,21 @@ def main():
     def stream_ptr():
         return work_stream.cuda_stream
 
-    def step(nq=B):
-        ix.search_batch_device(Q.data_ptr(), nq, K, out_d.data_ptr(), out_l.data_ptr(), out_n.data_ptr(),
+    def step():
+        ix.search_batch_device(Q.data_ptr(), B, K, out_d.data_ptr(), out_l.data_ptr(), out_n.data_ptr(),
                                stream=stream_ptr())
-        if world > 1:
+        if world > 1 and args.backend != "nccl":      # test aid: gloo has no device all-gather, stage through the host
+            work_stream.synchronize()
+            cd, cl = torch.empty(world * B, K, dtype=torch.float32), torch.empty(world * B, K, dtype=torch.int64)
+            dist.all_gather_into_tensor(cd, out_d.cpu())
+            dist.all_gather_into_tensor(cl, out_l.cpu())
+            all_d.copy_(cd)
+            all_l.copy_(cl)
+        elif world > 1:
             dist.all_gather_into_tensor(all_d, out_d)
             dist.all_gather_into_tensor(all_l, out_l)
-            vsa.merge_topk_device(all_d.data_ptr(), all_l.data_ptr(), world, nq, K, fin_d.data_ptr(),
+        if world > 1:
+            vsa.merge_topk_device(all_d.data_ptr(), all_l.data_ptr(), world, B, K, fin_d.data_ptr(),
                                   fin_l.data_ptr(), fin_n.data_ptr(), local_rank, stream_ptr())
 
     def barrier():
@@ -350,12 +366,15 @@ def main():
     # ---- extra: single-query scan (the memory-bound formulation of the same path) ----
     single = None
     if args.single_query_steps > 0:
-        step(1)
+        sq_d = torch.empty(K, device=device, dtype=torch.float32)       # own buffers: the batch answer stays intact
+        sq_l = torch.empty(K, device=device, dtype=torch.int64)
+        sq_n = torch.empty(1, device=device, dtype=torch.int32)
+        ix.search_batch_device(Q.data_ptr(), 1, K, sq_d.data_ptr(), sq_l.data_ptr(), sq_n.data_ptr(), stream=stream_ptr())
         barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.single_query_steps):
-            ix.search_batch_device(Q.data_ptr(), 1, K, out_d.data_ptr(), out_l.data_ptr(), out_n.data_ptr(),
+            ix.search_batch_device(Q.data_ptr(), 1, K, sq_d.data_ptr(), sq_l.data_ptr(), sq_n.data_ptr(),
                                    stream=stream_ptr())
         e1.record()
         torch.cuda.synchronize()
@@ -452,7 +471,31 @@ def main():
             "build_s": round(t_build, 2),
         }
         print(json.dumps(out))
+    if world > 1 and args.verify_merge:
+        # the n-shard answer must be bit-identical to the 1-shard answer (total order (distance,label))
+        if rank == 0:
+            full = vsa.Index("FLAT", D, "COSINE", initial_cap=N, device_id=local_rank, dtype=args.dtype)
+            fp, fstride = full.device_rows(N)
+            ft = device_view(fp, (N, fstride // 4), device)
+            if fstride != D * 4:
+                ft[:, D:] = 0
+            for lo, x in gen_rows(0, N, D, device):
+                ft[lo: lo + x.shape[0], :D] = x
+            torch.cuda.synchronize()
+            full.commit_device_rows(N, np.arange(N, dtype=np.uint64))
+            fd, fl, fn = full.search_batch(Q.cpu().numpy(), K)
+            same = bool((fl == result_l).all() and (fd.view(np.uint32) == result_d.view(np.uint32)).all())
+            if not same:
+                bad = np.argwhere(fl != result_l)
+                print("verify_merge: %d label mismatches, %d distance mismatches; first at %s: full %s / %s  merged %s / %s" % (
+                    len(bad), int((fd.view(np.uint32) != result_d.view(np.uint32)).sum()), bad[:1].tolist(),
+                    fl[bad[0][0]].tolist() if len(bad) else None, fd[bad[0][0]].tolist() if len(bad) else None,
+                    result_l[bad[0][0]].tolist() if len(bad) else None, result_d[bad[0][0]].tolist() if len(bad) else None),
+                    file=sys.stderr)
+            print(json.dumps({"verify_merge": "bit-identical" if same else "MISMATCH", "shards": world, "rows": N}))
+            assert same
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
