@@ -264,13 +264,13 @@ __device__ __forceinline__ void stage_mfma(f32x16 (&acc)[16], const Frag f) {
 // replaced by a running minimum (no divergent path), 2 = and the HBM loads re-read one hot tile (L2
 // hits only), 3 = no global loads at all, 4 = no LDS stores, 5 = no LDS fragment reads (MFMA +
 // epilogue arithmetic only)
-// kMode: 0 = two register staging sets (HBM loads in flight for ~2 stages); 1, 2 = four sets (~4
-// stages; needs stages % 4 == 0, i.e. a row stride that is a multiple of 128 floats) with two ways
-// of placing the loads; 3 = two sets with the hand placement of 2
+// kMode: 7 = the stage's memory operations pinned between the MFMAs (default), 0 = their placement left
+// to the compiler.  (Tried and dropped: staging straight into LDS with global_load_lds_dwordx4 and a
+// swizzled unpadded ring -- bit-exact, but a DMA completes well over two stages after issue (9 ms of
+// vmcnt stalls per launch; LDS has no room for a deeper ring), and even with the wait removed it was
+// only 1.8 ms faster than the register path.)
 template <int kAblate, int kMode, bool kRegList, bool kBf16>
 __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
-  constexpr bool kDeep = kMode == 1 || kMode == 2 || kMode == 4;
-  constexpr bool kInPlace = kMode >= 4 && kMode <= 6;
   extern __shared__ float lds[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
@@ -346,8 +346,8 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
   // a register that is the target of an in-flight load would wait for the load).
   const LaneOff loff = lane_offsets<kBf16>(lane, a.row_stride_f);
   StreamPos ld{first_tile * kTileRows + wave * 32, 0, total};   // next stage to fetch from HBM (this wave's rows)
-  Stg stg_a, stg_b, stg_c, stg_d;
-  // prologue: stages 0 and 1 straight to LDS, the next one (kDeep: three) left in registers.  A
+  Stg stg_a, stg_b;
+  // prologue: stages 0 and 1 straight to LDS, the next one left in registers.  A
   // stream has at least two stages; loads past its end re-read the last stage and are unused.
   stg_a = stage_load<kBf16>(a, loff, ld);
   stage_store<kBf16>(lds_x, lane, stg_a);
@@ -355,21 +355,9 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
   stg_a = stage_load<kBf16>(a, loff, ld);
   stage_store<kBf16>(lds_x + kBufFloats, lane, stg_a);
   stream_advance(ld, stages, tile_step_rows);
-  if constexpr (kDeep) {
-    // iteration i loads into set i%4 and stores set (i+1)%4: sets b, c, d hold stages 2, 3, 4
-    stg_b = stage_load<kBf16>(a, loff, ld);
-    stream_advance(ld, stages, tile_step_rows);
-    stg_c = stage_load<kBf16>(a, loff, ld);
-    stream_advance(ld, stages, tile_step_rows);
-    stg_d = stage_load<kBf16>(a, loff, ld);
-    stream_advance(ld, stages, tile_step_rows);
-    stg_a = stg_d;
-  } else {
-    stg_a = stage_load<kBf16>(a, loff, ld);
-    stg_b = stg_a;
-    stg_c = stg_d = stg_a;
-    stream_advance(ld, stages, tile_step_rows);
-  }
+  stg_a = stage_load<kBf16>(a, loff, ld);
+  stg_b = stg_a;
+  stream_advance(ld, stages, tile_step_rows);
   __syncthreads();                                       // the shared Q tile is in place
 
   const uint32_t x_off = li * kXStride + kk * 16;
@@ -387,41 +375,16 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
   {                                                                                               \
     /* HBM loads for a later stage, LDS fragment reads for stage +1, this stage's 16 MFMAs        */ \
     /* (operands fetched one stage ago), LDS store of the oldest loads in flight.                 */ \
-    /* kMode 0: placement left to the compiler (its own schedule beat hand placement for the      */ \
-    /* two-set pipeline).  kMode 1/2: four staging sets; at the VGPR limit the scheduler sinks    */ \
-    /* the loads towards their use, so they are pinned at the top of the stage.                   */ \
     const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
     if constexpr (kAblate < 2) SNEW = stage_load<kBf16>(a, loff, ld);                                    \
     if constexpr (kAblate == 2) { StreamPos hot = ld; hot.tile_row0 = wave * 32; SNEW = stage_load<kBf16>(a, loff, hot); } \
     stream_advance(ld, stages, tile_step_rows);                                                   \
-    if constexpr (kMode == 1) {                                                                   \
-      NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk);                          \
-      __builtin_amdgcn_sched_barrier(0);                                                          \
-      stage_mfma<ZERO>(acc, F);                                                                   \
-      stage_store<kBf16>(lds_x + wbuf * kBufFloats, lane, SOLD);                                         \
-    } else {                                                                                      \
+    {                                                                                             \
       stage_mfma<ZERO>(acc, F);                                                                   \
       if constexpr (kAblate < 5) NF = frag_load(lds_x + rbuf * kBufFloats + x_off, q_row, nst, kk); \
       if constexpr (kAblate < 4) stage_store<kBf16>(lds_x + wbuf * kBufFloats, lane, SOLD);              \
     }                                                                                             \
-    if constexpr (kMode == 8) {                                                                   \
-      /* as 7, but the LDS stores go last (M V x4 | R R R R | M x4 | R R | M x4 | R R | M W x4):   */ \
-      /* the staged loads get 2.0 instead of 1.6 stages to arrive                                  */ \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                        \
-      }                                                                                           \
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                          \
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                          \
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                          \
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                        \
-      }                                                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                          \
-    } else if constexpr (kMode == 7) {                                                            \
+    if constexpr (kMode == 7) {                                                            \
       /* M V M V M V M V | R R R R | M M M M | R R | M W M W M W M W | R R | M M M M: every       */ \
       /* fragment of the next stage is requested >= 4 MFMAs before this stage ends                 */ \
       _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
@@ -438,77 +401,7 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                          \
       __builtin_amdgcn_sched_barrier(0);                                                          \
-    } else if constexpr (kMode >= 2) {                                                            \
-      /* MFMA k followed by: a global load (k < 4), an LDS fragment read (4 <= k < 12), an LDS    */ \
-      /* store (k >= 12) */                                                                       \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                        \
-      }                                                                                           \
-      _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-      }                                                                                           \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                        \
-      }                                                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                          \
     }                                                                                             \
-    rbuf = rbuf == 2 ? 0u : rbuf + 1;                                                             \
-    wbuf = wbuf == 2 ? 0u : wbuf + 1;                                                             \
-  }
-
-  // kMode 4/5/6: ONE fragment set, refreshed in place -- the operands of class group p are re-read
-  // from LDS for the next stage right after the four MFMAs that consumed them, which frees VGPRs
-  // (kMode 4 spends them on two extra staging sets).  Issue order asked of the scheduler:
-  //   M V M V M V M V | R.. | M M M M | R R | M W M W M W M W | R R | M M M M | (R R)
-  // sched_group_barrier takes ANY MFMA of the region, so a group-3 MFMA may be pulled to the front
-  // of the stage: kMode 6 therefore double-buffers group 3 (F3 = this stage, NF3 = next stage, read
-  // early), so that every operand of a stage is in flight well before the stage begins.
-#define VK_GEMM_STAGE_IP(ZERO, ST, SNEW, SOLD, F3A, F3B, NF3A, NF3B)                              \
-  {                                                                                               \
-    constexpr bool kZeroC = ZERO;                                                                 \
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
-    const uint32_t nst = (ST) + 1 == stages ? 0u : (ST) + 1;                                      \
-    const float *xn = lds_x + rbuf * kBufFloats + x_off;                                          \
-    const float *qn = q_row + (nst * 2 + kk) * 16;                                                \
-    SNEW = stage_load<kBf16>(a, loff, ld);                                                               \
-    stream_advance(ld, stages, tile_step_rows);                                                   \
-    VK_MFMA4(0, f0.a0, f0.b0)                                                                     \
-    f0.a0 = *reinterpret_cast<const float4 *>(xn);                                                \
-    f0.b0 = *reinterpret_cast<const float4 *>(qn);                                                \
-    if constexpr (kMode == 6) {                                                                   \
-      NF3A = *reinterpret_cast<const float4 *>(xn + 12);                                          \
-      NF3B = *reinterpret_cast<const float4 *>(qn + 12);                                          \
-    }                                                                                             \
-    VK_MFMA4(1, f0.a1, f0.b1)                                                                     \
-    f0.a1 = *reinterpret_cast<const float4 *>(xn + 4);                                            \
-    f0.b1 = *reinterpret_cast<const float4 *>(qn + 4);                                            \
-    VK_MFMA4(2, f0.a2, f0.b2)                                                                     \
-    stage_store<kBf16>(lds_x + wbuf * kBufFloats, lane, SOLD);                                           \
-    f0.a2 = *reinterpret_cast<const float4 *>(xn + 8);                                            \
-    f0.b2 = *reinterpret_cast<const float4 *>(qn + 8);                                            \
-    VK_MFMA4(3, F3A, F3B)                                                                         \
-    if constexpr (kMode != 6) {                                                                   \
-      F3A = *reinterpret_cast<const float4 *>(xn + 12);                                           \
-      F3B = *reinterpret_cast<const float4 *>(qn + 12);                                           \
-    }                                                                                             \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                          \
-    }                                                                                             \
-    __builtin_amdgcn_sched_group_barrier(0x100, kMode == 6 ? 4 : 2, 0);                           \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                            \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                            \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                          \
-    }                                                                                             \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                            \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                            \
-    if constexpr (kMode != 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
     rbuf = rbuf == 2 ? 0u : rbuf + 1;                                                             \
     wbuf = wbuf == 2 ? 0u : wbuf + 1;                                                             \
   }
@@ -529,37 +422,7 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
     uint32_t bkey = 0xFF800000u;
     if constexpr (!kRegList) bkey = __hip_atomic_load(qbound_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f32x16 acc[16];
-    if constexpr (kInPlace && kDeep) {
-      VK_GEMM_STAGE_IP(true, 0u, stg_a, stg_b, f0.a3, f0.b3, f1.a3, f1.b3)   // accumulators are born from a zero C operand
-      VK_GEMM_STAGE_IP(false, 1u, stg_b, stg_c, f0.a3, f0.b3, f1.a3, f1.b3)
-      VK_GEMM_STAGE_IP(false, 2u, stg_c, stg_d, f0.a3, f0.b3, f1.a3, f1.b3)
-      VK_GEMM_STAGE_IP(false, 3u, stg_d, stg_a, f0.a3, f0.b3, f1.a3, f1.b3)
-      for (uint32_t st = 4; st < stages; st += 4) {
-        VK_GEMM_STAGE_IP(false, st, stg_a, stg_b, f0.a3, f0.b3, f1.a3, f1.b3)
-        VK_GEMM_STAGE_IP(false, st + 1, stg_b, stg_c, f0.a3, f0.b3, f1.a3, f1.b3)
-        VK_GEMM_STAGE_IP(false, st + 2, stg_c, stg_d, f0.a3, f0.b3, f1.a3, f1.b3)
-        VK_GEMM_STAGE_IP(false, st + 3, stg_d, stg_a, f0.a3, f0.b3, f1.a3, f1.b3)
-      }
-    } else if constexpr (kInPlace) {
-      // group 3 ping-pongs between f0.a3/b3 and f1.a3/b3 in kMode 6 (in place in kMode 5)
-      VK_GEMM_STAGE_IP(true, 0u, stg_b, stg_a, f0.a3, f0.b3, f1.a3, f1.b3)
-      VK_GEMM_STAGE_IP(false, 1u, stg_a, stg_b, f1.a3, f1.b3, f0.a3, f0.b3)
-      for (uint32_t st = 2; st < stages; st += 2) {
-        VK_GEMM_STAGE_IP(false, st, stg_b, stg_a, f0.a3, f0.b3, f1.a3, f1.b3)
-        VK_GEMM_STAGE_IP(false, st + 1, stg_a, stg_b, f1.a3, f1.b3, f0.a3, f0.b3)
-      }
-    } else     if constexpr (kDeep) {
-      VK_GEMM_STAGE(true, 0u, f0, f1, stg_a, stg_b)    // accumulators are born from a zero C operand
-      VK_GEMM_STAGE(false, 1u, f1, f0, stg_b, stg_c)
-      VK_GEMM_STAGE(false, 2u, f0, f1, stg_c, stg_d)
-      VK_GEMM_STAGE(false, 3u, f1, f0, stg_d, stg_a)
-      for (uint32_t st = 4; st < stages; st += 4) {
-        VK_GEMM_STAGE(false, st, f0, f1, stg_a, stg_b)
-        VK_GEMM_STAGE(false, st + 1, f1, f0, stg_b, stg_c)
-        VK_GEMM_STAGE(false, st + 2, f0, f1, stg_c, stg_d)
-        VK_GEMM_STAGE(false, st + 3, f1, f0, stg_d, stg_a)
-      }
-    } else {
+    {
       VK_GEMM_STAGE(true, 0u, f0, f1, stg_b, stg_a)    // accumulators are born from a zero C operand
       VK_GEMM_STAGE(false, 1u, f1, f0, stg_a, stg_b)
       for (uint32_t st = 2; st < stages; st += 2) {
@@ -623,7 +486,6 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
     }
   }
 #undef VK_GEMM_STAGE
-#undef VK_GEMM_STAGE_IP
 #undef VK_MFMA4
 }
 
