@@ -13,6 +13,7 @@ ap.add_argument("--dim", type=int, default=768)
 ap.add_argument("--nq", type=int, default=1024)
 ap.add_argument("--ef", type=int, default=128)
 ap.add_argument("--threads", type=int, default=0)
+ap.add_argument("--dtype", default="f32")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 N, D = args.rows, args.dim
@@ -25,7 +26,7 @@ gA = torch.Generator(device=dev); gA.manual_seed(1234)
 A = torch.randn(D, 32, generator=gA, device=dev)
 Q = torch.nn.functional.normalize(torch.randn(args.nq, 32, generator=g, device=dev) @ A.T + 0.05 * torch.randn(args.nq, D, generator=g, device=dev), dim=1).cpu().numpy()
 t = time.time()
-h = vsa.Index("HNSW", D, "COSINE", initial_cap=N, m=16, ef_construction=200, ef_runtime=args.ef, build_threads=args.threads)
+h = vsa.Index("HNSW", D, "COSINE", initial_cap=N, m=16, ef_construction=200, ef_runtime=args.ef, build_threads=args.threads, dtype=args.dtype)
 h.add_batch(hx)
 h.flush()
 tb = time.time() - t

@@ -506,7 +506,7 @@ class HnswIndex final : public Index {
     return Status::Ok();
   }
 
-  struct BuildTimes { double reg = 0, search = 0, select = 0, group = 0, relink = 0, upper = 0; uint64_t batches = 0, overflow = 0, evals = 0, points = 0; };
+  struct BuildTimes { double reg = 0, search = 0, select = 0, relink = 0, upper = 0; uint64_t batches = 0, overflow = 0, evals = 0, points = 0; };
   BuildTimes bt_;
   static double now_s() {
     timespec ts;
