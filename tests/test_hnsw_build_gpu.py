@@ -111,3 +111,21 @@ def test_small_batches_take_the_host_path_unchanged(vsa, oracle):
         d0, l0 = g.search(q, 10, ef=50)
         d1, l1 = o.search(q, 10, ef=50)
         assert l0.tolist() == l1.tolist()
+
+
+def test_batches_with_updates_or_duplicates_take_the_host_path(vsa):
+    """addPoint semantics per element must survive batching: a label that exists (or occurs twice in the
+    batch) is an update, so such a batch goes through the ordinary builder."""
+    n, dim = 9000, 32
+    x = latent(n, dim, 8)
+    g = vsa.Index("HNSW", dim, "L2", initial_cap=n + 100, m=8, ef_construction=60, ef_runtime=40)
+    labels = np.arange(n, dtype=np.uint64)
+    labels[5000] = 17                                  # duplicate inside the batch
+    g.add_batch(x, labels)
+    assert g.stats().count == n - 1                    # label 17 was inserted once and then updated
+    d, l = g.search(x[5000], 1, ef=60)
+    assert l[0] == 17 and d[0] <= 1e-6
+    g.add_batch(x[:6000] * np.float32(0.5), np.arange(6000, dtype=np.uint64))   # 5999 updates + label 5000, which is new
+    assert g.stats().count == n
+    d, l = g.search(x[100] * np.float32(0.5), 1, ef=60)
+    assert l[0] == 100 and d[0] <= 1e-6

@@ -514,8 +514,13 @@ bool HnswGraph::bulk_possible(const uint64_t *labels, size_t n) const {
   if (count_.load() + n > max_elements_) return false;
   if (allow_replace_deleted_ && num_deleted_.load()) return false;   // those inserts reuse tombstoned slots
   std::lock_guard<std::mutex> lk(label_lookup_lock_);
-  for (size_t i = 0; i < n; ++i)
-    if (label_lookup_.count(labels ? labels[i] : (uint64_t)i)) return false;   // an update, not an insert
+  std::unordered_set<uint64_t> seen;
+  seen.reserve(n * 2);
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t l = labels ? labels[i] : (uint64_t)i;
+    if (label_lookup_.count(l)) return false;       // an update, not an insert
+    if (!seen.insert(l).second) return false;       // the same label twice in one batch: the second is an update
+  }
   return true;
 }
 
