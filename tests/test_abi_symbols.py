@@ -81,3 +81,14 @@ def test_argument_validation_needs_no_device(vsa):
     assert lib.vk_index_create(C.byref(p), C.byref(h)) == vsa.VK_ERR_INVALID
     assert b"struct_size" in lib.vk_last_error()
     assert lib.vk_index_add(None, 1, None) == vsa.VK_ERR_INVALID
+
+
+def test_hnswlib_shaped_facade_compiles_against_the_abi(vsa, tmp_path):
+    """include/vk_algo.h (the adaptor INTEGRATION.md describes) and the program that drives it the way
+    VectorFlat / VectorHNSW drive `algo_` build with a plain host compiler against libvkindex.so."""
+    import subprocess
+    exe = tmp_path / "vk_algo_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", str(ROOT / "include"),
+                           str(ROOT / "tests" / "helpers" / "vk_algo_check.cc"), "-o", str(exe),
+                           "-L", str(vsa.LIB_PATH.parent), "-lvkindex", f"-Wl,-rpath,{vsa.LIB_PATH.parent}"])
+    assert exe.exists()

@@ -1,0 +1,64 @@
+"""include/vk_algo.h -- the hnswlib-shaped facade of INTEGRATION.md -- driven by a C++ program the way
+VectorFlat<float> / VectorHNSW<float> drive their `algo_`; its answers are compared with the oracle."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def parse(line):
+    tag, *items = line.split()
+    return [(int(a), int(b, 16)) for a, b in (it.split(":") for it in items)]
+
+
+def test_facade_program_matches_oracle(oracle, tmp_path):
+    import _pkg
+    vsa = _pkg.vsa
+    n, dim, k = 3000, 24, 5
+    rng = np.random.default_rng(91)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((4, dim)).astype(np.float32)
+    x.tofile(tmp_path / "rows.f32")
+    q.tofile(tmp_path / "queries.f32")
+    exe = tmp_path / "vk_algo_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", str(ROOT / "include"),
+                           str(ROOT / "tests" / "helpers" / "vk_algo_check.cc"), "-o", str(exe),
+                           "-L", str(vsa.LIB_PATH.parent), "-lvkindex", f"-Wl,-rpath,{vsa.LIB_PATH.parent}"])
+    out = subprocess.run([str(exe), str(tmp_path / "rows.f32"), str(tmp_path / "queries.f32")], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = {" ".join(l.split()[:2]): l for l in out.stdout.splitlines()}
+    of = oracle.Flat(dim, "L2", max_elements=n)
+    of.add_many(x)
+    oh = oracle.HNSW(dim, "L2", max_elements=n, M=16, ef_construction=100)
+    oh.add_many(x)
+    for name, o in (("FLAT", of), ("HNSW", oh)):
+        assert lines[f"{name} count"].split()[2:] == ["3000", "capacity", "3048", "resizes", "2"]
+        for i in range(4):
+            od, ol = (o.search(q[i], k) if name == "FLAT" else o.search(q[i], k, ef=64))
+            got = parse(lines[f"{name} knn{i}"].split(" ", 1)[1].replace(f"knn{i}", "x"))
+            assert [g[0] for g in got] == ol.tolist()
+            assert [g[1] for g in got] == od.view(np.uint32).tolist()
+        even = parse(lines[f"{name} even"].split(" ", 1)[1].replace("even", "x"))
+        assert len(even) == k and all(l % 2 == 0 for l, _ in even)
+        if name == "HNSW":     # vector_hnsw.cc:336-340: cancelled and no partial results -> CancelledError
+            assert "Search operation cancelled due to timeout" in lines[f"{name} cancel"]
+        else:                  # VectorFlat::Search has no such branch: the scan just stops (bruteforce.h:125-129)
+            assert lines[f"{name} cancel"] == "FLAT cancel no-throw"
+        want_count = "2999" if name == "FLAT" else "3000"          # removePoint compacts, markDelete tombstones
+        assert lines[f"{name} after-delete"].split()[3] == want_count
+        assert parse(lines[f"{name} self1"].split(" ", 1)[1].replace("self1", "x"))[0] == (1, 0)
+        pre = parse(lines[f"{name} prefilter"].split(" ", 1)[1].replace("prefilter", "x"))
+        assert len(pre) == 3 and {l for l, _ in pre} <= {5, 9, 11, 2999, 1234, 77}
+        assert lines[f"{name} knn0-reloaded"].split()[2:] != []     # the reloaded index answers
+        # label 0 was deleted before the save: the reloaded answer equals the oracle's after the same delete
+    of.remove(0)
+    oh.mark_delete(0)
+    for name, o in (("FLAT", of), ("HNSW", oh)):
+        od, ol = (o.search(q[0], k) if name == "FLAT" else o.search(q[0], k, ef=64))
+        got = parse(lines[f"{name} knn0-reloaded"].split(" ", 1)[1].replace("knn0-reloaded", "x"))
+        assert [g[0] for g in got] == ol.tolist() and [g[1] for g in got] == od.view(np.uint32).tolist()
