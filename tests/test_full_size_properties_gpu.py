@@ -1,0 +1,124 @@
+"""BASELINE.json configs[1] at FULL size (FLAT 10M x 768 f32 cosine, k=10), where the oracle cannot scan
+everything in test time: size-independent properties instead --
+  * the two independent device formulations agree bit for bit (single-query scan K3 vs batched MFMA K4),
+  * answers are ascending by (distance, label), complete (k entries) and idempotent,
+  * restricted by a filter to a sample of rows the answer equals the oracle's answer over that sample,
+  * a row queried with itself comes back first at distance 0 (self-retrieval, vector_test.cc:237-291),
+  * the answer over two row shards merged by (distance, label) equals the unsharded answer."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+N, D, K, B = 10_000_000, 768, 10, 64
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    import _pkg
+    from bench import gen_rows, device_view
+    vsa = _pkg.vsa
+    dev = torch.device("cuda", 0)
+    ix = vsa.Index("FLAT", D, "COSINE", initial_cap=N, device_id=0)
+    ptr, stride = ix.device_rows(N)
+    table = device_view(ptr, (N, stride // 4), dev)
+    for lo, x in gen_rows(0, N, D, dev):
+        table[lo:lo + x.shape[0], :D] = x
+    torch.cuda.synchronize()
+    ix.commit_device_rows(N, np.arange(N, dtype=np.uint64))
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    A = torch.randn(D, 32, generator=torch.Generator(device=dev).manual_seed(1234), device=dev)
+    Q = torch.nn.functional.normalize(torch.randn(B, 32, generator=g, device=dev) @ A.T +
+                                      0.05 * torch.randn(B, D, generator=g, device=dev), dim=1).cpu().numpy()
+    return vsa, ix, table, Q
+
+
+def test_scan_and_mfma_kernels_agree_at_full_size(world):
+    vsa, ix, table, Q = world
+    Db, Lb, Nb = ix.search_batch(Q, K)                 # >= 16 queries: K4 (matrix cores)
+    assert (Nb == K).all()
+    for i in range(0, B, 8):                           # one query per call: K3 (scan)
+        d, l = ix.search(Q[i], K)
+        assert l.tolist() == Lb[i].tolist() and d.view(np.uint32).tolist() == Db[i].view(np.uint32).tolist()
+    # ascending by (distance, label); idempotent
+    for i in range(B):
+        pairs = list(zip(Db[i].tolist(), Lb[i].tolist()))
+        assert pairs == sorted(pairs)
+    D2, L2, _ = ix.search_batch(Q, K)
+    assert (L2 == Lb).all() and (D2.view(np.uint32) == Db.view(np.uint32)).all()
+
+
+def test_filtered_answer_equals_oracle_on_the_sample(world, oracle):
+    vsa, ix, table, Q = world
+    S = 60_000
+    rows = np.sort(np.random.default_rng(5).choice(N, S, replace=False)).astype(np.uint64)
+    import torch
+    host = table[torch.from_numpy(rows.astype(np.int64)).to(table.device), :D].cpu().numpy()
+    o = oracle.Flat(D, "COSINE", max_elements=S)
+    o.add_many(np.ascontiguousarray(host), rows)
+    bits = oracle.allow_bitmap(rows, N)
+    Db, Lb, Nb = ix.search_batch(Q[:32], K, allow=bits, allow_nbits=N)      # K4 with a filter
+    for i in range(32):
+        od, ol = o.search(Q[i], K)
+        assert Lb[i, :Nb[i]].tolist() == ol.tolist()
+        assert Db[i, :Nb[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+    d, l = ix.search(Q[0], K, allow=bits, allow_nbits=N)                    # K3 with a filter
+    assert l.tolist() == o.search(Q[0], K)[1].tolist()
+
+
+def test_self_retrieval_and_shard_merge(world):
+    vsa, ix, table, Q = world
+    import torch
+    ids = [0, 1, 4_999_999, 5_000_000, N - 1]
+    for r in ids:
+        row = table[r, :D].cpu().numpy()
+        d, l = ix.search(row, 1)
+        assert l[0] == r and abs(float(d[0])) < 1e-6
+    # two shards by a label filter (rows below / from N/2), merged by (distance, label) == the unsharded answer
+    lo = np.zeros((N + 63) // 64, np.uint64)
+    lo[: N // 2 // 64] = ~np.uint64(0)
+    hi = ~lo
+    Da, La, Na = ix.search_batch(Q[:16], K, allow=lo, allow_nbits=N)
+    Dc, Lc, Nc = ix.search_batch(Q[:16], K, allow=hi, allow_nbits=N)
+    Df, Lf, Nf = ix.search_batch(Q[:16], K)
+    assert (La < N // 2).all() and (Lc >= N // 2).all()
+    for i in range(16):
+        merged = sorted(list(zip(Da[i].tolist(), La[i].tolist())) + list(zip(Dc[i].tolist(), Lc[i].tolist())))[:K]
+        assert merged == list(zip(Df[i].tolist(), Lf[i].tolist()))
+
+
+def test_hnsw_one_million_rows_properties(world):
+    """HNSW M=16 efC=200 over the first 1M rows of the same table (device-assisted build): answers sorted
+    and idempotent, single-query and batched entry points agree, self-retrieval, and recall@10 against the
+    exact FLAT answer over the same rows."""
+    vsa, ix, table, Q = world
+    Nh = 1_000_000
+    host = np.ascontiguousarray(table[:Nh, :D].cpu().numpy())
+    h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=128, device_id=0)
+    h.add_batch(host)
+    assert h.stats().count == Nh and h.stats().max_level >= 4
+    first = np.zeros((Nh + 63) // 64, np.uint64)
+    first[:] = ~np.uint64(0)
+    if Nh % 64:
+        first[-1] = np.uint64((1 << (Nh % 64)) - 1)
+    Dt, Lt, Nt = ix.search_batch(Q, K, allow=first, allow_nbits=Nh)          # exact, same rows
+    Dh, Lh, Nhh = h.search_batch(Q, K, ef=256)
+    recall = np.mean([len(set(Lh[i, :Nhh[i]].tolist()) & set(Lt[i].tolist())) / K for i in range(B)])
+    assert recall >= 0.9, recall
+    for i in range(B):
+        pairs = list(zip(Dh[i, :Nhh[i]].tolist(), Lh[i, :Nhh[i]].tolist()))
+        assert pairs == sorted(pairs) and len(pairs) == K
+    D2, L2, _ = h.search_batch(Q, K, ef=256)
+    assert (L2 == Lh).all() and (D2.view(np.uint32) == Dh.view(np.uint32)).all()
+    for i in range(0, B, 16):
+        d, l = h.search(Q[i], K, ef=256)
+        assert l.tolist() == Lh[i].tolist()
+    Ds, Ls, _ = h.search_batch(host[:2000], 1, ef=128)
+    assert (Ls[:, 0] == np.arange(2000)).mean() >= 0.99
