@@ -129,3 +129,24 @@ def test_batches_with_updates_or_duplicates_take_the_host_path(vsa):
     assert g.stats().count == n
     d, l = g.search(x[100] * np.float32(0.5), 1, ef=60)
     assert l[0] == 100 and d[0] <= 1e-6
+
+
+def test_device_build_with_bf16_rows(vsa, oracle):
+    """bf16 row storage through the device build: recall like the f32 build, and the saved graph (f32 values
+    of the rounded rows) searched by the oracle gives the device's answers."""
+    n, dim = 20000, 64
+    x = latent(n, dim, 9)
+    Q = latent(200, dim, 10)
+    flat = vsa.Index("FLAT", dim, "IP", initial_cap=n, dtype="bf16")
+    flat.add_batch(x)
+    g = vsa.Index("HNSW", dim, "IP", initial_cap=n, m=16, ef_construction=100, ef_runtime=64, dtype="bf16")
+    g.add_batch(x)
+    assert g.stats().count == n
+    rec = recall(g, flat, Q)
+    assert rec >= 0.9, rec
+    chunks = g.save()
+    o = oracle.HNSW.from_saved_chunks(chunks, dim, "IP", 16, ef_construction=100)
+    for q in Q[:20]:
+        d0, l0 = g.search(q, 10, ef=64)
+        d1, l1 = o.search(q, 10, ef=64)
+        assert l0.tolist() == l1.tolist() and d0.view(np.uint32).tolist() == d1.view(np.uint32).tolist()

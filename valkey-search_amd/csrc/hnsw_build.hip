@@ -25,14 +25,15 @@ namespace {
 constexpr uint32_t kFlagMask = 0xFFFF0000u;
 
 // stage row `id` as the wave's LDS query
+template <bool kBf16>
 __device__ __forceinline__ void stage_query(const HnswBuildArgs &a, float4 *qs, uint32_t id, int lane) {
-  const float4 *src = reinterpret_cast<const float4 *>(a.rows + (size_t)id * a.row_stride_f);
-  for (uint32_t i = lane; i < a.chunks * 4; i += kWave) qs[i] = src[i];
+  const char *src = row_base<kBf16>(a.rows, id, a.row_stride_f);
+  for (uint32_t i = lane; i < a.chunks * 4; i += kWave) qs[i] = row_piece<kBf16>(src, i);   // bf16 rows widen here
 }
 
 // getNeighborsByHeuristic2's inner test for one candidate c (already staged in qs): is any kept
 // node closer to c than c is to the base point?  kept ids live in LDS.
-template <bool kL2>
+template <bool kL2, bool kBf16>
 __device__ __forceinline__ bool dominated(const HnswBuildArgs &a, const float4 *qs, const uint32_t *kept, uint32_t nkept,
                                           float dist_to_base, int lane) {
   const int j = lane & 3, rq = lane >> 2;
@@ -40,8 +41,7 @@ __device__ __forceinline__ bool dominated(const HnswBuildArgs &a, const float4 *
     const uint32_t i = base + rq;
     const bool valid = i < nkept;
     const uint32_t sid = kept[valid ? i : 0];
-    const float d = quad_row_distance<kL2, false>(reinterpret_cast<const char *>(a.rows + (size_t)sid * a.row_stride_f), qs,
-                                                  a.chunks, j);
+    const float d = quad_row_distance<kL2, kBf16>(row_base<kBf16>(a.rows, sid, a.row_stride_f), qs, a.chunks, j);
     if (__ballot(valid && d < dist_to_base) != 0) return true;     // hnswalg.h:583-586
   }
   return false;
@@ -51,7 +51,7 @@ __device__ __forceinline__ bool dominated(const HnswBuildArgs &a, const float4 *
 // ---- selection for the new points --------------------------------------------------------------
 // in : cand_id/cand_dist [n_new][ld] ascending by distance (hnsw_search_kernel, ids as u64), cand_n
 // out: links0[first_id + p] = the selected neighbours; sel_* = the same, for the reverse links
-template <bool kL2>
+template <bool kL2, bool kBf16>
 __global__ __launch_bounds__(256) void hnsw_select_kernel(HnswBuildArgs a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void hnsw_select_kernel(HnswBuildArgs a) {
       const float dq = cd[ci];
       bool good = true;
       if (nk) {
-        stage_query(a, qs, c, lane);
-        good = !dominated<kL2>(a, qs, kept, nk, dq, lane);
+        stage_query<kBf16>(a, qs, c, lane);
+        good = !dominated<kL2, kBf16>(a, qs, kept, nk, dq, lane);
       }
       if (good) {
         if (lane == 0) { kept[nk] = c; sel_d[nk] = dq; }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void hnsw_select_kernel(HnswBuildArgs a) {
 // touched node t: s = node[t]; new points add_p[off[t]..off[t+1]) at distances add_d (ascending).
 // Room left: append.  Otherwise the old list (distances to s computed here) and the new points go
 // through the heuristic together with capacity maxM0 (hnswalg.h:706-738).
-template <bool kL2>
+template <bool kL2, bool kBf16>
 __global__ __launch_bounds__(256) void hnsw_relink_kernel(HnswBuildArgs a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -132,13 +132,12 @@ __global__ __launch_bounds__(256) void hnsw_relink_kernel(HnswBuildArgs a) {
   if (cnt + nadd > kCap) nadd = kCap - cnt;                 // additions are sorted: the farthest are dropped
 
   // candidates: old neighbours with their distance to s, then the new points
-  stage_query(a, qs, s, lane);
+  stage_query<kBf16>(a, qs, s, lane);
   for (uint32_t base = 0; base < cnt; base += kRowsPerWave) {
     const uint32_t i = base + rq;
     const bool valid = i < cnt;
     const uint32_t e = ll[1 + (valid ? i : 0)];
-    const float d = quad_row_distance<kL2, false>(reinterpret_cast<const char *>(a.rows + (size_t)e * a.row_stride_f), qs,
-                                                  a.chunks, j);
+    const float d = quad_row_distance<kL2, kBf16>(row_base<kBf16>(a.rows, e, a.row_stride_f), qs, a.chunks, j);
     if (valid && j == 0) { c_d[i] = d; c_id[i] = e; }
   }
   for (uint32_t i = lane; i < nadd; i += kWave) { c_d[cnt + i] = a.add_d[a0 + i]; c_id[cnt + i] = a.add_p[a0 + i]; }
@@ -162,8 +161,8 @@ __global__ __launch_bounds__(256) void hnsw_relink_kernel(HnswBuildArgs a) {
     const float dq = s_d[ci];
     bool good = true;
     if (nk) {
-      stage_query(a, qs, c, lane);
-      good = !dominated<kL2>(a, qs, kept, nk, dq, lane);
+      stage_query<kBf16>(a, qs, c, lane);
+      good = !dominated<kL2, kBf16>(a, qs, kept, nk, dq, lane);
     }
     if (good) {
       if (lane == 0) kept[nk] = c;
@@ -230,6 +229,19 @@ __global__ void hnsw_gather_lists_kernel(uint32_t *dst, const uint32_t *links0, 
 }
 }  // namespace
 
+// bf16 rows -> f32 query block for the beam search (queries are always f32)
+__global__ void hnsw_widen_rows_kernel(const uint16_t *rows, uint32_t stride_e, uint32_t first, uint32_t n, float *out) {
+  const uint64_t total = (uint64_t)n * stride_e;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x)
+    out[t] = __uint_as_float((uint32_t)rows[(size_t)first * stride_e + t] << 16);
+}
+hipError_t launch_hnsw_widen_rows(const void *rows, uint32_t stride_e, uint32_t first, uint32_t n, float *out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(hnsw_widen_rows_kernel, dim3(2048), dim3(256), 0, s, static_cast<const uint16_t *>(rows), stride_e, first,
+                     n, out);
+  return hipGetLastError();
+}
+
 size_t hnsw_group_tmp_bytes(uint32_t n_pairs) {
   size_t sort_b = 0, scan_b = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_b, (const uint64_t *)nullptr, (uint64_t *)nullptr,
@@ -269,10 +281,12 @@ size_t hnsw_build_lds_bytes(const HnswBuildArgs &a, bool relink) {
   return per_wave_f4 * 16 * 4;
 }
 
-hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, hipStream_t s) {
+hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, bool bf16, hipStream_t s) {
   const size_t lds = hnsw_build_lds_bytes(a, false);
-  const void *fn = l2 ? reinterpret_cast<const void *>(&hnsw_select_kernel<true>)
-                      : reinterpret_cast<const void *>(&hnsw_select_kernel<false>);
+  const void *fn = l2 ? (bf16 ? reinterpret_cast<const void *>(&hnsw_select_kernel<true, true>)
+                              : reinterpret_cast<const void *>(&hnsw_select_kernel<true, false>))
+                      : (bf16 ? reinterpret_cast<const void *>(&hnsw_select_kernel<false, true>)
+                              : reinterpret_cast<const void *>(&hnsw_select_kernel<false, false>));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   HnswBuildArgs args = a;
@@ -280,11 +294,13 @@ hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, hipStream_t s) {
   return hipLaunchKernel(fn, dim3((a.n_new + 3) / 4), dim3(256), params, lds, s);
 }
 
-hipError_t launch_hnsw_relink(const HnswBuildArgs &a, bool l2, hipStream_t s) {
+hipError_t launch_hnsw_relink(const HnswBuildArgs &a, bool l2, bool bf16, hipStream_t s) {
   if (a.n_touched == 0) return hipSuccess;    // with a.counts: n_touched is the upper bound (n_new * M)
   const size_t lds = hnsw_build_lds_bytes(a, true);
-  const void *fn = l2 ? reinterpret_cast<const void *>(&hnsw_relink_kernel<true>)
-                      : reinterpret_cast<const void *>(&hnsw_relink_kernel<false>);
+  const void *fn = l2 ? (bf16 ? reinterpret_cast<const void *>(&hnsw_relink_kernel<true, true>)
+                              : reinterpret_cast<const void *>(&hnsw_relink_kernel<true, false>))
+                      : (bf16 ? reinterpret_cast<const void *>(&hnsw_relink_kernel<false, true>)
+                              : reinterpret_cast<const void *>(&hnsw_relink_kernel<false, false>));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   HnswBuildArgs args = a;

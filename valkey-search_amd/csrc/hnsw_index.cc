@@ -468,7 +468,7 @@ class HnswIndex final : public Index {
 
   Status add_batch_device(const uint64_t *labels_in, const float *rows, uint64_t n, bool *handled) {
     *handled = false;
-    if (store_.bf16() || graph_->ef_construction() > 512 || graph_->maxM0() > 192) return Status::Ok();
+    if (graph_->ef_construction() > 512 || graph_->maxM0() > 192) return Status::Ok();
     if ((size_t)store_.stride_f() * 4 * 4 + 8192 > 160 * 1024) return Status::Ok();
     std::vector<uint64_t> iota;
     const uint64_t *labels = labels_in;
@@ -521,6 +521,18 @@ class HnswIndex final : public Index {
     double t0 = now_s();
     bt_.batches += 1;
     bt_.points += P;
+    std::vector<float> rounded;
+    if (store_.bf16()) {   // the host graph must hold what the device holds: rows rounded to bf16 (as add_one does)
+      rounded.resize((size_t)P * dim);
+      for (size_t i = 0; i < rounded.size(); ++i) {
+        uint32_t u;
+        memcpy(&u, rows + i, 4);
+        if (!((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu))) u += 0x7FFFu + ((u >> 16) & 1u);
+        u &= 0xFFFF0000u;
+        memcpy(&rounded[i], &u, 4);
+      }
+      rows = rounded.data();
+    }
     VK_TRY(graph_->bulk_register(rows, labels, P, &first));
     for (uint32_t i = 0; i < P; ++i) VK_TRY(store_.stage_write(first + i, rows + (size_t)i * dim, labels[i]));
     VK_TRY(flush_locked());          // rows, labels, the new (empty) lists, upper lists of earlier batches
@@ -535,6 +547,11 @@ class HnswIndex final : public Index {
     VK_TRY(ctx->d_out_l.ensure((size_t)P * efc * 8));
     VK_TRY(ctx->d_out_n.ensure((size_t)P * 4));
     const float *d_new = static_cast<const float *>(store_.d_rows()) + (size_t)first * store_.stride_f();
+    if (store_.bf16()) {   // the beam search takes f32 queries: widen the new rows into a query block
+      VK_TRY(ctx->d_q.ensure((size_t)P * store_.stride_f() * 4));
+      VK_HIP_TRY(launch_hnsw_widen_rows(store_.d_rows(), store_.stride_f(), first, P, ctx->d_q.as<float>(), s));
+      d_new = ctx->d_q.as<float>();
+    }
     VK_TRY(launch(ctx, d_new, P, efc, efc, nullptr, 0, ctx->d_out_d.as<float>(), ctx->d_out_l.as<uint64_t>(),
                   ctx->d_out_n.as<uint32_t>(), s, true, true));
     if (getenv("VK_HNSW_BUILD_VERBOSE")) {
@@ -565,7 +582,7 @@ class HnswIndex final : public Index {
     uint32_t *d_node = reinterpret_cast<uint32_t *>(db + o_ret + al(8));
     uint32_t *d_lists = reinterpret_cast<uint32_t *>(db + o_ret + al(8) + al(np * 4));
     HnswBuildArgs b{};
-    b.rows = static_cast<const float *>(store_.d_rows());
+    b.rows = store_.d_rows();
     b.row_stride_f = store_.stride_f();
     b.chunks = store_.stride_f() / 16;
     b.links0 = d_links0_.as<uint32_t>();
@@ -580,7 +597,7 @@ class HnswIndex final : public Index {
     b.sel_id = reinterpret_cast<uint32_t *>(db + o_sel_id);
     b.sel_dist = reinterpret_cast<float *>(db + o_sel_d);
     b.sel_n = reinterpret_cast<uint32_t *>(db + o_sel_n);
-    VK_HIP_TRY(launch_hnsw_select(b, l2(), s));
+    VK_HIP_TRY(launch_hnsw_select(b, l2(), store_.bf16(), s));
     HnswGroupArgs g{};
     g.sel_id = b.sel_id;
     g.sel_dist = b.sel_dist;
@@ -608,7 +625,7 @@ class HnswIndex final : public Index {
     b.counts = g.counts;
     b.n_touched = (uint32_t)np;
     b.max_keep = maxM0;
-    VK_HIP_TRY(launch_hnsw_relink(b, l2(), s));
+    VK_HIP_TRY(launch_hnsw_relink(b, l2(), store_.bf16(), s));
     VK_HIP_TRY(launch_hnsw_gather_lists(d_lists, d_links0_.as<uint32_t>(), l0s, first, P, d_node, d_counts, s));
     VK_TRY(ctx->h_q.ensure(ret_bytes));
     VK_HIP_TRY(hipMemcpyAsync(ctx->h_q.p, db + o_ret, ret_bytes, hipMemcpyDeviceToHost, s));

@@ -108,7 +108,7 @@ hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e
 
 // K9 (hnsw_build.hip): level-0 neighbour selection and reverse links for a batch of new points
 struct HnswBuildArgs {
-  const float *rows;           // f32 rows
+  const void *rows;            // f32 or bf16 rows
   uint32_t row_stride_f, chunks;
   uint32_t *links0;            // [cap][l0_stride], updated in place
   uint32_t l0_stride;
@@ -150,8 +150,9 @@ hipError_t launch_hnsw_group(const HnswGroupArgs &g, hipStream_t s);
 hipError_t launch_hnsw_gather_lists(uint32_t *dst, const uint32_t *links0, uint32_t stride, uint32_t first, uint32_t n_new,
                                     const uint32_t *node, const uint32_t *counts, hipStream_t s);
 size_t hnsw_build_lds_bytes(const HnswBuildArgs &a, bool relink);
-hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, hipStream_t s);
-hipError_t launch_hnsw_relink(const HnswBuildArgs &a, bool l2, hipStream_t s);
+hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, bool bf16, hipStream_t s);
+hipError_t launch_hnsw_relink(const HnswBuildArgs &a, bool l2, bool bf16, hipStream_t s);
+hipError_t launch_hnsw_widen_rows(const void *rows, uint32_t stride_e, uint32_t first, uint32_t n, float *out, hipStream_t s);
 
 // scatter rows of u32 words: dst[idx[i]*stride + w] = src[i*stride + w]
 hipError_t launch_scatter_u32(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride,
