@@ -490,11 +490,26 @@ class HnswIndex final : public Index {
     std::unique_lock<std::shared_mutex> lk(rw_);
     (void)hipSetDevice(store_.device());
     bt_ = BuildTimes{};
-    while (pos < n) {
-      const uint64_t count = graph_->count();
-      const uint64_t P = std::min<uint64_t>(n - pos, std::max<uint64_t>(build_min_batch_, std::min<uint64_t>(count / build_frac_, build_max_batch_)));
-      VK_TRY(device_batch(labels + pos, rows + pos * params_.dim, (uint32_t)P));
-      pos += P;
+    // batch b+1 is registered and staged on the host while the device links batch b
+    auto batch_size = [&](uint64_t at) {
+      return std::min<uint64_t>(n - at, std::max<uint64_t>(build_min_batch_, std::min<uint64_t>(graph_->count() / build_frac_, build_max_batch_)));
+    };
+    uint32_t first = 0;
+    uint64_t P = pos < n ? batch_size(pos) : 0;
+    if (P) VK_TRY(prepare_batch(labels + pos, rows + pos * params_.dim, (uint32_t)P, &first));
+    while (P) {
+      const uint64_t npos = pos + P;
+      uint32_t nfirst = 0;
+      uint64_t nP = 0;
+      auto prepare_next = [&]() -> Status {
+        if (npos >= n) return Status::Ok();
+        nP = batch_size(npos);
+        return prepare_batch(labels + npos, rows + npos * params_.dim, (uint32_t)nP, &nfirst);
+      };
+      VK_TRY(device_batch(first, (uint32_t)P, prepare_next));
+      pos = npos;
+      P = nP;
+      first = nfirst;
     }
     if (getenv("VK_HNSW_BUILD_VERBOSE"))
       fprintf(stderr,
@@ -514,13 +529,11 @@ class HnswIndex final : public Index {
     return ts.tv_sec + ts.tv_nsec * 1e-9;
   }
 
-  Status device_batch(const uint64_t *labels, const float *rows, uint32_t P) {
-    const uint32_t dim = params_.dim, M = (uint32_t)graph_->M(), maxM0 = (uint32_t)graph_->maxM0();
-    const uint32_t l0s = maxM0 + 1;
+  // host half of a batch: slots, labels, levels, rows into the graph and the row store's staging area
+  Status prepare_batch(const uint64_t *labels, const float *rows, uint32_t P, uint32_t *first_out) {
+    const uint32_t dim = params_.dim;
     uint32_t first = 0;
-    double t0 = now_s();
-    bt_.batches += 1;
-    bt_.points += P;
+    const double t0 = now_s();
     std::vector<float> rounded;
     if (store_.bf16()) {   // the host graph must hold what the device holds: rows rounded to bf16 (as add_one does)
       rounded.resize((size_t)P * dim);
@@ -535,6 +548,20 @@ class HnswIndex final : public Index {
     }
     VK_TRY(graph_->bulk_register(rows, labels, P, &first));
     for (uint32_t i = 0; i < P; ++i) VK_TRY(store_.stage_write(first + i, rows + (size_t)i * dim, labels[i]));
+    *first_out = first;
+    bt_.reg += now_s() - t0;
+    return Status::Ok();
+  }
+
+  // device half: the batch [first, first + P) is registered and staged; `prepare_next` (the host half of the
+  // following batch) runs while the device works
+  template <class PrepareNext>
+  Status device_batch(uint32_t first, uint32_t P, PrepareNext &&prepare_next) {
+    const uint32_t M = (uint32_t)graph_->M(), maxM0 = (uint32_t)graph_->maxM0();
+    const uint32_t l0s = maxM0 + 1;
+    double t0 = now_s();
+    bt_.batches += 1;
+    bt_.points += P;
     VK_TRY(flush_locked());          // rows, labels, the new (empty) lists, upper lists of earlier batches
     CtxLease lease(pool_);
     SearchCtx *ctx = lease.ctx;
@@ -659,6 +686,7 @@ class HnswIndex final : public Index {
       std::vector<std::thread> &p;
       ~Joiner() { for (auto &t : p) if (t.joinable()) t.join(); }
     } joiner{pool};
+    VK_TRY(prepare_next());          // host work for the next batch, behind the device
     VK_HIP_TRY(hipStreamSynchronize(s));
     bt_.select += now_s() - t0;
     t0 = now_s();
