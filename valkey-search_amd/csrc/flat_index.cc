@@ -516,12 +516,14 @@ class FlatIndex final : public Index {
     // pre-pass (this kernel over the first rows): a valid bound on every query's k-th best distance, so the per-lane
     // lists of K4 start gated instead of accepting everything until they have filled
     const float *init_bound = nullptr;
-    if (gemm_prepass_rows_ && count >= 8 * gemm_prepass_rows_ && k <= 10 && !in_prepass_) {
+    // (more rows for a larger k: the bound is the k-th best of the sample, and the lists of K4 pay per insert)
+    const uint64_t pre_rows = gemm_prepass_rows_ * ((k + 9) / 10);
+    if (pre_rows && count >= 8 * pre_rows && !in_prepass_) {
       in_prepass_ = true;   // the same kernel over the first rows only
-      Status ps = scan_gemm(ctx, d_q, nq, k, gemm_prepass_rows_, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
+      Status ps = scan_gemm(ctx, d_q, nq, k, pre_rows, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
       in_prepass_ = false;
       VK_TRY(ps);
-      VK_TRY(ctx->d_stats.ensure(std::max<size_t>(32, nq * 4)));
+      VK_TRY(ctx->d_stats.ensure(std::max<size_t>(32, nq * 8)));
       VK_HIP_TRY(launch_kth_bound(d_out_d, d_out_n, (uint32_t)k, (uint32_t)nq, ctx->d_stats.as<float>(), s));
       init_bound = ctx->d_stats.as<float>();
     }
@@ -557,7 +559,10 @@ class FlatIndex final : public Index {
     g.sync = ctx->d_sync.as<uint32_t>();
     g.qbound = g.sync + sync_bytes / 4;
     VK_HIP_TRY(hipMemsetAsync(g.sync, 0, sync_bytes, s));
-    VK_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g.qbound), (int)0xFF800000u, nq, s));   // key of +inf
+    if (init_bound)   // lists kept in HBM (k > 10) read the shared bound once per tile: start it at the pre-pass bound
+      VK_HIP_TRY(hipMemcpyAsync(g.qbound, reinterpret_cast<const uint32_t *>(init_bound) + nq, nq * 4, hipMemcpyDeviceToDevice, s));
+    else
+      VK_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g.qbound), (int)0xFF800000u, nq, s));   // key of +inf
     VK_HIP_TRY(launch_flat_gemm(g, s));
     MergeArgs m{};
     m.in_dist = g.part_dist;

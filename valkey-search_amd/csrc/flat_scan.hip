@@ -319,9 +319,14 @@ hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipSt
   return hipLaunchKernel(f, dim3(blocks), dim3(256), params, lds, s);
 }
 
+// bound[q] as a float and as the order-preserving u32 key the shared per-query bound of K4 uses
 __global__ void kth_bound_kernel(const float *out_dist, const uint32_t *out_n, uint32_t k, uint32_t nq, float *bound) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < nq) bound[q] = out_n[q] >= k ? out_dist[(size_t)q * k + k - 1] : __builtin_inff();
+  if (q >= nq) return;
+  const float b = out_n[q] >= k ? out_dist[(size_t)q * k + k - 1] : __builtin_inff();
+  const uint32_t u = __float_as_uint(b);
+  bound[q] = b;
+  reinterpret_cast<uint32_t *>(bound)[nq + q] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 hipError_t launch_kth_bound(const float *out_dist, const uint32_t *out_n, uint32_t k, uint32_t nq, float *bound, hipStream_t s) {
   if (nq == 0) return hipSuccess;

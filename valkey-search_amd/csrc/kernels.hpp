@@ -167,7 +167,8 @@ int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e);
 hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, int e, hipStream_t s);
 hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s);
 hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipStream_t s);
-// bound[q] = out_dist[q][k-1] if the query found k entries, +inf otherwise
+// bound[q] = out_dist[q][k-1] if the query found k entries, +inf otherwise; bound[nq + q] = the same as an
+// order-preserving u32 key (the buffer holds 2*nq words)
 hipError_t launch_kth_bound(const float *out_dist, const uint32_t *out_n, uint32_t k, uint32_t nq, float *bound, hipStream_t s);
 
 }  // namespace vk
