@@ -306,3 +306,17 @@ def test_baseline_config1_shape(vsa, oracle):
     D, L, Nn = g.search_batch(Q, k)
     for i, q in enumerate(Q):
         _assert_same(D[i, :Nn[i]], L[i, :Nn[i]], *o.search(q, k))
+
+
+@pytest.mark.parametrize("k", [11, 64, 100, 256, 300])
+def test_mfma_path_larger_k(vsa, oracle, k):
+    """k > 10 keeps the per-lane lists in HBM scratch (k <= 256 on the matrix-core path, beyond that the
+    scan kernel): same answers either way."""
+    n, dim, nq = 12000, 64, 24
+    x = _prep(oracle, _data(n, dim, 51), "COSINE")
+    g, o = _both(vsa, oracle, x, "COSINE")
+    Q = _prep(oracle, _data(nq, dim, 52), "COSINE")
+    D, L, N = g.search_batch(Q, k)
+    for i in range(nq):
+        od, ol = o.search(Q[i], k)
+        _assert_same(D[i, :N[i]], L[i, :N[i]], od, ol)

@@ -505,7 +505,7 @@ size_t flat_gemm_lds_bytes(uint32_t row_stride_f) {
 }
 
 bool flat_gemm_supported(uint32_t row_stride_f, uint64_t k) {
-  return (row_stride_f % 64) == 0 && flat_gemm_lds_bytes(row_stride_f) <= 160 * 1024 && k >= 1 && k <= 64;
+  return (row_stride_f % 64) == 0 && flat_gemm_lds_bytes(row_stride_f) <= 160 * 1024 && k >= 1 && k <= 256;   // k > 10: per-lane lists in HBM scratch (an insert costs O(k): beyond 256 the scan wins)
 }
 
 hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {

@@ -575,7 +575,7 @@ class FlatIndex final : public Index {
     m.out_dist = d_out_d;
     m.out_label = d_out_l;
     m.out_n = d_out_n;
-    VK_HIP_TRY(launch_merge_topk(m, 1, nq, s));
+    VK_HIP_TRY(launch_merge_topk(m, flat_scan_slots_per_lane(k), nq, s));
     return Status::Ok();
   }
 
