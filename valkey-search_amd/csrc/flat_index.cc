@@ -410,7 +410,9 @@ class FlatIndex final : public Index {
     const uint32_t nseg = (uint32_t)((row_end + seg_rows - 1) / seg_rows);
     // row partitions: enough blocks to fill 256 CUs, never more waves than 16-row tiles
     const uint64_t tiles = (std::min<uint64_t>(seg_rows, row_end) + 15) / 16;
-    uint32_t nrp = (uint32_t)std::min<uint64_t>((tiles + 3) / 4, std::max<uint32_t>(2048 / nqg, 256));
+    // ... and at least ~4 tiles per wave: every block leaves a partial list for the merge kernel (one wave per
+    // query), which dominates the latency of a small index when there are thousands of near-empty lists
+    uint32_t nrp = (uint32_t)std::min<uint64_t>((tiles + 15) / 16, std::max<uint32_t>(2048 / nqg, 256));
     nrp = std::max<uint32_t>(8, (nrp + 7) & ~7u);
     const uint64_t per_q = (uint64_t)nrp * (e == 1 ? 1 : 4) * k;   // e == 1: one list per block (merged in LDS)
     VK_TRY(ctx->d_part_d.ensure((size_t)nseg * nq * per_q * 4));

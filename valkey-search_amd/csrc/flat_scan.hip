@@ -171,18 +171,28 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs a) {
   for (uint32_t part = 0; part < a.parts; ++part) {
     const float *__restrict__ pd = a.in_dist + ((size_t)part * a.part_stride + q * a.q_stride);
     const uint64_t *__restrict__ pl = a.in_label + ((size_t)part * a.part_stride + q * a.q_stride);
-    for (uint32_t i0 = 0; i0 < a.per_part; i0 += kWave) {
-      const uint32_t i = i0 + lane;
-      float dist = __builtin_inff();
-      uint64_t lab = kNoLabel;
-      if (i < a.per_part) { dist = pd[i]; lab = pl[i]; }
-      uint64_t mask = __ballot(lab != kNoLabel && dist <= top.thr_d);
-      while (mask) {
-        const int b = __ffsll((unsigned long long)mask) - 1;
-        mask &= mask - 1;
-        const float cd = readlane_f32(dist, b);
-        if (!(cd <= top.thr_d)) continue;
-        top.insert(cd, readlane_u64(lab, b), lane);
+    // four 64-entry slabs per trip, all eight loads issued before the first one is looked at: the wave is
+    // alone on its query, so every dependent load it waits for is pure latency
+    for (uint32_t i0 = 0; i0 < a.per_part; i0 += 4 * kWave) {
+      float dist[4];
+      uint64_t lab[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * kWave + lane;
+        dist[u] = __builtin_inff();
+        lab[u] = kNoLabel;
+        if (i < a.per_part) { dist[u] = pd[i]; lab[u] = pl[i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        uint64_t mask = __ballot(lab[u] != kNoLabel && dist[u] <= top.thr_d);
+        while (mask) {
+          const int b = __ffsll((unsigned long long)mask) - 1;
+          mask &= mask - 1;
+          const float cd = readlane_f32(dist[u], b);
+          if (!(cd <= top.thr_d)) continue;
+          top.insert(cd, readlane_u64(lab[u], b), lane);
+        }
       }
     }
   }
