@@ -185,6 +185,72 @@ def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
                     "ids_identical_to_gpu": f"{same}/{n_cpu}", "graph_export_s": round(export_s, 2)}}
 
 
+def hnsw_sharded_leg(args, flat_ix, table, A, device, stream_ptr, world, rank, r0, dist, gather, local_rank):
+    """N > 1: one independent HNSW graph per shard (as one graph per cluster shard in the reference), every rank
+    searches its graph for the same query batch, per-shard top-k lists are all-gathered and merged by
+    (distance, label).  Ground truth = the exact FLAT answer over the same rows, merged the same way."""
+    from oracle import oracle as O
+    Nh, D, K, ef = min(args.hnsw_rows // world, table.shape[0]), args.dim, args.k, args.hnsw_ef
+    host_rows = np.ascontiguousarray(table[:Nh, :D].float().cpu().numpy())
+    t0 = time.perf_counter()
+    h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=ef, device_id=local_rank)
+    h.add_batch(host_rows, np.arange(r0, r0 + Nh, dtype=np.uint64))
+    h.flush()
+    build_s = time.perf_counter() - t0
+    nq = min(args.hnsw_queries, 2048)
+    qg = torch.Generator(device=device)
+    qg.manual_seed(9090)
+    Qh = torch.nn.functional.normalize(torch.randn(nq, 32, generator=qg, device=device) @ A.T +
+                                       0.05 * torch.randn(nq, D, generator=qg, device=device), dim=1).contiguous()
+    od = torch.empty(nq, K, device=device, dtype=torch.float32)
+    ol = torch.empty(nq, K, device=device, dtype=torch.int64)
+    on = torch.empty(nq, device=device, dtype=torch.int32)
+    ad = torch.empty(world * nq, K, device=device, dtype=torch.float32)
+    al = torch.empty(world * nq, K, device=device, dtype=torch.int64)
+    fd = torch.empty(nq, K, device=device, dtype=torch.float32)
+    fl = torch.empty(nq, K, device=device, dtype=torch.int64)
+    fn = torch.empty(nq, device=device, dtype=torch.int32)
+
+    def merged(search):
+        search()
+        gather(ad, od)
+        gather(al, ol)
+        vsa.merge_topk_device(ad.data_ptr(), al.data_ptr(), world, nq, K, fd.data_ptr(), fl.data_ptr(), fn.data_ptr(),
+                              local_rank, stream_ptr())
+
+    def hnsw_search():
+        h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef, stream=stream_ptr())
+
+    # exact answer over the same rows: this rank's FLAT shard restricted to its first Nh rows
+    bits = O.allow_bitmap(np.arange(r0, r0 + Nh, dtype=np.uint64), r0 + Nh)
+    d_bits = torch.from_numpy(bits.view(np.int64)).to(device)
+
+    def flat_search():
+        flat_ix.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(),
+                                    d_allow=d_bits.data_ptr(), allow_nbits=r0 + Nh, stream=stream_ptr())
+
+    merged(flat_search)
+    torch.cuda.synchronize()
+    gt = fl.cpu().numpy().copy()
+    merged(hnsw_search)
+    dist.barrier()
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        merged(hnsw_search)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    if args.backend == "nccl":
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    got = fl.cpu().numpy()
+    recall = float(np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got, gt)])) / K
+    return {"shards": world, "rows_per_shard": Nh, "rows": Nh * world, "M": 16, "ef_construction": 200, "ef": ef, "k": K,
+            "queries_per_batch": nq, "build_s_per_shard": round(build_s, 2), "gpu_qps": round(nq * reps / float(dt.item()), 1),
+            "recall_at_10": round(recall, 4), "merge": "all-gather + (distance,label) merge on every rank"}
+
+
 def coalescer_leg(ix, hq, K, threads=64, per_thread=4):
     """N1: the reference issues one query per FT.SEARCH from a pool of reader threads (search.cc:886-910).
     `threads` callers each issue `per_thread` single-query vk_index_search calls, first one at a time per
@@ -438,6 +504,16 @@ def main():
     hnsw = None
     if rank == 0 and world == 1 and args.hnsw_rows > 0 and not bf16:
         hnsw = hnsw_leg(args, ix, table, A, device, stream_ptr)
+    if world > 1 and args.hnsw_rows > 0 and not bf16:
+        def gather(dst, src):
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(dst, src)
+            else:                       # test aid (gloo): through the host
+                work_stream.synchronize()
+                c = torch.empty(dst.shape, dtype=dst.dtype)
+                dist.all_gather_into_tensor(c, src.cpu())
+                dst.copy_(c)
+        hnsw = hnsw_sharded_leg(args, ix, table, A, device, stream_ptr, world, rank, r0, dist, gather, local_rank)
 
     coalescer = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

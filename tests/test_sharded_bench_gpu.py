@@ -17,7 +17,7 @@ def test_two_shards_equal_one_index():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", str(ROOT / "bench.py"), "--gpus", "2", "--rows", "300000", "--steps", "2",
-           "--warmup", "1", "--backend", "gloo", "--same-device", "--verify-merge", "--hnsw-rows", "0",
+           "--warmup", "1", "--backend", "gloo", "--same-device", "--verify-merge", "--hnsw-rows", "40000",
            "--single-query-steps", "0"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -26,3 +26,6 @@ def test_two_shards_equal_one_index():
     ver = [l for l in lines if "verify_merge" in l]
     assert len(bench) == 1 and bench[0]["n_gpus"] == 2 and bench[0]["config"]["sharding"] == "rows/2"
     assert ver and ver[0]["verify_merge"] == "bit-identical"
+    # one HNSW graph per shard, merged the same way: recall against the exact answer over the same rows
+    h = bench[0]["hnsw"]
+    assert h["shards"] == 2 and h["rows_per_shard"] == 20000 and h["recall_at_10"] >= 0.9
