@@ -1,0 +1,56 @@
+"""N1 on the CPU: csrc/coalescer.hpp driven by many threads against a fake index (tests/helpers/
+coalescer_shim.cc).  Every request must be answered exactly once with its own answer; concurrent
+requests of one (k, ef) lane must travel in shared device batches; lanes never mix; an error of a batch
+reaches every request that travelled in it."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "valkey-search_amd" / "csrc"
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    out = tmp_path_factory.mktemp("co") / "libcoalescershim.so"
+    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-O2", "-std=c++17", "-fPIC", "-shared",
+                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", str(CSRC), "-I", str(ROOT / "include"),
+                           str(ROOT / "tests" / "helpers" / "coalescer_shim.cc"), "-lpthread", "-o", str(out)])
+    lib = C.CDLL(str(out))
+    lib.coalescer_run.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    return lib
+
+
+def run(lib, threads, per_thread, max_batch, max_wait_us, lanes=1, failing=0):
+    out = (C.c_uint64 * 8)()
+    bad = lib.coalescer_run(threads, per_thread, max_batch, max_wait_us, lanes, failing, out)
+    return bad, {"calls": out[0], "queries": out[1], "max_batch": out[2], "batches": out[3], "co_queries": out[4]}
+
+
+def test_every_request_gets_its_own_answer_and_batches_form(shim):
+    bad, st = run(shim, threads=48, per_thread=20, max_batch=16, max_wait_us=2000)
+    assert bad == 0
+    assert st["queries"] == 48 * 20 == st["co_queries"]          # each request served exactly once
+    assert st["calls"] == st["batches"] < 48 * 20                # ... and not one device pass per request
+    assert 1 < st["max_batch"] <= 16
+
+
+def test_lanes_by_k_and_ef_do_not_mix(shim):
+    # three lanes (k = 1, 2, 3 with ef = 100, 101, 102); the fake index derives its answer from k and ef of
+    # the batch it is called with, so a request riding in another lane's batch would be caught
+    bad, st = run(shim, threads=30, per_thread=30, max_batch=8, max_wait_us=1000, lanes=3)
+    assert bad == 0 and st["queries"] == 900 and st["max_batch"] <= 8
+
+
+def test_a_failing_batch_fails_every_rider_and_nobody_else(shim):
+    bad, st = run(shim, threads=24, per_thread=16, max_batch=8, max_wait_us=1000, lanes=4, failing=1)
+    assert bad == 0 and st["queries"] == 24 * 16
+
+
+def test_single_caller_and_max_batch_one(shim):
+    bad, st = run(shim, threads=1, per_thread=10, max_batch=8, max_wait_us=100)
+    assert bad == 0 and st["calls"] == 10 and st["max_batch"] == 1
+    bad, st = run(shim, threads=8, per_thread=10, max_batch=2, max_wait_us=100)
+    assert bad == 0 and st["queries"] == 80 and st["max_batch"] <= 2

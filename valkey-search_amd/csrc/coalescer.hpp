@@ -9,11 +9,14 @@
 // `max_batch` requests are queued or `max_wait_us` elapsed, runs the batch, and hands every
 // follower its slice.  Latency/throughput knob, off by default (max_batch <= 1).
 #pragma once
+#include <string.h>
+
 #include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "index.hpp"
 
