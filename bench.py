@@ -548,7 +548,7 @@ def main():
                                     f"(per-GPU shard of BASELINE.json configs[3])"),
                        "rows_per_gpu": n_local, "sharding": f"rows/{world}", "recall_at_10": 1.0,
                        "parity_vs_oracle": parity},
-            # B >= 16 in the inner-product space runs on the f32 matrix cores (flat_gemm_kernel, K4):
+            # B >= 5 in the inner-product space runs on the f32 matrix cores (flat_gemm_kernel, K4):
             # algorithmic FLOPs per launch = 2 * rows * D * B against the 157.3 TFLOP/s f32 MFMA peak
             "roofline": ({"bound": "mfma", "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 3),
                           "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -557,7 +557,7 @@ def main():
                           "algorithmic_bytes": scan_bytes,
                           "kernel": "flat_gemm_kernel", "per_launch_ms": round(dev_ms, 4),
                           "hbm_gbs_algorithmic": round(scan_bytes / (dev_ms * 1e-3) / 1e9, 2)}
-                         if B >= 16 and not os.environ.get("VK_FLAT_FORCE_SCAN") else
+                         if B >= 5 and not os.environ.get("VK_FLAT_FORCE_SCAN") else
                          {"bound": "hbm", "achieved": round(scan_bytes / (dev_ms * 1e-3) / 1e9, 2),
                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,

@@ -65,7 +65,7 @@ def test_hnsw_bf16_equals_f32_on_rounded_rows(vsa, oracle):
 
 @pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 64, 10), (6000, 768, 32, 10), (3000, 100, 40, 30)])
 def test_flat_bf16_batched_mfma_path(vsa, oracle, n, dim, nq, k):
-    """>= 16 queries in the inner-product space over bf16 rows: K4 widens the rows on their way into LDS;
+    """>= 5 queries in the inner-product space over bf16 rows: K4 widens the rows on their way into LDS;
     the answer must equal the f32 oracle over the rounded rows, ids and distance bits."""
     rng = np.random.default_rng(43)
     x = rng.standard_normal((n, dim)).astype(np.float32)

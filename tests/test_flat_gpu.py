@@ -246,7 +246,7 @@ def test_save_load_round_trip(vsa, oracle):
 @pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 256, 10), (5000, 100, 33, 10), (9000, 768, 64, 10), (4097, 16, 16, 5),
                                         (3000, 48, 100, 64), (300, 7, 40, 10)])
 def test_mfma_batched_path_bit_exact(vsa, oracle, metric, n, dim, nq, k):
-    """K4 (flat_gemm.hip): >= 16 queries in the inner-product space go through the f32 MFMA kernel; one
+    """K4 (flat_gemm.hip): >= 5 queries in the inner-product space go through the f32 MFMA kernel; one
     accumulator tile per SimSIMD lane class keeps the result bit-identical to the CPU reference."""
     x = _prep(oracle, _data(n, dim, 31), metric)
     g, o = _both(vsa, oracle, x, metric)

@@ -42,7 +42,7 @@ def world():
 
 def test_scan_and_mfma_kernels_agree_at_full_size(world):
     vsa, ix, table, Q = world
-    Db, Lb, Nb = ix.search_batch(Q, K)                 # >= 16 queries: K4 (matrix cores)
+    Db, Lb, Nb = ix.search_batch(Q, K)                 # >= 5 queries: K4 (matrix cores)
     assert (Nb == K).all()
     for i in range(0, B, 8):                           # one query per call: K3 (scan)
         d, l = ix.search(Q[i], K)
