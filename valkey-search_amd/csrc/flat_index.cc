@@ -393,14 +393,15 @@ class FlatIndex final : public Index {
   Status scan(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
               uint64_t allow_nbits, const volatile int *cancel, float *d_out_d, uint64_t *d_out_l,
               uint32_t *d_out_n, hipStream_t s) {
-    const int e = flat_scan_slots_per_lane(k);
+    int e = flat_scan_slots_per_lane(k);
     if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 needs the host entry points (vk_index_search / _batch), which page through the result in passes");
     const uint32_t chunks = store_.stride_f() / 16;
     // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
     if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !cancel && flat_gemm_supported(store_.stride_f(), k) && !force_scan_)
       return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
-    const int qb = flat_scan_pick_qb(nq, chunks, e);
+    if (lb_dist_) e = 16;            // the paged scan has one instantiation: 16 slots per lane, one query per pass
+    const int qb = lb_dist_ ? 1 : flat_scan_pick_qb(nq, chunks, e);
     const uint32_t nqg = (uint32_t)((nq + qb - 1) / qb);
     // rows: cancelled at entry -> only the first k rows are looked at (bruteforce.h:120-129)
     uint64_t row_end = count;

@@ -15,12 +15,16 @@
 // resolved by (distance,label) exactly like the std::pair heap of bruteforce.h.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 
 namespace vk {
 
-template <int kQB, bool kL2, int kE, bool kBf16>
+// kLb: the scan carries an exclusive lower bound (distance,label) per query (FlatIndex::search_in_passes, k > 1024:
+// always kQB == 1, kE == 16); without it the hot loop and the register budget do not pay for the paging feature
+template <int kQB, bool kL2, int kE, bool kBf16, bool kLb = false>
 __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   extern __shared__ float4 qs[];  // [kQB][chunks][4] float4 == kQB padded queries
   const int lane = threadIdx.x & 63;
@@ -54,8 +58,8 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   for (int qi = 0; qi < kQB; ++qi) {
     top[qi].init(a.k);
     const uint32_t q = qbase + qi < a.nq ? qbase + qi : a.nq - 1;
-    lbd[qi] = a.lb_dist ? a.lb_dist[q] : -__builtin_inff();
-    lbl[qi] = a.lb_dist ? a.lb_label[q] : 0;
+    lbd[qi] = kLb ? a.lb_dist[q] : -__builtin_inff();
+    lbl[qi] = kLb ? a.lb_label[q] : 0;
   }
 
   const uint32_t total_waves = a.nrp * 4;   // nrp is a multiple of 8
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
     for (int qi = 0; qi < kQB; ++qi) {
       const float dist = finish_distance<kL2>(quad_reduce16(acc[qi]));
       // distance gate first, filter second -- the order of bruteforce.h:131-135
-      const bool cand = valid && j == 0 && dist <= top[qi].thr_d && dist >= lbd[qi];
+      const bool cand = valid && j == 0 && dist <= top[qi].thr_d && (!kLb || dist >= lbd[qi]);
       uint64_t mask = __ballot(cand);
       while (mask) {
         const int b = __ffsll((unsigned long long)mask) - 1;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
         if (!(cd <= top[qi].thr_d)) continue;
         const uint32_t crow = __builtin_amdgcn_readlane((int)row, b);
         const uint64_t cl = a.labels[crow];
-        if (a.lb_dist && !dl_less(lbd[qi], lbl[qi], cd, cl)) continue;   // not beyond the previous pass
+        if (kLb && !dl_less(lbd[qi], lbl[qi], cd, cl)) continue;   // not beyond the previous pass
         if (!allow_bit(a.allow_bits, a.allow_nbits, cl)) continue;
         top[qi].insert(cd, cl, lane);
       }
@@ -244,6 +248,17 @@ __global__ __launch_bounds__(256) void gather_distance_kernel(GatherArgs a) {
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
+template <bool kL2, bool kBf16>
+static hipError_t launch_scan_lb(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<1, kL2, 16, kBf16, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((flat_scan_kernel<1, kL2, 16, kBf16, true>), grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
 template <int kQB, bool kL2, int kE, bool kBf16>
 static hipError_t launch_scan_t(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
   if (lds > 48 * 1024) {
@@ -280,7 +295,9 @@ int flat_scan_slots_per_lane(uint64_t k) {
 int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e) {
   // query block must fit LDS (<= 64 KiB so that two blocks share a CU) and, with wide
   // per-lane top-k state, registers
+  static const int qb_cap = getenv("VK_SCAN_QB") ? atoi(getenv("VK_SCAN_QB")) : 8;
   int qb = nq >= 8 ? 8 : nq >= 4 ? 4 : nq >= 2 ? 2 : 1;
+  if (qb > qb_cap) qb = qb_cap;
   if (e > 1) qb = qb > 2 ? 2 : qb;
   if (e > 4) qb = 1;
   while (qb > 1 && (size_t)qb * chunks * 64 > 64 * 1024) qb >>= 1;
@@ -293,6 +310,11 @@ hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, i
   size_t lds = (size_t)qb * a.chunks * 64;
   if (e == 1) lds = std::max<size_t>(lds, ((size_t)qb * 3 * a.k + 2) * 12);   // block-level merge buffers reuse it
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (a.lb_dist) {   // paged large-k scan
+    if (e != 16 || qb != 1) return hipErrorInvalidValue;
+    return l2 ? (bf16 ? launch_scan_lb<true, true>(a, grid, lds, s) : launch_scan_lb<true, false>(a, grid, lds, s))
+              : (bf16 ? launch_scan_lb<false, true>(a, grid, lds, s) : launch_scan_lb<false, false>(a, grid, lds, s));
+  }
   if (e == 1) return bf16 ? launch_scan_l2<1, true>(l2, qb, a, grid, lds, s) : launch_scan_l2<1, false>(l2, qb, a, grid, lds, s);
   if (e == 4) return bf16 ? launch_scan_l2<4, true>(l2, qb, a, grid, lds, s) : launch_scan_l2<4, false>(l2, qb, a, grid, lds, s);
   if (e == 16) return bf16 ? launch_scan_l2<16, true>(l2, qb, a, grid, lds, s) : launch_scan_l2<16, false>(l2, qb, a, grid, lds, s);
