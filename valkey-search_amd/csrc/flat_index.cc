@@ -413,7 +413,7 @@ class FlatIndex final : public Index {
     const uint64_t tiles = (std::min<uint64_t>(seg_rows, row_end) + 15) / 16;
     // ... and at least ~4 tiles per wave: every block leaves a partial list for the merge kernel (one wave per
     // query), which dominates the latency of a small index when there are thousands of near-empty lists
-    uint32_t nrp = (uint32_t)std::min<uint64_t>((tiles + 15) / 16, std::max<uint32_t>(2048 / nqg, 256));
+    uint32_t nrp = (uint32_t)std::min<uint64_t>((tiles + 15) / 16, std::max<uint32_t>((2048 + nqg - 1) / nqg, scan_min_nrp_));
     nrp = std::max<uint32_t>(8, (nrp + 7) & ~7u);
     const uint64_t per_q = (uint64_t)nrp * (e == 1 ? 1 : 4) * k;   // e == 1: one list per block (merged in LDS)
     VK_TRY(ctx->d_part_d.ensure((size_t)nseg * nq * per_q * 4));
@@ -593,6 +593,8 @@ class FlatIndex final : public Index {
   std::shared_mutex rw_;
   // K4 lockstep window in row tiles (see FlatGemmArgs::lockstep); VK_GEMM_LOCKSTEP=0 turns it off
   uint32_t gemm_lockstep_ = getenv("VK_GEMM_LOCKSTEP") ? (uint32_t)atoi(getenv("VK_GEMM_LOCKSTEP")) : 1;
+  // floor of the row partitions of a K3 launch (blocks = partitions x query groups)
+  uint32_t scan_min_nrp_ = getenv("VK_SCAN_MIN_NRP") ? (uint32_t)atoi(getenv("VK_SCAN_MIN_NRP")) : 8;
   uint64_t gemm_prepass_rows_ = getenv("VK_GEMM_PREPASS") ? (uint64_t)atoll(getenv("VK_GEMM_PREPASS")) : 16384;
   static thread_local bool in_prepass_;
   uint32_t gemm_contig_ = getenv("VK_GEMM_CONTIG") ? (uint32_t)atoi(getenv("VK_GEMM_CONTIG")) : 1;
