@@ -244,7 +244,8 @@ def test_save_load_round_trip(vsa, oracle):
 
 @pytest.mark.parametrize("metric", ["IP", "COSINE"])
 @pytest.mark.parametrize("n,dim,nq,k", [(20000, 128, 256, 10), (5000, 100, 33, 10), (9000, 768, 64, 10), (4097, 16, 16, 5),
-                                        (3000, 48, 100, 64), (300, 7, 40, 10)])
+                                        (3000, 48, 100, 64), (300, 7, 40, 10),
+                                        (3000, 1024, 50, 10), (2500, 1536, 40, 10), (2000, 1000, 70, 10)])   # 24 / 16 queries per tile
 def test_mfma_batched_path_bit_exact(vsa, oracle, metric, n, dim, nq, k):
     """K4 (flat_gemm.hip): >= 5 queries in the inner-product space go through the f32 MFMA kernel; one
     accumulator tile per SimSIMD lane class keeps the result bit-identical to the CPU reference."""

@@ -38,7 +38,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 constexpr int kTileRows = 128;
-constexpr int kTileQ = 32;
 constexpr int kXStride = 36;     // dwords per staged row: 2 chunks (32 floats) + 4 pad
 constexpr int kXBufs = 3;
 }  // namespace
@@ -287,15 +286,19 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
   constexpr uint32_t kBufFloats = 32 * kXStride;        // one stage of one wave: 32 rows x 36 dwords
   // each wave stages ITS OWN 32 rows through a private ring of kXBufs buffers: no block barrier in
   // the main loop (a barrier idles the matrix pipe of a one-wave-per-SIMD kernel every stage)
-  float *lds_x = lds + (size_t)kTileQ * qstride + (size_t)wave * kXBufs * kBufFloats;
+  // queries per block: 32 (the MFMA tile's width) while the resident tile fits LDS next to the staging rings,
+  // 24 or 16 for long rows (D = 1024, 1536, ...): the missing columns re-read the last resident query and their
+  // results are discarded -- matrix-core efficiency drops with them, the arithmetic of the live columns does not
+  const uint32_t tq = a.tile_q;
+  float *lds_x = lds + (size_t)tq * qstride + (size_t)wave * kXBufs * kBufFloats;
 
   const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
   const uint32_t rp = (seq / a.nqt) * 8u + xcd;
   const uint32_t qt = seq % a.nqt;
-  const uint32_t q0 = qt * kTileQ;
+  const uint32_t q0 = qt * tq;
 
   // ---- Q tile -> LDS (queries past nq replicate the last one; their results are discarded)
-  for (uint32_t i = tid; i < (uint32_t)kTileQ * (a.row_stride_f / 4); i += 256) {
+  for (uint32_t i = tid; i < tq * (a.row_stride_f / 4); i += 256) {
     const uint32_t q = i / (a.row_stride_f / 4), c4 = i % (a.row_stride_f / 4);
     const uint32_t gq = q0 + q < a.nq ? q0 + q : a.nq - 1;
     const float4 v = reinterpret_cast<const float4 *>(a.queries + (size_t)gq * a.q_stride_f)[c4];
@@ -304,7 +307,7 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
 
   // ---- this lane's private top-k list (HBM scratch) and threshold
   const uint32_t my_q = q0 + li;
-  const bool q_valid = my_q < a.nq;
+  const bool q_valid = li < tq && my_q < a.nq;
   const uint32_t slot = wave * 2 + kk;
   const size_t list_base = (((size_t)(q_valid ? my_q : 0) * a.nrp + rp) * 8 + slot) * a.k;
   float *list_d = a.part_dist + list_base;
@@ -361,7 +364,7 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
   __syncthreads();                                       // the shared Q tile is in place
 
   const uint32_t x_off = li * kXStride + kk * 16;
-  const float *q_row = lds_q + (size_t)li * qstride;
+  const float *q_row = lds_q + (size_t)(li < tq ? li : tq - 1) * qstride;
   Frag f0 = frag_load(lds_x + x_off, q_row, 0, kk), f1 = f0;
 
   uint32_t rbuf = 1;            // buffer of stage done+1
@@ -500,17 +503,24 @@ __global__ __launch_bounds__(256, 1) void flat_gemm_prepass_kernel(FlatGemmArgs 
   flat_gemm_body<0, 7, kRegList, kBf16>(a);
 }
 
-size_t flat_gemm_lds_bytes(uint32_t row_stride_f) {
-  return ((size_t)kTileQ * (row_stride_f + 4) + (size_t)kXBufs * kTileRows * kXStride) * 4;
+size_t flat_gemm_lds_bytes(uint32_t row_stride_f, uint32_t tile_q) {
+  return ((size_t)tile_q * (row_stride_f + 4) + (size_t)kXBufs * kTileRows * kXStride) * 4;
+}
+
+// queries per block for this row length: 32, 24 or 16 (0 = the kernel does not fit)
+uint32_t flat_gemm_tile_q(uint32_t row_stride_f) {
+  for (uint32_t tq : {32u, 24u, 16u})
+    if (flat_gemm_lds_bytes(row_stride_f, tq) <= 160 * 1024) return tq;
+  return 0;
 }
 
 bool flat_gemm_supported(uint32_t row_stride_f, uint64_t k) {
-  return (row_stride_f % 64) == 0 && flat_gemm_lds_bytes(row_stride_f) <= 160 * 1024 && k >= 1 && k <= 256;   // k > 10: per-lane lists in HBM scratch (an insert costs O(k): beyond 256 the scan wins)
+  return (row_stride_f % 64) == 0 && flat_gemm_tile_q(row_stride_f) != 0 && k >= 1 && k <= 256;   // k > 10: per-lane lists in HBM scratch (an insert costs O(k): beyond 256 the scan wins)
 }
 
 hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
-  if (a.nrp == 0 || (a.nrp & 7u) || a.nqt != (a.nq + kTileQ - 1) / kTileQ) return hipErrorInvalidValue;
-  const size_t lds = flat_gemm_lds_bytes(a.row_stride_f);
+  if (a.nrp == 0 || (a.nrp & 7u) || a.tile_q == 0 || a.nqt != (a.nq + a.tile_q - 1) / a.tile_q) return hipErrorInvalidValue;
+  const size_t lds = flat_gemm_lds_bytes(a.row_stride_f, a.tile_q);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static const int ablate = getenv("VK_GEMM_ABLATE") ? atoi(getenv("VK_GEMM_ABLATE")) : 0;
   // VK_GEMM_MODE=0: the compiler's own placement of the stage's memory operations (A/B switch)

@@ -544,7 +544,8 @@ class FlatIndex final : public Index {
     g.n_rows = (uint32_t)count;
     g.nq = (uint32_t)nq;
     g.k = (uint32_t)k;
-    g.nqt = (uint32_t)((nq + 31) / 32);
+    g.tile_q = flat_gemm_tile_q(store_.stride_f());
+    g.nqt = (uint32_t)((nq + g.tile_q - 1) / g.tile_q);
     const uint32_t tiles = (uint32_t)((count + 127) / 128);
     uint32_t nrp = std::max<uint32_t>(8, (256 / g.nqt) & ~7u);
     nrp = std::min<uint32_t>(nrp, std::max<uint32_t>(8, (tiles + 7) & ~7u));

@@ -37,7 +37,8 @@ struct FlatGemmArgs {
   uint32_t row_stride_f, q_stride_f, chunks;
   uint32_t n_rows, nq, k;
   uint32_t nrp;               // row partitions, multiple of 8
-  uint32_t nqt;               // query tiles of 32
+  uint32_t nqt;               // query tiles of tile_q
+  uint32_t tile_q;            // queries per block: 32, 24 or 16 (flat_gemm_tile_q)
   // lockstep window W among the nqt blocks that stream the same row panel through one XCD's L2
   // (0 = off): a wave starts row tile t only after every sharer has started tile t-W
   uint32_t lockstep;
@@ -49,7 +50,8 @@ struct FlatGemmArgs {
   const float *init_bound;    // optional [nq]: a valid upper bound of each query's k-th best distance (pre-pass)
   uint32_t contig;            // 1: a row partition owns a contiguous range of tiles, 0: tiles rp, rp+nrp, ...
 };
-size_t flat_gemm_lds_bytes(uint32_t row_stride_f);
+size_t flat_gemm_lds_bytes(uint32_t row_stride_f, uint32_t tile_q);
+uint32_t flat_gemm_tile_q(uint32_t row_stride_f);
 bool flat_gemm_supported(uint32_t row_stride_f, uint64_t k);
 hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s);
 
