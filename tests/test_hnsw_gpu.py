@@ -257,3 +257,13 @@ def test_large_ef_uses_the_lds_result_list(vsa, oracle, metric):
         _same(D[i, :N[i]], L[i, :N[i]], *o.search(q, 20, ef=800))
     with pytest.raises(vsa.VkError):
         g.search(Q[0], 10, ef=5000)
+
+
+def test_long_rows(vsa, oracle):
+    """D = 1536 (6 KB rows): the LDS query block and the 16-rows-per-round gathers at a long row length."""
+    rng = np.random.default_rng(71)
+    n, dim = 1200, 1536
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g, o = _pair(vsa, oracle, x, "COSINE" if False else "IP", M=16, efc=60)
+    for q in rng.standard_normal((6, dim)).astype(np.float32):
+        _same(*g.search(q, 10, ef=80), *o.search(q, 10, ef=80))
