@@ -167,17 +167,19 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
 // One wave per query: k best of `n_entries` (distance,label) pairs, written ascending.
 // Empty entries are (+inf, kNoLabel).
 template <int kE>
-__global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs a) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
+  // one block of four waves per query: each wave merges every fourth 256-entry slab into its own list, then
+  // waves 1..3 hand their lists to wave 0 through LDS (a lone wave spent its time waiting for dependent loads)
+  extern __shared__ float merge_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const uint64_t q = blockIdx.x;
   WaveTopK<kE> top;
   top.init(a.k);
   for (uint32_t part = 0; part < a.parts; ++part) {
     const float *__restrict__ pd = a.in_dist + ((size_t)part * a.part_stride + q * a.q_stride);
     const uint64_t *__restrict__ pl = a.in_label + ((size_t)part * a.part_stride + q * a.q_stride);
-    // four 64-entry slabs per trip, all eight loads issued before the first one is looked at: the wave is
-    // alone on its query, so every dependent load it waits for is pure latency
-    for (uint32_t i0 = 0; i0 < a.per_part; i0 += 4 * kWave) {
+    for (uint32_t i0 = (uint32_t)wave * 4 * kWave; i0 < a.per_part; i0 += 16 * kWave) {
       float dist[4];
       uint64_t lab[4];
 #pragma unroll
@@ -198,6 +200,31 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs a) {
           top.insert(cd, readlane_u64(lab[u], b), lane);
         }
       }
+    }
+  }
+  // waves 1..3 -> LDS -> wave 0
+  const uint32_t cap = (uint32_t)kE * kWave;
+  float *md = merge_lds;                                             // [3][cap]
+  uint64_t *ml = reinterpret_cast<uint64_t *>(merge_lds + 3 * cap + (cap & 1));
+  if (wave > 0) {
+#pragma unroll
+    for (int e = 0; e < kE; ++e) {
+      md[(wave - 1) * cap + e * kWave + lane] = top.d[e];
+      ml[(wave - 1) * cap + e * kWave + lane] = top.lab[e];
+    }
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  for (uint32_t i0 = 0; i0 < 3 * cap; i0 += kWave) {
+    const float dist = md[i0 + lane];
+    const uint64_t lab = ml[i0 + lane];
+    uint64_t mask = __ballot(lab != kNoLabel && dist <= top.thr_d);
+    while (mask) {
+      const int b = __ffsll((unsigned long long)mask) - 1;
+      mask &= mask - 1;
+      const float cd = readlane_f32(dist, b);
+      if (!(cd <= top.thr_d)) continue;
+      top.insert(cd, readlane_u64(lab, b), lane);
     }
   }
   // rank sort of the kept entries (all keys distinct: labels are unique)
@@ -324,9 +351,10 @@ hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, i
 hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s) {
   if (nq == 0) return hipSuccess;
   dim3 grid((uint32_t)nq);
-  if (e == 1) hipLaunchKernelGGL((merge_topk_kernel<1>), grid, dim3(64), 0, s, a);
-  else if (e == 4) hipLaunchKernelGGL((merge_topk_kernel<4>), grid, dim3(64), 0, s, a);
-  else if (e == 16) hipLaunchKernelGGL((merge_topk_kernel<16>), grid, dim3(64), 0, s, a);
+  const size_t lds = (size_t)(3 * e * 64 + 2) * 4 + (size_t)3 * e * 64 * 8;
+  if (e == 1) hipLaunchKernelGGL((merge_topk_kernel<1>), grid, dim3(256), lds, s, a);
+  else if (e == 4) hipLaunchKernelGGL((merge_topk_kernel<4>), grid, dim3(256), lds, s, a);
+  else if (e == 16) hipLaunchKernelGGL((merge_topk_kernel<16>), grid, dim3(256), lds, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
