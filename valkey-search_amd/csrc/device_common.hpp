@@ -165,6 +165,19 @@ struct WaveTopK {
       if (s < k && (!have || dl_less(bd, bl, d[e], lab[e]))) { bd = d[e]; bl = lab[e]; bs = s; have = true; }
     }
     if (!have) { bd = -__builtin_inff(); bl = 0; }
+    // fast path: reduce the distance alone (one shuffle per step instead of five); only when several lanes
+    // hold the maximum distance does the label have to take part
+    float md = bd;
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) md = fmaxf(md, __shfl_xor(md, m));
+    const uint64_t at_max = __ballot(have && bd == md);
+    if (__popcll(at_max) == 1) {
+      const int src = __ffsll((unsigned long long)at_max) - 1;
+      thr_d = md;
+      thr_lab = readlane_u64(bl, src);
+      thr_slot = (uint32_t)__builtin_amdgcn_readlane((int)bs, src);
+      return;
+    }
 #pragma unroll
     for (int m = 1; m < kWave; m <<= 1) {
       float od = __shfl_xor(bd, m);
