@@ -97,16 +97,28 @@ __device__ __forceinline__ float4 row_piece(const char *base, uint32_t piece) {
 
 // One row against the query block in LDS, by one quad (all 4 lanes return the distance).
 // base = start of the row; qs = padded query as float4[chunks*4]; j = lane inside the quad.
-template <bool kL2, bool kBf16>
+// kBatch = 16-B pieces in flight per lane before the first one is consumed.  8 keeps the register
+// count low (throughput kernels, many waves per SIMD); the latency-bound HNSW search of a few queries
+// uses 24, so a 768-d row costs two dependent memory round trips instead of six.
+template <bool kL2, bool kBf16, int kBatch = 8>
 __device__ __forceinline__ float quad_row_distance(const char *__restrict__ base, const float4 *qs, uint32_t chunks, int j) {
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t c = 0;
-  for (; c + 8 <= chunks; c += 8) {
-    float4 x[8];
+  for (; c + kBatch <= chunks; c += kBatch) {
+    float4 x[kBatch];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
+    for (int u = 0; u < kBatch; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) chunk_fma<kL2>(acc, x[u], qs[(c + u) * 4 + j]);
+    for (int u = 0; u < kBatch; ++u) chunk_fma<kL2>(acc, x[u], qs[(c + u) * 4 + j]);
+  }
+  if constexpr (kBatch > 8) {
+    for (; c + 8 <= chunks; c += 8) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) chunk_fma<kL2>(acc, x[u], qs[(c + u) * 4 + j]);
+    }
   }
   for (; c < chunks; ++c) chunk_fma<kL2>(acc, row_piece<kBf16>(base, c * 4 + j), qs[c * 4 + j]);
   return finish_distance<kL2>(quad_reduce16(acc));

@@ -155,9 +155,10 @@ __device__ __forceinline__ void pool_prune(Pool &c, float bound, int lane) {
 
 }  // namespace
 
-// 4 waves per SIMD (<= 128 VGPRs): the search is bound by gathers in flight, i.e. by resident waves
-template <bool kL2, int kE, bool kBf16>
-__global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
+// Shared body.  kBatch = row pieces in flight per lane (device_common.hpp): 8 for the throughput kernel,
+// 24 for the latency kernel that serves small batches.
+template <bool kL2, int kE, bool kBf16, int kBatch>
+__device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
     }
 
     auto row_dist = [&](uint32_t id) -> float {
-      return quad_row_distance<kL2, kBf16>(row_base<kBf16>(a.rows, id, a.row_stride_f), qs, chunks, j);
+      return quad_row_distance<kL2, kBf16, kBatch>(row_base<kBf16>(a.rows, id, a.row_stride_f), qs, chunks, j);
     };
     auto visit = [&](uint32_t id) -> bool {  // true if it was NOT visited before
       const uint32_t bit = 1u << (id & 31);
@@ -395,6 +396,18 @@ __global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
   }
 }
 
+// 4 waves per SIMD (<= 128 VGPRs): a full batch is bound by gathers in flight, i.e. by resident waves
+template <bool kL2, int kE, bool kBf16>
+__global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, 8>(a);
+}
+// a few queries cannot fill the device: each wave is alone with its memory latency, so it keeps three times as
+// many row pieces in flight (registers instead of occupancy)
+template <bool kL2, int kE, bool kBf16>
+__global__ __launch_bounds__(256, 2) void hnsw_search_latency_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, 24>(a);
+}
+
 __global__ void scatter_u32_kernel(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride) {
   const uint64_t total = (uint64_t)n * stride;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -430,27 +443,35 @@ size_t hnsw_lds_bytes(const HnswSearchArgs &a) {
 }
 
 template <bool kL2, int kE, bool kBf16>
-static const void *hnsw_fn() { return reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE, kBf16>); }
-
-template <int kE>
-static const void *hnsw_pick_e(bool l2, bool bf16) {
-  return l2 ? (bf16 ? hnsw_fn<true, kE, true>() : hnsw_fn<true, kE, false>())
-            : (bf16 ? hnsw_fn<false, kE, true>() : hnsw_fn<false, kE, false>());
+static const void *hnsw_fn(bool latency) {
+  if constexpr (kE >= 1 && kE <= 4) {
+    if (latency) return reinterpret_cast<const void *>(&hnsw_search_latency_kernel<kL2, kE, kBf16>);
+  }
+  return reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE, kBf16>);
 }
 
-static const void *hnsw_pick(bool l2, bool bf16, int e) {
+template <int kE>
+static const void *hnsw_pick_e(bool l2, bool bf16, bool latency) {
+  return l2 ? (bf16 ? hnsw_fn<true, kE, true>(latency) : hnsw_fn<true, kE, false>(latency))
+            : (bf16 ? hnsw_fn<false, kE, true>(latency) : hnsw_fn<false, kE, false>(latency));
+}
+
+// a batch this small leaves most SIMDs without a wave: latency, not occupancy, is what counts
+static bool hnsw_latency_variant(const HnswSearchArgs &a) { return a.nq <= 512; }
+
+static const void *hnsw_pick(bool l2, bool bf16, int e, bool latency) {
   switch (e) {
-    case 1: return hnsw_pick_e<1>(l2, bf16);
-    case 2: return hnsw_pick_e<2>(l2, bf16);
-    case 4: return hnsw_pick_e<4>(l2, bf16);
-    case 8: return hnsw_pick_e<8>(l2, bf16);
-    case kHnswLdsList: return hnsw_pick_e<0>(l2, bf16);
+    case 1: return hnsw_pick_e<1>(l2, bf16, latency);
+    case 2: return hnsw_pick_e<2>(l2, bf16, latency);
+    case 4: return hnsw_pick_e<4>(l2, bf16, latency);
+    case 8: return hnsw_pick_e<8>(l2, bf16, latency);
+    case kHnswLdsList: return hnsw_pick_e<0>(l2, bf16, latency);
   }
   return nullptr;
 }
 
 hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks) {
-  const void *f = hnsw_pick(l2, bf16, e);
+  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a));
   if (!f) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -470,7 +491,7 @@ hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, i
 }
 
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s) {
-  const void *f = hnsw_pick(l2, bf16, e);
+  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a));
   if (!f || blocks == 0) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 48 * 1024) {
