@@ -160,11 +160,32 @@ class FlatIndex final : public Index {
 
   Status add_batch(const uint64_t *labels, const float *rows, uint64_t n) override {
     std::unique_lock<std::shared_mutex> lk(rw_);
+    // Runs of labels that are new take consecutive slots at the end of the table (bruteforce.h:66-83), so a run
+    // can go from the caller's rows to HBM in one strided copy instead of row by row through the staging log;
+    // everything else (updates, the element that hits the capacity limit) keeps addPoint's path and message.
+    std::vector<uint64_t> run_labels;
+    uint64_t run_begin = 0;
+    auto close_run = [&](uint64_t end) -> Status {
+      if (run_labels.empty()) return Status::Ok();
+      const uint32_t first = (uint32_t)(count_ - run_labels.size());
+      Status s = store_.bulk_write(first, rows + run_begin * params_.dim, end - run_begin, run_labels.data());
+      run_labels.clear();
+      return s;
+    };
+    const bool bulk = n >= 256 && !store_.bf16();
     for (uint64_t i = 0; i < n; ++i) {
-      VK_TRY(add_locked(labels ? labels[i] : i, rows + i * params_.dim));
+      const uint64_t label = labels ? labels[i] : i;
+      if (bulk && count_ < capacity_ && slot_of_.find(label) == slot_of_.end()) {
+        if (run_labels.empty()) run_begin = i;
+        slot_of_.emplace(label, (uint32_t)count_++);
+        run_labels.push_back(label);
+        continue;
+      }
+      VK_TRY(close_run(i));
+      VK_TRY(add_locked(label, rows + i * params_.dim));
       if (store_.staged_bytes() >= ((size_t)256 << 20)) VK_TRY(store_.flush());
     }
-    return Status::Ok();
+    return close_run(n);
   }
 
   Status remove(uint64_t label) override {

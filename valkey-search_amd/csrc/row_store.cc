@@ -75,6 +75,29 @@ Status RowStore::stage_write(uint32_t slot, const float *row, uint64_t label) {
   return Status::Ok();
 }
 
+Status RowStore::bulk_write(uint32_t first, const float *rows, uint64_t n, const uint64_t *labels) {
+  if (elem_ != 4) return Status::Err(3, "bulk_write: f32 storage only");
+  if (n == 0) return Status::Ok();
+  VK_TRY(flush());
+  (void)hipSetDevice(device_);
+  VK_TRY(reserve((uint64_t)first + n));
+  const size_t rb = row_bytes(), src_pitch = (size_t)dim_ * 4;
+  char *dst = reinterpret_cast<char *>(d_rows_) + (size_t)first * rb;
+  if (rb != src_pitch) VK_HIP_TRY(hipMemsetAsync(dst, 0, n * rb, stream_));      // the zero padding of every row
+  // the source is the caller's pageable memory: pieces of 64 MiB keep the runtime's staging pipelined
+  const uint64_t piece = std::max<uint64_t>(1, ((uint64_t)64 << 20) / src_pitch);
+  for (uint64_t at = 0; at < n; at += piece) {
+    const uint64_t m = std::min<uint64_t>(piece, n - at);
+    VK_HIP_TRY(hipMemcpy2DAsync(dst + at * rb, rb, reinterpret_cast<const char *>(rows) + at * src_pitch, src_pitch, src_pitch, m,
+                                hipMemcpyHostToDevice, stream_));
+  }
+  if (h_labels_.size() < (size_t)first + n) h_labels_.resize((size_t)first + n, ~0ull);
+  memcpy(h_labels_.data() + first, labels, n * 8);
+  VK_HIP_TRY(hipMemcpyAsync(d_labels_ + first, labels, n * 8, hipMemcpyHostToDevice, stream_));
+  VK_HIP_TRY(hipStreamSynchronize(stream_));
+  return Status::Ok();
+}
+
 void RowStore::stage_move(uint32_t dst, uint32_t src, uint64_t label) {
   ops_.push_back(Op{1, dst, src, 0});
   stage_label(dst, label);

@@ -68,6 +68,9 @@ class RowStore {
 
   // host-side staging (caller serialises mutations)
   Status stage_write(uint32_t slot, const float *row, uint64_t label);  // row: dim floats
+  // n consecutive slots from `first`, straight from the caller's rows into the table (f32 storage only): pending
+  // operations are published first, so the order of effects is the order of calls
+  Status bulk_write(uint32_t first, const float *rows, uint64_t n, const uint64_t *labels);
   void stage_move(uint32_t dst, uint32_t src, uint64_t label);          // row[dst] = row[src]
   void stage_label(uint32_t slot, uint64_t label);
   // make sure the device arrays can hold `rows` slots (keeps contents)
