@@ -422,7 +422,7 @@ class FlatIndex final : public Index {
       return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     if (lb_dist_) e = 16;            // the paged scan has one instantiation: 16 slots per lane, one query per pass
-    const int qb = lb_dist_ ? 1 : flat_scan_pick_qb(nq, chunks, e);
+    const int qb = lb_dist_ ? 1 : flat_scan_pick_qb(nq, chunks, e, l2());
     const uint32_t nqg = (uint32_t)((nq + qb - 1) / qb);
     // rows: cancelled at entry -> only the first k rows are looked at (bruteforce.h:120-129)
     uint64_t row_end = count;

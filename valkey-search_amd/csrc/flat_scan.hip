@@ -319,12 +319,15 @@ int flat_scan_slots_per_lane(uint64_t k) {
   return 0;  // not served by the register-resident top-k
 }
 
-int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e) {
+int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e, bool l2) {
   // query block must fit LDS (<= 64 KiB so that two blocks share a CU) and, with wide
   // per-lane top-k state, registers
   static const int qb_cap = getenv("VK_SCAN_QB") ? atoi(getenv("VK_SCAN_QB")) : 8;
   int qb = nq >= 8 ? 8 : nq >= 4 ? 4 : nq >= 2 ? 2 : 1;
   if (qb > qb_cap) qb = qb_cap;
+  // L2 carries a subtract per element on top of the FMA: 8 queries per pass need all 256 VGPRs (one wave per
+  // SIMD) and run at 798 QPS at 10Mx768, B=256, where 4 per pass (two waves per SIMD) reach 1448
+  if (l2 && qb > 4) qb = 4;
   if (e > 1) qb = qb > 2 ? 2 : qb;
   if (e > 4) qb = 1;
   while (qb > 1 && (size_t)qb * chunks * 64 > 64 * 1024) qb >>= 1;

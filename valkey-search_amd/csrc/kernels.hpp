@@ -165,7 +165,7 @@ hipError_t launch_gather_u32(uint32_t *dst, const uint32_t *src, const uint32_t 
                              hipStream_t s);
 
 int flat_scan_slots_per_lane(uint64_t k);                 // 0 = k too large for the in-register top-k
-int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e);
+int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e, bool l2);
 hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, int e, hipStream_t s);
 hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s);
 hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipStream_t s);
