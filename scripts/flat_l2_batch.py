@@ -21,4 +21,4 @@ for B in (1, 8, 64, 256):
     t0 = time.perf_counter(); reps = 3
     for _ in range(reps): ix.search_batch(Q[:B], K)
     dt = (time.perf_counter() - t0) / reps
-    print(f"L2 B={B}: {dt*1e3:.2f} ms, {B/dt:.0f} QPS, {2*3*N*D*B/dt/1e12:.1f} TFLOP/s (sub+mul+add)", flush=True)
+    print(f"L2 B={B}: {dt*1e3:.2f} ms, {B/dt:.0f} QPS, {3*N*D*B/dt/1e12:.1f} TFLOP/s (sub+mul+add), {N*D*B/dt/1e12:.1f} T element-pairs/s", flush=True)

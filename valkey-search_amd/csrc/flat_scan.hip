@@ -20,6 +20,10 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+#ifndef VK_SCAN_XB
+#define VK_SCAN_XB(QB, L2) ((QB) >= 8 ? 4 : 8)
+#endif
+
 namespace vk {
 
 // kLb: the scan carries an exclusive lower bound (distance,label) per query (FlatIndex::search_in_passes, k > 1024:
@@ -77,13 +81,15 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
 #pragma unroll
     for (int qi = 0; qi < kQB; ++qi) acc[qi] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // row pieces in flight per lane: 8, or 4 where the accumulators of 8 queries need the registers
+    constexpr int kXB = VK_SCAN_XB(kQB, kL2);
     uint32_t c = 0;
-    for (; c + 8 <= chunks; c += 8) {
-      float4 x[8];
+    for (; c + kXB <= chunks; c += kXB) {
+      float4 x[kXB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
+      for (int u = 0; u < kXB; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kXB; ++u) {
 #pragma unroll
         for (int qi = 0; qi < kQB; ++qi) chunk_fma<kL2>(acc[qi], x[u], qs[(qi * chunks + c + u) * 4 + j]);
       }
@@ -325,9 +331,10 @@ int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e, bool l2) {
   static const int qb_cap = getenv("VK_SCAN_QB") ? atoi(getenv("VK_SCAN_QB")) : 8;
   int qb = nq >= 8 ? 8 : nq >= 4 ? 4 : nq >= 2 ? 2 : 1;
   if (qb > qb_cap) qb = qb_cap;
-  // L2 carries a subtract per element on top of the FMA: 8 queries per pass need all 256 VGPRs (one wave per
-  // SIMD) and run at 798 QPS at 10Mx768, B=256, where 4 per pass (two waves per SIMD) reach 1448
-  if (l2 && qb > 4) qb = 4;
+  // (occupancy decides here: with 8 row pieces in flight per lane, 8 queries per pass needed all 256 VGPRs for L2
+  // -- one wave per SIMD, 798 QPS at 10Mx768 B=256; with 4 in flight it is 158 VGPRs, three waves, 2359 QPS)
+  static const int qb_l2 = getenv("VK_SCAN_QB_L2") ? atoi(getenv("VK_SCAN_QB_L2")) : 8;
+  if (l2 && qb > qb_l2) qb = qb_l2;
   if (e > 1) qb = qb > 2 ? 2 : qb;
   if (e > 4) qb = 1;
   while (qb > 1 && (size_t)qb * chunks * 64 > 64 * 1024) qb >>= 1;
