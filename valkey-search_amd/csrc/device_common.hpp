@@ -185,7 +185,7 @@ struct WaveTopK {
     const uint64_t at_max = __ballot(have && bd == md);
     if (__popcll(at_max) == 1) {
       const int src = __ffsll((unsigned long long)at_max) - 1;
-      thr_d = md;
+      thr_d = readlane_f32(md, 0);       // (all lanes hold md; the read makes the gate a scalar register)
       thr_lab = readlane_u64(bl, src);
       thr_slot = (uint32_t)__builtin_amdgcn_readlane((int)bs, src);
       return;
@@ -198,9 +198,9 @@ struct WaveTopK {
       int oh = __shfl_xor((int)have, m);
       if (oh && (!have || dl_less(bd, bl, od, ol))) { bd = od; bl = ol; bs = os; have = true; }
     }
-    thr_d = bd;
-    thr_lab = bl;
-    thr_slot = bs;
+    thr_d = readlane_f32(bd, 0);
+    thr_lab = readlane_u64(bl, 0);
+    thr_slot = (uint32_t)__builtin_amdgcn_readlane((int)bs, 0);
   }
 
   // (cd, cl) wave-uniform.  Caller has already checked the distance gate cd <= thr_d.
