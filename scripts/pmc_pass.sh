@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 D=$ROOT/gpurun_out/pmc_$TAG
 rm -rf $D
 VK_GEMM_MODE=$M VK_GEMM_LOCKSTEP=$W timeout 300 rocprofv3 --pmc $CNT -d $D --output-format csv -- \
-  python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-query-steps 0 --hnsw-rows 0 > $D.log 2>&1
+  python $ROOT/bench.py ${BENCH_EXTRA:-} --steps 2 --warmup 1 --no-cpu-baseline --single-query-steps 0 --hnsw-rows 0 > $D.log 2>&1
 echo "== $TAG mode $M lockstep $W (rc $?)"
 python $ROOT/scripts/pmc_agg.py $D > $ROOT/gpurun_out/pmc_$TAG.json
 python - $ROOT/gpurun_out/pmc_$TAG.json <<'PY'

@@ -212,9 +212,13 @@ __device__ __forceinline__ void widen8(const float4 raw, float4 &lo, float4 &hi)
 template <bool kBf16>
 __device__ __forceinline__ void stage_store(float *buf, uint32_t lane, const Stg s) {
   if constexpr (kBf16) {
+    // The raw pieces are made opaque HERE, one stage after their load was issued: otherwise the compiler widens a
+    // piece right behind its global load and every stage waits (vmcnt(0)) for the HBM round trip it has just started.
+    float4 r0 = s.v0, r1 = s.v1;
+    asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
     float4 a0, a1, b0, b1;
-    widen8(s.v0, a0, a1);
-    widen8(s.v1, b0, b1);
+    widen8(r0, a0, a1);
+    widen8(r1, b0, b1);
     float *p0 = buf + bf16_lane_row(lane) * kXStride + (lane & 3) * 8;
     float *p1 = p0 + 16 * kXStride;
     *reinterpret_cast<float4 *>(p0) = a0;
@@ -399,6 +403,7 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
       _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                             \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+        if constexpr (kBf16) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   /* widen one float4 */ \
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                        \
       }                                                                                           \
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                          \
