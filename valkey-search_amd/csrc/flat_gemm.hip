@@ -530,7 +530,7 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
   static const int ablate = getenv("VK_GEMM_ABLATE") ? atoi(getenv("VK_GEMM_ABLATE")) : 0;
   // VK_GEMM_MODE=0: the compiler's own placement of the stage's memory operations (A/B switch)
   static const int mode_env = getenv("VK_GEMM_MODE") ? atoi(getenv("VK_GEMM_MODE")) : 7;
-  const int mode = mode_env == 7 || mode_env == 8 ? mode_env : 0;
+  const int mode = mode_env == 7 ? 7 : 0;
   static const int reg_env = getenv("VK_GEMM_REGLIST") ? atoi(getenv("VK_GEMM_REGLIST")) : 1;
   const bool reg = reg_env && a.k <= (uint32_t)kRegCap;
   const void *fn = a.prepass && !ablate ? (a.bf16 ? (reg ? reinterpret_cast<const void *>(&flat_gemm_prepass_kernel<true, true>)
@@ -542,8 +542,6 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
                  : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3, 7, false, false>)
                  : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4, 7, false, false>)
                  : ablate == 5 ? reinterpret_cast<const void *>(&flat_gemm_kernel<5, 7, false, false>)
-                 : mode == 8   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 8, true, false>)
-                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 8, false, false>))
                  : a.bf16      ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true, true>)
                                       : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false, true>))
                  : mode == 7   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true, false>)
