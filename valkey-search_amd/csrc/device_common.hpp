@@ -124,6 +124,38 @@ __device__ __forceinline__ float quad_row_distance(const char *__restrict__ base
   return finish_distance<kL2>(quad_reduce16(acc));
 }
 
+// The same distance for FEWER rows than the wave has quads: kSplit (2 or 4) quads share a row.  Quad g of a row
+// loads batch s*kSplit+g of its pieces while the others load theirs, then every quad receives the batches in
+// order through the cross-lane network and accumulates them, so the fma chain per lane class is the one of
+// quad_row_distance (bit-identical result) while one memory round trip covers kSplit batches.  Lane layout: group
+// g = lane / (64/kSplit); inside a group the usual quads (row = (lane % (64/kSplit)) / 4, j = lane % 4); `base` must
+// be the same row in every group.  All lanes return the distance.
+template <bool kL2, bool kBf16, int kBatch, int kSplit>
+__device__ __forceinline__ float quad_row_distance_split(const char *__restrict__ base, const float4 *qs, uint32_t chunks, int lane) {
+  constexpr int kGroupLanes = kWave / kSplit;
+  const int j = lane & 3, g = lane / kGroupLanes, in_group = lane % kGroupLanes;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t batches = chunks / kBatch;          // the caller checked chunks % kBatch == 0
+  for (uint32_t s0 = 0; s0 < batches; s0 += kSplit) {
+    float4 x[kBatch];
+    const uint32_t mine = s0 + g < batches ? s0 + g : batches - 1;   // (a group past the end re-reads the last batch)
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) x[u] = row_piece<kBf16>(base, (mine * kBatch + u) * 4 + j);
+#pragma unroll
+    for (int t = 0; t < kSplit; ++t) {
+      if (s0 + t < batches) {
+        const int src = t * kGroupLanes + in_group;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const float4 y = make_float4(__shfl(x[u].x, src), __shfl(x[u].y, src), __shfl(x[u].z, src), __shfl(x[u].w, src));
+          chunk_fma<kL2>(acc, y, qs[((s0 + t) * kBatch + u) * 4 + j]);
+        }
+      }
+    }
+  }
+  return finish_distance<kL2>(quad_reduce16(acc));
+}
+
 // ---- (distance,label) total order: std::pair<float,size_t> operator< ------------------
 __device__ __forceinline__ bool dl_less(float da, uint64_t la, float db, uint64_t lb) {
   return da < db || (da == db && la < lb);

@@ -33,6 +33,7 @@
 #include "device_common.hpp"
 #include "kernels.hpp"
 
+
 namespace vk {
 
 namespace {
@@ -157,7 +158,7 @@ __device__ __forceinline__ void pool_prune(Pool &c, float bound, int lane) {
 
 // Shared body.  kBatch = row pieces in flight per lane (device_common.hpp): 8 for the throughput kernel,
 // 24 for the latency kernel that serves small batches.
-template <bool kL2, int kE, bool kBf16, int kBatch>
+template <bool kL2, int kE, bool kBf16, int kBatch, bool kSplitRows>
 __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63;
@@ -196,6 +197,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
 
+    const bool can_split = kSplitRows && chunks % kBatch == 0 && chunks >= 2 * kBatch;
     auto row_dist = [&](uint32_t id) -> float {
       return quad_row_distance<kL2, kBf16, kBatch>(row_base<kBf16>(a.rows, id, a.row_stride_f), qs, chunks, j);
     };
@@ -295,12 +297,29 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         if (unv) nbr_id[nn + __popcll(m & ((1ull << lane) - 1ull))] = nid;
         nn += __popcll(m);
       }
-      // phase 3a: distances, 16 rows per round
-      for (uint32_t base = 0; base < nn; base += kRowsPerWave) {
-        const uint32_t u = base + rq;
-        const uint32_t nid = nbr_id[u < nn ? u : nn - 1];
-        const float dv = row_dist(nid);
-        if (u < nn && j == 0) nbr_d[u] = dv;
+      // phase 3a: distances, 16 rows per round; a round of <= 8 (<= 4) rows gives every row two (four) quads, which
+      // fetch alternate batches of its pieces (same arithmetic, half / a quarter of the memory round trips)
+      for (uint32_t base = 0; base < nn;) {
+        const uint32_t rem = nn - base;
+        if (rem > 8 || !can_split) {
+          const uint32_t u = base + rq;
+          const uint32_t nid = nbr_id[u < nn ? u : nn - 1];
+          const float dv = row_dist(nid);
+          if (u < nn && j == 0) nbr_d[u] = dv;
+          base += kRowsPerWave;
+        } else if (rem > 4) {
+          const uint32_t u = base + ((lane & 31) >> 2);
+          const uint32_t nid = nbr_id[u < nn ? u : nn - 1];
+          const float dv = quad_row_distance_split<kL2, kBf16, kBatch, 2>(row_base<kBf16>(a.rows, nid, a.row_stride_f), qs, chunks, lane);
+          if (u < nn && (lane & 35) == 0) nbr_d[u] = dv;      // j == 0 of group 0
+          base += 8;
+        } else {
+          const uint32_t u = base + ((lane & 15) >> 2);
+          const uint32_t nid = nbr_id[u < nn ? u : nn - 1];
+          const float dv = quad_row_distance_split<kL2, kBf16, kBatch, 4>(row_base<kBf16>(a.rows, nid, a.row_stride_f), qs, chunks, lane);
+          if (u < nn && (lane & 51) == 0) nbr_d[u] = dv;
+          base += 4;
+        }
       }
       st_eval += nn;
       // phase 3b: consider in list order, bound updated after each neighbour
@@ -399,13 +418,13 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
 // 4 waves per SIMD (<= 128 VGPRs): a full batch is bound by gathers in flight, i.e. by resident waves
 template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
-  hnsw_search_body<kL2, kE, kBf16, 8>(a);
+  hnsw_search_body<kL2, kE, kBf16, 8, false>(a);
 }
 // a few queries cannot fill the device: each wave is alone with its memory latency, so it keeps three times as
 // many row pieces in flight (registers instead of occupancy)
 template <bool kL2, int kE, bool kBf16>
-__global__ __launch_bounds__(256, 2) void hnsw_search_latency_kernel(HnswSearchArgs a) {
-  hnsw_search_body<kL2, kE, kBf16, 24>(a);
+__global__ __launch_bounds__(256, 1) void hnsw_search_latency_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, 24, true>(a);
 }
 
 __global__ void scatter_u32_kernel(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride) {
