@@ -233,17 +233,22 @@ class FlatIndex final : public Index {
     const uint64_t *d_allow = nullptr;
     VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
     if (k > kMaxPassK) return search_in_passes(ctx, rq, k, count, d_allow, out_dist, out_label, out_n);
-    VK_TRY(ctx->d_out_d.ensure(rq.nq * k * 4));
-    VK_TRY(ctx->d_out_l.ensure(rq.nq * k * 8));
-    VK_TRY(ctx->d_out_n.ensure(rq.nq * 4));
-    VK_TRY(scan(ctx, ctx->d_q.as<float>(), rq.nq, k, count, d_allow, rq.allow_nbits, rq.cancel_flag,
-                ctx->d_out_d.as<float>(), ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream));
     VK_TRY(ctx->h_out_d.ensure(rq.nq * k * 4));
     VK_TRY(ctx->h_out_l.ensure(rq.nq * k * 8));
     VK_TRY(ctx->h_out_n.ensure(rq.nq * 4));
-    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, ctx->d_out_d.p, rq.nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (rq.nq * k <= kZeroCopyEntries) {
+      VK_TRY(scan(ctx, ctx->d_q.as<float>(), rq.nq, k, count, d_allow, rq.allow_nbits, rq.cancel_flag,
+                  ctx->h_out_d.as<float>(), ctx->h_out_l.as<uint64_t>(), ctx->h_out_n.as<uint32_t>(), ctx->stream));
+    } else {
+      VK_TRY(ctx->d_out_d.ensure(rq.nq * k * 4));
+      VK_TRY(ctx->d_out_l.ensure(rq.nq * k * 8));
+      VK_TRY(ctx->d_out_n.ensure(rq.nq * 4));
+      VK_TRY(scan(ctx, ctx->d_q.as<float>(), rq.nq, k, count, d_allow, rq.allow_nbits, rq.cancel_flag,
+                  ctx->d_out_d.as<float>(), ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, ctx->d_out_d.p, rq.nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
     // caller's buffers are [nq][rq.k]
     for (uint64_t q = 0; q < rq.nq; ++q) {

@@ -148,17 +148,22 @@ class HnswIndex final : public Index {
     VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f()));
     const uint64_t *d_allow = nullptr;
     VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
-    VK_TRY(ctx->d_out_d.ensure(rq.nq * rq.k * 4));
-    VK_TRY(ctx->d_out_l.ensure(rq.nq * rq.k * 8));
-    VK_TRY(ctx->d_out_n.ensure(rq.nq * 4));
-    VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, rq.allow_nbits, ctx->d_out_d.as<float>(),
-                  ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream, true));
     VK_TRY(ctx->h_out_d.ensure(rq.nq * rq.k * 4));
     VK_TRY(ctx->h_out_l.ensure(rq.nq * rq.k * 8));
     VK_TRY(ctx->h_out_n.ensure(rq.nq * 4 + 32));
-    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, ctx->d_out_d.p, rq.nq * rq.k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * rq.k * 8, hipMemcpyDeviceToHost, ctx->stream));
-    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (rq.nq * rq.k <= kZeroCopyEntries) {   // the kernel writes the answer into the pinned host buffers
+      VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, rq.allow_nbits, ctx->h_out_d.as<float>(),
+                    ctx->h_out_l.as<uint64_t>(), ctx->h_out_n.as<uint32_t>(), ctx->stream, true));
+    } else {
+      VK_TRY(ctx->d_out_d.ensure(rq.nq * rq.k * 4));
+      VK_TRY(ctx->d_out_l.ensure(rq.nq * rq.k * 8));
+      VK_TRY(ctx->d_out_n.ensure(rq.nq * 4));
+      VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, rq.allow_nbits, ctx->d_out_d.as<float>(),
+                    ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream, true));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, ctx->d_out_d.p, rq.nq * rq.k * 4, hipMemcpyDeviceToHost, ctx->stream));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * rq.k * 8, hipMemcpyDeviceToHost, ctx->stream));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.as<char>() + rq.nq * 4, ctx->d_stats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
     VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
     {

@@ -35,6 +35,11 @@ struct PinBuf {
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
+// Results this small are written by the kernels straight into the pinned host buffers (hipHostMalloc memory is
+// mapped into the device's address space): a one-at-a-time query pays no device-to-host copy calls, only the
+// stream synchronisation.  Larger results go through device buffers and one copy each (PCIe bandwidth, not latency).
+constexpr uint64_t kZeroCopyEntries = 4096;   // nq * k
+
 // Per-call resources: a stream plus scratch, so that concurrent reader threads
 // (search.cc:886-910 schedules one query per reader-pool thread) do not serialise.
 struct SearchCtx {
