@@ -6,7 +6,7 @@ dev = torch.device("cuda", 0)
 N, D = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, 768
 x = torch.empty(N, D, device=dev)
 x.normal_()
-M = 2_000_000
+M = min(2_000_000, N)
 g = torch.Generator(device=dev); g.manual_seed(1)
 idx = torch.randint(0, N, (M,), device=dev, generator=g)
 out = torch.empty(M, D, device=dev)
