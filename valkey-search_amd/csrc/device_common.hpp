@@ -36,6 +36,21 @@ __device__ __forceinline__ float dpp_quad_xor2(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
 }
 
+// Wave-wide maximum, wave-uniform result, without the LDS crossbar: butterfly inside each row of 16 lanes with DPP
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row results through scalar registers.
+// (__shfl_xor is a ds_bpermute per step; this chain is what a top-k update waits on.)
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = fmaxf(v, dpp_quad_xor1(v));
+  v = fmaxf(v, dpp_quad_xor2(v));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));  // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 // acc = this lane's accumulators 4j..4j+3 of a row.  Every lane of the quad returns the
 // full 16-accumulator sum in _mm512_reduce_add_ps order.
 __device__ __forceinline__ float quad_reduce16(float4 acc) {
@@ -211,13 +226,11 @@ struct WaveTopK {
     if (!have) { bd = -__builtin_inff(); bl = 0; }
     // fast path: reduce the distance alone (one shuffle per step instead of five); only when several lanes
     // hold the maximum distance does the label have to take part
-    float md = bd;
-#pragma unroll
-    for (int m = 1; m < kWave; m <<= 1) md = fmaxf(md, __shfl_xor(md, m));
+    const float md = wave_max_f32(bd);
     const uint64_t at_max = __ballot(have && bd == md);
     if (__popcll(at_max) == 1) {
       const int src = __ffsll((unsigned long long)at_max) - 1;
-      thr_d = readlane_f32(md, 0);       // (all lanes hold md; the read makes the gate a scalar register)
+      thr_d = md;                        // (wave-uniform, in scalar registers)
       thr_lab = readlane_u64(bl, src);
       thr_slot = (uint32_t)__builtin_amdgcn_readlane((int)bs, src);
       return;

@@ -280,6 +280,132 @@ __global__ __launch_bounds__(256) void gather_distance_kernel(GatherArgs a) {
   }
 }
 
+// The same merge by SELECTION, for k <= 64 and at most 4096 partial entries per query (every scan of a small or
+// mid-sized index: the stream of inserts above is a serial chain of ~k*ln(n/k) wave-wide updates, 39 us for the 392
+// lists of a 100k-row index, more than the scan itself).  Each thread keeps its <= 16 entries in registers; the block
+// finds the k-th smallest distance key by a 32-step binary descent (a compare + ballot + s_bcnt1 per entry and step,
+// one barrier per step), breaks a tie at that key by a second descent over the labels, compacts the exactly k winners
+// into LDS and rank-sorts them.  Same answer as merge_topk_kernel: the k smallest by (distance, label), ascending.
+__device__ __forceinline__ uint32_t merge_key(float f) {   // order-preserving f32 -> u32 (no NaNs reach a merge)
+  uint32_t u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0;                            // -0 == +0 for the float compare of the other path
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+constexpr int kSelPerThread = 16;
+constexpr uint32_t kMergeSelectMax = 256 * kSelPerThread;
+
+__global__ __launch_bounds__(256) void merge_select_kernel(MergeArgs a) {
+  __shared__ uint32_t s_cnt[2][4];
+  __shared__ uint32_t s_n;
+  __shared__ float c_d[64];
+  __shared__ uint64_t c_l[64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t q = blockIdx.x;
+  const uint32_t total = a.parts * a.per_part;
+
+  uint32_t key[kSelPerThread];
+  uint64_t lab[kSelPerThread];
+  float dv[kSelPerThread];
+  {
+    // all loads first (an entry past the end re-reads entry 0 and is dropped afterwards): one memory round trip
+    const float *__restrict__ qd = a.in_dist + q * a.q_stride;
+    const uint64_t *__restrict__ ql = a.in_label + q * a.q_stride;
+    if (a.parts == 1) {
+#pragma unroll
+      for (int u = 0; u < kSelPerThread; ++u) {
+        const uint32_t e = tid + 256u * u < total ? tid + 256u * u : 0u;
+        lab[u] = ql[e];
+        dv[u] = qd[e];
+      }
+    } else {   // segmented scans, shard merges: entry (part, i)
+#pragma unroll
+      for (int u = 0; u < kSelPerThread; ++u) {
+        const uint32_t e = tid + 256u * u < total ? tid + 256u * u : 0u;
+        const uint32_t part = e / a.per_part;
+        const size_t o = (size_t)part * a.part_stride + (e - part * a.per_part);
+        lab[u] = ql[o];
+        dv[u] = qd[o];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSelPerThread; ++u) {
+      if (tid + 256u * u >= total) lab[u] = kNoLabel;
+      key[u] = lab[u] != kNoLabel ? merge_key(dv[u]) : 0xFFFFFFFFu;
+    }
+  }
+  if (tid == 0) s_n = 0;
+
+  uint32_t phase = 0;
+  // block-wide sum of the waves' (uniform) counts through LDS, one barrier (the two halves of s_cnt alternate)
+  auto block_sum = [&](uint32_t mine) -> uint32_t {
+    if (lane == 0) s_cnt[phase][wave] = mine;
+    __syncthreads();
+    const uint32_t t = s_cnt[phase][0] + s_cnt[phase][1] + s_cnt[phase][2] + s_cnt[phase][3];
+    phase ^= 1;
+    return t;
+  };
+  uint32_t c = 0;
+#pragma unroll
+  for (int u = 0; u < kSelPerThread; ++u) c += (uint32_t)__popcll(__ballot(lab[u] != kNoLabel));
+  const uint32_t real = block_sum(c);
+  const uint32_t k = real < a.k ? real : a.k;
+  float *od = a.out_dist + q * a.k;
+  uint64_t *ol = a.out_label + q * a.k;
+  if (tid >= k && tid < a.k) { od[tid] = __builtin_inff(); ol[tid] = kNoLabel; }
+  if (tid == 0) a.out_n[q] = k;
+  if (k == 0) return;
+
+  // T = the k-th smallest key: the largest T with count(key < T) < k
+  uint32_t T = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = T | (1u << bit);
+    c = 0;
+#pragma unroll
+    for (int u = 0; u < kSelPerThread; ++u) c += (uint32_t)__popcll(__ballot(key[u] < cand));
+    if (block_sum(c) < k) T = cand;
+  }
+  c = 0;
+  uint32_t ce = 0;
+#pragma unroll
+  for (int u = 0; u < kSelPerThread; ++u) {
+    c += (uint32_t)__popcll(__ballot(key[u] < T));
+    ce += (uint32_t)__popcll(__ballot(key[u] == T && lab[u] != kNoLabel));
+  }
+  const uint32_t below = block_sum(c), at = block_sum(ce);
+  // a tie at the k-th key: of the `at` entries there, the k - below with the smallest labels win
+  uint64_t L = ~0ull;
+  if (below + at > k) {
+    const uint32_t need = k - below;
+    L = 0;
+    for (int bit = 63; bit >= 0; --bit) {
+      const uint64_t cand = L | (1ull << bit);
+      c = 0;
+#pragma unroll
+      for (int u = 0; u < kSelPerThread; ++u) c += (uint32_t)__popcll(__ballot(key[u] == T && lab[u] < cand));
+      if (block_sum(c) < need) L = cand;
+    }
+  }
+  // the k winners -> LDS (any order), then every winner's rank among them by (distance, label)
+#pragma unroll
+  for (int u = 0; u < kSelPerThread; ++u) {
+    if (lab[u] != kNoLabel && (key[u] < T || (key[u] == T && lab[u] <= L))) {
+      const uint32_t slot = atomicAdd(&s_n, 1u);
+      c_d[slot] = dv[u];
+      c_l[slot] = lab[u];
+    }
+  }
+  __syncthreads();
+  if (tid < k) {
+    const float md = c_d[tid];
+    const uint64_t ml = c_l[tid];
+    uint32_t rank = 0;
+    for (uint32_t t = 0; t < k; ++t) rank += dl_less(c_d[t], c_l[t], md, ml) ? 1u : 0u;
+    od[rank] = md;
+    ol[rank] = ml;
+  }
+}
+
 // ---- launchers ----------------------------------------------------------------------------------
 template <bool kL2, bool kBf16>
 static hipError_t launch_scan_lb(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
@@ -361,6 +487,11 @@ hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, i
 hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s) {
   if (nq == 0) return hipSuccess;
   dim3 grid((uint32_t)nq);
+  static const bool select = !(getenv("VK_MERGE_SELECT") && atoi(getenv("VK_MERGE_SELECT")) == 0);
+  if (select && e == 1 && (uint64_t)a.parts * a.per_part <= kMergeSelectMax) {
+    hipLaunchKernelGGL(merge_select_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   const size_t lds = (size_t)(3 * e * 64 + 2) * 4 + (size_t)3 * e * 64 * 8;
   if (e == 1) hipLaunchKernelGGL((merge_topk_kernel<1>), grid, dim3(256), lds, s, a);
   else if (e == 4) hipLaunchKernelGGL((merge_topk_kernel<4>), grid, dim3(256), lds, s, a);
