@@ -78,8 +78,10 @@ struct WaveSorted {
 #pragma unroll
     for (int e = kE - 1; e >= 0; --e) {
       if ((uint32_t)e * kWave + (kWave - 1) < pos) continue;  // whole slot row is in front of pos
-      float up_d = __shfl_up(d[e], 1);
-      uint32_t up_id = __shfl_up((int)id[e], 1);
+      // lane i <- lane i-1 over the whole wave: DPP wave_shr:1, not a trip through the LDS crossbar (__shfl_up);
+      // lane 0 is patched below
+      float up_d = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[e]), 0x138, 0xF, 0xF, false));
+      uint32_t up_id = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)id[e], 0x138, 0xF, 0xF, false);
       float cd = 0.f;
       uint32_t cid = 0;
       if (e > 0) {
