@@ -422,11 +422,11 @@ template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
   hnsw_search_body<kL2, kE, kBf16, 8, false>(a);
 }
-// a few queries cannot fill the device: each wave is alone with its memory latency, so it keeps three times as
-// many row pieces in flight (registers instead of occupancy)
+// a few queries cannot fill the device: each wave is alone with its memory latency, so it keeps six times as
+// many row pieces in flight (a whole 768-d row per lane; one block per CU, registers instead of occupancy)
 template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 1) void hnsw_search_latency_kernel(HnswSearchArgs a) {
-  hnsw_search_body<kL2, kE, kBf16, 24, true>(a);
+  hnsw_search_body<kL2, kE, kBf16, 48, true>(a);
 }
 
 __global__ void scatter_u32_kernel(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride) {
