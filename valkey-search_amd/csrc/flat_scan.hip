@@ -295,11 +295,49 @@ __device__ __forceinline__ uint32_t merge_key(float f) {   // order-preserving f
 constexpr int kSelPerThread = 16;
 constexpr uint32_t kMergeSelectMax = 256 * kSelPerThread;
 
+// Wave-wide selection over kN entries per lane (empty entries: key 0xFFFFFFFF, label kNoLabel): thresholds (T, L) such
+// that exactly k entries satisfy key < T || (key == T && label <= L) -- the k smallest by (key, label); k <= the
+// number of real entries.  Counts are ballots + s_bcnt1, wave-uniform: no LDS, no barrier.
+template <int kN>
+__device__ __forceinline__ void wave_select(const uint32_t (&key)[kN], const uint64_t (&lab)[kN], uint32_t k, uint32_t &T,
+                                            uint64_t &L) {
+  T = 0;
+  for (int bit = 31; bit >= 0; --bit) {   // T = the k-th smallest key = the largest T with count(key < T) < k
+    const uint32_t cand = T | (1u << bit);
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < kN; ++u) c += (uint32_t)__popcll(__ballot(key[u] < cand));
+    if (c < k) T = cand;
+  }
+  uint32_t below = 0, at = 0;
+#pragma unroll
+  for (int u = 0; u < kN; ++u) {
+    below += (uint32_t)__popcll(__ballot(key[u] < T));
+    at += (uint32_t)__popcll(__ballot(key[u] == T && lab[u] != kNoLabel));
+  }
+  L = ~0ull;
+  if (below + at > k) {   // a tie at the k-th key: the k - below smallest labels among them
+    const uint32_t need = k - below;
+    L = 0;
+    for (int bit = 63; bit >= 0; --bit) {
+      const uint64_t cand = L | (1ull << bit);
+      uint32_t c = 0;
+#pragma unroll
+      for (int u = 0; u < kN; ++u) c += (uint32_t)__popcll(__ballot(key[u] == T && lab[u] < cand));
+      if (c < need) L = cand;
+    }
+  }
+}
+
+constexpr uint32_t kSelSurvivors = 256;   // 4 per lane of one wave
+
 __global__ __launch_bounds__(256) void merge_select_kernel(MergeArgs a) {
   __shared__ uint32_t s_cnt[2][4];
-  __shared__ uint32_t s_n;
+  __shared__ uint32_t s_n, s_bound;
   __shared__ float c_d[64];
   __shared__ uint64_t c_l[64];
+  __shared__ float v_d[kSelSurvivors];
+  __shared__ uint64_t v_l[kSelSurvivors];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t q = blockIdx.x;
   const uint32_t total = a.parts * a.per_part;
@@ -356,6 +394,82 @@ __global__ __launch_bounds__(256) void merge_select_kernel(MergeArgs a) {
   if (tid == 0) a.out_n[q] = k;
   if (k == 0) return;
 
+  // Fast path.  Wave 0 finds the k-th smallest key U of 256 of its entries (a sample; wave-local, no barriers);
+  // the answer lies among the entries with key <= U.  If at most 256 survive (k up to about 15 for a full input),
+  // wave 0 selects among them on its own: 4 barriers in all instead of one per bit.
+  if (wave == 0) {
+    uint32_t skey[4];
+    uint64_t slab[4];
+    uint32_t sreal = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      skey[u] = key[u];
+      slab[u] = lab[u];
+      sreal += (uint32_t)__popcll(__ballot(lab[u] != kNoLabel));
+    }
+    uint32_t U = 0xFFFFFFFFu;
+    if (sreal >= k) {
+      uint64_t Lu;
+      wave_select<4>(skey, slab, k, U, Lu);
+    }
+    if (lane == 0) s_bound = U;
+  }
+  __syncthreads();
+  const uint32_t U = s_bound;
+  c = 0;
+#pragma unroll
+  for (int u = 0; u < kSelPerThread; ++u) c += (uint32_t)__popcll(__ballot(lab[u] != kNoLabel && key[u] <= U));
+  const uint32_t survivors = block_sum(c);
+  if (survivors <= kSelSurvivors) {
+#pragma unroll
+    for (int u = 0; u < kSelPerThread; ++u) {
+      if (lab[u] != kNoLabel && key[u] <= U) {
+        const uint32_t slot = atomicAdd(&s_n, 1u);
+        v_d[slot] = dv[u];
+        v_l[slot] = lab[u];
+      }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t key2[4];
+    uint64_t lab2[4];
+    float d2[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t i = lane + 64u * w;
+      const bool have = i < survivors;
+      d2[w] = have ? v_d[i] : __builtin_inff();
+      lab2[w] = have ? v_l[i] : kNoLabel;
+      key2[w] = have ? merge_key(d2[w]) : 0xFFFFFFFFu;
+    }
+    uint32_t T2;
+    uint64_t L2;
+    wave_select<4>(key2, lab2, k, T2, L2);
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const bool win = lab2[w] != kNoLabel && (key2[w] < T2 || (key2[w] == T2 && lab2[w] <= L2));
+      const uint64_t m = __ballot(win);
+      if (win) {
+        const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        c_d[slot] = d2[w];
+        c_l[slot] = lab2[w];
+      }
+      base += (uint32_t)__popcll(m);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes before its reads below
+    if (lane < k) {
+      const float md = c_d[lane];
+      const uint64_t ml = c_l[lane];
+      uint32_t rank = 0;
+      for (uint32_t t = 0; t < k; ++t) rank += dl_less(c_d[t], c_l[t], md, ml) ? 1u : 0u;
+      od[rank] = md;
+      ol[rank] = ml;
+    }
+    return;
+  }
+
+  // General path: the same descent over all entries, block-wide (one barrier per bit).
   // T = the k-th smallest key: the largest T with count(key < T) < k
   uint32_t T = 0;
   for (int bit = 31; bit >= 0; --bit) {
