@@ -103,6 +103,29 @@ def test_ties_resolve_by_label(vsa, oracle):
         _assert_same(gd, gl, od, ol)
 
 
+@pytest.mark.parametrize("copies", [6000, 700])
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_massive_distance_ties_are_broken_by_label(vsa, oracle, copies, metric):
+    """A few distinct rows, each stored thousands of times under shuffled labels: every partial list the scan leaves
+    is full of equal distances, so the merge has to pick the k smallest LABELS at the k-th distance (the selection
+    merge's second descent; with 6000 copies the survivors overflow its fast path as well).  Single query, a batch
+    on the scan kernel and a batch on the matrix-core path."""
+    dim = 64
+    base = _data(3, dim, 91)
+    x = np.repeat(base, copies, axis=0)
+    labels = (np.random.default_rng(92).permutation(len(x)).astype(np.uint64) + 7)
+    g, o = _both(vsa, oracle, x, metric, labels=labels)
+    Q = np.concatenate([base, _data(5, dim, 93)])
+    for k in (1, 10, 64):
+        for q in Q[:4]:
+            _assert_same(*g.search(q, k), *o.search(q, k))
+        D, L, N = g.search_batch(Q, k)
+        for i in range(len(Q)):
+            od, ol = o.search(Q[i], k)
+            assert N[i] == k
+            _assert_same(D[i], L[i], od, ol)
+
+
 def test_reference_generator_collinear_data(vsa, oracle):
     """testing/common.cc vectors: near-collinear rows, many near ties (search_test.cc fixture)."""
     x = reference_vectors(10000, 100, 10.0)
