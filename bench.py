@@ -150,8 +150,10 @@ def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
     d_bits = torch.from_numpy(tag_bits.view(np.int64)).to(device)
     _, gt_f, _ = flat_ix.search_batch(hq[:1024], K, allow=tag_bits, allow_nbits=Nh)
 
+    ef_h = 256   # BASELINE.json configs[4]: efSearch = 256 for the hybrid queries
+
     def run_f():
-        h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef,
+        h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef_h,
                               d_allow=d_bits.data_ptr(), allow_nbits=Nh, stream=stream_ptr())
 
     run_f()
@@ -172,7 +174,7 @@ def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
     pre_dt = time.perf_counter() - t1
     _, gt_p, ngt = flat_ix.search_batch(hq[:256], K, allow=key_bits, allow_nbits=Nh)
     pre_ok = all(set(pre[i][1].tolist()) == set(gt_p[i, :ngt[i]].tolist()) for i in range(256))
-    hybrid = {"inline_filter": {"selectivity": 0.1, "gpu_qps": round(nq / (ms_f * 1e-3), 1), "recall_at_10": round(recall_f, 4)},
+    hybrid = {"inline_filter": {"selectivity": 0.1, "ef": ef_h, "gpu_qps": round(nq / (ms_f * 1e-3), 1), "recall_at_10": round(recall_f, 4)},
               "pre_filter": {"keys": int(len(keys)), "selectivity": round(len(keys) / Nh, 5),
                              "qps_single_caller": round(256 / pre_dt, 1), "exact": bool(pre_ok)}}
     return {"rows": Nh, "M": 16, "ef_construction": 200, "ef": ef, "k": K, "queries_per_batch": nq, "hybrid": hybrid,
