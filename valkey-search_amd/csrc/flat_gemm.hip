@@ -136,11 +136,13 @@ struct StreamPos {
   uint32_t left;        // stages still to come, this one included
 };
 __device__ __forceinline__ void stream_advance(StreamPos &p, uint32_t stages, uint32_t tile_step_rows) {
-  // branch-free (a stage of the main loop must stay one basic block for the instruction interleave),
-  // and a no-op once the stream is exhausted
-  const bool go = p.left != 0;
+  // branch-free (a stage of the main loop must stay one basic block for the instruction interleave).  The position
+  // never moves past the LAST stage of the stream: the prefetches issued behind the end re-read that stage (it used
+  // to step on to the following tile, up to 128 rows past the store's slack: a fault when the allocation ends on a
+  // page boundary right there -- 4362 rows of 576 floats did)
+  const bool go = p.left > 1;
   const bool wrap = go && p.st + 1 == stages;
-  p.left -= go ? 1u : 0u;
+  p.left -= p.left != 0 ? 1u : 0u;
   p.st = wrap ? 0u : p.st + (go ? 1u : 0u);
   p.tile_row0 += wrap ? tile_step_rows : 0u;
 }
