@@ -24,7 +24,7 @@ DIMS = [1, 3, 16, 17, 48, 64, 100, 128, 192, 255, 256, 320, 384, 512, 700, 768, 
 BATCHES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 31, 32, 33, 64, 100, 257]
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(72))
 def test_random_shape(vsa, oracle, seed):
     rng = np.random.default_rng(5000 + seed)
     dim = int(rng.choice(DIMS))
