@@ -1,0 +1,63 @@
+"""Randomised sweep over the device-assisted HNSW build (K9): size, dimension, M, efConstruction, metric, row
+storage and how the rows arrive (one add_batch, two, or a host-built prefix first).  Pinned: recall against the
+exact answer no worse than the host build's, the structural rules LoadIndex checks (via a save/load round trip),
+the degree bound, and that the CPU oracle walking the saved graph returns the device's answers."""
+import numpy as np
+import pytest
+
+from test_hnsw_build_gpu import build, latent, recall
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vsa():
+    import _pkg
+    return _pkg.vsa
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_build(vsa, oracle, seed):
+    rng = np.random.default_rng(7000 + seed)
+    dim = int(rng.choice([16, 48, 100, 256, 768]))
+    n = int(rng.integers(6000, 26000 if dim <= 100 else 12000))
+    M = int(rng.choice([4, 8, 16, 32, 48]))
+    efc = int(rng.choice([40, 100, 200]))
+    metric = str(rng.choice(["IP", "L2"]))
+    dtype = "bf16" if rng.random() < 0.3 else "f32"
+    tag = (dim, n, M, efc, metric, dtype)
+    x = latent(n, dim, 100 + seed)
+    Q = latent(200, dim, 200 + seed)
+    flat = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype)
+    flat.add_batch(x)
+    gd = vsa.Index("HNSW", dim, metric, initial_cap=n, m=M, ef_construction=efc, ef_runtime=64, dtype=dtype)
+    how = int(rng.integers(0, 3))
+    if how == 0:
+        gd.add_batch(x)
+    elif how == 1:                                     # two bulk batches
+        cut = n // 2
+        gd.add_batch(x[:cut], np.arange(cut, dtype=np.uint64))
+        gd.add_batch(x[cut:], np.arange(cut, n, dtype=np.uint64))
+    else:                                              # a host-built prefix, then the bulk path
+        for i in range(300):
+            assert gd.add(i, x[i]) == 0
+        gd.add_batch(x[300:], np.arange(300, n, dtype=np.uint64))
+    assert gd.stats().count == n, tag
+    gh = build(vsa, x, False, metric, M=M, efc=efc) if dtype == "f32" else None
+    rd = recall(gd, flat, Q)
+    if gh is not None:
+        rh = recall(gh, flat, Q)
+        assert rd >= rh - 0.03, (tag, rd, rh)
+    assert rd >= (0.55 if M == 4 else 0.8), (tag, rd)
+    chunks = gd.save()
+    g2 = vsa.Index.load(chunks, "HNSW", dim, metric, initial_cap=n, m=M, ef_construction=efc, dtype=dtype)
+    assert g2.stats().count == n, tag
+    M0 = 2 * M
+    deg = np.array([int(np.frombuffer(c[:4], np.uint32)[0] & 0xFFFF) for c in chunks[1:1 + n]])
+    assert deg.max() <= M0 and (deg == 0).sum() <= n // 1000, (tag, deg.max(), int((deg == 0).sum()))
+    if dtype == "f32":
+        o = oracle.HNSW.from_saved_chunks(chunks, dim, metric, M, ef_construction=efc)
+        for q in Q[:10]:
+            d0, l0 = gd.search(q, 10, ef=64)
+            d1, l1 = o.search(q, 10, ef=64)
+            assert l0.tolist() == l1.tolist() and d0.view(np.uint32).tolist() == d1.view(np.uint32).tolist(), tag
