@@ -81,3 +81,29 @@ def test_random_shape(vsa, oracle, seed):
             assert N[i] == len(sel), (dim, n, nq, metric, dtype, k)
             assert L[i, :N[i]].tolist() == ol[sel].tolist(), (dim, n, nq, metric, dtype, k)
             assert D[i, :N[i]].view(np.uint32).tolist() == od[sel].view(np.uint32).tolist()
+
+
+@pytest.mark.parametrize("dim", [64, 576, 768])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 4095, 4096, 4097, 16383, 16385])
+def test_sizes_around_tile_boundaries(vsa, oracle, n, dim):
+    """Row counts one below, at and one above the tile sizes of the kernels (16 rows per wave in the scan, 128 per
+    block on the matrix cores, 4096-entry merges), one query, a scan batch and a matrix-core batch; followed by a
+    save / load round trip that must answer the same."""
+    rng = np.random.default_rng(n * 131 + dim)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g = vsa.Index("FLAT", dim, "IP", initial_cap=n)
+    g.add_batch(x)
+    o = oracle.Flat(dim, "IP", max_elements=n)
+    o.add_many(x)
+    k = min(10, n)
+    for nq in (1, 4, 40):
+        Q = rng.standard_normal((nq, dim)).astype(np.float32)
+        D, L, N = g.search_batch(Q, k)
+        for i in range(0, nq, 7):
+            od, ol = o.search(Q[i], k)
+            assert N[i] == len(ol)
+            assert L[i, :N[i]].tolist() == ol.tolist(), (n, dim, nq)
+            assert D[i, :N[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist(), (n, dim, nq)
+    g2 = vsa.Index.load(g.save(), "FLAT", dim, "IP", initial_cap=n)
+    D2, L2, N2 = g2.search_batch(Q, k)
+    assert N2.tolist() == N.tolist() and L2.tolist() == L.tolist() and D2.view(np.uint32).tolist() == D.view(np.uint32).tolist()
