@@ -325,7 +325,8 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="row storage (bf16 = BASELINE.json configs[3] storage; queries and arithmetic stay f32)")
     ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
-    ap.add_argument("--cpu-queries-per-thread", type=int, default=2)
+    ap.add_argument("--cpu-queries-per-thread", type=int, default=24,
+                    help="CPU-baseline sample: queries per host thread (24 x 16 threads x a 200k-row scan is about 13 s of CPU work, under 1 s of wall time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-query-steps", type=int, default=5, help="extra: B=1 scan timing (HBM roofline)")
     ap.add_argument("--hnsw-rows", type=int, default=200_000, help="extra: HNSW leg over the first rows (0 = skip)")
