@@ -454,9 +454,11 @@ class HnswIndex final : public Index {
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)2 << 30) / (bm_bytes * wpb)));
     VK_TRY(ctx->d_tmp.ensure(blocks * wpb * bm_bytes));
     a.visited = ctx->d_tmp.as<uint32_t>();
-    VK_TRY(ctx->d_stats.ensure(32));
+    VK_TRY(ctx->d_stats.ensure(64));
     if (reset_stats) VK_HIP_TRY(hipMemsetAsync(ctx->d_stats.p, 0, 32, s));
     a.stats = ctx->d_stats.as<unsigned long long>();
+    a.queue = reinterpret_cast<uint32_t *>(a.stats + 4);
+    VK_HIP_TRY(hipMemsetAsync(a.queue, 0, 8, s));
     VK_HIP_TRY(launch_hnsw_search(a, l2(), store_.bf16(), e, (uint32_t)blocks, s));
     return Status::Ok();
   }

@@ -187,7 +187,10 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
 
   unsigned long long st_eval = 0, st_hops = 0, st_over = 0, st_q = 0;
 
-  for (uint32_t q = wslot; q < a.nq; q += wstride) {
+  // every wave slot starts on query `wslot`; further queries are handed out first come, first served (a.queue), so
+  // a batch that is not a multiple of the resident waves, or whose queries differ in length, still ends together
+  uint32_t q = wslot;
+  while (q < a.nq) {
     // ---- stage the query, clear this wave's visited bitmap --------------------------------
     {
       const float4 *src = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f);
@@ -407,6 +410,9 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     }
     if (lane == 0) a.out_n[q] = kout;
     st_q += 1;
+    uint32_t nxt = 0;
+    if (lane == 0) nxt = atomicAdd(a.queue, 1u);
+    q = wstride + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
   }
 
   if (lane == 0 && a.stats && st_q) {

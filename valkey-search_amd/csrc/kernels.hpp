@@ -89,6 +89,7 @@ struct HnswSearchArgs {
   uint64_t *out_label;
   uint32_t *out_n;
   unsigned long long *stats;   // [4]: n_eval, n_hops, cand_overflow, queries
+  uint32_t *queue;             // zeroed per launch: queries past the first wave of slots are taken in arrival order
   uint32_t row_stride_f, q_stride_f, chunks;
   uint32_t l0_stride, up_stride;
   uint32_t entry_point;
