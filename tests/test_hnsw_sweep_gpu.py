@@ -68,3 +68,8 @@ def test_random_shape(vsa, oracle, seed):
     gd, gl = g.search(Q[0], k, ef=ef, **kw)           # the one-query entry point
     od, ol = o.search(Q[0], k, ef=ef, **kw)
     assert gl.tolist() == ol.tolist() and gd.view(np.uint32).tolist() == od.view(np.uint32).tolist(), tag
+    if seed % 3 == 0:                                  # persistence round trip: the loaded index answers the same
+        g2 = vsa.Index.load(g.save(), "HNSW", dim, metric, initial_cap=n, m=M, ef_construction=efc, dtype=dtype)
+        D2, L2, N2 = g2.search_batch(Q, k, ef=ef, **kw)
+        assert N2.tolist() == N.tolist() and L2.tolist() == L.tolist(), tag
+        assert D2.view(np.uint32).tolist() == D.view(np.uint32).tolist(), tag
