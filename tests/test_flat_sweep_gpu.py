@@ -39,8 +39,24 @@ def test_random_shape(vsa, oracle, seed):
     if metric == "COSINE":
         x = np.stack([oracle.normalize(v)[0] for v in x])
     labels = (rng.permutation(n).astype(np.uint64) + int(rng.integers(0, 1000)))
-    g = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype)
-    g.add_batch(x, labels)
+    if rng.random() < 0.3 and n > 10:
+        # grown the way the module grows it (vector_flat.cc:167-173): start small, resize by a block when full,
+        # searches in between -- the row store is reallocated under the kernels several times
+        cap = max(1, n // 5)
+        g = vsa.Index("FLAT", dim, metric, initial_cap=cap, dtype=dtype)
+        done = 0
+        while done < n:
+            room = cap - done
+            if room == 0:
+                cap = min(n, cap + max(1, n // 5))
+                g.resize(cap)
+                continue
+            g.add_batch(x[done:done + room], labels[done:done + room])
+            done += room
+            g.search_batch(x[:min(8, done)], min(3, done))
+    else:
+        g = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype)
+        g.add_batch(x, labels)
     o = oracle.Flat(dim, metric, max_elements=n)
     o.add_many(_bf16_round(x) if dtype == "bf16" else x, labels)
     removed = 0
