@@ -30,13 +30,15 @@ def test_random_build(vsa, oracle, seed):
     Q = latent(200, dim, 200 + seed)
     flat = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype)
     flat.add_batch(x)
-    gd = vsa.Index("HNSW", dim, metric, initial_cap=n, m=M, ef_construction=efc, ef_runtime=64, dtype=dtype)
     how = int(rng.integers(0, 3))
+    gd = vsa.Index("HNSW", dim, metric, initial_cap=n // 2 if how == 1 else n, m=M, ef_construction=efc, ef_runtime=64, dtype=dtype)
     if how == 0:
         gd.add_batch(x)
-    elif how == 1:                                     # two bulk batches
+    elif how == 1:                                     # two bulk batches, the index resized in between (searched, too)
         cut = n // 2
         gd.add_batch(x[:cut], np.arange(cut, dtype=np.uint64))
+        gd.search_batch(Q[:16], 10)
+        gd.resize(n)
         gd.add_batch(x[cut:], np.arange(cut, n, dtype=np.uint64))
     else:                                              # a host-built prefix, then the bulk path
         for i in range(300):
