@@ -448,7 +448,7 @@ class HnswIndex final : public Index {
     int max_blocks = 0;
     VK_HIP_TRY(hnsw_max_blocks(a, l2(), store_.bf16(), e, &max_blocks));
     // visited bitmaps: one per resident wave, bounded to 2 GiB per context
-    const uint64_t wpb = (uint64_t)hnsw_waves_per_block(e);
+    const uint64_t wpb = (uint64_t)hnsw_waves_per_block(a);
     uint64_t blocks = std::min<uint64_t>((nq + wpb - 1) / wpb, (uint64_t)max_blocks);
     const uint64_t bm_bytes = (uint64_t)a.bitmap_words * 4;
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)2 << 30) / (bm_bytes * wpb)));

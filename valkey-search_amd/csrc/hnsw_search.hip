@@ -461,13 +461,21 @@ int hnsw_slots_per_lane(uint64_t ef) {
   return 0;
 }
 
-int hnsw_waves_per_block(int e) { return e == kHnswLdsList ? 1 : 4; }
-
-size_t hnsw_lds_bytes(const HnswSearchArgs &a) {
+static size_t hnsw_lds_per_wave(const HnswSearchArgs &a) {
   const bool lds_list = a.ef > 512;
   const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + a.cand_cap * 2 + a.nbr_cap * 2 + 3) / 4;
-  return per_wave_f4 * 16 * (lds_list ? 1 : 4);
+  return per_wave_f4 * 16;
 }
+
+// waves (queries) per block: 4, or fewer when the per-wave LDS (query + frontier pool, + result list for ef > 512)
+// of four does not fit a CU -- rows beyond ~9000 dimensions, up to the FLAT limit, run 2 or 1 waves per block
+int hnsw_waves_per_block(const HnswSearchArgs &a) {
+  if (a.ef > 512) return 1;
+  const size_t pw = hnsw_lds_per_wave(a);
+  return 4 * pw <= 160 * 1024 ? 4 : 2 * pw <= 160 * 1024 ? 2 : 1;
+}
+
+size_t hnsw_lds_bytes(const HnswSearchArgs &a) { return hnsw_lds_per_wave(a) * (size_t)hnsw_waves_per_block(a); }
 
 template <bool kL2, int kE, bool kBf16>
 static const void *hnsw_fn(bool latency) {
@@ -507,7 +515,7 @@ hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, i
     if (er != hipSuccess) return er;
   }
   int per_cu = 0;
-  hipError_t er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64 * hnsw_waves_per_block(e), lds);
+  hipError_t er = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, 64 * hnsw_waves_per_block(a), lds);
   if (er != hipSuccess) return er;
   int dev = 0, cus = 0;
   (void)hipGetDevice(&dev);
@@ -527,7 +535,7 @@ hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e
   }
   HnswSearchArgs args = a;
   void *params[] = {&args};
-  return hipLaunchKernel(f, dim3(blocks), dim3(64 * hnsw_waves_per_block(e)), params, lds, s);
+  return hipLaunchKernel(f, dim3(blocks), dim3(64 * hnsw_waves_per_block(a)), params, lds, s);
 }
 
 hipError_t launch_scatter_u32(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride,

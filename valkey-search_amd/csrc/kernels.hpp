@@ -104,7 +104,7 @@ struct HnswSearchArgs {
 constexpr int kHnswLdsList = 16;      // hnsw_slots_per_lane(): 512 < ef <= kHnswMaxEf, result list in LDS
 constexpr uint64_t kHnswMaxEf = 4096;
 int hnsw_slots_per_lane(uint64_t ef);                      // 0 = ef beyond kHnswMaxEf
-int hnsw_waves_per_block(int e);
+int hnsw_waves_per_block(const HnswSearchArgs &a);
 size_t hnsw_lds_bytes(const HnswSearchArgs &a);
 hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks);
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s);
