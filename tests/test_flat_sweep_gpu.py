@@ -7,6 +7,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# VK_SWEEP_OFFSET=<n> shifts every seed: a different set of shapes for a one-off hunt
+SWEEP_OFFSET = int(__import__("os").environ.get("VK_SWEEP_OFFSET", "0"))
+
 
 @pytest.fixture(scope="module")
 def vsa():
@@ -26,7 +29,7 @@ BATCHES = [1, 2, 3, 4, 5, 7, 8, 9, 16, 31, 32, 33, 64, 100, 257]
 
 @pytest.mark.parametrize("seed", range(72))
 def test_random_shape(vsa, oracle, seed):
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + SWEEP_OFFSET)
     dim = int(rng.choice(DIMS))
     n = int(rng.integers(1, 60000 if dim <= 256 else 12000))
     nq = int(rng.choice(BATCHES))

@@ -9,6 +9,9 @@ from test_hnsw_build_gpu import build, latent, recall
 
 pytestmark = pytest.mark.gpu
 
+# VK_SWEEP_OFFSET=<n> shifts every seed: a different set of shapes for a one-off hunt
+SWEEP_OFFSET = int(__import__("os").environ.get("VK_SWEEP_OFFSET", "0"))
+
 
 @pytest.fixture(scope="module")
 def vsa():
@@ -18,7 +21,7 @@ def vsa():
 
 @pytest.mark.parametrize("seed", range(10))
 def test_random_build(vsa, oracle, seed):
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + seed + SWEEP_OFFSET)
     dim = int(rng.choice([16, 48, 100, 256, 768]))
     n = int(rng.integers(6000, 26000 if dim <= 100 else 12000))
     M = int(rng.choice([4, 8, 16, 32, 48]))

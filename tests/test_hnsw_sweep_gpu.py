@@ -8,6 +8,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# VK_SWEEP_OFFSET=<n> shifts every seed: a different set of shapes for a one-off hunt
+SWEEP_OFFSET = int(__import__("os").environ.get("VK_SWEEP_OFFSET", "0"))
+
 
 @pytest.fixture(scope="module")
 def vsa():
@@ -23,7 +26,7 @@ def _bf16_round(x):
 
 @pytest.mark.parametrize("seed", range(48))
 def test_random_shape(vsa, oracle, seed):
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(9000 + seed + SWEEP_OFFSET)
     dim = int(rng.choice([1, 7, 16, 48, 100, 128, 200, 384, 768, 1000, 1536]))
     n = int(rng.integers(50, 2500 if dim <= 200 else 900))
     M = int(rng.choice([4, 8, 16, 16, 32, 48]))
@@ -33,8 +36,12 @@ def test_random_shape(vsa, oracle, seed):
     nq = int(rng.choice([1, 3, 16, 64, 600]))
     metric = str(rng.choice(["L2", "IP", "COSINE"]))
     dtype = "bf16" if rng.random() < 0.25 else "f32"
-    if dim == 1 and metric == "COSINE":
-        metric = "L2"      # unit vectors in one dimension are +-1: nothing but exact distance ties, where only recall is pinned
+    if dim == 1:
+        # one dimension is where exact distance ties come from -- unit vectors are +-1, bf16 leaves ~250 distinct values
+        # per binade -- and between equidistant nodes only recall is pinned, not ids
+        dtype = "f32"
+        if metric == "COSINE":
+            metric = "L2"
     tag = (dim, n, M, efc, ef, k, nq, metric, dtype)
     x = rng.standard_normal((n, dim)).astype(np.float32)
     if metric == "COSINE":

@@ -7,6 +7,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# VK_SWEEP_OFFSET=<n> shifts every seed: a different set of shapes for a one-off hunt
+SWEEP_OFFSET = int(__import__("os").environ.get("VK_SWEEP_OFFSET", "0"))
+
 
 @pytest.fixture(scope="module")
 def vsa():
@@ -16,7 +19,7 @@ def vsa():
 
 @pytest.mark.parametrize("seed", range(24))
 def test_random_key_lists(vsa, oracle, seed):
-    rng = np.random.default_rng(3000 + seed)
+    rng = np.random.default_rng(3000 + seed + SWEEP_OFFSET)
     algo = "HNSW" if seed % 3 == 0 else "FLAT"
     dim = int(rng.choice([1, 16, 100, 128, 384, 768, 1100]))
     n = int(rng.integers(20, 3000 if algo == "FLAT" else 600))
