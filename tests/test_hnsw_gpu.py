@@ -124,6 +124,32 @@ def test_filter_and_tombstones(vsa, oracle):
     assert g.distance(1000, Q[0]).view(np.uint32) == o.distance(1000, Q[0]).view(np.uint32)
 
 
+@pytest.mark.parametrize("selectivity", [0.3, 0.05])
+def test_filtered_search_keeps_the_whole_frontier(vsa, oracle, selectivity):
+    """With a selective filter (and tombstones) the result list fills slowly, so hnswlib's candidate_set grows to
+    about ef / selectivity entries before anything can be pruned -- thousands, far beyond the LDS pool.  The
+    device keeps that frontier in HBM; dropping entries (what a fixed pool did) ends the search early and misses
+    closer allowed nodes.  ids, distance bits and the eval / hop counts must be the oracle's."""
+    rng = np.random.default_rng(222)
+    n, dim = 6000, 96
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g, o = _pair(vsa, oracle, x, "IP", M=8, efc=40)
+    for lab in rng.choice(n, n // 8, replace=False):
+        assert g.remove(int(lab)) == 0 and o.mark_delete(int(lab)) == 0
+    bits = oracle.allow_bitmap(np.flatnonzero(rng.random(n) < selectivity), n)
+    Q = rng.standard_normal((24, dim)).astype(np.float32)
+    D, L, N = g.search_batch(Q, 50, ef=256, allow=bits, allow_nbits=n)
+    ne = nh = 0
+    for i in range(len(Q)):
+        od, ol, e, h = o.search(Q[i], 50, ef=256, allow=bits, allow_nbits=n, stats=True)
+        _same(D[i, :N[i]], L[i, :N[i]], od, ol)
+        ne += e
+        nh += h
+    st = g.stats()
+    assert (st.last_n_eval, st.last_n_hops) == (ne, nh)
+    _same(*g.search(Q[0], 50, ef=256, allow=bits, allow_nbits=n), *o.search(Q[0], 50, ef=256, allow=bits, allow_nbits=n))
+
+
 def test_search_test_cases_hnsw(vsa, oracle):
     """search_test.cc:793-899 with HNSW(M=10, efC=300, ef=30) on 10000 collinear-ish vectors."""
     N = 10000

@@ -58,7 +58,7 @@ void PinBuf::release() {
 
 SearchCtx::~SearchCtx() {
   if (stream) (void)hipStreamSynchronize(stream);
-  for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats})
+  for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats, &d_sync, &d_pool})
     b->release();
   for (PinBuf *b : {&h_q, &h_out_d, &h_out_l, &h_out_n, &h_tmp, &h_idx}) b->release();
   if (stream) (void)hipStreamDestroy(stream);

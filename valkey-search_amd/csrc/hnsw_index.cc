@@ -441,6 +441,12 @@ class HnswIndex final : public Index {
     a.k = (uint32_t)k;
     a.ef = (uint32_t)ef;
     a.cand_cap = (uint32_t)std::max<uint64_t>(cand_floor_, 2 * ef);   // frontier pool (LDS); overflow is counted in stats
+    // With a filter or tombstones the result list fills slowly and the frontier grows like the reference's unbounded
+    // candidate_set (about ef / selectivity entries): it moves to HBM, sized by the graph (every node enters it at
+    // most once), capped at 64k entries per wave
+    const bool gpool = d_allow != nullptr || graph_->deleted_count() > 0;
+    if (gpool) a.cand_cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(a.cand_cap, (count + 63) & ~(uint64_t)63));
+    a.pool_g = gpool ? reinterpret_cast<float *>(8) : nullptr;   // (placeholder until the buffer is sized below)
     a.nbr_cap = (uint32_t)((graph_->maxM0() + 63) & ~(size_t)63);
     a.check_deleted = graph_->deleted_count() ? 1 : 0;
     a.out_ids = out_ids ? 1 : 0;
@@ -452,6 +458,11 @@ class HnswIndex final : public Index {
     uint64_t blocks = std::min<uint64_t>((nq + wpb - 1) / wpb, (uint64_t)max_blocks);
     const uint64_t bm_bytes = (uint64_t)a.bitmap_words * 4;
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)2 << 30) / (bm_bytes * wpb)));
+    if (gpool) {   // ... and the HBM frontiers to 1 GiB
+      blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)1 << 30) / ((uint64_t)a.cand_cap * 8 * wpb)));
+      VK_TRY(ctx->d_pool.ensure(blocks * wpb * (uint64_t)a.cand_cap * 8));
+      a.pool_g = ctx->d_pool.as<float>();
+    }
     VK_TRY(ctx->d_tmp.ensure(blocks * wpb * bm_bytes));
     a.visited = ctx->d_tmp.as<uint32_t>();
     VK_TRY(ctx->d_stats.ensure(64));

@@ -133,24 +133,48 @@ struct LdsSorted {
   }
 };
 
-struct Pool {  // frontier in LDS
+// The frontier (hnswlib's candidate_set): an unsorted array with wave-wide extract-min.  kG = false: in LDS (the
+// usual case: once the result list is full, entries beyond the bound are pruned and a few hundred slots suffice).
+// kG = true: in HBM, for searches with a filter or tombstones (see HnswSearchArgs::pool_g); accesses bypass the
+// CU's vector L1 (agent-scope relaxed atomics) because lane 0's appends must be seen by the other lanes' scans.
+// (Plain 16-B loads behind an agent-scope release + acquire fence per hop were tried: 2.5x slower than this.)
+template <bool kG>
+struct Pool {
   float *d;
   uint32_t *id;
   uint32_t cnt, cap;
+  __device__ __forceinline__ float ld_d(uint32_t i) const {
+    if constexpr (kG) return __hip_atomic_load(d + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return d[i];
+  }
+  __device__ __forceinline__ uint32_t ld_id(uint32_t i) const {
+    if constexpr (kG) return __hip_atomic_load(id + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return id[i];
+  }
+  __device__ __forceinline__ void st(uint32_t i, float dv, uint32_t iv) {
+    if constexpr (kG) {
+      __hip_atomic_store(d + i, dv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(id + i, iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      d[i] = dv;
+      id[i] = iv;
+    }
+  }
 };
 
 // drop entries that can never be expanded: farther than `bound`
-__device__ __forceinline__ void pool_prune(Pool &c, float bound, int lane) {
+template <bool kG>
+__device__ __forceinline__ void pool_prune(Pool<kG> &c, float bound, int lane) {
   uint32_t w = 0;
   for (uint32_t base = 0; base < c.cnt; base += kWave) {
     const uint32_t i = base + lane;
     float dv = 0.f;
     uint32_t iv = 0;
     bool keep = false;
-    if (i < c.cnt) { dv = c.d[i]; iv = c.id[i]; keep = !(dv > bound); }
+    if (i < c.cnt) { dv = c.ld_d(i); iv = c.ld_id(i); keep = !(dv > bound); }
     const uint64_t m = __ballot(keep);
     const uint32_t pos = w + __popcll(m & ((1ull << lane) - 1ull));
-    if (keep) { c.d[pos] = dv; c.id[pos] = iv; }
+    if (keep) c.st(pos, dv, iv);
     w += __popcll(m);
   }
   c.cnt = w;
@@ -160,7 +184,7 @@ __device__ __forceinline__ void pool_prune(Pool &c, float bound, int lane) {
 
 // Shared body.  kBatch = row pieces in flight per lane (device_common.hpp): 8 for the throughput kernel,
 // 24 for the latency kernel that serves small batches.
-template <bool kL2, int kE, bool kBf16, int kBatch, bool kSplitRows>
+template <bool kL2, int kE, bool kBf16, int kBatch, bool kSplitRows, bool kGPool = false>
 __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63;
@@ -172,12 +196,13 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   // per-wave LDS carve: query | [result list d | id (kE == 0 only)] | pool d | pool id | nbr id | nbr dist
   constexpr bool kLdsList = kE == 0;
   const uint32_t list_words = kLdsList ? 2 * a.ef : 0;
-  const size_t per_wave_f4 = (size_t)chunks * 4 + (list_words + a.cand_cap * 2 + a.nbr_cap * 2 + 3) / 4;
+  const uint32_t lds_pool = kGPool ? 0u : a.cand_cap;
+  const size_t per_wave_f4 = (size_t)chunks * 4 + (list_words + lds_pool * 2 + a.nbr_cap * 2 + 3) / 4;
   float4 *qs = lds4 + wave * per_wave_f4;
   float *list_d = reinterpret_cast<float *>(qs + chunks * 4);
   float *pool_d = list_d + list_words;
-  uint32_t *pool_id = reinterpret_cast<uint32_t *>(pool_d + a.cand_cap);
-  uint32_t *nbr_id = pool_id + a.cand_cap;
+  uint32_t *pool_id = reinterpret_cast<uint32_t *>(pool_d + lds_pool);
+  uint32_t *nbr_id = pool_id + lds_pool;
   float *nbr_d = reinterpret_cast<float *>(nbr_id + a.nbr_cap);
 
   const uint32_t wpb = blockDim.x >> 6;                  // 4 waves per block, 1 with the LDS result list
@@ -247,7 +272,11 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     typename std::conditional<kLdsList, LdsSorted, WaveSorted<(kE > 0 ? kE : 1)>>::type top;
     if constexpr (kLdsList) { top.d = list_d; top.id = reinterpret_cast<uint32_t *>(list_d + a.ef); }
     top.init();
-    Pool c{pool_d, pool_id, 0, a.cand_cap};
+    Pool<kGPool> c{pool_d, pool_id, 0, a.cand_cap};
+    if constexpr (kGPool) {
+      c.d = a.pool_g + (size_t)wslot * 2 * a.cand_cap;
+      c.id = reinterpret_cast<uint32_t *>(c.d + a.cand_cap);
+    }
     float lowerBound;
     {
       bool ep_ok = true;
@@ -256,11 +285,11 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       if (ep_ok) {
         lowerBound = curdist;   // the reference recomputes the same distance (:378)
         top.insert(curdist, cur, a.ef, lane);
-        if (lane == 0) { c.d[0] = curdist; c.id[0] = cur; }
+        if (lane == 0) c.st(0, curdist, cur);
         st_eval += 1;
       } else {
         lowerBound = kFltMax;
-        if (lane == 0) { c.d[0] = kFltMax; c.id[0] = cur; }
+        if (lane == 0) c.st(0, kFltMax, cur);
       }
       c.cnt = 1;
       if (lane == 0) (void)visit(cur);
@@ -271,9 +300,21 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       // extract-min over the pool
       float bd = __builtin_inff();
       uint32_t bi = kNoneId;
-      for (uint32_t i = lane; i < c.cnt; i += kWave) {
-        const float dv = c.d[i];
-        if (dv < bd || bi == kNoneId) { bd = dv; bi = i; }
+      if constexpr (kGPool) {   // eight loads in flight per lane: the frontier can hold thousands of entries
+        constexpr int kU = 8;
+        for (uint32_t i = lane; i < c.cnt; i += kU * kWave) {
+          float dv[kU];
+#pragma unroll
+          for (int u = 0; u < kU; ++u) dv[u] = i + u * kWave < c.cnt ? c.ld_d(i + u * kWave) : __builtin_inff();
+#pragma unroll
+          for (int u = 0; u < kU; ++u)
+            if (i + u * kWave < c.cnt && (dv[u] < bd || bi == kNoneId)) { bd = dv[u]; bi = i + u * kWave; }
+        }
+      } else {
+        for (uint32_t i = lane; i < c.cnt; i += kWave) {
+          const float dv = c.ld_d(i);
+          if (dv < bd || bi == kNoneId) { bd = dv; bi = i; }
+        }
       }
 #pragma unroll
       for (int m = 1; m < kWave; m <<= 1) {
@@ -283,9 +324,9 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       }
       const float cand_dist = bd;
       if (cand_dist > lowerBound && top.cnt == a.ef) break;
-      const uint32_t cur_id = c.id[bi];
+      const uint32_t cur_id = c.ld_id(bi);
       // remove: move the last entry into the hole
-      if (lane == 0 && bi != c.cnt - 1) { c.d[bi] = c.d[c.cnt - 1]; c.id[bi] = c.id[c.cnt - 1]; }
+      if (lane == 0 && bi != c.cnt - 1) c.st(bi, c.ld_d(c.cnt - 1), c.ld_id(c.cnt - 1));
       c.cnt -= 1;
       st_hops += 1;
 
@@ -346,7 +387,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
             if (c.cnt == c.cap) st_over += 1;
           }
           if (c.cnt < c.cap) {
-            if (lane == 0) { c.d[c.cnt] = cd; c.id[c.cnt] = cid; }
+            if (lane == 0) c.st(c.cnt, cd, cid);
             c.cnt += 1;
           }
           // results
@@ -428,6 +469,11 @@ template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
   hnsw_search_body<kL2, kE, kBf16, 8, false>(a);
 }
+// searches with a filter or tombstones: the frontier lives in HBM (HnswSearchArgs::pool_g)
+template <bool kL2, int kE, bool kBf16>
+__global__ __launch_bounds__(256, 4) void hnsw_search_gpool_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, 8, false, true>(a);
+}
 // a few queries cannot fill the device: each wave is alone with its memory latency, so it keeps six times as
 // many row pieces in flight (a whole 768-d row per lane; one block per CU, registers instead of occupancy)
 template <bool kL2, int kE, bool kBf16>
@@ -463,7 +509,8 @@ int hnsw_slots_per_lane(uint64_t ef) {
 
 static size_t hnsw_lds_per_wave(const HnswSearchArgs &a) {
   const bool lds_list = a.ef > 512;
-  const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + a.cand_cap * 2 + a.nbr_cap * 2 + 3) / 4;
+  const size_t pool = a.pool_g ? 0 : (size_t)a.cand_cap * 2;
+  const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + pool + a.nbr_cap * 2 + 3) / 4;
   return per_wave_f4 * 16;
 }
 
@@ -478,7 +525,8 @@ int hnsw_waves_per_block(const HnswSearchArgs &a) {
 size_t hnsw_lds_bytes(const HnswSearchArgs &a) { return hnsw_lds_per_wave(a) * (size_t)hnsw_waves_per_block(a); }
 
 template <bool kL2, int kE, bool kBf16>
-static const void *hnsw_fn(bool latency) {
+static const void *hnsw_fn(bool latency, bool gpool) {
+  if (gpool) return reinterpret_cast<const void *>(&hnsw_search_gpool_kernel<kL2, kE, kBf16>);
   if constexpr (kE >= 1 && kE <= 4) {
     if (latency) return reinterpret_cast<const void *>(&hnsw_search_latency_kernel<kL2, kE, kBf16>);
   }
@@ -486,27 +534,27 @@ static const void *hnsw_fn(bool latency) {
 }
 
 template <int kE>
-static const void *hnsw_pick_e(bool l2, bool bf16, bool latency) {
-  return l2 ? (bf16 ? hnsw_fn<true, kE, true>(latency) : hnsw_fn<true, kE, false>(latency))
-            : (bf16 ? hnsw_fn<false, kE, true>(latency) : hnsw_fn<false, kE, false>(latency));
+static const void *hnsw_pick_e(bool l2, bool bf16, bool latency, bool gpool) {
+  return l2 ? (bf16 ? hnsw_fn<true, kE, true>(latency, gpool) : hnsw_fn<true, kE, false>(latency, gpool))
+            : (bf16 ? hnsw_fn<false, kE, true>(latency, gpool) : hnsw_fn<false, kE, false>(latency, gpool));
 }
 
 // a batch this small leaves most SIMDs without a wave: latency, not occupancy, is what counts
 static bool hnsw_latency_variant(const HnswSearchArgs &a) { return a.nq <= 512; }
 
-static const void *hnsw_pick(bool l2, bool bf16, int e, bool latency) {
+static const void *hnsw_pick(bool l2, bool bf16, int e, bool latency, bool gpool) {
   switch (e) {
-    case 1: return hnsw_pick_e<1>(l2, bf16, latency);
-    case 2: return hnsw_pick_e<2>(l2, bf16, latency);
-    case 4: return hnsw_pick_e<4>(l2, bf16, latency);
-    case 8: return hnsw_pick_e<8>(l2, bf16, latency);
-    case kHnswLdsList: return hnsw_pick_e<0>(l2, bf16, latency);
+    case 1: return hnsw_pick_e<1>(l2, bf16, latency, gpool);
+    case 2: return hnsw_pick_e<2>(l2, bf16, latency, gpool);
+    case 4: return hnsw_pick_e<4>(l2, bf16, latency, gpool);
+    case 8: return hnsw_pick_e<8>(l2, bf16, latency, gpool);
+    case kHnswLdsList: return hnsw_pick_e<0>(l2, bf16, latency, gpool);
   }
   return nullptr;
 }
 
 hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks) {
-  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a));
+  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a), a.pool_g != nullptr);
   if (!f) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -526,7 +574,7 @@ hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, i
 }
 
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s) {
-  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a));
+  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a), a.pool_g != nullptr);
   if (!f || blocks == 0) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 48 * 1024) {

@@ -44,7 +44,7 @@ constexpr uint64_t kZeroCopyEntries = 4096;   // nq * k
 // (search.cc:886-910 schedules one query per reader-pool thread) do not serialise.
 struct SearchCtx {
   hipStream_t stream = nullptr;
-  DevBuf d_q, d_part_d, d_part_l, d_out_d, d_out_l, d_out_n, d_allow, d_idx, d_tmp, d_stats, d_sync;
+  DevBuf d_q, d_part_d, d_part_l, d_out_d, d_out_l, d_out_n, d_allow, d_idx, d_tmp, d_stats, d_sync, d_pool;
   PinBuf h_q, h_out_d, h_out_l, h_out_n, h_tmp, h_idx;
   ~SearchCtx();
 };

@@ -96,7 +96,11 @@ struct HnswSearchArgs {
   int32_t max_level;
   uint32_t n_nodes, bitmap_words;
   uint32_t nq, k, ef;
-  uint32_t cand_cap;           // candidate pool entries per wave (LDS)
+  uint32_t cand_cap;           // frontier (candidate pool) entries per wave
+  // Frontier in HBM instead of LDS (pool_g != nullptr): with a filter or tombstones the result list fills slowly and
+  // the reference's candidate_set (an unbounded heap) grows to about ef / selectivity entries -- far more than fit
+  // the LDS next to the query; per wave slot cand_cap distances followed by cand_cap ids
+  float *pool_g;
   uint32_t nbr_cap;            // >= maxM0
   uint32_t check_deleted;      // any tombstones in the index
   uint32_t out_ids;            // 1: out_label receives internal ids (device-side graph construction)
