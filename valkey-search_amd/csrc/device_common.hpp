@@ -51,6 +51,8 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+__device__ __forceinline__ float wave_min_f32(float v) { return -wave_max_f32(-v); }
+
 // acc = this lane's accumulators 4j..4j+3 of a row.  Every lane of the quad returns the
 // full 16-accumulator sum in _mm512_reduce_add_ps order.
 __device__ __forceinline__ float quad_reduce16(float4 acc) {

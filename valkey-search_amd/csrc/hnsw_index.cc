@@ -445,7 +445,8 @@ class HnswIndex final : public Index {
     // candidate_set (about ef / selectivity entries): it moves to HBM, sized by the graph (every node enters it at
     // most once), capped at 64k entries per wave
     const bool gpool = d_allow != nullptr || graph_->deleted_count() > 0;
-    if (gpool) a.cand_cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(a.cand_cap, (count + 63) & ~(uint64_t)63));
+    if (gpool)   // (a multiple of 128: the kernel keeps one minimum per 64 entries in the LDS words of the pool)
+      a.cand_cap = (uint32_t)std::min<uint64_t>(65536, (std::max<uint64_t>(a.cand_cap, count) + 127) & ~(uint64_t)127);
     a.pool_g = gpool ? reinterpret_cast<float *>(8) : nullptr;   // (placeholder until the buffer is sized below)
     a.nbr_cap = (uint32_t)((graph_->maxM0() + 63) & ~(size_t)63);
     a.check_deleted = graph_->deleted_count() ? 1 : 0;

@@ -196,7 +196,8 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   // per-wave LDS carve: query | [result list d | id (kE == 0 only)] | pool d | pool id | nbr id | nbr dist
   constexpr bool kLdsList = kE == 0;
   const uint32_t list_words = kLdsList ? 2 * a.ef : 0;
-  const uint32_t lds_pool = kGPool ? 0u : a.cand_cap;
+  // (HBM frontier: the LDS keeps one minimum per segment of 64 entries in the pool's place, cand_cap / 64 floats)
+  const uint32_t lds_pool = kGPool ? a.cand_cap / 128 : a.cand_cap;
   const size_t per_wave_f4 = (size_t)chunks * 4 + (list_words + lds_pool * 2 + a.nbr_cap * 2 + 3) / 4;
   float4 *qs = lds4 + wave * per_wave_f4;
   float *list_d = reinterpret_cast<float *>(qs + chunks * 4);
@@ -273,6 +274,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     if constexpr (kLdsList) { top.d = list_d; top.id = reinterpret_cast<uint32_t *>(list_d + a.ef); }
     top.init();
     Pool<kGPool> c{pool_d, pool_id, 0, a.cand_cap};
+    float *seg_min = pool_d;   // kGPool: seg_min[s] = min distance of entries 64s .. 64s+63 (exact at all times)
     if constexpr (kGPool) {
       c.d = a.pool_g + (size_t)wslot * 2 * a.cand_cap;
       c.id = reinterpret_cast<uint32_t *>(c.d + a.cand_cap);
@@ -285,11 +287,11 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       if (ep_ok) {
         lowerBound = curdist;   // the reference recomputes the same distance (:378)
         top.insert(curdist, cur, a.ef, lane);
-        if (lane == 0) c.st(0, curdist, cur);
+        if (lane == 0) { c.st(0, curdist, cur); if (kGPool) seg_min[0] = curdist; }
         st_eval += 1;
       } else {
         lowerBound = kFltMax;
-        if (lane == 0) c.st(0, kFltMax, cur);
+        if (lane == 0) { c.st(0, kFltMax, cur); if (kGPool) seg_min[0] = kFltMax; }
       }
       c.cnt = 1;
       if (lane == 0) (void)visit(cur);
@@ -300,33 +302,63 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       // extract-min over the pool
       float bd = __builtin_inff();
       uint32_t bi = kNoneId;
-      if constexpr (kGPool) {   // eight loads in flight per lane: the frontier can hold thousands of entries
-        constexpr int kU = 8;
-        for (uint32_t i = lane; i < c.cnt; i += kU * kWave) {
-          float dv[kU];
-#pragma unroll
-          for (int u = 0; u < kU; ++u) dv[u] = i + u * kWave < c.cnt ? c.ld_d(i + u * kWave) : __builtin_inff();
-#pragma unroll
-          for (int u = 0; u < kU; ++u)
-            if (i + u * kWave < c.cnt && (dv[u] < bd || bi == kNoneId)) { bd = dv[u]; bi = i + u * kWave; }
+      float seg_v = 0.f;        // kGPool: this lane's entry of the winning segment
+      uint32_t seg_s = 0;
+      if constexpr (kGPool) {
+        // the minimum over the per-segment minima (LDS), then one load per lane of the winning segment: the entry is
+        // the first one there that equals it -- the smallest pool index among equal distances, like the scan below
+        uint32_t bs = kNoneId;
+        const uint32_t nseg = (c.cnt + kWave - 1) / kWave;
+        for (uint32_t sidx = lane; sidx < nseg; sidx += kWave) {
+          const float v = seg_min[sidx];
+          if (v < bd || bs == kNoneId) { bd = v; bs = sidx; }
         }
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) {
+          const float od = __shfl_xor(bd, m);
+          const uint32_t os = __shfl_xor((int)bs, m);
+          if (os != kNoneId && (bs == kNoneId || od < bd || (od == bd && os < bs))) { bd = od; bs = os; }
+        }
+        seg_s = bs;
+        const uint32_t i = seg_s * kWave + lane;
+        seg_v = i < c.cnt ? c.ld_d(i) : __builtin_inff();
+        const uint64_t hit = __ballot(i < c.cnt && seg_v == bd);
+        bi = seg_s * kWave + (uint32_t)(__ffsll((unsigned long long)hit) - 1);
       } else {
         for (uint32_t i = lane; i < c.cnt; i += kWave) {
           const float dv = c.ld_d(i);
           if (dv < bd || bi == kNoneId) { bd = dv; bi = i; }
         }
-      }
 #pragma unroll
-      for (int m = 1; m < kWave; m <<= 1) {
-        const float od = __shfl_xor(bd, m);
-        const uint32_t oi = __shfl_xor((int)bi, m);
-        if (oi != kNoneId && (bi == kNoneId || od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
+        for (int m = 1; m < kWave; m <<= 1) {
+          const float od = __shfl_xor(bd, m);
+          const uint32_t oi = __shfl_xor((int)bi, m);
+          if (oi != kNoneId && (bi == kNoneId || od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
+        }
       }
       const float cand_dist = bd;
       if (cand_dist > lowerBound && top.cnt == a.ef) break;
       const uint32_t cur_id = c.ld_id(bi);
       // remove: move the last entry into the hole
-      if (lane == 0 && bi != c.cnt - 1) c.st(bi, c.ld_d(c.cnt - 1), c.ld_id(c.cnt - 1));
+      if constexpr (kGPool) {
+        const uint32_t last = c.cnt - 1, sl = last / kWave;
+        const float d_last = c.ld_d(last);
+        const uint32_t id_last = c.ld_id(last);
+        if (lane == 0 && bi != last) c.st(bi, d_last, id_last);
+        // the two segments touched: the hole's (its values are in seg_v) and the last entry's
+        float nv = seg_v;
+        if (seg_s * kWave + lane == bi) nv = bi != last ? d_last : __builtin_inff();
+        if (seg_s == sl && seg_s * kWave + lane == last) nv = __builtin_inff();
+        const float m0 = wave_min_f32(nv);
+        if (seg_s != sl) {
+          const uint32_t i = sl * kWave + lane;
+          const float m1 = wave_min_f32(i < last ? c.ld_d(i) : __builtin_inff());
+          if (lane == 0) seg_min[sl] = m1;
+        }
+        if (lane == 0) seg_min[seg_s] = m0;
+      } else {
+        if (lane == 0 && bi != c.cnt - 1) c.st(bi, c.ld_d(c.cnt - 1), c.ld_id(c.cnt - 1));
+      }
       c.cnt -= 1;
       st_hops += 1;
 
@@ -383,11 +415,26 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
           const uint32_t cid = __builtin_amdgcn_readlane((int)nid, b);
           // frontier
           if (c.cnt == c.cap) {
-            if (top.cnt == a.ef) pool_prune(c, lowerBound, lane);
+            if (top.cnt == a.ef) {
+              pool_prune(c, lowerBound, lane);
+              if constexpr (kGPool) {   // the compaction moved everything: rebuild the segment minima
+                for (uint32_t sidx = 0; sidx * kWave < c.cnt; ++sidx) {
+                  const uint32_t i = sidx * kWave + lane;
+                  const float mv = wave_min_f32(i < c.cnt ? c.ld_d(i) : __builtin_inff());
+                  if (lane == 0) seg_min[sidx] = mv;
+                }
+              }
+            }
             if (c.cnt == c.cap) st_over += 1;
           }
           if (c.cnt < c.cap) {
-            if (lane == 0) c.st(c.cnt, cd, cid);
+            if (lane == 0) {
+              c.st(c.cnt, cd, cid);
+              if constexpr (kGPool) {
+                const uint32_t sidx = c.cnt / kWave;
+                seg_min[sidx] = (c.cnt % kWave) == 0 ? cd : fminf(seg_min[sidx], cd);
+              }
+            }
             c.cnt += 1;
           }
           // results
@@ -509,7 +556,7 @@ int hnsw_slots_per_lane(uint64_t ef) {
 
 static size_t hnsw_lds_per_wave(const HnswSearchArgs &a) {
   const bool lds_list = a.ef > 512;
-  const size_t pool = a.pool_g ? 0 : (size_t)a.cand_cap * 2;
+  const size_t pool = a.pool_g ? (size_t)(a.cand_cap / 128) * 2 : (size_t)a.cand_cap * 2;   // HBM frontier: segment minima only
   const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + pool + a.nbr_cap * 2 + 3) / 4;
   return per_wave_f4 * 16;
 }
