@@ -78,3 +78,17 @@ def test_flat_bf16_batched_mfma_path(vsa, oracle, n, dim, nq, k):
     for i in range(nq):
         od, ol = o.search(Q[i], k)
         _same(D[i, :N[i]], L[i, :N[i]], od, ol)
+
+
+def test_flat_bf16_save_load_round_trip(vsa):
+    """A bf16 FLAT index written out and read back (as f32 rows, the chunk format of the reference) answers the same."""
+    rng = np.random.default_rng(61)
+    n, dim = 3000, 200
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g = vsa.Index("FLAT", dim, "L2", initial_cap=n, dtype="bf16")
+    g.add_batch(x)
+    Q = rng.standard_normal((9, dim)).astype(np.float32)
+    D, L, N = g.search_batch(Q, 10)
+    g2 = vsa.Index.load(g.save(), "FLAT", dim, "L2", initial_cap=n, dtype="bf16")
+    D2, L2, N2 = g2.search_batch(Q, 10)
+    assert L2.tolist() == L.tolist() and D2.view(np.uint32).tolist() == D.view(np.uint32).tolist() and N2.tolist() == N.tolist()
