@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -587,7 +589,10 @@ static const void *hnsw_pick_e(bool l2, bool bf16, bool latency, bool gpool) {
 }
 
 // a batch this small leaves most SIMDs without a wave: latency, not occupancy, is what counts
-static bool hnsw_latency_variant(const HnswSearchArgs &a) { return a.nq <= 512; }
+static bool hnsw_latency_variant(const HnswSearchArgs &a) {
+  static const uint32_t max_nq = getenv("VK_HNSW_LATENCY_NQ") ? (uint32_t)atoll(getenv("VK_HNSW_LATENCY_NQ")) : 512;
+  return a.nq <= max_nq;
+}
 
 static const void *hnsw_pick(bool l2, bool bf16, int e, bool latency, bool gpool) {
   switch (e) {
