@@ -92,6 +92,12 @@ typedef struct vk_index_stats {
    * upper layers, hnswalg.h:1679-1680): */
   uint64_t last_n_eval;       /* distance evaluations */
   uint64_t last_n_hops;       /* expanded nodes */
+  /* filtered / tombstoned HNSW searches keep the whole frontier (hnswlib's unbounded candidate_set, hnswalg.h:367-370)
+   * in HBM: queries of the most recent batch whose frontier outgrew the first launch's 64k entries and were answered
+   * by the launch with the graph-sized frontier; and entries dropped (always 0: a search is never truncated -- a
+   * non-zero count fails the call with VK_ERR_INTERNAL) */
+  uint64_t last_frontier_redo;
+  uint64_t last_frontier_dropped;
   /* query coalescer (vk_index_set_coalescing): device batches run / single queries they carried */
   uint64_t coalesced_batches;
   uint64_t coalesced_queries;
@@ -149,7 +155,10 @@ int vk_index_search_batch(vk_index *ix, const void *queries, uint64_t nq, uint64
 /* Same, but queries and outputs are DEVICE pointers and the work is enqueued on
  * `hip_stream` (a hipStream_t, NULL = the index's own stream) without a host sync:
  * the shard leg of the multi-GPU path, whose outputs feed an RCCL all-gather.
- * out_n entries past the count are filled with (+inf, UINT64_MAX). */
+ * Entries past the count are filled with (+inf, UINT64_MAX); a shard with fewer than k rows (or none)
+ * answers with what it has.  Concurrent calls are safe (each takes its own scratch context; a context's
+ * next user is ordered behind the work still in flight).  The caller must synchronise the stream before
+ * the next writer phase (vk_index_flush / add / remove publish into the arrays the kernels read). */
 int vk_index_search_batch_device(vk_index *ix, const void *d_queries, uint64_t nq, uint64_t k,
                                  uint64_t ef_runtime, const uint64_t *d_allow_bits,
                                  uint64_t allow_nbits, float *d_out_dist, uint64_t *d_out_label,

@@ -49,6 +49,7 @@ struct vko_hnsw {
     uint16_t *visited; uint16_t curV;
     /* layer-0 work counters of the last search */
     uint64_t n_eval, n_hops;
+    int is_view;         /* vko_hnsw_view: shares every array of its base except the visited list */
 };
 
 static float h_dist(const vko_hnsw *h, const float *a, const float *b) {
@@ -109,6 +110,7 @@ vko_hnsw *vko_hnsw_new(size_t dim, vko_space_t space, vko_isa_t isa, size_t max_
 
 void vko_hnsw_free(vko_hnsw *h) {
     if (!h) return;
+    if (h->is_view) { free(h->visited); free(h); return; }
     for (size_t i = 0; i < h->count; ++i) { free(h->upper[i]); free(h->rows[i]); }
     free(h->l0); free(h->upper); free(h->levels); free(h->rows); free(h->labels);
     free(h->vacant); free(h->visited);
@@ -669,4 +671,120 @@ int vko_hnsw_load_graph(vko_hnsw *h, size_t n, const float *rows, const uint64_t
     h->maxlevel = max_level;
     h->enterpoint = entry_point;
     return 0;
+}
+
+/* A read-only view of `base` for one more searching thread: hnswlib hands every concurrent search its own
+ * VisitedList (visited_list_pool.h:35-77); the restatement keeps one per object, so a thread that wants to search
+ * the same graph concurrently takes a view (own visited list and work counters, everything else shared).  The base
+ * must not be mutated or freed while views are alive. */
+vko_hnsw *vko_hnsw_view(const vko_hnsw *base) {
+    vko_hnsw *v = (vko_hnsw *)malloc(sizeof(*v));
+    memcpy(v, base, sizeof(*v));
+    v->is_view = 1;
+    v->visited = NULL;
+    visited_alloc(v);
+    return v;
+}
+
+/* ---- SaveIndex chunk stream -> oracle graph, chunk by chunk (hnswalg.h:808-865) ---------------------------
+ * vko_sink_write has the signature of the product's vk_write_chunk_fn, so a test can hand it straight to
+ * vk_index_save and the CPU restatement searches the very graph the device searches (10M elements go through
+ * without 10M Python objects).  Chunk 0 = HNSWIndexHeader (varint fields: 3 = element count, 7 = max level,
+ * 8 = entry point), then one chunk per element [level-0 words | row | label], then per element a u64 size chunk
+ * followed, when non-zero, by the block of its upper-level lists. */
+struct vko_sink {
+    vko_hnsw *h;
+    size_t dim, M, efC;
+    vko_space_t space;
+    vko_isa_t isa;
+    size_t n, elem, upper_i;
+    int state;          /* 0 header, 1 elements, 2 size chunk, 3 upper block, 4 done, -1 error */
+    uint64_t pending;   /* bytes of the upper block announced by the last size chunk */
+    int max_level;
+    uint32_t entry_point;
+};
+typedef struct vko_sink vko_sink;
+
+vko_sink *vko_sink_new(size_t dim, vko_space_t space, vko_isa_t isa, size_t M, size_t ef_construction) {
+    vko_sink *s = (vko_sink *)calloc(1, sizeof(*s));
+    s->dim = dim; s->space = space; s->isa = isa; s->M = M; s->efC = ef_construction;
+    return s;
+}
+
+static int sink_fail(vko_sink *s, const char *msg) { vko_set_error(msg); s->state = -1; return 1; }
+
+int vko_sink_write(void *user, const void *data, uint64_t len) {
+    vko_sink *s = (vko_sink *)user;
+    const uint8_t *p = (const uint8_t *)data;
+    switch (s->state) {
+    case 0: {
+        uint64_t f[16] = {0};
+        const uint8_t *e = p + len;
+        while (p < e) {
+            uint8_t key = *p++;
+            unsigned field = key >> 3, wire = key & 7;
+            if (wire == 0) {
+                uint64_t v = 0; int sh = 0;
+                while (p < e) { uint8_t b = *p++; v |= (uint64_t)(b & 0x7F) << sh; sh += 7; if (!(b & 0x80)) break; }
+                if (field < 16) f[field] = v;
+            } else if (wire == 1) p += 8;
+            else return sink_fail(s, "sink: unexpected wire type in the header");
+        }
+        s->n = (size_t)f[3];
+        s->max_level = (int)(int32_t)(uint32_t)f[7];
+        s->entry_point = (uint32_t)f[8];
+        s->h = vko_hnsw_new(s->dim, s->space, s->isa, s->n ? s->n : 1, s->M, s->efC, 100, 0);
+        s->state = s->n ? 1 : 4;
+        return 0;
+    }
+    case 1: {
+        vko_hnsw *h = s->h;
+        const size_t sl0 = (h->maxM0 + 1) * 4, vec = h->dim * 4;
+        if (len != sl0 + vec + 8) return sink_fail(s, "sink: element chunk has the wrong size");
+        const uint32_t i = (uint32_t)s->elem;
+        memcpy(ll0(h, i), p, sl0);
+        h->rows[i] = (float *)malloc(vec);
+        memcpy(h->rows[i], p + sl0, vec);
+        memcpy(&h->labels[i], p + sl0 + vec, 8);
+        if (is_deleted(h, i)) h->num_deleted++;
+        else vko_map_put(&h->label_lookup, h->labels[i], i);
+        h->count = ++s->elem;      /* (free() walks count elements) */
+        if (s->elem == s->n) s->state = 2;
+        return 0;
+    }
+    case 2: {
+        if (len != 8) return sink_fail(s, "sink: size chunk has the wrong size");
+        memcpy(&s->pending, p, 8);
+        if (s->pending) { s->state = 3; return 0; }
+        if (++s->upper_i == s->n) s->state = 4;
+        return 0;
+    }
+    case 3: {
+        vko_hnsw *h = s->h;
+        if (len != s->pending || len % ((h->maxM + 1) * 4)) return sink_fail(s, "sink: upper block has the wrong size");
+        const uint32_t i = (uint32_t)s->upper_i;
+        h->levels[i] = (int)(len / ((h->maxM + 1) * 4));
+        h->upper[i] = (uint32_t *)malloc(len);
+        memcpy(h->upper[i], p, len);
+        s->state = ++s->upper_i == s->n ? 4 : 2;
+        return 0;
+    }
+    default:
+        return sink_fail(s, "sink: chunk after the end of the stream");
+    }
+}
+
+/* the finished oracle index (ownership passes to the caller), NULL when the stream was incomplete; frees the sink */
+vko_hnsw *vko_sink_finish(vko_sink *s) {
+    vko_hnsw *h = NULL;
+    if (s->state == 4 && s->h) {
+        h = s->h;
+        h->maxlevel = s->n ? s->max_level : -1;
+        h->enterpoint = s->n ? s->entry_point : 0xFFFFFFFFu;
+    } else {
+        if (s->state != -1) vko_set_error("sink: incomplete chunk stream");
+        vko_hnsw_free(s->h);
+    }
+    free(s);
+    return h;
 }

@@ -100,6 +100,14 @@ def _load():
     lib.vko_hnsw_row.argtypes = [C.c_void_p, C.c_uint32]
     lib.vko_hnsw_load_graph.restype = C.c_int
     lib.vko_hnsw_load_graph.argtypes = [C.c_void_p, C.c_size_t, _f32p, _u64p, _u32p, _u64p, _u32p, C.c_int, C.c_uint32]
+    lib.vko_hnsw_view.restype = C.c_void_p
+    lib.vko_hnsw_view.argtypes = [C.c_void_p]
+    lib.vko_sink_new.restype = C.c_void_p
+    lib.vko_sink_new.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t]
+    lib.vko_sink_write.restype = C.c_int
+    lib.vko_sink_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.vko_sink_finish.restype = C.c_void_p
+    lib.vko_sink_finish.argtypes = [C.c_void_p]
     lib.vko_merge_topk.restype = C.c_size_t
     lib.vko_merge_topk.argtypes = [_f32p, _u64p, _u32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p, _u64p]
     return lib
@@ -279,6 +287,34 @@ class HNSW:
         out = C.c_float()
         rc = LIB.vko_hnsw_distance(self._h, int(label), _fp(q), C.byref(out))
         return None if rc else np.float32(out.value)
+
+    @classmethod
+    def _adopt(cls, handle, dim, space, M, base=None):
+        self = cls.__new__(cls)
+        self.dim, self.space, self.M, self._h, self._base = dim, space, M, handle, base
+        return self
+
+    def view(self):
+        """One more searching thread over the same graph: own visited list and counters (hnswlib gives every
+        concurrent search its own VisitedList); keeps the base alive."""
+        return HNSW._adopt(LIB.vko_hnsw_view(self._h), self.dim, self.space, self.M, base=self)
+
+    @classmethod
+    def from_product_index(cls, save_fn, dim, space, M, ef_construction=200, isa="skylake", ef=10):
+        """The graph a PRODUCT index holds, through its own SaveIndex chunk stream, chunk by chunk in C:
+        `save_fn(callback, user)` must call vk_index_save(ix, callback, user).  10M elements pass without one Python
+        object per chunk."""
+        sink = LIB.vko_sink_new(dim, SPACE[space], ISA[isa], M, ef_construction)
+        cb = C.cast(LIB.vko_sink_write, C.c_void_p)
+        rc = save_fn(cb, C.c_void_p(sink))
+        h = LIB.vko_sink_finish(sink)
+        if rc or not h:
+            if h:
+                LIB.vko_hnsw_free(h)
+            raise RuntimeError(f"save into the oracle sink failed (rc={rc}): {last_error()}")
+        self = cls._adopt(h, dim, space, M)
+        LIB.vko_hnsw_set_ef(self._h, ef)
+        return self
 
     @classmethod
     def from_saved_chunks(cls, chunks, dim, space, M, ef_construction=200, isa="skylake", ef=10):

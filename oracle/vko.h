@@ -113,6 +113,15 @@ int vko_hnsw_load_graph(vko_hnsw *h, size_t n, const float *rows, const uint64_t
                         const uint32_t *l0_words, const uint64_t *upper_off, const uint32_t *upper_words,
                         int max_level, uint32_t entry_point);
 
+/* one more searching thread over the same graph (own visited list); free it with vko_hnsw_free before the base */
+vko_hnsw *vko_hnsw_view(const vko_hnsw *base);
+/* SaveIndex chunk stream (hnswalg.h:808-865) -> oracle index, chunk by chunk: vko_sink_write has the signature of
+ * the product's vk_write_chunk_fn */
+typedef struct vko_sink vko_sink;
+vko_sink *vko_sink_new(size_t dim, vko_space_t space, vko_isa_t isa, size_t M, size_t ef_construction);
+int vko_sink_write(void *user, const void *data, uint64_t len);
+vko_hnsw *vko_sink_finish(vko_sink *s);
+
 /* ---- cluster / shard merge (fanout.cc:162-175 semantics, made total) ------- */
 /* k smallest by (dist,label) over `parts` lists of `per` entries each */
 size_t vko_merge_topk(const float *dist, const uint64_t *label, const uint32_t *counts,

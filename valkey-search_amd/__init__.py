@@ -42,7 +42,8 @@ class Stats(C.Structure):
     _fields_ = [("count", C.c_uint64), ("deleted", C.c_uint64), ("capacity", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("host_bytes", C.c_uint64), ("staged_ops", C.c_uint64),
                 ("max_level", C.c_int32), ("entry_point", C.c_uint32), ("last_n_eval", C.c_uint64),
-                ("last_n_hops", C.c_uint64), ("coalesced_batches", C.c_uint64), ("coalesced_queries", C.c_uint64)]
+                ("last_n_hops", C.c_uint64), ("last_frontier_redo", C.c_uint64), ("last_frontier_dropped", C.c_uint64),
+                ("coalesced_batches", C.c_uint64), ("coalesced_queries", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -250,6 +251,11 @@ class Index:
                                                   d_out_label, d_out_n, stream))
 
     # ---- persistence
+    def save_raw(self, callback, user):
+        """vk_index_save with a C callback address (e.g. the test oracle's chunk sink): returns the status code."""
+        fn = C.cast(callback, WRITE_CHUNK)
+        return lib().vk_index_save(self._h, fn, user)
+
     def save(self):
         chunks = []
 

@@ -11,6 +11,8 @@
 #pragma once
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -26,10 +28,11 @@ class Coalescer {
  public:
   void configure(uint32_t max_batch, uint32_t max_wait_us) {
     std::lock_guard<std::mutex> lk(mu_);
-    max_batch_ = max_batch;
+    max_batch_.store(max_batch, std::memory_order_relaxed);
     max_wait_us_ = max_wait_us;
+    cv_.notify_all();   // a leader waiting for a batch that can no longer fill re-reads the limit
   }
-  bool enabled() const { return max_batch_ > 1; }
+  bool enabled() const { return max_batch_.load(std::memory_order_relaxed) > 1; }
   uint64_t batches() const { return batches_; }
   uint64_t queries() const { return queries_; }
 
@@ -38,9 +41,10 @@ class Coalescer {
                 uint64_t *out_n) {
     Req me{query, out_dist, out_label, out_n, Status::Ok(), false};
     std::unique_lock<std::mutex> lk(mu_);
-    Lane &lane = lanes_[std::make_pair(k, ef)];
+    const auto key = std::make_pair(k, ef);
+    Lane &lane = lanes_[key];
     lane.q.push_back(&me);
-    if (lane.leader_active && lane.q.size() >= max_batch_) cv_.notify_all();  // batch full: wake the leader
+    if (lane.leader_active && lane.q.size() >= batch_cap()) cv_.notify_all();  // batch full: wake the leader
     while (!me.done) {
       if (lane.leader_active) {
         cv_.wait(lk);
@@ -53,6 +57,10 @@ class Coalescer {
       lane.leader_active = false;
       cv_.notify_all();
     }
+    // (`lane` may be gone by now: it is not touched after `done`.)  Drop the lane of this (k, ef) once it is idle,
+    // so the map does not grow by one entry per distinct pair ever seen
+    auto it = lanes_.find(key);
+    if (it != lanes_.end() && it->second.q.empty() && !it->second.leader_active) lanes_.erase(it);
     return me.st;
   }
 
@@ -72,9 +80,12 @@ class Coalescer {
   void lead_one_batch(Index *ix, Lane &lane, uint64_t k, uint64_t ef, std::unique_lock<std::mutex> &lk) {
     const uint32_t dim = ix->params().dim;
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us_);
-    cv_.wait_until(lk, deadline, [&] { return lane.q.size() >= max_batch_; });
+    cv_.wait_until(lk, deadline, [&] { return lane.q.size() >= batch_cap(); });
+    // (the limit is re-read: vk_index_set_coalescing(ix, 0, ..) while requests are queued must still drain them --
+    // a leader always takes at least its own request)
+    const size_t cap = batch_cap();
     std::vector<Req *> batch;
-    while (!lane.q.empty() && batch.size() < max_batch_) {
+    while (!lane.q.empty() && batch.size() < cap) {
       batch.push_back(lane.q.front());
       lane.q.pop_front();
     }
@@ -115,10 +126,13 @@ class Coalescer {
     }
   }
 
+  size_t batch_cap() const { return std::max<uint32_t>(1u, max_batch_.load(std::memory_order_relaxed)); }
+
   std::mutex mu_;
   std::condition_variable cv_;
   std::map<std::pair<uint64_t, uint64_t>, Lane> lanes_;
-  uint32_t max_batch_ = 0, max_wait_us_ = 0;
+  std::atomic<uint32_t> max_batch_{0};
+  uint32_t max_wait_us_ = 0;
   uint64_t batches_ = 0, queries_ = 0;
 };
 

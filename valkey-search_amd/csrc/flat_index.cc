@@ -56,9 +56,26 @@ void PinBuf::release() {
   cap = 0;
 }
 
+Status SearchCtx::begin_on(hipStream_t s) {
+  if (has_busy) {
+    VK_HIP_TRY(hipStreamWaitEvent(s, busy, 0));
+    has_busy = false;
+  }
+  return Status::Ok();
+}
+
+Status SearchCtx::end_async(hipStream_t s) {
+  if (!busy) VK_HIP_TRY(hipEventCreateWithFlags(&busy, hipEventDisableTiming));
+  VK_HIP_TRY(hipEventRecord(busy, s));
+  has_busy = true;
+  return Status::Ok();
+}
+
 SearchCtx::~SearchCtx() {
+  if (has_busy) (void)hipEventSynchronize(busy);
+  if (busy) (void)hipEventDestroy(busy);
   if (stream) (void)hipStreamSynchronize(stream);
-  for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats, &d_sync, &d_pool})
+  for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats, &d_sync, &d_pool, &d_pool2, &d_redo})
     b->release();
   for (PinBuf *b : {&h_q, &h_out_d, &h_out_l, &h_out_n, &h_tmp, &h_idx}) b->release();
   if (stream) (void)hipStreamDestroy(stream);
@@ -69,23 +86,34 @@ CtxPool::~CtxPool() {
   all_.clear();
 }
 
-SearchCtx *CtxPool::acquire() {
-  std::unique_lock<std::mutex> lk(mu_);
-  for (;;) {
-    if (!free_.empty()) {
-      SearchCtx *c = free_.back();
-      free_.pop_back();
-      return c;
+SearchCtx *CtxPool::acquire(hipStream_t on) {
+  SearchCtx *c = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      if (!free_.empty()) {
+        c = free_.back();
+        free_.pop_back();
+        break;
+      }
+      if (all_.size() < max_) {
+        (void)hipSetDevice(device_);
+        auto n = std::make_unique<SearchCtx>();
+        (void)hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
+        all_.push_back(std::move(n));
+        return all_.back().get();
+      }
+      cv_.wait(lk);
     }
-    if (all_.size() < max_) {
-      (void)hipSetDevice(device_);
-      auto c = std::make_unique<SearchCtx>();
-      (void)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-      all_.push_back(std::move(c));
-      return all_.back().get();
-    }
-    cv_.wait(lk);
   }
+  if (c->has_busy) {
+    (void)hipSetDevice(device_);
+    if (!c->begin_on(on ? on : c->stream).ok()) {   // (could not order the streams: wait on the host instead)
+      (void)hipEventSynchronize(c->busy);
+      c->has_busy = false;
+    }
+  }
+  return c;
 }
 
 void CtxPool::release(SearchCtx *c) {
@@ -266,25 +294,33 @@ class FlatIndex final : public Index {
     std::shared_lock<std::shared_mutex> lk(rw_);
     (void)hipSetDevice(store_.device());
     if (rq.nq == 0) return Status::Ok();
-    if (!dev_ctx_) {
-      dev_ctx_ = std::make_unique<SearchCtx>();
-      VK_HIP_TRY(hipStreamCreateWithFlags(&dev_ctx_->stream, hipStreamNonBlocking));
-    }
-    hipStream_t s = stream ? stream : dev_ctx_->stream;
+    if (rq.k == 0) return Status::Err(VK_ERR_INVALID, "search_batch_device needs k > 0");
+    // a context per call (concurrent callers never share scratch); the work goes on the caller's stream and is still
+    // in flight when the call returns -- the context's next user is ordered behind it (SearchCtx::busy)
+    CtxLease lease(pool_, stream);
+    SearchCtx *ctx = lease.ctx;
+    hipStream_t s = stream ? stream : ctx->stream;
     const uint64_t count = count_;
-    if (rq.k > count || rq.k == 0)
-      return Status::Err(VK_ERR_INVALID, "search_batch_device needs 0 < k <= element count");
+    // a shard with fewer than k rows (vector_flat.cc:234-236 clamps k): the lists are [nq][rq.k] all the same, the
+    // tail is (+inf, UINT64_MAX) -- what the shard merge expects of a short shard
+    const uint64_t k = std::min<uint64_t>(rq.k, count);
+    if (k == 0) {
+      VK_HIP_TRY(launch_fill_empty(d_out_dist, d_out_label, d_out_n, (uint32_t)rq.nq, (uint32_t)rq.k, s));
+      return ctx->end_async(s);
+    }
     const float *dq = rq.queries;
     if (store_.stride_f() != params_.dim) {
       const size_t q_pitch = (size_t)store_.stride_f() * 4;   // queries are always f32
-      VK_TRY(dev_ctx_->d_q.ensure(rq.nq * q_pitch));
-      VK_HIP_TRY(hipMemsetAsync(dev_ctx_->d_q.p, 0, rq.nq * q_pitch, s));
-      VK_HIP_TRY(hipMemcpy2DAsync(dev_ctx_->d_q.p, q_pitch, rq.queries, (size_t)params_.dim * 4,
+      VK_TRY(ctx->d_q.ensure(rq.nq * q_pitch));
+      VK_HIP_TRY(hipMemsetAsync(ctx->d_q.p, 0, rq.nq * q_pitch, s));
+      VK_HIP_TRY(hipMemcpy2DAsync(ctx->d_q.p, q_pitch, rq.queries, (size_t)params_.dim * 4,
                                   (size_t)params_.dim * 4, rq.nq, hipMemcpyDeviceToDevice, s));
-      dq = dev_ctx_->d_q.as<float>();
+      dq = ctx->d_q.as<float>();
     }
-    return scan(dev_ctx_.get(), dq, rq.nq, rq.k, count, rq.allow_bits, rq.allow_nbits, nullptr, d_out_dist,
-                d_out_label, d_out_n, s);
+    Status st = scan(ctx, dq, rq.nq, k, count, rq.allow_bits, rq.allow_nbits, nullptr, d_out_dist,
+                     d_out_label, d_out_n, s, rq.k);
+    Status en = ctx->end_async(s);
+    return st.ok() ? en : st;
   }
 
   Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n, float *out_dist,
@@ -418,13 +454,14 @@ class FlatIndex final : public Index {
   // enqueue scan + merge of rows [0,count) on stream s; all pointers device
   Status scan(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
               uint64_t allow_nbits, const volatile int *cancel, float *d_out_d, uint64_t *d_out_l,
-              uint32_t *d_out_n, hipStream_t s) {
+              uint32_t *d_out_n, hipStream_t s, uint64_t out_ld = 0) {
+    if (out_ld == 0) out_ld = k;                      // entries per query in the output arrays (>= k; the tail is padding)
     int e = flat_scan_slots_per_lane(k);
     if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 needs the host entry points (vk_index_search / _batch), which page through the result in passes");
     const uint32_t chunks = store_.stride_f() / 16;
     // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
     if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !cancel && flat_gemm_supported(store_.stride_f(), k) && !force_scan_)
-      return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
+      return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld);
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     if (lb_dist_) e = 16;            // the paged scan has one instantiation: 16 slots per lane, one query per pass
     const int qb = lb_dist_ ? 1 : flat_scan_pick_qb(nq, chunks, e, l2());
@@ -479,6 +516,7 @@ class FlatIndex final : public Index {
     m.parts = done;
     m.per_part = (uint32_t)per_q;
     m.k = (uint32_t)k;
+    m.out_ld = (uint32_t)out_ld;
     m.out_dist = d_out_d;
     m.out_label = d_out_l;
     m.out_n = d_out_n;
@@ -541,7 +579,9 @@ class FlatIndex final : public Index {
 
   // K4 launch: persistent grid of ~one block per CU, nrp row partitions x nqt query tiles of 32
   Status scan_gemm(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
-                   uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s) {
+                   uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
+                   uint64_t out_ld = 0) {
+    if (out_ld == 0) out_ld = k;
     // pre-pass (this kernel over the first rows): a valid bound on every query's k-th best distance, so the per-lane
     // lists of K4 start gated instead of accepting everything until they have filled
     const float *init_bound = nullptr;
@@ -602,6 +642,7 @@ class FlatIndex final : public Index {
     m.parts = 1;
     m.per_part = (uint32_t)per_q;
     m.k = (uint32_t)k;
+    m.out_ld = (uint32_t)(in_prepass_ ? k : out_ld);
     m.out_dist = d_out_d;
     m.out_label = d_out_l;
     m.out_n = d_out_n;
@@ -616,7 +657,6 @@ class FlatIndex final : public Index {
   static thread_local const uint64_t *lb_label_;
   RowStore store_;
   CtxPool pool_;
-  std::unique_ptr<SearchCtx> dev_ctx_;
   std::shared_mutex rw_;
   // K4 lockstep window in row tiles (see FlatGemmArgs::lockstep); VK_GEMM_LOCKSTEP=0 turns it off
   uint32_t gemm_lockstep_ = getenv("VK_GEMM_LOCKSTEP") ? (uint32_t)atoi(getenv("VK_GEMM_LOCKSTEP")) : 1;

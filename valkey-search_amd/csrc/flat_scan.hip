@@ -235,8 +235,9 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
   }
   // rank sort of the kept entries (all keys distinct: labels are unique)
   const uint32_t cnt = top.cnt;
-  float *od = a.out_dist + q * a.k;
-  uint64_t *ol = a.out_label + q * a.k;
+  float *od = a.out_dist + q * a.out_ld;
+  uint64_t *ol = a.out_label + q * a.out_ld;
+  for (uint32_t s = a.k + lane; s < a.out_ld; s += kWave) { od[s] = __builtin_inff(); ol[s] = kNoLabel; }
 #pragma unroll
   for (int e = 0; e < kE; ++e) {
     const uint32_t s = (uint32_t)e * kWave + lane;
@@ -388,9 +389,10 @@ __global__ __launch_bounds__(256) void merge_select_kernel(MergeArgs a) {
   for (int u = 0; u < kSelPerThread; ++u) c += (uint32_t)__popcll(__ballot(lab[u] != kNoLabel));
   const uint32_t real = block_sum(c);
   const uint32_t k = real < a.k ? real : a.k;
-  float *od = a.out_dist + q * a.k;
-  uint64_t *ol = a.out_label + q * a.k;
-  if (tid >= k && tid < a.k) { od[tid] = __builtin_inff(); ol[tid] = kNoLabel; }
+  float *od = a.out_dist + q * a.out_ld;
+  uint64_t *ol = a.out_label + q * a.out_ld;
+  for (uint32_t s = tid; s < a.out_ld; s += 256)
+    if (s >= k) { od[s] = __builtin_inff(); ol[s] = kNoLabel; }
   if (tid == 0) a.out_n[q] = k;
   if (k == 0) return;
 
@@ -598,8 +600,10 @@ hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, i
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s) {
+hipError_t launch_merge_topk(const MergeArgs &a_in, int e, uint64_t nq, hipStream_t s) {
   if (nq == 0) return hipSuccess;
+  MergeArgs a = a_in;
+  if (a.out_ld < a.k) a.out_ld = a.k;
   dim3 grid((uint32_t)nq);
   static const bool select = !(getenv("VK_MERGE_SELECT") && atoi(getenv("VK_MERGE_SELECT")) == 0);
   if (select && e == 1 && (uint64_t)a.parts * a.per_part <= kMergeSelectMax) {
@@ -643,6 +647,22 @@ __global__ void kth_bound_kernel(const float *out_dist, const uint32_t *out_n, u
   bound[q] = b;
   reinterpret_cast<uint32_t *>(bound)[nq + q] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__global__ void fill_empty_kernel(float *out_dist, uint64_t *out_label, uint32_t *out_n, uint32_t nq, uint32_t k) {
+  const uint64_t total = (uint64_t)nq * k;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    out_dist[i] = __builtin_inff();
+    out_label[i] = kNoLabel;
+  }
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) out_n[q] = 0;
+}
+hipError_t launch_fill_empty(float *out_dist, uint64_t *out_label, uint32_t *out_n, uint32_t nq, uint32_t k, hipStream_t s) {
+  if (nq == 0) return hipSuccess;
+  const uint64_t total = std::max<uint64_t>((uint64_t)nq * k, nq);
+  hipLaunchKernelGGL(fill_empty_kernel, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 1024)), dim3(256), 0, s, out_dist,
+                     out_label, out_n, nq, k);
+  return hipGetLastError();
+}
+
 hipError_t launch_kth_bound(const float *out_dist, const uint32_t *out_n, uint32_t k, uint32_t nq, float *bound, hipStream_t s) {
   if (nq == 0) return hipSuccess;
   hipLaunchKernelGGL(kth_bound_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, out_dist, out_n, k, nq, bound);

@@ -86,14 +86,16 @@ bool HnswGraph::lookup(uint64_t label, uint32_t *id) const {
   return true;
 }
 
-void HnswGraph::ensure_row_chunk(uint32_t id) {
+Status HnswGraph::ensure_row_chunk(uint32_t id) {
   const size_t c = id >> kChunkShift;
   std::lock_guard<std::mutex> lk(rows_mu_);
   if (!rows_[c]) {
     void *p = nullptr;
-    if (posix_memalign(&p, 64, ((size_t)1 << kChunkShift) * dim_ * sizeof(float))) p = nullptr;
+    if (posix_memalign(&p, 64, ((size_t)1 << kChunkShift) * dim_ * sizeof(float)) || !p)
+      return Status::Err(kErrInternal, "out of host memory for the HNSW row chunks");
     rows_[c] = static_cast<float *>(p);
   }
+  return Status::Ok();
 }
 
 std::unique_ptr<HnswGraph::VisitedList> HnswGraph::get_visited() {
@@ -257,7 +259,7 @@ Status HnswGraph::mutually_connect(const float *q, uint32_t cur_c, Heap &top, in
 
 Status HnswGraph::mark_deleted_internal(uint32_t id) {   // :1194-1209
   if (is_deleted(id)) return Status::Err(kErrInternal, "The requested to delete element is already deleted");
-  links0_mut(id)[0] |= kDeleteFlag;
+  __atomic_fetch_or(links0_mut(id), kDeleteFlag, __ATOMIC_RELAXED);   // (see set_list_count)
   num_deleted_ += 1;
   mark(id, 0);
   if (allow_replace_deleted_) {
@@ -269,7 +271,7 @@ Status HnswGraph::mark_deleted_internal(uint32_t id) {   // :1194-1209
 
 Status HnswGraph::unmark_deleted_internal(uint32_t id) { // :1236-1251
   if (!is_deleted(id)) return Status::Err(kErrInternal, "The requested to undelete element is not deleted");
-  links0_mut(id)[0] &= ~kDeleteFlag;
+  __atomic_fetch_and(links0_mut(id), ~kDeleteFlag, __ATOMIC_RELAXED);
   num_deleted_ -= 1;
   mark(id, 0);
   if (allow_replace_deleted_) {
@@ -399,7 +401,7 @@ Status HnswGraph::add_point_level(const float *new_row, uint64_t label, int leve
     if (count_.load() >= max_elements_)
       return Status::Err(kErrCapacity, "The number of elements exceeds the specified limit");
     cur_c = (uint32_t)count_.load();
-    ensure_row_chunk(cur_c);
+    VK_TRY(ensure_row_chunk(cur_c));
     // initialise the slot before it becomes visible through count_ / label_lookup_
     memset(links0_mut(cur_c), 0, (maxM0_ + 1) * sizeof(uint32_t));
     labels_[cur_c] = label;
@@ -532,7 +534,7 @@ Status HnswGraph::bulk_register(const float *rows, const uint64_t *labels, size_
   *first_id = first;
   for (size_t i = 0; i < n; ++i) {
     const uint32_t id = first + (uint32_t)i;
-    ensure_row_chunk(id);
+    VK_TRY(ensure_row_chunk(id));
     memset(links0_mut(id), 0, (maxM0_ + 1) * sizeof(uint32_t));
     labels_[id] = labels[i];
     memcpy(row_mut(id), rows + i * dim_, dim_ * sizeof(float));
@@ -599,7 +601,7 @@ Status HnswGraph::bulk_link_upper(uint32_t id) {
 // ---- load path ----------------------------------------------------------------------------------
 Status HnswGraph::load_element(uint32_t id, const uint32_t *links0_words, const float *new_row, uint64_t label) {
   if (id >= max_elements_) return Status::Err(kErrInternal, "element id beyond max_elements");
-  ensure_row_chunk(id);
+  VK_TRY(ensure_row_chunk(id));
   memcpy(links0_mut(id), links0_words, (maxM0_ + 1) * sizeof(uint32_t));
   memcpy(row_mut(id), new_row, dim_ * sizeof(float));
   labels_[id] = label;

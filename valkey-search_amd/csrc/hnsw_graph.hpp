@@ -62,7 +62,7 @@ class HnswGraph {
   double mult() const { return mult_; }
 
   bool lookup(uint64_t label, uint32_t *id) const;      // label_lookup_
-  bool is_deleted(uint32_t id) const { return (links0(id)[0] & kDeleteFlag) != 0; }
+  bool is_deleted(uint32_t id) const { return (__atomic_load_n(links0(id), __ATOMIC_RELAXED) & kDeleteFlag) != 0; }
   uint64_t label_of(uint32_t id) const { return labels_[id]; }
   int level_of(uint32_t id) const { return levels_[id]; }
   const float *row(uint32_t id) const { return rows_[id >> kChunkShift] + (size_t)(id & kChunkMask) * dim_; }
@@ -148,9 +148,17 @@ class HnswGraph {
   uint32_t *upper_mut(uint32_t id, int level) { return upper_[id] + (size_t)(level - 1) * (maxM_ + 1); }
   uint32_t *list_at(uint32_t id, int level) { return level == 0 ? links0_mut(id) : upper_mut(id, level); }
   static unsigned list_count(const uint32_t *ll) { return *ll & 0xFFFFu; }
-  static void set_list_count(uint32_t *ll, unsigned n) { *ll = (*ll & 0xFFFF0000u) | (n & 0xFFFFu); }
+  // word 0 of a level-0 list carries the neighbour count (low 16 bits, written under the node's link lock) AND the
+  // tombstone bit (written by markDelete under the label lock only): both sides update it atomically, so neither a
+  // count nor a tombstone can be lost when a remove overlaps an insert that re-links the node (hnswlib keeps them in
+  // separate bytes, hnswalg.h:1196,1269)
+  static void set_list_count(uint32_t *ll, unsigned n) {
+    uint32_t old = __atomic_load_n(ll, __ATOMIC_RELAXED);
+    while (!__atomic_compare_exchange_n(ll, &old, (old & 0xFFFF0000u) | (n & 0xFFFFu), true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+  }
   float *row_mut(uint32_t id) { return rows_[id >> kChunkShift] + (size_t)(id & kChunkMask) * dim_; }
-  void ensure_row_chunk(uint32_t id);
+  Status ensure_row_chunk(uint32_t id);
   void mark(uint32_t id, int level) {
     const uint8_t prev = dirty_[id].fetch_or(level == 0 ? kDirtyL0 : kDirtyUpper, std::memory_order_acq_rel);
     if (prev == 0) {

@@ -137,7 +137,7 @@ class HnswIndex final : public Index {
     std::shared_lock<std::shared_mutex> lk(rw_);
     (void)hipSetDevice(store_.device());
     if (rq.nq == 0) return Status::Ok();
-    if (graph_->count() == 0 || rq.k == 0) {
+    if (pub_.count == 0 || rq.k == 0) {
       for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
       return Status::Ok();
     }
@@ -150,7 +150,7 @@ class HnswIndex final : public Index {
     VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
     VK_TRY(ctx->h_out_d.ensure(rq.nq * rq.k * 4));
     VK_TRY(ctx->h_out_l.ensure(rq.nq * rq.k * 8));
-    VK_TRY(ctx->h_out_n.ensure(rq.nq * 4 + 32));
+    VK_TRY(ctx->h_out_n.ensure(rq.nq * 4 + 64));
     if (rq.nq * rq.k <= kZeroCopyEntries) {   // the kernel writes the answer into the pinned host buffers
       VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, rq.allow_nbits, ctx->h_out_d.as<float>(),
                     ctx->h_out_l.as<uint64_t>(), ctx->h_out_n.as<uint32_t>(), ctx->stream, true));
@@ -164,13 +164,17 @@ class HnswIndex final : public Index {
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * rq.k * 8, hipMemcpyDeviceToHost, ctx->stream));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.as<char>() + rq.nq * 4, ctx->d_stats.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t st_off = (rq.nq * 4 + 7) & ~(size_t)7;
+    VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.as<char>() + st_off, ctx->d_stats.p, 40, hipMemcpyDeviceToHost, ctx->stream));
     VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
     {
-      const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out_n.as<char>() + rq.nq * 4);
+      const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out_n.as<char>() + st_off);
       last_n_eval_ = st[0];
       last_n_hops_ = st[1];
       last_overflow_ = st[2];
+      last_redo_ = st[4];
+      // (cannot happen: the LDS frontier holds at most 2*ef live entries, the graph-sized one every node)
+      if (st[2]) return Status::Err(VK_ERR_INTERNAL, "HNSW search: frontier entries were dropped");
     }
     if (rq.cancel_flag && *rq.cancel_flag && !rq.partial_ok)
       return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
@@ -189,23 +193,29 @@ class HnswIndex final : public Index {
     std::shared_lock<std::shared_mutex> lk(rw_);
     (void)hipSetDevice(store_.device());
     if (rq.nq == 0) return Status::Ok();
-    if (graph_->count() == 0 || rq.k == 0) return Status::Err(VK_ERR_INVALID, "empty index or k == 0");
-    if (!dev_ctx_) {
-      dev_ctx_ = std::make_unique<SearchCtx>();
-      VK_HIP_TRY(hipStreamCreateWithFlags(&dev_ctx_->stream, hipStreamNonBlocking));
+    if (rq.k == 0) return Status::Err(VK_ERR_INVALID, "search_batch_device needs k > 0");
+    // a context per call; the work is still in flight on the caller's stream when the call returns, the context's
+    // next user is ordered behind it (SearchCtx::busy)
+    CtxLease lease(pool_, stream);
+    SearchCtx *ctx = lease.ctx;
+    hipStream_t s = stream ? stream : ctx->stream;
+    if (pub_.count == 0) {   // an empty shard answers with empty lists
+      VK_HIP_TRY(launch_fill_empty(d_out_dist, d_out_label, d_out_n, (uint32_t)rq.nq, (uint32_t)rq.k, s));
+      return ctx->end_async(s);
     }
-    hipStream_t s = stream ? stream : dev_ctx_->stream;
     const float *dq = rq.queries;
     if (store_.stride_f() != params_.dim) {
       const size_t q_pitch = (size_t)store_.stride_f() * 4;   // queries are always f32
-      VK_TRY(dev_ctx_->d_q.ensure(rq.nq * q_pitch));
-      VK_HIP_TRY(hipMemsetAsync(dev_ctx_->d_q.p, 0, rq.nq * q_pitch, s));
-      VK_HIP_TRY(hipMemcpy2DAsync(dev_ctx_->d_q.p, q_pitch, rq.queries, (size_t)params_.dim * 4,
+      VK_TRY(ctx->d_q.ensure(rq.nq * q_pitch));
+      VK_HIP_TRY(hipMemsetAsync(ctx->d_q.p, 0, rq.nq * q_pitch, s));
+      VK_HIP_TRY(hipMemcpy2DAsync(ctx->d_q.p, q_pitch, rq.queries, (size_t)params_.dim * 4,
                                   (size_t)params_.dim * 4, rq.nq, hipMemcpyDeviceToDevice, s));
-      dq = dev_ctx_->d_q.as<float>();
+      dq = ctx->d_q.as<float>();
     }
-    return launch(dev_ctx_.get(), dq, rq.nq, rq.k, rq.ef, rq.allow_bits, rq.allow_nbits, d_out_dist, d_out_label,
-                  d_out_n, s, false);
+    Status st = launch(ctx, dq, rq.nq, rq.k, rq.ef, rq.allow_bits, rq.allow_nbits, d_out_dist, d_out_label,
+                       d_out_n, s, true);
+    Status en = ctx->end_async(s);
+    return st.ok() ? en : st;
   }
 
   Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n, float *out_dist,
@@ -225,7 +235,7 @@ class HnswIndex final : public Index {
     for (uint64_t i = 0; i < n; ++i) {
       uint32_t id;
       // tombstoned labels are "not found" (vector_hnsw.cc:55-64)
-      if (!graph_->lookup(labels[i], &id) || graph_->is_deleted(id)) continue;
+      if (!graph_->lookup(labels[i], &id) || id >= pub_.count || graph_->is_deleted(id)) continue;   // (not published yet = not found)
       idx[m] = id;
       found[m++] = labels[i];
     }
@@ -261,6 +271,7 @@ class HnswIndex final : public Index {
   }
 
   Status contains(uint64_t label, bool *found) override {
+    std::shared_lock<std::shared_mutex> lk(rw_);   // (resize reallocates the tables under the unique lock)
     uint32_t id;
     *found = graph_->lookup(label, &id) && !graph_->is_deleted(id);
     return Status::Ok();
@@ -279,6 +290,8 @@ class HnswIndex final : public Index {
     out->entry_point = graph_->entry_point();
     out->last_n_eval = last_n_eval_;
     out->last_n_hops = last_n_hops_;
+    out->last_frontier_redo = last_redo_;
+    out->last_frontier_dropped = last_overflow_;
     return Status::Ok();
   }
 
@@ -321,10 +334,30 @@ class HnswIndex final : public Index {
     return flush_locked();
   }
 
+  // What the device mirror holds as of the last flush.  Searches run on THIS, not on the live host graph: add() and
+  // remove() hold only the shared lock, so they may run between a flush and a kernel launch (or during the kernel) --
+  // a new entry point, a higher level or a larger count whose rows / lists were never published must not reach the
+  // launch arguments.
+  struct Published { uint32_t count = 0, entry_point = HnswGraph::kNone; int max_level = -1; uint64_t deleted = 0; };
+  Published pub_;
+
   Status flush_locked() {
     (void)hipSetDevice(store_.device());
     VK_TRY(store_.flush());
-    if (!graph_->any_dirty()) return Status::Ok();
+    if (!graph_->any_dirty()) { publish_snapshot(); return Status::Ok(); }
+    Status st = flush_links();
+    if (st.ok()) publish_snapshot();
+    return st;
+  }
+
+  void publish_snapshot() {   // caller holds rw_ exclusively: no add / remove is running
+    pub_.count = (uint32_t)graph_->count();
+    pub_.entry_point = graph_->entry_point();
+    pub_.max_level = graph_->max_level();
+    pub_.deleted = graph_->deleted_count();
+  }
+
+  Status flush_links() {
     graph_->clear_any_dirty();
     const uint32_t count = (uint32_t)graph_->count();
     const uint32_t l0s = (uint32_t)graph_->maxM0() + 1, ups = (uint32_t)graph_->maxM() + 1;
@@ -416,7 +449,7 @@ class HnswIndex final : public Index {
     const int e = hnsw_slots_per_lane(ef);
     if (e == 0) return Status::Err(VK_ERR_INVALID, "ef (or k) > 4096 is not served by this build of the HNSW search");
     if (graph_->maxM0() > 256) return Status::Err(VK_ERR_INVALID, "M > 128 is not served by this build of the HNSW search");
-    const uint32_t count = (uint32_t)graph_->count();
+    const uint32_t count = pub_.count;
     HnswSearchArgs a{};
     a.rows = store_.d_rows();
     a.labels = store_.d_labels();
@@ -433,23 +466,27 @@ class HnswIndex final : public Index {
     a.chunks = store_.stride_f() / 16;
     a.l0_stride = (uint32_t)graph_->maxM0() + 1;
     a.up_stride = (uint32_t)graph_->maxM() + 1;
-    a.entry_point = graph_->entry_point();
-    a.max_level = graph_->max_level();
+    a.entry_point = pub_.entry_point;
+    a.max_level = pub_.max_level;
     a.n_nodes = count;
     a.bitmap_words = (((count + 31) / 32) + 3) & ~3u;
     a.nq = (uint32_t)nq;
     a.k = (uint32_t)k;
     a.ef = (uint32_t)ef;
-    a.cand_cap = (uint32_t)std::max<uint64_t>(cand_floor_, 2 * ef);   // frontier pool (LDS); overflow is counted in stats
+    a.cand_cap = (uint32_t)std::max<uint64_t>(cand_floor_, 2 * ef);   // frontier pool (LDS): cannot outgrow 2*ef without a filter
     // With a filter or tombstones the result list fills slowly and the frontier grows like the reference's unbounded
-    // candidate_set (about ef / selectivity entries): it moves to HBM, sized by the graph (every node enters it at
-    // most once), capped at 64k entries per wave
-    const bool gpool = d_allow != nullptr || graph_->deleted_count() > 0;
+    // candidate_set (hnswalg.h:367-370; about ef / selectivity entries): it moves to HBM.  First launch: sized by the
+    // graph (every node enters it at most once), capped at 64k entries per wave; a query that outgrows the cap is
+    // abandoned there and answered by a second launch whose frontier IS graph-sized (fewer waves; see below), so no
+    // search is ever truncated.
+    const bool gpool = d_allow != nullptr || pub_.deleted > 0;
+    a.gpool_level = gpool ? 1 : 0;
     if (gpool)   // (a multiple of 128: the kernel keeps one minimum per 64 entries in the LDS words of the pool)
-      a.cand_cap = (uint32_t)std::min<uint64_t>(65536, (std::max<uint64_t>(a.cand_cap, count) + 127) & ~(uint64_t)127);
+      a.cand_cap = (uint32_t)std::min<uint64_t>(gpool_cap_, (std::max<uint64_t>(a.cand_cap, count) + 127) & ~(uint64_t)127);
+    const bool redo = gpool && a.cand_cap < count;
     a.pool_g = gpool ? reinterpret_cast<float *>(8) : nullptr;   // (placeholder until the buffer is sized below)
     a.nbr_cap = (uint32_t)((graph_->maxM0() + 63) & ~(size_t)63);
-    a.check_deleted = graph_->deleted_count() ? 1 : 0;
+    a.check_deleted = pub_.deleted ? 1 : 0;
     a.out_ids = out_ids ? 1 : 0;
     if (hnsw_lds_bytes(a) > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     int max_blocks = 0;
@@ -464,14 +501,46 @@ class HnswIndex final : public Index {
       VK_TRY(ctx->d_pool.ensure(blocks * wpb * (uint64_t)a.cand_cap * 8));
       a.pool_g = ctx->d_pool.as<float>();
     }
-    VK_TRY(ctx->d_tmp.ensure(blocks * wpb * bm_bytes));
+    // the second launch (graph-sized frontier: cand_cap >= count, a multiple of 8192; per wave the entries plus one
+    // minimum per 64 of them): as many waves as its memory budget holds
+    HnswSearchArgs b{};
+    uint64_t blocks2 = 0, wpb2 = 0;
+    if (redo) {
+      b = a;
+      b.gpool_level = 2;
+      b.cand_cap = (uint32_t)(((uint64_t)count + 8191) & ~(uint64_t)8191);
+      if (hnsw_lds_bytes(b) > 160 * 1024) return Status::Err(VK_ERR_INVALID, "graph too large for the LDS frontier index");
+      int mb2 = 0;
+      VK_HIP_TRY(hnsw_max_blocks(b, l2(), store_.bf16(), e, &mb2));
+      wpb2 = (uint64_t)hnsw_waves_per_block(b);
+      const uint64_t per_wave = (uint64_t)b.cand_cap * 8 + (uint64_t)b.cand_cap / 64 * 4;
+      blocks2 = std::min<uint64_t>((nq + wpb2 - 1) / wpb2, (uint64_t)mb2);
+      blocks2 = std::max<uint64_t>(1, std::min<uint64_t>(blocks2, redo_bytes_ / (per_wave * wpb2)));
+      blocks2 = std::max<uint64_t>(1, std::min<uint64_t>(blocks2, ((uint64_t)2 << 30) / (bm_bytes * wpb2)));
+      VK_TRY(ctx->d_pool2.ensure(blocks2 * wpb2 * per_wave));
+      VK_TRY(ctx->d_redo.ensure((nq + 1) * 4));
+      b.pool_g = ctx->d_pool2.as<float>();
+    }
+    VK_TRY(ctx->d_tmp.ensure(std::max(blocks * wpb, blocks2 * wpb2) * bm_bytes));
     a.visited = ctx->d_tmp.as<uint32_t>();
     VK_TRY(ctx->d_stats.ensure(64));
-    if (reset_stats) VK_HIP_TRY(hipMemsetAsync(ctx->d_stats.p, 0, 32, s));
+    if (reset_stats) VK_HIP_TRY(hipMemsetAsync(ctx->d_stats.p, 0, 40, s));
     a.stats = ctx->d_stats.as<unsigned long long>();
-    a.queue = reinterpret_cast<uint32_t *>(a.stats + 4);
+    a.queue = reinterpret_cast<uint32_t *>(a.stats + 6);          // [0]: first launch, [1]: second
     VK_HIP_TRY(hipMemsetAsync(a.queue, 0, 8, s));
+    if (redo) {
+      a.redo_out = ctx->d_redo.as<uint32_t>();
+      VK_HIP_TRY(hipMemsetAsync(a.redo_out, 0, 4, s));
+    }
     VK_HIP_TRY(launch_hnsw_search(a, l2(), store_.bf16(), e, (uint32_t)blocks, s));
+    if (redo) {   // a few microseconds when the list is empty
+      b.visited = a.visited;
+      b.stats = a.stats;
+      b.queue = a.queue + 1;
+      b.redo_out = nullptr;
+      b.redo_in = ctx->d_redo.as<uint32_t>();
+      VK_HIP_TRY(launch_hnsw_search(b, l2(), store_.bf16(), e, (uint32_t)blocks2, s));
+    }
     return Status::Ok();
   }
 
@@ -739,15 +808,18 @@ class HnswIndex final : public Index {
   uint64_t build_min_batch_ = getenv("VK_HNSW_BUILD_MIN_BATCH") ? (uint64_t)atoll(getenv("VK_HNSW_BUILD_MIN_BATCH")) : 64;
   uint64_t build_frac_ = getenv("VK_HNSW_BUILD_FRAC") ? (uint64_t)std::max(1, atoi(getenv("VK_HNSW_BUILD_FRAC"))) : 32;
   uint64_t cand_floor_ = getenv("VK_HNSW_POOL_FLOOR") ? (uint64_t)atoll(getenv("VK_HNSW_POOL_FLOOR")) : 512;
+  // cap of the first launch's HBM frontier (entries per wave, a multiple of 128) and the memory the second launch's
+  // graph-sized frontiers may take per context; VK_HNSW_GPOOL_CAP=128 forces the second launch on small test graphs
+  uint64_t gpool_cap_ = std::max<uint64_t>(128, (getenv("VK_HNSW_GPOOL_CAP") ? (uint64_t)atoll(getenv("VK_HNSW_GPOOL_CAP")) : 65536) & ~(uint64_t)127);
+  uint64_t redo_bytes_ = getenv("VK_HNSW_REDO_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_REDO_BYTES")) : ((uint64_t)2 << 30);
   bool device_build_ = !(getenv("VK_HNSW_DEVICE_BUILD") && atoi(getenv("VK_HNSW_DEVICE_BUILD")) == 0);
   RowStore store_;
   CtxPool pool_;
-  std::unique_ptr<SearchCtx> dev_ctx_;
   std::unique_ptr<HnswGraph> graph_;
   std::shared_mutex rw_;
   std::mutex store_mu_;
   DevBuf d_links0_, d_upper_slot_, d_upper_pool_;
-  std::atomic<uint64_t> last_n_eval_{0}, last_n_hops_{0}, last_overflow_{0};
+  std::atomic<uint64_t> last_n_eval_{0}, last_n_hops_{0}, last_overflow_{0}, last_redo_{0};
 };
 
 // ---- persistence: hnswalg.h:808-865 (SaveIndex), :887-1139 (LoadIndex + loadCheck) -----------------

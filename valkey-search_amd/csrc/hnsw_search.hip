@@ -186,7 +186,11 @@ __device__ __forceinline__ void pool_prune(Pool<kG> &c, float bound, int lane) {
 
 // Shared body.  kBatch = row pieces in flight per lane (device_common.hpp): 8 for the throughput kernel,
 // 24 for the latency kernel that serves small batches.
-template <bool kL2, int kE, bool kBf16, int kBatch, bool kSplitRows, bool kGPool = false>
+// kGPool: where the frontier lives.  0 = LDS (no filter, no tombstones: it cannot outgrow 2*ef).  1 = HBM, at most 64k
+// entries, one exact minimum per segment of 64 entries in LDS; a query whose frontier does not fit is ABANDONED and
+// queued in a.redo_out.  2 = HBM, sized by the graph (a node enters the frontier at most once, so it cannot overflow),
+// segment minima in HBM too and one minimum per 64 segments in LDS: the kernel that re-runs the abandoned queries.
+template <bool kL2, int kE, bool kBf16, int kBatch, bool kSplitRows, int kGPool = 0>
 __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63;
@@ -198,8 +202,9 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   // per-wave LDS carve: query | [result list d | id (kE == 0 only)] | pool d | pool id | nbr id | nbr dist
   constexpr bool kLdsList = kE == 0;
   const uint32_t list_words = kLdsList ? 2 * a.ef : 0;
-  // (HBM frontier: the LDS keeps one minimum per segment of 64 entries in the pool's place, cand_cap / 64 floats)
-  const uint32_t lds_pool = kGPool ? a.cand_cap / 128 : a.cand_cap;
+  // (HBM frontier: the LDS keeps one minimum per segment of 64 entries in the pool's place, cand_cap / 64 floats;
+  // two-level: one per 64 segments, cand_cap / 4096 floats)
+  const uint32_t lds_pool = kGPool == 2 ? a.cand_cap / 8192 : kGPool == 1 ? a.cand_cap / 128 : a.cand_cap;
   const size_t per_wave_f4 = (size_t)chunks * 4 + (list_words + lds_pool * 2 + a.nbr_cap * 2 + 3) / 4;
   float4 *qs = lds4 + wave * per_wave_f4;
   float *list_d = reinterpret_cast<float *>(qs + chunks * 4);
@@ -216,9 +221,14 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   unsigned long long st_eval = 0, st_hops = 0, st_over = 0, st_q = 0;
 
   // every wave slot starts on query `wslot`; further queries are handed out first come, first served (a.queue), so
-  // a batch that is not a multiple of the resident waves, or whose queries differ in length, still ends together
-  uint32_t q = wslot;
-  while (q < a.nq) {
+  // a batch that is not a multiple of the resident waves, or whose queries differ in length, still ends together.
+  // With a.redo_in the work list is that array (the queries an earlier launch abandoned): [0] = count, then ids.
+  const uint32_t n_work = a.redo_in ? __hip_atomic_load(a.redo_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.nq;
+  uint32_t qi = wslot;
+  while (qi < n_work) {
+    const uint32_t q = a.redo_in ? a.redo_in[1 + qi] : qi;
+    unsigned long long q_eval = 0, q_hops = 0;
+    bool abandoned = false;
     // ---- stage the query, clear this wave's visited bitmap --------------------------------
     {
       const float4 *src = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f);
@@ -275,44 +285,83 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     typename std::conditional<kLdsList, LdsSorted, WaveSorted<(kE > 0 ? kE : 1)>>::type top;
     if constexpr (kLdsList) { top.d = list_d; top.id = reinterpret_cast<uint32_t *>(list_d + a.ef); }
     top.init();
-    Pool<kGPool> c{pool_d, pool_id, 0, a.cand_cap};
-    float *seg_min = pool_d;   // kGPool: seg_min[s] = min distance of entries 64s .. 64s+63 (exact at all times)
-    if constexpr (kGPool) {
-      c.d = a.pool_g + (size_t)wslot * 2 * a.cand_cap;
+    Pool<(kGPool != 0)> c{pool_d, pool_id, 0, a.cand_cap};
+    // kGPool: seg_min[s] = min distance of entries 64s .. 64s+63, exact at all times (LDS).  kGPool == 2: seg_min lives
+    // in HBM behind the entries (agent-scope accesses like them) and sup_min[t] = min of seg_min[64t .. 64t+63] in LDS
+    float *seg_min = pool_d;
+    float *sup_min = pool_d;
+    float tail_min = 0.f;      // kGPool == 2: minimum of the segment the next append goes to (wave-uniform)
+    if constexpr (kGPool != 0) {
+      const size_t per_wave = kGPool == 2 ? (size_t)2 * a.cand_cap + a.cand_cap / kWave : (size_t)2 * a.cand_cap;
+      c.d = a.pool_g + (size_t)wslot * per_wave;
       c.id = reinterpret_cast<uint32_t *>(c.d + a.cand_cap);
+      if constexpr (kGPool == 2) seg_min = c.d + 2 * (size_t)a.cand_cap;
     }
+    auto ld_seg = [&](uint32_t sidx) -> float {
+      if constexpr (kGPool == 2) return __hip_atomic_load(seg_min + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else return seg_min[sidx];
+    };
+    auto st_seg = [&](uint32_t sidx, float v) {
+      if constexpr (kGPool == 2) __hip_atomic_store(seg_min + sidx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else seg_min[sidx] = v;
+    };
+    // all minima from the entries (after a compaction)
+    auto rebuild_minima = [&]() {
+      if constexpr (kGPool != 0) {
+        const uint32_t nseg = (c.cnt + kWave - 1) / kWave;
+        float gmin = __builtin_inff();
+        for (uint32_t sidx = 0; sidx < nseg; ++sidx) {
+          const uint32_t i = sidx * kWave + lane;
+          const float mv = wave_min_f32(i < c.cnt ? c.ld_d(i) : __builtin_inff());
+          if (lane == 0) st_seg(sidx, mv);
+          tail_min = mv;
+          if constexpr (kGPool == 2) {
+            gmin = (sidx % kWave) == 0 ? mv : fminf(gmin, mv);
+            if (lane == 0 && ((sidx % kWave) == kWave - 1 || sidx + 1 == nseg)) sup_min[sidx / kWave] = gmin;
+          }
+        }
+      }
+    };
     float lowerBound;
     {
       bool ep_ok = true;
       if (a.check_deleted && (a.links0[(size_t)cur * a.l0_stride] & kDeleteFlag)) ep_ok = false;
       if (ep_ok && a.allow_bits && !allow_bit(a.allow_bits, a.allow_nbits, a.labels[cur])) ep_ok = false;
+      const float d0 = ep_ok ? curdist : kFltMax;
       if (ep_ok) {
         lowerBound = curdist;   // the reference recomputes the same distance (:378)
         top.insert(curdist, cur, a.ef, lane);
-        if (lane == 0) { c.st(0, curdist, cur); if (kGPool) seg_min[0] = curdist; }
-        st_eval += 1;
+        q_eval += 1;
       } else {
         lowerBound = kFltMax;
-        if (lane == 0) { c.st(0, kFltMax, cur); if (kGPool) seg_min[0] = kFltMax; }
       }
+      if (lane == 0) {
+        c.st(0, d0, cur);
+        if constexpr (kGPool != 0) st_seg(0, d0);
+        if constexpr (kGPool == 2) sup_min[0] = d0;
+      }
+      tail_min = d0;
       c.cnt = 1;
       if (lane == 0) (void)visit(cur);
     }
 
     for (;;) {
-      if (c.cnt == 0) break;
+      if (c.cnt == 0 || abandoned) break;
       // extract-min over the pool
       float bd = __builtin_inff();
       uint32_t bi = kNoneId;
       float seg_v = 0.f;        // kGPool: this lane's entry of the winning segment
+      float grp_v = 0.f;        // kGPool == 2: this lane's segment minimum in the winning group of 64 segments
       uint32_t seg_s = 0;
-      if constexpr (kGPool) {
-        // the minimum over the per-segment minima (LDS), then one load per lane of the winning segment: the entry is
-        // the first one there that equals it -- the smallest pool index among equal distances, like the scan below
+      if constexpr (kGPool != 0) {
+        // the minimum over the per-segment minima, then one load per lane of the winning segment: the entry is the
+        // first one there that equals it -- the smallest pool index among equal distances, like the scan below
         uint32_t bs = kNoneId;
         const uint32_t nseg = (c.cnt + kWave - 1) / kWave;
-        for (uint32_t sidx = lane; sidx < nseg; sidx += kWave) {
-          const float v = seg_min[sidx];
+        const uint32_t ntop = kGPool == 2 ? (nseg + kWave - 1) / kWave : nseg;
+        const float *top_min = kGPool == 2 ? sup_min : seg_min;
+        for (uint32_t sidx = lane; sidx < ntop; sidx += kWave) {
+          const float v = top_min[sidx];
           if (v < bd || bs == kNoneId) { bd = v; bs = sidx; }
         }
 #pragma unroll
@@ -320,6 +369,12 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
           const float od = __shfl_xor(bd, m);
           const uint32_t os = __shfl_xor((int)bs, m);
           if (os != kNoneId && (bs == kNoneId || od < bd || (od == bd && os < bs))) { bd = od; bs = os; }
+        }
+        if constexpr (kGPool == 2) {   // one level down: the first segment of that group whose minimum it is
+          const uint32_t si = bs * kWave + lane;
+          grp_v = si < nseg ? ld_seg(si) : __builtin_inff();
+          const uint64_t hit1 = __ballot(si < nseg && grp_v == bd);
+          bs = bs * kWave + (uint32_t)(__ffsll((unsigned long long)hit1) - 1);
         }
         seg_s = bs;
         const uint32_t i = seg_s * kWave + lane;
@@ -342,7 +397,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       if (cand_dist > lowerBound && top.cnt == a.ef) break;
       const uint32_t cur_id = c.ld_id(bi);
       // remove: move the last entry into the hole
-      if constexpr (kGPool) {
+      if constexpr (kGPool != 0) {
         const uint32_t last = c.cnt - 1, sl = last / kWave;
         const float d_last = c.ld_d(last);
         const uint32_t id_last = c.ld_id(last);
@@ -352,17 +407,36 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         if (seg_s * kWave + lane == bi) nv = bi != last ? d_last : __builtin_inff();
         if (seg_s == sl && seg_s * kWave + lane == last) nv = __builtin_inff();
         const float m0 = wave_min_f32(nv);
+        float m1 = m0;
         if (seg_s != sl) {
           const uint32_t i = sl * kWave + lane;
-          const float m1 = wave_min_f32(i < last ? c.ld_d(i) : __builtin_inff());
-          if (lane == 0) seg_min[sl] = m1;
+          m1 = wave_min_f32(i < last ? c.ld_d(i) : __builtin_inff());
+          if (lane == 0) st_seg(sl, m1);
         }
-        if (lane == 0) seg_min[seg_s] = m0;
+        if (lane == 0) st_seg(seg_s, m0);
+        tail_min = m1;          // the segment the next append goes to is the last entry's (or a fresh one)
+        if constexpr (kGPool == 2) {
+          // the group minima above them, from the values this lane already holds (no re-read of what was just stored)
+          const uint32_t g0 = seg_s / kWave, g1 = sl / kWave;
+          float gv = grp_v;
+          if ((uint32_t)lane == seg_s % kWave) gv = m0;
+          if (g1 == g0 && (uint32_t)lane == sl % kWave) gv = m1;
+          const float n0 = wave_min_f32(gv);
+          if (lane == 0) sup_min[g0] = n0;
+          if (g1 != g0) {
+            const uint32_t nseg = (c.cnt + kWave - 1) / kWave;
+            const uint32_t si = g1 * kWave + lane;
+            float v = si < nseg ? ld_seg(si) : __builtin_inff();
+            if ((uint32_t)lane == sl % kWave) v = m1;
+            const float n1 = wave_min_f32(v);
+            if (lane == 0) sup_min[g1] = n1;
+          }
+        }
       } else {
         if (lane == 0 && bi != c.cnt - 1) c.st(bi, c.ld_d(c.cnt - 1), c.ld_id(c.cnt - 1));
       }
       c.cnt -= 1;
-      st_hops += 1;
+      q_hops += 1;
 
       // phase 1: unvisited neighbours, list order preserved
       const uint32_t *ll = a.links0 + (size_t)cur_id * a.l0_stride;
@@ -401,9 +475,9 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
           base += 4;
         }
       }
-      st_eval += nn;
+      q_eval += nn;
       // phase 3b: consider in list order, bound updated after each neighbour
-      for (uint32_t base = 0; base < nn; base += kWave) {
+      for (uint32_t base = 0; base < nn && !abandoned; base += kWave) {
         const uint32_t u = base + lane;
         const float dv = u < nn ? nbr_d[u] : __builtin_inff();
         const uint32_t nid = u < nn ? nbr_id[u] : 0;
@@ -419,20 +493,29 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
           if (c.cnt == c.cap) {
             if (top.cnt == a.ef) {
               pool_prune(c, lowerBound, lane);
-              if constexpr (kGPool) {   // the compaction moved everything: rebuild the segment minima
-                for (uint32_t sidx = 0; sidx * kWave < c.cnt; ++sidx) {
-                  const uint32_t i = sidx * kWave + lane;
-                  const float mv = wave_min_f32(i < c.cnt ? c.ld_d(i) : __builtin_inff());
-                  if (lane == 0) seg_min[sidx] = mv;
-                }
-              }
+              rebuild_minima();   // the compaction moved everything
             }
-            if (c.cnt == c.cap) st_over += 1;
+            if (c.cnt == c.cap) {
+              // The reference's candidate_set is unbounded (hnswalg.h:367-370,506): dropping the entry would end the
+              // search early.  The capped HBM frontier gives the query up instead -- it is re-run by the launch with the
+              // graph-sized frontier (a.redo_out); the LDS frontier and the graph-sized one cannot get here
+              // (counted, and the host turns a non-zero count into an error).
+              if (kGPool == 1 && a.redo_out) { abandoned = true; break; }
+              st_over += 1;
+            }
           }
           if (c.cnt < c.cap) {
-            if (lane == 0) {
+            if constexpr (kGPool == 2) {
+              tail_min = (c.cnt % kWave) == 0 ? cd : fminf(tail_min, cd);
+              if (lane == 0) {
+                c.st(c.cnt, cd, cid);
+                st_seg(c.cnt / kWave, tail_min);
+                const uint32_t g = c.cnt / (kWave * kWave);
+                sup_min[g] = (c.cnt % (kWave * kWave)) == 0 ? cd : fminf(sup_min[g], cd);
+              }
+            } else if (lane == 0) {
               c.st(c.cnt, cd, cid);
-              if constexpr (kGPool) {
+              if constexpr (kGPool == 1) {
                 const uint32_t sidx = c.cnt / kWave;
                 seg_min[sidx] = (c.cnt % kWave) == 0 ? cd : fminf(seg_min[sidx], cd);
               }
@@ -448,6 +531,19 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         }
       }
     }
+
+    if (abandoned) {   // nothing is written for this query: the graph-sized launch answers it
+      if (lane == 0) {
+        const uint32_t slot = atomicAdd(a.redo_out, 1u);
+        a.redo_out[1 + slot] = q;
+      }
+      uint32_t nxt = 0;
+      if (lane == 0) nxt = atomicAdd(a.queue, 1u);
+      qi = wstride + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+      continue;
+    }
+    st_eval += q_eval;
+    st_hops += q_hops;
 
     // ---- trim to k, label, order by (distance,label) ---------------------------------------------
     const uint32_t kout = top.cnt < a.k ? top.cnt : a.k;
@@ -502,7 +598,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     st_q += 1;
     uint32_t nxt = 0;
     if (lane == 0) nxt = atomicAdd(a.queue, 1u);
-    q = wstride + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+    qi = wstride + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
   }
 
   if (lane == 0 && a.stats && st_q) {
@@ -510,6 +606,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     atomicAdd(&a.stats[1], st_hops);
     atomicAdd(&a.stats[2], st_over);
     atomicAdd(&a.stats[3], st_q);
+    if (a.redo_in) atomicAdd(&a.stats[4], st_q);   // ... of which answered by the graph-sized-frontier launch
   }
 }
 
@@ -521,7 +618,12 @@ __global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
 // searches with a filter or tombstones: the frontier lives in HBM (HnswSearchArgs::pool_g)
 template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 4) void hnsw_search_gpool_kernel(HnswSearchArgs a) {
-  hnsw_search_body<kL2, kE, kBf16, 8, false, true>(a);
+  hnsw_search_body<kL2, kE, kBf16, 8, false, 1>(a);
+}
+// ... and the queries whose frontier outgrew that kernel's 64k entries, again, with a frontier sized by the graph
+template <bool kL2, int kE, bool kBf16>
+__global__ __launch_bounds__(256, 4) void hnsw_search_gpool2_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, 8, false, 2>(a);
 }
 // a few queries cannot fill the device: each wave is alone with its memory latency, so it keeps six times as
 // many row pieces in flight (a whole 768-d row per lane; one block per CU, registers instead of occupancy)
@@ -558,7 +660,9 @@ int hnsw_slots_per_lane(uint64_t ef) {
 
 static size_t hnsw_lds_per_wave(const HnswSearchArgs &a) {
   const bool lds_list = a.ef > 512;
-  const size_t pool = a.pool_g ? (size_t)(a.cand_cap / 128) * 2 : (size_t)a.cand_cap * 2;   // HBM frontier: segment minima only
+  // HBM frontier: segment minima only (gpool_level 2: one per 64 segments)
+  const size_t pool = a.gpool_level == 2 ? (size_t)(a.cand_cap / 8192) * 2
+                      : a.gpool_level == 1 ? (size_t)(a.cand_cap / 128) * 2 : (size_t)a.cand_cap * 2;
   const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + pool + a.nbr_cap * 2 + 3) / 4;
   return per_wave_f4 * 16;
 }
@@ -574,7 +678,8 @@ int hnsw_waves_per_block(const HnswSearchArgs &a) {
 size_t hnsw_lds_bytes(const HnswSearchArgs &a) { return hnsw_lds_per_wave(a) * (size_t)hnsw_waves_per_block(a); }
 
 template <bool kL2, int kE, bool kBf16>
-static const void *hnsw_fn(bool latency, bool gpool) {
+static const void *hnsw_fn(bool latency, int gpool) {
+  if (gpool == 2) return reinterpret_cast<const void *>(&hnsw_search_gpool2_kernel<kL2, kE, kBf16>);
   if (gpool) return reinterpret_cast<const void *>(&hnsw_search_gpool_kernel<kL2, kE, kBf16>);
   if constexpr (kE >= 1 && kE <= 4) {
     if (latency) return reinterpret_cast<const void *>(&hnsw_search_latency_kernel<kL2, kE, kBf16>);
@@ -583,7 +688,7 @@ static const void *hnsw_fn(bool latency, bool gpool) {
 }
 
 template <int kE>
-static const void *hnsw_pick_e(bool l2, bool bf16, bool latency, bool gpool) {
+static const void *hnsw_pick_e(bool l2, bool bf16, bool latency, int gpool) {
   return l2 ? (bf16 ? hnsw_fn<true, kE, true>(latency, gpool) : hnsw_fn<true, kE, false>(latency, gpool))
             : (bf16 ? hnsw_fn<false, kE, true>(latency, gpool) : hnsw_fn<false, kE, false>(latency, gpool));
 }
@@ -594,7 +699,7 @@ static bool hnsw_latency_variant(const HnswSearchArgs &a) {
   return a.nq <= max_nq;
 }
 
-static const void *hnsw_pick(bool l2, bool bf16, int e, bool latency, bool gpool) {
+static const void *hnsw_pick(bool l2, bool bf16, int e, bool latency, int gpool) {
   switch (e) {
     case 1: return hnsw_pick_e<1>(l2, bf16, latency, gpool);
     case 2: return hnsw_pick_e<2>(l2, bf16, latency, gpool);
@@ -606,7 +711,7 @@ static const void *hnsw_pick(bool l2, bool bf16, int e, bool latency, bool gpool
 }
 
 hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks) {
-  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a), a.pool_g != nullptr);
+  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a), (int)a.gpool_level);
   if (!f) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -626,7 +731,7 @@ hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, i
 }
 
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s) {
-  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a), a.pool_g != nullptr);
+  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a), (int)a.gpool_level);
   if (!f || blocks == 0) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 48 * 1024) {

@@ -44,8 +44,16 @@ constexpr uint64_t kZeroCopyEntries = 4096;   // nq * k
 // (search.cc:886-910 schedules one query per reader-pool thread) do not serialise.
 struct SearchCtx {
   hipStream_t stream = nullptr;
-  DevBuf d_q, d_part_d, d_part_l, d_out_d, d_out_l, d_out_n, d_allow, d_idx, d_tmp, d_stats, d_sync, d_pool;
+  DevBuf d_q, d_part_d, d_part_l, d_out_d, d_out_l, d_out_n, d_allow, d_idx, d_tmp, d_stats, d_sync, d_pool, d_pool2, d_redo;
   PinBuf h_q, h_out_d, h_out_l, h_out_n, h_tmp, h_idx;
+  // A device-buffer search (vk_index_search_batch_device) returns with its kernels still in flight on the CALLER's
+  // stream and gives the context back: `busy` is recorded behind that work, and whoever leases the context next makes
+  // its own stream wait for it before touching the scratch (begin_on) -- no host wait, and no two calls ever share
+  // scratch that is live.  (DevBuf::ensure growing a buffer frees the old one with hipFree, which waits for the device.)
+  hipEvent_t busy = nullptr;
+  bool has_busy = false;
+  Status begin_on(hipStream_t s);   // order the work about to be enqueued on `s` behind the context's previous user
+  Status end_async(hipStream_t s);  // the work enqueued on `s` is the context's last user from now on
   ~SearchCtx();
 };
 
@@ -53,7 +61,9 @@ class CtxPool {
  public:
   explicit CtxPool(int device, size_t max_ctx = 16) : device_(device), max_(max_ctx) {}
   ~CtxPool();
-  SearchCtx *acquire();
+  // `on` = the stream the lease holder will enqueue on (nullptr = the context's own): it is ordered behind the
+  // context's previous asynchronous user (SearchCtx::busy)
+  SearchCtx *acquire(hipStream_t on = nullptr);
   void release(SearchCtx *c);
 
  private:
@@ -68,7 +78,7 @@ class CtxPool {
 struct CtxLease {
   CtxPool &pool;
   SearchCtx *ctx;
-  explicit CtxLease(CtxPool &p) : pool(p), ctx(p.acquire()) {}
+  explicit CtxLease(CtxPool &p, hipStream_t on = nullptr) : pool(p), ctx(p.acquire(on)) {}
   ~CtxLease() { pool.release(ctx); }
 };
 

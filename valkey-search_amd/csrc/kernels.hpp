@@ -61,7 +61,8 @@ struct MergeArgs {
   uint64_t part_stride, q_stride;
   uint32_t parts, per_part;
   uint32_t k;
-  float *out_dist;            // [nq][k] ascending by (dist,label)
+  uint32_t out_ld;            // entries per query in the output arrays, 0 = k; entries past the count are (+inf, kNoLabel)
+  float *out_dist;            // [nq][out_ld] ascending by (dist,label)
   uint64_t *out_label;
   uint32_t *out_n;            // [nq]
 };
@@ -88,7 +89,7 @@ struct HnswSearchArgs {
   float *out_dist;             // [nq][k]
   uint64_t *out_label;
   uint32_t *out_n;
-  unsigned long long *stats;   // [4]: n_eval, n_hops, cand_overflow, queries
+  unsigned long long *stats;   // [5]: n_eval, n_hops, frontier entries dropped (must stay 0), queries, queries re-run (redo_in)
   uint32_t *queue;             // zeroed per launch: queries past the first wave of slots are taken in arrival order
   uint32_t row_stride_f, q_stride_f, chunks;
   uint32_t l0_stride, up_stride;
@@ -101,6 +102,12 @@ struct HnswSearchArgs {
   // the reference's candidate_set (an unbounded heap) grows to about ef / selectivity entries -- far more than fit
   // the LDS next to the query; per wave slot cand_cap distances followed by cand_cap ids
   float *pool_g;
+  // 0 = frontier in LDS, 1 = in HBM with cand_cap <= 64k (a multiple of 128) and a query that outgrows it abandoned
+  // into redo_out, 2 = in HBM with cand_cap >= n_nodes (a multiple of 8192; per wave slot also cand_cap / 64 segment
+  // minima behind the ids): the launch that answers the abandoned queries, its work list is redo_in
+  uint32_t gpool_level;
+  uint32_t *redo_out;          // [1 + nq]: [0] = number of abandoned queries (zeroed before the launch), then their ids
+  const uint32_t *redo_in;     // the same array, read by the second launch
   uint32_t nbr_cap;            // >= maxM0
   uint32_t check_deleted;      // any tombstones in the index
   uint32_t out_ids;            // 1: out_label receives internal ids (device-side graph construction)
@@ -174,6 +181,8 @@ int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e, bool l2);
 hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, int e, hipStream_t s);
 hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s);
 hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipStream_t s);
+// the answer of an empty index / shard: out_n = 0, every entry (+inf, kNoLabel)
+hipError_t launch_fill_empty(float *out_dist, uint64_t *out_label, uint32_t *out_n, uint32_t nq, uint32_t k, hipStream_t s);
 // bound[q] = out_dist[q][k-1] if the query found k entries, +inf otherwise; bound[nq + q] = the same as an
 // order-preserving u32 key (the buffer holds 2*nq words)
 hipError_t launch_kth_bound(const float *out_dist, const uint32_t *out_n, uint32_t k, uint32_t nq, float *bound, hipStream_t s);

@@ -120,18 +120,23 @@ Status RowStore::reserve(uint64_t rows) {
   // kRowSlack rows beyond the capacity stay allocated (and zero): the tiled kernels read whole
   // 128-row tiles and mask the rows past the count afterwards, instead of clamping every address
   VK_HIP_TRY(hipMalloc(&nr, (want + kRowSlack) * row_bytes()));
-  VK_HIP_TRY(hipMemsetAsync(static_cast<char *>(nr) + want * row_bytes(), 0, kRowSlack * row_bytes(), stream_));
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&nl), want * 8);
-  if (e != hipSuccess) {
+  // (every failure from here on gives the new arrays back: the store keeps its old ones)
+  auto step = [&](hipError_t err, const char *what) -> Status {
+    if (err == hipSuccess) return Status::Ok();
+    (void)hipStreamSynchronize(stream_);
     (void)hipFree(nr);
-    return Status::Err(4, std::string("hipMalloc labels: ") + hipGetErrorString(e));
-  }
+    if (nl) (void)hipFree(nl);
+    return Status::Err(4, std::string(what) + ": " + hipGetErrorString(err));
+  };
+  if (e != hipSuccess) { nl = nullptr; return step(e, "hipMalloc labels"); }
+  VK_TRY(step(hipMemsetAsync(static_cast<char *>(nr) + want * row_bytes(), 0, kRowSlack * row_bytes(), stream_), "hipMemsetAsync slack"));
   if (alloc_rows_) {
-    VK_HIP_TRY(hipMemcpyAsync(nr, d_rows_, alloc_rows_ * row_bytes(), hipMemcpyDeviceToDevice, stream_));
-    VK_HIP_TRY(hipMemcpyAsync(nl, d_labels_, alloc_rows_ * 8, hipMemcpyDeviceToDevice, stream_));
+    VK_TRY(step(hipMemcpyAsync(nr, d_rows_, alloc_rows_ * row_bytes(), hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync rows"));
+    VK_TRY(step(hipMemcpyAsync(nl, d_labels_, alloc_rows_ * 8, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync labels"));
   }
-  VK_HIP_TRY(hipMemsetAsync(nl + alloc_rows_, 0xFF, (want - alloc_rows_) * 8, stream_));
-  VK_HIP_TRY(hipStreamSynchronize(stream_));
+  VK_TRY(step(hipMemsetAsync(nl + alloc_rows_, 0xFF, (want - alloc_rows_) * 8, stream_), "hipMemsetAsync labels"));
+  VK_TRY(step(hipStreamSynchronize(stream_), "hipStreamSynchronize"));
   if (d_rows_) (void)hipFree(d_rows_);
   if (d_labels_) (void)hipFree(d_labels_);
   d_rows_ = nr;
