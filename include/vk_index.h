@@ -138,8 +138,12 @@ int vk_index_flush(vk_index *ix);
  *   allow_bits   : optional filter, the materialised BaseFilterFunctor (hnswlib.h:144-149):
  *                  bit `label` set = allowed, labels >= allow_nbits rejected; NULL = no filter
  *   cancel_flag  : optional host word, non-zero = cancelled (BaseCancellationFunctor,
- *                  hnswlib.h:153-157); polled between kernel phases.  FLAT returns what it
- *                  has; HNSW returns VK_ERR_CANCELLED unless partial_ok
+ *                  hnswlib.h:153-157).  The calling thread watches it while it waits for the
+ *                  device and relays it to the running kernels, which poll between row tiles
+ *                  (FLAT: bruteforce.h:129) / every few expanded nodes (HNSW: hnswalg.h:400-402)
+ *                  and stop: the call returns within about a millisecond of the flag.  FLAT
+ *                  returns what it has; HNSW returns what its result lists hold when partial_ok,
+ *                  else VK_ERR_CANCELLED (vector_hnsw.cc:327-329)
  *   out_dist/out_label : caller buffers of k entries; *out_n receives the count */
 int vk_index_search(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime,
                     const uint64_t *allow_bits, uint64_t allow_nbits,

@@ -28,6 +28,19 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_first():
+    """On a GPU box, initialise torch's HIP runtime before libvkindex makes its first HIP call: torch ships its own
+    copy of the runtime, and when the system runtime (libvkindex links /opt/rocm) initialises first, torch's later
+    initialisation reports "No HIP GPUs are available" (seen on a fresh box with a test that touched torch only after
+    building an index).  The other order -- what bench.py does -- works."""
+    if _have_gpu():
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O

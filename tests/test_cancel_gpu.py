@@ -1,0 +1,123 @@
+"""In-kernel cancellation (BaseCancellationFunctor, hnswlib.h:153-157).
+
+The reference polls the token inside its loops: per row in BruteforceSearch::searchKnn (bruteforce.h:129), per popped
+candidate in searchBaseLayerST (hnswalg.h:400-402); VectorHNSW::Search turns a cancelled search without
+partial results into CancelledError (vector_hnsw.cc:327-329).  Here the waiting host thread relays the caller's flag to
+a pinned word the running kernels poll.  Pinned: a flag raised from another thread in the middle of a long batch ends
+the call within milliseconds (not after the batch), the answer is then "what it has" (every entry a true distance of a
+real row, ascending), and a flag that is passed but never raised changes nothing."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vsa():
+    import _pkg
+    return _pkg.vsa
+
+
+def _timed_cancel(fn, flag, after_s):
+    """run fn() in this thread; another thread raises `flag` after `after_s`; returns (result, seconds from raise to return)"""
+    t_raise = [None]
+
+    def raiser():
+        time.sleep(after_s)
+        t_raise[0] = time.perf_counter()
+        flag.value = 1
+
+    th = threading.Thread(target=raiser)
+    th.start()
+    try:
+        out = fn()
+        err = None
+    except Exception as e:   # noqa: BLE001
+        out, err = None, e
+    t_done = time.perf_counter()
+    th.join()
+    return out, err, (t_done - t_raise[0]) if t_raise[0] is not None and t_done > t_raise[0] else None
+
+
+def test_hnsw_cancel_interrupts_a_long_filtered_batch(vsa, oracle):
+    rng = np.random.default_rng(31)
+    n, dim = 60_000, 64
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=16, ef_construction=100)
+    g.add_batch(x)
+    g.flush()
+    bits = oracle.allow_bitmap(np.flatnonzero(rng.random(n) < 0.01), n)
+    Q = rng.standard_normal((8192, dim)).astype(np.float32)
+    k = 10
+    t0 = time.perf_counter()
+    D0, L0, N0 = g.search_batch(Q, k, ef=512, allow=bits, allow_nbits=n)
+    full_s = time.perf_counter() - t0
+    assert full_s > 0.05, "the batch is too short to interrupt meaningfully: %.3f s" % full_s
+    # a flag that is passed but never raised: the same answer
+    quiet = C.c_int(0)
+    D1, L1, N1 = g.search_batch(Q[:512], k, ef=512, allow=bits, allow_nbits=n, cancel=quiet)
+    assert (L1 == L0[:512]).all() and (D1.view(np.uint32) == D0[:512].view(np.uint32)).all() and (N1 == N0[:512]).all()
+    # raised mid-flight, partial results wanted
+    flag = C.c_int(0)
+    out, err, lag = _timed_cancel(lambda: g.search_batch(Q, k, ef=512, allow=bits, allow_nbits=n, cancel=flag, partial_ok=True),
+                                  flag, full_s * 0.2)
+    assert err is None and lag is not None
+    assert lag < 0.02 and lag < full_s * 0.5, "returned %.1f ms after the flag (whole batch %.1f ms)" % (lag * 1e3, full_s * 1e3)
+    D, L, N = out
+    assert (N <= k).all() and (N < N0).any()                         # somebody was cut short
+    rows = {int(l): x[int(l)] for l in np.unique(L[L != np.iinfo(np.uint64).max])}
+    for i in np.flatnonzero(N > 0)[:200]:
+        d = D[i, :N[i]]
+        assert (np.diff(d) >= 0).all()
+        for dd, ll in zip(d, L[i, :N[i]]):
+            assert (bits[int(ll) >> 6] >> (int(ll) & 63)) & 1
+            assert np.float32(dd).view(np.uint32) == oracle.distance("L2", Q[i], rows[int(ll)]).view(np.uint32)
+    # raised mid-flight, no partial results: CancelledError
+    flag = C.c_int(0)
+    out, err, lag = _timed_cancel(lambda: g.search_batch(Q, k, ef=512, allow=bits, allow_nbits=n, cancel=flag, partial_ok=False),
+                                  flag, full_s * 0.2)
+    assert isinstance(err, vsa.VkError) and err.code == vsa.VK_ERR_CANCELLED and "cancelled" in err.msg
+    assert lag is not None and lag < 0.02
+
+
+@pytest.mark.parametrize("metric,nq", [("L2", 2048), ("COSINE", 4096)])     # the VALU scan / the matrix-core kernel
+def test_flat_cancel_returns_what_it_has(vsa, oracle, metric, nq):
+    rng = np.random.default_rng(32)
+    n, dim, k = 1_000_000, 128, 10
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    if metric == "COSINE":
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+    g = vsa.Index("FLAT", dim, metric, initial_cap=n)
+    g.add_batch(x)
+    Q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if metric == "COSINE":
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    g.search_batch(Q[:64], k)
+    t0 = time.perf_counter()
+    D0, L0, N0 = g.search_batch(Q, k)
+    full_s = time.perf_counter() - t0
+    quiet = C.c_int(0)
+    D1, L1, N1 = g.search_batch(Q, k, cancel=quiet)
+    assert (L1 == L0).all() and (D1.view(np.uint32) == D0.view(np.uint32)).all()
+    flag = C.c_int(0)
+    out, err, lag = _timed_cancel(lambda: g.search_batch(Q, k, cancel=flag), flag, full_s * 0.25)
+    assert err is None
+    if lag is None:
+        pytest.skip("the batch finished before the flag (%.1f ms)" % (full_s * 1e3))
+    assert lag < 0.02 and lag < full_s * 0.6, "returned %.1f ms after the flag (whole batch %.1f ms)" % (lag * 1e3, full_s * 1e3)
+    D, L, N = out
+    assert (N <= k).all()
+    assert (L[:, 0] != L0[:, 0]).any() or (N < k).any()               # not the full answer
+    for i in range(0, nq, max(1, nq // 64)):
+        d = D[i, :N[i]]
+        assert (np.diff(d) >= 0).all()
+        for dd, ll in zip(d, L[i, :N[i]]):
+            assert np.float32(dd).view(np.uint32) == oracle.distance(metric, Q[i], x[int(ll)]).view(np.uint32)
+    # raised before the call: only the first k rows are looked at (bruteforce.h:120-129)
+    flag = C.c_int(1)
+    D, L, N = g.search_batch(Q[:4], k, cancel=flag)
+    assert (L < k).all() and (N == k).all()

@@ -275,6 +275,12 @@ struct WaveTopK {
   }
 };
 
+// the host's cancellation word (pinned host memory, written by the thread that waits for the kernel): a system-scope
+// load, one PCIe read per wave and poll
+__device__ __forceinline__ bool poll_cancel(const uint32_t *flag) {
+  return flag != nullptr && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+}
+
 __device__ __forceinline__ bool allow_bit(const uint64_t *__restrict__ bits, uint64_t nbits, uint64_t label) {
   if (!bits) return true;
   if (label >= nbits) return false;

@@ -427,6 +427,10 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
   constexpr uint32_t kMaxSpins = 4096;
 
   for (uint32_t t = 0; t < my_tiles; ++t) {
+    // cancellation word (host memory): requested at the start of every kCancelPollTiles-th tile, looked at behind its
+    // epilogue -- the PCIe round trip hides behind the tile
+    uint32_t cancel_now = 0;
+    if (a.cancel && (t % kCancelPollTiles) == 0) cancel_now = __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (lockstep && lane == 0) __hip_atomic_store(sync_grp + qt, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the query's shared pruning bound, fetched now and used a whole tile later in the epilogue
     uint32_t bkey = 0xFF800000u;
@@ -472,6 +476,7 @@ __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     tile_row0 += tile_step_rows;
+    if (cancel_now) break;   // (bruteforce.h:129) the lists keep what they hold
     if (lockstep && t + 1 < my_tiles) {
       // about to start tile t+1: everyone must have started tile t+1-W, i.e. published >= t+2-W
       const uint32_t need = t + 2 > lockstep ? t + 2 - lockstep : 0;

@@ -16,7 +16,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <queue>
+#include <thread>
 
 #include "index.hpp"
 
@@ -71,13 +73,38 @@ Status SearchCtx::end_async(hipStream_t s) {
   return Status::Ok();
 }
 
+Status SearchCtx::arm_cancel(const volatile int *caller_flag, const uint32_t **device_word) {
+  *device_word = nullptr;
+  if (!caller_flag) return Status::Ok();
+  VK_TRY(h_cancel.ensure(64));
+  *h_cancel.as<volatile uint32_t>() = *caller_flag ? 1u : 0u;
+  *device_word = h_cancel.as<uint32_t>();
+  return Status::Ok();
+}
+
+Status SearchCtx::wait(const volatile int *caller_flag) {
+  if (!caller_flag || !h_cancel.p) {
+    VK_HIP_TRY(hipStreamSynchronize(stream));
+    return Status::Ok();
+  }
+  volatile uint32_t *word = h_cancel.as<volatile uint32_t>();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(stream);
+    if (e == hipSuccess) return Status::Ok();
+    if (e != hipErrorNotReady) return Status::Err(4, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+    if (*caller_flag) *word = 1u;
+    if (spins < 2000) __builtin_ia32_pause();
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
+
 SearchCtx::~SearchCtx() {
   if (has_busy) (void)hipEventSynchronize(busy);
   if (busy) (void)hipEventDestroy(busy);
   if (stream) (void)hipStreamSynchronize(stream);
   for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats, &d_sync, &d_pool, &d_pool2, &d_redo})
     b->release();
-  for (PinBuf *b : {&h_q, &h_out_d, &h_out_l, &h_out_n, &h_tmp, &h_idx}) b->release();
+  for (PinBuf *b : {&h_q, &h_out_d, &h_out_l, &h_out_n, &h_tmp, &h_idx, &h_cancel}) b->release();
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -277,7 +304,7 @@ class FlatIndex final : public Index {
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    VK_TRY(ctx->wait(rq.cancel_flag));   // (a raised flag stops the kernels: the answer is what they had, bruteforce.h:129)
     // caller's buffers are [nq][rq.k]
     for (uint64_t q = 0; q < rq.nq; ++q) {
       uint32_t n = ctx->h_out_n.as<uint32_t>()[q];
@@ -460,33 +487,32 @@ class FlatIndex final : public Index {
     if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 needs the host entry points (vk_index_search / _batch), which page through the result in passes");
     const uint32_t chunks = store_.stride_f() / 16;
     // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
-    if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !cancel && flat_gemm_supported(store_.stride_f(), k) && !force_scan_)
-      return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld);
+    if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !(cancel && *cancel) && flat_gemm_supported(store_.stride_f(), k) && !force_scan_) {
+      const uint32_t *d_cancel = nullptr;
+      VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
+      return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel);
+    }
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     if (lb_dist_) e = 16;            // the paged scan has one instantiation: 16 slots per lane, one query per pass
     const int qb = lb_dist_ ? 1 : flat_scan_pick_qb(nq, chunks, e, l2());
     const uint32_t nqg = (uint32_t)((nq + qb - 1) / qb);
-    // rows: cancelled at entry -> only the first k rows are looked at (bruteforce.h:120-129)
+    // rows: cancelled at entry -> only the first k rows are looked at (bruteforce.h:120-129); cancelled later -> the
+    // kernel stops between row tiles (FlatScanArgs::cancel) and the answer is what the lists hold
     uint64_t row_end = count;
-    bool cancelled = cancel && *cancel;
-    if (cancelled) row_end = std::min<uint64_t>(count, k);
-    const uint64_t seg_rows = cancel ? ((uint64_t)4 << 20) : row_end;
-    const uint32_t nseg = (uint32_t)((row_end + seg_rows - 1) / seg_rows);
+    if (cancel && *cancel) row_end = std::min<uint64_t>(count, k);
+    const uint32_t *d_cancel = nullptr;
+    VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
     // row partitions: enough blocks to fill 256 CUs, never more waves than 16-row tiles
-    const uint64_t tiles = (std::min<uint64_t>(seg_rows, row_end) + 15) / 16;
+    const uint64_t tiles = (row_end + 15) / 16;
     // ... and at least ~4 tiles per wave: every block leaves a partial list for the merge kernel (one wave per
     // query), which dominates the latency of a small index when there are thousands of near-empty lists
     uint32_t nrp = (uint32_t)std::min<uint64_t>((tiles + 15) / 16, std::max<uint32_t>((2048 + nqg - 1) / nqg, scan_min_nrp_));
     nrp = std::max<uint32_t>(8, (nrp + 7) & ~7u);
     const uint64_t per_q = (uint64_t)nrp * (e == 1 ? 1 : 4) * k;   // e == 1: one list per block (merged in LDS)
-    VK_TRY(ctx->d_part_d.ensure((size_t)nseg * nq * per_q * 4));
-    VK_TRY(ctx->d_part_l.ensure((size_t)nseg * nq * per_q * 8));
-    uint32_t done = 0;
-    for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
-      if (sgi > 0 && cancel) {
-        VK_HIP_TRY(hipStreamSynchronize(s));
-        if (*cancel) break;
-      }
+    VK_TRY(ctx->d_part_d.ensure((size_t)nq * per_q * 4));
+    VK_TRY(ctx->d_part_l.ensure((size_t)nq * per_q * 8));
+    const uint32_t done = 1;
+    {
       FlatScanArgs a{};
       a.rows = store_.d_rows();
       a.labels = store_.d_labels();
@@ -495,18 +521,18 @@ class FlatIndex final : public Index {
       a.allow_nbits = allow_nbits;
       a.lb_dist = lb_dist_;
       a.lb_label = lb_label_;
-      a.part_dist = ctx->d_part_d.as<float>() + (size_t)sgi * nq * per_q;
-      a.part_label = ctx->d_part_l.as<uint64_t>() + (size_t)sgi * nq * per_q;
+      a.part_dist = ctx->d_part_d.as<float>();
+      a.part_label = ctx->d_part_l.as<uint64_t>();
       a.row_stride_f = a.q_stride_f = store_.stride_f();
       a.chunks = chunks;
-      a.row_begin = (uint32_t)(sgi * seg_rows);
-      a.row_end = (uint32_t)std::min<uint64_t>(row_end, (uint64_t)(sgi + 1) * seg_rows);
+      a.row_begin = 0;
+      a.row_end = (uint32_t)row_end;
       a.nq = (uint32_t)nq;
       a.k = (uint32_t)k;
       a.nrp = nrp;
       a.nqg = nqg;
+      a.cancel = d_cancel;
       VK_HIP_TRY(launch_flat_scan(a, l2(), store_.bf16(), qb, e, s));
-      ++done;
     }
     MergeArgs m{};
     m.in_dist = ctx->d_part_d.as<float>();
@@ -580,7 +606,7 @@ class FlatIndex final : public Index {
   // K4 launch: persistent grid of ~one block per CU, nrp row partitions x nqt query tiles of 32
   Status scan_gemm(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
                    uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
-                   uint64_t out_ld = 0) {
+                   uint64_t out_ld = 0, const uint32_t *d_cancel = nullptr) {
     if (out_ld == 0) out_ld = k;
     // pre-pass (this kernel over the first rows): a valid bound on every query's k-th best distance, so the per-lane
     // lists of K4 start gated instead of accepting everything until they have filled
@@ -623,6 +649,7 @@ class FlatIndex final : public Index {
     g.part_label = ctx->d_part_l.as<uint64_t>();
     g.lockstep = g.nqt > 1 && g.nqt <= 32 ? gemm_lockstep_ : 0;
     g.contig = gemm_contig_;
+    g.cancel = in_prepass_ ? nullptr : d_cancel;
     // [ progress words | per-query bounds ]
     const size_t sync_bytes = (size_t)nrp * 4 * 32 * 4;
     VK_TRY(ctx->d_sync.ensure(sync_bytes + nq * 4));

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   const uint32_t n_rows = a.row_end - a.row_begin;
   const uint32_t n_tiles = (n_rows + kRowsPerWave - 1) / kRowsPerWave;
 
+  uint32_t polled = 0;
   for (uint32_t tile = wave_gid; tile < n_tiles; tile += total_waves) {
+    if (a.cancel && (polled++ % kCancelPollTiles) == 0 && poll_cancel(a.cancel)) break;   // bruteforce.h:129
     const uint32_t row = a.row_begin + tile * kRowsPerWave + rq;
     const bool valid = row < a.row_end;
     const uint32_t lrow = valid ? row : a.row_end - 1;

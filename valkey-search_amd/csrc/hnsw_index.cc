@@ -151,22 +151,24 @@ class HnswIndex final : public Index {
     VK_TRY(ctx->h_out_d.ensure(rq.nq * rq.k * 4));
     VK_TRY(ctx->h_out_l.ensure(rq.nq * rq.k * 8));
     VK_TRY(ctx->h_out_n.ensure(rq.nq * 4 + 64));
+    const uint32_t *d_cancel = nullptr;
+    VK_TRY(ctx->arm_cancel(rq.cancel_flag, &d_cancel));
     if (rq.nq * rq.k <= kZeroCopyEntries) {   // the kernel writes the answer into the pinned host buffers
       VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, rq.allow_nbits, ctx->h_out_d.as<float>(),
-                    ctx->h_out_l.as<uint64_t>(), ctx->h_out_n.as<uint32_t>(), ctx->stream, true));
+                    ctx->h_out_l.as<uint64_t>(), ctx->h_out_n.as<uint32_t>(), ctx->stream, true, false, d_cancel));
     } else {
       VK_TRY(ctx->d_out_d.ensure(rq.nq * rq.k * 4));
       VK_TRY(ctx->d_out_l.ensure(rq.nq * rq.k * 8));
       VK_TRY(ctx->d_out_n.ensure(rq.nq * 4));
       VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, rq.allow_nbits, ctx->d_out_d.as<float>(),
-                    ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream, true));
+                    ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream, true, false, d_cancel));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, ctx->d_out_d.p, rq.nq * rq.k * 4, hipMemcpyDeviceToHost, ctx->stream));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * rq.k * 8, hipMemcpyDeviceToHost, ctx->stream));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     const size_t st_off = (rq.nq * 4 + 7) & ~(size_t)7;
     VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.as<char>() + st_off, ctx->d_stats.p, 40, hipMemcpyDeviceToHost, ctx->stream));
-    VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    VK_TRY(ctx->wait(rq.cancel_flag));   // (a raised flag stops the kernel between hops: hnswalg.h:400-402)
     {
       const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out_n.as<char>() + st_off);
       last_n_eval_ = st[0];
@@ -443,7 +445,7 @@ class HnswIndex final : public Index {
 
   Status launch(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef_runtime, const uint64_t *d_allow,
                 uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
-                bool reset_stats, bool out_ids = false) {
+                bool reset_stats, bool out_ids = false, const uint32_t *d_cancel = nullptr) {
     uint64_t ef = ef_runtime ? ef_runtime : graph_->ef();
     ef = std::max<uint64_t>(ef, k);                       // hnswalg.h:1705,1710
     const int e = hnsw_slots_per_lane(ef);
@@ -488,6 +490,7 @@ class HnswIndex final : public Index {
     a.nbr_cap = (uint32_t)((graph_->maxM0() + 63) & ~(size_t)63);
     a.check_deleted = pub_.deleted ? 1 : 0;
     a.out_ids = out_ids ? 1 : 0;
+    a.cancel = d_cancel;
     if (hnsw_lds_bytes(a) > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     int max_blocks = 0;
     VK_HIP_TRY(hnsw_max_blocks(a, l2(), store_.bf16(), e, &max_blocks));

@@ -229,6 +229,14 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     const uint32_t q = a.redo_in ? a.redo_in[1 + qi] : qi;
     unsigned long long q_eval = 0, q_hops = 0;
     bool abandoned = false;
+    if (poll_cancel(a.cancel)) {   // cancelled before this query started: an empty answer, and on to drain the queue
+      for (uint32_t r = lane; r < a.k; r += kWave) { a.out_dist[(size_t)q * a.k + r] = __builtin_inff(); a.out_label[(size_t)q * a.k + r] = kNoLabel; }
+      if (lane == 0) a.out_n[q] = 0;
+      uint32_t nxt0 = 0;
+      if (lane == 0) nxt0 = atomicAdd(a.queue, 1u);
+      qi = wstride + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt0);
+      continue;
+    }
     // ---- stage the query, clear this wave's visited bitmap --------------------------------
     {
       const float4 *src = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f);
@@ -347,6 +355,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
 
     for (;;) {
       if (c.cnt == 0 || abandoned) break;
+      if (a.cancel && (q_hops % kCancelPollHops) == kCancelPollHops - 1 && poll_cancel(a.cancel)) break;   // :400-402
       // extract-min over the pool
       float bd = __builtin_inff();
       uint32_t bi = kNoneId;

@@ -45,7 +45,13 @@ constexpr uint64_t kZeroCopyEntries = 4096;   // nq * k
 struct SearchCtx {
   hipStream_t stream = nullptr;
   DevBuf d_q, d_part_d, d_part_l, d_out_d, d_out_l, d_out_n, d_allow, d_idx, d_tmp, d_stats, d_sync, d_pool, d_pool2, d_redo;
-  PinBuf h_q, h_out_d, h_out_l, h_out_n, h_tmp, h_idx;
+  PinBuf h_q, h_out_d, h_out_l, h_out_n, h_tmp, h_idx, h_cancel;
+  // In-kernel cancellation: the caller's flag (any host memory) cannot be read by the device, so the thread that
+  // waits for the stream polls it and raises the context's own word in pinned memory, which the kernels poll
+  // (FlatScanArgs::cancel).  arm_cancel: allocate + clear, returns the device-visible word (nullptr when the call
+  // carries no flag); wait: hipStreamSynchronize, or with a flag a poll of stream and flag.
+  Status arm_cancel(const volatile int *caller_flag, const uint32_t **device_word);
+  Status wait(const volatile int *caller_flag);
   // A device-buffer search (vk_index_search_batch_device) returns with its kernels still in flight on the CALLER's
   // stream and gives the context back: `busy` is recorded behind that work, and whoever leases the context next makes
   // its own stream wait for it before touching the scratch (begin_on) -- no host wait, and no two calls ever share

@@ -22,7 +22,13 @@ struct FlatScanArgs {
   uint32_t nq, k;
   uint32_t nrp;               // row partitions (blocks along the rows), multiple of 8
   uint32_t nqg;               // query groups = ceil(nq / kQB); grid = nrp * nqg blocks
+  // optional cancellation word in host-pinned memory (BaseCancellationFunctor, hnswlib.h:153-157; the reference
+  // polls it per row, bruteforce.h:129): polled once per kCancelPollTiles row tiles, non-zero = stop scanning and
+  // hand over what the lists hold
+  const uint32_t *cancel;
 };
+constexpr uint32_t kCancelPollTiles = 16;
+constexpr uint32_t kCancelPollHops = 16;
 
 // K4: batched FLAT (inner-product space) on the matrix cores, fused per-lane top-k
 struct FlatGemmArgs {
@@ -49,6 +55,7 @@ struct FlatGemmArgs {
   uint32_t prepass;           // 1: this launch is the pre-pass (same code, separate kernel name)
   const float *init_bound;    // optional [nq]: a valid upper bound of each query's k-th best distance (pre-pass)
   uint32_t contig;            // 1: a row partition owns a contiguous range of tiles, 0: tiles rp, rp+nrp, ...
+  const uint32_t *cancel;     // optional, as FlatScanArgs::cancel (polled every kCancelPollTiles 128-row tiles)
 };
 size_t flat_gemm_lds_bytes(uint32_t row_stride_f, uint32_t tile_q);
 uint32_t flat_gemm_tile_q(uint32_t row_stride_f);
@@ -111,6 +118,10 @@ struct HnswSearchArgs {
   uint32_t nbr_cap;            // >= maxM0
   uint32_t check_deleted;      // any tombstones in the index
   uint32_t out_ids;            // 1: out_label receives internal ids (device-side graph construction)
+  // optional cancellation word in host-pinned memory: polled at the start of a query and every kCancelPollHops
+  // expanded nodes (the reference polls per popped candidate, hnswalg.h:400-402); a cancelled search keeps what its
+  // result list holds, queries not started yet answer with empty lists
+  const uint32_t *cancel;
 };
 constexpr int kHnswLdsList = 16;      // hnsw_slots_per_lane(): 512 < ef <= kHnswMaxEf, result list in LDS
 constexpr uint64_t kHnswMaxEf = 4096;
