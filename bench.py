@@ -86,86 +86,172 @@ def gen_rows(n_begin, n_rows, dim, device, chunk=65536, latent=32, noise=0.05, s
         yield lo, x[lo - c * chunk: hi - c * chunk].contiguous()
 
 
-def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
-    """HNSW over the first --hnsw-rows rows: device-assisted bulk build (K9), device search, recall vs the
-    exact FLAT answer on the same rows, the CPU oracle searching the SAME graph, and the two hybrid paths
-    of BASELINE.json configs[4] (inline filter at 10 % selectivity, pre-filter below 0.1 %)."""
+GATHER_CEILING_GBS = 6300.0   # profiles/r01_gather_ceiling_10Mx768.log: random 3 KiB rows of a 30 GB table, quad per row
+
+
+def make_queries(A, nq, D, device, seed):
+    """queries from the same rank-32 latent model as the rows, disjoint seed"""
+    qg = torch.Generator(device=device)
+    qg.manual_seed(seed)
+    return torch.nn.functional.normalize(torch.randn(nq, 32, generator=qg, device=device) @ A.T +
+                                         0.05 * torch.randn(nq, A.shape[0], generator=qg, device=device), dim=1).contiguous()
+
+
+def timed(fn, reps):
+    """mean milliseconds of fn() over reps, HIP events on the current (work) stream"""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def recall_of(got, gt, K):
+    return float(np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got, gt)])) / K
+
+
+def exact_ground_truth(flat_ix, hq, K, n_rows, total_rows):
+    """exact top-K of the first n_rows rows from the FLAT index (labels == row numbers), 256 queries per call"""
+    bits = nb = None
+    if n_rows < total_rows:
+        from oracle import oracle as O
+        bits, nb = O.allow_bitmap(np.arange(n_rows, dtype=np.uint64), n_rows), n_rows
+    out = np.empty((hq.shape[0], K), np.uint64)
+    for i in range(0, hq.shape[0], 256):
+        _, L, _ = flat_ix.search_batch(hq[i:i + 256], K, allow=bits, allow_nbits=nb)
+        out[i:i + 256] = L
+    return out
+
+
+def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
+    """BASELINE.json configs[2]: HNSW M=16 efC=200 over the first --hnsw-rows rows (default: all 10M), efSearch=128,
+    k=10: device-assisted bulk build (K9), device search, recall@10 against the exact FLAT answer, the CPU oracle
+    searching the SAME graph on all quota threads (ids compared), the layer-0 work counters and the useful bytes they
+    imply, and the matched-recall point (smallest ef of the sweep with recall@10 >= 0.95).  Shape of the reference's
+    own harness: testing/vector_test.cc:138-197."""
     from oracle import oracle as O
-    Nh, D, K, ef = min(args.hnsw_rows, table.shape[0]), args.dim, args.k, args.hnsw_ef
-    host_rows = np.ascontiguousarray(table[:Nh, :D].cpu().numpy())
+    Nh, D, K, ef = host_rows.shape[0], args.dim, args.k, args.hnsw_ef
+    t_leg = time.perf_counter()
     t0 = time.perf_counter()
     h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=ef)
     h.add_batch(host_rows)
     h.flush()
     build_s = time.perf_counter() - t0
     nq = args.hnsw_queries
-    qg = torch.Generator(device=device)
-    qg.manual_seed(9090)
-    Qh = torch.nn.functional.normalize(torch.randn(nq, 32, generator=qg, device=device) @ A.T +
-                                       0.05 * torch.randn(nq, D, generator=qg, device=device), dim=1).contiguous()
+    Qh = make_queries(A, nq, D, device, 9090)
     hq = Qh.cpu().numpy()
-    # exact ground truth from the FLAT index restricted to the same rows (labels < Nh)
-    bits = O.allow_bitmap(np.arange(Nh, dtype=np.uint64), Nh)
-    _, gt, _ = flat_ix.search_batch(hq, K, allow=bits, allow_nbits=Nh)
+    gt = exact_ground_truth(flat_ix, hq, K, Nh, total_rows)
     od = torch.empty(nq, K, device=device, dtype=torch.float32)
     ol = torch.empty(nq, K, device=device, dtype=torch.int64)
     on = torch.empty(nq, device=device, dtype=torch.int32)
 
-    def run():
-        h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef, stream=stream_ptr())
+    def point(ef_s, reps=5):
+        ms = timed(lambda: h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef_s,
+                                                 stream=stream_ptr()), reps)
+        gl = ol.cpu().numpy().view(np.uint64).copy()
+        _D, _L, _N = h.search_batch(hq[:1024], K, ef=ef_s)        # host path once: fills the work counters
+        st = h.stats()
+        useful = (st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132) / 1024.0 * nq
+        gbs = useful / (ms * 1e-3) / 1e9
+        return gl, {"ef": ef_s, "gpu_qps": round(nq / (ms * 1e-3), 1), "ms_per_batch": round(ms, 3),
+                    "recall_at_10": round(recall_of(gl, gt, K), 4),
+                    "n_eval_per_query": round(st.last_n_eval / 1024.0, 1), "n_hops_per_query": round(st.last_n_hops / 1024.0, 1),
+                    "useful_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                    "frac_of_gather_ceiling": round(gbs / GATHER_CEILING_GBS, 4)}
 
-    run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    gl = ol.cpu().numpy().view(np.uint64)
-    recall = float(np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gl, gt)])) / K
-    _D, _L, _N = h.search_batch(hq[:1024], K, ef=ef)        # host path once: fills the work counters
-    st = h.stats()
-    useful = (st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132) / 1024.0 * nq
-    # CPU: the oracle searches the very same graph (SaveIndex chunk stream), one query per thread
+    gl, head = point(ef)
+    # matched recall: the smallest ef of the sweep whose recall@10 reaches 0.95 (SURVEY.md 8e asks for both points)
+    sweep, matched = [head], None
+    for ef_s in (192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096):
+        if ef_s <= ef:
+            continue
+        _, pt = point(ef_s, reps=2)
+        sweep.append(pt)
+        if pt["recall_at_10"] >= 0.95:
+            matched = pt
+            break
+    # one query at a time (latency kernel)
     t1 = time.perf_counter()
-    o = O.HNSW.from_saved_chunks(h.save(), D, "COSINE", 16, ef_construction=200)
+    for i in range(64):
+        h.search(hq[i], K, ef=ef)
+    lat_ms = (time.perf_counter() - t1) / 64 * 1e3
+    # CPU: the oracle searches the very same graph (SaveIndex chunk stream straight into its C loader), one query per
+    # thread on every quota thread, each thread with its own visited list like hnswlib's pool
+    t1 = time.perf_counter()
+    o = O.HNSW.from_product_index(h.save_raw, D, "COSINE", 16, ef_construction=200)
     export_s = time.perf_counter() - t1
     threads = effective_cpus()
-    ncq = min(nq, threads * 64)
+    views = [o] + [o.view() for _ in range(threads - 1)]
+    ncq = min(nq, threads * args.hnsw_cpu_queries_per_thread)
     o.search(hq[0], K, ef=ef)
+
+    def cpu_chunk(t):
+        return [(i, views[t].search(hq[i], K, ef=ef)) for i in range(t, ncq, threads)]
+
     t1 = time.perf_counter()
-    # the oracle's visited list is per index object: searches are serialised per object, so give each
-    # thread its own view of the graph?  No -- hnswlib hands out one visited list per concurrent search;
-    # the oracle is single-threaded by design, so time it on one thread and report that honestly.
-    cpu_res = [o.search(hq[i], K, ef=ef) for i in range(min(ncq, 512))]
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(cpu_chunk, range(threads)))
     cdt = time.perf_counter() - t1
-    n_cpu = len(cpu_res)
-    cpu_recall = float(np.mean([len(set(r[1].tolist()) & set(gt[i].tolist())) for i, r in enumerate(cpu_res)])) / K
-    same = sum(int(cpu_res[i][1].tolist() == gl[i][:len(cpu_res[i][1])].tolist()) for i in range(n_cpu))
-    # ---- hybrid: TAG-like filters as allow-bitmaps over labels (planner.cc:21-45 picks the path) ----
-    tag_bits = O.allow_bitmap(np.arange(3, Nh, 10, dtype=np.uint64), Nh)           # 10 % of the rows: inline
+    cpu_res = dict(kv for p in parts for kv in p)
+    cpu_recall = recall_of([cpu_res[i][1] for i in range(ncq)], gt[:ncq], K)
+    same = sum(int(cpu_res[i][1].tolist() == gl[i][:len(cpu_res[i][1])].tolist()) for i in range(ncq))
+    del views
+    return {"workload": f"HNSW {Nh}x{D} fp32 COSINE M=16 efC=200 efSearch={ef} k={K} (BASELINE.json configs[2])",
+            "rows": Nh, "M": 16, "ef_construction": 200, "k": K, "queries_per_batch": nq,
+            "build_s": round(build_s, 2), "build_inserts_per_s": round(Nh / build_s, 1), "build": "device-assisted (K9)",
+            **head, "single_query_ms": round(lat_ms, 3),
+            "roofline": {"bound": "hbm", "achieved": head["useful_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": head["frac_of_hbm_peak"], "kernel": "hnsw_search_kernel",
+                         "bytes": "n_eval*(D*4+4) + n_hops*132 per query, counted by the kernel",
+                         "gather_ceiling_gbs": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r01_gather_ceiling_10Mx768.log"},
+            "matched_recall_0.95": matched, "ef_sweep": sweep,
+            "cpu": {"kind": "port", "threads": threads, "qps": round(ncq / cdt, 1), "qps_per_thread": round(ncq / cdt / threads, 1),
+                    "queries": ncq, "ef": ef, "recall_at_10": round(cpu_recall, 4), "same_graph": True,
+                    "ids_identical_to_gpu": f"{same}/{ncq}", "graph_export_s": round(export_s, 2)},
+            "leg_s": round(time.perf_counter() - t_leg, 1)}
+
+
+def hybrid_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
+    """One shard of BASELINE.json configs[4]: HNSW over 1.25M rows + a TAG-like filter as an allow-bitmap over labels
+    (planner.cc:21-45 picks the path): inline filter at 10 % selectivity with efSearch=256, and the pre-filter branch
+    below 0.1 %.  Recall against the exact filtered FLAT answer; the oracle answers a sample on the same graph."""
+    from oracle import oracle as O
+    Nh, D, K, ef_h = host_rows.shape[0], args.dim, args.k, 256
+    t_leg = time.perf_counter()
+    t0 = time.perf_counter()
+    h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=ef_h)
+    h.add_batch(host_rows)
+    h.flush()
+    build_s = time.perf_counter() - t0
+    nq = args.hybrid_queries
+    Qh = make_queries(A, nq, D, device, 7070)
+    hq = Qh.cpu().numpy()
+    tag_bits = O.allow_bitmap(np.arange(3, Nh, 10, dtype=np.uint64), Nh)           # "tag t3": 10 % of the rows
     d_bits = torch.from_numpy(tag_bits.view(np.int64)).to(device)
-    _, gt_f, _ = flat_ix.search_batch(hq[:1024], K, allow=tag_bits, allow_nbits=Nh)
-
-    ef_h = 256   # BASELINE.json configs[4]: efSearch = 256 for the hybrid queries
-
-    def run_f():
-        h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef_h,
-                              d_allow=d_bits.data_ptr(), allow_nbits=Nh, stream=stream_ptr())
-
-    run_f()
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        run_f()
-    e1.record()
-    torch.cuda.synchronize()
-    ms_f = e0.elapsed_time(e1) / reps
-    glf = ol.cpu().numpy().view(np.uint64)[:1024]
-    recall_f = float(np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(glf, gt_f)])) / K
+    gt_f = np.empty((nq, K), np.uint64)
+    for i in range(0, nq, 256):
+        _, L, _ = flat_ix.search_batch(hq[i:i + 256], K, allow=tag_bits, allow_nbits=Nh)
+        gt_f[i:i + 256] = L
+    od = torch.empty(nq, K, device=device, dtype=torch.float32)
+    ol = torch.empty(nq, K, device=device, dtype=torch.int64)
+    on = torch.empty(nq, device=device, dtype=torch.int32)
+    ms_f = timed(lambda: h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef_h,
+                                               d_allow=d_bits.data_ptr(), allow_nbits=Nh, stream=stream_ptr()), 3)
+    glf = ol.cpu().numpy().view(np.uint64).copy()
+    recall_f = recall_of(glf, gt_f, K)
+    Dh, Lh, Nn = h.search_batch(hq[:512], K, ef=ef_h, allow=tag_bits, allow_nbits=Nh)
+    st = h.stats()
+    # the oracle on the same graph, same filter: ids, distance bits (a sample)
+    o = O.HNSW.from_product_index(h.save_raw, D, "COSINE", 16, ef_construction=200)
+    ns = min(64, nq)
+    same = 0
+    for i in range(ns):
+        e_d, e_l = o.search(hq[i], K, ef=ef_h, allow=tag_bits, allow_nbits=Nh)
+        same += int(Lh[i, :Nn[i]].tolist() == e_l.tolist() and Dh[i, :Nn[i]].view(np.uint32).tolist() == e_d.view(np.uint32).tolist())
     # pre-filter (<= 0.001 * N keys): exact kNN over the key list, one call per query like CalcBestMatchingPrefilteredKeys
     keys = np.sort(np.random.default_rng(77).choice(Nh, max(1, Nh // 2000), replace=False)).astype(np.uint64)
     key_bits = O.allow_bitmap(keys, Nh)
@@ -174,17 +260,64 @@ def hnsw_leg(args, flat_ix, table, A, device, stream_ptr):
     pre_dt = time.perf_counter() - t1
     _, gt_p, ngt = flat_ix.search_batch(hq[:256], K, allow=key_bits, allow_nbits=Nh)
     pre_ok = all(set(pre[i][1].tolist()) == set(gt_p[i, :ngt[i]].tolist()) for i in range(256))
-    hybrid = {"inline_filter": {"selectivity": 0.1, "ef": ef_h, "gpu_qps": round(nq / (ms_f * 1e-3), 1), "recall_at_10": round(recall_f, 4)},
-              "pre_filter": {"keys": int(len(keys)), "selectivity": round(len(keys) / Nh, 5),
-                             "qps_single_caller": round(256 / pre_dt, 1), "exact": bool(pre_ok)}}
-    return {"rows": Nh, "M": 16, "ef_construction": 200, "ef": ef, "k": K, "queries_per_batch": nq, "hybrid": hybrid,
-            "build_s": round(build_s, 2), "build_inserts_per_s": round(Nh / build_s, 1), "build": "device-assisted (K9)", "host_threads": threads,
-            "gpu_qps": round(nq / (ms * 1e-3), 1), "ms_per_batch": round(ms, 3), "recall_at_10": round(recall, 4),
-            "n_eval_per_query": round(st.last_n_eval / 1024.0, 1), "n_hops_per_query": round(st.last_n_hops / 1024.0, 1),
-            "useful_gbs": round(useful / (ms * 1e-3) / 1e9, 1),
-            "cpu": {"kind": "port", "threads": 1, "qps_per_thread": round(n_cpu / cdt, 1), "queries": n_cpu,
-                    "recall_at_10": round(cpu_recall, 4), "same_graph": True,
-                    "ids_identical_to_gpu": f"{same}/{n_cpu}", "graph_export_s": round(export_s, 2)}}
+    return {"workload": f"one shard of BASELINE.json configs[4]: HNSW {Nh}x{D} fp32 COSINE M=16 efC=200 + TAG filter, efSearch={ef_h}, k={K}",
+            "rows": Nh, "build_s": round(build_s, 2), "queries_per_batch": nq,
+            "inline_filter": {"selectivity": 0.1, "ef": ef_h, "gpu_qps": round(nq / (ms_f * 1e-3), 1), "ms_per_batch": round(ms_f, 3),
+                              "recall_at_10": round(recall_f, 4),
+                              "n_eval_per_query": round(st.last_n_eval / 512.0, 1), "n_hops_per_query": round(st.last_n_hops / 512.0, 1),
+                              "frontier_redo_queries": int(st.last_frontier_redo), "frontier_dropped": int(st.last_frontier_dropped),
+                              "oracle_same_graph_bit_identical": f"{same}/{ns}"},
+            "pre_filter": {"keys": int(len(keys)), "selectivity": round(len(keys) / Nh, 5),
+                           "qps_single_caller": round(256 / pre_dt, 1), "exact": bool(pre_ok)},
+            "leg_s": round(time.perf_counter() - t_leg, 1)}
+
+
+def bf16_ip_leg(args, A, device, stream_ptr, local_rank):
+    """One shard of BASELINE.json configs[3]: FLAT 10Mx768, bf16 row storage, IP metric (rows L2-normalised by the
+    generator, so IP == cosine here -- stated, not assumed by the kernel), k=10, batch=256.  Parity: the answer
+    restricted by a filter to the first rows must equal the oracle's IP answer over the RNE-rounded rows, bit for bit."""
+    from oracle import oracle as O
+    N, D, B, K = args.bf16_rows, args.dim, args.batch, args.k
+    t_leg = time.perf_counter()
+    ix = vsa.Index("FLAT", D, "IP", initial_cap=N, device_id=local_rank, dtype="bf16")
+    base_ptr, stride = ix.device_rows(N)
+    table = device_view_typed(base_ptr, (N, stride // 2), device, "<i2").view(torch.bfloat16)
+    if stride != D * 2:
+        table[:, D:] = 0
+    for lo, x in gen_rows(0, N, D, device):
+        table[lo: lo + x.shape[0], :D] = x        # round to nearest even, as the library's ingest does
+    torch.cuda.synchronize()
+    ix.commit_device_rows(N, np.arange(N, dtype=np.uint64))
+    Q = make_queries(A, B, D, device, 4242)
+    od = torch.empty(B, K, device=device, dtype=torch.float32)
+    ol = torch.empty(B, K, device=device, dtype=torch.int64)
+    on = torch.empty(B, device=device, dtype=torch.int32)
+    ms = timed(lambda: ix.search_batch_device(Q.data_ptr(), B, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), stream=stream_ptr()),
+               args.steps)
+    ms1 = timed(lambda: ix.search_batch_device(Q.data_ptr(), 1, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), stream=stream_ptr()), 5)
+    S = min(100_000, N)
+    host = np.ascontiguousarray(table[:S, :D].float().cpu().numpy())
+    o = O.Flat(D, "IP", isa="skylake", max_elements=S)
+    o.add_many(host, np.arange(S, dtype=np.uint64), borrowed=True)
+    bits = O.allow_bitmap(np.arange(S, dtype=np.uint64), S)
+    hq = Q.cpu().numpy()
+    ok = True
+    bd, bl, bn = ix.search_batch(hq[:32], K, allow=bits, allow_nbits=S)
+    for i in range(32):
+        e_d, e_l = o.search(hq[i], K)
+        ok = ok and bl[i, :bn[i]].tolist() == e_l.tolist() and bd[i, :bn[i]].view(np.uint32).tolist() == e_d.view(np.uint32).tolist()
+    for i in range(2):
+        gd, gl = ix.search(hq[i], K, allow=bits, allow_nbits=S)
+        e_d, e_l = o.search(hq[i], K)
+        ok = ok and gl.tolist() == e_l.tolist() and gd.view(np.uint32).tolist() == e_d.view(np.uint32).tolist()
+    scan_bytes = N * stride
+    return {"workload": f"one shard of BASELINE.json configs[3]: FLAT {N}x{D} bf16 rows, IP, k={K}, batch={B}",
+            "rows": N, "gpu_qps": round(B / (ms * 1e-3), 1), "ms_per_step": round(ms, 3),
+            "hbm_gbs_algorithmic": round(scan_bytes / (ms * 1e-3) / 1e9, 1),
+            "tflops": round(2.0 * N * D * B / (ms * 1e-3) / 1e12, 2),
+            "single_query": {"ms": round(ms1, 4), "hbm_gbs": round(scan_bytes / (ms1 * 1e-3) / 1e9, 1),
+                             "hbm_frac": round(scan_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "parity_vs_oracle": "bit-exact" if ok else "MISMATCH", "leg_s": round(time.perf_counter() - t_leg, 1)}
 
 
 def hnsw_sharded_leg(args, flat_ix, table, A, device, stream_ptr, world, rank, r0, dist, gather, local_rank):
@@ -299,18 +432,34 @@ def _baseline_metric():
 BASELINE_METRIC = _baseline_metric()
 
 
-def pmc_traffic(N, D, B, world):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE
-    is a separate run by rule, so bench.py cannot collect it live): profiles/r01_pmc_fetch_size_k4.json,
-    valid for the default single-GPU workload only."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_fetch_size_k4.json")
-    if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not os.path.exists(path) or "bf16" in sys.argv:
+def source_sha256():
+    """Hash of the kernel and library sources (csrc/*.hip, *.hpp, *.cc): the build id a PMC traffic file is stamped with."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = ROOT / "valkey-search_amd" / "csrc"
+    for f in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.hpp")) + list(csrc.glob("*.cc"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()
+
+
+def pmc_traffic(N, D, B, world, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc is a separate run by
+    rule, so bench.py cannot collect it live): profiles/r02_pmc_fetch_size.json, written by scripts/pmc_traffic.sh and
+    stamped with the hash of the sources it measured.  Printed only for the default single-GPU workload AND only while
+    that hash equals the current sources' -- a stale file yields null, never an old number."""
+    path = ROOT / "profiles" / "r02_pmc_fetch_size.json"
+    if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not path.exists() or "bf16" in sys.argv:
         return None, None
-    if os.environ.get("VK_FLAT_FORCE_SCAN") or os.environ.get("VK_GEMM_MODE") or os.environ.get("VK_GEMM_ABLATE"):
+    if any(os.environ.get(v) for v in ("VK_FLAT_FORCE_SCAN", "VK_GEMM_MODE", "VK_GEMM_ABLATE", "VK_GEMM_LOCKSTEP")):
         return None, None
     j = json.load(open(path))
-    key = "lockstep_off" if os.environ.get("VK_GEMM_LOCKSTEP") == "0" else "lockstep_on"
-    return round(j[key]["hbm_bytes_per_launch"]), "profiles/r01_pmc_fetch_size_k4.json (rocprofv3 --pmc FETCH_SIZE, separate pass)"
+    if j.get("src_sha256") != source_sha256():
+        return None, "profiles/r02_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
+    for name, v in j.get("kernels", {}).items():
+        if kernel_prefix in name and "prepass" not in name:
+            return round(v["hbm_bytes_per_launch"]), "profiles/r02_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
+    return None, None
 
 
 def main():
@@ -324,14 +473,22 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="row storage (bf16 = BASELINE.json configs[3] storage; queries and arithmetic stay f32)")
-    ap.add_argument("--cpu-rows", type=int, default=200_000, help="rows of the CPU-baseline sample")
-    ap.add_argument("--cpu-queries-per-thread", type=int, default=24,
-                    help="CPU-baseline sample: queries per host thread (24 x 16 threads x a 200k-row scan is about 13 s of CPU work, under 1 s of wall time)")
+    ap.add_argument("--cpu-rows", type=int, default=0,
+                    help="rows the CPU baseline scans per query (0 = the whole index: a full-size pass, no scaling)")
+    ap.add_argument("--cpu-queries-per-thread", type=int, default=1,
+                    help="CPU baseline: queries per host thread (1 x 16 threads x a 10M-row scan is about 30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-query-steps", type=int, default=5, help="extra: B=1 scan timing (HBM roofline)")
-    ap.add_argument("--hnsw-rows", type=int, default=200_000, help="extra: HNSW leg over the first rows (0 = skip)")
+    ap.add_argument("--hnsw-rows", type=int, default=-1,
+                    help="HNSW leg (BASELINE.json configs[2]) over the first rows: -1 = all of --rows (10M), 0 = skip")
     ap.add_argument("--hnsw-ef", type=int, default=128)
-    ap.add_argument("--hnsw-queries", type=int, default=4096)
+    ap.add_argument("--hnsw-queries", type=int, default=8192)
+    ap.add_argument("--hnsw-cpu-queries-per-thread", type=int, default=32)
+    ap.add_argument("--hybrid-rows", type=int, default=1_250_000,
+                    help="one shard of BASELINE.json configs[4] (HNSW + TAG filter, efSearch=256): rows (0 = skip)")
+    ap.add_argument("--hybrid-queries", type=int, default=4096)
+    ap.add_argument("--bf16-rows", type=int, default=-1,
+                    help="one shard of BASELINE.json configs[3] (FLAT bf16 IP): rows, -1 = as --rows, 0 = skip")
     ap.add_argument("--hnsw-sharded", action="store_true",
                     help="N > 1: also run the sharded HNSW leg (one graph per rank; extra collectives after the timed region)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -356,6 +513,10 @@ def main():
             dist.init_process_group(args.backend)
 
     N, D, B, K = args.rows, args.dim, args.batch, args.k
+    if args.hnsw_rows < 0:
+        args.hnsw_rows = N
+    if args.bf16_rows < 0:
+        args.bf16_rows = N
     r0 = rank * N // world
     r1 = (rank + 1) * N // world
     n_local = r1 - r0
@@ -470,49 +631,80 @@ def main():
     # ---- CPU baseline + parity spot check on rank 0 (oracle = checker, never the product) ----
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only (bench contract)
+    host_rows = None
+    extras = rank == 0 and world == 1
+    need_host = extras and (not args.no_cpu_baseline or (args.hnsw_rows > 0 and not bf16) or (args.hybrid_rows > 0 and not bf16))
+    if need_host:
+        # one host copy of the rows serves the CPU baseline (borrowed, not copied again) and the HNSW builds
+        n_host = n_local
+        if args.no_cpu_baseline:
+            n_host = min(n_local, max(args.hnsw_rows, args.hybrid_rows))
+        host_rows = np.ascontiguousarray(table[:n_host, :D].float().cpu().numpy())   # bf16: the widened stored values
+    if extras and not args.no_cpu_baseline:
         from oracle import oracle as O
-        S = min(args.cpu_rows, n_local)
-        host_rows = np.ascontiguousarray(table[:S, :D].float().cpu().numpy())   # bf16: the widened stored values
+        S = n_local if args.cpu_rows <= 0 else min(args.cpu_rows, n_local)
         flat = O.Flat(D, "COSINE", isa="skylake", max_elements=S)
-        flat.add_many(host_rows, np.arange(r0, r0 + S, dtype=np.uint64), borrowed=True)
+        flat.add_many(host_rows[:S], np.arange(r0, r0 + S, dtype=np.uint64), borrowed=True)
         hq = Q.cpu().numpy()
         threads = effective_cpus()
         nqt = threads * args.cpu_queries_per_thread
-        flat.search(hq[0], K)  # warm
+        if S <= 1_000_000:
+            flat.search(hq[0], K)   # (warm-up only where it is cheap)
         t1 = time.perf_counter()
         with ThreadPoolExecutor(threads) as ex:
             res = list(ex.map(lambda i: flat.search(hq[i % B], K), range(nqt)))
         cdt = time.perf_counter() - t1
         qps_sample = nqt / cdt
+        full = S == N
         cpu = {"value": round(qps_sample * S / N, 4), "unit": "queries/s", "cores": threads, "kind": "port",
-               "sample": f"oracle FLAT scan ({O.cpu_path()} clone of the SimSIMD skylake order), {nqt} queries over "
-                         f"the first {S} rows on {threads} threads ({qps_sample:.1f} q/s on the sample), scaled "
-                         f"linearly to {N} rows"}
-        # parity at full index size: the GPU answer restricted by a filter to the sampled rows must equal
-        # the oracle's answer on those rows, ids and distance bits
-        bits = O.allow_bitmap(np.arange(r0, r0 + S, dtype=np.uint64), r0 + S)
+               "seconds": round(cdt, 2), "host_gbs": round(nqt * S * D * 4 / cdt / 1e9, 1),
+               "sample": (f"oracle FLAT scan ({O.cpu_path()} clone of the SimSIMD skylake order), {nqt} queries, each a full pass "
+                          f"over all {S} rows, one query per thread on {threads} threads (the container's CPU quota)" if full else
+                          f"oracle FLAT scan ({O.cpu_path()} clone of the SimSIMD skylake order), {nqt} queries over "
+                          f"the first {S} rows on {threads} threads ({qps_sample:.1f} q/s on the sample), scaled "
+                          f"linearly to {N} rows")}
+        # parity at full index size: the GPU answer must equal the oracle's, ids and distance bits -- through the
+        # single-query scan and through the timed batched (matrix-core) path
+        bits = None if full else O.allow_bitmap(np.arange(r0, r0 + S, dtype=np.uint64), r0 + S)
+        nbits = None if full else r0 + S
         ok = True
-        for i in range(4):
-            gd, gl = ix.search(hq[i], K, allow=bits, allow_nbits=r0 + S)
-            od, ol = res[i] if i < len(res) else flat.search(hq[i], K)
+        for i in range(min(4, len(res))):
+            gd, gl = ix.search(hq[i], K, allow=bits, allow_nbits=nbits)
+            od, ol = res[i]
             ok = ok and gl.tolist() == ol.tolist() and gd.view(np.uint32).tolist() == od.view(np.uint32).tolist()
-        # ... and the same through the timed path (batched: K4 on the matrix cores)
-        nb = min(B, 32)
-        bd, bl, bn = ix.search_batch(hq[:nb], K, allow=bits, allow_nbits=r0 + S)
+        nb = min(B, len(res), 32)
+        bd, bl, bn = ix.search_batch(hq[:max(nb, 5)], K, allow=bits, allow_nbits=nbits)
         for i in range(nb):
-            od, ol = res[i] if i < len(res) else flat.search(hq[i], K)
+            od, ol = res[i]
             ok = ok and bl[i, :bn[i]].tolist() == ol.tolist() and bd[i, :bn[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+        if full:   # ... and the timed step's own output, already on the host
+            for i in range(min(B, len(res))):
+                od, ol = res[i]
+                ok = ok and result_l[i].tolist() == ol.tolist() and result_d[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
         parity = "bit-exact" if ok else "MISMATCH"
+        del flat
 
-    # ---- extra: HNSW (BASELINE.json configs[2] shape: M=16 efC=200, cosine, ef=128, k=10) on rank 0 ----
-    hnsw = None
     # (the extra legs must never cost the headline line: a failure in one of them is reported in its place)
-    if rank == 0 and world == 1 and args.hnsw_rows > 0 and not bf16:
+    def leg(fn, *a):
         try:
-            hnsw = hnsw_leg(args, ix, table, A, device, stream_ptr)
+            return fn(*a)
         except Exception as e:   # noqa: BLE001
-            hnsw = {"error": f"{type(e).__name__}: {e}"}
+            import traceback
+            return {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().strip().splitlines()[-3:]}
+
+    # ---- BASELINE.json configs[2]: HNSW M=16 efC=200, efSearch=128, k=10 over the same rows ----
+    hnsw = None
+    if extras and args.hnsw_rows > 0 and not bf16:
+        hnsw = leg(hnsw_leg, args, ix, host_rows[:min(args.hnsw_rows, n_local)], A, device, stream_ptr, n_local)
+    # ---- one shard of configs[4]: HNSW + TAG filter ----
+    hybrid = None
+    if extras and args.hybrid_rows > 0 and not bf16:
+        hybrid = leg(hybrid_leg, args, ix, host_rows[:min(args.hybrid_rows, n_local)], A, device, stream_ptr, n_local)
+    host_rows = None
+    # ---- one shard of configs[3]: FLAT bf16 IP ----
+    bf16_shard = None
+    if extras and args.bf16_rows > 0 and not bf16:
+        bf16_shard = leg(bf16_ip_leg, args, A, device, stream_ptr, local_rank)
     if world > 1 and args.hnsw_sharded and args.hnsw_rows > 0 and not bf16:
         def gather(dst, src):
             if args.backend == "nccl":
@@ -535,7 +727,7 @@ def main():
             coalescer = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        traffic, traffic_src = pmc_traffic(N, D, B, world)
+        traffic, traffic_src = pmc_traffic(N, D, B, world, "flat_gemm_kernel" if B >= 5 else "flat_scan_kernel")
         qps = B * args.steps / dt
         scan_bytes = n_local * stride                       # algorithmic bytes of one pass over the shard
         flops = 2.0 * n_local * D * B                       # per step per GPU
@@ -570,6 +762,8 @@ def main():
             "single_query_scan": single,
             "coalescer": coalescer,
             "hnsw": hnsw,
+            "config4_shard_hybrid": hybrid,
+            "config3_shard_bf16_ip": bf16_shard,
             "build_s": round(t_build, 2),
         }
         print(json.dumps(out))

@@ -86,6 +86,14 @@ static int flat_add(vko_flat *f, const float *row, uint64_t label, int copy) {
 }
 int vko_flat_add(vko_flat *f, const float *row, uint64_t label) { return flat_add(f, row, label, 1); }
 int vko_flat_add_borrowed(vko_flat *f, const float *row, uint64_t label) { return flat_add(f, row, label, 0); }
+/* n rows, `stride_bytes` apart, labels NULL = 0..n-1: addPoint in a loop (full-size baselines register 10M rows) */
+int vko_flat_add_many(vko_flat *f, const float *rows, size_t stride_bytes, const uint64_t *labels, size_t n, int borrowed) {
+    for (size_t i = 0; i < n; ++i) {
+        int rc = flat_add(f, (const float *)((const char *)rows + i * stride_bytes), labels ? labels[i] : (uint64_t)i, !borrowed);
+        if (rc) return rc;
+    }
+    return 0;
+}
 
 void vko_flat_remove(vko_flat *f, uint64_t label) { /* bruteforce.h:92-113 */
     uint32_t cur;

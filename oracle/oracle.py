@@ -54,6 +54,8 @@ def _load():
     for n in ("vko_flat_add", "vko_flat_add_borrowed"):
         getattr(lib, n).restype = C.c_int
         getattr(lib, n).argtypes = [C.c_void_p, _f32p, C.c_uint64]
+    lib.vko_flat_add_many.restype = C.c_int
+    lib.vko_flat_add_many.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
     lib.vko_flat_remove.argtypes = [C.c_void_p, C.c_uint64]
     lib.vko_flat_resize.argtypes = [C.c_void_p, C.c_size_t]
     lib.vko_flat_count.restype = C.c_size_t
@@ -188,14 +190,11 @@ class Flat:
         rows = f32(rows)
         if borrowed:
             self._keep.append(rows)
-        fn = LIB.vko_flat_add_borrowed if borrowed else LIB.vko_flat_add
-        base = rows.ctypes.data
-        stride = rows.strides[0]
-        for i in range(rows.shape[0]):
-            lab = int(labels[i]) if labels is not None else i
-            rc = fn(self._h, C.cast(base + i * stride, _f32p), lab)
-            if rc:
-                raise RuntimeError(last_error())
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint64)
+        rc = LIB.vko_flat_add_many(self._h, rows.ctypes.data, rows.strides[0], None if lab is None else lab.ctypes.data,
+                                   rows.shape[0], int(borrowed))
+        if rc:
+            raise RuntimeError(last_error())
 
     def remove(self, label):
         LIB.vko_flat_remove(self._h, int(label))

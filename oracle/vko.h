@@ -55,6 +55,7 @@ int vko_flat_add(vko_flat *f, const float *row, uint64_t label);
 /* like vko_flat_add, but the index keeps the caller's pointer (as the
  * reference does, bruteforce.h:81) instead of copying -- for big baselines */
 int vko_flat_add_borrowed(vko_flat *f, const float *row, uint64_t label);
+int vko_flat_add_many(vko_flat *f, const float *rows, size_t stride_bytes, const uint64_t *labels, size_t n, int borrowed);
 void vko_flat_remove(vko_flat *f, uint64_t label);
 void vko_flat_resize(vko_flat *f, size_t new_max);
 size_t vko_flat_count(const vko_flat *f);
