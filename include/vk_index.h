@@ -62,6 +62,8 @@ typedef enum { VK_METRIC_L2 = 0, VK_METRIC_IP = 1, VK_METRIC_COSINE = 2 } vk_met
  * index answers exactly like an f32 index holding the rounded rows.  get_row / save return f32. */
 typedef enum { VK_DTYPE_F32 = 0, VK_DTYPE_BF16 = 1 } vk_dtype;
 
+#define VK_MAX_SHARDS 16
+
 typedef struct vk_index_params {
   uint32_t struct_size;       /* = sizeof(vk_index_params) */
   uint32_t algo;              /* vk_algo */
@@ -77,6 +79,14 @@ typedef struct vk_index_params {
   uint64_t random_seed;       /* hnswlib ctor random_seed, reference default 100 */
   int32_t device_id;          /* HIP device ordinal, -1 = current device */
   uint32_t build_threads;     /* HNSW: host threads used by vk_index_add_batch, 0 = hardware */
+  /* Multi-GPU (one node, one process): n_shards >= 1 makes ONE index of n_shards sub-indexes, shard s on HIP device
+   * shard_devices[s] (-1 = current device; a device may be named more than once: "logical shards").  Rows are dealt
+   * to the shards in contiguous runs, every search fans out to all shards and the per-shard top-k lists are merged by
+   * (distance,label) on the first shard's device -- the role of the cluster fan-out and
+   * SearchPartitionResultsTracker::AddResult (src/query/fanout.cc:162-175) inside one index; HNSW = one graph per
+   * shard, like one per cluster shard.  0 = a plain single-device index on device_id. */
+  uint32_t n_shards;
+  int32_t shard_devices[VK_MAX_SHARDS];
 } vk_index_params;
 
 typedef struct vk_index_stats {
@@ -158,7 +168,8 @@ int vk_index_search_batch(vk_index *ix, const void *queries, uint64_t nq, uint64
                           float *out_dist, uint64_t *out_label, uint64_t *out_n);
 /* Same, but queries and outputs are DEVICE pointers and the work is enqueued on
  * `hip_stream` (a hipStream_t, NULL = the index's own stream) without a host sync:
- * the shard leg of the multi-GPU path, whose outputs feed an RCCL all-gather.
+ * what a sharded index calls on each of its shards (on a sharded index itself the pointers are
+ * on the first shard's device and the call covers broadcast, shard searches, gather and merge).
  * Entries past the count are filled with (+inf, UINT64_MAX); a shard with fewer than k rows (or none)
  * answers with what it has.  Concurrent calls are safe (each takes its own scratch context; a context's
  * next user is ordered behind the work still in flight).  The caller must synchronise the stream before
@@ -195,6 +206,11 @@ int vk_index_get_stats(vk_index *ix, vk_index_stats *out);
  * (NULL = 0..n-1).  FLAT only. */
 int vk_index_device_rows(vk_index *ix, uint64_t n_rows, void **d_rows, uint64_t *row_stride_bytes);
 int vk_index_commit_device_rows(vk_index *ix, uint64_t n_rows, const uint64_t *labels);
+/* the same for ONE shard of a sharded index (rows on that shard's device; labels are required and must be unique
+ * across the shards); vk_index_shard_count is 0 for a plain index */
+int vk_index_shard_count(vk_index *ix, uint32_t *out_n);
+int vk_index_shard_device_rows(vk_index *ix, uint32_t shard, uint64_t n_rows, void **d_rows, uint64_t *row_stride_bytes);
+int vk_index_shard_commit_device_rows(vk_index *ix, uint32_t shard, uint64_t n_rows, const uint64_t *labels);
 
 /* ---- shard merge (multi-GPU) ---------------------------------------------------------------
  * k smallest by (distance,label) out of `parts` per-shard lists: the role of

@@ -40,7 +40,7 @@ struct FakeIndex final : vk::Index {
   vk::Status set_ef(uint32_t) override { return vk::Status::Ok(); }
   vk::Status flush() override { return vk::Status::Ok(); }
   vk::Status search_device(const vk::SearchRequest &, float *, uint64_t *, uint32_t *, hipStream_t) override { return vk::Status::Ok(); }
-  vk::Status search_labels(const float *, uint64_t, const uint64_t *, uint64_t, float *, uint64_t *, uint64_t *) override { return vk::Status::Ok(); }
+  vk::Status label_distances(const float *, const uint64_t *, uint64_t, float *, uint8_t *) override { return vk::Status::Ok(); }
   vk::Status distance(uint64_t, const float *, float *) override { return vk::Status::Ok(); }
   vk::Status get_row(uint64_t, float *) override { return vk::Status::Ok(); }
   vk::Status contains(uint64_t, bool *) override { return vk::Status::Ok(); }

@@ -35,7 +35,8 @@ class Params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("algo", C.c_uint32), ("metric", C.c_uint32), ("dtype", C.c_uint32),
                 ("dim", C.c_uint32), ("block_size", C.c_uint32), ("initial_cap", C.c_uint64), ("m", C.c_uint32),
                 ("ef_construction", C.c_uint32), ("ef_runtime", C.c_uint32), ("allow_replace_deleted", C.c_uint32),
-                ("random_seed", C.c_uint64), ("device_id", C.c_int32), ("build_threads", C.c_uint32)]
+                ("random_seed", C.c_uint64), ("device_id", C.c_int32), ("build_threads", C.c_uint32),
+                ("n_shards", C.c_uint32), ("shard_devices", C.c_int32 * 16)]
 
 
 class Stats(C.Structure):
@@ -94,6 +95,9 @@ def lib() -> C.CDLL:
     L.vk_index_device_rows.argtypes = [vp, u64, C.POINTER(vp), u64p]
     L.vk_index_commit_device_rows.argtypes = [vp, u64, vp]
     L.vk_merge_topk_device.argtypes = [vp, vp, u32, u64, u64, vp, vp, vp, i32, vp]
+    L.vk_index_shard_count.argtypes = [vp, u32p]
+    L.vk_index_shard_device_rows.argtypes = [vp, u32, u64, C.POINTER(vp), u64p]
+    L.vk_index_shard_commit_device_rows.argtypes = [vp, u32, u64, vp]
     L.vk_index_save.argtypes = [vp, WRITE_CHUNK, vp]
     L.vk_index_load.argtypes = [C.POINTER(Params), READ_CHUNK, vp, C.POINTER(vp)]
     _lib = L
@@ -113,9 +117,15 @@ DTYPE = {"f32": 0, "bf16": 1}
 
 
 def make_params(algo, dim, metric, initial_cap, block_size=1024, m=16, ef_construction=200, ef_runtime=10,
-                seed=100, allow_replace_deleted=False, device_id=-1, build_threads=0, dtype="f32") -> Params:
-    return Params(C.sizeof(Params), ALGO[algo], METRIC[metric], DTYPE[dtype], dim, block_size, initial_cap, m, ef_construction,
-                  ef_runtime, int(allow_replace_deleted), seed, device_id, build_threads)
+                seed=100, allow_replace_deleted=False, device_id=-1, build_threads=0, dtype="f32", shard_devices=None) -> Params:
+    """shard_devices: list of HIP device ordinals, one sub-index per entry (a device may repeat: logical shards)"""
+    p = Params(C.sizeof(Params), ALGO[algo], METRIC[metric], DTYPE[dtype], dim, block_size, initial_cap, m, ef_construction,
+               ef_runtime, int(allow_replace_deleted), seed, device_id, build_threads)
+    if shard_devices:
+        p.n_shards = len(shard_devices)
+        for i, d in enumerate(shard_devices):
+            p.shard_devices[i] = int(d)
+    return p
 
 
 class Index:
@@ -244,6 +254,20 @@ class Index:
     def commit_device_rows(self, n, labels=None):
         lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint64)
         _check(lib().vk_index_commit_device_rows(self._h, n, _ptr(lab)))
+
+    def shard_count(self) -> int:
+        n = C.c_uint32()
+        _check(lib().vk_index_shard_count(self._h, C.byref(n)))
+        return n.value
+
+    def shard_device_rows(self, shard, n):
+        p, stride = C.c_void_p(), C.c_uint64()
+        _check(lib().vk_index_shard_device_rows(self._h, shard, n, C.byref(p), C.byref(stride)))
+        return p.value, stride.value
+
+    def shard_commit_device_rows(self, shard, n, labels):
+        lab = np.ascontiguousarray(labels, dtype=np.uint64)
+        _check(lib().vk_index_shard_commit_device_rows(self._h, shard, n, _ptr(lab)))
 
     def search_batch_device(self, d_queries, nq, k, d_out_dist, d_out_label, d_out_n, ef=0, d_allow=None,
                             allow_nbits=0, stream=None):

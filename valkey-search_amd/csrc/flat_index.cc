@@ -77,7 +77,7 @@ Status SearchCtx::arm_cancel(const volatile int *caller_flag, const uint32_t **d
   *device_word = nullptr;
   if (!caller_flag) return Status::Ok();
   VK_TRY(h_cancel.ensure(64));
-  *h_cancel.as<volatile uint32_t>() = *caller_flag ? 1u : 0u;
+  *h_cancel.as<volatile uint32_t>() = 0u;   // (the waiting thread raises it; a flag that was up at entry is the caller's case)
   *device_word = h_cancel.as<uint32_t>();
   return Status::Ok();
 }
@@ -200,6 +200,20 @@ void prefilter_heap_select(const float *dist, const uint64_t *labels, uint64_t n
     out_label[m] = results.top().second;
     results.pop();
   }
+}
+
+// the pre-filter path on any index: per-key distances from the device, then the reference's heap rule in key order
+Status Index::search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n, float *out_dist,
+                            uint64_t *out_label, uint64_t *out_n) {
+  *out_n = 0;
+  if (n == 0 || k == 0) return Status::Ok();
+  std::vector<float> d(n);
+  std::vector<uint8_t> found(n);
+  VK_TRY(label_distances(query, labels, n, d.data(), found.data()));
+  std::vector<uint64_t> lab(n);
+  for (uint64_t i = 0; i < n; ++i) lab[i] = found[i] ? labels[i] : ~0ull;   // unknown key: skipped by the heap
+  prefilter_heap_select(d.data(), lab.data(), n, k, out_dist, out_label, out_n);
+  return Status::Ok();
 }
 
 // ---- FlatIndex ---------------------------------------------------------------------------
@@ -345,31 +359,27 @@ class FlatIndex final : public Index {
       dq = ctx->d_q.as<float>();
     }
     Status st = scan(ctx, dq, rq.nq, k, count, rq.allow_bits, rq.allow_nbits, nullptr, d_out_dist,
-                     d_out_label, d_out_n, s, rq.k);
+                     d_out_label, d_out_n, s, rq.k, rq.cancel_word);
     Status en = ctx->end_async(s);
     return st.ok() ? en : st;
   }
 
-  Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n, float *out_dist,
-                       uint64_t *out_label, uint64_t *out_n) override {
+  Status label_distances(const float *query, const uint64_t *labels, uint64_t n, float *out_dist, uint8_t *found) override {
     VK_TRY(flush_if_dirty());
     std::shared_lock<std::shared_mutex> lk(rw_);
     (void)hipSetDevice(store_.device());
-    *out_n = 0;
-    if (n == 0 || k == 0) return Status::Ok();
+    if (n == 0) return Status::Ok();
     CtxLease lease(pool_);
     SearchCtx *ctx = lease.ctx;
     // label -> slot on the host (dict_external_to_internal, vector_flat.cc:260-265)
     VK_TRY(ctx->h_idx.ensure(n * 4));
     VK_TRY(ctx->h_tmp.ensure(n * 4));
-    std::vector<uint64_t> found(n);
     uint32_t *idx = ctx->h_idx.as<uint32_t>();
     uint64_t m = 0;
     for (uint64_t i = 0; i < n; ++i) {
       auto it = slot_of_.find(labels[i]);
-      if (it == slot_of_.end()) continue;
-      idx[m] = it->second;
-      found[m++] = labels[i];
+      found[i] = it != slot_of_.end();
+      if (found[i]) idx[m++] = it->second;
     }
     if (m == 0) return Status::Ok();
     VK_TRY(upload_queries(ctx, query, 1, params_.dim, store_.stride_f()));
@@ -381,7 +391,9 @@ class FlatIndex final : public Index {
     VK_HIP_TRY(launch_gather_distance(ga, l2(), store_.bf16(), ctx->stream));
     VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_tmp.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
     VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    prefilter_heap_select(ctx->h_tmp.as<float>(), found.data(), m, k, out_dist, out_label, out_n);
+    const float *hd = ctx->h_tmp.as<float>();
+    for (uint64_t i = 0, j = 0; i < n; ++i)
+      if (found[i]) out_dist[i] = hd[j++];
     return Status::Ok();
   }
 
@@ -481,15 +493,15 @@ class FlatIndex final : public Index {
   // enqueue scan + merge of rows [0,count) on stream s; all pointers device
   Status scan(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
               uint64_t allow_nbits, const volatile int *cancel, float *d_out_d, uint64_t *d_out_l,
-              uint32_t *d_out_n, hipStream_t s, uint64_t out_ld = 0) {
+              uint32_t *d_out_n, hipStream_t s, uint64_t out_ld = 0, const uint32_t *cancel_word = nullptr) {
     if (out_ld == 0) out_ld = k;                      // entries per query in the output arrays (>= k; the tail is padding)
     int e = flat_scan_slots_per_lane(k);
     if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 needs the host entry points (vk_index_search / _batch), which page through the result in passes");
     const uint32_t chunks = store_.stride_f() / 16;
     // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
     if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !(cancel && *cancel) && flat_gemm_supported(store_.stride_f(), k) && !force_scan_) {
-      const uint32_t *d_cancel = nullptr;
-      VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
+      const uint32_t *d_cancel = cancel_word;
+      if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
       return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel);
     }
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
@@ -499,9 +511,9 @@ class FlatIndex final : public Index {
     // rows: cancelled at entry -> only the first k rows are looked at (bruteforce.h:120-129); cancelled later -> the
     // kernel stops between row tiles (FlatScanArgs::cancel) and the answer is what the lists hold
     uint64_t row_end = count;
-    if (cancel && *cancel) row_end = std::min<uint64_t>(count, k);
-    const uint32_t *d_cancel = nullptr;
-    VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
+    const uint32_t *d_cancel = cancel_word;
+    if (cancel && *cancel) row_end = std::min<uint64_t>(count, k);          // (those rows are scanned whatever the flag says)
+    else if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
     // row partitions: enough blocks to fill 256 CUs, never more waves than 16-row tiles
     const uint64_t tiles = (row_end + 15) / 16;
     // ... and at least ~4 tiles per wave: every block leaves a partial list for the merge kernel (one wave per

@@ -215,31 +215,27 @@ class HnswIndex final : public Index {
       dq = ctx->d_q.as<float>();
     }
     Status st = launch(ctx, dq, rq.nq, rq.k, rq.ef, rq.allow_bits, rq.allow_nbits, d_out_dist, d_out_label,
-                       d_out_n, s, true);
+                       d_out_n, s, true, false, rq.cancel_word);
     Status en = ctx->end_async(s);
     return st.ok() ? en : st;
   }
 
-  Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n, float *out_dist,
-                       uint64_t *out_label, uint64_t *out_n) override {
+  Status label_distances(const float *query, const uint64_t *labels, uint64_t n, float *out_dist, uint8_t *found) override {
     VK_TRY(flush_if_dirty());
     std::shared_lock<std::shared_mutex> lk(rw_);
     (void)hipSetDevice(store_.device());
-    *out_n = 0;
-    if (n == 0 || k == 0) return Status::Ok();
+    if (n == 0) return Status::Ok();
     CtxLease lease(pool_);
     SearchCtx *ctx = lease.ctx;
     VK_TRY(ctx->h_idx.ensure(n * 4));
     VK_TRY(ctx->h_tmp.ensure(n * 4));
-    std::vector<uint64_t> found(n);
     uint32_t *idx = ctx->h_idx.as<uint32_t>();
     uint64_t m = 0;
     for (uint64_t i = 0; i < n; ++i) {
       uint32_t id;
-      // tombstoned labels are "not found" (vector_hnsw.cc:55-64)
-      if (!graph_->lookup(labels[i], &id) || id >= pub_.count || graph_->is_deleted(id)) continue;   // (not published yet = not found)
-      idx[m] = id;
-      found[m++] = labels[i];
+      // tombstoned labels are "not found" (vector_hnsw.cc:55-64); so are labels not published to the device yet
+      found[i] = graph_->lookup(labels[i], &id) && id < pub_.count && !graph_->is_deleted(id);
+      if (found[i]) idx[m++] = id;
     }
     if (m == 0) return Status::Ok();
     VK_TRY(upload_queries(ctx, query, 1, params_.dim, store_.stride_f()));
@@ -251,7 +247,9 @@ class HnswIndex final : public Index {
     VK_HIP_TRY(launch_gather_distance(ga, l2(), store_.bf16(), ctx->stream));
     VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_tmp.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
     VK_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    prefilter_heap_select(ctx->h_tmp.as<float>(), found.data(), m, k, out_dist, out_label, out_n);
+    const float *hd = ctx->h_tmp.as<float>();
+    for (uint64_t i = 0, j = 0; i < n; ++i)
+      if (found[i]) out_dist[i] = hd[j++];
     return Status::Ok();
   }
 

@@ -95,6 +95,9 @@ struct SearchRequest {
   uint64_t allow_nbits = 0;
   const volatile int *cancel_flag = nullptr;
   bool partial_ok = true;
+  // search_device only: a device-visible cancellation word the caller maintains itself (the sharded index relays one
+  // host flag to the kernels of every shard through it)
+  const uint32_t *cancel_word = nullptr;
 };
 
 class Index {
@@ -114,8 +117,16 @@ class Index {
   // device buffers in/out, enqueued on `stream` (nullptr = internal) without host sync
   virtual Status search_device(const SearchRequest &rq, float *d_out_dist, uint64_t *d_out_label,
                                uint32_t *d_out_n, hipStream_t stream) = 0;
-  virtual Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n,
-                               float *out_dist, uint64_t *out_label, uint64_t *out_n) = 0;
+  // distance of every listed label that the index holds (found[i] = 1), in list order: the device half of the
+  // pre-filter path (ComputeDistanceFromRecordImpl per key, vector_base.cc:509-530)
+  virtual Status label_distances(const float *query, const uint64_t *labels, uint64_t n, float *out_dist, uint8_t *found) = 0;
+  // ... and its host half: AddPrefilteredKey's heap over those distances, in key order
+  Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n, float *out_dist,
+                       uint64_t *out_label, uint64_t *out_n);
+  // sharded index: its shards (vk_index_shard_device_rows / _commit_device_rows address one of them)
+  virtual uint32_t shard_count() const { return 0; }
+  virtual Status shard_device_rows(uint32_t, uint64_t, void **, uint64_t *) { return Status::Err(VK_ERR_INVALID, "not a sharded index"); }
+  virtual Status shard_commit_device_rows(uint32_t, uint64_t, const uint64_t *) { return Status::Err(VK_ERR_INVALID, "not a sharded index"); }
   virtual Status distance(uint64_t label, const float *query, float *out) = 0;
   virtual Status get_row(uint64_t label, float *out) = 0;
   virtual Status contains(uint64_t label, bool *found) = 0;
@@ -129,6 +140,8 @@ class Index {
   vk_index_params params_;
 };
 
+Status create_sharded(const vk_index_params &p, std::unique_ptr<Index> *out);
+Status load_sharded(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std::unique_ptr<Index> *out);
 Status create_flat(const vk_index_params &p, std::unique_ptr<Index> *out);
 Status create_hnsw(const vk_index_params &p, std::unique_ptr<Index> *out);
 Status load_flat(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std::unique_ptr<Index> *out);

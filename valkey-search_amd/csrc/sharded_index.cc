@@ -1,0 +1,779 @@
+// sharded_index.cc -- one index over several GPUs of one node, inside the library (one process, as valkey-server is).
+//
+// The reference scales a vector index by cluster shards: every shard holds an independent index over its slice of the
+// keys, a query fans out to all of them and SearchPartitionResultsTracker::AddResult keeps the best k of what comes
+// back (src/query/fanout.cc:162-175).  The same shape inside one vk_index: n_shards sub-indexes (FLAT or HNSW, one
+// graph per shard), each on its own device -- or several on one device, "logical shards", which is how a one-GPU box
+// tests this path.  Rows are dealt to the shards in contiguous runs (a bulk load of N rows puts rows
+// [s*N/S, (s+1)*N/S) on shard s); a label stays on the shard it first went to.
+//
+// A search: the queries (on the serving device = the first shard's) are broadcast to the other devices by peer copy on
+// each shard's stream, every shard answers on its own stream (vk_index_search_batch_device of the sub-index: the same
+// kernels as a single-device index), the per-shard top-k lists land in one [shard][query][k] array on the serving
+// device -- written there directly by a shard that lives on that device, one peer copy per list otherwise (xGMI; 30 KiB
+// per shard at B=256, k=10: latency-bound, so one-shot copies rather than a ring collective) -- and merge_topk_kernel
+// selects the k best by (distance,label).  That order is total, so the S-shard answer is bit-identical to the
+// answer of one index over all rows (FLAT), unlike the reference's arrival-order tie rule (fanout.cc:171).
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+
+#include "index.hpp"
+
+namespace vk {
+
+namespace {
+
+constexpr uint32_t kMaxShards = 16;
+const char kShardMagic[8] = {'V', 'K', 'S', 'H', 'A', 'R', 'D', 'S'};
+
+// per-call resources of a sharded search: per shard a stream, an event and buffers on the shard's device; on the serving
+// device the gathered lists; pinned host buffers for the host entry points
+struct ShardLane {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  DevBuf d_q, d_allow, d_out_d, d_out_l, d_out_n;
+};
+struct MultiCtx {
+  std::vector<ShardLane> lane;
+  int dev0 = 0;
+  hipStream_t s0 = nullptr;
+  hipEvent_t ready = nullptr, busy = nullptr;
+  bool has_busy = false;
+  DevBuf d_q, d_allow, d_all_d, d_all_l, d_all_n, d_fin_d, d_fin_l, d_fin_n;
+  PinBuf h_q, h_fin_d, h_fin_l, h_fin_n, h_cancel;
+  ~MultiCtx() {
+    (void)hipSetDevice(dev0);
+    if (s0) (void)hipStreamSynchronize(s0);
+    for (ShardLane &l : lane) {
+      (void)hipSetDevice(l.device);
+      if (l.stream) (void)hipStreamSynchronize(l.stream);
+      for (DevBuf *b : {&l.d_q, &l.d_allow, &l.d_out_d, &l.d_out_l, &l.d_out_n}) b->release();
+      if (l.done) (void)hipEventDestroy(l.done);
+      if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    (void)hipSetDevice(dev0);
+    for (DevBuf *b : {&d_q, &d_allow, &d_all_d, &d_all_l, &d_all_n, &d_fin_d, &d_fin_l, &d_fin_n}) b->release();
+    for (PinBuf *b : {&h_q, &h_fin_d, &h_fin_l, &h_fin_n, &h_cancel}) b->release();
+    if (ready) (void)hipEventDestroy(ready);
+    if (busy) (void)hipEventDestroy(busy);
+    if (s0) (void)hipStreamDestroy(s0);
+  }
+};
+
+}  // namespace
+
+class ShardedIndex final : public Index {
+ public:
+  ShardedIndex(const vk_index_params &p, std::vector<int> devices)
+      : Index(p), devices_(std::move(devices)), counts_(devices_.size(), 0), capacity_(p.initial_cap) {}
+
+  Status init() {
+    const size_t S = devices_.size();
+    for (size_t s = 0; s < S; ++s) {
+      vk_index_params sp = params_;
+      sp.n_shards = 0;
+      sp.device_id = devices_[s];
+      // a shard starts with its share of the capacity and grows on demand (the limit the caller sees is capacity_)
+      sp.initial_cap = std::max<uint64_t>(1024, (params_.initial_cap + S - 1) / S);
+      std::unique_ptr<Index> sub;
+      if (params_.algo == VK_ALGO_FLAT) VK_TRY(create_flat(sp, &sub));
+      else VK_TRY(create_hnsw(sp, &sub));
+      shards_.push_back(std::move(sub));
+      shard_cap_.push_back(sp.initial_cap);
+    }
+    // peer access between the devices involved (a failure only means the copies are staged by the runtime)
+    for (size_t a = 0; a < S; ++a)
+      for (size_t b = 0; b < S; ++b)
+        if (devices_[a] != devices_[b]) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, devices_[a], devices_[b]) == hipSuccess && can) {
+            (void)hipSetDevice(devices_[a]);
+            hipError_t e = hipDeviceEnablePeerAccess(devices_[b], 0);
+            if (e != hipSuccess) (void)hipGetLastError();   // (already enabled)
+          }
+        }
+    return Status::Ok();
+  }
+
+  uint32_t shard_count() const override { return (uint32_t)shards_.size(); }
+
+  // ---- mutations ------------------------------------------------------------------------------------
+  Status add(uint64_t label, const float *row) override {
+    uint32_t s;
+    bool fresh;
+    VK_TRY(route_for_add(label, &s, &fresh));
+    Status st = add_to_shard(s, label, row);
+    if (!st.ok() && fresh) unroute(label, s);
+    return st;
+  }
+
+  Status add_batch(const uint64_t *labels, const float *rows, uint64_t n) override {
+    const size_t S = shards_.size();
+    std::vector<uint64_t> iota;
+    if (!labels) {
+      iota.resize(n);
+      for (uint64_t i = 0; i < n; ++i) iota[i] = i;
+      labels = iota.data();
+    }
+    // shard of every row: a known label stays where it is, new labels are dealt out in contiguous runs that even out
+    // the shard sizes (an all-new bulk load of N rows: rows [s*N/S, (s+1)*N/S) to shard s)
+    std::vector<uint32_t> shard_of(n);
+    bool over_capacity = false;
+    uint64_t n_used = n;
+    {
+      std::unique_lock<std::shared_mutex> lk(rw_);
+      uint64_t total = 0;
+      for (uint64_t c : counts_) total += c;
+      std::vector<uint64_t> fresh_idx;
+      for (uint64_t i = 0; i < n; ++i) {
+        auto it = route_.find(labels[i]);
+        if (it != route_.end()) { shard_of[i] = it->second; continue; }
+        if (total + fresh_idx.size() >= capacity_) {   // addPoint fails at the limit; everything before it is in
+          over_capacity = true;
+          n_used = i;
+          break;
+        }
+        shard_of[i] = kMaxShards;   // marks "new"
+        fresh_idx.push_back(i);
+      }
+      const uint64_t after = total + fresh_idx.size();
+      size_t s = 0;
+      uint64_t quota = 0;
+      auto next_quota = [&]() {
+        for (; s < S; ++s) {
+          const uint64_t target = (after * (s + 1)) / S - (after * s) / S;   // even split of the final size
+          if (target > counts_[s]) { quota = target - counts_[s]; return; }
+        }
+        quota = ~0ull;
+        s = S - 1;
+      };
+      next_quota();
+      for (uint64_t i : fresh_idx) {
+        if (quota == 0) { ++s; next_quota(); }
+        // a label twice in one batch: the second occurrence follows the first
+        auto ins = route_.emplace(labels[i], (uint32_t)s);
+        if (ins.second) { counts_[s]++; quota--; }
+        shard_of[i] = ins.first->second;
+      }
+    }
+    // one add_batch per shard, concurrently (each shard has its own device, streams and -- HNSW -- graph builder)
+    std::vector<Status> res(S);
+    std::vector<std::thread> th;
+    for (size_t s = 0; s < S; ++s) {
+      th.emplace_back([&, s]() {
+        // rows of shard s: one contiguous slice of the input in the usual case (no copy), else gathered
+        uint64_t first = n_used, last = 0, cnt = 0;
+        for (uint64_t i = 0; i < n_used; ++i)
+          if (shard_of[i] == s) { first = std::min(first, i); last = i; ++cnt; }
+        if (cnt == 0) return;
+        const uint32_t dim = params_.dim;
+        if (last - first + 1 == cnt) {
+          res[s] = shard_add_batch((uint32_t)s, labels + first, rows + first * dim, cnt);
+          return;
+        }
+        std::vector<uint64_t> ls;
+        std::vector<float> rs;
+        ls.reserve(cnt);
+        rs.reserve(cnt * dim);
+        for (uint64_t i = first; i <= last; ++i)
+          if (shard_of[i] == s) {
+            ls.push_back(labels[i]);
+            rs.insert(rs.end(), rows + i * dim, rows + (i + 1) * dim);
+          }
+        res[s] = shard_add_batch((uint32_t)s, ls.data(), rs.data(), cnt);
+      });
+    }
+    for (auto &t : th) t.join();
+    for (const Status &st : res)
+      if (!st.ok()) return st;
+    if (over_capacity) return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+    return Status::Ok();
+  }
+
+  Status remove(uint64_t label) override {
+    uint32_t s;
+    {
+      std::unique_lock<std::shared_mutex> lk(rw_);
+      auto it = route_.find(label);
+      if (it == route_.end())   // FLAT ignores unknown labels (bruteforce.h:95-98), HNSW reports them
+        return params_.algo == VK_ALGO_FLAT ? Status::Ok() : Status::Err(VK_ERR_NOT_FOUND, "Label not found");
+      s = it->second;
+      if (params_.algo == VK_ALGO_FLAT) {   // the row is gone; an HNSW tombstone keeps its slot (and its shard)
+        route_.erase(it);
+        counts_[s]--;
+      }
+    }
+    return shards_[s]->remove(label);
+  }
+
+  Status resize(uint64_t new_max) override {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    capacity_ = new_max;
+    return Status::Ok();
+  }
+
+  Status set_ef(uint32_t ef) override {
+    for (auto &s : shards_) VK_TRY(s->set_ef(ef));
+    return Status::Ok();
+  }
+
+  Status flush() override {
+    for (auto &s : shards_) VK_TRY(s->flush());
+    return Status::Ok();
+  }
+
+  // ---- queries --------------------------------------------------------------------------------------
+  Status search(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) override {
+    if (rq.nq == 0) return Status::Ok();
+    if (rq.k == 0) {
+      for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
+      return Status::Ok();
+    }
+    if (rq.cancel_flag && *rq.cancel_flag && !rq.partial_ok && params_.algo == VK_ALGO_HNSW)
+      return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
+    if (flat_scan_slots_per_lane(rq.k) == 0) return search_by_host_merge(rq, out_dist, out_label, out_n);
+    MultiLease lease(*this);
+    MultiCtx *mc = lease.mc;
+    (void)hipSetDevice(mc->dev0);
+    const uint32_t dim = params_.dim;
+    const size_t qbytes = (size_t)rq.nq * dim * 4, nk = (size_t)rq.nq * rq.k;
+    VK_TRY(mc->h_q.ensure(qbytes));
+    VK_TRY(mc->d_q.ensure(qbytes));
+    memcpy(mc->h_q.p, rq.queries, qbytes);
+    VK_HIP_TRY(hipMemcpyAsync(mc->d_q.p, mc->h_q.p, qbytes, hipMemcpyHostToDevice, mc->s0));
+    const uint64_t *d_allow = nullptr;
+    if (rq.allow_bits) {
+      const size_t words = (size_t)((rq.allow_nbits + 63) / 64);
+      VK_TRY(mc->d_allow.ensure(std::max<size_t>(words * 8, 8)));
+      if (words) VK_HIP_TRY(hipMemcpyAsync(mc->d_allow.p, rq.allow_bits, words * 8, hipMemcpyHostToDevice, mc->s0));
+      d_allow = mc->d_allow.as<uint64_t>();
+    }
+    const uint32_t *d_cancel = nullptr;
+    if (rq.cancel_flag) {
+      VK_TRY(mc->h_cancel.ensure(64));
+      *mc->h_cancel.as<volatile uint32_t>() = *rq.cancel_flag ? 1u : 0u;
+      d_cancel = mc->h_cancel.as<uint32_t>();
+    }
+    VK_TRY(mc->d_fin_d.ensure(nk * 4));
+    VK_TRY(mc->d_fin_l.ensure(nk * 8));
+    VK_TRY(mc->d_fin_n.ensure(rq.nq * 4));
+    VK_TRY(mc->h_fin_d.ensure(nk * 4));
+    VK_TRY(mc->h_fin_l.ensure(nk * 8));
+    VK_TRY(mc->h_fin_n.ensure(rq.nq * 4));
+    SearchRequest drq = rq;
+    drq.queries = mc->d_q.as<float>();
+    drq.allow_bits = d_allow;
+    drq.cancel_word = d_cancel;
+    VK_TRY(fan_out(mc, drq, mc->d_fin_d.as<float>(), mc->d_fin_l.as<uint64_t>(), mc->d_fin_n.as<uint32_t>(), mc->s0));
+    (void)hipSetDevice(mc->dev0);
+    VK_HIP_TRY(hipMemcpyAsync(mc->h_fin_d.p, mc->d_fin_d.p, nk * 4, hipMemcpyDeviceToHost, mc->s0));
+    VK_HIP_TRY(hipMemcpyAsync(mc->h_fin_l.p, mc->d_fin_l.p, nk * 8, hipMemcpyDeviceToHost, mc->s0));
+    VK_HIP_TRY(hipMemcpyAsync(mc->h_fin_n.p, mc->d_fin_n.p, rq.nq * 4, hipMemcpyDeviceToHost, mc->s0));
+    // wait; with a cancel flag, relay it to the word every shard's kernels poll
+    if (!rq.cancel_flag) {
+      VK_HIP_TRY(hipStreamSynchronize(mc->s0));
+    } else {
+      volatile uint32_t *word = mc->h_cancel.as<volatile uint32_t>();
+      for (unsigned spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(mc->s0);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) return Status::Err(VK_ERR_INTERNAL, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        if (*rq.cancel_flag) *word = 1u;
+        if (spins < 2000) __builtin_ia32_pause();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+      }
+      if (*rq.cancel_flag && !rq.partial_ok && params_.algo == VK_ALGO_HNSW)
+        return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
+    }
+    for (uint64_t q = 0; q < rq.nq; ++q) {
+      const uint32_t m = mc->h_fin_n.as<uint32_t>()[q];
+      out_n[q] = m;
+      memcpy(out_dist + q * rq.k, mc->h_fin_d.as<float>() + q * rq.k, (size_t)m * 4);
+      memcpy(out_label + q * rq.k, mc->h_fin_l.as<uint64_t>() + q * rq.k, (size_t)m * 8);
+    }
+    return Status::Ok();
+  }
+
+  // queries / outputs on the serving device (the first shard's), work enqueued on `stream` without a host sync
+  Status search_device(const SearchRequest &rq, float *d_out_dist, uint64_t *d_out_label, uint32_t *d_out_n,
+                       hipStream_t stream) override {
+    if (rq.nq == 0) return Status::Ok();
+    if (rq.k == 0 || flat_scan_slots_per_lane(rq.k) == 0)
+      return Status::Err(VK_ERR_INVALID, "search_batch_device on a sharded index needs 0 < k <= 1024");
+    MultiLease lease(*this, stream);
+    MultiCtx *mc = lease.mc;
+    hipStream_t s0 = stream ? stream : mc->s0;
+    Status st = fan_out(mc, rq, d_out_dist, d_out_label, d_out_n, s0);
+    (void)hipSetDevice(mc->dev0);
+    if (hipEventRecord(mc->busy, s0) == hipSuccess) mc->has_busy = true;
+    return st;
+  }
+
+  Status label_distances(const float *query, const uint64_t *labels, uint64_t n, float *out_dist, uint8_t *found) override {
+    const size_t S = shards_.size();
+    std::vector<std::vector<uint64_t>> idx(S), lab(S);
+    {
+      std::shared_lock<std::shared_mutex> lk(rw_);
+      for (uint64_t i = 0; i < n; ++i) {
+        found[i] = 0;
+        auto it = route_.find(labels[i]);
+        if (it == route_.end()) continue;
+        idx[it->second].push_back(i);
+        lab[it->second].push_back(labels[i]);
+      }
+    }
+    for (size_t s = 0; s < S; ++s) {
+      if (lab[s].empty()) continue;
+      std::vector<float> d(lab[s].size());
+      std::vector<uint8_t> f(lab[s].size());
+      VK_TRY(shards_[s]->label_distances(query, lab[s].data(), lab[s].size(), d.data(), f.data()));
+      for (size_t j = 0; j < lab[s].size(); ++j) {
+        found[idx[s][j]] = f[j];
+        out_dist[idx[s][j]] = d[j];
+      }
+    }
+    return Status::Ok();
+  }
+
+  Status distance(uint64_t label, const float *query, float *out) override {
+    uint32_t s;
+    if (!route_of(label, &s)) return Status::Err(VK_ERR_NOT_FOUND, "Couldn't find internal id");
+    return shards_[s]->distance(label, query, out);
+  }
+  Status get_row(uint64_t label, float *out) override {
+    uint32_t s;
+    if (!route_of(label, &s)) return Status::Err(VK_ERR_NOT_FOUND, "label not found");
+    return shards_[s]->get_row(label, out);
+  }
+  Status contains(uint64_t label, bool *found) override {
+    uint32_t s;
+    *found = false;
+    if (!route_of(label, &s)) return Status::Ok();
+    return shards_[s]->contains(label, found);
+  }
+
+  Status stats(vk_index_stats *out) override {
+    memset(out, 0, sizeof(*out));
+    out->max_level = -1;
+    for (size_t s = 0; s < shards_.size(); ++s) {
+      vk_index_stats t;
+      VK_TRY(shards_[s]->stats(&t));
+      out->count += t.count;
+      out->deleted += t.deleted;
+      out->device_bytes += t.device_bytes;
+      out->host_bytes += t.host_bytes;
+      out->staged_ops += t.staged_ops;
+      out->max_level = std::max(out->max_level, t.max_level);
+      if (s == 0) out->entry_point = t.entry_point;
+    }
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    out->capacity = capacity_;
+    out->host_bytes += route_.size() * 24;
+    return Status::Ok();
+  }
+
+  Status device_rows(uint64_t, void **, uint64_t *) override {
+    return Status::Err(VK_ERR_INVALID, "a sharded index loads device rows shard by shard (vk_index_shard_device_rows)");
+  }
+  Status commit_device_rows(uint64_t, const uint64_t *) override {
+    return Status::Err(VK_ERR_INVALID, "a sharded index loads device rows shard by shard (vk_index_shard_commit_device_rows)");
+  }
+  Status shard_device_rows(uint32_t s, uint64_t n, void **d_rows, uint64_t *stride) override {
+    if (s >= shards_.size()) return Status::Err(VK_ERR_INVALID, "shard out of range");
+    VK_TRY(shards_[s]->resize(std::max<uint64_t>(n, shard_cap_[s])));
+    shard_cap_[s] = std::max<uint64_t>(n, shard_cap_[s]);
+    return shards_[s]->device_rows(n, d_rows, stride);
+  }
+  Status shard_commit_device_rows(uint32_t s, uint64_t n, const uint64_t *labels) override {
+    if (s >= shards_.size()) return Status::Err(VK_ERR_INVALID, "shard out of range");
+    if (!labels) return Status::Err(VK_ERR_INVALID, "a sharded bulk load needs explicit labels (unique across the shards)");
+    {
+      std::unique_lock<std::shared_mutex> lk(rw_);
+      uint64_t total = 0;
+      for (uint64_t c : counts_) total += c;
+      if (total + n > capacity_) return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+      for (uint64_t i = 0; i < n; ++i)
+        if (route_.count(labels[i])) return Status::Err(VK_ERR_INVALID, "duplicate label in bulk load");
+      route_.reserve(route_.size() + n);
+      for (uint64_t i = 0; i < n; ++i) route_.emplace(labels[i], s);
+      counts_[s] += n;
+    }
+    return shards_[s]->commit_device_rows(n, labels);
+  }
+
+  Status save(vk_write_chunk_fn fn, void *user) override;
+  Status load_from(vk_read_chunk_fn fn, void *user);
+
+ private:
+  // ---- routing ------------------------------------------------------------------------------------------
+  bool route_of(uint64_t label, uint32_t *s) {
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    auto it = route_.find(label);
+    if (it == route_.end()) return false;
+    *s = it->second;
+    return true;
+  }
+  Status route_for_add(uint64_t label, uint32_t *s, bool *fresh) {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    auto it = route_.find(label);
+    if (it != route_.end()) { *s = it->second; *fresh = false; return Status::Ok(); }
+    uint64_t total = 0;
+    for (uint64_t c : counts_) total += c;
+    if (total >= capacity_) return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+    uint32_t best = 0;
+    for (uint32_t i = 1; i < counts_.size(); ++i)
+      if (counts_[i] < counts_[best]) best = i;
+    route_.emplace(label, best);
+    counts_[best]++;
+    *s = best;
+    *fresh = true;
+    return Status::Ok();
+  }
+  void unroute(uint64_t label, uint32_t s) {
+    std::unique_lock<std::shared_mutex> lk(rw_);
+    if (route_.erase(label)) counts_[s]--;
+  }
+  // a shard's own capacity is an internal matter: grow it and retry (the caller's limit is capacity_)
+  Status add_to_shard(uint32_t s, uint64_t label, const float *row) {
+    Status st = shards_[s]->add(label, row);
+    if (st.code != VK_ERR_CAPACITY) return st;
+    VK_TRY(grow_shard(s, 1));
+    return shards_[s]->add(label, row);
+  }
+  Status shard_add_batch(uint32_t s, const uint64_t *labels, const float *rows, uint64_t n) {
+    vk_index_stats t;
+    VK_TRY(shards_[s]->stats(&t));
+    if (t.count + n > shard_cap_[s]) VK_TRY(grow_shard(s, t.count + n - shard_cap_[s]));
+    return shards_[s]->add_batch(labels, rows, n);
+  }
+  Status grow_shard(uint32_t s, uint64_t at_least) {
+    std::lock_guard<std::mutex> g(grow_mu_);
+    const uint64_t want = std::max<uint64_t>(shard_cap_[s] + at_least, shard_cap_[s] + shard_cap_[s] / 2);
+    VK_TRY(shards_[s]->resize(want));
+    shard_cap_[s] = want;
+    return Status::Ok();
+  }
+
+  // ---- per-call contexts ---------------------------------------------------------------------------------
+  MultiCtx *acquire(hipStream_t on) {
+    MultiCtx *mc = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(ctx_mu_);
+      for (;;) {
+        if (!free_.empty()) { mc = free_.back(); free_.pop_back(); break; }
+        if (all_.size() < 8) {
+          auto n = std::make_unique<MultiCtx>();
+          n->dev0 = devices_[0];
+          (void)hipSetDevice(n->dev0);
+          (void)hipStreamCreateWithFlags(&n->s0, hipStreamNonBlocking);
+          (void)hipEventCreateWithFlags(&n->ready, hipEventDisableTiming);
+          (void)hipEventCreateWithFlags(&n->busy, hipEventDisableTiming);
+          n->lane.resize(devices_.size());
+          for (size_t s = 0; s < devices_.size(); ++s) {
+            ShardLane &l = n->lane[s];
+            l.device = devices_[s];
+            (void)hipSetDevice(l.device);
+            (void)hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+            (void)hipEventCreateWithFlags(&l.done, hipEventDisableTiming);
+          }
+          all_.push_back(std::move(n));
+          mc = all_.back().get();
+          break;
+        }
+        ctx_cv_.wait(lk);
+      }
+    }
+    if (mc->has_busy) {   // its previous user's work may still be in flight: the new work goes behind it
+      (void)hipSetDevice(mc->dev0);
+      if (hipStreamWaitEvent(on ? on : mc->s0, mc->busy, 0) != hipSuccess) (void)hipEventSynchronize(mc->busy);
+      mc->has_busy = false;
+    }
+    return mc;
+  }
+  void release(MultiCtx *mc) {
+    {
+      std::lock_guard<std::mutex> lk(ctx_mu_);
+      free_.push_back(mc);
+    }
+    ctx_cv_.notify_one();
+  }
+  struct MultiLease {
+    ShardedIndex &ix;
+    MultiCtx *mc;
+    explicit MultiLease(ShardedIndex &i, hipStream_t on = nullptr) : ix(i), mc(i.acquire(on)) {}
+    ~MultiLease() { ix.release(mc); }
+  };
+
+  // the fan-out itself: rq holds DEVICE pointers on the serving device, valid on stream s0; the merged answer is written
+  // to d_out_* (serving device) by work enqueued on s0
+  Status fan_out(MultiCtx *mc, const SearchRequest &rq, float *d_out_dist, uint64_t *d_out_label, uint32_t *d_out_n,
+                 hipStream_t s0) {
+    const size_t S = shards_.size();
+    const uint32_t dim = params_.dim;
+    const size_t qbytes = (size_t)rq.nq * dim * 4, nk = (size_t)rq.nq * rq.k;
+    const size_t abytes = rq.allow_bits ? (size_t)((rq.allow_nbits + 63) / 64) * 8 : 0;
+    (void)hipSetDevice(mc->dev0);
+    VK_TRY(mc->d_all_d.ensure(S * nk * 4));
+    VK_TRY(mc->d_all_l.ensure(S * nk * 8));
+    VK_TRY(mc->d_all_n.ensure(S * rq.nq * 4));
+    VK_HIP_TRY(hipEventRecord(mc->ready, s0));   // queries (and filter) are in place on the serving device
+    for (size_t s = 0; s < S; ++s) {
+      ShardLane &l = mc->lane[s];
+      (void)hipSetDevice(l.device);
+      VK_HIP_TRY(hipStreamWaitEvent(l.stream, mc->ready, 0));
+      SearchRequest srq = rq;
+      srq.cancel_flag = nullptr;
+      float *od = mc->d_all_d.as<float>() + s * nk;
+      uint64_t *ol = mc->d_all_l.as<uint64_t>() + s * nk;
+      uint32_t *on = mc->d_all_n.as<uint32_t>() + s * rq.nq;
+      const bool local = l.device == mc->dev0;
+      if (!local) {   // broadcast by peer copy, answer into the shard's own buffers
+        VK_TRY(l.d_q.ensure(qbytes));
+        VK_HIP_TRY(hipMemcpyPeerAsync(l.d_q.p, l.device, rq.queries, mc->dev0, qbytes, l.stream));
+        srq.queries = l.d_q.as<float>();
+        if (rq.allow_bits) {
+          VK_TRY(l.d_allow.ensure(std::max<size_t>(abytes, 8)));
+          if (abytes) VK_HIP_TRY(hipMemcpyPeerAsync(l.d_allow.p, l.device, rq.allow_bits, mc->dev0, abytes, l.stream));
+          srq.allow_bits = l.d_allow.as<uint64_t>();
+        }
+        VK_TRY(l.d_out_d.ensure(nk * 4));
+        VK_TRY(l.d_out_l.ensure(nk * 8));
+        VK_TRY(l.d_out_n.ensure(rq.nq * 4));
+        od = l.d_out_d.as<float>();
+        ol = l.d_out_l.as<uint64_t>();
+        on = l.d_out_n.as<uint32_t>();
+      }
+      VK_TRY(shards_[s]->search_device(srq, od, ol, on, l.stream));
+      (void)hipSetDevice(l.device);
+      if (!local) {   // the shard's lists -> their slice of the gathered array on the serving device
+        VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_d.as<float>() + s * nk, mc->dev0, od, l.device, nk * 4, l.stream));
+        VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_l.as<uint64_t>() + s * nk, mc->dev0, ol, l.device, nk * 8, l.stream));
+      }
+      VK_HIP_TRY(hipEventRecord(l.done, l.stream));
+    }
+    (void)hipSetDevice(mc->dev0);
+    for (size_t s = 0; s < S; ++s) VK_HIP_TRY(hipStreamWaitEvent(s0, mc->lane[s].done, 0));
+    MergeArgs m{};
+    m.in_dist = mc->d_all_d.as<float>();
+    m.in_label = mc->d_all_l.as<uint64_t>();
+    m.part_stride = nk;
+    m.q_stride = rq.k;
+    m.parts = (uint32_t)S;
+    m.per_part = (uint32_t)rq.k;
+    m.k = (uint32_t)rq.k;
+    m.out_ld = (uint32_t)rq.k;
+    m.out_dist = d_out_dist;
+    m.out_label = d_out_label;
+    m.out_n = d_out_n;
+    VK_HIP_TRY(launch_merge_topk(m, flat_scan_slots_per_lane(rq.k), rq.nq, s0));
+    return Status::Ok();
+  }
+
+  // k beyond the device merge (FLAT pages such results on the host anyway): every shard's host answer, merged here
+  Status search_by_host_merge(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) {
+    const size_t S = shards_.size();
+    const size_t nk = (size_t)rq.nq * rq.k;
+    std::vector<float> d(S * nk);
+    std::vector<uint64_t> l(S * nk), cnt(S * rq.nq);
+    for (size_t s = 0; s < S; ++s)
+      VK_TRY(shards_[s]->search(rq, d.data() + s * nk, l.data() + s * nk, cnt.data() + s * rq.nq));
+    std::vector<std::pair<float, uint64_t>> all;
+    for (uint64_t q = 0; q < rq.nq; ++q) {
+      all.clear();
+      for (size_t s = 0; s < S; ++s)
+        for (uint64_t i = 0; i < cnt[s * rq.nq + q]; ++i)
+          all.emplace_back(d[s * nk + q * rq.k + i], l[s * nk + q * rq.k + i]);
+      const size_t m = std::min<size_t>(all.size(), rq.k);
+      std::partial_sort(all.begin(), all.begin() + m, all.end());
+      out_n[q] = m;
+      for (size_t i = 0; i < m; ++i) { out_dist[q * rq.k + i] = all[i].first; out_label[q * rq.k + i] = all[i].second; }
+    }
+    return Status::Ok();
+  }
+
+  std::vector<int> devices_;
+  std::vector<std::unique_ptr<Index>> shards_;
+  std::vector<uint64_t> shard_cap_;
+  std::shared_mutex rw_;                              // route_, counts_, capacity_
+  std::unordered_map<uint64_t, uint32_t> route_;      // label -> shard
+  std::vector<uint64_t> counts_;                      // labels routed to each shard
+  uint64_t capacity_;
+  std::mutex grow_mu_;
+  std::mutex ctx_mu_;
+  std::condition_variable ctx_cv_;
+  std::vector<MultiCtx *> free_;
+  std::vector<std::unique_ptr<MultiCtx>> all_;
+};
+
+// ---- persistence ---------------------------------------------------------------------------------------------
+// FLAT: ONE stream in the reference's layout (bruteforce.h:147-207): a header with the totals, then every shard's
+// element chunks -- any BruteforceSearch::LoadIndex reads it, and any shard count loads it back.
+// HNSW: one graph per shard cannot be one hnswlib stream; the shards' own streams follow a marker chunk
+// ("VKSHARDS", shard count).  A plain single-graph stream loads too: its rows are re-inserted.
+namespace {
+struct SkipHeader {
+  vk_write_chunk_fn fn;
+  void *user;
+  bool first = true;
+};
+int skip_header_cb(void *u, const void *data, uint64_t len) {
+  SkipHeader *s = static_cast<SkipHeader *>(u);
+  if (s->first) { s->first = false; return 0; }
+  return s->fn(s->user, data, len);
+}
+}  // namespace
+
+Status ShardedIndex::save(vk_write_chunk_fn fn, void *user) {
+  if (params_.algo == VK_ALGO_FLAT) {
+    vk_index_stats t;
+    VK_TRY(stats(&t));
+    std::string hdr;
+    pb_put_varint_field(hdr, 1, t.capacity);
+    pb_put_varint_field(hdr, 2, (uint64_t)params_.dim * 4 + 8);
+    pb_put_varint_field(hdr, 3, t.count);
+    if (fn(user, hdr.data(), hdr.size())) return Status::Err(VK_ERR_INTERNAL, "write_chunk failed");
+    for (auto &s : shards_) {
+      SkipHeader sh{fn, user};
+      VK_TRY(s->save(skip_header_cb, &sh));
+    }
+    return Status::Ok();
+  }
+  char marker[16] = {0};
+  memcpy(marker, kShardMagic, 8);
+  const uint64_t S = shards_.size();
+  memcpy(marker + 8, &S, 8);
+  if (fn(user, marker, sizeof marker)) return Status::Err(VK_ERR_INTERNAL, "write_chunk failed");
+  for (auto &s : shards_) VK_TRY(s->save(fn, user));
+  return Status::Ok();
+}
+
+Status ShardedIndex::load_from(vk_read_chunk_fn fn, void *user) {
+  const uint32_t dim = params_.dim;
+  const size_t vec = (size_t)dim * 4;
+  std::vector<char> buf(std::max<size_t>(vec + 8 + 4 + 8 * 10000 + 4096, 1 << 16));
+  uint64_t len = 0;
+  if (fn(user, buf.data(), buf.size(), &len)) return Status::Err(VK_ERR_INTERNAL, "read_chunk failed");
+  if (params_.algo == VK_ALGO_HNSW && len == 16 && memcmp(buf.data(), kShardMagic, 8) == 0) {
+    uint64_t S;
+    memcpy(&S, buf.data() + 8, 8);
+    if (S != shards_.size()) return Status::Err(VK_ERR_INVALID, "the stream holds a different number of HNSW shards than the index definition");
+    for (size_t s = 0; s < shards_.size(); ++s) {
+      vk_index_params sp = params_;
+      sp.n_shards = 0;
+      sp.device_id = devices_[s];
+      sp.initial_cap = shard_cap_[s];
+      std::unique_ptr<Index> sub;
+      VK_TRY(load_hnsw(sp, fn, user, &sub));
+      shards_[s] = std::move(sub);
+      // rebuild the routes from what the shard holds: its saved labels come back through a save into a collector
+      struct Collect { ShardedIndex *self; uint32_t shard; size_t vec, sl0; uint64_t n = 0, seen = 0; bool hdr = true; } c{this, (uint32_t)s, vec, 0};
+      vk_index_stats t;
+      VK_TRY(shards_[s]->stats(&t));
+      c.n = t.count;
+      c.sl0 = ((size_t)params_.m * 2 + 1) * 4;
+      auto cb = [](void *u, const void *data, uint64_t l) -> int {
+        Collect *c = static_cast<Collect *>(u);
+        if (c->hdr) { c->hdr = false; return 0; }
+        if (c->seen < c->n && l == c->sl0 + c->vec + 8) {
+          uint64_t lab;
+          memcpy(&lab, static_cast<const char *>(data) + c->sl0 + c->vec, 8);
+          if (c->self->route_.emplace(lab, c->shard).second) c->self->counts_[c->shard]++;
+          c->seen++;
+        }
+        return 0;
+      };
+      VK_TRY(shards_[s]->save(cb, &c));
+      shard_cap_[s] = std::max<uint64_t>(shard_cap_[s], t.capacity);
+    }
+    return Status::Ok();
+  }
+  // a single stream: FLAT elements (or the rows of one HNSW graph) dealt out to the shards
+  uint64_t f[16] = {0};
+  {
+    PbReader r{reinterpret_cast<const uint8_t *>(buf.data()), reinterpret_cast<const uint8_t *>(buf.data()) + len};
+    uint32_t field, wire;
+    uint64_t val;
+    while (r.next(&field, &wire, &val))
+      if (field < 16 && wire == 0) f[field] = val;
+  }
+  const bool hnsw = params_.algo == VK_ALGO_HNSW;
+  const uint64_t count = f[3];
+  const size_t sl0 = hnsw ? ((size_t)params_.m * 2 + 1) * 4 : 0;
+  const size_t elem = sl0 + vec + 8;
+  if (!hnsw && f[2] != vec + 8) return Status::Err(VK_ERR_INTERNAL, "Persisted size_per_element does not match expectation.");
+  if (hnsw && f[4] != elem) return Status::Err(VK_ERR_INTERNAL, "HNSW index load validation failed: serialized element size is inconsistent with the geometry");
+  capacity_ = std::max<uint64_t>(capacity_, std::max<uint64_t>(hnsw ? f[2] : f[1], count));
+  if (buf.size() < elem) buf.resize(elem);
+  const uint64_t group = std::max<uint64_t>(1, ((uint64_t)64 << 20) / vec);
+  std::vector<float> rows;
+  std::vector<uint64_t> labs;
+  auto flush_group = [&]() -> Status {
+    if (labs.empty()) return Status::Ok();
+    Status st = add_batch(labs.data(), rows.data(), labs.size());
+    rows.clear();
+    labs.clear();
+    return st;
+  };
+  for (uint64_t i = 0; i < count; ++i) {
+    if (fn(user, buf.data(), buf.size(), &len) || len != elem) return Status::Err(VK_ERR_INTERNAL, "truncated element chunk");
+    if (hnsw && (reinterpret_cast<const uint32_t *>(buf.data())[0] & 0x00010000u)) continue;   // tombstoned: not re-inserted
+    uint64_t lab;
+    memcpy(&lab, buf.data() + sl0 + vec, 8);
+    labs.push_back(lab);
+    const float *v = reinterpret_cast<const float *>(buf.data() + sl0);
+    rows.insert(rows.end(), v, v + dim);
+    if (labs.size() >= group) VK_TRY(flush_group());
+  }
+  VK_TRY(flush_group());
+  if (hnsw) {   // drain the upper-level section of the graph that is not taken over
+    for (uint64_t i = 0; i < count; ++i) {
+      if (fn(user, buf.data(), buf.size(), &len) || len != 8) return Status::Err(VK_ERR_INTERNAL, "HNSW index load validation failed: link-list size chunk has the wrong size");
+      uint64_t sz;
+      memcpy(&sz, buf.data(), 8);
+      if (!sz) continue;
+      if (buf.size() < sz) buf.resize(sz);
+      if (fn(user, buf.data(), buf.size(), &len) || len != sz) return Status::Err(VK_ERR_INTERNAL, "HNSW index load validation failed: upper-level link-list chunk has the wrong size");
+    }
+  }
+  return flush();
+}
+
+static Status shard_devices(const vk_index_params &p, std::vector<int> *devices) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return Status::Err(VK_ERR_NO_DEVICE, "no HIP device: libvkindex needs a gfx950 GPU (no CPU fallback)");
+  if (p.n_shards > kMaxShards) return Status::Err(VK_ERR_INVALID, "n_shards out of range");
+  for (uint32_t s = 0; s < p.n_shards; ++s) {
+    int d = p.shard_devices[s];
+    if (d < 0 && hipGetDevice(&d) != hipSuccess) d = 0;
+    if (d >= n) return Status::Err(VK_ERR_INVALID, "shard_devices: device out of range");
+    devices->push_back(d);
+  }
+  return Status::Ok();
+}
+
+Status create_sharded(const vk_index_params &p, std::unique_ptr<Index> *out) {
+  std::vector<int> devices;
+  VK_TRY(shard_devices(p, &devices));
+  auto ix = std::make_unique<ShardedIndex>(p, devices);
+  VK_TRY(ix->init());
+  *out = std::move(ix);
+  return Status::Ok();
+}
+
+Status load_sharded(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std::unique_ptr<Index> *out) {
+  std::vector<int> devices;
+  VK_TRY(shard_devices(p, &devices));
+  auto ix = std::make_unique<ShardedIndex>(p, devices);
+  VK_TRY(ix->init());
+  VK_TRY(ix->load_from(fn, user));
+  *out = std::move(ix);
+  return Status::Ok();
+}
+
+}  // namespace vk

@@ -49,6 +49,7 @@ vk::Status check_params(const vk_index_params *p) {
   if (p->dim == 0 || p->dim > 64000) return vk::Status::Err(VK_ERR_INVALID, "dimension out of range");
   if (p->initial_cap >= (1ull << 32)) return vk::Status::Err(VK_ERR_INVALID, "initial_cap out of range");
   if (p->algo == VK_ALGO_HNSW && (p->m < 2 || p->m > 10000)) return vk::Status::Err(VK_ERR_INVALID, "M out of range");
+  if (p->n_shards > VK_MAX_SHARDS) return vk::Status::Err(VK_ERR_INVALID, "n_shards out of range");
   return vk::Status::Ok();
 }
 }  // namespace
@@ -69,7 +70,8 @@ int vk_index_create(const vk_index_params *params, vk_index **out) {
   return guarded([&]() -> vk::Status {
     VK_TRY(check_params(params));
     std::unique_ptr<vk::Index> impl;
-    if (params->algo == VK_ALGO_FLAT) VK_TRY(vk::create_flat(*params, &impl));
+    if (params->n_shards >= 1) VK_TRY(vk::create_sharded(*params, &impl));
+    else if (params->algo == VK_ALGO_FLAT) VK_TRY(vk::create_flat(*params, &impl));
     else VK_TRY(vk::create_hnsw(*params, &impl));
     *out = new vk_index;
     (*out)->impl = std::move(impl);
@@ -232,6 +234,24 @@ int vk_index_commit_device_rows(vk_index *ix, uint64_t n_rows, const uint64_t *l
   return guarded([&] { return ix->impl->commit_device_rows(n_rows, labels); });
 }
 
+int vk_index_shard_count(vk_index *ix, uint32_t *out_n) {
+  VK_NEED(ix);
+  if (!out_n) return fail(VK_ERR_INVALID, "out_n is NULL");
+  *out_n = ix->impl->shard_count();
+  return VK_OK;
+}
+
+int vk_index_shard_device_rows(vk_index *ix, uint32_t shard, uint64_t n_rows, void **d_rows, uint64_t *row_stride_bytes) {
+  VK_NEED(ix);
+  if (!d_rows || !row_stride_bytes) return fail(VK_ERR_INVALID, "NULL argument");
+  return guarded([&] { return ix->impl->shard_device_rows(shard, n_rows, d_rows, row_stride_bytes); });
+}
+
+int vk_index_shard_commit_device_rows(vk_index *ix, uint32_t shard, uint64_t n_rows, const uint64_t *labels) {
+  VK_NEED(ix);
+  return guarded([&] { return ix->impl->shard_commit_device_rows(shard, n_rows, labels); });
+}
+
 int vk_merge_topk_device(const float *d_dist, const uint64_t *d_label, uint32_t parts, uint64_t nq, uint64_t k,
                          float *d_out_dist, uint64_t *d_out_label, uint32_t *d_out_n, int device_id,
                          void *hip_stream) {
@@ -268,7 +288,8 @@ int vk_index_load(const vk_index_params *params, vk_read_chunk_fn read_chunk, vo
   return guarded([&]() -> vk::Status {
     VK_TRY(check_params(params));
     std::unique_ptr<vk::Index> impl;
-    if (params->algo == VK_ALGO_FLAT) VK_TRY(vk::load_flat(*params, read_chunk, user, &impl));
+    if (params->n_shards >= 1) VK_TRY(vk::load_sharded(*params, read_chunk, user, &impl));
+    else if (params->algo == VK_ALGO_FLAT) VK_TRY(vk::load_flat(*params, read_chunk, user, &impl));
     else VK_TRY(vk::load_hnsw(*params, read_chunk, user, &impl));
     *out = new vk_index;
     (*out)->impl = std::move(impl);
