@@ -386,6 +386,165 @@ def hnsw_sharded_leg(args, flat_ix, table, A, device, stream_ptr, world, rank, r
             "recall_at_10": round(recall, 4), "merge": "all-gather + (distance,label) merge on every rank"}
 
 
+def lib_multi_gpu(args, world, rank, local_rank, dist, device):
+    """--gpus N through the PRODUCT's multi-GPU path: rank 0 holds ONE vk_index with n_shards = N (shard s on HIP device
+    s; vk_index_params.shard_devices), built and searched from this one process like valkey-server would; the other
+    ranks only keep the launch contract (barriers, max-over-ranks timing).  A step = one
+    vk_index_search_batch_device on the sharded index: queries broadcast by peer copy, every shard scans its rows on its
+    own device and stream, per-shard top-k lists gathered on device 0, (distance,label) merge.  Returns the JSON dict
+    on rank 0 (None elsewhere), or raises on rank 0 before any collective if the sharded index cannot be set up."""
+    N, D, B, K = args.rows, args.dim, args.batch, args.k
+    bf16 = args.dtype == "bf16"
+    esz = 2 if bf16 else 4
+    devs = [0] * world if args.same_device else list(range(world))
+    out = None
+    state = {}
+    ok = torch.ones(1, device=device if args.backend == "nccl" else "cpu")
+    if rank == 0:
+        try:
+            if vsa.lib().vk_device_count() < (1 if args.same_device else world):
+                raise RuntimeError(f"rank 0 sees {vsa.lib().vk_device_count()} HIP devices, needs {world}")
+            t_build = time.time()
+            ix = vsa.Index("FLAT", D, "COSINE", initial_cap=N, dtype=args.dtype, shard_devices=devs)
+            for s_i, dv in enumerate(devs):
+                r0, r1 = s_i * N // world, (s_i + 1) * N // world
+                sdev = torch.device("cuda", dv)
+                ptr, stride = ix.shard_device_rows(s_i, r1 - r0)
+                if bf16:
+                    tab = device_view_typed(ptr, (r1 - r0, stride // 2), sdev, "<i2").view(torch.bfloat16)
+                else:
+                    tab = device_view(ptr, (r1 - r0, stride // 4), sdev)
+                if stride != D * esz:
+                    tab[:, D:] = 0
+                for lo, x in gen_rows(r0, r1 - r0, D, sdev):
+                    tab[lo - r0: lo - r0 + x.shape[0], :D] = x
+                torch.cuda.synchronize(sdev)
+                ix.shard_commit_device_rows(s_i, r1 - r0, np.arange(r0, r1, dtype=np.uint64))
+            state["build_s"] = time.time() - t_build
+            gA = torch.Generator(device=device)
+            gA.manual_seed(1234)
+            A = torch.randn(D, 32, generator=gA, device=device, dtype=torch.float32)
+            Q = make_queries(A, B, D, device, 4242)
+            od = torch.empty(B, K, device=device, dtype=torch.float32)
+            ol = torch.empty(B, K, device=device, dtype=torch.int64)
+            on = torch.empty(B, device=device, dtype=torch.int32)
+            ws = torch.cuda.Stream(device=device)
+            torch.cuda.set_stream(ws)
+            state.update(ix=ix, A=A, Q=Q, od=od, ol=ol, on=on, ws=ws)
+
+            def step():
+                ix.search_batch_device(Q.data_ptr(), B, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), stream=ws.cuda_stream)
+
+            for _ in range(max(1, args.warmup)):
+                step()
+            torch.cuda.synchronize()
+            state["step"] = step
+        except Exception as e:   # noqa: BLE001
+            ok.zero_()
+            state["error"] = f"{type(e).__name__}: {e}"
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) == 0.0:
+        if rank == 0:
+            print(f"bench: library multi-GPU path unavailable ({state.get('error')}); falling back to one process per GPU",
+                  file=sys.stderr)
+        state.clear()
+        torch.cuda.empty_cache()
+        return "fallback"
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    if rank == 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            state["step"]()
+        e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        ix, Q, od, ol = state["ix"], state["Q"], state["od"], state["ol"]
+        dev_ms = e0.elapsed_time(e1) / args.steps
+        res_d, res_l = od.cpu().numpy(), ol.cpu().numpy().view(np.uint64)
+        verify = None
+        if args.verify_merge:   # the N-shard answer must be bit-identical to the 1-shard answer
+            full = vsa.Index("FLAT", D, "COSINE", initial_cap=N, device_id=0, dtype=args.dtype)
+            fp, fstride = full.device_rows(N)
+            ft = (device_view_typed(fp, (N, fstride // 2), device, "<i2").view(torch.bfloat16) if bf16
+                  else device_view(fp, (N, fstride // 4), device))
+            if fstride != D * esz:
+                ft[:, D:] = 0
+            for lo, x in gen_rows(0, N, D, device):
+                ft[lo: lo + x.shape[0], :D] = x
+            torch.cuda.synchronize()
+            full.commit_device_rows(N, np.arange(N, dtype=np.uint64))
+            fd, fl, fn = full.search_batch(Q.cpu().numpy(), K)
+            same = bool((fl == res_l).all() and (fd.view(np.uint32) == res_d.view(np.uint32)).all())
+            verify = "bit-identical" if same else "MISMATCH"
+            del full
+        hnsw = None
+        if args.hnsw_sharded and args.hnsw_rows > 0 and not bf16:
+            # one HNSW graph per shard inside ONE index; recall against the sharded FLAT answer over the same rows
+            Nh = min(args.hnsw_rows, N)
+            nq = min(args.hnsw_queries, 2048)
+            Qh = make_queries(state["A"], nq, D, device, 9090)
+            rows = torch.cat([x for _, x in gen_rows(0, Nh, D, device)])[:Nh]
+            host_rows = np.ascontiguousarray(rows.cpu().numpy())
+            del rows
+            t1 = time.perf_counter()
+            h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=args.hnsw_ef, shard_devices=devs)
+            h.add_batch(host_rows)
+            h.flush()
+            hb = time.perf_counter() - t1
+            hd = torch.empty(nq, K, device=device, dtype=torch.float32)
+            hl = torch.empty(nq, K, device=device, dtype=torch.int64)
+            hn = torch.empty(nq, device=device, dtype=torch.int32)
+            ms = timed(lambda: h.search_batch_device(Qh.data_ptr(), nq, K, hd.data_ptr(), hl.data_ptr(), hn.data_ptr(),
+                                                     ef=args.hnsw_ef, stream=state["ws"].cuda_stream), 3)
+            from oracle import oracle as O
+            bits = O.allow_bitmap(np.arange(Nh, dtype=np.uint64), Nh) if Nh < N else None
+            gt = np.empty((nq, K), np.uint64)
+            hq = Qh.cpu().numpy()
+            for i in range(0, nq, 256):
+                _, L, _ = ix.search_batch(hq[i:i + 256], K, allow=bits, allow_nbits=Nh if bits is not None else None)
+                gt[i:i + 256] = L
+            hnsw = {"shards": world, "rows_per_shard": Nh // world, "rows": Nh, "M": 16, "ef_construction": 200, "ef": args.hnsw_ef,
+                    "k": K, "queries_per_batch": nq, "build_s": round(hb, 2), "gpu_qps": round(nq / (ms * 1e-3), 1),
+                    "recall_at_10": round(recall_of(hl.cpu().numpy().view(np.uint64), gt, K), 4),
+                    "merge": "one graph per shard inside one vk_index; per-shard top-k gathered on device 0, (distance,label) merge"}
+        qps = B * args.steps / dt
+        n_local = N // world
+        stride = ((D + 63) // 64) * 64 * esz
+        flops = 2.0 * N * D * B
+        out = {"metric": BASELINE_METRIC if not bf16 else "kNN queries/sec, FLAT 10Mx768 bf16-stored cosine k=10 batch=256",
+               "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "row_storage": args.dtype, "data": "synthetic",
+               "config": {"workload": f"FLAT {N}x{D} {'bf16 rows' if bf16 else 'fp32'} COSINE k={K} batch={B} (BASELINE.json configs[1])",
+                          "rows_per_gpu": n_local, "sharding": f"rows/{world}", "recall_at_10": 1.0,
+                          "parallelism": f"one vk_index with n_shards={world} in ONE process (rank 0): queries broadcast by peer copy, "
+                                         f"per-shard top-k gathered on device 0, (distance,label) merge; ranks 1..{world - 1} idle",
+                          "devices": devs, "verify_merge": verify},
+               "roofline": {"bound": "mfma", "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 3), "peak": F32_MFMA_PEAK_TF * world,
+                            "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF * world), 5),
+                            "traffic": None, "kernel": "flat_gemm_kernel (per shard)", "per_launch_ms": round(dev_ms, 4),
+                            "algorithmic_bytes": n_local * stride},
+               "cpu_baseline": None, "hnsw": hnsw, "build_s": round(state["build_s"], 2)}
+        print(json.dumps(out))
+        if verify is not None:
+            print(json.dumps({"verify_merge": verify, "shards": world, "rows": N}))
+            assert verify == "bit-identical"
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
 def coalescer_leg(ix, hq, K, threads=64, per_thread=4):
     """N1: the reference issues one query per FT.SEARCH from a pool of reader threads (search.cc:886-910).
     `threads` callers each issue `per_thread` single-query vk_index_search calls, first one at a time per
@@ -492,6 +651,9 @@ def main():
     ap.add_argument("--hnsw-sharded", action="store_true",
                     help="N > 1: also run the sharded HNSW leg (one graph per rank; extra collectives after the timed region)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--multi-gpu", choices=["lib", "ranks"], default="lib",
+                    help="N > 1: 'lib' = the product's own multi-GPU index (n_shards = N inside one process, rank 0), falling back to "
+                         "'ranks' = one process per GPU, each with its shard, RCCL all-gather of the per-shard top-k + device merge")
     ap.add_argument("--same-device", action="store_true",
                     help="test aid: every rank uses cuda:0 (with --backend gloo, two ranks can exercise the sharded path on one GPU)")
     ap.add_argument("--verify-merge", action="store_true",
@@ -517,6 +679,9 @@ def main():
         args.hnsw_rows = N
     if args.bf16_rows < 0:
         args.bf16_rows = N
+    if world > 1 and args.multi_gpu == "lib":
+        if lib_multi_gpu(args, world, rank, local_rank, dist, device) != "fallback":
+            return
     r0 = rank * N // world
     r1 = (rank + 1) * N // world
     n_local = r1 - r0
