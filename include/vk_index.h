@@ -108,6 +108,11 @@ typedef struct vk_index_stats {
    * non-zero count fails the call with VK_ERR_INTERNAL) */
   uint64_t last_frontier_redo;
   uint64_t last_frontier_dropped;
+  /* batched FLAT searches through the f16 candidate filter + exact re-rank (host entry points only): survivors of the
+   * most recent batch summed over its queries (0 = the batch did not take that path), and whether a survivor list
+   * overflowed so that the exact matrix-core kernel answered instead */
+  uint64_t last_filter_candidates;
+  uint64_t last_filter_fallback;
   /* query coalescer (vk_index_set_coalescing): device batches run / single queries they carried */
   uint64_t coalesced_batches;
   uint64_t coalesced_queries;

@@ -1,0 +1,162 @@
+"""K4h: batched FLAT through the f16 matrix-core candidate filter + exact re-rank (flat_filter.hip).
+
+The filter only decides WHICH rows get an exact distance; the distances and the selection are the exact path's.  So the
+answer must be bit-identical (ids and distance bits, ties by label) to the exact matrix-core kernel and to the oracle,
+for every shape the pipeline branches on -- and when the filter cannot bound its error or its survivor lists overflow,
+the exact kernel enqueued behind it must take over (decided on the device).  vk_index_stats says which happened."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vsa():
+    import _pkg
+    return _pkg.vsa
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+SMALL = dict(VK_FILTER_PREPASS=4096, VK_FILTER_MIN_ROWS=32768)     # let mid-sized test indexes take the filter path
+
+
+def _pair(vsa, dim, metric, x, labels=None, **env):
+    with _Env(**{**SMALL, **env}):
+        f = vsa.Index("FLAT", dim, metric, initial_cap=len(x))
+    with _Env(VK_FLAT_FILTER=0):
+        e = vsa.Index("FLAT", dim, metric, initial_cap=len(x))
+    f.add_batch(x, labels)
+    e.add_batch(x, labels)
+    return f, e
+
+
+def _same(a, b):
+    (ad, al, an), (bd, bl, bn) = a, b
+    assert an.tolist() == bn.tolist()
+    assert (al == bl).all()
+    assert (ad.view(np.uint32) == bd.view(np.uint32)).all()
+
+
+def _unit(x):
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("dim", [64, 96, 200, 768])          # 1, 2, 4 and 12 pipeline stages per row tile
+def test_filter_path_equals_exact_path_and_oracle(vsa, oracle, dim):
+    rng = np.random.default_rng(dim)
+    n = 60_000 if dim < 768 else 40_000
+    # clustered rows: plenty of near neighbours within the filter's margin of each other
+    centres = rng.standard_normal((50, dim)).astype(np.float32)
+    x = _unit(centres[rng.integers(0, 50, n)] + 0.3 * rng.standard_normal((n, dim)).astype(np.float32))
+    f, e = _pair(vsa, dim, "COSINE", x)
+    Q = _unit(centres[rng.integers(0, 50, 300)] + 0.3 * rng.standard_normal((300, dim)).astype(np.float32))
+    for nq in (33, 64, 100, 256, 300):
+        for k in (1, 10, 64):
+            got = f.search_batch(Q[:nq], k)
+            st = f.stats()
+            assert st.last_filter_candidates >= nq * k and st.last_filter_fallback == 0, (nq, k, st.last_filter_candidates)
+            _same(got, e.search_batch(Q[:nq], k))
+            assert e.stats().last_filter_candidates == 0
+    o = oracle.Flat(dim, "COSINE", max_elements=n)
+    o.add_many(x)
+    D, L, N = f.search_batch(Q[:40], 10)
+    for i in range(40):
+        od, ol = o.search(Q[i], 10)
+        assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+    # small batches stay on the exact kernels
+    f.search_batch(Q[:32], 10)
+    assert f.stats().last_filter_candidates == 0
+
+
+def test_filter_with_allow_bitmap_and_unnormalised_ip(vsa, oracle):
+    rng = np.random.default_rng(77)
+    n, dim = 80_000, 128
+    x = (rng.standard_normal((n, dim)) * rng.uniform(0.05, 4.0, (n, 1))).astype(np.float32)    # norms from 0.5 to 45
+    labels = rng.permutation(4 * n)[:n].astype(np.uint64)
+    f, e = _pair(vsa, dim, "IP", x, labels)
+    Q = (rng.standard_normal((128, dim)) * rng.uniform(0.1, 3.0, (128, 1))).astype(np.float32)
+    _same(f.search_batch(Q, 10), e.search_batch(Q, 10))
+    assert f.stats().last_filter_candidates > 0
+    nb = int(labels.max()) + 1
+    bits = oracle.allow_bitmap(labels[rng.random(n) < 0.25], nb)
+    _same(f.search_batch(Q, 10, allow=bits, allow_nbits=nb), e.search_batch(Q, 10, allow=bits, allow_nbits=nb))
+    st = f.stats()
+    assert st.last_filter_candidates > 0 and st.last_filter_fallback == 0
+    # a filter so selective that the sample holds fewer than k allowed rows: no bound, every row survives, the lists
+    # overflow -- the exact kernel answers
+    few = oracle.allow_bitmap(labels[rng.random(n) < 0.0005], nb)
+    _same(f.search_batch(Q, 10, allow=few, allow_nbits=nb), e.search_batch(Q, 10, allow=few, allow_nbits=nb))
+    assert f.stats().last_filter_fallback == 1
+
+
+def test_survivor_overflow_falls_back_to_the_exact_kernel(vsa, oracle):
+    """40 000 copies of one vector: every copy is within the filter's margin of the k-th best, far more than a survivor
+    list holds.  The answer (ties broken by label) must still be the exact one."""
+    rng = np.random.default_rng(5)
+    n, dim = 70_000, 64
+    x = _unit(rng.standard_normal((n, dim)).astype(np.float32))
+    x[10_000:50_000] = x[7]
+    labels = rng.permutation(n).astype(np.uint64)
+    f, e = _pair(vsa, dim, "COSINE", x, labels)
+    Q = np.vstack([x[7:8] + 0.01 * rng.standard_normal((40, dim)).astype(np.float32), rng.standard_normal((60, dim)).astype(np.float32)])
+    Q = _unit(Q)
+    got = f.search_batch(Q, 10)
+    assert f.stats().last_filter_fallback == 1
+    _same(got, e.search_batch(Q, 10))
+    # only queries far from the duplicated vector: no overflow, same index
+    got = f.search_batch(Q[40:], 10)
+    assert f.stats().last_filter_fallback == 0 and f.stats().last_filter_candidates > 0
+    _same(got, e.search_batch(Q[40:], 10))
+
+
+def test_inputs_outside_the_f16_range_fall_back(vsa, oracle):
+    rng = np.random.default_rng(6)
+    n, dim = 50_000, 64
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[123, 5] = 1.0e6                                   # does not fit f16
+    f, e = _pair(vsa, dim, "IP", x)
+    Q = rng.standard_normal((64, dim)).astype(np.float32)
+    got = f.search_batch(Q, 10)
+    assert f.stats().last_filter_fallback == 1
+    _same(got, e.search_batch(Q, 10))
+    # a huge QUERY among ordinary ones (rows fine)
+    x[123, 5] = 1.0
+    f2, e2 = _pair(vsa, dim, "IP", x)
+    Q[3, 0] = 5.0e5
+    got = f2.search_batch(Q, 10)
+    assert f2.stats().last_filter_fallback == 1
+    _same(got, e2.search_batch(Q, 10))
+
+
+def test_filter_sees_mutations(vsa, oracle):
+    """rows added, overwritten and removed between batches: the row statistics and the answers follow"""
+    rng = np.random.default_rng(8)
+    n, dim = 50_000, 64
+    x = _unit(rng.standard_normal((n, dim)).astype(np.float32))
+    f, e = _pair(vsa, dim, "COSINE", x[:40_000])
+    Q = _unit(rng.standard_normal((64, dim)).astype(np.float32))
+    _same(f.search_batch(Q, 10), e.search_batch(Q, 10))
+    for ix in (f, e):
+        ix.add_batch(x[40_000:], np.arange(40_000, n, dtype=np.uint64))
+        for lab in range(0, 3000, 7):
+            ix.remove(lab)
+        ix.add(5, 3.0 * x[5])                             # a longer row: the norm bound must grow with it
+    _same(f.search_batch(Q, 10), e.search_batch(Q, 10))
+    assert f.stats().last_filter_candidates > 0 and f.stats().last_filter_fallback == 0

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <queue>
 #include <thread>
@@ -102,7 +103,8 @@ SearchCtx::~SearchCtx() {
   if (has_busy) (void)hipEventSynchronize(busy);
   if (busy) (void)hipEventDestroy(busy);
   if (stream) (void)hipStreamSynchronize(stream);
-  for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats, &d_sync, &d_pool, &d_pool2, &d_redo})
+  for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats, &d_sync, &d_pool, &d_pool2, &d_redo,
+                    &d_fq16, &d_fthr, &d_fcnt, &d_fcand, &d_fpart_d, &d_fpart_l})
     b->release();
   for (PinBuf *b : {&h_q, &h_out_d, &h_out_l, &h_out_n, &h_tmp, &h_idx, &h_cancel}) b->release();
   if (stream) (void)hipStreamDestroy(stream);
@@ -221,6 +223,10 @@ class FlatIndex final : public Index {
  public:
   explicit FlatIndex(const vk_index_params &p, int device)
       : Index(p), store_(device, p.dim, p.dtype == VK_DTYPE_BF16), pool_(device), capacity_(p.initial_cap) {}
+  ~FlatIndex() override {
+    (void)hipSetDevice(store_.device());
+    d_rowstats_.release();
+  }
 
   Status add(uint64_t label, const float *row) override {
     std::unique_lock<std::shared_mutex> lk(rw_);
@@ -298,6 +304,7 @@ class FlatIndex final : public Index {
     }
     CtxLease lease(pool_);
     SearchCtx *ctx = lease.ctx;
+    filter_used_ = false;
     VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f()));
     const uint64_t *d_allow = nullptr;
     VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
@@ -318,7 +325,21 @@ class FlatIndex final : public Index {
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (filter_used_) {   // survivor counts + the overflow flag of the candidate filter, for vk_index_stats
+      VK_TRY(ctx->h_tmp.ensure(rq.nq * 4 + 4));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_fcnt.p, rq.nq * 4 + 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     VK_TRY(ctx->wait(rq.cancel_flag));   // (a raised flag stops the kernels: the answer is what they had, bruteforce.h:129)
+    if (filter_used_) {
+      const uint32_t *c = ctx->h_tmp.as<uint32_t>();
+      uint64_t sum = 0;
+      for (uint64_t q = 0; q < rq.nq; ++q) sum += c[q];
+      last_filter_cands_ = sum;
+      last_filter_fallback_ = c[rq.nq];
+    } else {
+      last_filter_cands_ = 0;
+      last_filter_fallback_ = 0;
+    }
     // caller's buffers are [nq][rq.k]
     for (uint64_t q = 0; q < rq.nq; ++q) {
       uint32_t n = ctx->h_out_n.as<uint32_t>()[q];
@@ -432,6 +453,8 @@ class FlatIndex final : public Index {
     out->host_bytes = store_.host_bytes() + slot_of_.size() * 24;
     out->staged_ops = store_.staged_ops();
     out->max_level = -1;
+    out->last_filter_candidates = last_filter_cands_;
+    out->last_filter_fallback = last_filter_fallback_;
     return Status::Ok();
   }
 
@@ -460,6 +483,7 @@ class FlatIndex final : public Index {
       store_.stage_label((uint32_t)i, lab);
     }
     count_ = n;
+    store_.note_written(0, n);   // (the caller filled the rows on the device)
     return store_.flush();
   }
 
@@ -498,6 +522,15 @@ class FlatIndex final : public Index {
     int e = flat_scan_slots_per_lane(k);
     if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 needs the host entry points (vk_index_search / _batch), which page through the result in passes");
     const uint32_t chunks = store_.stride_f() / 16;
+    // K4h + exact re-rank: a batch large enough that the exact matrix-core kernel is the bottleneck, an index large
+    // enough that the pre-pass sample is a small part of it
+    if (!lb_dist_ && nq >= filter_min_queries_ && !(cancel && *cancel) && !force_scan_ && filter_enabled_ &&
+        flat_filter_supported(store_.stride_f(), k, store_.bf16(), l2()) && flat_gemm_supported(store_.stride_f(), k) &&
+        count >= 8 * filter_prepass_rows(k) && count >= filter_min_rows_) {
+      const uint32_t *d_cancel = cancel_word;
+      if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
+      return scan_filter(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel);
+    }
     // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
     if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !(cancel && *cancel) && flat_gemm_supported(store_.stride_f(), k) && !force_scan_) {
       const uint32_t *d_cancel = cancel_word;
@@ -618,14 +651,15 @@ class FlatIndex final : public Index {
   // K4 launch: persistent grid of ~one block per CU, nrp row partitions x nqt query tiles of 32
   Status scan_gemm(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
                    uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
-                   uint64_t out_ld = 0, const uint32_t *d_cancel = nullptr) {
+                   uint64_t out_ld = 0, const uint32_t *d_cancel = nullptr, const float *bound_given = nullptr,
+                   const uint32_t *run_flag = nullptr, uint32_t run_if = 0) {
     if (out_ld == 0) out_ld = k;
     // pre-pass (this kernel over the first rows): a valid bound on every query's k-th best distance, so the per-lane
     // lists of K4 start gated instead of accepting everything until they have filled
-    const float *init_bound = nullptr;
+    const float *init_bound = bound_given;   // (the candidate-filter path has run its own, larger, pre-pass)
     // (more rows for a larger k: the bound is the k-th best of the sample, and the lists of K4 pay per insert)
     const uint64_t pre_rows = gemm_prepass_rows_ * ((k + 9) / 10);
-    if (pre_rows && count >= 8 * pre_rows && !in_prepass_) {
+    if (!bound_given && pre_rows && count >= 8 * pre_rows && !in_prepass_) {
       in_prepass_ = true;   // the same kernel over the first rows only
       Status ps = scan_gemm(ctx, d_q, nq, k, pre_rows, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
       in_prepass_ = false;
@@ -662,6 +696,8 @@ class FlatIndex final : public Index {
     g.lockstep = g.nqt > 1 && g.nqt <= 32 ? gemm_lockstep_ : 0;
     g.contig = gemm_contig_;
     g.cancel = in_prepass_ ? nullptr : d_cancel;
+    g.run_flag = run_flag;
+    g.run_if = run_if;
     // [ progress words | per-query bounds ]
     const size_t sync_bytes = (size_t)nrp * 4 * 32 * 4;
     VK_TRY(ctx->d_sync.ensure(sync_bytes + nq * 4));
@@ -685,10 +721,158 @@ class FlatIndex final : public Index {
     m.out_dist = d_out_d;
     m.out_label = d_out_l;
     m.out_n = d_out_n;
+    m.run_flag = run_flag;
+    m.run_if = run_if;
     VK_HIP_TRY(launch_merge_topk(m, flat_scan_slots_per_lane(k), nq, s));
     return Status::Ok();
   }
 
+  // sample the exact kernel bounds the k-th best distance on, for the candidate filter: its survivors are about
+  // count * k / sample per query
+  uint64_t filter_prepass_rows(uint64_t k) const { return filter_prepass_rows_ * ((k + 9) / 10); }
+
+  // the largest row norm / element of the index, brought up to date for the rows written since the last call (once
+  // after a writer phase; the searches of a reader phase find nothing to do)
+  Status ensure_row_stats() {
+    std::lock_guard<std::mutex> g(stats_mu_);
+    uint64_t lo, hi;
+    const bool first = d_rowstats_.p == nullptr;
+    if (first) {
+      VK_TRY(d_rowstats_.ensure(64));
+      VK_HIP_TRY(hipMemsetAsync(d_rowstats_.p, 0, 64, store_.stream()));
+    }
+    if (store_.take_written(&lo, &hi) || first) {
+      if (first) { lo = 0; hi = count_; }
+      hi = std::min<uint64_t>(hi, store_.alloc_rows());
+      VK_HIP_TRY(launch_row_stats(store_.d_rows(), store_.bf16(), store_.stride_f(), (uint32_t)lo, (uint32_t)hi,
+                                  d_rowstats_.as<uint32_t>(), store_.stream()));
+      VK_HIP_TRY(hipStreamSynchronize(store_.stream()));
+    }
+    return Status::Ok();
+  }
+
+  // K4h pipeline (flat_filter.hip): exact pre-pass over a sample -> bound; f16 matrix-core filter over all rows ->
+  // survivor lists; exact re-rank of the survivors + selection.  Same answer as scan_gemm, bit for bit; when a survivor
+  // list overflows, the exact kernel enqueued behind runs instead (device-side flag, no host round trip).
+  Status scan_filter(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
+                     uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
+                     uint64_t out_ld, const uint32_t *d_cancel) {
+    VK_TRY(ensure_row_stats());
+    // 1. bound: the exact kernel over the first rows (answers land in the output arrays for a moment)
+    in_prepass_ = true;
+    Status ps = scan_gemm(ctx, d_q, nq, k, filter_prepass_rows(k), d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
+    in_prepass_ = false;
+    VK_TRY(ps);
+    VK_TRY(ctx->d_stats.ensure(std::max<size_t>(64, nq * 8)));
+    VK_HIP_TRY(launch_kth_bound(d_out_d, d_out_n, (uint32_t)k, (uint32_t)nq, ctx->d_stats.as<float>(), s));
+    const float *bound = ctx->d_stats.as<float>();
+    // 2. queries -> f16 fragments + gates
+    const uint32_t dp = store_.stride_f();
+    const uint32_t nqt = (uint32_t)((nq + 31) / 32);
+    const uint32_t cap = (uint32_t)std::max<uint64_t>(filter_cap_, 64 * k);
+    VK_TRY(ctx->d_fq16.ensure((size_t)nqt * 32 * dp * 2));
+    VK_TRY(ctx->d_fthr.ensure((size_t)nqt * 32 * 4));
+    VK_TRY(ctx->d_fcnt.ensure(nq * 4 + 4));
+    VK_TRY(ctx->d_fcand.ensure(nq * (size_t)cap * 4));
+    VK_HIP_TRY(hipMemsetAsync(ctx->d_fcnt.p, 0, nq * 4 + 4, s));
+    uint32_t *ovf = ctx->d_fcnt.as<uint32_t>() + nq;
+    FlatFilterArgs f{};
+    f.rows = store_.d_rows();
+    f.labels = store_.d_labels();
+    f.allow_bits = d_allow;
+    f.allow_nbits = allow_nbits;
+    f.queries = d_q;
+    f.q_stride_f = dp;
+    f.q16 = ctx->d_fq16.p;
+    f.thr = ctx->d_fthr.as<float>();
+    f.bound = bound;
+    f.row_stats = d_rowstats_.as<uint32_t>();
+    f.cand_cnt = ctx->d_fcnt.as<uint32_t>();
+    f.cand_row = ctx->d_fcand.as<uint32_t>();
+    f.cap = cap;
+    f.ovf = ovf;
+    f.row_stride_f = dp;
+    f.n_rows = (uint32_t)count;
+    f.nq = (uint32_t)nq;
+    f.nqt = nqt;
+    f.cancel = d_cancel;
+    VK_HIP_TRY(launch_flat_qprep(f, s));
+    // 3. the filter: one launch per 256 queries, every launch one pass over the rows
+    if (filter_blocks_ == 0) {
+      int cus = 0;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, store_.device());
+      filter_blocks_ = cus > 0 ? (uint32_t)cus : 256;
+    }
+    for (uint32_t g0 = 0; g0 < nqt; g0 += 8) {
+      FlatFilterArgs fg = f;
+      fg.nqt = std::min<uint32_t>(8, nqt - g0);
+      fg.nq = (uint32_t)std::min<uint64_t>(256, nq - (uint64_t)g0 * 32);
+      fg.q16 = static_cast<char *>(f.q16) + (size_t)g0 * 32 * dp * 2;
+      fg.thr = f.thr + (size_t)g0 * 32;
+      fg.cand_cnt = f.cand_cnt + (size_t)g0 * 32;
+      fg.cand_row = f.cand_row + (size_t)g0 * 32 * cap;
+      VK_HIP_TRY(launch_flat_filter(fg, filter_blocks_, s));
+    }
+    // 4. exact re-rank of the survivors (unless a list overflowed) ...
+    const int e = flat_scan_slots_per_lane(k);
+    const uint32_t nrp = 8;
+    const uint64_t per_q = (uint64_t)nrp * k;
+    VK_TRY(ctx->d_fpart_d.ensure(nq * per_q * 4));
+    VK_TRY(ctx->d_fpart_l.ensure(nq * per_q * 8));
+    FlatScanArgs r{};
+    r.rows = store_.d_rows();
+    r.labels = store_.d_labels();
+    r.queries = d_q;
+    r.allow_bits = d_allow;
+    r.allow_nbits = allow_nbits;
+    r.part_dist = ctx->d_fpart_d.as<float>();
+    r.part_label = ctx->d_fpart_l.as<uint64_t>();
+    r.row_stride_f = r.q_stride_f = dp;
+    r.chunks = dp / 16;
+    r.row_begin = 0;
+    r.row_end = (uint32_t)count;
+    r.nq = (uint32_t)nq;
+    r.k = (uint32_t)k;
+    r.nrp = nrp;
+    r.nqg = (uint32_t)nq;
+    r.cand_cnt = f.cand_cnt;
+    r.cand_row = f.cand_row;
+    r.cand_cap = cap;
+    r.run_flag = ovf;
+    r.run_if = 0;
+    VK_HIP_TRY(launch_flat_scan(r, l2(), store_.bf16(), 1, e, s));
+    MergeArgs m{};
+    m.in_dist = r.part_dist;
+    m.in_label = r.part_label;
+    m.part_stride = nq * per_q;
+    m.q_stride = per_q;
+    m.parts = 1;
+    m.per_part = (uint32_t)per_q;
+    m.k = (uint32_t)k;
+    m.out_ld = (uint32_t)out_ld;
+    m.out_dist = d_out_d;
+    m.out_label = d_out_l;
+    m.out_n = d_out_n;
+    m.run_flag = ovf;
+    m.run_if = 0;
+    VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
+    // 5. ... or the exact kernel over everything (only when the flag is up: its blocks return at once otherwise)
+    VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, bound, ovf, 1));
+    filter_used_ = true;
+    return Status::Ok();
+  }
+
+  // candidate filter (K4h): switches and sizes
+  bool filter_enabled_ = !(getenv("VK_FLAT_FILTER") && atoi(getenv("VK_FLAT_FILTER")) == 0);
+  uint64_t filter_min_queries_ = getenv("VK_FILTER_MIN_QUERIES") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_QUERIES")) : 33;
+  uint64_t filter_min_rows_ = getenv("VK_FILTER_MIN_ROWS") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_ROWS")) : 262144;
+  uint64_t filter_prepass_rows_ = getenv("VK_FILTER_PREPASS") ? (uint64_t)atoll(getenv("VK_FILTER_PREPASS")) : 65536;
+  uint64_t filter_cap_ = getenv("VK_FILTER_CAP") ? (uint64_t)atoll(getenv("VK_FILTER_CAP")) : 8192;
+  uint32_t filter_blocks_ = 0;
+  DevBuf d_rowstats_;
+  std::mutex stats_mu_;
+  std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0};
+  static thread_local bool filter_used_;
   static constexpr uint64_t kGemmMinQueries = 5;    // measured at 10Mx768: K3 4 queries 5.3 ms, 8 queries 11.7 ms; K4 up to 32 queries 6.1 ms
   static constexpr uint64_t kMaxPassK = 1024;
   // per-call lower bounds of search_in_passes (set only around its scan() calls, under the ctx lease)
@@ -711,6 +895,7 @@ class FlatIndex final : public Index {
 };
 
 thread_local bool FlatIndex::in_prepass_ = false;
+thread_local bool FlatIndex::filter_used_ = false;
 thread_local const float *FlatIndex::lb_dist_ = nullptr;
 thread_local const uint64_t *FlatIndex::lb_label_ = nullptr;
 

@@ -28,9 +28,11 @@ namespace vk {
 
 // kLb: the scan carries an exclusive lower bound (distance,label) per query (FlatIndex::search_in_passes, k > 1024:
 // always kQB == 1, kE == 16); without it the hot loop and the register budget do not pay for the paging feature
-template <int kQB, bool kL2, int kE, bool kBf16, bool kLb = false>
+// kIdx: re-rank mode (FlatScanArgs::cand_row): the rows of the block's one query come from its survivor list
+template <int kQB, bool kL2, int kE, bool kBf16, bool kLb = false, bool kIdx = false>
 __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   extern __shared__ float4 qs[];  // [kQB][chunks][4] float4 == kQB padded queries
+  if (a.run_flag && __hip_atomic_load(a.run_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.run_if) return;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 3;
@@ -68,15 +70,30 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
 
   const uint32_t total_waves = a.nrp * 4;   // nrp is a multiple of 8
   const uint32_t wave_gid = rp * 4 + wave;
-  const uint32_t n_rows = a.row_end - a.row_begin;
+  uint32_t n_rows = a.row_end - a.row_begin;
+  const uint32_t *cand = nullptr;
+  if constexpr (kIdx) {
+    const uint32_t q = qbase < a.nq ? qbase : a.nq - 1;
+    const uint32_t c = a.cand_cnt[q];
+    n_rows = c < a.cand_cap ? c : a.cand_cap;
+    cand = a.cand_row + (size_t)q * a.cand_cap;
+  }
   const uint32_t n_tiles = (n_rows + kRowsPerWave - 1) / kRowsPerWave;
 
   uint32_t polled = 0;
   for (uint32_t tile = wave_gid; tile < n_tiles; tile += total_waves) {
     if (a.cancel && (polled++ % kCancelPollTiles) == 0 && poll_cancel(a.cancel)) break;   // bruteforce.h:129
-    const uint32_t row = a.row_begin + tile * kRowsPerWave + rq;
-    const bool valid = row < a.row_end;
-    const uint32_t lrow = valid ? row : a.row_end - 1;
+    uint32_t row, lrow;
+    bool valid;
+    if constexpr (kIdx) {
+      const uint32_t i = tile * kRowsPerWave + rq;
+      valid = i < n_rows;
+      row = lrow = cand[valid ? i : n_rows - 1];
+    } else {
+      row = a.row_begin + tile * kRowsPerWave + rq;
+      valid = row < a.row_end;
+      lrow = valid ? row : a.row_end - 1;
+    }
     const char *__restrict__ base = row_base<kBf16>(a.rows, lrow, a.row_stride_f);
 
     float4 acc[kQB];
@@ -179,6 +196,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
   // one block of four waves per query: each wave merges every fourth 256-entry slab into its own list, then
   // waves 1..3 hand their lists to wave 0 through LDS (a lone wave spent its time waiting for dependent loads)
   extern __shared__ float merge_lds[];
+  if (a.run_flag && __hip_atomic_load(a.run_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.run_if) return;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const uint64_t q = blockIdx.x;
@@ -341,6 +359,7 @@ __global__ __launch_bounds__(256) void merge_select_kernel(MergeArgs a) {
   __shared__ uint64_t c_l[64];
   __shared__ float v_d[kSelSurvivors];
   __shared__ uint64_t v_l[kSelSurvivors];
+  if (a.run_flag && __hip_atomic_load(a.run_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.run_if) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t q = blockIdx.x;
   const uint32_t total = a.parts * a.per_part;
@@ -562,6 +581,18 @@ static hipError_t launch_scan_l2(bool l2, int qb, const FlatScanArgs &a, dim3 gr
   return l2 ? launch_scan_qb<true, kE, kBf16>(qb, a, grid, lds, s) : launch_scan_qb<false, kE, kBf16>(qb, a, grid, lds, s);
 }
 
+// re-rank launch: one query per block column (kQB = 1), k <= 64 (kE = 1), rows from the survivor lists
+template <bool kL2, bool kBf16>
+static hipError_t launch_rerank_t(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<1, kL2, 1, kBf16, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((flat_scan_kernel<1, kL2, 1, kBf16, false, true>), grid, dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
 int flat_scan_slots_per_lane(uint64_t k) {
   if (k <= 64) return 1;
   if (k <= 256) return 4;
@@ -591,6 +622,11 @@ hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, i
   size_t lds = (size_t)qb * a.chunks * 64;
   if (e == 1) lds = std::max<size_t>(lds, ((size_t)qb * 3 * a.k + 2) * 12);   // block-level merge buffers reuse it
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (a.cand_row) {  // re-rank of a survivor list
+    if (e != 1 || qb != 1) return hipErrorInvalidValue;
+    return l2 ? (bf16 ? launch_rerank_t<true, true>(a, grid, lds, s) : launch_rerank_t<true, false>(a, grid, lds, s))
+              : (bf16 ? launch_rerank_t<false, true>(a, grid, lds, s) : launch_rerank_t<false, false>(a, grid, lds, s));
+  }
   if (a.lb_dist) {   // paged large-k scan
     if (e != 16 || qb != 1) return hipErrorInvalidValue;
     return l2 ? (bf16 ? launch_scan_lb<true, true>(a, grid, lds, s) : launch_scan_lb<true, false>(a, grid, lds, s))

@@ -26,6 +26,14 @@ struct FlatScanArgs {
   // polls it per row, bruteforce.h:129): polled once per kCancelPollTiles row tiles, non-zero = stop scanning and
   // hand over what the lists hold
   const uint32_t *cancel;
+  // re-rank mode (the exact stage behind flat_filter_kernel): the rows of query q are the first
+  // min(cand_cnt[q], cand_cap) entries of cand_row[q][..] instead of [row_begin, row_end); one query per block
+  const uint32_t *cand_cnt;
+  const uint32_t *cand_row;
+  uint32_t cand_cap;
+  // device-side conditional launch: the kernel returns at once unless *run_flag == run_if (run_flag == nullptr: always runs)
+  const uint32_t *run_flag;
+  uint32_t run_if;
 };
 constexpr uint32_t kCancelPollTiles = 16;
 constexpr uint32_t kCancelPollHops = 16;
@@ -56,7 +64,35 @@ struct FlatGemmArgs {
   const float *init_bound;    // optional [nq]: a valid upper bound of each query's k-th best distance (pre-pass)
   uint32_t contig;            // 1: a row partition owns a contiguous range of tiles, 0: tiles rp, rp+nrp, ...
   const uint32_t *cancel;     // optional, as FlatScanArgs::cancel (polled every kCancelPollTiles 128-row tiles)
+  const uint32_t *run_flag;   // as FlatScanArgs::run_flag
+  uint32_t run_if;
 };
+// K4h (flat_filter.hip): candidate stage of the batched FLAT search on the f16 matrix cores
+struct FlatFilterArgs {
+  const void *rows;           // f32 rows, row_stride_f elements apart
+  const uint64_t *labels;
+  const uint64_t *allow_bits;
+  uint64_t allow_nbits;
+  const float *queries;       // [nq][q_stride_f] f32, padded (input of flat_qprep_kernel)
+  uint32_t q_stride_f;
+  void *q16;                  // [nqt][row_stride_f/16][64][8] f16: the queries in MFMA fragment order (written by qprep)
+  float *thr;                 // [nqt*32] gate in dot space per query column (+inf = closed, -inf = open)
+  const float *bound;         // [nq] upper bound of each query's final k-th best exact distance (+inf = none)
+  const uint32_t *row_stats;  // [2] f32 bits: largest |row|^2, largest |element| (row_stats_kernel)
+  uint32_t *cand_cnt;         // [nq] survivors per query (zeroed before the launch; may exceed cap)
+  uint32_t *cand_row;         // [nq][cap] their row slots
+  uint32_t cap;
+  uint32_t *ovf;              // [1] raised when a list overflowed: the exact kernel answers the batch
+  uint32_t row_stride_f, n_rows, nq;
+  uint32_t nqt;               // query tiles of 32 (<= 8 per launch)
+  const uint32_t *cancel;
+};
+size_t flat_filter_lds_bytes();
+bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2);
+hipError_t launch_row_stats(const void *rows, bool bf16, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t *stats, hipStream_t s);
+hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s);
+hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s);
+
 size_t flat_gemm_lds_bytes(uint32_t row_stride_f, uint32_t tile_q);
 uint32_t flat_gemm_tile_q(uint32_t row_stride_f);
 bool flat_gemm_supported(uint32_t row_stride_f, uint64_t k);
@@ -72,6 +108,8 @@ struct MergeArgs {
   float *out_dist;            // [nq][out_ld] ascending by (dist,label)
   uint64_t *out_label;
   uint32_t *out_n;            // [nq]
+  const uint32_t *run_flag;   // as FlatScanArgs::run_flag
+  uint32_t run_if;
 };
 
 struct GatherArgs {

@@ -91,6 +91,7 @@ Status RowStore::bulk_write(uint32_t first, const float *rows, uint64_t n, const
     VK_HIP_TRY(hipMemcpy2DAsync(dst + at * rb, rb, reinterpret_cast<const char *>(rows) + at * src_pitch, src_pitch, src_pitch, m,
                                 hipMemcpyHostToDevice, stream_));
   }
+  note_written(first, (uint64_t)first + n);
   if (h_labels_.size() < (size_t)first + n) h_labels_.resize((size_t)first + n, ~0ull);
   memcpy(h_labels_.data() + first, labels, n * 8);
   VK_HIP_TRY(hipMemcpyAsync(d_labels_ + first, labels, n * 8, hipMemcpyHostToDevice, stream_));
@@ -152,6 +153,7 @@ Status RowStore::flush() {
   for (const Op &op : ops_) need = std::max<uint64_t>(need, (uint64_t)op.slot + 1);
   VK_TRY(reserve(need));
   const size_t rb = row_bytes();
+  for (const Op &op : ops_) note_written(op.slot, (uint64_t)op.slot + 1);
   size_t i = 0;
   while (i < ops_.size()) {
     const Op &op = ops_[i];

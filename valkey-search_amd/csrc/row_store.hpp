@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,17 @@ class RowStore {
   Status read_row(uint32_t slot, float *out);
   // labels mirror (authoritative on the host)
   std::vector<uint64_t> &host_labels() { return h_labels_; }
+  // slots whose ROW bytes were (re)written on the device since the last call -- what per-row statistics kept beside
+  // the table have to be brought up to date for (FlatIndex: the candidate filter's norm / range bounds)
+  void note_written(uint64_t lo, uint64_t hi) { written_lo_ = std::min(written_lo_, lo); written_hi_ = std::max(written_hi_, hi); }
+  bool take_written(uint64_t *lo, uint64_t *hi) {
+    if (written_lo_ >= written_hi_) return false;
+    *lo = written_lo_;
+    *hi = written_hi_;
+    written_lo_ = ~0ull;
+    written_hi_ = 0;
+    return true;
+  }
 
  private:
   struct Op { uint8_t kind; uint32_t slot; uint32_t src; size_t off; };  // kind 0 write, 1 move
@@ -94,6 +106,7 @@ class RowStore {
   uint64_t alloc_rows_ = 0;
   std::vector<uint64_t> h_labels_;
   uint64_t label_dirty_lo_ = ~0ull, label_dirty_hi_ = 0;
+  uint64_t written_lo_ = ~0ull, written_hi_ = 0;
   std::vector<Op> ops_;
   std::vector<char *> chunks_;   // pinned staging chunks
   size_t chunk_bytes_ = 0, chunk_used_ = 0, cur_chunk_ = 0;
