@@ -34,7 +34,7 @@ class _Env:
                 os.environ[k] = v
 
 
-SMALL = dict(VK_FILTER_PREPASS=4096, VK_FILTER_MIN_ROWS=32768)     # let mid-sized test indexes take the filter path
+SMALL = dict(VK_FILTER_PREPASS=1024, VK_FILTER_MIN_ROWS=32768)     # let mid-sized test indexes take the filter path
 
 
 def _pair(vsa, dim, metric, x, labels=None, **env):
@@ -61,7 +61,7 @@ def _unit(x):
 @pytest.mark.parametrize("dim", [64, 96, 200, 768])          # 1, 2, 4 and 12 pipeline stages per row tile
 def test_filter_path_equals_exact_path_and_oracle(vsa, oracle, dim):
     rng = np.random.default_rng(dim)
-    n = 60_000 if dim < 768 else 40_000
+    n = 60_000
     # clustered rows: plenty of near neighbours within the filter's margin of each other
     centres = rng.standard_normal((50, dim)).astype(np.float32)
     x = _unit(centres[rng.integers(0, 50, n)] + 0.3 * rng.standard_normal((n, dim)).astype(np.float32))
@@ -99,11 +99,17 @@ def test_filter_with_allow_bitmap_and_unnormalised_ip(vsa, oracle):
     _same(f.search_batch(Q, 10, allow=bits, allow_nbits=nb), e.search_batch(Q, 10, allow=bits, allow_nbits=nb))
     st = f.stats()
     assert st.last_filter_candidates > 0 and st.last_filter_fallback == 0
-    # a filter so selective that the sample holds fewer than k allowed rows: no bound, every row survives, the lists
-    # overflow -- the exact kernel answers
-    few = oracle.allow_bitmap(labels[rng.random(n) < 0.0005], nb)
+    # a filter so selective that the sample holds fewer than k allowed rows: no bound, the gate is open -- but only
+    # ALLOWED rows become survivors, a few dozen per query here, and the re-rank settles it
+    keep = rng.random(n) < 0.0005
+    few = oracle.allow_bitmap(labels[keep], nb)
     _same(f.search_batch(Q, 10, allow=few, allow_nbits=nb), e.search_batch(Q, 10, allow=few, allow_nbits=nb))
-    assert f.stats().last_filter_fallback == 1
+    st = f.stats()
+    assert st.last_filter_fallback == 0 and st.last_filter_candidates == int(keep.sum()) * len(Q)
+    # ... and with no allowed row at all
+    none = oracle.allow_bitmap(np.zeros(0, np.uint64), nb)
+    D, L, N = f.search_batch(Q, 10, allow=none, allow_nbits=nb)
+    assert (N == 0).all()
 
 
 def test_survivor_overflow_falls_back_to_the_exact_kernel(vsa, oracle):
@@ -154,6 +160,7 @@ def test_filter_sees_mutations(vsa, oracle):
     Q = _unit(rng.standard_normal((64, dim)).astype(np.float32))
     _same(f.search_batch(Q, 10), e.search_batch(Q, 10))
     for ix in (f, e):
+        ix.resize(n)
         ix.add_batch(x[40_000:], np.arange(40_000, n, dtype=np.uint64))
         for lab in range(0, 3000, 7):
             ix.remove(lab)

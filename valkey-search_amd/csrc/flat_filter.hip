@@ -142,16 +142,18 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
 }
 
 // ---- the filter ------------------------------------------------------------------------------------------------------
-struct RowStage { float4 v[8]; };   // this thread's share of one stage: 128 rows x 64 k f32 = 2048 float4 / 256 threads
+// Block = 512 threads = 8 waves, two per SIMD (so that one wave's wait for memory is the other's matrix time): wave w
+// owns query tile w (32 queries) against all 128 rows of the tile = four 32 x 32 accumulator tiles.
+constexpr int kFThreads = 512;
+struct RowStage { float4 v[4]; };   // this thread's share of one stage: 128 rows x 64 k f32 = 2048 float4 / 512 threads
 
-template <bool kBf16>
 __device__ __forceinline__ RowStage stage_rows_load(const FlatFilterArgs &a, uint32_t tile_row0, uint32_t st, uint32_t tid) {
   RowStage s;
-  // idx = tid + 256 u: row = idx / 16, 16-byte column idx % 16 of the row's 256-byte stage slice (coalesced 256 B per row)
+  // idx = tid + 512 u: row = idx / 16, 16-byte column idx % 16 of the row's 256-byte stage slice (coalesced 256 B per row)
   const float *base = static_cast<const float *>(a.rows) + (size_t)tile_row0 * a.row_stride_f + st * kFStageK;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const uint32_t idx = tid + 256u * u;
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t idx = tid + (uint32_t)kFThreads * u;
     s.v[u] = *reinterpret_cast<const float4 *>(base + (size_t)(idx >> 4) * a.row_stride_f + (idx & 15) * 4);
   }
   return s;
@@ -159,8 +161,8 @@ __device__ __forceinline__ RowStage stage_rows_load(const FlatFilterArgs &a, uin
 
 __device__ __forceinline__ void stage_rows_store(_Float16 *buf, uint32_t tid, const RowStage &s) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const uint32_t idx = tid + 256u * u;
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t idx = tid + (uint32_t)kFThreads * u;
     f16x4 h;
     h[0] = (_Float16)s.v[u].x;
     h[1] = (_Float16)s.v[u].y;
@@ -170,59 +172,94 @@ __device__ __forceinline__ void stage_rows_store(_Float16 *buf, uint32_t tid, co
   }
 }
 
-struct BFrags { f16x8 b[2][4]; };   // this wave's two query tiles x the stage's four K-steps
+struct BFrags { f16x8 b[4]; };   // this wave's query tile x the stage's four K-steps
 
 __device__ __forceinline__ BFrags stage_b_load(const FlatFilterArgs &a, uint32_t wave, uint32_t st, uint32_t lane) {
   BFrags f;
   const uint32_t ks_n = a.row_stride_f / 16;
+  const uint32_t jt = wave < a.nqt ? wave : a.nqt - 1;   // (a wave without queries re-reads the last tile)
+  const f16x8 *p = reinterpret_cast<const f16x8 *>(a.q16) + ((size_t)(jt * ks_n + st * 4) * kWave + lane);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const uint32_t jt = wave * 2 + t < a.nqt ? wave * 2 + t : a.nqt - 1;   // (a wave without queries re-reads the last tile)
-    const f16x8 *p = reinterpret_cast<const f16x8 *>(a.q16) + ((size_t)(jt * ks_n + st * 4) * kWave + lane);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) f.b[t][kk] = p[(size_t)kk * kWave];
-  }
+  for (int kk = 0; kk < 4; ++kk) f.b[kk] = p[(size_t)kk * kWave];
   return f;
 }
 
+// Survivors are collected per wave in LDS (a ring of 64 (query, row) entries) and written out 64 at a time: the global
+// append is an atomicAdd that RETURNS the slot, a round trip of a microsecond or two -- paid per survivor it sat on the
+// critical path of every row tile (some wave of the block nearly always had one, and the block's barrier waits for it).
+struct SurvivorRing {
+  uint32_t *q;     // [64] LDS
+  uint32_t *row;   // [64] LDS
+  uint32_t cnt;    // wave-uniform
+};
+__device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing &r, uint32_t lane) {
+  if (lane < r.cnt) {
+    const uint32_t q = r.q[lane], row = r.row[lane];
+    const uint32_t at = atomicAdd(&a.cand_cnt[q], 1u);
+    if (at < a.cap) a.cand_row[(size_t)q * a.cap + at] = row;
+    else __hip_atomic_store(a.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  r.cnt = 0;
+}
+
 // Tile done: the gate.  Output register r of row tile rt is row rt*32 + (r&3) + 8*(r>>2) + 4*g, column li of the wave's
-// query tile t.  Almost every 32 x 32 block has no survivor: one max over the lane's 16 values, one ballot.
-__device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[4][2], const float (&thr)[2], uint32_t tile_row0,
-                                            uint32_t wave, uint32_t li, uint32_t g) {
+// query tile.  Almost every 32 x 32 block has no survivor: one max over the lane's 16 values, one ballot.
+__device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[4], float thr, uint32_t tile_row0,
+                                            uint32_t wave, uint32_t li, uint32_t g, SurvivorRing &ring, uint32_t lane) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int rt = 0; rt < 4; ++rt) {
+    float m = acc[rt][0];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      float m = acc[rt][t][0];
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
+    if (__builtin_amdgcn_ballot_w64(m >= thr) != 0) {   // (rare: a survivor somewhere in this 32 x 32 block)
+      const uint32_t q = wave * 32 + li;
 #pragma unroll
-      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][t][r]);
-      if (__builtin_amdgcn_ballot_w64(m >= thr[t]) != 0) {
-        const uint32_t q = (wave * 2 + t) * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t row = tile_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          if (acc[rt][t][r] >= thr[t] && row < a.n_rows && q < a.nq) {
-            if (a.allow_bits == nullptr || allow_bit(a.allow_bits, a.allow_nbits, a.labels[row])) {
-              const uint32_t at = atomicAdd(&a.cand_cnt[q], 1u);
-              if (at < a.cap) a.cand_row[(size_t)q * a.cap + at] = row;
-              else __hip_atomic_store(a.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t row = tile_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        bool pass = acc[rt][r] >= thr && row < a.n_rows && q < a.nq;
+        if (pass && a.allow_bits != nullptr) pass = allow_bit(a.allow_bits, a.allow_nbits, a.labels[row]);
+        const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
+        if (pm != 0) {
+          const uint32_t n = (uint32_t)__popcll(pm);
+          if (ring.cnt + n > kWave) ring_flush(a, ring, lane);
+          if (pass) {
+            const uint32_t at = ring.cnt + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+            ring.q[at] = q;
+            ring.row[at] = row;
           }
+          ring.cnt += n;
         }
       }
-      acc[rt][t] = zero;
     }
+    acc[rt] = zero;
   }
 }
 
-__global__ __launch_bounds__(256, 1) void flat_filter_kernel(FlatFilterArgs a) {
-  extern __shared__ _Float16 lds_a[];   // [2 stages][128 rows][kFAStride]
+// position in a block's flattened (tile, stage) stream, advanced without divisions; it never moves past the last
+// stage (prefetches behind the end re-read it and are not used)
+struct FPos { uint32_t row0, st, left; };
+__device__ __forceinline__ void fpos_advance(FPos &p, uint32_t stages) {
+  const bool go = p.left > 1;
+  const bool wrap = go && p.st + 1 == stages;
+  p.left -= p.left != 0 ? 1u : 0u;
+  p.st = wrap ? 0u : p.st + (go ? 1u : 0u);
+  p.row0 += wrap ? (uint32_t)kFTileRows : 0u;
+}
+
+// kAblate: timing experiments only (compile-time, so that the product kernel has no branches around its loads)
+template <int kAblate>
+__global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
+  extern __shared__ _Float16 lds_a[];   // [2 stages][128 rows][kFAStride], then the waves' survivor rings
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t li = lane & 31, g = lane >> 5;
   const uint32_t stages = a.row_stride_f / kFStageK;
   constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;
+  SurvivorRing ring;
+  ring.q = reinterpret_cast<uint32_t *>(lds_a + 2 * kBufHalfs) + wave * 2 * kWave;
+  ring.row = ring.q + kWave;
+  ring.cnt = 0;
 
   // this block's contiguous range of row tiles
   const uint32_t n_tiles = (a.n_rows + kFTileRows - 1) / kFTileRows;
@@ -231,68 +268,95 @@ __global__ __launch_bounds__(256, 1) void flat_filter_kernel(FlatFilterArgs a) {
   const uint32_t my_tiles = t_base + (blockIdx.x < t_rem ? 1u : 0u);
   if (my_tiles == 0) return;
   const uint32_t total = my_tiles * stages;
-  const bool has_q = wave * 2 < a.nqt;
+  const bool has_q = wave < a.nqt;
+  const float thr = has_q ? a.thr[wave * 32 + li] : __builtin_inff();   // gate of this lane's query column
 
-  // gates of this lane's two query columns
-  float thr[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) thr[t] = wave * 2 + t < a.nqt ? a.thr[(wave * 2 + t) * 32 + li] : __builtin_inff();
-
-  // flattened (tile, stage) stream; loads run two stages ahead, LDS one stage ahead
-  auto pos_of = [&](uint32_t s, uint32_t &row0, uint32_t &st) {
-    const uint32_t sc = s < total ? s : total - 1;          // past the end: re-read the last stage (unused)
-    row0 = (first_tile + sc / stages) * kFTileRows;
-    st = sc % stages;
-  };
-  uint32_t r0, s0;
-  pos_of(0, r0, s0);
-  // register sets by stage parity: ra holds even stages, rb odd ones; b0 / b1 the same for the B operands.  The loop is
-  // unrolled by two with the sets named explicitly -- rotating them through a copy would make the copy wait for loads
-  // that are still in flight.
-  RowStage ra = stage_rows_load<false>(a, r0, s0, tid), rb;
-  stage_rows_store(lds_a, tid, ra);
-  BFrags b0 = stage_b_load(a, wave, s0, lane), b1 = b0;
-  pos_of(1, r0, s0);
-  rb = stage_rows_load<false>(a, r0, s0, tid);
+  // Software pipeline, iteration S = stage S of the stream:
+  //   top     the B operands (L2) and the rows (HBM) of stage S+4 into the register sets whose previous content (stage S)
+  //           is consumed in this iteration / went to LDS one iteration ago.  Both run the SAME distance ahead: loads
+  //           return in order (one vmcnt counter), so a B operand fetched one iteration ahead would make the wait for it
+  //           a wait for every row load issued before it -- the rows would have one iteration of cover, not four.
+  //           Three to four stages of rows (96-128 KB per CU) are in flight: at 6 TB/s the loaded HBM latency is
+  //           several microseconds
+  //   middle  the 16 MFMAs of stage S: A fragments from LDS buffer S & 1, fetched one K-step ahead of their use
+  //   bottom  stage S+1 (loaded one iteration ago) converted to f16 into the other LDS buffer, one barrier
+  // Unrolled by four with the register sets named explicitly (rows and B operands of stage s in sets s % 4):
+  // rotating them through a copy would make the copy wait for loads that are still in flight.
+  FPos ld{first_tile * kFTileRows, 0, total};   // next stage whose rows are fetched
+  FPos lb = ld;                                  // next stage whose B operands are fetched
+  RowStage x0 = stage_rows_load(a, ld.row0, ld.st, tid), x1, x2, x3;
+  stage_rows_store(lds_a, tid, x0);
+  BFrags b0 = stage_b_load(a, wave, lb.st, lane), b1, b2, b3;
+  fpos_advance(ld, stages);
+  fpos_advance(lb, stages);
+  b1 = stage_b_load(a, wave, lb.st, lane);        // stages 1, 2, 3: B operands, then rows
+  x1 = stage_rows_load(a, ld.row0, ld.st, tid);
+  fpos_advance(ld, stages);
+  fpos_advance(lb, stages);
+  b2 = stage_b_load(a, wave, lb.st, lane);
+  x2 = stage_rows_load(a, ld.row0, ld.st, tid);
+  fpos_advance(ld, stages);
+  fpos_advance(lb, stages);
+  b3 = stage_b_load(a, wave, lb.st, lane);
+  x3 = stage_rows_load(a, ld.row0, ld.st, tid);
+  fpos_advance(ld, stages);
+  fpos_advance(lb, stages);
   __syncthreads();
 
-  f32x16 acc[4][2];
+  f32x16 acc[4];
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) { acc[rt][0] = zero; acc[rt][1] = zero; }
+  for (int rt = 0; rt < 4; ++rt) acc[rt] = zero;
 
   uint32_t tile_row0 = first_tile * kFTileRows;
+  uint32_t st_c = 0, left_c = total, tile_c = 0;
   uint32_t cancel_now = 0;
   bool stop = false;
+  const uint32_t hot_row0 = first_tile * kFTileRows;
 
-  // iteration S: HBM loads of stage S+2 into RLOAD (its previous content, stage S, went to LDS one iteration ago), B
-  // operands of stage S+1 into BNEXT, the 32 MFMAs of stage S (A from LDS buffer S & 1, B from BCUR), stage S+1 from
-  // RSTORE into the other LDS buffer, one barrier.  (S == total only when the stream has an odd length: no compute.)
-#define VK_FSTAGE(S, RLOAD, RSTORE, BCUR, BNEXT)                                                                    \
+#define VK_FMMA(AV, KK)                                                                                             \
+  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
+    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AV[rt], bcur_.b[KK], acc[rt], 0, 0, 0);
+#define VK_FAREAD(AV, KK)                                                                                           \
+  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
+    AV[rt] = *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + (KK) * 16);
+
+#define VK_FSTAGE(PAR, RLOAD, RSTORE, BCUR, BNEXT)                                                                  \
   {                                                                                                                 \
-    const uint32_t s_ = (S);                                                                                        \
-    const uint32_t st = s_ % stages;                                                                                \
-    const bool live = s_ < total;                                                                                   \
-    if (live && st == 0 && a.cancel && ((s_ / stages) % kCancelPollTiles) == 0)                                     \
+    const bool live = left_c != 0;                                                                                  \
+    if (live && st_c == 0 && a.cancel && (tile_c % kCancelPollTiles) == 0)                                          \
       cancel_now = __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                        \
-    uint32_t nr0, nst, n1r0, n1st;                                                                                  \
-    pos_of(s_ + 2, nr0, nst);                                                                                       \
-    pos_of(s_ + 1, n1r0, n1st);                                                                                     \
-    RLOAD = stage_rows_load<false>(a, nr0, nst, tid);                                                               \
-    BNEXT = stage_b_load(a, wave, n1st, lane);                                                                      \
-    const _Float16 *ab = lds_a + (s_ & 1) * kBufHalfs + li * kFAStride + g * 8;                                     \
-    if (has_q && live) {                                                                                            \
-      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                            \
-        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                                          \
-          const f16x8 av = *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + kk * 16);                    \
-          acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, BCUR.b[0][kk], acc[rt][0], 0, 0, 0);              \
-          acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, BCUR.b[1][kk], acc[rt][1], 0, 0, 0);              \
-        }                                                                                                           \
-      }                                                                                                             \
+    const _Float16 *ab = lds_a + (PAR) * kBufHalfs + li * kFAStride + g * 8;                                        \
+    f16x8 fa[4], fb[4];                                                                                             \
+    VK_FAREAD(fa, 0)                                                                                                \
+    const BFrags bcur_ = BCUR;                                                                                      \
+    if (has_q && live && !(kAblate & 4)) {                                                                          \
+      VK_FAREAD(fb, 1)                                                                                              \
+      VK_FMMA(fa, 0)                                                                                                \
+      VK_FAREAD(fa, 2)                                                                                              \
+      VK_FMMA(fb, 1)                                                                                                \
+      VK_FAREAD(fb, 3)                                                                                              \
+      VK_FMMA(fa, 2)                                                                                                \
+      VK_FMMA(fb, 3)                                                                                                \
+      /* operands of a K-step are requested a whole K-step (four MFMAs) before their use */                       \
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                            \
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                            \
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                            \
     }                                                                                                               \
-    stage_rows_store(lds_a + ((s_ + 1) & 1) * kBufHalfs, tid, RSTORE);                                              \
-    if (live && st + 1 == stages) {                                                                                 \
-      if (has_q) filter_gate(a, acc, thr, tile_row0, wave, li, g);                                                  \
+    if constexpr (!(kAblate & 16)) BNEXT = stage_b_load(a, wave, lb.st, lane);                                      \
+    fpos_advance(lb, stages);                                                                                       \
+    if constexpr (!(kAblate & 32)) RLOAD = stage_rows_load(a, (kAblate & 1) ? hot_row0 : ld.row0, ld.st, tid);      \
+    fpos_advance(ld, stages);                                                                                       \
+    if constexpr (!(kAblate & 8)) stage_rows_store(lds_a + ((PAR) ^ 1) * kBufHalfs, tid, RSTORE);                   \
+    left_c -= live ? 1u : 0u;                                                                                       \
+    st_c += 1;                                                                                                      \
+    if (live && st_c == stages) {                                                                                   \
+      if (has_q && !(kAblate & 2)) filter_gate(a, acc, thr, tile_row0, wave, li, g, ring, lane);                                \
+      st_c = 0;                                                                                                     \
+      tile_c += 1;                                                                                                  \
       tile_row0 += kFTileRows;                                                                                      \
       stop = __syncthreads_or((int)cancel_now) != 0;   /* block-uniform: every wave leaves at the same tile */      \
     } else {                                                                                                        \
@@ -300,15 +364,22 @@ __global__ __launch_bounds__(256, 1) void flat_filter_kernel(FlatFilterArgs a) {
     }                                                                                                               \
   }
 
-  for (uint32_t s = 0; s < total && !stop; s += 2) {
-    VK_FSTAGE(s, ra, rb, b0, b1)
+  while (left_c != 0 && !stop) {
+    VK_FSTAGE(0, x0, x1, b0, b0)
     if (stop) break;
-    VK_FSTAGE(s + 1, rb, ra, b1, b0)
+    VK_FSTAGE(1, x1, x2, b1, b1)
+    if (stop) break;
+    VK_FSTAGE(0, x2, x3, b2, b2)
+    if (stop) break;
+    VK_FSTAGE(1, x3, x0, b3, b3)
   }
 #undef VK_FSTAGE
+#undef VK_FMMA
+#undef VK_FAREAD
+  ring_flush(a, ring, lane);
 }
 
-size_t flat_filter_lds_bytes() { return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16); }
+size_t flat_filter_lds_bytes() { return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)(kFThreads / kWave) * 2 * kWave * 4; }
 
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2) {
   return !bf16 && !l2 && (row_stride_f % kFStageK) == 0 && k >= 1 && k <= 64;
@@ -321,7 +392,14 @@ hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
 
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.nqt == 0 || a.nqt > 8 || blocks == 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(flat_filter_kernel, dim3(blocks), dim3(256), flat_filter_lds_bytes(), s, a);
+  switch (a.ablate) {
+    case 0: hipLaunchKernelGGL(flat_filter_kernel<0>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 30: hipLaunchKernelGGL(flat_filter_kernel<30>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 26: hipLaunchKernelGGL(flat_filter_kernel<26>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 2: hipLaunchKernelGGL(flat_filter_kernel<2>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 32: hipLaunchKernelGGL(flat_filter_kernel<32>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -796,6 +796,8 @@ class FlatIndex final : public Index {
     f.nq = (uint32_t)nq;
     f.nqt = nqt;
     f.cancel = d_cancel;
+    static const uint32_t ablate = getenv("VK_FILTER_ABLATE") ? (uint32_t)atoi(getenv("VK_FILTER_ABLATE")) : 0;
+    f.ablate = ablate;
     VK_HIP_TRY(launch_flat_qprep(f, s));
     // 3. the filter: one launch per 256 queries, every launch one pass over the rows
     if (filter_blocks_ == 0) {
