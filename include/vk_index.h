@@ -113,6 +113,11 @@ typedef struct vk_index_stats {
    * overflowed so that the exact matrix-core kernel answered instead */
   uint64_t last_filter_candidates;
   uint64_t last_filter_fallback;
+  /* cumulative: batches that went through the candidate filter and the device time of its kernel launches (HIP events
+   * on the stream they ran on; a batch counts once its events have completed) -- the per-launch duration behind
+   * bench.py's HBM roofline figure */
+  uint64_t filter_batches;
+  uint64_t filter_kernel_ns;
   /* query coalescer (vk_index_set_coalescing): device batches run / single queries they carried */
   uint64_t coalesced_batches;
   uint64_t coalesced_queries;

@@ -37,11 +37,11 @@ class _Env:
 SMALL = dict(VK_FILTER_PREPASS=1024, VK_FILTER_MIN_ROWS=32768)     # let mid-sized test indexes take the filter path
 
 
-def _pair(vsa, dim, metric, x, labels=None, **env):
+def _pair(vsa, dim, metric, x, labels=None, dtype="f32", **env):
     with _Env(**{**SMALL, **env}):
-        f = vsa.Index("FLAT", dim, metric, initial_cap=len(x))
+        f = vsa.Index("FLAT", dim, metric, initial_cap=len(x), dtype=dtype)
     with _Env(VK_FLAT_FILTER=0):
-        e = vsa.Index("FLAT", dim, metric, initial_cap=len(x))
+        e = vsa.Index("FLAT", dim, metric, initial_cap=len(x), dtype=dtype)
     f.add_batch(x, labels)
     e.add_batch(x, labels)
     return f, e
@@ -167,3 +167,24 @@ def test_filter_sees_mutations(vsa, oracle):
         ix.add(5, 3.0 * x[5])                             # a longer row: the norm bound must grow with it
     _same(f.search_batch(Q, 10), e.search_batch(Q, 10))
     assert f.stats().last_filter_candidates > 0 and f.stats().last_filter_fallback == 0
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "IP"])
+def test_bf16_rows_through_the_filter(vsa, oracle, metric):
+    """bf16 row storage (BASELINE configs[3]): bf16 -> f16 is exact, so the filter's margin carries the query rounding
+    only; the answer equals the exact kernel's over the same rounded rows"""
+    rng = np.random.default_rng(11)
+    n, dim = 70_000, 192
+    centres = rng.standard_normal((40, dim)).astype(np.float32)
+    x = centres[rng.integers(0, 40, n)] + 0.4 * rng.standard_normal((n, dim)).astype(np.float32)
+    if metric == "COSINE":
+        x = _unit(x)
+    f, e = _pair(vsa, dim, metric, x, dtype="bf16")
+    Q = centres[rng.integers(0, 40, 200)] + 0.4 * rng.standard_normal((200, dim)).astype(np.float32)
+    if metric == "COSINE":
+        Q = _unit(Q)
+    for nq, k in ((64, 10), (200, 1), (200, 32)):
+        got = f.search_batch(Q[:nq], k)
+        st = f.stats()
+        assert st.last_filter_candidates >= nq * k and st.last_filter_fallback == 0
+        _same(got, e.search_batch(Q[:nq], k))

@@ -45,6 +45,7 @@ class Stats(C.Structure):
                 ("max_level", C.c_int32), ("entry_point", C.c_uint32), ("last_n_eval", C.c_uint64),
                 ("last_n_hops", C.c_uint64), ("last_frontier_redo", C.c_uint64), ("last_frontier_dropped", C.c_uint64),
                 ("last_filter_candidates", C.c_uint64), ("last_filter_fallback", C.c_uint64),
+                ("filter_batches", C.c_uint64), ("filter_kernel_ns", C.c_uint64),
                 ("coalesced_batches", C.c_uint64), ("coalesced_queries", C.c_uint64)]
 
 

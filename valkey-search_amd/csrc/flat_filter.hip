@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
     const float qn = sqrtf(n2) * 1.0001f, bound = a.bound[q];
     const float D = (float)a.row_stride_f;
     // see the header: relative part, absolute (subnormal) part, the reference's own rounding, 1 - dot
-    const float rel = 0x1p-10f + 0x1p-22f + D * 0x1p-22f + (D / 16.f + 5.f) * 0x1p-24f;
+    const float rel = (a.bf16 ? 0x1p-11f : 0x1p-10f) + 0x1p-22f + D * 0x1p-22f + (D / 16.f + 5.f) * 0x1p-24f;   // (bf16 rows convert exactly)
     const float eps = (R * qn * rel + 0x1.01p-25f * sqrtf(D) * (R + qn) + 0x1p-23f * fmaxf(1.f, 1.f + R * qn)) * 1.001f;
     const bool f16_ok = !bad && mx <= 32768.f && amax <= 32768.f && (R - R == 0.f) && (eps - eps == 0.f);
     // no bound yet (fewer than k allowed rows in the sample) or inputs that cannot go through f16: every row passes,
@@ -145,29 +145,43 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
 // Block = 512 threads = 8 waves, two per SIMD (so that one wave's wait for memory is the other's matrix time): wave w
 // owns query tile w (32 queries) against all 128 rows of the tile = four 32 x 32 accumulator tiles.
 constexpr int kFThreads = 512;
-struct RowStage { float4 v[4]; };   // this thread's share of one stage: 128 rows x 64 k f32 = 2048 float4 / 512 threads
+// this thread's share of one stage: 128 rows x 64 k = 2048 groups of 4 elements / 512 threads (16 B of f32, 8 B of bf16)
+template <bool kBf16> struct RowStage { float4 v[4]; };
+template <> struct RowStage<true> { uint2 v[4]; };
 
-__device__ __forceinline__ RowStage stage_rows_load(const FlatFilterArgs &a, uint32_t tile_row0, uint32_t st, uint32_t tid) {
-  RowStage s;
-  // idx = tid + 512 u: row = idx / 16, 16-byte column idx % 16 of the row's 256-byte stage slice (coalesced 256 B per row)
-  const float *base = static_cast<const float *>(a.rows) + (size_t)tile_row0 * a.row_stride_f + st * kFStageK;
+template <bool kBf16>
+__device__ __forceinline__ RowStage<kBf16> stage_rows_load(const FlatFilterArgs &a, uint32_t tile_row0, uint32_t st, uint32_t tid) {
+  RowStage<kBf16> s;
+  // idx = tid + 512 u: row = idx / 16, 4-element column idx % 16 of the row's 64-element stage slice (coalesced per row)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const uint32_t idx = tid + (uint32_t)kFThreads * u;
-    s.v[u] = *reinterpret_cast<const float4 *>(base + (size_t)(idx >> 4) * a.row_stride_f + (idx & 15) * 4);
+    const size_t e = ((size_t)tile_row0 + (idx >> 4)) * a.row_stride_f + st * kFStageK + (idx & 15) * 4;
+    if constexpr (kBf16) s.v[u] = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(a.rows) + e);
+    else s.v[u] = *reinterpret_cast<const float4 *>(static_cast<const float *>(a.rows) + e);
   }
   return s;
 }
 
-__device__ __forceinline__ void stage_rows_store(_Float16 *buf, uint32_t tid, const RowStage &s) {
+// -> f16 in LDS.  f32 rows: round to nearest even.  bf16 rows: bf16 -> f32 is a shift and f32 -> f16 is then EXACT for
+// every value in f16's normal range (8 significant bits fit 11), so a bf16 index carries no row rounding error at all.
+template <bool kBf16>
+__device__ __forceinline__ void stage_rows_store(_Float16 *buf, uint32_t tid, const RowStage<kBf16> &s) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const uint32_t idx = tid + (uint32_t)kFThreads * u;
     f16x4 h;
-    h[0] = (_Float16)s.v[u].x;
-    h[1] = (_Float16)s.v[u].y;
-    h[2] = (_Float16)s.v[u].z;
-    h[3] = (_Float16)s.v[u].w;
+    if constexpr (kBf16) {
+      h[0] = (_Float16)__uint_as_float(s.v[u].x << 16);
+      h[1] = (_Float16)__uint_as_float(s.v[u].x & 0xFFFF0000u);
+      h[2] = (_Float16)__uint_as_float(s.v[u].y << 16);
+      h[3] = (_Float16)__uint_as_float(s.v[u].y & 0xFFFF0000u);
+    } else {
+      h[0] = (_Float16)s.v[u].x;
+      h[1] = (_Float16)s.v[u].y;
+      h[2] = (_Float16)s.v[u].z;
+      h[3] = (_Float16)s.v[u].w;
+    }
     *reinterpret_cast<f16x4 *>(buf + (idx >> 4) * kFAStride + (idx & 15) * 4) = h;
   }
 }
@@ -248,7 +262,7 @@ __device__ __forceinline__ void fpos_advance(FPos &p, uint32_t stages) {
 }
 
 // kAblate: timing experiments only (compile-time, so that the product kernel has no branches around its loads)
-template <int kAblate>
+template <int kAblate, bool kBf16>
 __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
   extern __shared__ _Float16 lds_a[];   // [2 stages][128 rows][kFAStride], then the waves' survivor rings
   const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -284,21 +298,21 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
   // rotating them through a copy would make the copy wait for loads that are still in flight.
   FPos ld{first_tile * kFTileRows, 0, total};   // next stage whose rows are fetched
   FPos lb = ld;                                  // next stage whose B operands are fetched
-  RowStage x0 = stage_rows_load(a, ld.row0, ld.st, tid), x1, x2, x3;
-  stage_rows_store(lds_a, tid, x0);
+  RowStage<kBf16> x0 = stage_rows_load<kBf16>(a, ld.row0, ld.st, tid), x1, x2, x3;
+  stage_rows_store<kBf16>(lds_a, tid, x0);
   BFrags b0 = stage_b_load(a, wave, lb.st, lane), b1, b2, b3;
   fpos_advance(ld, stages);
   fpos_advance(lb, stages);
   b1 = stage_b_load(a, wave, lb.st, lane);        // stages 1, 2, 3: B operands, then rows
-  x1 = stage_rows_load(a, ld.row0, ld.st, tid);
+  x1 = stage_rows_load<kBf16>(a, ld.row0, ld.st, tid);
   fpos_advance(ld, stages);
   fpos_advance(lb, stages);
   b2 = stage_b_load(a, wave, lb.st, lane);
-  x2 = stage_rows_load(a, ld.row0, ld.st, tid);
+  x2 = stage_rows_load<kBf16>(a, ld.row0, ld.st, tid);
   fpos_advance(ld, stages);
   fpos_advance(lb, stages);
   b3 = stage_b_load(a, wave, lb.st, lane);
-  x3 = stage_rows_load(a, ld.row0, ld.st, tid);
+  x3 = stage_rows_load<kBf16>(a, ld.row0, ld.st, tid);
   fpos_advance(ld, stages);
   fpos_advance(lb, stages);
   __syncthreads();
@@ -348,9 +362,9 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
     }                                                                                                               \
     if constexpr (!(kAblate & 16)) BNEXT = stage_b_load(a, wave, lb.st, lane);                                      \
     fpos_advance(lb, stages);                                                                                       \
-    if constexpr (!(kAblate & 32)) RLOAD = stage_rows_load(a, (kAblate & 1) ? hot_row0 : ld.row0, ld.st, tid);      \
+    if constexpr (!(kAblate & 32)) RLOAD = stage_rows_load<kBf16>(a, (kAblate & 1) ? hot_row0 : ld.row0, ld.st, tid); \
     fpos_advance(ld, stages);                                                                                       \
-    if constexpr (!(kAblate & 8)) stage_rows_store(lds_a + ((PAR) ^ 1) * kBufHalfs, tid, RSTORE);                   \
+    if constexpr (!(kAblate & 8)) stage_rows_store<kBf16>(lds_a + ((PAR) ^ 1) * kBufHalfs, tid, RSTORE);            \
     left_c -= live ? 1u : 0u;                                                                                       \
     st_c += 1;                                                                                                      \
     if (live && st_c == stages) {                                                                                   \
@@ -382,7 +396,8 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
 size_t flat_filter_lds_bytes() { return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)(kFThreads / kWave) * 2 * kWave * 4; }
 
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2) {
-  return !bf16 && !l2 && (row_stride_f % kFStageK) == 0 && k >= 1 && k <= 64;
+  (void)bf16;
+  return !l2 && (row_stride_f % kFStageK) == 0 && k >= 1 && k <= 64;
 }
 
 hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
@@ -392,12 +407,15 @@ hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
 
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.nqt == 0 || a.nqt > 8 || blocks == 0) return hipErrorInvalidValue;
+  if (a.bf16) {
+    if (a.ablate) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((flat_filter_kernel<0, true>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a);
+    return hipGetLastError();
+  }
   switch (a.ablate) {
-    case 0: hipLaunchKernelGGL(flat_filter_kernel<0>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
-    case 30: hipLaunchKernelGGL(flat_filter_kernel<30>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
-    case 26: hipLaunchKernelGGL(flat_filter_kernel<26>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
-    case 2: hipLaunchKernelGGL(flat_filter_kernel<2>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
-    case 32: hipLaunchKernelGGL(flat_filter_kernel<32>, dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 0: hipLaunchKernelGGL((flat_filter_kernel<0, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 2: hipLaunchKernelGGL((flat_filter_kernel<2, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 32: hipLaunchKernelGGL((flat_filter_kernel<32, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

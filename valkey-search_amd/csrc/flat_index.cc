@@ -100,6 +100,10 @@ Status SearchCtx::wait(const volatile int *caller_flag) {
 }
 
 SearchCtx::~SearchCtx() {
+  for (TimedPair &t : timed) {
+    if (t.t0) (void)hipEventDestroy(t.t0);
+    if (t.t1) (void)hipEventDestroy(t.t1);
+  }
   if (has_busy) (void)hipEventSynchronize(busy);
   if (busy) (void)hipEventDestroy(busy);
   if (stream) (void)hipStreamSynchronize(stream);
@@ -455,6 +459,10 @@ class FlatIndex final : public Index {
     out->max_level = -1;
     out->last_filter_candidates = last_filter_cands_;
     out->last_filter_fallback = last_filter_fallback_;
+    (void)hipSetDevice(store_.device());
+    pool_.for_each_free([&](SearchCtx *c) { for (auto &tp : c->timed) drain_timed(tp); });
+    out->filter_batches = filter_batches_;
+    out->filter_kernel_ns = filter_ns_total_;
     return Status::Ok();
   }
 
@@ -727,6 +735,17 @@ class FlatIndex final : public Index {
     return Status::Ok();
   }
 
+  // a finished (t0, t1) pair around the filter launches of one batch -> the index's totals
+  void drain_timed(SearchCtx::TimedPair &tp) {
+    if (!tp.pending || hipEventQuery(tp.t1) != hipSuccess) return;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, tp.t0, tp.t1) == hipSuccess) {
+      filter_ns_total_ += (uint64_t)((double)ms * 1e6);
+      filter_batches_ += 1;
+    }
+    tp.pending = false;
+  }
+
   // sample the exact kernel bounds the k-th best distance on, for the candidate filter: its survivors are about
   // count * k / sample per query
   uint64_t filter_prepass_rows(uint64_t k) const { return filter_prepass_rows_ * ((k + 9) / 10); }
@@ -778,6 +797,7 @@ class FlatIndex final : public Index {
     uint32_t *ovf = ctx->d_fcnt.as<uint32_t>() + nq;
     FlatFilterArgs f{};
     f.rows = store_.d_rows();
+    f.bf16 = store_.bf16() ? 1 : 0;
     f.labels = store_.d_labels();
     f.allow_bits = d_allow;
     f.allow_nbits = allow_nbits;
@@ -805,6 +825,13 @@ class FlatIndex final : public Index {
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, store_.device());
       filter_blocks_ = cus > 0 ? (uint32_t)cus : 256;
     }
+    SearchCtx::TimedPair &tp = ctx->timed[ctx->timed_next++ % 8];
+    drain_timed(tp);
+    if (!tp.t0) {
+      VK_HIP_TRY(hipEventCreate(&tp.t0));
+      VK_HIP_TRY(hipEventCreate(&tp.t1));
+    }
+    VK_HIP_TRY(hipEventRecord(tp.t0, s));
     for (uint32_t g0 = 0; g0 < nqt; g0 += 8) {
       FlatFilterArgs fg = f;
       fg.nqt = std::min<uint32_t>(8, nqt - g0);
@@ -815,6 +842,8 @@ class FlatIndex final : public Index {
       fg.cand_row = f.cand_row + (size_t)g0 * 32 * cap;
       VK_HIP_TRY(launch_flat_filter(fg, filter_blocks_, s));
     }
+    VK_HIP_TRY(hipEventRecord(tp.t1, s));
+    tp.pending = true;
     // 4. exact re-rank of the survivors (unless a list overflowed) ...
     const int e = flat_scan_slots_per_lane(k);
     const uint32_t nrp = 8;
@@ -873,7 +902,7 @@ class FlatIndex final : public Index {
   uint32_t filter_blocks_ = 0;
   DevBuf d_rowstats_;
   std::mutex stats_mu_;
-  std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0};
+  std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0}, filter_ns_total_{0}, filter_batches_{0};
   static thread_local bool filter_used_;
   static constexpr uint64_t kGemmMinQueries = 5;    // measured at 10Mx768: K3 4 queries 5.3 ms, 8 queries 11.7 ms; K4 up to 32 queries 6.1 ms
   static constexpr uint64_t kMaxPassK = 1024;

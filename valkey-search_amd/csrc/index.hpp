@@ -59,6 +59,11 @@ struct SearchCtx {
   // scratch that is live.  (DevBuf::ensure growing a buffer frees the old one with hipFree, which waits for the device.)
   hipEvent_t busy = nullptr;
   bool has_busy = false;
+  // kernel-level timing of the candidate filter for vk_index_stats (bench.py's roofline): event pairs around its
+  // launches, drained into the index's totals when a pair is reused or when the statistics are read
+  struct TimedPair { hipEvent_t t0 = nullptr, t1 = nullptr; bool pending = false; };
+  TimedPair timed[8];
+  uint32_t timed_next = 0;
   Status begin_on(hipStream_t s);   // order the work about to be enqueued on `s` behind the context's previous user
   Status end_async(hipStream_t s);  // the work enqueued on `s` is the context's last user from now on
   ~SearchCtx();
@@ -72,6 +77,11 @@ class CtxPool {
   // context's previous asynchronous user (SearchCtx::busy)
   SearchCtx *acquire(hipStream_t on = nullptr);
   void release(SearchCtx *c);
+  // every context that is not leased right now
+  template <class F> void for_each_free(F &&f) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (SearchCtx *c : free_) f(c);
+  }
 
  private:
   int device_;

@@ -69,7 +69,8 @@ struct FlatGemmArgs {
 };
 // K4h (flat_filter.hip): candidate stage of the batched FLAT search on the f16 matrix cores
 struct FlatFilterArgs {
-  const void *rows;           // f32 rows, row_stride_f elements apart
+  const void *rows;           // f32 or (bf16 = 1) bf16 rows, row_stride_f elements apart
+  uint32_t bf16;
   const uint64_t *labels;
   const uint64_t *allow_bits;
   uint64_t allow_nbits;
