@@ -218,6 +218,7 @@ __device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing
 
 // Tile done: the gate.  Output register r of row tile rt is row rt*32 + (r&3) + 8*(r>>2) + 4*g, column li of the wave's
 // query tile.  Almost every 32 x 32 block has no survivor: one max over the lane's 16 values, one ballot.
+template <bool kTiny = false>
 __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[4], float thr, uint32_t tile_row0,
                                             uint32_t wave, uint32_t li, uint32_t g, SurvivorRing &ring, uint32_t lane) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -227,6 +228,7 @@ __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&ac
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
     if (__builtin_amdgcn_ballot_w64(m >= thr) != 0) {   // (rare: a survivor somewhere in this 32 x 32 block)
+      if constexpr (kTiny) { ring.cnt += 1; acc[rt] = zero; continue; }
       const uint32_t q = wave * 32 + li;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -327,6 +329,9 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
   uint32_t cancel_now = 0;
   bool stop = false;
   const uint32_t hot_row0 = first_tile * kFTileRows;
+  // (kAblate & 128: cycles per phase -- 0 fragment reads + MFMAs, 1 issue of the loads, 2 wait for the rows + convert +
+  // LDS stores, 3 gate, 4 barrier -- summed over the waves into a.dbg)
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 
 #define VK_FMMA(AV, KK)                                                                                             \
   _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
@@ -335,8 +340,15 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
   _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
     AV[rt] = *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + (KK) * 16);
 
+#define VK_TICK(I)                                                                                                  \
+  if constexpr (kAblate & 128) {                                                                                    \
+    const unsigned long long now_ = __builtin_readcyclecounter();                                                   \
+    ph[I] += now_ - tlast;                                                                                          \
+    tlast = now_;                                                                                                   \
+  }
 #define VK_FSTAGE(PAR, RLOAD, RSTORE, BCUR, BNEXT)                                                                  \
   {                                                                                                                 \
+    VK_TICK(4)                                                                                                      \
     const bool live = left_c != 0;                                                                                  \
     if (live && st_c == 0 && a.cancel && (tile_c % kCancelPollTiles) == 0)                                          \
       cancel_now = __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                        \
@@ -360,18 +372,26 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                            \
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                            \
     }                                                                                                               \
+    if constexpr (kAblate & 128) asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");            \
+    VK_TICK(0)                                                                                                      \
+    /* (the loads go out behind the MFMAs: placed between them -- one per MFMA -- the f32 kernel lost 40 %: the  */ \
+    /* compiler then also hoists the LDS stores, and with them the wait for HBM data, into the MFMA sequence)   */ \
     if constexpr (!(kAblate & 16)) BNEXT = stage_b_load(a, wave, lb.st, lane);                                      \
     fpos_advance(lb, stages);                                                                                       \
     if constexpr (!(kAblate & 32)) RLOAD = stage_rows_load<kBf16>(a, (kAblate & 1) ? hot_row0 : ld.row0, ld.st, tid); \
     fpos_advance(ld, stages);                                                                                       \
+    VK_TICK(1)                                                                                                      \
     if constexpr (!(kAblate & 8)) stage_rows_store<kBf16>(lds_a + ((PAR) ^ 1) * kBufHalfs, tid, RSTORE);            \
+    if constexpr (kAblate & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+    VK_TICK(2)                                                                                                      \
     left_c -= live ? 1u : 0u;                                                                                       \
     st_c += 1;                                                                                                      \
     if (live && st_c == stages) {                                                                                   \
-      if (has_q && !(kAblate & 2)) filter_gate(a, acc, thr, tile_row0, wave, li, g, ring, lane);                                \
+      if (has_q && !(kAblate & 2)) filter_gate<(kAblate & 64) != 0>(a, acc, thr, tile_row0, wave, li, g, ring, lane);                                \
       st_c = 0;                                                                                                     \
       tile_c += 1;                                                                                                  \
       tile_row0 += kFTileRows;                                                                                      \
+      VK_TICK(3)                                                                                                    \
       stop = __syncthreads_or((int)cancel_now) != 0;   /* block-uniform: every wave leaves at the same tile */      \
     } else {                                                                                                        \
       __syncthreads();                                                                                              \
@@ -388,8 +408,14 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
     VK_FSTAGE(1, x3, x0, b3, b3)
   }
 #undef VK_FSTAGE
+#undef VK_TICK
 #undef VK_FMMA
 #undef VK_FAREAD
+  if constexpr (kAblate & 128) {
+    if (lane == 0 && a.dbg)
+      for (int i = 0; i < 5; ++i) atomicAdd(&a.dbg[i], ph[i]);
+  }
+  if constexpr (kAblate & 64) { if (ring.cnt == 0xFFFFFFFFu) a.ovf[0] = 1; return; }
   ring_flush(a, ring, lane);
 }
 
@@ -414,6 +440,8 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
   }
   switch (a.ablate) {
     case 0: hipLaunchKernelGGL((flat_filter_kernel<0, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 128: hipLaunchKernelGGL((flat_filter_kernel<128, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 64: hipLaunchKernelGGL((flat_filter_kernel<64, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
     case 2: hipLaunchKernelGGL((flat_filter_kernel<2, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
     case 32: hipLaunchKernelGGL((flat_filter_kernel<32, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
     default: return hipErrorInvalidValue;

@@ -12,6 +12,7 @@
 // those that passed).  That corner is unreachable through FT.SEARCH (FLAT + filter always
 // takes the pre-filter path, src/query/planner.cc:23-29); here a filtered scan returns
 // the exact k best allowed rows.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -818,6 +819,11 @@ class FlatIndex final : public Index {
     f.cancel = d_cancel;
     static const uint32_t ablate = getenv("VK_FILTER_ABLATE") ? (uint32_t)atoi(getenv("VK_FILTER_ABLATE")) : 0;
     f.ablate = ablate;
+    if (ablate & 128) {   // phase timing experiment: the d_fthr buffer's tail holds the five counters
+      VK_TRY(ctx->d_idx.ensure(64));
+      VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 64, s));
+      f.dbg = ctx->d_idx.as<unsigned long long>();
+    }
     VK_HIP_TRY(launch_flat_qprep(f, s));
     // 3. the filter: one launch per 256 queries, every launch one pass over the rows
     if (filter_blocks_ == 0) {
@@ -825,7 +831,7 @@ class FlatIndex final : public Index {
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, store_.device());
       filter_blocks_ = cus > 0 ? (uint32_t)cus : 256;
     }
-    SearchCtx::TimedPair &tp = ctx->timed[ctx->timed_next++ % 8];
+    SearchCtx::TimedPair &tp = ctx->timed[ctx->timed_next++ % 32];
     drain_timed(tp);
     if (!tp.t0) {
       VK_HIP_TRY(hipEventCreate(&tp.t0));
@@ -890,6 +896,14 @@ class FlatIndex final : public Index {
     // 5. ... or the exact kernel over everything (only when the flag is up: its blocks return at once otherwise)
     VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, bound, ovf, 1));
     filter_used_ = true;
+    if (ablate & 128) {
+      unsigned long long h[5];
+      VK_HIP_TRY(hipStreamSynchronize(s));
+      VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, 40, hipMemcpyDeviceToHost));
+      const double waves = (double)filter_blocks_ * 8;
+      fprintf(stderr, "[vk] filter phases, cycles per wave: mfma %.0f  load-issue %.0f  rows-wait+convert+store %.0f  gate %.0f  barrier %.0f\n",
+              h[0] / waves, h[1] / waves, h[2] / waves, h[3] / waves, h[4] / waves);
+    }
     return Status::Ok();
   }
 

@@ -62,7 +62,7 @@ struct SearchCtx {
   // kernel-level timing of the candidate filter for vk_index_stats (bench.py's roofline): event pairs around its
   // launches, drained into the index's totals when a pair is reused or when the statistics are read
   struct TimedPair { hipEvent_t t0 = nullptr, t1 = nullptr; bool pending = false; };
-  TimedPair timed[8];
+  TimedPair timed[32];
   uint32_t timed_next = 0;
   Status begin_on(hipStream_t s);   // order the work about to be enqueued on `s` behind the context's previous user
   Status end_async(hipStream_t s);  // the work enqueued on `s` is the context's last user from now on

@@ -90,6 +90,7 @@ struct FlatFilterArgs {
   // timing experiments only (VK_FILTER_ABLATE, bits; results invalid): 1 rows re-read from the block's first tile (L2
   // hits), 2 no gate, 4 no MFMAs / fragment reads, 8 no conversion + LDS stores, 16 no B loads, 32 no row loads
   uint32_t ablate;
+  unsigned long long *dbg;    // ablate & 128: [5] cycles per phase, summed over the waves
 };
 size_t flat_filter_lds_bytes();
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2);
