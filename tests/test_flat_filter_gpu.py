@@ -188,3 +188,34 @@ def test_bf16_rows_through_the_filter(vsa, oracle, metric):
         st = f.stats()
         assert st.last_filter_candidates >= nq * k and st.last_filter_fallback == 0
         _same(got, e.search_batch(Q[:nq], k))
+
+
+@pytest.mark.parametrize("dim,dtype", [(64, "f32"), (200, "f32"), (768, "f32"), (128, "bf16")])
+def test_l2_through_the_filter(vsa, oracle, dim, dtype):
+    """L2: the filter accumulates x.q - |x|^2/2 (the half norms ride along as one more K-step), the gate and the exact
+    re-rank are the same machinery -- batched L2 had no matrix path at all before"""
+    rng = np.random.default_rng(dim + 1)
+    n = 60_000
+    centres = 2.0 * rng.standard_normal((30, dim)).astype(np.float32)
+    x = centres[rng.integers(0, 30, n)] + rng.standard_normal((n, dim)).astype(np.float32) * rng.uniform(0.2, 1.5, (n, 1)).astype(np.float32)
+    f, e = _pair(vsa, dim, "L2", x, dtype=dtype)
+    Q = centres[rng.integers(0, 30, 260)] + rng.standard_normal((260, dim)).astype(np.float32)
+    for nq, k in ((40, 10), (256, 1), (260, 10), (100, 64)):
+        got = f.search_batch(Q[:nq], k)
+        st = f.stats()
+        assert st.last_filter_candidates >= nq * k and st.last_filter_fallback == 0, (nq, k)
+        _same(got, e.search_batch(Q[:nq], k))
+    if dtype == "f32":
+        o = oracle.Flat(dim, "L2", max_elements=n)
+        o.add_many(x)
+        D, L, N = f.search_batch(Q[:40], 10)
+        for i in range(40):
+            od, ol = o.search(Q[i], 10)
+            assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+    # rows too long for the f16 half norms: the exact scan takes over
+    y = x.copy()
+    y[17] *= 400.0
+    f2, e2 = _pair(vsa, dim, "L2", y, dtype=dtype)
+    got = f2.search_batch(Q[:64], 10)
+    assert f2.stats().last_filter_fallback == 1
+    _same(got, e2.search_batch(Q[:64], 10))

@@ -54,8 +54,10 @@ constexpr uint32_t kF16Safe = 0x47000000u;   // 32768.0f: inputs beyond it do no
 // stats[0] = max over rows of |x|^2 (f32 bits, rounded up), stats[1] = max |x_i| (f32 bits; +inf for a non-finite element):
 // both only ever grow (atomicMax on the bit patterns of non-negative floats), which keeps them valid bounds when rows
 // are overwritten or removed.
+// hn16 (optional, L2 indexes): per row half its squared norm, split into two f16 (hi | lo << 16) -- the extra K-step
+// that turns the filter's dot product into dot - |x|^2 / 2.
 __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32_t bf16, uint32_t stride_e, uint32_t chunks,
-                                                        uint32_t lo, uint32_t hi, uint32_t *stats) {
+                                                        uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *hn16) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 3, rq = lane >> 2;
   const uint32_t total_waves = gridDim.x * 4, n_tiles = (hi - lo + kRowsPerWave - 1) / kRowsPerWave;
   float best_n2 = 0.f, best_abs = 0.f;
@@ -74,6 +76,12 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32
     n2 += dpp_quad_xor1(n2);
     n2 += dpp_quad_xor2(n2);
     if (bad || !(n2 - n2 == 0.f)) mx = __builtin_inff();
+    if (hn16 != nullptr && row < hi && j == 0) {
+      const float hn = 0.5f * n2;
+      const _Float16 h0 = (_Float16)hn;
+      const _Float16 h1 = (_Float16)(hn - (float)h0);
+      hn16[row] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+    }
     best_n2 = fmaxf(best_n2, n2);
     best_abs = fmaxf(best_abs, mx);
   }
@@ -85,11 +93,12 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32
   }
 }
 
-hipError_t launch_row_stats(const void *rows, bool bf16, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t *stats, hipStream_t s) {
+hipError_t launch_row_stats(const void *rows, bool bf16, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *hn16,
+                            hipStream_t s) {
   if (hi <= lo) return hipSuccess;
   const uint32_t tiles = (hi - lo + kRowsPerWave - 1) / kRowsPerWave;
   const uint32_t blocks = std::min<uint32_t>((tiles + 3) / 4, 2048);
-  hipLaunchKernelGGL(row_stats_kernel, dim3(blocks), dim3(256), 0, s, rows, bf16 ? 1u : 0u, stride_e, stride_e / 16, lo, hi, stats);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(blocks), dim3(256), 0, s, rows, bf16 ? 1u : 0u, stride_e, stride_e / 16, lo, hi, stats, hn16);
   return hipGetLastError();
 }
 
@@ -133,10 +142,23 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
     // see the header: relative part, absolute (subnormal) part, the reference's own rounding, 1 - dot
     const float rel = (a.bf16 ? 0x1p-11f : 0x1p-10f) + 0x1p-22f + D * 0x1p-22f + (D / 16.f + 5.f) * 0x1p-24f;   // (bf16 rows convert exactly)
     const float eps = (R * qn * rel + 0x1.01p-25f * sqrtf(D) * (R + qn) + 0x1p-23f * fmaxf(1.f, 1.f + R * qn)) * 1.001f;
-    const bool f16_ok = !bad && mx <= 32768.f && amax <= 32768.f && (R - R == 0.f) && (eps - eps == 0.f);
+    bool f16_ok = !bad && mx <= 32768.f && amax <= 32768.f && (R - R == 0.f) && (eps - eps == 0.f);
     // no bound yet (fewer than k allowed rows in the sample) or inputs that cannot go through f16: every row passes,
     // the list overflows, and the exact kernel answers this batch
-    thr = (f16_ok && bound - bound == 0.f) ? ((1.f - bound) - eps) - 0x1p-22f * fmaxf(1.f, fabsf(1.f - bound)) : -__builtin_inff();
+    if (!a.l2) {
+      thr = (f16_ok && bound - bound == 0.f) ? ((1.f - bound) - eps) - 0x1p-22f * fmaxf(1.f, fabsf(1.f - bound)) : -__builtin_inff();
+    } else {
+      // |x - q|^2 = 2 (|x|^2/2) + |q|^2 - 2 x.q: the kernel accumulates x.q - |x|^2/2 (half norms as one more K-step,
+      // split in two f16: 2^-21 relative), so a row stays iff  acc >= (|q|^2 - bound - eps2) / 2.  eps2: twice the dot
+      // product's margin, the f32 rounding of both norms (D 2^-23 relative, generously), the split of the half norm, and
+      // the reference's own rounding of its sum of squared differences ((D/16 + 6) 2^-24 of at most (R + |q|)^2).
+      const float nq2 = n2;
+      const float sumsq = R * R + qn * qn, top = (R + qn) * (R + qn);
+      const float eps2 = (2.f * eps + sumsq * (D * 0x1p-23f + 0x1p-20f) + top * (D / 16.f + 6.f) * 0x1p-23f) * 1.001f;
+      f16_ok = f16_ok && 0.5f * R * R <= 60000.f && (eps2 - eps2 == 0.f);
+      const float c = 0.5f * (nq2 - bound) - 0.5f * eps2;
+      thr = (f16_ok && bound - bound == 0.f) ? c - 0x1p-21f * fmaxf(1.f, fabsf(c)) : -__builtin_inff();
+    }
   }
   a.thr[j] = thr;
 }
@@ -146,12 +168,20 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
 // owns query tile w (32 queries) against all 128 rows of the tile = four 32 x 32 accumulator tiles.
 constexpr int kFThreads = 512;
 // this thread's share of one stage: 128 rows x 64 k = 2048 groups of 4 elements / 512 threads (16 B of f32, 8 B of bf16)
-template <bool kBf16> struct RowStage { float4 v[4]; };
-template <> struct RowStage<true> { uint2 v[4]; };
+template <bool kBf16> struct RowStage { float4 v[4]; uint32_t hn; };
+template <> struct RowStage<true> { uint2 v[4]; uint32_t hn; };
 
-template <bool kBf16>
+// (kL2: every stage also carries the packed half norm of row tid % 128 of its tile -- 4 bytes per thread, L2 hits after
+// the tile's first stage -- so that it travels through the same register sets and LDS buffers as the rows, without a
+// load or a branch of its own in the loop)
+template <bool kBf16, bool kL2>
 __device__ __forceinline__ RowStage<kBf16> stage_rows_load(const FlatFilterArgs &a, uint32_t tile_row0, uint32_t st, uint32_t tid) {
   RowStage<kBf16> s;
+  s.hn = 0;
+  if constexpr (kL2) {
+    const uint32_t r = tile_row0 + (tid & (kFTileRows - 1));
+    s.hn = a.hn16[r < a.n_rows ? r : a.n_rows - 1];
+  }
   // idx = tid + 512 u: row = idx / 16, 4-element column idx % 16 of the row's 64-element stage slice (coalesced per row)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -165,8 +195,11 @@ __device__ __forceinline__ RowStage<kBf16> stage_rows_load(const FlatFilterArgs 
 
 // -> f16 in LDS.  f32 rows: round to nearest even.  bf16 rows: bf16 -> f32 is a shift and f32 -> f16 is then EXACT for
 // every value in f16's normal range (8 significant bits fit 11), so a bf16 index carries no row rounding error at all.
-template <bool kBf16>
-__device__ __forceinline__ void stage_rows_store(_Float16 *buf, uint32_t tid, const RowStage<kBf16> &s) {
+template <bool kBf16, bool kL2>
+__device__ __forceinline__ void stage_rows_store(_Float16 *buf, uint32_t *hn_buf, uint32_t tid, const RowStage<kBf16> &s) {
+  if constexpr (kL2) {
+    if (tid < (uint32_t)kFTileRows) hn_buf[tid] = s.hn;
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const uint32_t idx = tid + (uint32_t)kFThreads * u;
@@ -264,7 +297,7 @@ __device__ __forceinline__ void fpos_advance(FPos &p, uint32_t stages) {
 }
 
 // kAblate: timing experiments only (compile-time, so that the product kernel has no branches around its loads)
-template <int kAblate, bool kBf16>
+template <int kAblate, bool kBf16, bool kL2>
 __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
   extern __shared__ _Float16 lds_a[];   // [2 stages][128 rows][kFAStride], then the waves' survivor rings
   const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -276,6 +309,7 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
   ring.q = reinterpret_cast<uint32_t *>(lds_a + 2 * kBufHalfs) + wave * 2 * kWave;
   ring.row = ring.q + kWave;
   ring.cnt = 0;
+  uint32_t *hn_lds = reinterpret_cast<uint32_t *>(lds_a + 2 * kBufHalfs) + (kFThreads / kWave) * 2 * kWave;   // [2][128] (kL2)
 
   // this block's contiguous range of row tiles
   const uint32_t n_tiles = (a.n_rows + kFTileRows - 1) / kFTileRows;
@@ -300,21 +334,21 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
   // rotating them through a copy would make the copy wait for loads that are still in flight.
   FPos ld{first_tile * kFTileRows, 0, total};   // next stage whose rows are fetched
   FPos lb = ld;                                  // next stage whose B operands are fetched
-  RowStage<kBf16> x0 = stage_rows_load<kBf16>(a, ld.row0, ld.st, tid), x1, x2, x3;
-  stage_rows_store<kBf16>(lds_a, tid, x0);
+  RowStage<kBf16> x0 = stage_rows_load<kBf16, kL2>(a, ld.row0, ld.st, tid), x1, x2, x3;
+  stage_rows_store<kBf16, kL2>(lds_a, hn_lds, tid, x0);
   BFrags b0 = stage_b_load(a, wave, lb.st, lane), b1, b2, b3;
   fpos_advance(ld, stages);
   fpos_advance(lb, stages);
   b1 = stage_b_load(a, wave, lb.st, lane);        // stages 1, 2, 3: B operands, then rows
-  x1 = stage_rows_load<kBf16>(a, ld.row0, ld.st, tid);
+  x1 = stage_rows_load<kBf16, kL2>(a, ld.row0, ld.st, tid);
   fpos_advance(ld, stages);
   fpos_advance(lb, stages);
   b2 = stage_b_load(a, wave, lb.st, lane);
-  x2 = stage_rows_load<kBf16>(a, ld.row0, ld.st, tid);
+  x2 = stage_rows_load<kBf16, kL2>(a, ld.row0, ld.st, tid);
   fpos_advance(ld, stages);
   fpos_advance(lb, stages);
   b3 = stage_b_load(a, wave, lb.st, lane);
-  x3 = stage_rows_load<kBf16>(a, ld.row0, ld.st, tid);
+  x3 = stage_rows_load<kBf16, kL2>(a, ld.row0, ld.st, tid);
   fpos_advance(ld, stages);
   fpos_advance(lb, stages);
   __syncthreads();
@@ -371,6 +405,16 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                            \
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                            \
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                            \
+      if constexpr (kL2) {                                                                                          \
+        if (st_c + 1 == stages) {   /* one more K-step: (hn_hi, hn_lo, 0 ...) x (-1, -1, 0 ...) = - |x|^2 / 2 */    \
+          const uint4 nb = make_uint4(g == 0 ? 0xBC00BC00u : 0u, 0u, 0u, 0u);                                       \
+          _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                                        \
+            const uint4 na = make_uint4(g == 0 ? hn_lds[(PAR) * kFTileRows + rt * 32 + li] : 0u, 0u, 0u, 0u);       \
+            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, na), __builtin_bit_cast(f16x8, nb), \
+                                                             acc[rt], 0, 0, 0);                                     \
+          }                                                                                                         \
+        }                                                                                                           \
+      }                                                                                                             \
     }                                                                                                               \
     if constexpr (kAblate & 128) asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");            \
     VK_TICK(0)                                                                                                      \
@@ -378,10 +422,10 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
     /* compiler then also hoists the LDS stores, and with them the wait for HBM data, into the MFMA sequence)   */ \
     if constexpr (!(kAblate & 16)) BNEXT = stage_b_load(a, wave, lb.st, lane);                                      \
     fpos_advance(lb, stages);                                                                                       \
-    if constexpr (!(kAblate & 32)) RLOAD = stage_rows_load<kBf16>(a, (kAblate & 1) ? hot_row0 : ld.row0, ld.st, tid); \
+    if constexpr (!(kAblate & 32)) RLOAD = stage_rows_load<kBf16, kL2>(a, (kAblate & 1) ? hot_row0 : ld.row0, ld.st, tid); \
     fpos_advance(ld, stages);                                                                                       \
     VK_TICK(1)                                                                                                      \
-    if constexpr (!(kAblate & 8)) stage_rows_store<kBf16>(lds_a + ((PAR) ^ 1) * kBufHalfs, tid, RSTORE);            \
+    if constexpr (!(kAblate & 8)) stage_rows_store<kBf16, kL2>(lds_a + ((PAR) ^ 1) * kBufHalfs, hn_lds + ((PAR) ^ 1) * kFTileRows, tid, RSTORE); \
     if constexpr (kAblate & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
     VK_TICK(2)                                                                                                      \
     left_c -= live ? 1u : 0u;                                                                                       \
@@ -419,11 +463,14 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
   ring_flush(a, ring, lane);
 }
 
-size_t flat_filter_lds_bytes() { return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)(kFThreads / kWave) * 2 * kWave * 4; }
+size_t flat_filter_lds_bytes() {
+  return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)(kFThreads / kWave) * 2 * kWave * 4 + (size_t)2 * kFTileRows * 4;
+}
 
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2) {
   (void)bf16;
-  return !l2 && (row_stride_f % kFStageK) == 0 && k >= 1 && k <= 64;
+  (void)l2;
+  return (row_stride_f % kFStageK) == 0 && k >= 1 && k <= 64;
 }
 
 hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
@@ -433,17 +480,20 @@ hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
 
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.nqt == 0 || a.nqt > 8 || blocks == 0) return hipErrorInvalidValue;
-  if (a.bf16) {
+  const dim3 grid(blocks), block(kFThreads);
+  const size_t lds = flat_filter_lds_bytes();
+  if (a.bf16 || a.l2) {
     if (a.ablate) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((flat_filter_kernel<0, true>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a);
+    if (a.bf16 && a.l2) hipLaunchKernelGGL((flat_filter_kernel<0, true, true>), grid, block, lds, s, a);
+    else if (a.bf16) hipLaunchKernelGGL((flat_filter_kernel<0, true, false>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((flat_filter_kernel<0, false, true>), grid, block, lds, s, a);
     return hipGetLastError();
   }
   switch (a.ablate) {
-    case 0: hipLaunchKernelGGL((flat_filter_kernel<0, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
-    case 128: hipLaunchKernelGGL((flat_filter_kernel<128, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
-    case 64: hipLaunchKernelGGL((flat_filter_kernel<64, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
-    case 2: hipLaunchKernelGGL((flat_filter_kernel<2, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
-    case 32: hipLaunchKernelGGL((flat_filter_kernel<32, false>), dim3(blocks), dim3(kFThreads), flat_filter_lds_bytes(), s, a); break;
+    case 0: hipLaunchKernelGGL((flat_filter_kernel<0, false, false>), grid, block, lds, s, a); break;
+    case 128: hipLaunchKernelGGL((flat_filter_kernel<128, false, false>), grid, block, lds, s, a); break;
+    case 64: hipLaunchKernelGGL((flat_filter_kernel<64, false, false>), grid, block, lds, s, a); break;
+    case 32: hipLaunchKernelGGL((flat_filter_kernel<32, false, false>), grid, block, lds, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -231,6 +231,7 @@ class FlatIndex final : public Index {
   ~FlatIndex() override {
     (void)hipSetDevice(store_.device());
     d_rowstats_.release();
+    d_hn16_.release();
   }
 
   Status add(uint64_t label, const float *row) override {
@@ -534,7 +535,7 @@ class FlatIndex final : public Index {
     // K4h + exact re-rank: a batch large enough that the exact matrix-core kernel is the bottleneck, an index large
     // enough that the pre-pass sample is a small part of it
     if (!lb_dist_ && nq >= filter_min_queries_ && !(cancel && *cancel) && !force_scan_ && filter_enabled_ &&
-        flat_filter_supported(store_.stride_f(), k, store_.bf16(), l2()) && flat_gemm_supported(store_.stride_f(), k) &&
+        flat_filter_supported(store_.stride_f(), k, store_.bf16(), l2()) && (l2() || flat_gemm_supported(store_.stride_f(), k)) &&
         count >= 8 * filter_prepass_rows(k) && count >= filter_min_rows_) {
       const uint32_t *d_cancel = cancel_word;
       if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
@@ -546,16 +547,25 @@ class FlatIndex final : public Index {
       if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
       return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel);
     }
+    const uint32_t *d_cancel = cancel_word;
+    uint64_t row_end = count;
+    if (cancel && *cancel) row_end = std::min<uint64_t>(count, k);          // (those rows are scanned whatever the flag says)
+    else if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
+    return scan_k3(ctx, d_q, nq, k, row_end, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld);
+  }
+
+  // K3 (+ merge) over rows [0, row_end): the VALU scan; run_flag: device-side conditional launch (kernels.hpp)
+  Status scan_k3(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t row_end, const uint64_t *d_allow,
+                 uint64_t allow_nbits, const uint32_t *d_cancel, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n,
+                 hipStream_t s, uint64_t out_ld, const uint32_t *run_flag = nullptr, uint32_t run_if = 0) {
+    int e = flat_scan_slots_per_lane(k);
+    const uint32_t chunks = store_.stride_f() / 16;
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
     if (lb_dist_) e = 16;            // the paged scan has one instantiation: 16 slots per lane, one query per pass
     const int qb = lb_dist_ ? 1 : flat_scan_pick_qb(nq, chunks, e, l2());
     const uint32_t nqg = (uint32_t)((nq + qb - 1) / qb);
-    // rows: cancelled at entry -> only the first k rows are looked at (bruteforce.h:120-129); cancelled later -> the
-    // kernel stops between row tiles (FlatScanArgs::cancel) and the answer is what the lists hold
-    uint64_t row_end = count;
-    const uint32_t *d_cancel = cancel_word;
-    if (cancel && *cancel) row_end = std::min<uint64_t>(count, k);          // (those rows are scanned whatever the flag says)
-    else if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
+    // (rows: cancelled at entry -> only the first k rows are looked at, bruteforce.h:120-129; cancelled later -> the
+    // kernel stops between row tiles, FlatScanArgs::cancel, and the answer is what the lists hold)
     // row partitions: enough blocks to fill 256 CUs, never more waves than 16-row tiles
     const uint64_t tiles = (row_end + 15) / 16;
     // ... and at least ~4 tiles per wave: every block leaves a partial list for the merge kernel (one wave per
@@ -586,6 +596,8 @@ class FlatIndex final : public Index {
       a.nrp = nrp;
       a.nqg = nqg;
       a.cancel = d_cancel;
+      a.run_flag = run_flag;
+      a.run_if = run_if;
       VK_HIP_TRY(launch_flat_scan(a, l2(), store_.bf16(), qb, e, s));
     }
     MergeArgs m{};
@@ -600,6 +612,8 @@ class FlatIndex final : public Index {
     m.out_dist = d_out_d;
     m.out_label = d_out_l;
     m.out_n = d_out_n;
+    m.run_flag = run_flag;
+    m.run_if = run_if;
     VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
     return Status::Ok();
   }
@@ -761,11 +775,16 @@ class FlatIndex final : public Index {
       VK_TRY(d_rowstats_.ensure(64));
       VK_HIP_TRY(hipMemsetAsync(d_rowstats_.p, 0, 64, store_.stream()));
     }
-    if (store_.take_written(&lo, &hi) || first) {
-      if (first) { lo = 0; hi = count_; }
+    bool all = first;
+    if (l2() && d_hn16_.cap < store_.alloc_rows() * 4) {   // (the half-norm table follows the row table's size)
+      VK_TRY(d_hn16_.ensure(store_.alloc_rows() * 4));
+      all = true;
+    }
+    if (store_.take_written(&lo, &hi) || all) {
+      if (all) { lo = 0; hi = count_; }
       hi = std::min<uint64_t>(hi, store_.alloc_rows());
       VK_HIP_TRY(launch_row_stats(store_.d_rows(), store_.bf16(), store_.stride_f(), (uint32_t)lo, (uint32_t)hi,
-                                  d_rowstats_.as<uint32_t>(), store_.stream()));
+                                  d_rowstats_.as<uint32_t>(), l2() ? d_hn16_.as<uint32_t>() : nullptr, store_.stream()));
       VK_HIP_TRY(hipStreamSynchronize(store_.stream()));
     }
     return Status::Ok();
@@ -779,10 +798,14 @@ class FlatIndex final : public Index {
                      uint64_t out_ld, const uint32_t *d_cancel) {
     VK_TRY(ensure_row_stats());
     // 1. bound: the exact kernel over the first rows (answers land in the output arrays for a moment)
-    in_prepass_ = true;
-    Status ps = scan_gemm(ctx, d_q, nq, k, filter_prepass_rows(k), d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
-    in_prepass_ = false;
-    VK_TRY(ps);
+    if (l2()) {   // (L2 has no exact matrix-core kernel: the VALU scan over the sample)
+      VK_TRY(scan_k3(ctx, d_q, nq, k, filter_prepass_rows(k), d_allow, allow_nbits, nullptr, d_out_d, d_out_l, d_out_n, s, k));
+    } else {
+      in_prepass_ = true;
+      Status ps = scan_gemm(ctx, d_q, nq, k, filter_prepass_rows(k), d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
+      in_prepass_ = false;
+      VK_TRY(ps);
+    }
     VK_TRY(ctx->d_stats.ensure(std::max<size_t>(64, nq * 8)));
     VK_HIP_TRY(launch_kth_bound(d_out_d, d_out_n, (uint32_t)k, (uint32_t)nq, ctx->d_stats.as<float>(), s));
     const float *bound = ctx->d_stats.as<float>();
@@ -799,6 +822,8 @@ class FlatIndex final : public Index {
     FlatFilterArgs f{};
     f.rows = store_.d_rows();
     f.bf16 = store_.bf16() ? 1 : 0;
+    f.l2 = l2() ? 1 : 0;
+    f.hn16 = l2() ? d_hn16_.as<uint32_t>() : nullptr;
     f.labels = store_.d_labels();
     f.allow_bits = d_allow;
     f.allow_nbits = allow_nbits;
@@ -894,7 +919,8 @@ class FlatIndex final : public Index {
     m.run_if = 0;
     VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
     // 5. ... or the exact kernel over everything (only when the flag is up: its blocks return at once otherwise)
-    VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, bound, ovf, 1));
+    if (l2()) VK_TRY(scan_k3(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld, ovf, 1));
+    else VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, bound, ovf, 1));
     filter_used_ = true;
     if (ablate & 128) {
       unsigned long long h[5];
@@ -914,7 +940,7 @@ class FlatIndex final : public Index {
   uint64_t filter_prepass_rows_ = getenv("VK_FILTER_PREPASS") ? (uint64_t)atoll(getenv("VK_FILTER_PREPASS")) : 65536;
   uint64_t filter_cap_ = getenv("VK_FILTER_CAP") ? (uint64_t)atoll(getenv("VK_FILTER_CAP")) : 8192;
   uint32_t filter_blocks_ = 0;
-  DevBuf d_rowstats_;
+  DevBuf d_rowstats_, d_hn16_;
   std::mutex stats_mu_;
   std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0}, filter_ns_total_{0}, filter_batches_{0};
   static thread_local bool filter_used_;

@@ -71,6 +71,8 @@ struct FlatGemmArgs {
 struct FlatFilterArgs {
   const void *rows;           // f32 or (bf16 = 1) bf16 rows, row_stride_f elements apart
   uint32_t bf16;
+  uint32_t l2;                // squared Euclidean distance instead of 1 - dot
+  const uint32_t *hn16;       // l2: per row |x|^2 / 2 as two f16 (hi | lo << 16), written by row_stats_kernel
   const uint64_t *labels;
   const uint64_t *allow_bits;
   uint64_t allow_nbits;
@@ -94,7 +96,8 @@ struct FlatFilterArgs {
 };
 size_t flat_filter_lds_bytes();
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2);
-hipError_t launch_row_stats(const void *rows, bool bf16, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t *stats, hipStream_t s);
+hipError_t launch_row_stats(const void *rows, bool bf16, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *hn16,
+                            hipStream_t s);
 hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s);
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s);
 
