@@ -176,6 +176,14 @@ int vk_index_search_batch(vk_index *ix, const void *queries, uint64_t nq, uint64
                           uint64_t ef_runtime, const uint64_t *allow_bits, uint64_t allow_nbits,
                           const volatile int *cancel_flag, int partial_ok,
                           float *out_dist, uint64_t *out_label, uint64_t *out_n);
+/* The same with ONE FILTER PER QUERY: allow_bits_tab[q] / allow_nbits_tab[q] is query q's bitmap (NULL = unfiltered).
+ * The reference evaluates its InlineVectorFilter per FT.SEARCH (search.cc:103-134), so a batch of coalesced hybrid
+ * queries carries as many filters as queries; HNSW applies them inside one launch, FLAT (always pre-filtered by the
+ * planner, planner.cc:23-29) serves the batch in runs of queries that share a bitmap. */
+int vk_index_search_batch_filters(vk_index *ix, const void *queries, uint64_t nq, uint64_t k, uint64_t ef_runtime,
+                                  const uint64_t *const *allow_bits_tab, const uint64_t *allow_nbits_tab,
+                                  const volatile int *cancel_flag, int partial_ok,
+                                  float *out_dist, uint64_t *out_label, uint64_t *out_n);
 /* Same, but queries and outputs are DEVICE pointers and the work is enqueued on
  * `hip_stream` (a hipStream_t, NULL = the index's own stream) without a host sync:
  * what a sharded index calls on each of its shards (on a sharded index itself the pointers are
@@ -201,10 +209,12 @@ int vk_index_distance(vk_index *ix, uint64_t label, const void *query, float *ou
 /* the stored row (GetValueImpl -> getPoint bruteforce.h:85-90 / getDataByInternalId) */
 /* Query coalescing for vk_index_search.  The reference issues ONE query per call from up to
  * `reader-threads` pool threads (search.cc:886-910 -> :135-170); with max_batch > 1, concurrent
- * vk_index_search calls that carry no filter and no cancel flag and agree on (k, ef_runtime) are
- * merged into one device batch: the first caller waits until max_batch calls are queued or
- * max_wait_us elapsed, runs the batch and hands each caller its own answer (identical to the
- * answer it would have got alone).  max_batch <= 1 turns it off (the default). */
+ * vk_index_search calls that agree on (k, ef_runtime) are merged into one device batch -- each with
+ * its own filter bitmap or none (one filter per query inside the batch) and its own cancellation flag
+ * (a caller whose flag is raised while it waits leaves at once; the batch itself runs to its end): the
+ * first caller waits until max_batch calls are queued or max_wait_us elapsed, runs the batch and hands
+ * each caller its own answer (identical to the answer it would have got alone).  max_batch <= 1 turns
+ * it off (the default). */
 int vk_index_set_coalescing(vk_index *ix, uint32_t max_batch, uint32_t max_wait_us);
 int vk_index_get_row(vk_index *ix, uint64_t label, void *out_row);
 int vk_index_contains(vk_index *ix, uint64_t label, int *out_found);

@@ -25,9 +25,11 @@ struct FakeIndex final : vk::Index {
       const float *v = rq.queries + q * params_.dim;
       const uint64_t n = rq.k < 3 ? rq.k : 3;            // "fewer than k found" is part of the contract
       on[q] = n;
+      // a per-query filter shows in the answer: word 0 of the query's own bitmap is added to every label
+      const uint64_t tag = rq.allow_tab && rq.allow_tab[q] ? rq.allow_tab[q][0] + rq.allow_nbits_tab[q] : 0;
       for (uint64_t i = 0; i < n; ++i) {
         od[q * rq.k + i] = v[0] * 1000.f + (float)i + (float)rq.ef * 0.001f;
-        ol[q * rq.k + i] = (uint64_t)v[1] * 10 + i;
+        ol[q * rq.k + i] = (uint64_t)v[1] * 10 + i + tag;
       }
     }
     return vk::Status::Ok();
@@ -55,6 +57,8 @@ struct FakeIndex final : vk::Index {
 // request got its own answer.  out[0..3] = device calls, queries served, largest batch, coalescer batches.
 extern "C" int coalescer_run(int threads, int per_thread, uint32_t max_batch, uint32_t max_wait_us, int n_lanes,
                              int with_failing_lane, uint64_t *out) {
+  const bool toggle = (with_failing_lane & 2) != 0;
+  with_failing_lane &= 1;
   vk_index_params p{};
   p.struct_size = sizeof p;
   p.dim = 4;
@@ -72,7 +76,18 @@ extern "C" int coalescer_run(int threads, int per_thread, uint32_t max_batch, ui
       float q[4] = {(float)id, (float)(id + 7), 0.f, 0.f};
       float d[16];
       uint64_t l[16], n = 99;
-      vk::Status st = co.search(&ix, q, k, ef, d, l, &n);
+      // every third request carries its own filter; every 17th is cancelled before it is served and must come back
+      // at once with nothing, whatever the batch it would have ridden in does
+      const bool filtered = id % 3 == 0, cancelled = !fail && id % 17 == 5;
+      const uint64_t bits[1] = {(uint64_t)id * 1000};
+      const uint64_t nbits = 64 + (uint64_t)(id % 5);
+      volatile int flag = cancelled ? 1 : 0;
+      if (toggle && id == threads * per_thread / 2) co.configure(0, 0);      // coalescing switched off under load
+      vk::Status st = co.search(&ix, q, k, ef, filtered ? bits : nullptr, filtered ? nbits : 0, &flag, true, d, l, &n);
+      if (cancelled) {
+        if (!st.ok() || n != 0) bad += 1;
+        continue;
+      }
       if (fail) {
         if (st.ok() || st.msg.find("on purpose") == std::string::npos) bad += 1;
         continue;
@@ -80,7 +95,8 @@ extern "C" int coalescer_run(int threads, int per_thread, uint32_t max_batch, ui
       const uint64_t want_n = k < 3 ? k : 3;
       if (!st.ok() || n != want_n) { bad += 1; continue; }
       for (uint64_t i = 0; i < n; ++i)
-        if (d[i] != (float)id * 1000.f + (float)i + (float)ef * 0.001f || l[i] != (uint64_t)(id + 7) * 10 + i) bad += 1;
+        if (d[i] != (float)id * 1000.f + (float)i + (float)ef * 0.001f ||
+            l[i] != (uint64_t)(id + 7) * 10 + i + (filtered ? bits[0] + nbits : 0)) bad += 1;
     }
   };
   std::vector<std::thread> ts;

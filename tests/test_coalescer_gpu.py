@@ -104,3 +104,92 @@ def test_single_caller_is_not_stalled_beyond_the_wait(vsa):
     dt = time.perf_counter() - t0
     assert l[0] == 5 and d[0] == 0.0
     assert 0.015 < dt < 1.0
+
+
+def test_64_callers_each_with_its_own_tag_filter(vsa, oracle):
+    """Hybrid FT.SEARCH traffic: every caller brings its own filter (InlineVectorFilter is built per query,
+    search.cc:103-134) and a cancellation token that is never raised.  The calls must still coalesce -- one launch with
+    one filter per query -- and every caller must get the oracle's answer for ITS filter, on the same graph."""
+    import ctypes as C
+    rng = np.random.default_rng(14)
+    n, dim, k, M = 8000, 48, 10, 12
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    ix = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=M, ef_construction=80, ef_runtime=100, build_threads=4)
+    ix.add_batch(X)
+    for lab in rng.choice(n, 300, replace=False):
+        assert ix.remove(int(lab)) == 0
+    ix.flush()
+    o = oracle.HNSW.from_product_index(ix.save_raw, dim, "L2", M, ef_construction=80)
+    ncall = 64
+    Q = rng.standard_normal((ncall * 3, dim)).astype(np.float32)
+    # caller c: tag c % 16 (selectivity from 50 % down to 3 %); every fifth caller has no filter at all
+    tags = [None if c % 5 == 4 else oracle.allow_bitmap(np.flatnonzero(rng.random(n) < 0.5 / (1 + c % 16)), n) for c in range(ncall)]
+    got = [None] * len(Q)
+    err = []
+
+    def worker(c):
+        try:
+            flag = C.c_int(0)
+            for r in range(3):
+                i = c * 3 + r
+                got[i] = ix.search_one(Q[i], k, ef=100, allow=tags[c], allow_nbits=n, cancel=flag)
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    ix.set_coalescing(ncall, 2000)
+    ts = [threading.Thread(target=worker, args=(c,)) for c in range(ncall)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err, err
+    st = ix.stats()
+    assert st.coalesced_queries == len(Q) and st.coalesced_batches < len(Q) // 4
+    for i in range(len(Q)):
+        c = i // 3
+        d, l = o.search(Q[i], k, ef=100, allow=tags[c], allow_nbits=n if tags[c] is not None else None)
+        assert got[i][1].tolist() == l.tolist(), i
+        assert got[i][0].view(np.uint32).tolist() == d.view(np.uint32).tolist(), i
+    # the batch entry point with one filter per query, and FLAT serving such a batch run by run
+    ix.set_coalescing(0, 0)
+    D, L, N = ix.search_batch_filters(Q[:ncall], k, [tags[i // 3] for i in range(ncall)], [n] * ncall, ef=100)
+    for i in range(ncall):
+        assert L[i, :N[i]].tolist() == got[i][1].tolist()
+    f = vsa.Index("FLAT", dim, "L2", initial_cap=n)
+    f.add_batch(X)
+    of = oracle.Flat(dim, "L2", max_elements=n)
+    of.add_many(X)
+    D, L, N = f.search_batch_filters(Q[:40], k, [tags[i % 7] for i in range(40)], [n] * 40)
+    for i in range(40):
+        t = tags[i % 7]
+        d, l = of.search(Q[i], k, allow=t, allow_nbits=n if t is not None else None)
+        assert L[i, :N[i]].tolist() == l.tolist() and D[i, :N[i]].view(np.uint32).tolist() == d.view(np.uint32).tolist()
+
+
+def test_a_cancelled_caller_leaves_a_coalesced_batch_at_once(vsa):
+    import ctypes as C
+    import time
+    rng = np.random.default_rng(15)
+    X = rng.standard_normal((4000, 32)).astype(np.float32)
+    ix = vsa.Index("HNSW", 32, "L2", initial_cap=4000, m=8, ef_construction=40)
+    ix.add_batch(X)
+    ix.search_one(X[0], 3)
+    ix.set_coalescing(64, 200000)     # a 200 ms window that will not fill
+    flag = C.c_int(0)
+    res = {}
+
+    def caller():
+        t0 = time.perf_counter()
+        try:
+            res["out"] = ix.search_one(X[1], 3, cancel=flag, partial_ok=False)
+        except vsa.VkError as e:
+            res["err"] = e
+        res["dt"] = time.perf_counter() - t0
+
+    th = threading.Thread(target=caller)
+    th.start()
+    time.sleep(0.02)
+    flag.value = 1
+    th.join()
+    # the leader of a lane cannot leave its own batch, a follower can: either way the call is back long before the window
+    assert res["dt"] < 0.19 or "err" in res
+    if "err" in res:
+        assert res["err"].code == vsa.VK_ERR_CANCELLED

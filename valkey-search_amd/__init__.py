@@ -88,6 +88,7 @@ def lib() -> C.CDLL:
     L.vk_index_set_coalescing.argtypes = [vp, u32, u32]
     L.vk_index_search.argtypes = [vp, vp, u64, u64, vp, u64, vp, i32, vp, vp, u64p]
     L.vk_index_search_batch.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, i32, vp, vp, vp]
+    L.vk_index_search_batch_filters.argtypes = [vp, vp, u64, u64, u64, vp, vp, vp, i32, vp, vp, vp]
     L.vk_index_search_batch_device.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, vp, vp, vp]
     L.vk_index_search_labels.argtypes = [vp, vp, u64, vp, u64, vp, vp, u64p]
     L.vk_index_distance.argtypes = [vp, u64, vp, f32p]
@@ -184,15 +185,30 @@ class Index:
         """Merge concurrent single-query searches into device batches (vk_index_set_coalescing)."""
         _check(lib().vk_index_set_coalescing(self._h, int(max_batch), int(max_wait_us)))
 
-    def search_one(self, q, k, ef=0):
+    def search_one(self, q, k, ef=0, allow=None, allow_nbits=None, cancel=None, partial_ok=True):
         """vk_index_search itself (the per-FT.SEARCH entry point; ctypes drops the GIL around it)."""
         q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
         d = np.empty(k, np.float32)
         l = np.empty(k, np.uint64)
         n = C.c_uint64(0)
-        _check(lib().vk_index_search(self._h, q.ctypes.data, int(k), int(ef), None, 0, None, 1, d.ctypes.data,
+        ap, nb = (None, 0) if allow is None else (allow.ctypes.data, int(allow_nbits if allow_nbits is not None else allow.size * 64))
+        cflag = None if cancel is None else C.cast(C.pointer(cancel), C.c_void_p)
+        _check(lib().vk_index_search(self._h, q.ctypes.data, int(k), int(ef), ap, nb, cflag, int(partial_ok), d.ctypes.data,
                                      l.ctypes.data, C.byref(n)))
         return d[:n.value], l[:n.value]
+
+    def search_batch_filters(self, Q, k, allows, nbits, ef=0):
+        """one allow-bitmap (uint64 array or None) per query: vk_index_search_batch_filters"""
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        nq = Q.shape[0]
+        keep = [None if a is None else np.ascontiguousarray(a, dtype=np.uint64) for a in allows]
+        tab = (C.c_void_p * nq)(*[None if a is None else a.ctypes.data for a in keep])
+        nb = np.array([0 if a is None else int(b) for a, b in zip(keep, nbits)], dtype=np.uint64)
+        od = np.full((nq, max(k, 1)), np.inf, dtype=np.float32)
+        ol = np.full((nq, max(k, 1)), np.iinfo(np.uint64).max, dtype=np.uint64)
+        on = np.zeros(nq, dtype=np.uint64)
+        _check(lib().vk_index_search_batch_filters(self._h, _ptr(Q), nq, k, ef, tab, _ptr(nb), None, 1, _ptr(od), _ptr(ol), _ptr(on)))
+        return od[:, :k], ol[:, :k], on
 
     # ---- queries
     def search(self, q, k, ef=0, allow=None, allow_nbits=None, cancel=None, partial_ok=True):

@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -36,18 +37,38 @@ class Coalescer {
   uint64_t batches() const { return batches_; }
   uint64_t queries() const { return queries_; }
 
-  // one single-query request; returns the status of the batch it travelled in
-  Status search(Index *ix, const float *query, uint64_t k, uint64_t ef, float *out_dist, uint64_t *out_label,
-                uint64_t *out_n) {
-    Req me{query, out_dist, out_label, out_n, Status::Ok(), false};
+  // One single-query request; returns the status of the batch it travelled in.  Requests of one (k, ef) lane travel
+  // together whatever their filters: each carries its own allow-bitmap (or none) and the batch is searched with one
+  // filter per query (SearchRequest::allow_tab) -- hybrid FT.SEARCH traffic batches like plain traffic.  A request
+  // with a cancellation flag keeps watching it while it waits: once raised, the caller leaves at once (HNSW without
+  // partial results: VK_ERR_CANCELLED, vector_hnsw.cc:327-329; otherwise an empty answer, "what it has") and the
+  // batch's answer for it is dropped.
+  Status search(Index *ix, const float *query, uint64_t k, uint64_t ef, const uint64_t *allow_bits, uint64_t allow_nbits,
+                const volatile int *cancel_flag, bool partial_ok, float *out_dist, uint64_t *out_label, uint64_t *out_n) {
+    auto me = std::make_shared<Req>();
+    me->q = query;
+    me->allow = allow_bits;
+    me->allow_nbits = allow_nbits;
+    me->od = out_dist;
+    me->ol = out_label;
+    me->on = out_n;
     std::unique_lock<std::mutex> lk(mu_);
     const auto key = std::make_pair(k, ef);
     Lane &lane = lanes_[key];
-    lane.q.push_back(&me);
+    lane.q.push_back(me);
     if (lane.leader_active && lane.q.size() >= batch_cap()) cv_.notify_all();  // batch full: wake the leader
-    while (!me.done) {
+    while (!me->done) {
+      if (cancel_flag && *cancel_flag) {   // leave; whoever runs the batch finds the request abandoned
+        me->abandoned = true;
+        for (auto it = lane.q.begin(); it != lane.q.end(); ++it)
+          if (it->get() == me.get()) { lane.q.erase(it); break; }
+        *out_n = 0;
+        const bool hnsw = ix->params().algo == VK_ALGO_HNSW;
+        return hnsw && !partial_ok ? Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout") : Status::Ok();
+      }
       if (lane.leader_active) {
-        cv_.wait(lk);
+        if (cancel_flag) cv_.wait_for(lk, std::chrono::microseconds(100));
+        else cv_.wait(lk);
         continue;
       }
       // nobody is driving this lane: lead one batch (ours is in it unless the queue is longer
@@ -61,20 +82,22 @@ class Coalescer {
     // so the map does not grow by one entry per distinct pair ever seen
     auto it = lanes_.find(key);
     if (it != lanes_.end() && it->second.q.empty() && !it->second.leader_active) lanes_.erase(it);
-    return me.st;
+    return me->st;
   }
 
  private:
   struct Req {
-    const float *q;
-    float *od;
-    uint64_t *ol;
-    uint64_t *on;
+    const float *q = nullptr;
+    const uint64_t *allow = nullptr;
+    uint64_t allow_nbits = 0;
+    float *od = nullptr;
+    uint64_t *ol = nullptr;
+    uint64_t *on = nullptr;
     Status st;
-    bool done;
+    bool done = false, abandoned = false;
   };
   struct Lane {
-    std::deque<Req *> q;
+    std::deque<std::shared_ptr<Req>> q;
     bool leader_active = false;
   };
   void lead_one_batch(Index *ix, Lane &lane, uint64_t k, uint64_t ef, std::unique_lock<std::mutex> &lk) {
@@ -84,7 +107,7 @@ class Coalescer {
     // (the limit is re-read: vk_index_set_coalescing(ix, 0, ..) while requests are queued must still drain them --
     // a leader always takes at least its own request)
     const size_t cap = batch_cap();
-    std::vector<Req *> batch;
+    std::vector<std::shared_ptr<Req>> batch;
     while (!lane.q.empty() && batch.size() < cap) {
       batch.push_back(lane.q.front());
       lane.q.pop_front();
@@ -93,19 +116,31 @@ class Coalescer {
     const uint64_t nq = batch.size();
     Status st = Status::Ok();
     std::vector<float> Q, D;
-    std::vector<uint64_t> L, N;
+    std::vector<uint64_t> L, N, nbits;
+    std::vector<const uint64_t *> tab;
     try {
       Q.resize(nq * dim);
       D.resize(nq * k);
       L.resize(nq * k);
       N.resize(nq);
-      for (uint64_t i = 0; i < nq; ++i) memcpy(Q.data() + i * dim, batch[i]->q, (size_t)dim * 4);
+      bool any_filter = false;
+      for (uint64_t i = 0; i < nq; ++i) {
+        memcpy(Q.data() + i * dim, batch[i]->q, (size_t)dim * 4);
+        any_filter = any_filter || batch[i]->allow != nullptr;
+      }
       SearchRequest rq;
       rq.queries = Q.data();
       rq.nq = nq;
       rq.k = k;
       rq.ef = ef;
-      st = ix->search(rq, D.data(), L.data(), N.data());
+      if (any_filter) {
+        tab.resize(nq);
+        nbits.resize(nq);
+        for (uint64_t i = 0; i < nq; ++i) { tab[i] = batch[i]->allow; nbits[i] = batch[i]->allow_nbits; }
+        rq.allow_tab = tab.data();
+        rq.allow_nbits_tab = nbits.data();
+      }
+      if (nq) st = ix->search(rq, D.data(), L.data(), N.data());
     } catch (const std::exception &e) {
       st = Status::Err(VK_ERR_INTERNAL, e.what());
     }
@@ -113,7 +148,8 @@ class Coalescer {
     batches_ += 1;
     queries_ += nq;
     for (uint64_t i = 0; i < nq; ++i) {
-      Req *r = batch[i];
+      Req *r = batch[i].get();
+      if (r->abandoned) continue;          // its caller has left (cancelled): the buffers are no longer ours to write
       r->st = st;
       if (st.ok()) {
         *r->on = N[i];

@@ -109,7 +109,7 @@ SearchCtx::~SearchCtx() {
   if (busy) (void)hipEventDestroy(busy);
   if (stream) (void)hipStreamSynchronize(stream);
   for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats, &d_sync, &d_pool, &d_pool2, &d_redo,
-                    &d_fq16, &d_fthr, &d_fcnt, &d_fcand, &d_fpart_d, &d_fpart_l})
+                    &d_fq16, &d_fthr, &d_fcnt, &d_fcand, &d_fpart_d, &d_fpart_l, &d_allow_tab})
     b->release();
   for (PinBuf *b : {&h_q, &h_out_d, &h_out_l, &h_out_n, &h_tmp, &h_idx, &h_cancel}) b->release();
   if (stream) (void)hipStreamDestroy(stream);
@@ -182,6 +182,39 @@ Status upload_allow(SearchCtx *ctx, const uint64_t *allow_bits, uint64_t allow_n
   VK_TRY(ctx->d_allow.ensure(std::max<size_t>(words * 8, 8)));
   if (words) VK_HIP_TRY(hipMemcpyAsync(ctx->d_allow.p, allow_bits, words * 8, hipMemcpyHostToDevice, ctx->stream));
   *d_allow = ctx->d_allow.as<uint64_t>();
+  return Status::Ok();
+}
+
+Status search_grouped_by_filter(Index *ix, const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) {
+  const uint32_t dim = ix->params().dim;
+  std::vector<uint8_t> done(rq.nq, 0);
+  std::vector<float> Q, D;
+  std::vector<uint64_t> L, N, idx;
+  for (uint64_t q0 = 0; q0 < rq.nq; ++q0) {
+    if (done[q0]) continue;
+    idx.clear();
+    for (uint64_t q = q0; q < rq.nq; ++q)
+      if (!done[q] && rq.allow_tab[q] == rq.allow_tab[q0] && rq.allow_nbits_tab[q] == rq.allow_nbits_tab[q0]) { idx.push_back(q); done[q] = 1; }
+    const uint64_t m = idx.size();
+    Q.resize(m * dim);
+    D.resize(m * rq.k);
+    L.resize(m * rq.k);
+    N.resize(m);
+    for (uint64_t i = 0; i < m; ++i) memcpy(Q.data() + i * dim, rq.queries + idx[i] * dim, (size_t)dim * 4);
+    SearchRequest g = rq;
+    g.queries = Q.data();
+    g.nq = m;
+    g.allow_tab = nullptr;
+    g.allow_nbits_tab = nullptr;
+    g.allow_bits = rq.allow_tab[q0];
+    g.allow_nbits = rq.allow_nbits_tab[q0];
+    VK_TRY(ix->search(g, D.data(), L.data(), N.data()));
+    for (uint64_t i = 0; i < m; ++i) {
+      out_n[idx[i]] = N[i];
+      memcpy(out_dist + idx[i] * rq.k, D.data() + i * rq.k, (size_t)N[i] * 4);
+      memcpy(out_label + idx[i] * rq.k, L.data() + i * rq.k, (size_t)N[i] * 8);
+    }
+  }
   return Status::Ok();
 }
 
@@ -299,6 +332,8 @@ class FlatIndex final : public Index {
   }
 
   Status search(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) override {
+    // (FLAT + filter is the pre-filter path in valkey-search, planner.cc:23-29: per-query bitmaps are served run by run)
+    if (rq.allow_tab) return search_grouped_by_filter(this, rq, out_dist, out_label, out_n);
     VK_TRY(flush_if_dirty());
     std::shared_lock<std::shared_mutex> lk(rw_);
     (void)hipSetDevice(store_.device());

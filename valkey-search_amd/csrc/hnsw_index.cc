@@ -148,6 +148,47 @@ class HnswIndex final : public Index {
     VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f()));
     const uint64_t *d_allow = nullptr;
     VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
+    // one filter per query: every distinct bitmap goes to the device once, the kernel gets [nq] pointers and lengths
+    const uint64_t *const *d_tab = nullptr;
+    const uint64_t *d_tab_nbits = nullptr;
+    if (rq.allow_tab) {
+      std::vector<const uint64_t *> uniq;
+      std::vector<uint64_t> uniq_bits, off;
+      size_t words = 0;
+      std::vector<uint32_t> which(rq.nq, ~0u);
+      for (uint64_t q = 0; q < rq.nq; ++q) {
+        if (!rq.allow_tab[q]) continue;
+        uint32_t u = 0;
+        for (; u < uniq.size(); ++u)
+          if (uniq[u] == rq.allow_tab[q] && uniq_bits[u] == rq.allow_nbits_tab[q]) break;
+        if (u == uniq.size()) {
+          uniq.push_back(rq.allow_tab[q]);
+          uniq_bits.push_back(rq.allow_nbits_tab[q]);
+          off.push_back(words);
+          words += (size_t)((rq.allow_nbits_tab[q] + 63) / 64) + 1;
+        }
+        which[q] = u;
+      }
+      const size_t tab_bytes = rq.nq * 16;
+      VK_TRY(ctx->d_allow_tab.ensure(tab_bytes + words * 8 + 8));
+      VK_TRY(ctx->h_tmp.ensure(tab_bytes));
+      char *base = ctx->d_allow_tab.as<char>();
+      uint64_t *h = ctx->h_tmp.as<uint64_t>();
+      for (uint64_t q = 0; q < rq.nq; ++q) {
+        h[q] = which[q] == ~0u ? 0 : reinterpret_cast<uint64_t>(base + tab_bytes + off[which[q]] * 8);
+        h[rq.nq + q] = which[q] == ~0u ? 0 : rq.allow_nbits_tab[q];
+      }
+      VK_HIP_TRY(hipMemcpyAsync(base, h, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+      for (size_t u = 0; u < uniq.size(); ++u) {
+        const size_t w = (size_t)((uniq_bits[u] + 63) / 64);
+        if (w) VK_HIP_TRY(hipMemcpyAsync(base + tab_bytes + off[u] * 8, uniq[u], w * 8, hipMemcpyHostToDevice, ctx->stream));
+      }
+      d_tab = reinterpret_cast<const uint64_t *const *>(base);
+      d_tab_nbits = reinterpret_cast<const uint64_t *>(base + rq.nq * 8);
+      if (uniq.empty()) d_tab = nullptr;   // (every entry was "no filter")
+    }
+    tab_ = d_tab;
+    tab_nbits_ = d_tab_nbits;
     VK_TRY(ctx->h_out_d.ensure(rq.nq * rq.k * 4));
     VK_TRY(ctx->h_out_l.ensure(rq.nq * rq.k * 8));
     VK_TRY(ctx->h_out_n.ensure(rq.nq * 4 + 64));
@@ -479,7 +520,11 @@ class HnswIndex final : public Index {
     // graph (every node enters it at most once), capped at 64k entries per wave; a query that outgrows the cap is
     // abandoned there and answered by a second launch whose frontier IS graph-sized (fewer waves; see below), so no
     // search is ever truncated.
-    const bool gpool = d_allow != nullptr || pub_.deleted > 0;
+    a.allow_tab = tab_;
+    a.allow_nbits_tab = tab_nbits_;
+    tab_ = nullptr;          // (set by search() around its launch() calls only)
+    tab_nbits_ = nullptr;
+    const bool gpool = d_allow != nullptr || a.allow_tab != nullptr || pub_.deleted > 0;
     a.gpool_level = gpool ? 1 : 0;
     if (gpool)   // (a multiple of 128: the kernel keeps one minimum per 64 entries in the LDS words of the pool)
       a.cand_cap = (uint32_t)std::min<uint64_t>(gpool_cap_, (std::max<uint64_t>(a.cand_cap, count) + 127) & ~(uint64_t)127);
@@ -821,7 +866,12 @@ class HnswIndex final : public Index {
   std::mutex store_mu_;
   DevBuf d_links0_, d_upper_slot_, d_upper_pool_;
   std::atomic<uint64_t> last_n_eval_{0}, last_n_hops_{0}, last_overflow_{0}, last_redo_{0};
+  static thread_local const uint64_t *const *tab_;
+  static thread_local const uint64_t *tab_nbits_;
 };
+
+thread_local const uint64_t *const *HnswIndex::tab_ = nullptr;
+thread_local const uint64_t *HnswIndex::tab_nbits_ = nullptr;
 
 // ---- persistence: hnswalg.h:808-865 (SaveIndex), :887-1139 (LoadIndex + loadCheck) -----------------
 Status HnswIndex::save(vk_write_chunk_fn fn, void *user) {

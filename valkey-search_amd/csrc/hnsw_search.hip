@@ -229,6 +229,10 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     const uint32_t q = a.redo_in ? a.redo_in[1 + qi] : qi;
     unsigned long long q_eval = 0, q_hops = 0;
     bool abandoned = false;
+    // this query's filter: its own bitmap when the batch carries one per query (InlineVectorFilter is built per
+    // FT.SEARCH, search.cc:103-134), else the batch's
+    const uint64_t *q_bits = a.allow_tab ? a.allow_tab[q] : a.allow_bits;
+    const uint64_t q_nbits = a.allow_tab ? a.allow_nbits_tab[q] : a.allow_nbits;
     if (poll_cancel(a.cancel)) {   // cancelled before this query started: an empty answer, and on to drain the queue
       for (uint32_t r = lane; r < a.k; r += kWave) { a.out_dist[(size_t)q * a.k + r] = __builtin_inff(); a.out_label[(size_t)q * a.k + r] = kNoLabel; }
       if (lane == 0) a.out_n[q] = 0;
@@ -334,7 +338,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     {
       bool ep_ok = true;
       if (a.check_deleted && (a.links0[(size_t)cur * a.l0_stride] & kDeleteFlag)) ep_ok = false;
-      if (ep_ok && a.allow_bits && !allow_bit(a.allow_bits, a.allow_nbits, a.labels[cur])) ep_ok = false;
+      if (ep_ok && q_bits && !allow_bit(q_bits, q_nbits, a.labels[cur])) ep_ok = false;
       const float d0 = ep_ok ? curdist : kFltMax;
       if (ep_ok) {
         lowerBound = curdist;   // the reference recomputes the same distance (:378)
@@ -534,7 +538,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
           // results
           bool ok = true;
           if (a.check_deleted && (a.links0[(size_t)cid * a.l0_stride] & kDeleteFlag)) ok = false;
-          if (ok && a.allow_bits && !allow_bit(a.allow_bits, a.allow_nbits, a.labels[cid])) ok = false;
+          if (ok && q_bits && !allow_bit(q_bits, q_nbits, a.labels[cid])) ok = false;
           if (ok) top.insert(cd, cid, a.ef, lane);
           if (top.cnt) lowerBound = top.at_d(top.cnt - 1);
         }

@@ -45,7 +45,8 @@ constexpr uint64_t kZeroCopyEntries = 4096;   // nq * k
 struct SearchCtx {
   hipStream_t stream = nullptr;
   DevBuf d_q, d_part_d, d_part_l, d_out_d, d_out_l, d_out_n, d_allow, d_idx, d_tmp, d_stats, d_sync, d_pool, d_pool2, d_redo,
-      d_fq16, d_fthr, d_fcnt, d_fcand, d_fpart_d, d_fpart_l;   // candidate filter (flat_filter.hip)
+      d_fq16, d_fthr, d_fcnt, d_fcand, d_fpart_d, d_fpart_l,   // candidate filter (flat_filter.hip)
+      d_allow_tab;                                             // per-query filter table + the bitmaps behind it
   PinBuf h_q, h_out_d, h_out_l, h_out_n, h_tmp, h_idx, h_cancel;
   // In-kernel cancellation: the caller's flag (any host memory) cannot be read by the device, so the thread that
   // waits for the stream polls it and raises the context's own word in pinned memory, which the kernels poll
@@ -104,6 +105,11 @@ struct SearchRequest {
   uint64_t nq = 0, k = 0, ef = 0;
   const uint64_t *allow_bits = nullptr;
   uint64_t allow_nbits = 0;
+  // one filter per query (host entry points: host arrays of host pointers, nullptr entry = unfiltered); overrides
+  // allow_bits.  The reference builds its filter per FT.SEARCH (search.cc:103-134), so a batch of coalesced hybrid
+  // queries carries as many bitmaps as queries.
+  const uint64_t *const *allow_tab = nullptr;
+  const uint64_t *allow_nbits_tab = nullptr;
   const volatile int *cancel_flag = nullptr;
   bool partial_ok = true;
   // search_device only: a device-visible cancellation word the caller maintains itself (the sharded index relays one
@@ -162,6 +168,8 @@ Status load_hnsw(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std:
 // pad nq host queries of `dim` floats into ctx->h_q ([nq][stride_f]) and copy to ctx->d_q
 Status upload_queries(SearchCtx *ctx, const float *queries, uint64_t nq, uint32_t dim, uint32_t stride_f);
 Status upload_allow(SearchCtx *ctx, const uint64_t *allow_bits, uint64_t allow_nbits, const uint64_t **d_allow);
+// an index without per-query filters in its kernels: the batch split into runs of queries that share a bitmap
+Status search_grouped_by_filter(Index *ix, const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n);
 // exact kNN over gathered distances with the AddPrefilteredKey rule (vector_base.cc:509-530)
 void prefilter_heap_select(const float *dist, const uint64_t *labels, uint64_t n, uint64_t k,
                            float *out_dist, uint64_t *out_label, uint64_t *out_n);

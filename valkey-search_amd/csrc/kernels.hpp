@@ -138,6 +138,8 @@ struct HnswSearchArgs {
   const float *queries;        // [nq][q_stride_f] padded
   const uint64_t *allow_bits;  // optional, by label
   uint64_t allow_nbits;
+  const uint64_t *const *allow_tab;   // optional [nq]: one bitmap per query (nullptr entry = no filter); overrides allow_bits
+  const uint64_t *allow_nbits_tab;    // [nq]
   uint32_t *visited;           // [wave slots][bitmap_words] scratch bitmaps
   float *out_dist;             // [nq][k]
   uint64_t *out_label;

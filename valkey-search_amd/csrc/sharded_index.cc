@@ -230,6 +230,7 @@ class ShardedIndex final : public Index {
   // ---- queries --------------------------------------------------------------------------------------
   Status search(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) override {
     if (rq.nq == 0) return Status::Ok();
+    if (rq.allow_tab) return search_grouped_by_filter(this, rq, out_dist, out_label, out_n);
     if (rq.k == 0) {
       for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
       return Status::Ok();

@@ -142,14 +142,36 @@ int vk_index_search_batch(vk_index *ix, const void *queries, uint64_t nq, uint64
   });
 }
 
+int vk_index_search_batch_filters(vk_index *ix, const void *queries, uint64_t nq, uint64_t k, uint64_t ef_runtime,
+                                  const uint64_t *const *allow_bits_tab, const uint64_t *allow_nbits_tab,
+                                  const volatile int *cancel_flag, int partial_ok, float *out_dist, uint64_t *out_label,
+                                  uint64_t *out_n) {
+  VK_NEED(ix);
+  if (nq && (!queries || !out_n)) return fail(VK_ERR_INVALID, "queries/out_n is NULL");
+  if (nq && k && (!out_dist || !out_label)) return fail(VK_ERR_INVALID, "output buffers are NULL");
+  if (nq && allow_bits_tab && !allow_nbits_tab) return fail(VK_ERR_INVALID, "allow_nbits_tab is NULL");
+  return guarded([&] {
+    vk::SearchRequest rq;
+    rq.queries = static_cast<const float *>(queries);
+    rq.nq = nq;
+    rq.k = k;
+    rq.ef = ef_runtime;
+    rq.allow_tab = allow_bits_tab;
+    rq.allow_nbits_tab = allow_nbits_tab;
+    rq.cancel_flag = cancel_flag;
+    rq.partial_ok = partial_ok != 0;
+    return ix->impl->search(rq, out_dist, out_label, out_n);
+  });
+}
+
 int vk_index_search(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, const uint64_t *allow_bits,
                     uint64_t allow_nbits, const volatile int *cancel_flag, int partial_ok, float *out_dist,
                     uint64_t *out_label, uint64_t *out_n) {
-  if (ix && ix->impl && ix->coalescer.enabled() && !allow_bits && !cancel_flag && k) {
+  if (ix && ix->impl && ix->coalescer.enabled() && k && !(cancel_flag && *cancel_flag)) {
     if (!query || !out_n || !out_dist || !out_label) return fail(VK_ERR_INVALID, "NULL argument");
     return guarded([&] {
-      return ix->coalescer.search(ix->impl.get(), static_cast<const float *>(query), k, ef_runtime, out_dist,
-                                  out_label, out_n);
+      return ix->coalescer.search(ix->impl.get(), static_cast<const float *>(query), k, ef_runtime, allow_bits, allow_nbits,
+                                  cancel_flag, partial_ok != 0, out_dist, out_label, out_n);
     });
   }
   return vk_index_search_batch(ix, query, 1, k, ef_runtime, allow_bits, allow_nbits, cancel_flag, partial_ok,
