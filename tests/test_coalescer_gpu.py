@@ -189,7 +189,8 @@ def test_a_cancelled_caller_leaves_a_coalesced_batch_at_once(vsa):
     time.sleep(0.02)
     flag.value = 1
     th.join()
-    # the leader of a lane cannot leave its own batch, a follower can: either way the call is back long before the window
-    assert res["dt"] < 0.19 or "err" in res
+    # a follower leaves the batch; the leader of a lane stops waiting for company and runs what is queued: either way
+    # the call is back long before the 200 ms window
+    assert res["dt"] < 0.1
     if "err" in res:
         assert res["err"].code == vsa.VK_ERR_CANCELLED

@@ -74,7 +74,7 @@ class Coalescer {
       // nobody is driving this lane: lead one batch (ours is in it unless the queue is longer
       // than max_batch, in which case the loop leads or follows again)
       lane.leader_active = true;
-      lead_one_batch(ix, lane, k, ef, lk);
+      lead_one_batch(ix, lane, k, ef, lk, cancel_flag);
       lane.leader_active = false;
       cv_.notify_all();
     }
@@ -100,10 +100,18 @@ class Coalescer {
     std::deque<std::shared_ptr<Req>> q;
     bool leader_active = false;
   };
-  void lead_one_batch(Index *ix, Lane &lane, uint64_t k, uint64_t ef, std::unique_lock<std::mutex> &lk) {
+  void lead_one_batch(Index *ix, Lane &lane, uint64_t k, uint64_t ef, std::unique_lock<std::mutex> &lk,
+                      const volatile int *leader_cancel) {
     const uint32_t dim = ix->params().dim;
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us_);
-    cv_.wait_until(lk, deadline, [&] { return lane.q.size() >= batch_cap(); });
+    // (a leader whose own token is raised stops waiting for company and runs what is queued)
+    while (lane.q.size() < batch_cap() && !(leader_cancel && *leader_cancel)) {
+      const auto now = std::chrono::steady_clock::now();
+      if (now >= deadline) break;
+      const auto slice = leader_cancel ? std::min<std::chrono::steady_clock::duration>(deadline - now, std::chrono::microseconds(100))
+                                       : deadline - now;
+      cv_.wait_for(lk, slice);
+    }
     // (the limit is re-read: vk_index_set_coalescing(ix, 0, ..) while requests are queued must still drain them --
     // a leader always takes at least its own request)
     const size_t cap = batch_cap();
