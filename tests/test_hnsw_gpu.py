@@ -281,8 +281,9 @@ def test_large_ef_uses_the_lds_result_list(vsa, oracle, metric):
     D, L, N = g.search_batch(Q, 20, ef=800)
     for i, q in enumerate(Q):
         _same(D[i, :N[i]], L[i, :N[i]], *o.search(q, 20, ef=800))
+    _same(*g.search(Q[0], 10, ef=5000), *o.search(Q[0], 10, ef=5000))      # (the ceiling is 16384 now)
     with pytest.raises(vsa.VkError):
-        g.search(Q[0], 10, ef=5000)
+        g.search(Q[0], 10, ef=20000)
 
 
 def test_long_rows(vsa, oracle):
@@ -293,3 +294,24 @@ def test_long_rows(vsa, oracle):
     g, o = _pair(vsa, oracle, x, "COSINE" if False else "IP", M=16, efc=60)
     for q in rng.standard_normal((6, dim)).astype(np.float32):
         _same(*g.search(q, 10, ef=80), *o.search(q, 10, ef=80))
+
+
+def test_k_up_to_the_default_max_vector_knn_and_wide_graphs(vsa, oracle):
+    """ft_search_parser.cc:34-45: max-vector-knn defaults to 10000 -- k (hence ef) that large must be served, and so must
+    graphs wider than M = 128"""
+    rng = np.random.default_rng(31)
+    n, dim = 12_000, 32
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g, o = _pair(vsa, oracle, x, "L2", M=8, efc=40, threads=1)
+    Q = rng.standard_normal((3, dim)).astype(np.float32)
+    for k, ef in ((5000, 0), (10000, 0), (10, 6000)):
+        D, L, N = g.search_batch(Q, k, ef=ef)
+        for i in range(len(Q)):
+            od, ol = o.search(Q[i], k, ef=ef)
+            assert N[i] == len(ol)
+            _same(D[i, :N[i]], L[i, :N[i]], od, ol)
+    with pytest.raises(vsa.VkError):                     # beyond the LDS list: a clean error, not a wrong answer
+        g.search_batch(Q, 20000)
+    w, ow = _pair(vsa, oracle, x[:3000], "L2", M=150, efc=320, threads=1)
+    for q in Q:
+        _same(*w.search(q, 10, ef=64), *ow.search(q, 10, ef=64))

@@ -488,8 +488,8 @@ class HnswIndex final : public Index {
     uint64_t ef = ef_runtime ? ef_runtime : graph_->ef();
     ef = std::max<uint64_t>(ef, k);                       // hnswalg.h:1705,1710
     const int e = hnsw_slots_per_lane(ef);
-    if (e == 0) return Status::Err(VK_ERR_INVALID, "ef (or k) > 4096 is not served by this build of the HNSW search");
-    if (graph_->maxM0() > 256) return Status::Err(VK_ERR_INVALID, "M > 128 is not served by this build of the HNSW search");
+    if (e == 0) return Status::Err(VK_ERR_INVALID, "ef (or k) > 16384 is not served by this build of the HNSW search");
+    if (graph_->maxM0() > 4096) return Status::Err(VK_ERR_INVALID, "M > 2048 is not served by this build of the HNSW search");
     const uint32_t count = pub_.count;
     HnswSearchArgs a{};
     a.rows = store_.d_rows();
@@ -524,7 +524,8 @@ class HnswIndex final : public Index {
     a.allow_nbits_tab = tab_nbits_;
     tab_ = nullptr;          // (set by search() around its launch() calls only)
     tab_nbits_ = nullptr;
-    const bool gpool = d_allow != nullptr || a.allow_tab != nullptr || pub_.deleted > 0;
+    // (a result list beyond 2048 entries takes the LDS the frontier would need: the frontier moves to HBM then, too)
+    const bool gpool = d_allow != nullptr || a.allow_tab != nullptr || pub_.deleted > 0 || ef > 2048;
     a.gpool_level = gpool ? 1 : 0;
     if (gpool)   // (a multiple of 128: the kernel keeps one minimum per 64 entries in the LDS words of the pool)
       a.cand_cap = (uint32_t)std::min<uint64_t>(gpool_cap_, (std::max<uint64_t>(a.cand_cap, count) + 127) & ~(uint64_t)127);
@@ -534,7 +535,8 @@ class HnswIndex final : public Index {
     a.check_deleted = pub_.deleted ? 1 : 0;
     a.out_ids = out_ids ? 1 : 0;
     a.cancel = d_cancel;
-    if (hnsw_lds_bytes(a) > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
+    if (hnsw_lds_bytes(a) > 160 * 1024)
+      return Status::Err(VK_ERR_INVALID, "query block + result list (dimension, ef, M) do not fit the 160 KiB of LDS");
     int max_blocks = 0;
     VK_HIP_TRY(hnsw_max_blocks(a, l2(), store_.bf16(), e, &max_blocks));
     // visited bitmaps: one per resident wave, bounded to 2 GiB per context

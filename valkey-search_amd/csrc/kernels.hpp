@@ -172,7 +172,7 @@ struct HnswSearchArgs {
   const uint32_t *cancel;
 };
 constexpr int kHnswLdsList = 16;      // hnsw_slots_per_lane(): 512 < ef <= kHnswMaxEf, result list in LDS
-constexpr uint64_t kHnswMaxEf = 4096;
+constexpr uint64_t kHnswMaxEf = 16384;   // (2 * ef words of LDS: the default max-vector-knn of 10000 fits, ft_search_parser.cc:34-45)
 int hnsw_slots_per_lane(uint64_t ef);                      // 0 = ef beyond kHnswMaxEf
 int hnsw_waves_per_block(const HnswSearchArgs &a);
 size_t hnsw_lds_bytes(const HnswSearchArgs &a);
