@@ -1,8 +1,11 @@
-"""World-size-2 `gloo` test (CPU) of the multi-GPU shard/merge logic: rows split in contiguous ranges,
-per-shard top-k, all-gather of (distance,label)[B][k], merge by (distance,label) -- the answer must be
-identical to the single-shard answer (fanout.cc:162-175 is the reference's cluster-level
-analogue).  The per-shard searches and the merge rule come from the oracle here (no GPU in this
-container); the same sharding code path is what bench.py drives with RCCL and the device merge."""
+"""World-size-2 `gloo` test (CPU) of the SPECIFICATION the multi-GPU path is built to, not of the product: rows split in
+contiguous ranges, per-shard top-k, all-gather of (distance,label)[B][k], merge by (distance,label) -- the merged
+answer must be identical to the single-shard answer, exact cross-shard ties included (fanout.cc:162-175
+is the reference's cluster-level analogue, whose arrival-order tie rule this total order replaces).  Everything here
+is the oracle's (there is no GPU in this container): it pins the rule and the world-size-2 plumbing of bench.py's
+fallback mode.  The PRODUCT's sharding, gather and merge kernel are tested where a GPU is:
+tests/test_sharded_index_gpu.py (the in-library sharded index against the unsharded one and the oracle) and
+tests/test_sharded_bench_gpu.py (both bench.py modes)."""
 import os
 import socket
 import sys
