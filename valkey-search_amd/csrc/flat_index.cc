@@ -798,7 +798,12 @@ class FlatIndex final : public Index {
 
   // sample the exact kernel bounds the k-th best distance on, for the candidate filter: its survivors are about
   // count * k / sample per query
-  uint64_t filter_prepass_rows(uint64_t k) const { return filter_prepass_rows_ * ((k + 9) / 10); }
+  // (at most 1/64 of the index: about 64 k survivors per query whatever the size, and the exact pass over the sample --
+  // for L2 the VALU scan -- stays a small part of the batch on mid-sized indexes)
+  uint64_t filter_prepass_rows(uint64_t k) const {
+    const uint64_t cap = filter_prepass_rows_ * ((k + 9) / 10);
+    return std::max<uint64_t>(std::min<uint64_t>(cap, count_ / 64), std::min<uint64_t>(cap, 1024 * ((k + 9) / 10)));
+  }
 
   // the largest row norm / element of the index, brought up to date for the rows written since the last call (once
   // after a writer phase; the searches of a reader phase find nothing to do)
@@ -834,7 +839,7 @@ class FlatIndex final : public Index {
     VK_TRY(ensure_row_stats());
     // 1. bound: the exact kernel over the first rows (answers land in the output arrays for a moment)
     if (l2()) {   // (L2 has no exact matrix-core kernel: the VALU scan over the sample)
-      VK_TRY(scan_k3(ctx, d_q, nq, k, filter_prepass_rows(k), d_allow, allow_nbits, nullptr, d_out_d, d_out_l, d_out_n, s, k));
+      VK_TRY(scan_k3(ctx, d_q, nq, k, filter_prepass_rows(k), d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, k));
     } else {
       in_prepass_ = true;
       Status ps = scan_gemm(ctx, d_q, nq, k, filter_prepass_rows(k), d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
