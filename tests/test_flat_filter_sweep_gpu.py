@@ -1,0 +1,95 @@
+"""Randomised sweep over the f16 candidate filter + exact re-rank (K4h): index size, dimension (padding, 1 to 25 pipeline
+stages per tile), batch size around the 32-query tiles and the 256-query launch groups, k up to 64, metric, row storage,
+row scales from 1e-3 to 1e2, duplicated rows (ties by label, survivor overflow), allow-bitmaps and deletions, drawn from a
+fixed seed.  The filter path must return exactly what the oracle returns -- ids and distance bits -- whatever it did on
+the way (vk_index_stats says whether it re-ranked its survivors or handed the batch to the exact kernel)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SWEEP_OFFSET = int(os.environ.get("VK_SWEEP_OFFSET", "0"))
+
+
+@pytest.fixture(scope="module")
+def vsa():
+    import _pkg
+    return _pkg.vsa
+
+
+def _bf16_round(x):
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+DIMS = [8, 33, 64, 65, 100, 128, 200, 256, 384, 500, 768, 1024, 1536]
+BATCHES = [33, 40, 63, 64, 65, 96, 128, 200, 255, 256, 257, 300, 513]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shape_through_the_filter(vsa, oracle, seed):
+    rng = np.random.default_rng(9000 + seed + SWEEP_OFFSET)
+    dim = int(rng.choice(DIMS))
+    n = int(rng.integers(34_000, 70_000 if dim <= 512 else 40_000))
+    nq = int(rng.choice(BATCHES))
+    metric = str(rng.choice(["L2", "IP", "COSINE"]))
+    dtype = "bf16" if rng.random() < 0.3 else "f32"
+    k = int(rng.choice([1, 3, 10, 10, 10, 17, 32, 64]))
+    scale = float(10.0 ** rng.uniform(-3, 2))
+    nc = int(rng.integers(5, 60))
+    centres = rng.standard_normal((nc, dim)).astype(np.float32)
+    spread = float(rng.uniform(0.05, 1.0))
+    x = (centres[rng.integers(0, nc, n)] + spread * rng.standard_normal((n, dim)).astype(np.float32)) * np.float32(scale)
+    dup = rng.random()
+    if dup < 0.15:                                # a few hundred copies: ties at the k-th distance
+        x[1000:1400] = x[999]
+    elif dup < 0.25:                              # tens of thousands: the survivor lists overflow
+        x[n // 3:] = x[7]
+    if metric == "COSINE":
+        x = (x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    labels = rng.permutation(3 * n)[:n].astype(np.uint64)
+    old = {v: os.environ.get(v) for v in ("VK_FILTER_PREPASS", "VK_FILTER_MIN_ROWS")}
+    os.environ.update(VK_FILTER_PREPASS="1024", VK_FILTER_MIN_ROWS="32768")
+    try:
+        g = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype)
+    finally:
+        for v, o in old.items():
+            if o is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = o
+    g.add_batch(x, labels)
+    xs = _bf16_round(x) if dtype == "bf16" else x
+    o = oracle.Flat(dim, metric, max_elements=n)
+    o.add_many(xs, labels)
+    if rng.random() < 0.3:
+        for lab in rng.choice(labels, 500, replace=False):
+            g.remove(int(lab))
+            o.remove(int(lab))
+    Q = (centres[rng.integers(0, nc, nq)] + spread * rng.standard_normal((nq, dim)).astype(np.float32)) * np.float32(scale)
+    if metric == "COSINE":
+        Q = (Q / np.maximum(np.linalg.norm(Q, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    allow = nbits = None
+    if rng.random() < 0.3:
+        nbits = int(labels.max()) + 1
+        allow = oracle.allow_bitmap(labels[rng.random(n) < rng.choice([0.5, 0.1, 0.01])], nbits)
+    D, L, N = g.search_batch(Q, k, allow=allow, allow_nbits=nbits)
+    st = g.stats()
+    # (the path needs an index at least eight times the bound's sample: 1024 rows per 10 of k with this test's settings)
+    if g.stats().count >= 8 * 1024 * ((k + 9) // 10):
+        assert st.last_filter_candidates > 0 or st.last_filter_fallback == 1, "the batch did not take the filter path: %s %s dim %d n %d nq %d k %d scale %g count %d allow %s" % (
+            metric, dtype, dim, n, nq, k, scale, g.stats().count, allow is not None)
+    if allow is not None:
+        # with a filter the reference's brute-force loop can under-fill (bruteforce.h:120-141, unreachable through
+        # FT.SEARCH); the product returns the exact k best allowed rows: the oracle over the allowed rows alone
+        keep = np.array([bool((allow[int(l) >> 6] >> np.uint64(int(l) & 63)) & np.uint64(1)) for l in labels])
+        live = np.array([o.distance(int(l), Q[0]) is not None for l in labels])
+        o = oracle.Flat(dim, metric, max_elements=n)
+        o.add_many(xs[keep & live], labels[keep & live])
+    for i in rng.choice(nq, min(nq, 24), replace=False):
+        od, ol = o.search(Q[i], k)
+        assert N[i] == len(ol), (seed, i)
+        assert L[i, :N[i]].tolist() == ol.tolist(), (seed, i, metric, dtype, dim, n, nq, k)
+        assert D[i, :N[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist(), (seed, i)

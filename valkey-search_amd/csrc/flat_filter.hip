@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
     // no bound yet (fewer than k allowed rows in the sample) or inputs that cannot go through f16: every row passes,
     // the list overflows, and the exact kernel answers this batch
     if (!a.l2) {
-      thr = (f16_ok && bound - bound == 0.f) ? ((1.f - bound) - eps) - 0x1p-22f * fmaxf(1.f, fabsf(1.f - bound)) : -__builtin_inff();
+      thr = (bound - bound == 0.f) ? ((1.f - bound) - eps) - 0x1p-22f * fmaxf(1.f, fabsf(1.f - bound)) : -__builtin_inff();
     } else {
       // |x - q|^2 = 2 (|x|^2/2) + |q|^2 - 2 x.q: the kernel accumulates x.q - |x|^2/2 (half norms as one more K-step,
       // split in two f16: 2^-21 relative), so a row stays iff  acc >= (|q|^2 - bound - eps2) / 2.  eps2: twice the dot
@@ -157,7 +157,14 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
       const float eps2 = (2.f * eps + sumsq * (D * 0x1p-23f + 0x1p-20f) + top * (D / 16.f + 6.f) * 0x1p-23f) * 1.001f;
       f16_ok = f16_ok && 0.5f * R * R <= 60000.f && (eps2 - eps2 == 0.f);
       const float c = 0.5f * (nq2 - bound) - 0.5f * eps2;
-      thr = (f16_ok && bound - bound == 0.f) ? c - 0x1p-21f * fmaxf(1.f, fabsf(c)) : -__builtin_inff();
+      thr = (bound - bound == 0.f) ? c - 0x1p-21f * fmaxf(1.f, fabsf(c)) : -__builtin_inff();
+    }
+    // Inputs that cannot go through f16 (values beyond its range, non-finite rows or queries, half norms beyond 60000):
+    // the products may be NaN, and a NaN passes no gate, open or not -- so the hand-over to the exact kernel is
+    // requested here, outright, and this column's gate stays closed.
+    if (!f16_ok) {
+      thr = __builtin_inff();
+      __hip_atomic_store(a.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   a.thr[j] = thr;
