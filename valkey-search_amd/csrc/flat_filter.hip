@@ -258,23 +258,29 @@ __device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing
 
 // Tile done: the gate.  Output register r of row tile rt is row rt*32 + (r&3) + 8*(r>>2) + 4*g, column li of the wave's
 // query tile.  Almost every 32 x 32 block has no survivor: one max over the lane's 16 values, one ballot.
-template <bool kTiny = false>
-__device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[4], float thr, uint32_t tile_row0,
+template <bool kTiny = false, int kRt = 4, bool kZero = true>
+__device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[kRt], float thr, uint32_t tile_row0,
                                             uint32_t wave, uint32_t li, uint32_t g, SurvivorRing &ring, uint32_t lane) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < kRt; ++rt) {
     float m = acc[rt][0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
     if (__builtin_amdgcn_ballot_w64(m >= thr) != 0) {   // (rare: a survivor somewhere in this 32 x 32 block)
       if constexpr (kTiny) { ring.cnt += 1; acc[rt] = zero; continue; }
       const uint32_t q = wave * 32 + li;
+      // the lane's passing registers as a bit mask, then one round per remaining bit of the busiest lane (usually one)
+      uint32_t mk = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; ++r) mk |= acc[rt][r] >= thr ? 1u << r : 0u;
+      if (q >= a.nq) mk = 0;
+      while (__builtin_amdgcn_ballot_w64(mk != 0) != 0) {
+        const uint32_t r = (uint32_t)__builtin_ctz(mk | 0x10000u);
         const uint32_t row = tile_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        bool pass = acc[rt][r] >= thr && row < a.n_rows && q < a.nq;
+        bool pass = mk != 0 && row < a.n_rows;
         if (pass && a.allow_bits != nullptr) pass = allow_bit(a.allow_bits, a.allow_nbits, a.labels[row]);
+        mk &= mk - 1;
         const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
         if (pm != 0) {
           const uint32_t n = (uint32_t)__popcll(pm);
@@ -288,7 +294,7 @@ __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&ac
         }
       }
     }
-    acc[rt] = zero;
+    if constexpr (kZero) acc[rt] = zero;
   }
 }
 
@@ -470,6 +476,368 @@ __global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
   ring_flush(a, ring, lane);
 }
 
+// ---- the filter, wave-specialised ---------------------------------------------------------------------------------------
+// Cycle counters in the kernel above say where its time goes: all eight waves multiply at the same time and then all
+// eight issue their loads at the same time (72 wave-loads through one address path) -- the matrix pipes and the address
+// path take turns, and the sum of the two is longer than the HBM time of the stage.  Here they belong to different waves:
+//   waves 0-3  CONSUMERS, one per SIMD: wave w multiplies the 128 rows of the tile with query tiles 2w, 2w+1 (eight
+//              32 x 32 accumulator tiles, 32 MFMAs per stage back to back).  A AND B operands come from LDS; the wave
+//              issues no memory instruction at all
+//   waves 4-5  ROW PRODUCERS: stream the rows, HBM -> registers (three stages in flight) -> f16 -> LDS
+//   waves 6-7  QUERY PRODUCERS: the stage's B operands, L2 -> registers (two stages in flight) -> LDS
+// so each SIMD holds one wave that keeps the matrix pipe busy and one that keeps the memory pipe busy, and a producer
+// that waits for HBM holds up nobody's MFMAs.  One barrier per stage; LDS: A 2 x 18 KB, B 2 x 32 KB.
+//
+// Why rows and B operands have producers of their own: loads return in order (one vmcnt counter per wave), so a wave
+// that fetches both waits for a B block (an L2 hit, needed soon) by waiting for the HBM rows requested before it; and
+// with all four producers fetching both, the stage's 64 wave-loads were issued more slowly than by two and two (cycle
+// counters: 1 900 against 1 270 cycles per stage -- the CU's one address path is the contended resource, 16 cycles per
+// 64-lane x 16-byte load at best).  Why the B operands go through registers although global_load_lds could write them to
+// LDS directly: a CU keeps only a few LDS-DMA pieces in flight -- eight per stage and wave took 1 350 cycles to ISSUE,
+// more than the MFMAs of the stage.
+//
+// The producers' loads are ordinary loads and the compiler places the waits (it counts the loads issued after the
+// one whose data is needed -- exactly the vmcnt values above); what has to be kept away from it is LDS-DMA in the same
+// wave (it then waits with vmcnt(0) everywhere) and __syncthreads() in the producers (below).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+template <bool kBf16> struct WsRows { f32x4v v[16]; uint32_t hn; };    // row producer thread: 128 rows x 64 k / 128 threads
+template <> struct WsRows<true> { u32x2v v[16]; uint32_t hn; };
+struct WsB { u32x4v v[16]; };                                          // query producer thread: 4 query tiles x 4 K-steps
+
+// idx = t + 128 u: row = idx / 16 = t / 16 + 8 u, 4-element column t % 16 of the row's stage slice.  The tile / stage /
+// u part of the address is uniform (a scalar base), the thread's part (voff, bytes) is computed once.
+// The producers load through buffer descriptors: the wave-uniform part of an address (tile, stage, row group) lives in
+// scalar registers -- descriptor base and scalar offset -- and the thread supplies one 32-bit offset computed once
+// (buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen).  With 64-bit per-lane addresses the same 16 loads took half as
+// long again to issue.  (0x00020000: the gfx9 raw-buffer format word; no bounds are wanted, the range is the maximum.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
+}
+template <bool kBf16, bool kL2>
+__device__ __forceinline__ void ws_rows_load(WsRows<kBf16> &s, const FlatFilterArgs &a, uint32_t tile_row0, uint32_t st, uint32_t t, uint32_t voff) {
+  if constexpr (kL2) {
+    const uint32_t r = tile_row0 + t;
+    s.hn = a.hn16[r < a.n_rows ? r : a.n_rows - 1];
+  }
+  constexpr size_t esz = kBf16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t r =
+      ws_rsrc(static_cast<const char *>(a.rows) + ((size_t)tile_row0 * a.row_stride_f + (size_t)st * kFStageK) * esz);
+  const uint32_t step = 8u * a.row_stride_f * (uint32_t)esz;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    // (aux 2 = nt: the rows are read once -- they should not push the query block out of L2)
+    if constexpr (kBf16) s.v[u] = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)(u * step), 2);
+    else s.v[u] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(u * step), 2));
+  }
+}
+template <bool kBf16, bool kL2>
+__device__ __forceinline__ void ws_rows_store(_Float16 *buf, uint32_t *hn_buf, uint32_t t, const WsRows<kBf16> &s) {
+  if constexpr (kL2) hn_buf[t] = s.hn;
+  _Float16 *dst = buf + (t >> 4) * kFAStride + (t & 15) * 4;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    f16x4 h;
+    if constexpr (kBf16) {
+      h[0] = (_Float16)__uint_as_float(s.v[u][0] << 16);
+      h[1] = (_Float16)__uint_as_float(s.v[u][0] & 0xFFFF0000u);
+      h[2] = (_Float16)__uint_as_float(s.v[u][1] << 16);
+      h[3] = (_Float16)__uint_as_float(s.v[u][1] & 0xFFFF0000u);
+    } else {
+      h[0] = (_Float16)s.v[u][0];
+      h[1] = (_Float16)s.v[u][1];
+      h[2] = (_Float16)s.v[u][2];
+      h[3] = (_Float16)s.v[u][3];
+    }
+    *reinterpret_cast<f16x4 *>(dst + u * 8 * kFAStride) = h;
+  }
+}
+// query producer wave p: the B operands of query tiles 4p .. 4p+3 of stage st, 16 x (64 lanes x 16 B), from the
+// fragment-major query copy; in LDS a stage is [query tile 8][K-step 4][lane 64] x 16 B
+constexpr int kWsBStage = 8 * 4 * kWave;   // in 16-byte slots
+__device__ __forceinline__ void ws_b_load(WsB &b, const FlatFilterArgs &a, uint32_t p, uint32_t st, uint32_t lane) {
+  const uint32_t ks_n = a.row_stride_f / 16;
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    const uint32_t jt0 = p * 4 + t4, jt = jt0 < a.nqt ? jt0 : a.nqt - 1;
+    const __amdgpu_buffer_rsrc_t r = ws_rsrc(reinterpret_cast<const char *>(a.q16) + ((size_t)jt * ks_n + st * 4) * kWave * 16);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) b.v[t4 * 4 + kk] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(lane * 16 + kk * 1024), 0, 0);
+  }
+}
+__device__ __forceinline__ void ws_b_store(uint4 *slot, uint32_t p, uint32_t lane, const WsB &b) {
+  u32x4v *dst = reinterpret_cast<u32x4v *>(slot) + (p * 16) * kWave + lane;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dst[i * kWave] = b.v[i];
+}
+
+template <bool kBf16, bool kL2, bool kTiming>
+__global__ __launch_bounds__(512, 1) void flat_filter_ws_kernel(FlatFilterArgs a) {
+  extern __shared__ _Float16 lds_a[];
+  constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;                    // one A stage
+  uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + 2 * kBufHalfs);          // [2][kWsBStage]
+  uint32_t *lds_ring = reinterpret_cast<uint32_t *>(lds_b + 2 * kWsBStage); // [4 consumer waves][2][64]
+  uint32_t *hn_lds = lds_ring + 4 * 2 * kWave;                              // [2][128] (kL2)
+  // [2]: cancellation seen during tile T -> word T & 1.  (An LDS-qualified pointer: through a generic one the accesses
+  // become FLAT instructions, whose out-of-order return forces every later wait for a load to be vmcnt(0).)
+  volatile __attribute__((address_space(3))) uint32_t *lds_stop =
+      (volatile __attribute__((address_space(3))) uint32_t *)(hn_lds + 2 * kFTileRows);
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t stages = a.row_stride_f / kFStageK;
+
+  const uint32_t n_tiles = (a.n_rows + kFTileRows - 1) / kFTileRows;
+  const uint32_t t_base = n_tiles / gridDim.x, t_rem = n_tiles % gridDim.x;
+  const uint32_t first_tile = blockIdx.x * t_base + (blockIdx.x < t_rem ? blockIdx.x : t_rem);
+  const uint32_t my_tiles = t_base + (blockIdx.x < t_rem ? 1u : 0u);
+  if (my_tiles == 0) return;
+  const uint32_t total = my_tiles * stages;
+  uint32_t st_c = 0, tile_c = 0, left_c = total;
+  bool stop = false;
+  if (tid < 2) lds_stop[tid] = 0;
+
+  // Leaving early (cancellation) must be decided identically by all eight waves or the next barrier never completes: the
+  // polling thread publishes what it saw during tile T in lds_stop[T & 1] before the tile's last barrier, everybody reads
+  // that word after it, and the word is not written again before tile T+2, i.e. behind a barrier that follows every read.
+  // (The read is hidden from the compiler: it would make every LDS read wait for the LDS-DMA pieces in flight.)
+#define VK_WS_TILE_END(BARRIER)                                                                                     \
+  {                                                                                                                 \
+    BARRIER;                                                                                                        \
+    uint32_t sv_;                                                                                                   \
+    asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(sv_) : "v"((uint32_t)(uintptr_t)(lds_stop + (tile_c & 1))) : "memory"); \
+    stop = sv_ != 0;                                                                                                \
+    st_c = 0;                                                                                                       \
+    tile_c += 1;                                                                                                    \
+  }
+
+  // (kTiming: cycles per phase, summed over the waves into a.dbg -- row producers 0 loads issued, 2 wait + convert + LDS
+  // stores, 3 barrier; query producers 4 issue + wait + LDS stores, 8 barrier; consumers 5 operands + MFMAs, 6 gate,
+  // 7 barrier)
+  constexpr bool timing = kTiming;
+#define VK_WS_TICK(I)                                                                                               \
+  if constexpr (timing) {                                                                                           \
+    const unsigned long long now_ = __builtin_readcyclecounter();                                                   \
+    ph[I] += now_ - tlast;                                                                                          \
+    tlast = now_;                                                                                                   \
+  }
+  // The producers' barrier is the bare instruction behind an explicit wait for the wave's own LDS stores:
+  // __syncthreads() puts a release fence in front of it, which for a wave with loads in flight may become vmcnt(0) --
+  // every stage of prefetch drained per stage.
+#define VK_WS_PBARRIER()                                                                                            \
+  {                                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                   \
+    asm volatile("" ::: "memory");                                                                                  \
+  }
+  if (wave >= 6) {
+    // ================================ query producer =====================================================
+    // iteration S: request B(S+2) into the register set B(S) left, write B(S+1) (requested one iteration ago) to slot
+    // (S+1) & 1, barrier.  Past the end of the stream the loads re-read its last stage (no branch around a load).
+    const uint32_t p = wave - 6;
+    FPos lb{first_tile * kFTileRows, 0, total};
+    WsB b0, b1;
+    ws_b_load(b0, a, p, lb.st, lane);
+    fpos_advance(lb, stages);
+    ws_b_load(b1, a, p, lb.st, lane);
+    fpos_advance(lb, stages);
+    ws_b_store(lds_b, p, lane, b0);
+    VK_WS_PBARRIER()
+    unsigned long long ph[2] = {0, 0}, tlast = __builtin_readcyclecounter();
+#define VK_WS_BPROD(PAR, BLOAD, BSTORE)                                                                             \
+    {                                                                                                               \
+      const bool live = left_c != 0;                                                                                \
+      VK_WS_TICK(1)                                                                                                 \
+      ws_b_load(BLOAD, a, p, lb.st, lane);                                                                          \
+      fpos_advance(lb, stages);                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      ws_b_store(lds_b + ((PAR) ^ 1) * kWsBStage, p, lane, BSTORE);                                                 \
+      if constexpr (timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+      VK_WS_TICK(0)                                                                                                 \
+      left_c -= live ? 1u : 0u;                                                                                     \
+      st_c += 1;                                                                                                    \
+      if (live && st_c == stages) VK_WS_TILE_END(VK_WS_PBARRIER()) else VK_WS_PBARRIER();                           \
+    }
+    while (left_c != 0 && !stop) {
+      VK_WS_BPROD(0, b0, b1)
+      if (stop) break;
+      VK_WS_BPROD(1, b1, b0)
+    }
+#undef VK_WS_BPROD
+    if constexpr (timing) {
+      if (lane == 0 && a.dbg) {
+        atomicAdd(&a.dbg[4], ph[0]);
+        atomicAdd(&a.dbg[8], ph[1]);
+      }
+    }
+    return;
+  }
+  if (wave >= 4) {
+    // ================================ row producer =======================================================
+    // Rows of stage s live in register set s % 3.  Iteration S: request the rows of stage S+3 into the set stage S
+    // left (converted one iteration ago), convert stage S+1 (the 32 loads of S+2 and S+3 stay outstanding) into LDS
+    // buffer (S+1) & 1, barrier.  Three stages of rows (96 KB per CU) are in flight.
+    const uint32_t t = tid - 256;
+    const uint32_t voff = ((t >> 4) * a.row_stride_f + (t & 15) * 4) * (kBf16 ? 2u : 4u);
+    FPos ld{first_tile * kFTileRows, 0, total};
+    WsRows<kBf16> x0, x1, x2;
+    x0.hn = x1.hn = x2.hn = 0;
+    ws_rows_load<kBf16, kL2>(x0, a, ld.row0, ld.st, t, voff);
+    fpos_advance(ld, stages);
+    ws_rows_load<kBf16, kL2>(x1, a, ld.row0, ld.st, t, voff);
+    fpos_advance(ld, stages);
+    ws_rows_load<kBf16, kL2>(x2, a, ld.row0, ld.st, t, voff);
+    fpos_advance(ld, stages);
+    ws_rows_store<kBf16, kL2>(lds_a, hn_lds, t, x0);
+    VK_WS_PBARRIER()
+    uint32_t ppar = 0;                                                       // S & 1
+    unsigned long long ph[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define VK_WS_PROD(RLOAD, RSTORE)                                                                                   \
+    {                                                                                                               \
+      const bool live = left_c != 0;                                                                                \
+      VK_WS_TICK(3)                                                                                                 \
+      if (live && st_c == 0 && t == 0 && a.cancel && (tile_c % kCancelPollTiles) == 0) {                            \
+        if (__hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) lds_stop[tile_c & 1] = 1; \
+      }                                                                                                             \
+      ws_rows_load<kBf16, kL2>(RLOAD, a, ld.row0, ld.st, t, voff);                                                  \
+      fpos_advance(ld, stages);                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      VK_WS_TICK(0)                                                                                                 \
+      ppar ^= 1;                                                                                                    \
+      ws_rows_store<kBf16, kL2>(lds_a + ppar * kBufHalfs, hn_lds + ppar * kFTileRows, t, RSTORE);                   \
+      if constexpr (timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+      VK_WS_TICK(2)                                                                                                 \
+      left_c -= live ? 1u : 0u;                                                                                     \
+      st_c += 1;                                                                                                    \
+      if (live && st_c == stages) VK_WS_TILE_END(VK_WS_PBARRIER()) else VK_WS_PBARRIER();                           \
+    }
+    while (left_c != 0 && !stop) {
+      VK_WS_PROD(x0, x1)
+      if (stop) break;
+      VK_WS_PROD(x1, x2)
+      if (stop) break;
+      VK_WS_PROD(x2, x0)
+    }
+#undef VK_WS_PROD
+    if constexpr (timing) {
+      if (lane == 0 && a.dbg)
+        for (int i = 0; i < 4; ++i) atomicAdd(&a.dbg[i], ph[i]);
+    }
+    return;
+  }
+#undef VK_WS_PBARRIER
+
+  // ================================== consumer ===========================================================
+  const uint32_t li = lane & 31, g = lane >> 5;
+  SurvivorRing ring;
+  ring.q = lds_ring + wave * 2 * kWave;
+  ring.row = ring.q + kWave;
+  ring.cnt = 0;
+  const bool has_q = wave * 2 < a.nqt;
+  float thr[2];
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) thr[t2] = wave * 2 + t2 < a.nqt ? a.thr[(wave * 2 + t2) * 32 + li] : __builtin_inff();
+  f32x16 acc[2][4];
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[t2][rt] = zero;
+  uint32_t tile_row0 = first_tile * kFTileRows;
+  uint32_t par = 0;
+  __syncthreads();                                            // (the prologue's barrier)
+
+  // iteration S: 32 MFMAs of stage S, operands from LDS (A: buffer S & 1, row li of each row tile; B: slot S & 1,
+  // query tiles 2w, 2w+1), fetched one K-step ahead; gate at the end of a tile; barrier.  Not unrolled (the buffer and
+  // the slot are offsets in a register): one copy of the gate's code.
+#define VK_WS_AB(FA, FB0, FB1, KK)                                                                                  \
+  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
+    FA[rt] = *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + (KK) * 16);                                \
+  FB0 = bb[(KK) * kWave];                                                                                           \
+  FB1 = bb[(4 + (KK)) * kWave];
+#define VK_WS_MM(FA, FB0, FB1)                                                                                      \
+  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                                                \
+    acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB0, acc[0][rt], 0, 0, 0);                          \
+    acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB1, acc[1][rt], 0, 0, 0);                          \
+  }
+  // (first K-step of a tile: the accumulators are not cleared -- 128 register moves -- but started from the constant 0)
+#define VK_WS_MMZ(FA, FB0, FB1)                                                                                     \
+  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                                                \
+    acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB0, zero, 0, 0, 0);                                \
+    acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB1, zero, 0, 0, 0);                                \
+  }
+#define VK_WS_STAGE(MM0)                                                                                            \
+  {                                                                                                                 \
+    f16x8 fa[4], fb[4], b0, b1, b2, b3;                                                                             \
+    VK_WS_AB(fa, b0, b1, 0)                                                                                         \
+    VK_WS_AB(fb, b2, b3, 1)                                                                                         \
+    MM0(fa, b0, b1)                                                                                                 \
+    VK_WS_AB(fa, b0, b1, 2)                                                                                         \
+    VK_WS_MM(fb, b2, b3)                                                                                            \
+    VK_WS_AB(fb, b2, b3, 3)                                                                                         \
+    VK_WS_MM(fa, b0, b1)                                                                                            \
+    VK_WS_MM(fb, b2, b3)                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                                                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                                             \
+  }
+  unsigned long long ph[3] = {0, 0, 0}, tlast = __builtin_readcyclecounter();
+  while (left_c != 0 && !stop) {
+    VK_WS_TICK(2)
+    const _Float16 *ab = lds_a + par * kBufHalfs + li * kFAStride + g * 8;
+    const f16x8 *bb = reinterpret_cast<const f16x8 *>(lds_b + par * kWsBStage + (wave * 2) * 4 * kWave) + lane;
+    if (has_q) {
+      if (st_c == 0) VK_WS_STAGE(VK_WS_MMZ) else VK_WS_STAGE(VK_WS_MM)
+      if constexpr (kL2) {
+        if (st_c + 1 == stages) {   // one more K-step: (hn_hi, hn_lo, 0 ...) x (-1, -1, 0 ...) = - |x|^2 / 2
+          const uint4 nb = make_uint4(g == 0 ? 0xBC00BC00u : 0u, 0u, 0u, 0u);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            const uint4 na = make_uint4(g == 0 ? hn_lds[par * kFTileRows + rt * 32 + li] : 0u, 0u, 0u, 0u);
+            acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, na), __builtin_bit_cast(f16x8, nb), acc[0][rt], 0, 0, 0);
+            acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, na), __builtin_bit_cast(f16x8, nb), acc[1][rt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if constexpr (timing) asm volatile("s_nop 7\n s_nop 7" ::: "memory");
+    VK_WS_TICK(0)
+    left_c -= 1;
+    st_c += 1;
+    par ^= 1;
+    if (st_c == stages) {
+      if (has_q) {
+        filter_gate<false, 4, false>(a, acc[0], thr[0], tile_row0, wave * 2, li, g, ring, lane);
+        filter_gate<false, 4, false>(a, acc[1], thr[1], tile_row0, wave * 2 + 1, li, g, ring, lane);
+      }
+      tile_row0 += kFTileRows;
+      VK_WS_TICK(1)
+      VK_WS_TILE_END(__syncthreads())
+    } else {
+      __syncthreads();
+    }
+  }
+#undef VK_WS_AB
+#undef VK_WS_MM
+#undef VK_WS_MMZ
+#undef VK_WS_STAGE
+#undef VK_WS_TILE_END
+#undef VK_WS_TICK
+  if constexpr (timing) {
+    if (lane == 0 && a.dbg)
+      for (int i = 0; i < 3; ++i) atomicAdd(&a.dbg[5 + i], ph[i]);
+  }
+  ring_flush(a, ring, lane);
+}
+
+size_t flat_filter_ws_lds_bytes() {
+  return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 +
+         (size_t)2 * kFTileRows * 4 + 16;
+}
+
 size_t flat_filter_lds_bytes() {
   return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)(kFThreads / kWave) * 2 * kWave * 4 + (size_t)2 * kFTileRows * 4;
 }
@@ -488,6 +856,19 @@ hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.nqt == 0 || a.nqt > 8 || blocks == 0) return hipErrorInvalidValue;
   const dim3 grid(blocks), block(kFThreads);
+  if (a.ablate & 256) {   // the wave-specialised kernel
+    const size_t wl = flat_filter_ws_lds_bytes();
+    const void *fn = a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_ws_kernel<true, true, false>)
+                                    : reinterpret_cast<const void *>(&flat_filter_ws_kernel<true, false, false>))
+                            : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_ws_kernel<false, true, false>)
+                                    : reinterpret_cast<const void *>(&flat_filter_ws_kernel<false, false, false>));
+    if ((a.ablate & 128) && !a.bf16 && !a.l2) fn = reinterpret_cast<const void *>(&flat_filter_ws_kernel<false, false, true>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+    if (e != hipSuccess) return e;
+    FlatFilterArgs args = a;
+    void *params[] = {&args};
+    return hipLaunchKernel(fn, grid, block, params, wl, s);
+  }
   const size_t lds = flat_filter_lds_bytes();
   if (a.bf16 || a.l2) {
     if (a.ablate) return hipErrorInvalidValue;

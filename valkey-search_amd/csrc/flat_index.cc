@@ -885,8 +885,8 @@ class FlatIndex final : public Index {
     static const uint32_t ablate = getenv("VK_FILTER_ABLATE") ? (uint32_t)atoi(getenv("VK_FILTER_ABLATE")) : 0;
     f.ablate = ablate;
     if (ablate & 128) {   // phase timing experiment: the d_fthr buffer's tail holds the five counters
-      VK_TRY(ctx->d_idx.ensure(64));
-      VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 64, s));
+      VK_TRY(ctx->d_idx.ensure(128));
+      VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
       f.dbg = ctx->d_idx.as<unsigned long long>();
     }
     VK_HIP_TRY(launch_flat_qprep(f, s));
@@ -963,9 +963,18 @@ class FlatIndex final : public Index {
     else VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, bound, ovf, 1));
     filter_used_ = true;
     if (ablate & 128) {
-      unsigned long long h[5];
+      unsigned long long h[8];
       VK_HIP_TRY(hipStreamSynchronize(s));
-      VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, 40, hipMemcpyDeviceToHost));
+      VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, 64, hipMemcpyDeviceToHost));
+      if (ablate & 256) {
+        const double w2 = (double)filter_blocks_ * 2, w4 = (double)filter_blocks_ * 4;
+        unsigned long long h8 = 0;
+        VK_HIP_TRY(hipMemcpy(&h8, (char *)ctx->d_idx.p + 64, 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[vk] ws filter phases, cycles per wave: row producers issue %.0f  wait+convert+store %.0f  barrier %.0f | "
+                        "query producers issue+wait+store %.0f  barrier %.0f | consumers mfma %.0f  gate %.0f  barrier %.0f\n",
+                h[0] / w2, h[2] / w2, h[3] / w2, h[4] / w2, h8 / w2, h[5] / w4, h[6] / w4, h[7] / w4);
+        return Status::Ok();
+      }
       const double waves = (double)filter_blocks_ * 8;
       fprintf(stderr, "[vk] filter phases, cycles per wave: mfma %.0f  load-issue %.0f  rows-wait+convert+store %.0f  gate %.0f  barrier %.0f\n",
               h[0] / waves, h[1] / waves, h[2] / waves, h[3] / waves, h[4] / waves);
