@@ -610,7 +610,7 @@ def pmc_traffic(N, D, B, world, kernel_prefix):
     path = ROOT / "profiles" / "r02_pmc_fetch_size.json"
     if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not path.exists() or "bf16" in sys.argv:
         return None, None
-    if any(os.environ.get(v) for v in ("VK_FLAT_FORCE_SCAN", "VK_GEMM_MODE", "VK_GEMM_ABLATE", "VK_GEMM_LOCKSTEP", "VK_FILTER_ABLATE", "VK_FLAT_FILTER")):
+    if any(os.environ.get(v) for v in ("VK_FLAT_FORCE_SCAN", "VK_GEMM_MODE", "VK_GEMM_ABLATE", "VK_GEMM_LOCKSTEP", "VK_FILTER_TIMING", "VK_FLAT_FILTER")):
         return None, None
     j = json.load(open(path))
     if j.get("src_sha256") != source_sha256():

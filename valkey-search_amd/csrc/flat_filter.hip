@@ -25,13 +25,14 @@
 // max(1, |dist|).  eps_q below adds these with |x| <= R = the largest row norm in the index (tracked by row_stats_kernel)
 // and rounds everything up.
 //
-// Data movement per 128-row tile and block (4 waves, one per SIMD, 128 rows x 256 queries of accumulators):
-//   rows     393 KB f32 from HBM, once, by all 256 threads -> converted -> f16 in LDS (36 KB, two stages) -> A operands
-//            of all four waves (ds_read_b128, conflict-free 144-B row stride)
-//   queries  wave w owns queries [64w, 64w+64): its B operands come straight from L2 in MFMA fragment order
-//            (16 B per lane and K-step, prepared once by flat_qprep_kernel) -- no LDS, no sharing needed
-// so HBM traffic is the row bytes and L2 traffic twice that.  Roofline: HBM (30.72 GB per launch at 10M x 768 f32);
-// the matrix cores are about one third busy (3.9 TFLOP of f16 per launch against 2.5 PFLOP/s).
+// Data movement per 128-row tile and block (eight waves with three different jobs, see the kernel):
+//   rows     393 KB f32 from HBM, once -> converted -> f16 in LDS (two stages of 18 KB, 144-B row stride: conflict-free
+//            ds_read_b128) -> A operands of the four multiplying waves
+//   queries  the batch's f16 copy in MFMA fragment order (flat_qprep_kernel, 384 KB at 256 x 768) comes from L2, one
+//            32 KB stage at a time, through LDS -> B operands
+// so HBM traffic is the row bytes and L2 traffic twice that (PMC: TCC misses 30.8 GB, hits 30.8 GB per launch).
+// Roofline: HBM (30.72 GB per launch at 10M x 768 f32); the matrix cores are about one third busy (3.9 TFLOP of f16
+// per launch against 2.5 PFLOP/s).
 #include <stdlib.h>
 
 #include "device_common.hpp"
@@ -47,7 +48,6 @@ namespace {
 constexpr int kFTileRows = 128;
 constexpr int kFStageK = 64;                 // k per pipeline stage: 4 MFMA K-steps of 16
 constexpr int kFAStride = 72;                // halfs per staged row: 64 + 8 pad = 144 B (conflict-free b128 reads)
-constexpr uint32_t kF16Safe = 0x47000000u;   // 32768.0f: inputs beyond it do not go through f16
 }  // namespace
 
 // ---- row statistics: the largest row norm and the largest |element| over rows [lo, hi) -------------------------------
@@ -170,74 +170,7 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
   a.thr[j] = thr;
 }
 
-// ---- the filter ------------------------------------------------------------------------------------------------------
-// Block = 512 threads = 8 waves, two per SIMD (so that one wave's wait for memory is the other's matrix time): wave w
-// owns query tile w (32 queries) against all 128 rows of the tile = four 32 x 32 accumulator tiles.
-constexpr int kFThreads = 512;
-// this thread's share of one stage: 128 rows x 64 k = 2048 groups of 4 elements / 512 threads (16 B of f32, 8 B of bf16)
-template <bool kBf16> struct RowStage { float4 v[4]; uint32_t hn; };
-template <> struct RowStage<true> { uint2 v[4]; uint32_t hn; };
-
-// (kL2: every stage also carries the packed half norm of row tid % 128 of its tile -- 4 bytes per thread, L2 hits after
-// the tile's first stage -- so that it travels through the same register sets and LDS buffers as the rows, without a
-// load or a branch of its own in the loop)
-template <bool kBf16, bool kL2>
-__device__ __forceinline__ RowStage<kBf16> stage_rows_load(const FlatFilterArgs &a, uint32_t tile_row0, uint32_t st, uint32_t tid) {
-  RowStage<kBf16> s;
-  s.hn = 0;
-  if constexpr (kL2) {
-    const uint32_t r = tile_row0 + (tid & (kFTileRows - 1));
-    s.hn = a.hn16[r < a.n_rows ? r : a.n_rows - 1];
-  }
-  // idx = tid + 512 u: row = idx / 16, 4-element column idx % 16 of the row's 64-element stage slice (coalesced per row)
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const uint32_t idx = tid + (uint32_t)kFThreads * u;
-    const size_t e = ((size_t)tile_row0 + (idx >> 4)) * a.row_stride_f + st * kFStageK + (idx & 15) * 4;
-    if constexpr (kBf16) s.v[u] = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(a.rows) + e);
-    else s.v[u] = *reinterpret_cast<const float4 *>(static_cast<const float *>(a.rows) + e);
-  }
-  return s;
-}
-
-// -> f16 in LDS.  f32 rows: round to nearest even.  bf16 rows: bf16 -> f32 is a shift and f32 -> f16 is then EXACT for
-// every value in f16's normal range (8 significant bits fit 11), so a bf16 index carries no row rounding error at all.
-template <bool kBf16, bool kL2>
-__device__ __forceinline__ void stage_rows_store(_Float16 *buf, uint32_t *hn_buf, uint32_t tid, const RowStage<kBf16> &s) {
-  if constexpr (kL2) {
-    if (tid < (uint32_t)kFTileRows) hn_buf[tid] = s.hn;
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const uint32_t idx = tid + (uint32_t)kFThreads * u;
-    f16x4 h;
-    if constexpr (kBf16) {
-      h[0] = (_Float16)__uint_as_float(s.v[u].x << 16);
-      h[1] = (_Float16)__uint_as_float(s.v[u].x & 0xFFFF0000u);
-      h[2] = (_Float16)__uint_as_float(s.v[u].y << 16);
-      h[3] = (_Float16)__uint_as_float(s.v[u].y & 0xFFFF0000u);
-    } else {
-      h[0] = (_Float16)s.v[u].x;
-      h[1] = (_Float16)s.v[u].y;
-      h[2] = (_Float16)s.v[u].z;
-      h[3] = (_Float16)s.v[u].w;
-    }
-    *reinterpret_cast<f16x4 *>(buf + (idx >> 4) * kFAStride + (idx & 15) * 4) = h;
-  }
-}
-
-struct BFrags { f16x8 b[4]; };   // this wave's query tile x the stage's four K-steps
-
-__device__ __forceinline__ BFrags stage_b_load(const FlatFilterArgs &a, uint32_t wave, uint32_t st, uint32_t lane) {
-  BFrags f;
-  const uint32_t ks_n = a.row_stride_f / 16;
-  const uint32_t jt = wave < a.nqt ? wave : a.nqt - 1;   // (a wave without queries re-reads the last tile)
-  const f16x8 *p = reinterpret_cast<const f16x8 *>(a.q16) + ((size_t)(jt * ks_n + st * 4) * kWave + lane);
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) f.b[kk] = p[(size_t)kk * kWave];
-  return f;
-}
-
+// ---- survivors, gate, stream position --------------------------------------------------------------------------------
 // Survivors are collected per wave in LDS (a ring of 64 (query, row) entries) and written out 64 at a time: the global
 // append is an atomicAdd that RETURNS the slot, a round trip of a microsecond or two -- paid per survivor it sat on the
 // critical path of every row tile (some wave of the block nearly always had one, and the block's barrier waits for it).
@@ -258,7 +191,7 @@ __device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing
 
 // Tile done: the gate.  Output register r of row tile rt is row rt*32 + (r&3) + 8*(r>>2) + 4*g, column li of the wave's
 // query tile.  Almost every 32 x 32 block has no survivor: one max over the lane's 16 values, one ballot.
-template <bool kTiny = false, int kRt = 4, bool kZero = true>
+template <int kRt, bool kZero>
 __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[kRt], float thr, uint32_t tile_row0,
                                             uint32_t wave, uint32_t li, uint32_t g, SurvivorRing &ring, uint32_t lane) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -268,7 +201,6 @@ __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&ac
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
     if (__builtin_amdgcn_ballot_w64(m >= thr) != 0) {   // (rare: a survivor somewhere in this 32 x 32 block)
-      if constexpr (kTiny) { ring.cnt += 1; acc[rt] = zero; continue; }
       const uint32_t q = wave * 32 + li;
       // the lane's passing registers as a bit mask, then one round per remaining bit of the busiest lane (usually one)
       uint32_t mk = 0;
@@ -307,173 +239,6 @@ __device__ __forceinline__ void fpos_advance(FPos &p, uint32_t stages) {
   p.left -= p.left != 0 ? 1u : 0u;
   p.st = wrap ? 0u : p.st + (go ? 1u : 0u);
   p.row0 += wrap ? (uint32_t)kFTileRows : 0u;
-}
-
-// kAblate: timing experiments only (compile-time, so that the product kernel has no branches around its loads)
-template <int kAblate, bool kBf16, bool kL2>
-__global__ __launch_bounds__(512, 1) void flat_filter_kernel(FlatFilterArgs a) {
-  extern __shared__ _Float16 lds_a[];   // [2 stages][128 rows][kFAStride], then the waves' survivor rings
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t li = lane & 31, g = lane >> 5;
-  const uint32_t stages = a.row_stride_f / kFStageK;
-  constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;
-  SurvivorRing ring;
-  ring.q = reinterpret_cast<uint32_t *>(lds_a + 2 * kBufHalfs) + wave * 2 * kWave;
-  ring.row = ring.q + kWave;
-  ring.cnt = 0;
-  uint32_t *hn_lds = reinterpret_cast<uint32_t *>(lds_a + 2 * kBufHalfs) + (kFThreads / kWave) * 2 * kWave;   // [2][128] (kL2)
-
-  // this block's contiguous range of row tiles
-  const uint32_t n_tiles = (a.n_rows + kFTileRows - 1) / kFTileRows;
-  const uint32_t t_base = n_tiles / gridDim.x, t_rem = n_tiles % gridDim.x;
-  const uint32_t first_tile = blockIdx.x * t_base + (blockIdx.x < t_rem ? blockIdx.x : t_rem);
-  const uint32_t my_tiles = t_base + (blockIdx.x < t_rem ? 1u : 0u);
-  if (my_tiles == 0) return;
-  const uint32_t total = my_tiles * stages;
-  const bool has_q = wave < a.nqt;
-  const float thr = has_q ? a.thr[wave * 32 + li] : __builtin_inff();   // gate of this lane's query column
-
-  // Software pipeline, iteration S = stage S of the stream:
-  //   top     the B operands (L2) and the rows (HBM) of stage S+4 into the register sets whose previous content (stage S)
-  //           is consumed in this iteration / went to LDS one iteration ago.  Both run the SAME distance ahead: loads
-  //           return in order (one vmcnt counter), so a B operand fetched one iteration ahead would make the wait for it
-  //           a wait for every row load issued before it -- the rows would have one iteration of cover, not four.
-  //           Three to four stages of rows (96-128 KB per CU) are in flight: at 6 TB/s the loaded HBM latency is
-  //           several microseconds
-  //   middle  the 16 MFMAs of stage S: A fragments from LDS buffer S & 1, fetched one K-step ahead of their use
-  //   bottom  stage S+1 (loaded one iteration ago) converted to f16 into the other LDS buffer, one barrier
-  // Unrolled by four with the register sets named explicitly (rows and B operands of stage s in sets s % 4):
-  // rotating them through a copy would make the copy wait for loads that are still in flight.
-  FPos ld{first_tile * kFTileRows, 0, total};   // next stage whose rows are fetched
-  FPos lb = ld;                                  // next stage whose B operands are fetched
-  RowStage<kBf16> x0 = stage_rows_load<kBf16, kL2>(a, ld.row0, ld.st, tid), x1, x2, x3;
-  stage_rows_store<kBf16, kL2>(lds_a, hn_lds, tid, x0);
-  BFrags b0 = stage_b_load(a, wave, lb.st, lane), b1, b2, b3;
-  fpos_advance(ld, stages);
-  fpos_advance(lb, stages);
-  b1 = stage_b_load(a, wave, lb.st, lane);        // stages 1, 2, 3: B operands, then rows
-  x1 = stage_rows_load<kBf16, kL2>(a, ld.row0, ld.st, tid);
-  fpos_advance(ld, stages);
-  fpos_advance(lb, stages);
-  b2 = stage_b_load(a, wave, lb.st, lane);
-  x2 = stage_rows_load<kBf16, kL2>(a, ld.row0, ld.st, tid);
-  fpos_advance(ld, stages);
-  fpos_advance(lb, stages);
-  b3 = stage_b_load(a, wave, lb.st, lane);
-  x3 = stage_rows_load<kBf16, kL2>(a, ld.row0, ld.st, tid);
-  fpos_advance(ld, stages);
-  fpos_advance(lb, stages);
-  __syncthreads();
-
-  f32x16 acc[4];
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) acc[rt] = zero;
-
-  uint32_t tile_row0 = first_tile * kFTileRows;
-  uint32_t st_c = 0, left_c = total, tile_c = 0;
-  uint32_t cancel_now = 0;
-  bool stop = false;
-  const uint32_t hot_row0 = first_tile * kFTileRows;
-  // (kAblate & 128: cycles per phase -- 0 fragment reads + MFMAs, 1 issue of the loads, 2 wait for the rows + convert +
-  // LDS stores, 3 gate, 4 barrier -- summed over the waves into a.dbg)
-  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-
-#define VK_FMMA(AV, KK)                                                                                             \
-  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
-    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AV[rt], bcur_.b[KK], acc[rt], 0, 0, 0);
-#define VK_FAREAD(AV, KK)                                                                                           \
-  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
-    AV[rt] = *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + (KK) * 16);
-
-#define VK_TICK(I)                                                                                                  \
-  if constexpr (kAblate & 128) {                                                                                    \
-    const unsigned long long now_ = __builtin_readcyclecounter();                                                   \
-    ph[I] += now_ - tlast;                                                                                          \
-    tlast = now_;                                                                                                   \
-  }
-#define VK_FSTAGE(PAR, RLOAD, RSTORE, BCUR, BNEXT)                                                                  \
-  {                                                                                                                 \
-    VK_TICK(4)                                                                                                      \
-    const bool live = left_c != 0;                                                                                  \
-    if (live && st_c == 0 && a.cancel && (tile_c % kCancelPollTiles) == 0)                                          \
-      cancel_now = __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                        \
-    const _Float16 *ab = lds_a + (PAR) * kBufHalfs + li * kFAStride + g * 8;                                        \
-    f16x8 fa[4], fb[4];                                                                                             \
-    VK_FAREAD(fa, 0)                                                                                                \
-    const BFrags bcur_ = BCUR;                                                                                      \
-    if (has_q && live && !(kAblate & 4)) {                                                                          \
-      VK_FAREAD(fb, 1)                                                                                              \
-      VK_FMMA(fa, 0)                                                                                                \
-      VK_FAREAD(fa, 2)                                                                                              \
-      VK_FMMA(fb, 1)                                                                                                \
-      VK_FAREAD(fb, 3)                                                                                              \
-      VK_FMMA(fa, 2)                                                                                                \
-      VK_FMMA(fb, 3)                                                                                                \
-      /* operands of a K-step are requested a whole K-step (four MFMAs) before their use */                       \
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                            \
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                            \
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                            \
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                            \
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                            \
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                            \
-      if constexpr (kL2) {                                                                                          \
-        if (st_c + 1 == stages) {   /* one more K-step: (hn_hi, hn_lo, 0 ...) x (-1, -1, 0 ...) = - |x|^2 / 2 */    \
-          const uint4 nb = make_uint4(g == 0 ? 0xBC00BC00u : 0u, 0u, 0u, 0u);                                       \
-          _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                                        \
-            const uint4 na = make_uint4(g == 0 ? hn_lds[(PAR) * kFTileRows + rt * 32 + li] : 0u, 0u, 0u, 0u);       \
-            acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, na), __builtin_bit_cast(f16x8, nb), \
-                                                             acc[rt], 0, 0, 0);                                     \
-          }                                                                                                         \
-        }                                                                                                           \
-      }                                                                                                             \
-    }                                                                                                               \
-    if constexpr (kAblate & 128) asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");            \
-    VK_TICK(0)                                                                                                      \
-    /* (the loads go out behind the MFMAs: placed between them -- one per MFMA -- the f32 kernel lost 40 %: the  */ \
-    /* compiler then also hoists the LDS stores, and with them the wait for HBM data, into the MFMA sequence)   */ \
-    if constexpr (!(kAblate & 16)) BNEXT = stage_b_load(a, wave, lb.st, lane);                                      \
-    fpos_advance(lb, stages);                                                                                       \
-    if constexpr (!(kAblate & 32)) RLOAD = stage_rows_load<kBf16, kL2>(a, (kAblate & 1) ? hot_row0 : ld.row0, ld.st, tid); \
-    fpos_advance(ld, stages);                                                                                       \
-    VK_TICK(1)                                                                                                      \
-    if constexpr (!(kAblate & 8)) stage_rows_store<kBf16, kL2>(lds_a + ((PAR) ^ 1) * kBufHalfs, hn_lds + ((PAR) ^ 1) * kFTileRows, tid, RSTORE); \
-    if constexpr (kAblate & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
-    VK_TICK(2)                                                                                                      \
-    left_c -= live ? 1u : 0u;                                                                                       \
-    st_c += 1;                                                                                                      \
-    if (live && st_c == stages) {                                                                                   \
-      if (has_q && !(kAblate & 2)) filter_gate<(kAblate & 64) != 0>(a, acc, thr, tile_row0, wave, li, g, ring, lane);                                \
-      st_c = 0;                                                                                                     \
-      tile_c += 1;                                                                                                  \
-      tile_row0 += kFTileRows;                                                                                      \
-      VK_TICK(3)                                                                                                    \
-      stop = __syncthreads_or((int)cancel_now) != 0;   /* block-uniform: every wave leaves at the same tile */      \
-    } else {                                                                                                        \
-      __syncthreads();                                                                                              \
-    }                                                                                                               \
-  }
-
-  while (left_c != 0 && !stop) {
-    VK_FSTAGE(0, x0, x1, b0, b0)
-    if (stop) break;
-    VK_FSTAGE(1, x1, x2, b1, b1)
-    if (stop) break;
-    VK_FSTAGE(0, x2, x3, b2, b2)
-    if (stop) break;
-    VK_FSTAGE(1, x3, x0, b3, b3)
-  }
-#undef VK_FSTAGE
-#undef VK_TICK
-#undef VK_FMMA
-#undef VK_FAREAD
-  if constexpr (kAblate & 128) {
-    if (lane == 0 && a.dbg)
-      for (int i = 0; i < 5; ++i) atomicAdd(&a.dbg[i], ph[i]);
-  }
-  if constexpr (kAblate & 64) { if (ring.cnt == 0xFFFFFFFFu) a.ovf[0] = 1; return; }
-  ring_flush(a, ring, lane);
 }
 
 // ---- the filter, wave-specialised ---------------------------------------------------------------------------------------
@@ -556,6 +321,7 @@ __device__ __forceinline__ void ws_rows_store(_Float16 *buf, uint32_t *hn_buf, u
 // query producer wave p: the B operands of query tiles 4p .. 4p+3 of stage st, 16 x (64 lanes x 16 B), from the
 // fragment-major query copy; in LDS a stage is [query tile 8][K-step 4][lane 64] x 16 B
 constexpr int kWsBStage = 8 * 4 * kWave;   // in 16-byte slots
+constexpr int kWsThreads = 512;
 __device__ __forceinline__ void ws_b_load(WsB &b, const FlatFilterArgs &a, uint32_t p, uint32_t st, uint32_t lane) {
   const uint32_t ks_n = a.row_stride_f / 16;
 #pragma unroll
@@ -573,7 +339,7 @@ __device__ __forceinline__ void ws_b_store(uint4 *slot, uint32_t p, uint32_t lan
 }
 
 template <bool kBf16, bool kL2, bool kTiming>
-__global__ __launch_bounds__(512, 1) void flat_filter_ws_kernel(FlatFilterArgs a) {
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_kernel(FlatFilterArgs a) {
   extern __shared__ _Float16 lds_a[];
   constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;                    // one A stage
   uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + 2 * kBufHalfs);          // [2][kWsBStage]
@@ -810,8 +576,8 @@ __global__ __launch_bounds__(512, 1) void flat_filter_ws_kernel(FlatFilterArgs a
     par ^= 1;
     if (st_c == stages) {
       if (has_q) {
-        filter_gate<false, 4, false>(a, acc[0], thr[0], tile_row0, wave * 2, li, g, ring, lane);
-        filter_gate<false, 4, false>(a, acc[1], thr[1], tile_row0, wave * 2 + 1, li, g, ring, lane);
+        filter_gate<4, false>(a, acc[0], thr[0], tile_row0, wave * 2, li, g, ring, lane);
+        filter_gate<4, false>(a, acc[1], thr[1], tile_row0, wave * 2 + 1, li, g, ring, lane);
       }
       tile_row0 += kFTileRows;
       VK_WS_TICK(1)
@@ -833,13 +599,9 @@ __global__ __launch_bounds__(512, 1) void flat_filter_ws_kernel(FlatFilterArgs a
   ring_flush(a, ring, lane);
 }
 
-size_t flat_filter_ws_lds_bytes() {
+size_t flat_filter_lds_bytes() {
   return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 +
          (size_t)2 * kFTileRows * 4 + 16;
-}
-
-size_t flat_filter_lds_bytes() {
-  return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)(kFThreads / kWave) * 2 * kWave * 4 + (size_t)2 * kFTileRows * 4;
 }
 
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2) {
@@ -855,36 +617,20 @@ hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
 
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.nqt == 0 || a.nqt > 8 || blocks == 0) return hipErrorInvalidValue;
-  const dim3 grid(blocks), block(kFThreads);
-  if (a.ablate & 256) {   // the wave-specialised kernel
-    const size_t wl = flat_filter_ws_lds_bytes();
-    const void *fn = a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_ws_kernel<true, true, false>)
-                                    : reinterpret_cast<const void *>(&flat_filter_ws_kernel<true, false, false>))
-                            : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_ws_kernel<false, true, false>)
-                                    : reinterpret_cast<const void *>(&flat_filter_ws_kernel<false, false, false>));
-    if ((a.ablate & 128) && !a.bf16 && !a.l2) fn = reinterpret_cast<const void *>(&flat_filter_ws_kernel<false, false, true>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
-    if (e != hipSuccess) return e;
-    FlatFilterArgs args = a;
-    void *params[] = {&args};
-    return hipLaunchKernel(fn, grid, block, params, wl, s);
-  }
   const size_t lds = flat_filter_lds_bytes();
-  if (a.bf16 || a.l2) {
-    if (a.ablate) return hipErrorInvalidValue;
-    if (a.bf16 && a.l2) hipLaunchKernelGGL((flat_filter_kernel<0, true, true>), grid, block, lds, s, a);
-    else if (a.bf16) hipLaunchKernelGGL((flat_filter_kernel<0, true, false>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((flat_filter_kernel<0, false, true>), grid, block, lds, s, a);
-    return hipGetLastError();
+  const void *fn = a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, true, false>)
+                                  : reinterpret_cast<const void *>(&flat_filter_kernel<true, false, false>))
+                          : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_kernel<false, true, false>)
+                                  : reinterpret_cast<const void *>(&flat_filter_kernel<false, false, false>));
+  if (a.timing) {
+    if (a.bf16 || a.l2) return hipErrorInvalidValue;
+    fn = reinterpret_cast<const void *>(&flat_filter_kernel<false, false, true>);
   }
-  switch (a.ablate) {
-    case 0: hipLaunchKernelGGL((flat_filter_kernel<0, false, false>), grid, block, lds, s, a); break;
-    case 128: hipLaunchKernelGGL((flat_filter_kernel<128, false, false>), grid, block, lds, s, a); break;
-    case 64: hipLaunchKernelGGL((flat_filter_kernel<64, false, false>), grid, block, lds, s, a); break;
-    case 32: hipLaunchKernelGGL((flat_filter_kernel<32, false, false>), grid, block, lds, s, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (above the 64 KB default)
+  if (e != hipSuccess) return e;
+  FlatFilterArgs args = a;
+  void *params[] = {&args};
+  return hipLaunchKernel(fn, dim3(blocks), dim3(kWsThreads), params, lds, s);
 }
 
 }  // namespace vk

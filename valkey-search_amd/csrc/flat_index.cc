@@ -566,7 +566,6 @@ class FlatIndex final : public Index {
     if (out_ld == 0) out_ld = k;                      // entries per query in the output arrays (>= k; the tail is padding)
     int e = flat_scan_slots_per_lane(k);
     if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 needs the host entry points (vk_index_search / _batch), which page through the result in passes");
-    const uint32_t chunks = store_.stride_f() / 16;
     // K4h + exact re-rank: a batch large enough that the exact matrix-core kernel is the bottleneck, an index large
     // enough that the pre-pass sample is a small part of it
     if (!lb_dist_ && nq >= filter_min_queries_ && !(cancel && *cancel) && !force_scan_ && filter_enabled_ &&
@@ -882,9 +881,9 @@ class FlatIndex final : public Index {
     f.nq = (uint32_t)nq;
     f.nqt = nqt;
     f.cancel = d_cancel;
-    static const uint32_t ablate = getenv("VK_FILTER_ABLATE") ? (uint32_t)atoi(getenv("VK_FILTER_ABLATE")) : 0;
-    f.ablate = ablate;
-    if (ablate & 128) {   // phase timing experiment: the d_fthr buffer's tail holds the five counters
+    static const bool timing = getenv("VK_FILTER_TIMING") && atoi(getenv("VK_FILTER_TIMING")) != 0;
+    f.timing = timing && !store_.bf16() && !l2();
+    if (f.timing) {   // phase timing experiment: nine counters
       VK_TRY(ctx->d_idx.ensure(128));
       VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
       f.dbg = ctx->d_idx.as<unsigned long long>();
@@ -962,22 +961,14 @@ class FlatIndex final : public Index {
     if (l2()) VK_TRY(scan_k3(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld, ovf, 1));
     else VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, bound, ovf, 1));
     filter_used_ = true;
-    if (ablate & 128) {
-      unsigned long long h[8];
+    if (f.timing) {
+      unsigned long long h[9];
       VK_HIP_TRY(hipStreamSynchronize(s));
-      VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, 64, hipMemcpyDeviceToHost));
-      if (ablate & 256) {
-        const double w2 = (double)filter_blocks_ * 2, w4 = (double)filter_blocks_ * 4;
-        unsigned long long h8 = 0;
-        VK_HIP_TRY(hipMemcpy(&h8, (char *)ctx->d_idx.p + 64, 8, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[vk] ws filter phases, cycles per wave: row producers issue %.0f  wait+convert+store %.0f  barrier %.0f | "
-                        "query producers issue+wait+store %.0f  barrier %.0f | consumers mfma %.0f  gate %.0f  barrier %.0f\n",
-                h[0] / w2, h[2] / w2, h[3] / w2, h[4] / w2, h8 / w2, h[5] / w4, h[6] / w4, h[7] / w4);
-        return Status::Ok();
-      }
-      const double waves = (double)filter_blocks_ * 8;
-      fprintf(stderr, "[vk] filter phases, cycles per wave: mfma %.0f  load-issue %.0f  rows-wait+convert+store %.0f  gate %.0f  barrier %.0f\n",
-              h[0] / waves, h[1] / waves, h[2] / waves, h[3] / waves, h[4] / waves);
+      VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, sizeof h, hipMemcpyDeviceToHost));
+      const double w2 = (double)filter_blocks_ * 2, w4 = (double)filter_blocks_ * 4;
+      fprintf(stderr, "[vk] filter phases, cycles per wave: row producers issue %.0f  wait+convert+store %.0f  barrier %.0f | "
+                      "query producers issue+wait+store %.0f  barrier %.0f | consumers mfma %.0f  gate %.0f  barrier %.0f\n",
+              h[0] / w2, h[2] / w2, h[3] / w2, h[4] / w2, h[8] / w2, h[5] / w4, h[6] / w4, h[7] / w4);
     }
     return Status::Ok();
   }

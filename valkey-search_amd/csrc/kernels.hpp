@@ -89,10 +89,8 @@ struct FlatFilterArgs {
   uint32_t row_stride_f, n_rows, nq;
   uint32_t nqt;               // query tiles of 32 (<= 8 per launch)
   const uint32_t *cancel;
-  // timing experiments only (VK_FILTER_ABLATE, bits; results invalid): 1 rows re-read from the block's first tile (L2
-  // hits), 2 no gate, 4 no MFMAs / fragment reads, 8 no conversion + LDS stores, 16 no B loads, 32 no row loads
-  uint32_t ablate;
-  unsigned long long *dbg;    // ablate & 128: [5] cycles per phase, summed over the waves
+  uint32_t timing;            // VK_FILTER_TIMING=1: the kernel variant with cycle counters per phase (f32 rows, IP only)
+  unsigned long long *dbg;    // timing: [9] cycles per phase, summed over the waves (see the kernel)
 };
 size_t flat_filter_lds_bytes();
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2);
