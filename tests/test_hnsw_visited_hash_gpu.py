@@ -1,0 +1,118 @@
+"""The visited set of a batched HNSW search as an exact hash set of node ids.
+
+hnswlib marks visited nodes in a tag array sized by the graph (visited_list_pool.h; hnswalg.h:453-464).  The device
+keeps one visited set per resident wave; on a large graph a bitmap of all nodes per wave (1.25 MB at 10M) limits how many
+waves can run and is mostly cleared, never touched.  A batch that fills the device therefore uses an open-addressing
+table of the ids a search actually touches; a query that would fill its table beyond 3/4 is abandoned and re-run by a
+second launch with the bitmap.  Whatever the path: ids, distance bits and the layer-0 work counters are the oracle's on
+the SAME graph."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vsa():
+    import _pkg
+    return _pkg.vsa
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _check(g, o, Q, k, ef):
+    D, L, N = g.search_batch(Q, k, ef=ef)
+    ne = nh = 0
+    for i in range(len(Q)):
+        od, ol, e, h = o.search(Q[i], k, ef=ef, stats=True)
+        assert L[i, :N[i]].tolist() == ol.tolist(), i
+        assert D[i, :N[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist(), i
+        ne += e
+        nh += h
+    st = g.stats()
+    assert (st.last_n_eval, st.last_n_hops) == (ne, nh)
+    assert st.last_frontier_dropped == 0
+    return st
+
+
+@pytest.mark.parametrize("metric", ["L2", "COSINE"])
+@pytest.mark.parametrize("ef,k", [(32, 10), (128, 10), (300, 40), (700, 20)])   # register lists (1, 2, 8 slots) and the LDS list
+@pytest.mark.parametrize("log2", [None, 7, 9])   # table sized by ef / 128 words (nearly every query re-run) / 512 words (some)
+def test_hash_visited_set_matches_the_oracle(vsa, oracle, metric, ef, k, log2):
+    rng = np.random.default_rng(97 + ef)
+    n, dim, M = 5000, 48, 8
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    env = {"VK_HNSW_VISITED_HASH": 2}
+    if log2:
+        env["VK_HNSW_HASH_LOG2"] = log2
+    with _Env(**env):
+        g = vsa.Index("HNSW", dim, metric, initial_cap=n, m=M, ef_construction=40, build_threads=4)
+    g.add_batch(x)
+    g.flush()
+    o = oracle.HNSW.from_product_index(g.save_raw, dim, metric, M, ef_construction=40)
+    Q = rng.standard_normal((70, dim)).astype(np.float32)
+    st = _check(g, o, Q, k, ef)
+    if log2 == 7:
+        assert st.last_frontier_redo > 0       # 96 entries hold no search with ef >= 32 on this graph
+    if log2 is None:
+        assert st.last_frontier_redo == 0      # sized by ef: nobody outgrows it here
+
+
+def test_hash_visited_set_bf16_rows(vsa, oracle):
+    """bf16 rows take the same code (the reference only has FLOAT32: parity against the oracle over the rounded rows,
+    graph built point by point on both sides)."""
+    rng = np.random.default_rng(11)
+    n, dim = 2500, 64
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    with _Env(VK_HNSW_VISITED_HASH=2, VK_HNSW_HASH_LOG2=9):
+        g = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=16, ef_construction=100, dtype="bf16")
+    for i in range(n):
+        assert g.add(i, x[i]) == 0
+    u = x.view(np.uint32)
+    xr = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+    o = oracle.HNSW(dim, "L2", max_elements=n, M=16, ef_construction=100)
+    o.add_many(xr)
+    Q = rng.standard_normal((40, dim)).astype(np.float32)
+    st = _check(g, o, Q, 10, 64)
+    assert st.last_frontier_redo > 0
+
+
+def test_default_choice_small_graph_keeps_the_bitmap_and_filters_never_hash(vsa, oracle):
+    rng = np.random.default_rng(3)
+    n, dim, M = 4000, 32, 8
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=M, ef_construction=40, build_threads=4)
+    g.add_batch(x)
+    g.flush()
+    o = oracle.HNSW.from_product_index(g.save_raw, dim, "L2", M, ef_construction=40)
+    Q = rng.standard_normal((600, dim)).astype(np.float32)     # a batch past the latency variant's limit
+    st = _check(g, o, Q[:600:10], 10, 64)
+    assert st.last_frontier_redo == 0
+    # forced on, but with a filter: the HBM-frontier kernels keep their bitmaps, answers as before
+    with _Env(VK_HNSW_VISITED_HASH=2, VK_HNSW_HASH_LOG2=7):
+        g2 = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=M, ef_construction=40, build_threads=4)
+    g2.add_batch(x)
+    g2.flush()
+    o2 = oracle.HNSW.from_product_index(g2.save_raw, dim, "L2", M, ef_construction=40)
+    bits = oracle.allow_bitmap(np.flatnonzero(rng.random(n) < 0.3), n)
+    D, L, N = g2.search_batch(Q[:30], 10, ef=64, allow=bits, allow_nbits=n)
+    for i in range(30):
+        od, ol = o2.search(Q[i], 10, ef=64, allow=bits, allow_nbits=n)
+        assert L[i, :N[i]].tolist() == ol.tolist()
+        assert D[i, :N[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist()

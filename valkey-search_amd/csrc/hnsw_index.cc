@@ -529,7 +529,7 @@ class HnswIndex final : public Index {
     a.gpool_level = gpool ? 1 : 0;
     if (gpool)   // (a multiple of 128: the kernel keeps one minimum per 64 entries in the LDS words of the pool)
       a.cand_cap = (uint32_t)std::min<uint64_t>(gpool_cap_, (std::max<uint64_t>(a.cand_cap, count) + 127) & ~(uint64_t)127);
-    const bool redo = gpool && a.cand_cap < count;
+    bool redo = gpool && a.cand_cap < count;
     a.pool_g = gpool ? reinterpret_cast<float *>(8) : nullptr;   // (placeholder until the buffer is sized below)
     a.nbr_cap = (uint32_t)((graph_->maxM0() + 63) & ~(size_t)63);
     a.check_deleted = pub_.deleted ? 1 : 0;
@@ -539,11 +539,34 @@ class HnswIndex final : public Index {
       return Status::Err(VK_ERR_INVALID, "query block + result list (dimension, ef, M) do not fit the 160 KiB of LDS");
     int max_blocks = 0;
     VK_HIP_TRY(hnsw_max_blocks(a, l2(), store_.bf16(), e, &max_blocks));
-    // visited bitmaps: one per resident wave, bounded to 2 GiB per context
+    // visited sets: one per resident wave, bounded to 2 GiB per context.  A bitmap of the graph -- or, for a batch that
+    // fills the device on a graph large enough for it to matter, an exact hash set of the ids the search touches
+    // (typically 25 x ef of them): 64 KB instead of 1.25 MB per wave at 10M nodes, ef = 128, so every wave the CUs can
+    // hold gets one (the bitmaps' 2 GiB allowed 1 636 of 4 096), clearing it costs nothing and its atomics hit in cache.
+    // A query that outgrows its table is abandoned there and answered by a second launch with bitmaps.
     const uint64_t wpb = (uint64_t)hnsw_waves_per_block(a);
     uint64_t blocks = std::min<uint64_t>((nq + wpb - 1) / wpb, (uint64_t)max_blocks);
     const uint64_t bm_bytes = (uint64_t)a.bitmap_words * 4;
-    blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)2 << 30) / (bm_bytes * wpb)));
+    uint32_t hash_log2 = 0;
+    if (!gpool && visited_hash_ != 0 && (visited_hash_ == 2 || !hnsw_uses_latency_variant(a))) {
+      uint32_t lg = 14;      // (a search evaluates about 25 x ef nodes on the graphs measured: 64 x ef words, at least 64 KB)
+      while (lg < 17 && ((uint64_t)1 << lg) < hash_per_ef_ * ef) ++lg;
+      if (hash_log2_forced_) lg = hash_log2_forced_;
+      if (visited_hash_ == 2 || ((uint64_t)8 << lg) <= bm_bytes) hash_log2 = lg;   // (at most half the bitmap's size)
+    }
+    HnswSearchArgs h{};
+    uint64_t blocks_h = 0;
+    if (hash_log2) {
+      h = a;
+      h.vis_hash_log2 = hash_log2;
+      h.bitmap_words = 1u << hash_log2;
+      int mbh = 0;
+      VK_HIP_TRY(hnsw_max_blocks(h, l2(), store_.bf16(), e, &mbh));
+      blocks_h = std::min<uint64_t>((nq + wpb - 1) / wpb, (uint64_t)mbh);
+      blocks_h = std::max<uint64_t>(1, std::min<uint64_t>(blocks_h, visited_bytes_ / ((uint64_t)h.bitmap_words * 4 * wpb)));
+      VK_TRY(ctx->d_redo.ensure((nq + 1) * 4));
+    }
+    blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, visited_bytes_ / (bm_bytes * wpb)));
     if (gpool) {   // ... and the HBM frontiers to 1 GiB
       blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)1 << 30) / ((uint64_t)a.cand_cap * 8 * wpb)));
       VK_TRY(ctx->d_pool.ensure(blocks * wpb * (uint64_t)a.cand_cap * 8));
@@ -564,12 +587,12 @@ class HnswIndex final : public Index {
       const uint64_t per_wave = (uint64_t)b.cand_cap * 8 + (uint64_t)b.cand_cap / 64 * 4;
       blocks2 = std::min<uint64_t>((nq + wpb2 - 1) / wpb2, (uint64_t)mb2);
       blocks2 = std::max<uint64_t>(1, std::min<uint64_t>(blocks2, redo_bytes_ / (per_wave * wpb2)));
-      blocks2 = std::max<uint64_t>(1, std::min<uint64_t>(blocks2, ((uint64_t)2 << 30) / (bm_bytes * wpb2)));
+      blocks2 = std::max<uint64_t>(1, std::min<uint64_t>(blocks2, visited_bytes_ / (bm_bytes * wpb2)));
       VK_TRY(ctx->d_pool2.ensure(blocks2 * wpb2 * per_wave));
       VK_TRY(ctx->d_redo.ensure((nq + 1) * 4));
       b.pool_g = ctx->d_pool2.as<float>();
     }
-    VK_TRY(ctx->d_tmp.ensure(std::max(blocks * wpb, blocks2 * wpb2) * bm_bytes));
+    VK_TRY(ctx->d_tmp.ensure(std::max(std::max(blocks * wpb, blocks2 * wpb2) * bm_bytes, blocks_h * wpb * (uint64_t)h.bitmap_words * 4)));
     a.visited = ctx->d_tmp.as<uint32_t>();
     VK_TRY(ctx->d_stats.ensure(64));
     if (reset_stats) VK_HIP_TRY(hipMemsetAsync(ctx->d_stats.p, 0, 40, s));
@@ -579,6 +602,20 @@ class HnswIndex final : public Index {
     if (redo) {
       a.redo_out = ctx->d_redo.as<uint32_t>();
       VK_HIP_TRY(hipMemsetAsync(a.redo_out, 0, 4, s));
+    }
+    if (hash_log2) {
+      // first the launch with the hash sets; then the same kernel as always, with bitmaps, over the queries it gave up
+      // (a few microseconds when there are none)
+      h.visited = a.visited;
+      h.stats = a.stats;
+      h.queue = a.queue;
+      h.redo_out = ctx->d_redo.as<uint32_t>();
+      VK_HIP_TRY(hipMemsetAsync(h.redo_out, 0, 4, s));
+      VK_HIP_TRY(launch_hnsw_search(h, l2(), store_.bf16(), e, (uint32_t)blocks_h, s));
+      a.queue = a.queue + 1;
+      a.redo_in = ctx->d_redo.as<uint32_t>();
+      VK_HIP_TRY(launch_hnsw_search(a, l2(), store_.bf16(), e, (uint32_t)blocks, s));
+      return Status::Ok();
     }
     VK_HIP_TRY(launch_hnsw_search(a, l2(), store_.bf16(), e, (uint32_t)blocks, s));
     if (redo) {   // a few microseconds when the list is empty
@@ -859,6 +896,11 @@ class HnswIndex final : public Index {
   // cap of the first launch's HBM frontier (entries per wave, a multiple of 128) and the memory the second launch's
   // graph-sized frontiers may take per context; VK_HNSW_GPOOL_CAP=128 forces the second launch on small test graphs
   uint64_t gpool_cap_ = std::max<uint64_t>(128, (getenv("VK_HNSW_GPOOL_CAP") ? (uint64_t)atoll(getenv("VK_HNSW_GPOOL_CAP")) : 65536) & ~(uint64_t)127);
+  // visited sets as hash tables: 0 never, 1 when it pays (default), 2 always (tests); table words per unit of ef; fixed size
+  uint32_t visited_hash_ = getenv("VK_HNSW_VISITED_HASH") ? (uint32_t)atoi(getenv("VK_HNSW_VISITED_HASH")) : 1;
+  uint64_t hash_per_ef_ = getenv("VK_HNSW_HASH_PER_EF") ? (uint64_t)atoll(getenv("VK_HNSW_HASH_PER_EF")) : 64;
+  uint32_t hash_log2_forced_ = getenv("VK_HNSW_HASH_LOG2") ? (uint32_t)atoi(getenv("VK_HNSW_HASH_LOG2")) : 0;
+  uint64_t visited_bytes_ = getenv("VK_HNSW_VISITED_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_VISITED_BYTES")) : ((uint64_t)2 << 30);
   uint64_t redo_bytes_ = getenv("VK_HNSW_REDO_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_REDO_BYTES")) : ((uint64_t)2 << 30);
   bool device_build_ = !(getenv("VK_HNSW_DEVICE_BUILD") && atoi(getenv("VK_HNSW_DEVICE_BUILD")) == 0);
   RowStore store_;

@@ -190,7 +190,7 @@ __device__ __forceinline__ void pool_prune(Pool<kG> &c, float bound, int lane) {
 // entries, one exact minimum per segment of 64 entries in LDS; a query whose frontier does not fit is ABANDONED and
 // queued in a.redo_out.  2 = HBM, sized by the graph (a node enters the frontier at most once, so it cannot overflow),
 // segment minima in HBM too and one minimum per 64 segments in LDS: the kernel that re-runs the abandoned queries.
-template <bool kL2, int kE, bool kBf16, int kBatch, bool kSplitRows, int kGPool = 0>
+template <bool kL2, int kE, bool kBf16, int kBatch, bool kSplitRows, int kGPool = 0, bool kHash = false>
 __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63;
@@ -228,6 +228,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   while (qi < n_work) {
     const uint32_t q = a.redo_in ? a.redo_in[1 + qi] : qi;
     unsigned long long q_eval = 0, q_hops = 0;
+    uint32_t q_vis = 0;            // kHash: entries in the visited table
     bool abandoned = false;
     // this query's filter: its own bitmap when the batch carries one per query (InlineVectorFilter is built per
     // FT.SEARCH, search.cc:103-134), else the batch's
@@ -246,7 +247,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       const float4 *src = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f);
       for (uint32_t i = lane; i < chunks * 4; i += kWave) qs[i] = src[i];
       uint4 *bm4 = reinterpret_cast<uint4 *>(bitmap);
-      const uint4 z = make_uint4(0, 0, 0, 0);
+      const uint4 z = kHash ? make_uint4(kNoneId, kNoneId, kNoneId, kNoneId) : make_uint4(0, 0, 0, 0);
       for (uint32_t i = lane; i < a.bitmap_words / 4; i += kWave) bm4[i] = z;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -257,8 +258,22 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       return quad_row_distance<kL2, kBf16, kBatch>(row_base<kBf16>(a.rows, id, a.row_stride_f), qs, chunks, j);
     };
     auto visit = [&](uint32_t id) -> bool {  // true if it was NOT visited before
-      const uint32_t bit = 1u << (id & 31);
-      return (atomicOr(&bitmap[id >> 5], bit) & bit) == 0;
+      if constexpr (kHash) {
+        // exact set of ids, linear probing from a multiplicative hash; never more than 3/4 full (checked per hop), so
+        // the probe ends.  The lanes of the wave insert the (distinct) ids of one list at the same time: two that meet in
+        // a slot are told apart by the compare-and-swap
+        const uint32_t mask = (1u << a.vis_hash_log2) - 1u;
+        uint32_t h = (id * 2654435761u) >> (32u - a.vis_hash_log2);
+        for (;;) {
+          const uint32_t old = atomicCAS(&bitmap[h], kNoneId, id);
+          if (old == kNoneId) return true;
+          if (old == id) return false;
+          h = (h + 1) & mask;
+        }
+      } else {
+        const uint32_t bit = 1u << (id & 31);
+        return (atomicOr(&bitmap[id >> 5], bit) & bit) == 0;
+      }
     };
 
     // ---- K6: greedy descent over the upper layers (:1667-1697) -------------------------------
@@ -355,6 +370,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       tail_min = d0;
       c.cnt = 1;
       if (lane == 0) (void)visit(cur);
+      q_vis = 1;
     }
 
     for (;;) {
@@ -454,6 +470,9 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       // phase 1: unvisited neighbours, list order preserved
       const uint32_t *ll = a.links0 + (size_t)cur_id * a.l0_stride;
       const uint32_t size = ll[0] & 0xFFFFu;
+      if constexpr (kHash) {   // the table must not fill up: this query goes to the launch with the bitmap
+        if (q_vis + size > (3u << a.vis_hash_log2) / 4u) { abandoned = true; break; }
+      }
       uint32_t nn = 0;
       for (uint32_t base = 0; base < size; base += kWave) {
         const uint32_t i = base + lane;
@@ -489,6 +508,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         }
       }
       q_eval += nn;
+      q_vis += nn;
       // phase 3b: consider in list order, bound updated after each neighbour
       for (uint32_t base = 0; base < nn && !abandoned; base += kWave) {
         const uint32_t u = base + lane;
@@ -628,6 +648,11 @@ template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
   hnsw_search_body<kL2, kE, kBf16, 8, false>(a);
 }
+// ... with the visited set as a hash table of ids (HnswSearchArgs::vis_hash_log2)
+template <bool kL2, int kE, bool kBf16>
+__global__ __launch_bounds__(256, 4) void hnsw_search_hash_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, 8, false, 0, true>(a);
+}
 // searches with a filter or tombstones: the frontier lives in HBM (HnswSearchArgs::pool_g)
 template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 4) void hnsw_search_gpool_kernel(HnswSearchArgs a) {
@@ -691,7 +716,8 @@ int hnsw_waves_per_block(const HnswSearchArgs &a) {
 size_t hnsw_lds_bytes(const HnswSearchArgs &a) { return hnsw_lds_per_wave(a) * (size_t)hnsw_waves_per_block(a); }
 
 template <bool kL2, int kE, bool kBf16>
-static const void *hnsw_fn(bool latency, int gpool) {
+static const void *hnsw_fn(bool latency, int gpool, bool hash) {
+  if (hash) return reinterpret_cast<const void *>(&hnsw_search_hash_kernel<kL2, kE, kBf16>);
   if (gpool == 2) return reinterpret_cast<const void *>(&hnsw_search_gpool2_kernel<kL2, kE, kBf16>);
   if (gpool) return reinterpret_cast<const void *>(&hnsw_search_gpool_kernel<kL2, kE, kBf16>);
   if constexpr (kE >= 1 && kE <= 4) {
@@ -701,9 +727,9 @@ static const void *hnsw_fn(bool latency, int gpool) {
 }
 
 template <int kE>
-static const void *hnsw_pick_e(bool l2, bool bf16, bool latency, int gpool) {
-  return l2 ? (bf16 ? hnsw_fn<true, kE, true>(latency, gpool) : hnsw_fn<true, kE, false>(latency, gpool))
-            : (bf16 ? hnsw_fn<false, kE, true>(latency, gpool) : hnsw_fn<false, kE, false>(latency, gpool));
+static const void *hnsw_pick_e(bool l2, bool bf16, bool latency, int gpool, bool hash) {
+  return l2 ? (bf16 ? hnsw_fn<true, kE, true>(latency, gpool, hash) : hnsw_fn<true, kE, false>(latency, gpool, hash))
+            : (bf16 ? hnsw_fn<false, kE, true>(latency, gpool, hash) : hnsw_fn<false, kE, false>(latency, gpool, hash));
 }
 
 // a batch this small leaves most SIMDs without a wave: latency, not occupancy, is what counts
@@ -712,19 +738,24 @@ static bool hnsw_latency_variant(const HnswSearchArgs &a) {
   return a.nq <= max_nq;
 }
 
-static const void *hnsw_pick(bool l2, bool bf16, int e, bool latency, int gpool) {
+static const void *hnsw_pick(const HnswSearchArgs &a, bool l2, bool bf16, int e) {
+  const bool hash = a.vis_hash_log2 != 0;
+  if (hash && (a.gpool_level != 0 || a.redo_in != nullptr)) return nullptr;   // (LDS-frontier first launches only)
+  const bool latency = !hash && hnsw_latency_variant(a);
+  const int gpool = (int)a.gpool_level;
   switch (e) {
-    case 1: return hnsw_pick_e<1>(l2, bf16, latency, gpool);
-    case 2: return hnsw_pick_e<2>(l2, bf16, latency, gpool);
-    case 4: return hnsw_pick_e<4>(l2, bf16, latency, gpool);
-    case 8: return hnsw_pick_e<8>(l2, bf16, latency, gpool);
-    case kHnswLdsList: return hnsw_pick_e<0>(l2, bf16, latency, gpool);
+    case 1: return hnsw_pick_e<1>(l2, bf16, latency, gpool, hash);
+    case 2: return hnsw_pick_e<2>(l2, bf16, latency, gpool, hash);
+    case 4: return hnsw_pick_e<4>(l2, bf16, latency, gpool, hash);
+    case 8: return hnsw_pick_e<8>(l2, bf16, latency, gpool, hash);
+    case kHnswLdsList: return hnsw_pick_e<0>(l2, bf16, latency, gpool, hash);
   }
   return nullptr;
 }
+bool hnsw_uses_latency_variant(const HnswSearchArgs &a) { return hnsw_latency_variant(a); }
 
 hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks) {
-  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a), (int)a.gpool_level);
+  const void *f = hnsw_pick(a, l2, bf16, e);
   if (!f) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -744,7 +775,7 @@ hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, i
 }
 
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s) {
-  const void *f = hnsw_pick(l2, bf16, e, hnsw_latency_variant(a), (int)a.gpool_level);
+  const void *f = hnsw_pick(a, l2, bf16, e);
   if (!f || blocks == 0) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 48 * 1024) {

@@ -138,7 +138,7 @@ struct HnswSearchArgs {
   uint64_t allow_nbits;
   const uint64_t *const *allow_tab;   // optional [nq]: one bitmap per query (nullptr entry = no filter); overrides allow_bits
   const uint64_t *allow_nbits_tab;    // [nq]
-  uint32_t *visited;           // [wave slots][bitmap_words] scratch bitmaps
+  uint32_t *visited;           // [wave slots][bitmap_words] scratch: visited bitmaps, or (vis_hash_log2 != 0) hash sets
   float *out_dist;             // [nq][k]
   uint64_t *out_label;
   uint32_t *out_n;
@@ -168,11 +168,17 @@ struct HnswSearchArgs {
   // expanded nodes (the reference polls per popped candidate, hnswalg.h:400-402); a cancelled search keeps what its
   // result list holds, queries not started yet answer with empty lists
   const uint32_t *cancel;
+  // Visited set as an exact hash set of node ids (open addressing, 2^vis_hash_log2 words per wave slot = bitmap_words)
+  // instead of one bit per node of the graph: a search touches a few thousand of 10M nodes, a table of 64 KB stays in
+  // cache and is cleared in no time where the bitmap takes 1.25 MB per resident wave.  LDS-frontier launches only; a
+  // query that would fill the table beyond 3/4 is abandoned into redo_out and re-run with the bitmap.
+  uint32_t vis_hash_log2;
 };
 constexpr int kHnswLdsList = 16;      // hnsw_slots_per_lane(): 512 < ef <= kHnswMaxEf, result list in LDS
 constexpr uint64_t kHnswMaxEf = 16384;   // (2 * ef words of LDS: the default max-vector-knn of 10000 fits, ft_search_parser.cc:34-45)
 int hnsw_slots_per_lane(uint64_t ef);                      // 0 = ef beyond kHnswMaxEf
 int hnsw_waves_per_block(const HnswSearchArgs &a);
+bool hnsw_uses_latency_variant(const HnswSearchArgs &a);   // (a batch too small to fill the device)
 size_t hnsw_lds_bytes(const HnswSearchArgs &a);
 hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, int *blocks);
 hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e, uint32_t blocks, hipStream_t s);
