@@ -560,6 +560,9 @@ class HnswIndex final : public Index {
       h = a;
       h.vis_hash_log2 = hash_log2;
       h.bitmap_words = 1u << hash_log2;
+      // (its LDS frontier need not hold 2 x ef entries for the worst run of equal distances: a query that fills it is
+      // re-run like one that fills its table, and the LDS saved is resident waves at large ef)
+      h.cand_cap = (uint32_t)((std::max<uint64_t>(cand_floor_, ef + std::max<uint64_t>(64, ef / 4)) + 3) & ~(uint64_t)3);
       int mbh = 0;
       VK_HIP_TRY(hnsw_max_blocks(h, l2(), store_.bf16(), e, &mbh));
       blocks_h = std::min<uint64_t>((nq + wpb - 1) / wpb, (uint64_t)mbh);
@@ -576,7 +579,7 @@ class HnswIndex final : public Index {
     // minimum per 64 of them): as many waves as its memory budget holds
     HnswSearchArgs b{};
     uint64_t blocks2 = 0, wpb2 = 0;
-    if (redo) {
+    if (redo || hash_log2) {
       b = a;
       b.gpool_level = 2;
       b.cand_cap = (uint32_t)(((uint64_t)count + 8191) & ~(uint64_t)8191);
@@ -604,17 +607,20 @@ class HnswIndex final : public Index {
       VK_HIP_TRY(hipMemsetAsync(a.redo_out, 0, 4, s));
     }
     if (hash_log2) {
-      // first the launch with the hash sets; then the same kernel as always, with bitmaps, over the queries it gave up
-      // (a few microseconds when there are none)
+      // first the launch with the hash sets; then, over the queries it gave up, the kernel that nothing can overflow:
+      // bitmaps and a frontier sized by the graph (a few microseconds when there are none)
       h.visited = a.visited;
       h.stats = a.stats;
       h.queue = a.queue;
       h.redo_out = ctx->d_redo.as<uint32_t>();
       VK_HIP_TRY(hipMemsetAsync(h.redo_out, 0, 4, s));
       VK_HIP_TRY(launch_hnsw_search(h, l2(), store_.bf16(), e, (uint32_t)blocks_h, s));
-      a.queue = a.queue + 1;
-      a.redo_in = ctx->d_redo.as<uint32_t>();
-      VK_HIP_TRY(launch_hnsw_search(a, l2(), store_.bf16(), e, (uint32_t)blocks, s));
+      b.visited = a.visited;
+      b.stats = a.stats;
+      b.queue = a.queue + 1;
+      b.redo_out = nullptr;
+      b.redo_in = ctx->d_redo.as<uint32_t>();
+      VK_HIP_TRY(launch_hnsw_search(b, l2(), store_.bf16(), e, (uint32_t)blocks2, s));
       return Status::Ok();
     }
     VK_HIP_TRY(launch_hnsw_search(a, l2(), store_.bf16(), e, (uint32_t)blocks, s));

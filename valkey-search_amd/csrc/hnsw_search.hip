@@ -533,7 +533,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
               // search early.  The capped HBM frontier gives the query up instead -- it is re-run by the launch with the
               // graph-sized frontier (a.redo_out); the LDS frontier and the graph-sized one cannot get here
               // (counted, and the host turns a non-zero count into an error).
-              if (kGPool == 1 && a.redo_out) { abandoned = true; break; }
+              if ((kGPool == 1 || kHash) && a.redo_out) { abandoned = true; break; }
               st_over += 1;
             }
           }
@@ -644,13 +644,15 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
 }
 
 // 4 waves per SIMD (<= 128 VGPRs): a full batch is bound by gathers in flight, i.e. by resident waves
+// (16 result slots per lane, 512 < ef <= 1024: 32 more registers than fit 128 -- three waves per SIMD instead of four,
+// still twelve per CU where the LDS result list allows seven)
 template <bool kL2, int kE, bool kBf16>
-__global__ __launch_bounds__(256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
+__global__ __launch_bounds__(256, kE == 16 ? 3 : 4) void hnsw_search_kernel(HnswSearchArgs a) {
   hnsw_search_body<kL2, kE, kBf16, 8, false>(a);
 }
 // ... with the visited set as a hash table of ids (HnswSearchArgs::vis_hash_log2)
 template <bool kL2, int kE, bool kBf16>
-__global__ __launch_bounds__(256, 4) void hnsw_search_hash_kernel(HnswSearchArgs a) {
+__global__ __launch_bounds__(256, kE == 16 ? 3 : 4) void hnsw_search_hash_kernel(HnswSearchArgs a) {
   hnsw_search_body<kL2, kE, kBf16, 8, false, 0, true>(a);
 }
 // searches with a filter or tombstones: the frontier lives in HBM (HnswSearchArgs::pool_g)
@@ -692,12 +694,16 @@ int hnsw_slots_per_lane(uint64_t ef) {
   if (ef <= 128) return 2;
   if (ef <= 256) return 4;
   if (ef <= 512) return 8;
+  if (ef <= 1024) return 16;                   // (LDS-frontier kernels; the others keep the list in LDS from 512 on)
   if (ef <= kHnswMaxEf) return kHnswLdsList;   // result list in LDS, one wave per block
   return 0;
 }
 
+// the result list of this launch lives in LDS (one wave per block) rather than in the lanes' registers
+static bool hnsw_list_in_lds(const HnswSearchArgs &a) { return a.ef > 1024 || (a.ef > 512 && a.gpool_level != 0); }
+
 static size_t hnsw_lds_per_wave(const HnswSearchArgs &a) {
-  const bool lds_list = a.ef > 512;
+  const bool lds_list = hnsw_list_in_lds(a);
   // HBM frontier: segment minima only (gpool_level 2: one per 64 segments)
   const size_t pool = a.gpool_level == 2 ? (size_t)(a.cand_cap / 8192) * 2
                       : a.gpool_level == 1 ? (size_t)(a.cand_cap / 128) * 2 : (size_t)a.cand_cap * 2;
@@ -708,7 +714,7 @@ static size_t hnsw_lds_per_wave(const HnswSearchArgs &a) {
 // waves (queries) per block: 4, or fewer when the per-wave LDS (query + frontier pool, + result list for ef > 512)
 // of four does not fit a CU -- rows beyond ~9000 dimensions, up to the FLAT limit, run 2 or 1 waves per block
 int hnsw_waves_per_block(const HnswSearchArgs &a) {
-  if (a.ef > 512) return 1;
+  if (hnsw_list_in_lds(a)) return 1;
   const size_t pw = hnsw_lds_per_wave(a);
   return 4 * pw <= 160 * 1024 ? 4 : 2 * pw <= 160 * 1024 ? 2 : 1;
 }
@@ -718,12 +724,16 @@ size_t hnsw_lds_bytes(const HnswSearchArgs &a) { return hnsw_lds_per_wave(a) * (
 template <bool kL2, int kE, bool kBf16>
 static const void *hnsw_fn(bool latency, int gpool, bool hash) {
   if (hash) return reinterpret_cast<const void *>(&hnsw_search_hash_kernel<kL2, kE, kBf16>);
-  if (gpool == 2) return reinterpret_cast<const void *>(&hnsw_search_gpool2_kernel<kL2, kE, kBf16>);
-  if (gpool) return reinterpret_cast<const void *>(&hnsw_search_gpool_kernel<kL2, kE, kBf16>);
-  if constexpr (kE >= 1 && kE <= 4) {
-    if (latency) return reinterpret_cast<const void *>(&hnsw_search_latency_kernel<kL2, kE, kBf16>);
+  if constexpr (kE == 16) {   // (LDS-frontier kernels only)
+    return gpool ? nullptr : reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE, kBf16>);
+  } else {
+    if (gpool == 2) return reinterpret_cast<const void *>(&hnsw_search_gpool2_kernel<kL2, kE, kBf16>);
+    if (gpool) return reinterpret_cast<const void *>(&hnsw_search_gpool_kernel<kL2, kE, kBf16>);
+    if constexpr (kE >= 1 && kE <= 4) {
+      if (latency) return reinterpret_cast<const void *>(&hnsw_search_latency_kernel<kL2, kE, kBf16>);
+    }
+    return reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE, kBf16>);
   }
-  return reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE, kBf16>);
 }
 
 template <int kE>
@@ -748,6 +758,7 @@ static const void *hnsw_pick(const HnswSearchArgs &a, bool l2, bool bf16, int e)
     case 2: return hnsw_pick_e<2>(l2, bf16, latency, gpool, hash);
     case 4: return hnsw_pick_e<4>(l2, bf16, latency, gpool, hash);
     case 8: return hnsw_pick_e<8>(l2, bf16, latency, gpool, hash);
+    case 16: return gpool ? hnsw_pick_e<0>(l2, bf16, latency, gpool, hash) : hnsw_pick_e<16>(l2, bf16, latency, gpool, hash);
     case kHnswLdsList: return hnsw_pick_e<0>(l2, bf16, latency, gpool, hash);
   }
   return nullptr;

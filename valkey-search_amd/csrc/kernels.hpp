@@ -174,7 +174,8 @@ struct HnswSearchArgs {
   // query that would fill the table beyond 3/4 is abandoned into redo_out and re-run with the bitmap.
   uint32_t vis_hash_log2;
 };
-constexpr int kHnswLdsList = 16;      // hnsw_slots_per_lane(): 512 < ef <= kHnswMaxEf, result list in LDS
+constexpr int kHnswLdsList = 255;     // hnsw_slots_per_lane(): 1024 < ef <= kHnswMaxEf, result list in LDS (also 512 < ef <= 1024
+                                      // when the frontier lives in HBM: those kernels have no 16-slot variant)
 constexpr uint64_t kHnswMaxEf = 16384;   // (2 * ef words of LDS: the default max-vector-knn of 10000 fits, ft_search_parser.cc:34-45)
 int hnsw_slots_per_lane(uint64_t ef);                      // 0 = ef beyond kHnswMaxEf
 int hnsw_waves_per_block(const HnswSearchArgs &a);
