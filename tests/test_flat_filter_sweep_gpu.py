@@ -1,7 +1,7 @@
 """Randomised sweep over the f16 candidate filter + exact re-rank (K4h): index size, dimension (padding, 1 to 25 pipeline
 stages per tile), batch size around the 32-query tiles and the 256-query launch groups, k up to 64, metric, row storage,
-row scales from 1e-3 to 1e2, duplicated rows (ties by label, survivor overflow), allow-bitmaps and deletions, drawn from a
-fixed seed.  The filter path must return exactly what the oracle returns -- ids and distance bits -- whatever it did on
+row scales from 1e-3 to 1e2, duplicated rows (ties by label, survivor overflow), allow-bitmaps and deletions, one- and
+two-level bounds, drawn from a fixed seed.  The filter path must return exactly what the oracle returns -- ids and distance bits -- whatever it did on
 the way (vk_index_stats says whether it re-ranked its survivors or handed the batch to the exact kernel)."""
 import os
 
@@ -50,8 +50,10 @@ def test_random_shape_through_the_filter(vsa, oracle, seed):
     if metric == "COSINE":
         x = (x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-30)).astype(np.float32)
     labels = rng.permutation(3 * n)[:n].astype(np.uint64)
-    old = {v: os.environ.get(v) for v in ("VK_FILTER_PREPASS", "VK_FILTER_MIN_ROWS")}
-    os.environ.update(VK_FILTER_PREPASS="1024", VK_FILTER_MIN_ROWS="32768")
+    old = {v: os.environ.get(v) for v in ("VK_FILTER_PREPASS", "VK_FILTER_MIN_ROWS", "VK_FILTER_SEED")}
+    # odd seeds: the sample's own k-th best comes from a filter pass seeded by the exact kernel over its first 128 rows
+    # per 10 of k (what a large index does); even seeds: from the exact kernel over the whole sample
+    os.environ.update(VK_FILTER_PREPASS="1024", VK_FILTER_MIN_ROWS="32768", VK_FILTER_SEED="128" if seed % 2 else "1000000")
     try:
         g = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype)
     finally:

@@ -795,13 +795,18 @@ class FlatIndex final : public Index {
     tp.pending = false;
   }
 
-  // sample the exact kernel bounds the k-th best distance on, for the candidate filter: its survivors are about
-  // count * k / sample per query
-  // (at most 1/64 of the index: about 64 k survivors per query whatever the size, and the exact pass over the sample --
-  // for L2 the VALU scan -- stays a small part of the batch on mid-sized indexes)
+  // The sample whose exact k-th best distance bounds the whole index's, for the candidate filter: the final pass keeps
+  // about count * k / sample rows per query (380 at 10M rows, k = 10).  At most 1/32 of the index, so that finding the
+  // sample's own k-th best -- a filter pass over it -- stays a few per cent of the batch.
   uint64_t filter_prepass_rows(uint64_t k) const {
-    const uint64_t cap = filter_prepass_rows_ * ((k + 9) / 10);
-    return std::max<uint64_t>(std::min<uint64_t>(cap, count_ / 64), std::min<uint64_t>(cap, 1024 * ((k + 9) / 10)));
+    const uint64_t kk = (k + 9) / 10, cap = filter_prepass_rows_ * kk;
+    return std::max<uint64_t>(std::min<uint64_t>(cap, count_ / 32), std::min<uint64_t>(cap, 1024 * kk));
+  }
+  // ... and the seed: the first rows of the sample, the only ones the exact matrix-core kernel (1/16 of the f16 rate)
+  // looks at; their k-th best bounds the sample's (sample * k / seed candidates per query there)
+  uint64_t filter_seed_rows(uint64_t k, uint64_t sample) const {
+    const uint64_t seed = filter_seed_rows_ * ((k + 9) / 10);
+    return sample >= 2 * seed ? seed : sample;
   }
 
   // the largest row norm / element of the index, brought up to date for the rows written since the last call (once
@@ -836,140 +841,169 @@ class FlatIndex final : public Index {
                      uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
                      uint64_t out_ld, const uint32_t *d_cancel) {
     VK_TRY(ensure_row_stats());
-    // 1. bound: the exact kernel over the first rows (answers land in the output arrays for a moment)
-    if (l2()) {   // (L2 has no exact matrix-core kernel: the VALU scan over the sample)
-      VK_TRY(scan_k3(ctx, d_q, nq, k, filter_prepass_rows(k), d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, k));
-    } else {
-      in_prepass_ = true;
-      Status ps = scan_gemm(ctx, d_q, nq, k, filter_prepass_rows(k), d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
-      in_prepass_ = false;
-      VK_TRY(ps);
-    }
-    VK_TRY(ctx->d_stats.ensure(std::max<size_t>(64, nq * 8)));
-    VK_HIP_TRY(launch_kth_bound(d_out_d, d_out_n, (uint32_t)k, (uint32_t)nq, ctx->d_stats.as<float>(), s));
-    const float *bound = ctx->d_stats.as<float>();
-    // 2. queries -> f16 fragments + gates
     const uint32_t dp = store_.stride_f();
     const uint32_t nqt = (uint32_t)((nq + 31) / 32);
     const uint32_t cap = (uint32_t)std::max<uint64_t>(filter_cap_, 64 * k);
+    const int e = flat_scan_slots_per_lane(k);
+    const uint32_t nrp = 8;
+    const uint64_t per_q = (uint64_t)nrp * k;
+    VK_TRY(ctx->d_stats.ensure(std::max<size_t>(64, nq * 8)));
     VK_TRY(ctx->d_fq16.ensure((size_t)nqt * 32 * dp * 2));
     VK_TRY(ctx->d_fthr.ensure((size_t)nqt * 32 * 4));
-    VK_TRY(ctx->d_fcnt.ensure(nq * 4 + 4));
+    VK_TRY(ctx->d_fcnt.ensure(nq * 4 + 8));
     VK_TRY(ctx->d_fcand.ensure(nq * (size_t)cap * 4));
-    VK_HIP_TRY(hipMemsetAsync(ctx->d_fcnt.p, 0, nq * 4 + 4, s));
-    uint32_t *ovf = ctx->d_fcnt.as<uint32_t>() + nq;
-    FlatFilterArgs f{};
-    f.rows = store_.d_rows();
-    f.bf16 = store_.bf16() ? 1 : 0;
-    f.l2 = l2() ? 1 : 0;
-    f.hn16 = l2() ? d_hn16_.as<uint32_t>() : nullptr;
-    f.labels = store_.d_labels();
-    f.allow_bits = d_allow;
-    f.allow_nbits = allow_nbits;
-    f.queries = d_q;
-    f.q_stride_f = dp;
-    f.q16 = ctx->d_fq16.p;
-    f.thr = ctx->d_fthr.as<float>();
-    f.bound = bound;
-    f.row_stats = d_rowstats_.as<uint32_t>();
-    f.cand_cnt = ctx->d_fcnt.as<uint32_t>();
-    f.cand_row = ctx->d_fcand.as<uint32_t>();
-    f.cap = cap;
-    f.ovf = ovf;
-    f.row_stride_f = dp;
-    f.n_rows = (uint32_t)count;
-    f.nq = (uint32_t)nq;
-    f.nqt = nqt;
-    f.cancel = d_cancel;
-    static const bool timing = getenv("VK_FILTER_TIMING") && atoi(getenv("VK_FILTER_TIMING")) != 0;
-    f.timing = timing && !store_.bf16() && !l2();
-    if (f.timing) {   // phase timing experiment: nine counters
-      VK_TRY(ctx->d_idx.ensure(128));
-      VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
-      f.dbg = ctx->d_idx.as<unsigned long long>();
-    }
-    VK_HIP_TRY(launch_flat_qprep(f, s));
-    // 3. the filter: one launch per 256 queries, every launch one pass over the rows
+    VK_TRY(ctx->d_fpart_d.ensure(nq * per_q * 4));
+    VK_TRY(ctx->d_fpart_l.ensure(nq * per_q * 8));
+    float *bound = ctx->d_stats.as<float>();
+    uint32_t *ovf = ctx->d_fcnt.as<uint32_t>() + nq;       // the final pass's flag: the exact kernel answers the batch
+    uint32_t *ovf_mid = ovf + 1;                           // the sample pass's flag: the exact kernel bounds the sample
+    VK_HIP_TRY(hipMemsetAsync(ovf, 0, 8, s));
     if (filter_blocks_ == 0) {
       int cus = 0;
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, store_.device());
       filter_blocks_ = cus > 0 ? (uint32_t)cus : 256;
     }
-    SearchCtx::TimedPair &tp = ctx->timed[ctx->timed_next++ % 32];
-    drain_timed(tp);
-    if (!tp.t0) {
-      VK_HIP_TRY(hipEventCreate(&tp.t0));
-      VK_HIP_TRY(hipEventCreate(&tp.t1));
+    static const bool timing = getenv("VK_FILTER_TIMING") && atoi(getenv("VK_FILTER_TIMING")) != 0;
+
+    // the exact kernel over the first `rows_n` rows (for L2, which has no exact matrix-core kernel, the VALU scan);
+    // answers land in the output arrays, k per query
+    auto exact_prefix = [&](uint64_t rows_n, const uint32_t *run_flag, uint32_t run_if) -> Status {
+      if (l2()) return scan_k3(ctx, d_q, nq, k, rows_n, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, k, run_flag, run_if);
+      in_prepass_ = true;
+      Status ps = scan_gemm(ctx, d_q, nq, k, rows_n, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, 0, nullptr, nullptr, run_flag, run_if);
+      in_prepass_ = false;
+      return ps;
+    };
+    // queries -> f16 fragments + gates from `bound`; f16 filter over the first `rows_n` rows (one launch per 256
+    // queries, every launch one pass over those rows); exact re-rank of the survivors + selection into the output
+    // arrays (ld entries per query) unless a list overflowed (*flag raised: nothing is written)
+    auto filter_pass = [&](uint64_t rows_n, uint32_t *flag, uint64_t ld, bool timed) -> Status {
+      VK_HIP_TRY(hipMemsetAsync(ctx->d_fcnt.p, 0, nq * 4, s));
+      FlatFilterArgs f{};
+      f.rows = store_.d_rows();
+      f.bf16 = store_.bf16() ? 1 : 0;
+      f.l2 = l2() ? 1 : 0;
+      f.hn16 = l2() ? d_hn16_.as<uint32_t>() : nullptr;
+      f.labels = store_.d_labels();
+      f.allow_bits = d_allow;
+      f.allow_nbits = allow_nbits;
+      f.queries = d_q;
+      f.q_stride_f = dp;
+      f.q16 = ctx->d_fq16.p;
+      f.thr = ctx->d_fthr.as<float>();
+      f.bound = bound;
+      f.row_stats = d_rowstats_.as<uint32_t>();
+      f.cand_cnt = ctx->d_fcnt.as<uint32_t>();
+      f.cand_row = ctx->d_fcand.as<uint32_t>();
+      f.cap = cap;
+      f.ovf = flag;
+      f.row_stride_f = dp;
+      f.n_rows = (uint32_t)rows_n;
+      f.nq = (uint32_t)nq;
+      f.nqt = nqt;
+      f.cancel = d_cancel;
+      f.timing = timed && timing && !store_.bf16() && !l2();
+      if (f.timing) {   // phase timing experiment: nine counters
+        VK_TRY(ctx->d_idx.ensure(128));
+        VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
+        f.dbg = ctx->d_idx.as<unsigned long long>();
+      }
+      VK_HIP_TRY(launch_flat_qprep(f, s));
+      SearchCtx::TimedPair *tp = nullptr;
+      if (timed) {
+        tp = &ctx->timed[ctx->timed_next++ % 32];
+        drain_timed(*tp);
+        if (!tp->t0) {
+          VK_HIP_TRY(hipEventCreate(&tp->t0));
+          VK_HIP_TRY(hipEventCreate(&tp->t1));
+        }
+        VK_HIP_TRY(hipEventRecord(tp->t0, s));
+      }
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>(filter_blocks_, (rows_n + 127) / 128);
+      for (uint32_t g0 = 0; g0 < nqt; g0 += 8) {
+        FlatFilterArgs fg = f;
+        fg.nqt = std::min<uint32_t>(8, nqt - g0);
+        fg.nq = (uint32_t)std::min<uint64_t>(256, nq - (uint64_t)g0 * 32);
+        fg.q16 = static_cast<char *>(f.q16) + (size_t)g0 * 32 * dp * 2;
+        fg.thr = f.thr + (size_t)g0 * 32;
+        fg.cand_cnt = f.cand_cnt + (size_t)g0 * 32;
+        fg.cand_row = f.cand_row + (size_t)g0 * 32 * cap;
+        VK_HIP_TRY(launch_flat_filter(fg, blocks, s));
+      }
+      if (timed) {
+        VK_HIP_TRY(hipEventRecord(tp->t1, s));
+        tp->pending = true;
+      }
+      FlatScanArgs r{};
+      r.rows = store_.d_rows();
+      r.labels = store_.d_labels();
+      r.queries = d_q;
+      r.allow_bits = d_allow;
+      r.allow_nbits = allow_nbits;
+      r.part_dist = ctx->d_fpart_d.as<float>();
+      r.part_label = ctx->d_fpart_l.as<uint64_t>();
+      r.row_stride_f = r.q_stride_f = dp;
+      r.chunks = dp / 16;
+      r.row_begin = 0;
+      r.row_end = (uint32_t)rows_n;
+      r.nq = (uint32_t)nq;
+      r.k = (uint32_t)k;
+      r.nrp = nrp;
+      r.nqg = (uint32_t)nq;
+      r.cand_cnt = f.cand_cnt;
+      r.cand_row = f.cand_row;
+      r.cand_cap = cap;
+      r.run_flag = flag;
+      r.run_if = 0;
+      VK_HIP_TRY(launch_flat_scan(r, l2(), store_.bf16(), 1, e, s));
+      MergeArgs m{};
+      m.in_dist = r.part_dist;
+      m.in_label = r.part_label;
+      m.part_stride = nq * per_q;
+      m.q_stride = per_q;
+      m.parts = 1;
+      m.per_part = (uint32_t)per_q;
+      m.k = (uint32_t)k;
+      m.out_ld = (uint32_t)ld;
+      m.out_dist = d_out_d;
+      m.out_label = d_out_l;
+      m.out_n = d_out_n;
+      m.run_flag = flag;
+      m.run_if = 0;
+      VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
+      if (f.timing) {
+        unsigned long long h[9];
+        VK_HIP_TRY(hipStreamSynchronize(s));
+        VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, sizeof h, hipMemcpyDeviceToHost));
+        const double w2 = (double)blocks * 2, w4 = (double)blocks * 4;
+        fprintf(stderr, "[vk] filter phases, cycles per wave: row producers issue %.0f  wait+convert+store %.0f  barrier %.0f | "
+                        "query producers issue+wait+store %.0f  barrier %.0f | consumers mfma %.0f  gate %.0f  barrier %.0f\n",
+                h[0] / w2, h[2] / w2, h[3] / w2, h[4] / w2, h[8] / w2, h[5] / w4, h[6] / w4, h[7] / w4);
+      }
+      return Status::Ok();
+    };
+
+    // 1. bound: an upper bound of every query's final k-th best exact distance = its exact k-th best over a sample (the
+    //    first `sample` rows).  The exact kernel runs at 1/16 of the f16 rate, so it only looks at a seed (the first
+    //    `seed` rows); the sample's own k-th best is then found the way the whole index's is: filter the sample with the
+    //    seed's bound, re-rank exactly.  Should that overflow (it holds sample * k / seed candidates per query when all
+    //    goes well), the exact kernel bounds the sample after all.
+    const uint64_t sample = filter_prepass_rows(k), seed = filter_seed_rows(k, sample);
+    if (seed < sample) {
+      VK_TRY(exact_prefix(seed, nullptr, 0));
+      VK_HIP_TRY(launch_kth_bound(d_out_d, d_out_n, (uint32_t)k, (uint32_t)nq, bound, s));
+      VK_TRY(filter_pass(sample, ovf_mid, k, false));
+      VK_TRY(exact_prefix(sample, ovf_mid, 1));
+    } else {
+      VK_TRY(exact_prefix(sample, nullptr, 0));
     }
-    VK_HIP_TRY(hipEventRecord(tp.t0, s));
-    for (uint32_t g0 = 0; g0 < nqt; g0 += 8) {
-      FlatFilterArgs fg = f;
-      fg.nqt = std::min<uint32_t>(8, nqt - g0);
-      fg.nq = (uint32_t)std::min<uint64_t>(256, nq - (uint64_t)g0 * 32);
-      fg.q16 = static_cast<char *>(f.q16) + (size_t)g0 * 32 * dp * 2;
-      fg.thr = f.thr + (size_t)g0 * 32;
-      fg.cand_cnt = f.cand_cnt + (size_t)g0 * 32;
-      fg.cand_row = f.cand_row + (size_t)g0 * 32 * cap;
-      VK_HIP_TRY(launch_flat_filter(fg, filter_blocks_, s));
-    }
-    VK_HIP_TRY(hipEventRecord(tp.t1, s));
-    tp.pending = true;
-    // 4. exact re-rank of the survivors (unless a list overflowed) ...
-    const int e = flat_scan_slots_per_lane(k);
-    const uint32_t nrp = 8;
-    const uint64_t per_q = (uint64_t)nrp * k;
-    VK_TRY(ctx->d_fpart_d.ensure(nq * per_q * 4));
-    VK_TRY(ctx->d_fpart_l.ensure(nq * per_q * 8));
-    FlatScanArgs r{};
-    r.rows = store_.d_rows();
-    r.labels = store_.d_labels();
-    r.queries = d_q;
-    r.allow_bits = d_allow;
-    r.allow_nbits = allow_nbits;
-    r.part_dist = ctx->d_fpart_d.as<float>();
-    r.part_label = ctx->d_fpart_l.as<uint64_t>();
-    r.row_stride_f = r.q_stride_f = dp;
-    r.chunks = dp / 16;
-    r.row_begin = 0;
-    r.row_end = (uint32_t)count;
-    r.nq = (uint32_t)nq;
-    r.k = (uint32_t)k;
-    r.nrp = nrp;
-    r.nqg = (uint32_t)nq;
-    r.cand_cnt = f.cand_cnt;
-    r.cand_row = f.cand_row;
-    r.cand_cap = cap;
-    r.run_flag = ovf;
-    r.run_if = 0;
-    VK_HIP_TRY(launch_flat_scan(r, l2(), store_.bf16(), 1, e, s));
-    MergeArgs m{};
-    m.in_dist = r.part_dist;
-    m.in_label = r.part_label;
-    m.part_stride = nq * per_q;
-    m.q_stride = per_q;
-    m.parts = 1;
-    m.per_part = (uint32_t)per_q;
-    m.k = (uint32_t)k;
-    m.out_ld = (uint32_t)out_ld;
-    m.out_dist = d_out_d;
-    m.out_label = d_out_l;
-    m.out_n = d_out_n;
-    m.run_flag = ovf;
-    m.run_if = 0;
-    VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
-    // 5. ... or the exact kernel over everything (only when the flag is up: its blocks return at once otherwise)
+    VK_HIP_TRY(launch_kth_bound(d_out_d, d_out_n, (uint32_t)k, (uint32_t)nq, bound, s));
+    // 2. the filter over all rows + exact re-rank of the survivors ...
+    VK_TRY(filter_pass(count, ovf, out_ld, true));
+    // 3. ... or the exact kernel over everything (only when the flag is up: its blocks return at once otherwise)
     if (l2()) VK_TRY(scan_k3(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld, ovf, 1));
     else VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, bound, ovf, 1));
     filter_used_ = true;
-    if (f.timing) {
-      unsigned long long h[9];
-      VK_HIP_TRY(hipStreamSynchronize(s));
-      VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, sizeof h, hipMemcpyDeviceToHost));
-      const double w2 = (double)filter_blocks_ * 2, w4 = (double)filter_blocks_ * 4;
-      fprintf(stderr, "[vk] filter phases, cycles per wave: row producers issue %.0f  wait+convert+store %.0f  barrier %.0f | "
-                      "query producers issue+wait+store %.0f  barrier %.0f | consumers mfma %.0f  gate %.0f  barrier %.0f\n",
-              h[0] / w2, h[2] / w2, h[3] / w2, h[4] / w2, h[8] / w2, h[5] / w4, h[6] / w4, h[7] / w4);
-    }
     return Status::Ok();
   }
 
@@ -977,7 +1011,8 @@ class FlatIndex final : public Index {
   bool filter_enabled_ = !(getenv("VK_FLAT_FILTER") && atoi(getenv("VK_FLAT_FILTER")) == 0);
   uint64_t filter_min_queries_ = getenv("VK_FILTER_MIN_QUERIES") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_QUERIES")) : 33;
   uint64_t filter_min_rows_ = getenv("VK_FILTER_MIN_ROWS") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_ROWS")) : 262144;
-  uint64_t filter_prepass_rows_ = getenv("VK_FILTER_PREPASS") ? (uint64_t)atoll(getenv("VK_FILTER_PREPASS")) : 65536;
+  uint64_t filter_prepass_rows_ = getenv("VK_FILTER_PREPASS") ? (uint64_t)atoll(getenv("VK_FILTER_PREPASS")) : 262144;
+  uint64_t filter_seed_rows_ = getenv("VK_FILTER_SEED") ? (uint64_t)atoll(getenv("VK_FILTER_SEED")) : 8192;
   uint64_t filter_cap_ = getenv("VK_FILTER_CAP") ? (uint64_t)atoll(getenv("VK_FILTER_CAP")) : 8192;
   uint32_t filter_blocks_ = 0;
   DevBuf d_rowstats_, d_hn16_;
