@@ -616,7 +616,7 @@ def pmc_traffic(N, D, B, world, kernel_prefix):
     if j.get("src_sha256") != source_sha256():
         return None, "profiles/r02_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
     for name, v in j.get("kernels", {}).items():
-        if kernel_prefix in name and "prepass" not in name:
+        if kernel_prefix in name and "prepass" not in name and "[small]" not in name:
             return round(v["hbm_bytes_per_launch"]), "profiles/r02_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
     return None, None
 

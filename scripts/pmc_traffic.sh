@@ -6,6 +6,7 @@
 #   scripts/pmc_traffic.sh [out.json]        (run on the GPU box; default out: gpurun_out/r02_pmc_fetch_size.json)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$ROOT/gpurun_out/r02_pmc_fetch_size.json}
+case "$OUT" in /*) ;; *) OUT="$PWD/$OUT" ;; esac
 mkdir -p $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 D=$ROOT/gpurun_out/pmc_traffic
@@ -21,7 +22,8 @@ from bench import source_sha256
 agg = json.load(open(sys.argv[1]))
 N, D, = 10_000_000, 768
 row_bytes = N * D * 4.0
-cal = [k for k in agg if "flat_scan_kernel<1," in k]
+# (the full single-query scan, not the re-rank instantiation of the same kernel: the one that fetched the most)
+cal = sorted([k for k in agg if "flat_scan_kernel<1," in k and "[small]" not in k], key=lambda k: -agg[k].get("FETCH_SIZE", 0.0))
 out = {"note": "rocprofv3 --pmc FETCH_SIZE, own pass (scripts/pmc_traffic.sh) of bench.py --steps 3 at 10Mx768 f32, B=256, k=10. "
                "FETCH_SIZE carries the gfx950 1/2 factor for 128-B requests and KiB units (MI355X_MICROARCH.md): it is calibrated "
                "on the single-query scan kernel, which reads each of the 30.72e9 row bytes exactly once.",

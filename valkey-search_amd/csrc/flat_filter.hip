@@ -339,7 +339,7 @@ __device__ __forceinline__ void ws_b_store(uint4 *slot, uint32_t p, uint32_t lan
 }
 
 template <bool kBf16, bool kL2, bool kTiming>
-__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_kernel(FlatFilterArgs a) {
+__device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   extern __shared__ _Float16 lds_a[];
   constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;                    // one A stage
   uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + 2 * kBufHalfs);          // [2][kWsBStage]
@@ -599,6 +599,17 @@ __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_kernel(FlatFilterAr
   ring_flush(a, ring, lane);
 }
 
+template <bool kBf16, bool kL2, bool kTiming>
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_kernel(FlatFilterArgs a) {
+  flat_filter_body<kBf16, kL2, kTiming>(a);
+}
+// the same kernel under another name for the pass over the bound's sample (a few per cent of the rows), so that a
+// profile's per-kernel averages are averages over launches of one size
+template <bool kBf16, bool kL2>
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_sample_kernel(FlatFilterArgs a) {
+  flat_filter_body<kBf16, kL2, false>(a);
+}
+
 size_t flat_filter_lds_bytes() {
   return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 +
          (size_t)2 * kFTileRows * 4 + 16;
@@ -622,6 +633,11 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
                                   : reinterpret_cast<const void *>(&flat_filter_kernel<true, false, false>))
                           : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_kernel<false, true, false>)
                                   : reinterpret_cast<const void *>(&flat_filter_kernel<false, false, false>));
+  if (a.sample_pass)
+    fn = a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_sample_kernel<true, true>)
+                        : reinterpret_cast<const void *>(&flat_filter_sample_kernel<true, false>))
+                : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_sample_kernel<false, true>)
+                        : reinterpret_cast<const void *>(&flat_filter_sample_kernel<false, false>));
   if (a.timing) {
     if (a.bf16 || a.l2) return hipErrorInvalidValue;
     fn = reinterpret_cast<const void *>(&flat_filter_kernel<false, false, true>);

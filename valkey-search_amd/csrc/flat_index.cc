@@ -902,6 +902,7 @@ class FlatIndex final : public Index {
       f.nq = (uint32_t)nq;
       f.nqt = nqt;
       f.cancel = d_cancel;
+      f.sample_pass = timed ? 0 : 1;
       f.timing = timed && timing && !store_.bf16() && !l2();
       if (f.timing) {   // phase timing experiment: nine counters
         VK_TRY(ctx->d_idx.ensure(128));

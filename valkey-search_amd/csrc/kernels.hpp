@@ -89,6 +89,7 @@ struct FlatFilterArgs {
   uint32_t row_stride_f, n_rows, nq;
   uint32_t nqt;               // query tiles of 32 (<= 8 per launch)
   const uint32_t *cancel;
+  uint32_t sample_pass;       // the pass over the bound's sample: same code, launched as flat_filter_sample_kernel
   uint32_t timing;            // VK_FILTER_TIMING=1: the kernel variant with cycle counters per phase (f32 rows, IP only)
   unsigned long long *dbg;    // timing: [9] cycles per phase, summed over the waves (see the kernel)
 };
