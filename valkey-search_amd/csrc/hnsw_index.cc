@@ -539,7 +539,7 @@ class HnswIndex final : public Index {
       return Status::Err(VK_ERR_INVALID, "query block + result list (dimension, ef, M) do not fit the 160 KiB of LDS");
     int max_blocks = 0;
     VK_HIP_TRY(hnsw_max_blocks(a, l2(), store_.bf16(), e, &max_blocks));
-    // visited sets: one per resident wave, bounded to 2 GiB per context.  A bitmap of the graph -- or, for a batch that
+    // visited sets: one per resident wave, bounded to 4 GiB per search context (VK_HNSW_VISITED_BYTES).  A bitmap of the graph -- or, for a batch that
     // fills the device on a graph large enough for it to matter, an exact hash set of the ids the search touches
     // (typically 25 x ef of them): 64 KB instead of 1.25 MB per wave at 10M nodes, ef = 128, so every wave the CUs can
     // hold gets one (the bitmaps' 2 GiB allowed 1 636 of 4 096), clearing it costs nothing and its atomics hit in cache.
@@ -570,8 +570,8 @@ class HnswIndex final : public Index {
       VK_TRY(ctx->d_redo.ensure((nq + 1) * 4));
     }
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, visited_bytes_ / (bm_bytes * wpb)));
-    if (gpool) {   // ... and the HBM frontiers to 1 GiB
-      blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)1 << 30) / ((uint64_t)a.cand_cap * 8 * wpb)));
+    if (gpool) {   // ... and the HBM frontiers to 4 GiB (VK_HNSW_POOL_BYTES; 1 GiB held half the waves a CU can run: 29.9k -> 36.0k QPS on the hybrid shard)
+      blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, pool_bytes_ / ((uint64_t)a.cand_cap * 8 * wpb)));
       VK_TRY(ctx->d_pool.ensure(blocks * wpb * (uint64_t)a.cand_cap * 8));
       a.pool_g = ctx->d_pool.as<float>();
     }
@@ -906,7 +906,8 @@ class HnswIndex final : public Index {
   uint32_t visited_hash_ = getenv("VK_HNSW_VISITED_HASH") ? (uint32_t)atoi(getenv("VK_HNSW_VISITED_HASH")) : 1;
   uint64_t hash_per_ef_ = getenv("VK_HNSW_HASH_PER_EF") ? (uint64_t)atoll(getenv("VK_HNSW_HASH_PER_EF")) : 64;
   uint32_t hash_log2_forced_ = getenv("VK_HNSW_HASH_LOG2") ? (uint32_t)atoi(getenv("VK_HNSW_HASH_LOG2")) : 0;
-  uint64_t visited_bytes_ = getenv("VK_HNSW_VISITED_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_VISITED_BYTES")) : ((uint64_t)2 << 30);
+  uint64_t pool_bytes_ = getenv("VK_HNSW_POOL_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_POOL_BYTES")) : ((uint64_t)4 << 30);
+  uint64_t visited_bytes_ = getenv("VK_HNSW_VISITED_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_VISITED_BYTES")) : ((uint64_t)4 << 30);
   uint64_t redo_bytes_ = getenv("VK_HNSW_REDO_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_REDO_BYTES")) : ((uint64_t)2 << 30);
   bool device_build_ = !(getenv("VK_HNSW_DEVICE_BUILD") && atoi(getenv("VK_HNSW_DEVICE_BUILD")) == 0);
   RowStore store_;

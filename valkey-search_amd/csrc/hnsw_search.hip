@@ -651,6 +651,9 @@ __global__ __launch_bounds__(256, kE == 16 ? 3 : 4) void hnsw_search_kernel(Hnsw
   hnsw_search_body<kL2, kE, kBf16, 8, false>(a);
 }
 // ... with the visited set as a hash table of ids (HnswSearchArgs::vis_hash_log2)
+// (row pieces in flight per lane x waves per SIMD, same 10M graph and batch: 8 x 4 here; 12 x 3 and 24 x 2 +2.5 %,
+// 16 x 3 the same, 16 x 4 and 12 x 4 -- spilling -- 2-4 % slower: the batch is bound by what the memory system does
+// with this mix of accesses, not by one wave's chain of round trips)
 template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, kE == 16 ? 3 : 4) void hnsw_search_hash_kernel(HnswSearchArgs a) {
   hnsw_search_body<kL2, kE, kBf16, 8, false, 0, true>(a);
