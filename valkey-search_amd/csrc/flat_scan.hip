@@ -101,8 +101,20 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
     for (int qi = 0; qi < kQB; ++qi) acc[qi] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // row pieces in flight per lane: 8, or 4 where the accumulators of 8 queries need the registers
+    // (list mode: a wave has one round of 16 survivors, nothing to overlap its memory round trips with -- three times
+    // the pieces in flight, a third of the round trips)
     constexpr int kXB = VK_SCAN_XB(kQB, kL2);
     uint32_t c = 0;
+    if constexpr (kIdx && kQB == 1) {
+      constexpr int kXL = 24;
+      for (; c + kXL <= chunks; c += kXL) {
+        float4 x[kXL];
+#pragma unroll
+        for (int u = 0; u < kXL; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
+#pragma unroll
+        for (int u = 0; u < kXL; ++u) chunk_fma<kL2>(acc[0], x[u], qs[(c + u) * 4 + j]);
+      }
+    }
     for (; c + kXB <= chunks; c += kXB) {
       float4 x[kXB];
 #pragma unroll
