@@ -84,7 +84,7 @@ def test_hnsw_cancel_interrupts_a_long_filtered_batch(vsa, oracle):
     assert lag is not None and lag < 0.02
 
 
-@pytest.mark.parametrize("metric,nq,filt", [("L2", 2048, 0), ("COSINE", 4096, 0), ("COSINE", 4096, 1), ("L2", 4096, 1)])
+@pytest.mark.parametrize("metric,nq,filt", [("L2", 2048, 0), ("COSINE", 4096, 0), ("COSINE", 4096, 1), ("L2", 4096, 1), ("COSINE", 32768, 1)])
 def test_flat_cancel_returns_what_it_has(vsa, oracle, metric, nq, filt):
     """filt = 0: the exact kernels (VALU scan / f32 matrix-core kernel: batches long enough to time the reaction);
     filt = 1: the f16 candidate filter + re-rank (a batch of a few milliseconds: only the answer is checked)"""
