@@ -219,3 +219,34 @@ def test_l2_through_the_filter(vsa, oracle, dim, dtype):
     got = f2.search_batch(Q[:64], 10)
     assert f2.stats().last_filter_fallback == 1
     _same(got, e2.search_batch(Q[:64], 10))
+
+
+@pytest.mark.parametrize("metric,dtype", [("COSINE", "f32"), ("L2", "f32"), ("IP", "bf16")])
+@pytest.mark.parametrize("seed_rows", [64, 1000000])        # two-level bound / exact kernel over the whole sample
+def test_k_up_to_256_through_the_filter(vsa, oracle, metric, dtype, seed_rows):
+    """64 < k <= 256: four result slots per lane in the re-rank (one list per wave instead of per block) and in the
+    merge; sample and seed scale with k.  Same answer as the exact kernels and the oracle, bit for bit."""
+    rng = np.random.default_rng(256 + seed_rows % 7)
+    n, dim = 230_000, 64
+    centres = rng.standard_normal((40, dim)).astype(np.float32)
+    x = centres[rng.integers(0, 40, n)] + 0.4 * rng.standard_normal((n, dim)).astype(np.float32)
+    if metric == "COSINE":
+        x = _unit(x)
+    x[5000:5300] = x[4999]                     # a run of equal distances across the k-th place: ties go by label
+    f, e = _pair(vsa, dim, metric, x, dtype=dtype, VK_FILTER_SEED=seed_rows)
+    Q = centres[rng.integers(0, 40, 130)] + 0.4 * rng.standard_normal((130, dim)).astype(np.float32)
+    Q[3] = x[4999]
+    if metric == "COSINE":
+        Q = _unit(Q)
+    for nq, k in ((130, 65), (64, 100), (40, 200), (33, 256)):
+        got = f.search_batch(Q[:nq], k)
+        st = f.stats()
+        assert st.last_filter_candidates >= nq * k and st.last_filter_fallback == 0, (nq, k, st.last_filter_candidates)
+        _same(got, e.search_batch(Q[:nq], k))
+    if dtype == "f32":
+        o = oracle.Flat(dim, metric, max_elements=n)
+        o.add_many(x)
+        D, L, N = f.search_batch(Q[:36], 100)
+        for i in range(0, 36, 3):
+            od, ol = o.search(Q[i], 100)
+            assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()

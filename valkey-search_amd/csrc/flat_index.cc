@@ -846,7 +846,7 @@ class FlatIndex final : public Index {
     const uint32_t cap = (uint32_t)std::max<uint64_t>(filter_cap_, 64 * k);
     const int e = flat_scan_slots_per_lane(k);
     const uint32_t nrp = 8;
-    const uint64_t per_q = (uint64_t)nrp * k;
+    const uint64_t per_q = (uint64_t)nrp * (e == 1 ? 1 : 4) * k;   // e == 1: one list per block (merged in LDS), else per wave
     VK_TRY(ctx->d_stats.ensure(std::max<size_t>(64, nq * 8)));
     VK_TRY(ctx->d_fq16.ensure((size_t)nqt * 32 * dp * 2));
     VK_TRY(ctx->d_fthr.ensure((size_t)nqt * 32 * 4));

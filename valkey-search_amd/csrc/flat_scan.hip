@@ -593,16 +593,21 @@ static hipError_t launch_scan_l2(bool l2, int qb, const FlatScanArgs &a, dim3 gr
   return l2 ? launch_scan_qb<true, kE, kBf16>(qb, a, grid, lds, s) : launch_scan_qb<false, kE, kBf16>(qb, a, grid, lds, s);
 }
 
-// re-rank launch: one query per block column (kQB = 1), k <= 64 (kE = 1), rows from the survivor lists
-template <bool kL2, bool kBf16>
+// re-rank launch: one query per block column (kQB = 1), k <= 256 (kE = 1 or 4), rows from the survivor lists
+template <bool kL2, bool kBf16, int kE>
 static hipError_t launch_rerank_t(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<1, kL2, 1, kBf16, false, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<1, kL2, kE, kBf16, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((flat_scan_kernel<1, kL2, 1, kBf16, false, true>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((flat_scan_kernel<1, kL2, kE, kBf16, false, true>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
+}
+template <int kE>
+static hipError_t launch_rerank_e(const FlatScanArgs &a, bool l2, bool bf16, dim3 grid, size_t lds, hipStream_t s) {
+  return l2 ? (bf16 ? launch_rerank_t<true, true, kE>(a, grid, lds, s) : launch_rerank_t<true, false, kE>(a, grid, lds, s))
+            : (bf16 ? launch_rerank_t<false, true, kE>(a, grid, lds, s) : launch_rerank_t<false, false, kE>(a, grid, lds, s));
 }
 
 int flat_scan_slots_per_lane(uint64_t k) {
@@ -635,9 +640,8 @@ hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, i
   if (e == 1) lds = std::max<size_t>(lds, ((size_t)qb * 3 * a.k + 2) * 12);   // block-level merge buffers reuse it
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (a.cand_row) {  // re-rank of a survivor list
-    if (e != 1 || qb != 1) return hipErrorInvalidValue;
-    return l2 ? (bf16 ? launch_rerank_t<true, true>(a, grid, lds, s) : launch_rerank_t<true, false>(a, grid, lds, s))
-              : (bf16 ? launch_rerank_t<false, true>(a, grid, lds, s) : launch_rerank_t<false, false>(a, grid, lds, s));
+    if ((e != 1 && e != 4) || qb != 1) return hipErrorInvalidValue;
+    return e == 1 ? launch_rerank_e<1>(a, l2, bf16, grid, lds, s) : launch_rerank_e<4>(a, l2, bf16, grid, lds, s);
   }
   if (a.lb_dist) {   // paged large-k scan
     if (e != 16 || qb != 1) return hipErrorInvalidValue;
