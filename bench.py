@@ -917,7 +917,7 @@ def main():
                        "parity_vs_oracle": parity},
             # B >= 5 in the inner-product space runs on the f32 matrix cores (flat_gemm_kernel, K4):
             # algorithmic FLOPs per launch = 2 * rows * D * B against the 157.3 TFLOP/s f32 MFMA peak
-            # B > 32 in the inner-product space: f16 matrix-core candidate filter (flat_filter_kernel, one pass over the rows:
+            # B >= 5: f16 matrix-core candidate filter (flat_filter_kernel, one pass over the rows:
             # HBM-bound, algorithmic bytes = rows * row bytes) + exact re-rank of the survivors; 5 <= B <= 32: the exact f32
             # matrix-core kernel (MFMA-bound); else the scan (HBM-bound)
             "roofline": ({"bound": "hbm", "achieved": round(scan_bytes / (filt_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -80,8 +80,8 @@ def test_filter_path_equals_exact_path_and_oracle(vsa, oracle, dim):
     for i in range(40):
         od, ol = o.search(Q[i], 10)
         assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
-    # small batches stay on the exact kernels
-    f.search_batch(Q[:32], 10)
+    # batches of fewer than five queries stay on the scan kernel
+    f.search_batch(Q[:4], 10)
     assert f.stats().last_filter_candidates == 0
 
 

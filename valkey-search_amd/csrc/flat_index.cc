@@ -1010,7 +1010,7 @@ class FlatIndex final : public Index {
 
   // candidate filter (K4h): switches and sizes
   bool filter_enabled_ = !(getenv("VK_FLAT_FILTER") && atoi(getenv("VK_FLAT_FILTER")) == 0);
-  uint64_t filter_min_queries_ = getenv("VK_FILTER_MIN_QUERIES") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_QUERIES")) : 33;
+  uint64_t filter_min_queries_ = getenv("VK_FILTER_MIN_QUERIES") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_QUERIES")) : 5;
   uint64_t filter_min_rows_ = getenv("VK_FILTER_MIN_ROWS") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_ROWS")) : 262144;
   uint64_t filter_prepass_rows_ = getenv("VK_FILTER_PREPASS") ? (uint64_t)atoll(getenv("VK_FILTER_PREPASS")) : 262144;
   uint64_t filter_seed_rows_ = getenv("VK_FILTER_SEED") ? (uint64_t)atoll(getenv("VK_FILTER_SEED")) : 8192;
