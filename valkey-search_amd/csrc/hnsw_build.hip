@@ -14,8 +14,6 @@
 //
 // Both kernels: one wave per node, distances 16 rows at a time (one row per quad of lanes) against a
 // "query" row staged in LDS, the same lane-exact f32 arithmetic as everywhere else.
-#include <hipcub/hipcub.hpp>
-
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -242,29 +240,137 @@ hipError_t launch_hnsw_widen_rows(const void *rows, uint32_t stride_e, uint32_t 
   return hipGetLastError();
 }
 
+// ---- sort and scan of a batch's (target node, distance) pairs ---------------------------------------------------------
+// At most a few hundred thousand pairs per batch: a stable LSD radix sort, 8 bits per pass, one wave per chunk of the
+// input (histogram -> one-block exclusive scan of the chunk histograms, digit-major -> stable scatter in input order),
+// and a two-level exclusive scan of the head flags.
+namespace {
+constexpr uint32_t kSortChunks = 128;     // blocks (= waves) per pass
+constexpr uint32_t kScanBlock = 1024;     // flags per block of the scan
+
+__global__ __launch_bounds__(64) void radix_hist_kernel(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t *hist) {
+  __shared__ uint32_t h[256];
+  const uint32_t lane = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
+  for (uint32_t d = lane; d < 256; d += kWave) h[d] = 0;
+  __syncthreads();
+  const uint32_t chunk = (n + nb - 1) / nb, lo = b * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (uint32_t i = lo + lane; i < hi; i += kWave) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+  __syncthreads();
+  for (uint32_t d = lane; d < 256; d += kWave) hist[d * nb + b] = h[d];   // digit-major: a scan over it is the scatter order
+}
+// exclusive scan of `total` counters by one block (total = 256 digits x chunks, or the block sums of the flag scan)
+__global__ __launch_bounds__(256) void scan_one_block_kernel(uint32_t *v, uint32_t total) {
+  __shared__ uint32_t part[256];
+  const uint32_t t = threadIdx.x, per = (total + 255) / 256, lo = t * per, hi = lo + per < total ? lo + per : total;
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) sum += v[i];
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 256; ++i) { const uint32_t c = part[i]; part[i] = run; run += c; }
+  }
+  __syncthreads();
+  uint32_t run = part[t];
+  for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = v[i]; v[i] = run; run += c; }
+}
+__global__ __launch_bounds__(64) void radix_scatter_kernel(const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout,
+                                                           uint32_t n, uint32_t shift, const uint32_t *hist) {
+  __shared__ uint32_t off[256];
+  const uint32_t lane = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
+  for (uint32_t d = lane; d < 256; d += kWave) off[d] = hist[d * nb + b];
+  __syncthreads();
+  const uint32_t chunk = (n + nb - 1) / nb, lo = b * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (uint32_t base = lo; base < hi; base += kWave) {
+    const uint32_t i = base + lane;
+    const bool valid = i < hi;
+    const uint64_t key = valid ? kin[i] : 0;
+    const uint32_t val = valid ? vin[i] : 0;
+    const uint32_t d = (uint32_t)(key >> shift) & 255u;
+    // the lanes of this round with the same digit; a lane's place among them = its rank in input order (stability)
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const uint64_t m = __ballot(one);
+      peers &= one ? m : ~m;
+    }
+    const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), cnt = (uint32_t)__popcll(peers);
+    uint32_t dst = 0;
+    if (valid) dst = off[d] + rank;
+    __syncthreads();
+    if (valid) {
+      kout[dst] = key;
+      vout[dst] = val;
+      if (rank == cnt - 1) off[d] += cnt;      // one lane per digit moves the digit's cursor on
+    }
+    __syncthreads();
+  }
+}
+// flags -> exclusive positions: per block of 1024, then the block sums, then the offsets added back
+__global__ __launch_bounds__(256) void scan_blocks_kernel(const uint32_t *flags, uint32_t n, uint32_t *pos, uint32_t *sums) {
+  __shared__ uint32_t part[256];
+  const uint32_t t = threadIdx.x, lo = blockIdx.x * kScanBlock + t * 4;
+  uint32_t f[4], sum = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { f[u] = lo + u < n ? flags[lo + u] : 0; sum += f[u]; }
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 256; ++i) { const uint32_t c = part[i]; part[i] = run; run += c; }
+    sums[blockIdx.x] = run;
+  }
+  __syncthreads();
+  uint32_t run = part[t];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { if (lo + u < n) pos[lo + u] = run; run += f[u]; }
+}
+__global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *pos, uint32_t n, const uint32_t *sums) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[i] += sums[i / kScanBlock];
+}
+}  // namespace
+
+// scratch of launch_hnsw_group: the sort's second buffer (keys + values), the chunk histograms, the scan's block sums
 size_t hnsw_group_tmp_bytes(uint32_t n_pairs) {
-  size_t sort_b = 0, scan_b = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_b, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_pairs, 0, 64, nullptr);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_pairs,
-                                         nullptr);
-  return std::max(sort_b, scan_b) + 256;
+  const size_t n = n_pairs;
+  return ((n * 8 + 255) & ~(size_t)255) + ((n * 4 + 255) & ~(size_t)255) + (size_t)256 * kSortChunks * 4 +
+         (((n + kScanBlock - 1) / kScanBlock) * 4 + 255 & ~(size_t)255) + 256;
 }
 
 // sel_* -> CSR {node, off, add_p, add_d, counts}; everything on stream s, no host round trip
 hipError_t launch_hnsw_group(const HnswGroupArgs &g, hipStream_t s) {
   const uint32_t n = g.n_new * g.m;
   if (n == 0) return hipSuccess;
+  if (g.tmp_bytes < hnsw_group_tmp_bytes(n)) return hipErrorInvalidValue;
   const uint32_t blocks = (n + 255) / 256;
   hipLaunchKernelGGL(hnsw_pairs_kernel, dim3(blocks), dim3(256), 0, s, g.sel_id, g.sel_dist, g.sel_n, g.n_new, g.m,
                      g.first_id, g.keys_a, g.vals_a);
-  size_t tb = g.tmp_bytes;
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs(g.tmp, tb, g.keys_a, g.keys_b, g.vals_a, g.add_p, (int)n, 0, 64, s);
-  if (e != hipSuccess) return e;
+  // (keys_a, vals_a) -> (keys_b, add_p), ascending by (node, distance), equal keys in input order: eight passes that
+  // alternate between the input buffers and the scratch pair and end in the output pair
+  char *tp = static_cast<char *>(g.tmp);
+  uint64_t *keys_t = reinterpret_cast<uint64_t *>(tp);
+  tp += ((size_t)n * 8 + 255) & ~(size_t)255;
+  uint32_t *vals_t = reinterpret_cast<uint32_t *>(tp);
+  tp += ((size_t)n * 4 + 255) & ~(size_t)255;
+  uint32_t *hist = reinterpret_cast<uint32_t *>(tp);
+  tp += (size_t)256 * kSortChunks * 4;
+  uint32_t *sums = reinterpret_cast<uint32_t *>(tp);
+  for (uint32_t pass = 0; pass < 8; ++pass) {
+    const uint64_t *kin = (pass & 1) ? keys_t : g.keys_a;
+    const uint32_t *vin = (pass & 1) ? vals_t : g.vals_a;
+    uint64_t *kout = pass == 7 ? g.keys_b : (pass & 1) ? g.keys_a : keys_t;
+    uint32_t *vout = pass == 7 ? g.add_p : (pass & 1) ? g.vals_a : vals_t;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(kSortChunks), dim3(64), 0, s, kin, n, pass * 8, hist);
+    hipLaunchKernelGGL(scan_one_block_kernel, dim3(1), dim3(256), 0, s, hist, 256u * kSortChunks);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(kSortChunks), dim3(64), 0, s, kin, vin, kout, vout, n, pass * 8, hist);
+  }
   hipLaunchKernelGGL(hnsw_heads_kernel, dim3(blocks), dim3(256), 0, s, g.keys_b, n, g.flags);
-  tb = g.tmp_bytes;
-  e = hipcub::DeviceScan::ExclusiveSum(g.tmp, tb, g.flags, g.pos, (int)n, s);
-  if (e != hipSuccess) return e;
+  const uint32_t sblocks = (n + kScanBlock - 1) / kScanBlock;
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(sblocks), dim3(256), 0, s, g.flags, n, g.pos, sums);
+  hipLaunchKernelGGL(scan_one_block_kernel, dim3(1), dim3(256), 0, s, sums, sblocks);
+  hipLaunchKernelGGL(scan_add_kernel, dim3(blocks), dim3(256), 0, s, g.pos, n, sums);
   hipLaunchKernelGGL(hnsw_csr_kernel, dim3(blocks), dim3(256), 0, s, g.keys_b, g.flags, g.pos, n, g.node, g.off, g.add_d,
                      g.counts);
   return hipGetLastError();
