@@ -143,8 +143,8 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
     const float rel = (a.bf16 ? 0x1p-11f : 0x1p-10f) + 0x1p-22f + D * 0x1p-22f + (D / 16.f + 5.f) * 0x1p-24f;   // (bf16 rows convert exactly)
     const float eps = (R * qn * rel + 0x1.01p-25f * sqrtf(D) * (R + qn) + 0x1p-23f * fmaxf(1.f, 1.f + R * qn)) * 1.001f;
     bool f16_ok = !bad && mx <= 32768.f && amax <= 32768.f && (R - R == 0.f) && (eps - eps == 0.f);
-    // no bound yet (fewer than k allowed rows in the sample) or inputs that cannot go through f16: every row passes,
-    // the list overflows, and the exact kernel answers this batch
+    // no bound yet (fewer than k allowed rows in the sample: the filter leaves only a few rows of the whole index): the
+    // gate is open, every ALLOWED row becomes a survivor and the re-rank settles it
     if (!a.l2) {
       thr = (bound - bound == 0.f) ? ((1.f - bound) - eps) - 0x1p-22f * fmaxf(1.f, fabsf(1.f - bound)) : -__builtin_inff();
     } else {
@@ -362,6 +362,11 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   uint32_t st_c = 0, tile_c = 0, left_c = total;
   bool stop = false;
   if (tid < 2) lds_stop[tid] = 0;
+  // the hand-over to the exact kernel was already requested (inputs outside f16, an earlier launch of this batch
+  // overflowed): nothing this pass finds would be used.  One thread looks, so that all eight waves agree.
+  if (tid == 0) lds_stop[2] = __hip_atomic_load(a.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (lds_stop[2] != 0) return;
 
   // Leaving early (cancellation) must be decided identically by all eight waves or the next barrier never completes: the
   // polling thread publishes what it saw during tile T in lds_stop[T & 1] before the tile's last barrier, everybody reads
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_sample_kernel(FlatF
 
 size_t flat_filter_lds_bytes() {
   return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 +
-         (size_t)2 * kFTileRows * 4 + 16;
+         (size_t)2 * kFTileRows * 4 + 16;   // (+ the stop words)
 }
 
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2) {
