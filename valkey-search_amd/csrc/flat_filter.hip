@@ -268,7 +268,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 template <bool kBf16> struct WsRows { f32x4v v[16]; uint32_t hn; };    // row producer thread: 128 rows x 64 k / 128 threads
-template <> struct WsRows<true> { u32x2v v[16]; uint32_t hn; };
+template <> struct WsRows<true> { u32x4v v[8]; uint32_t hn; };         // bf16 rows: 8 elements per 16-byte load, half as many loads
 struct WsB { u32x4v v[16]; };                                          // query producer thread: 4 query tiles x 4 K-steps
 
 // idx = t + 128 u: row = idx / 16 = t / 16 + 8 u, 4-element column t % 16 of the row's stage slice.  The tile / stage /
@@ -289,33 +289,47 @@ __device__ __forceinline__ void ws_rows_load(WsRows<kBf16> &s, const FlatFilterA
   constexpr size_t esz = kBf16 ? 2 : 4;
   const __amdgpu_buffer_rsrc_t r =
       ws_rsrc(static_cast<const char *>(a.rows) + ((size_t)tile_row0 * a.row_stride_f + (size_t)st * kFStageK) * esz);
-  const uint32_t step = 8u * a.row_stride_f * (uint32_t)esz;
+  // (aux 2 = nt: the rows are read once -- they should not push the query block out of L2)
+  if constexpr (kBf16) {
+    // idx = t + 128 u: row = idx / 8 = t / 8 + 16 u, 8-element column t % 8 of the row's stage slice
+    const uint32_t step = 16u * a.row_stride_f * (uint32_t)esz;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    // (aux 2 = nt: the rows are read once -- they should not push the query block out of L2)
-    if constexpr (kBf16) s.v[u] = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)(u * step), 2);
-    else s.v[u] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(u * step), 2));
+    for (int u = 0; u < 8; ++u) s.v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(u * step), 2);
+  } else {
+    const uint32_t step = 8u * a.row_stride_f * (uint32_t)esz;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      s.v[u] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(u * step), 2));
   }
 }
+// -> f16 in LDS.  f32 rows: round to nearest even.  bf16 rows: bf16 -> f32 is a shift and f32 -> f16 is then EXACT for
+// every value in f16's normal range (8 significant bits fit 11), so a bf16 index carries no row rounding error at all.
 template <bool kBf16, bool kL2>
 __device__ __forceinline__ void ws_rows_store(_Float16 *buf, uint32_t *hn_buf, uint32_t t, const WsRows<kBf16> &s) {
   if constexpr (kL2) hn_buf[t] = s.hn;
-  _Float16 *dst = buf + (t >> 4) * kFAStride + (t & 15) * 4;
+  if constexpr (kBf16) {
+    _Float16 *dst = buf + (t >> 3) * kFAStride + (t & 7) * 8;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    f16x4 h;
-    if constexpr (kBf16) {
-      h[0] = (_Float16)__uint_as_float(s.v[u][0] << 16);
-      h[1] = (_Float16)__uint_as_float(s.v[u][0] & 0xFFFF0000u);
-      h[2] = (_Float16)__uint_as_float(s.v[u][1] << 16);
-      h[3] = (_Float16)__uint_as_float(s.v[u][1] & 0xFFFF0000u);
-    } else {
+    for (int u = 0; u < 8; ++u) {
+      f16x8 h;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        h[2 * w] = (_Float16)__uint_as_float(s.v[u][w] << 16);
+        h[2 * w + 1] = (_Float16)__uint_as_float(s.v[u][w] & 0xFFFF0000u);
+      }
+      *reinterpret_cast<f16x8 *>(dst + u * 16 * kFAStride) = h;
+    }
+  } else {
+    _Float16 *dst = buf + (t >> 4) * kFAStride + (t & 15) * 4;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      f16x4 h;
       h[0] = (_Float16)s.v[u][0];
       h[1] = (_Float16)s.v[u][1];
       h[2] = (_Float16)s.v[u][2];
       h[3] = (_Float16)s.v[u][3];
+      *reinterpret_cast<f16x4 *>(dst + u * 8 * kFAStride) = h;
     }
-    *reinterpret_cast<f16x4 *>(dst + u * 8 * kFAStride) = h;
   }
 }
 // query producer wave p: the B operands of query tiles 4p .. 4p+3 of stage st, 16 x (64 lanes x 16 B), from the
@@ -449,7 +463,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     // left (converted one iteration ago), convert stage S+1 (the 32 loads of S+2 and S+3 stay outstanding) into LDS
     // buffer (S+1) & 1, barrier.  Three stages of rows (96 KB per CU) are in flight.
     const uint32_t t = tid - 256;
-    const uint32_t voff = ((t >> 4) * a.row_stride_f + (t & 15) * 4) * (kBf16 ? 2u : 4u);
+    const uint32_t voff = kBf16 ? ((t >> 3) * a.row_stride_f + (t & 7) * 8) * 2u : ((t >> 4) * a.row_stride_f + (t & 15) * 4) * 4u;
     FPos ld{first_tile * kFTileRows, 0, total};
     WsRows<kBf16> x0, x1, x2;
     x0.hn = x1.hn = x2.hn = 0;
