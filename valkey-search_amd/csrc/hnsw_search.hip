@@ -516,6 +516,18 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         const uint32_t nid = u < nn ? nbr_id[u] : 0;
         // once the list is full the bound only shrinks: anything not below it now never will be
         uint64_t m = __ballot(u < nn && (top.cnt < a.ef || lowerBound > dv));
+        // tombstone and filter of every neighbour that may be considered, looked up by its own lane BEFORE the walk in
+        // list order: inside it they were two dependent loads (label, bitmap word) per neighbour, one neighbour at a time
+        // (hybrid shard, same lease: 31.2k -> 31.7k QPS)
+        uint64_t okm = ~0ull;
+        if (a.check_deleted || q_bits) {
+          bool okl = true;
+          if ((m >> lane) & 1ull) {
+            if (a.check_deleted && (a.links0[(size_t)nid * a.l0_stride] & kDeleteFlag)) okl = false;
+            if (okl && q_bits && !allow_bit(q_bits, q_nbits, a.labels[nid])) okl = false;
+          }
+          okm = __ballot(okl);
+        }
         while (m) {
           const int b = __ffsll((unsigned long long)m) - 1;
           m &= m - 1;
@@ -556,9 +568,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
             c.cnt += 1;
           }
           // results
-          bool ok = true;
-          if (a.check_deleted && (a.links0[(size_t)cid * a.l0_stride] & kDeleteFlag)) ok = false;
-          if (ok && q_bits && !allow_bit(q_bits, q_nbits, a.labels[cid])) ok = false;
+          const bool ok = (okm >> b) & 1ull;
           if (ok) top.insert(cd, cid, a.ef, lane);
           if (top.cnt) lowerBound = top.at_d(top.cnt - 1);
         }
