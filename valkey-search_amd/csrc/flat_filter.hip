@@ -242,9 +242,10 @@ __device__ __forceinline__ void fpos_advance(FPos &p, uint32_t stages) {
 }
 
 // ---- the filter, wave-specialised ---------------------------------------------------------------------------------------
-// Cycle counters in the kernel above say where its time goes: all eight waves multiply at the same time and then all
-// eight issue their loads at the same time (72 wave-loads through one address path) -- the matrix pipes and the address
-// path take turns, and the sum of the two is longer than the HBM time of the stage.  Here they belong to different waves:
+// Round 2's first version had eight identical waves (each its own query tile, B operands from L2 into registers, a
+// share of the row loads); its cycle counters said that all eight multiply at the same time and then all eight issue
+// their loads at the same time (72 wave-loads through one address path) -- the matrix pipes and the address path took
+// turns, and the sum of the two was longer than the HBM time of the stage.  Here they belong to different waves:
 //   waves 0-3  CONSUMERS, one per SIMD: wave w multiplies the 128 rows of the tile with query tiles 2w, 2w+1 (eight
 //              32 x 32 accumulator tiles, 32 MFMAs per stage back to back).  A AND B operands come from LDS; the wave
 //              issues no memory instruction at all
@@ -262,10 +263,9 @@ __device__ __forceinline__ void fpos_advance(FPos &p, uint32_t stages) {
 // more than the MFMAs of the stage.
 //
 // The producers' loads are ordinary loads and the compiler places the waits (it counts the loads issued after the
-// one whose data is needed -- exactly the vmcnt values above); what has to be kept away from it is LDS-DMA in the same
+// one whose data is needed); what has to be kept away from it is LDS-DMA in the same
 // wave (it then waits with vmcnt(0) everywhere) and __syncthreads() in the producers (below).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 template <bool kBf16> struct WsRows { f32x4v v[16]; uint32_t hn; };    // row producer thread: 128 rows x 64 k / 128 threads
 template <> struct WsRows<true> { u32x4v v[8]; uint32_t hn; };         // bf16 rows: 8 elements per 16-byte load, half as many loads
