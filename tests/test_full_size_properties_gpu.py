@@ -1,6 +1,7 @@
 """BASELINE.json configs[1] at FULL size (FLAT 10M x 768 f32 cosine, k=10), where the oracle cannot scan
 everything in test time: size-independent properties instead --
-  * the two independent device formulations agree bit for bit (single-query scan K3 vs batched MFMA K4),
+  * the two independent device formulations agree bit for bit (single-query scan K3 vs the batched path: f16
+    matrix-core candidate filter + exact re-rank, K4h),
   * answers are ascending by (distance, label), complete (k entries) and idempotent,
   * restricted by a filter to a sample of rows the answer equals the oracle's answer over that sample,
   * a row queried with itself comes back first at distance 0 (self-retrieval, vector_test.cc:237-291),
@@ -42,8 +43,10 @@ def world():
 
 def test_scan_and_mfma_kernels_agree_at_full_size(world):
     vsa, ix, table, Q = world
-    Db, Lb, Nb = ix.search_batch(Q, K)                 # >= 5 queries: K4 (matrix cores)
+    Db, Lb, Nb = ix.search_batch(Q, K)                 # >= 5 queries: K4h (f16 filter on the matrix cores + exact re-rank)
     assert (Nb == K).all()
+    st = ix.stats()
+    assert st.last_filter_candidates >= B * K and st.last_filter_fallback == 0
     for i in range(0, B, 8):                           # one query per call: K3 (scan)
         d, l = ix.search(Q[i], K)
         assert l.tolist() == Lb[i].tolist() and d.view(np.uint32).tolist() == Db[i].view(np.uint32).tolist()
@@ -64,7 +67,7 @@ def test_filtered_answer_equals_oracle_on_the_sample(world, oracle):
     o = oracle.Flat(D, "COSINE", max_elements=S)
     o.add_many(np.ascontiguousarray(host), rows)
     bits = oracle.allow_bitmap(rows, N)
-    Db, Lb, Nb = ix.search_batch(Q[:32], K, allow=bits, allow_nbits=N)      # K4 with a filter
+    Db, Lb, Nb = ix.search_batch(Q[:32], K, allow=bits, allow_nbits=N)      # K4h with a filter
     for i in range(32):
         od, ol = o.search(Q[i], K)
         assert Lb[i, :Nb[i]].tolist() == ol.tolist()
