@@ -58,6 +58,37 @@ def test_scan_and_mfma_kernels_agree_at_full_size(world):
     assert (L2 == Lb).all() and (D2.view(np.uint32) == Db.view(np.uint32)).all()
 
 
+def test_filter_path_equals_exact_matrix_core_kernel_at_full_size(world):
+    """K4h against K4 (exact f32 MFMA arithmetic for every row) over the same 10M rows: ids and distance bits, k = 10 and
+    k = 100, a batch that spans two launch groups."""
+    import os
+    import torch
+    vsa, ix, table, Q = world
+    from bench import device_view
+    old = os.environ.get("VK_FLAT_FILTER")
+    os.environ["VK_FLAT_FILTER"] = "0"
+    try:
+        ex = vsa.Index("FLAT", D, "COSINE", initial_cap=N, device_id=0)
+    finally:
+        if old is None:
+            os.environ.pop("VK_FLAT_FILTER")
+        else:
+            os.environ["VK_FLAT_FILTER"] = old
+    ptr, stride = ex.device_rows(N)
+    device_view(ptr, (N, stride // 4), table.device).copy_(table)
+    torch.cuda.synchronize()
+    ex.commit_device_rows(N, np.arange(N, dtype=np.uint64))
+    rng = np.random.default_rng(3)
+    Qm = np.concatenate([Q] * 5)[:300] + 0.01 * rng.standard_normal((300, D)).astype(np.float32)
+    Qm = (Qm / np.linalg.norm(Qm, axis=1, keepdims=True)).astype(np.float32)
+    for q, k in ((Qm, K), (Q[:40], 100)):
+        Df, Lf, Nf = ix.search_batch(q, k)
+        assert ix.stats().last_filter_candidates >= len(q) * k and ix.stats().last_filter_fallback == 0
+        De, Le, Ne = ex.search_batch(q, k)
+        assert ex.stats().last_filter_candidates == 0
+        assert (Nf == Ne).all() and (Lf == Le).all() and (Df.view(np.uint32) == De.view(np.uint32)).all()
+
+
 def test_filtered_answer_equals_oracle_on_the_sample(world, oracle):
     vsa, ix, table, Q = world
     S = 60_000
