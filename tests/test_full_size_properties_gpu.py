@@ -156,3 +156,30 @@ def test_hnsw_one_million_rows_properties(world):
         assert l.tolist() == Lh[i].tolist()
     Ds, Ls, _ = h.search_batch(host[:2000], 1, ef=128)
     assert (Ls[:, 0] == np.arange(2000)).mean() >= 0.99
+
+
+def test_hnsw_hash_visited_sets_equal_bitmaps_on_a_large_graph(world):
+    """2.2M rows: large enough for a full batch to take the hash visited sets by itself (table at most half the bitmap).
+    The same graph answers the same queries through both kernels -- one batch of 1536 (hash tables) against chunks of 256
+    (the small-batch kernel, bitmaps): ids, distance bits and the work counters must agree."""
+    vsa, ix, table, Q = world
+    Nh = 2_200_000
+    host = np.ascontiguousarray(table[:Nh, :D].cpu().numpy())
+    h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=100, ef_runtime=96, device_id=0)
+    h.add_batch(host)
+    rng = np.random.default_rng(8)
+    Qm = np.concatenate([Q] * 24)[:1536] + 0.02 * rng.standard_normal((1536, D)).astype(np.float32)
+    Qm = (Qm / np.linalg.norm(Qm, axis=1, keepdims=True)).astype(np.float32)
+    for ef in (96, 600):                                  # two and sixteen result slots per lane
+        Da, La, Na = h.search_batch(Qm, K, ef=ef)
+        sa = h.stats()
+        assert sa.last_frontier_dropped == 0
+        ne = nh = 0
+        for lo in range(0, 1536, 256):
+            Db, Lb, Nb = h.search_batch(Qm[lo:lo + 256], K, ef=ef)
+            sb = h.stats()
+            ne += sb.last_n_eval
+            nh += sb.last_n_hops
+            assert (Nb == Na[lo:lo + 256]).all() and (Lb == La[lo:lo + 256]).all()
+            assert (Db.view(np.uint32) == Da[lo:lo + 256].view(np.uint32)).all()
+        assert (sa.last_n_eval, sa.last_n_hops) == (ne, nh)
