@@ -569,7 +569,8 @@ def coalescer_leg(ix, hq, K, threads=64, per_thread=4):
     ix.set_coalescing(0, 0)
     dt0, ref = drive(threads)
     before = ix.stats()
-    ix.set_coalescing(threads, 300)
+    wait_us = int(os.environ.get("VK_BENCH_COALESCE_WAIT_US", "300"))
+    ix.set_coalescing(threads, wait_us)
     dt1, got = drive(threads)
     after = ix.stats()
     ix.set_coalescing(0, 0)
@@ -578,7 +579,7 @@ def coalescer_leg(ix, hq, K, threads=64, per_thread=4):
     nq = threads * per_thread
     batches = after.coalesced_batches - before.coalesced_batches
     return {"callers": threads, "queries": nq, "uncoalesced_qps": round(nq / dt0, 1), "coalesced_qps": round(nq / dt1, 1),
-            "device_batches": int(batches), "mean_batch": round(nq / max(1, batches), 1), "max_wait_us": 300,
+            "device_batches": int(batches), "mean_batch": round(nq / max(1, batches), 1), "max_wait_us": wait_us,
             "answers_identical": bool(same)}
 
 
