@@ -212,9 +212,11 @@ int vk_index_distance(vk_index *ix, uint64_t label, const void *query, float *ou
  * vk_index_search calls that agree on (k, ef_runtime) are merged into one device batch -- each with
  * its own filter bitmap or none (one filter per query inside the batch) and its own cancellation flag
  * (a caller whose flag is raised while it waits leaves at once; the batch itself runs to its end): the
- * first caller waits until max_batch calls are queued or max_wait_us elapsed, runs the batch and hands
- * each caller its own answer (identical to the answer it would have got alone).  max_batch <= 1 turns
- * it off (the default). */
+ * first caller waits until max_batch calls are queued, max_wait_us elapsed, or nobody has arrived for a
+ * quarter of max_wait_us (20-200 us: a lone caller is not held for the whole window, and the callers of a
+ * batch that just finished -- who come back within microseconds of each other -- are all taken along), runs
+ * the batch and hands each caller its own answer (identical to the answer it would have got alone).
+ * max_batch <= 1 turns it off (the default). */
 int vk_index_set_coalescing(vk_index *ix, uint32_t max_batch, uint32_t max_wait_us);
 int vk_index_get_row(vk_index *ix, uint64_t label, void *out_row);
 int vk_index_contains(vk_index *ix, uint64_t label, int *out_found);

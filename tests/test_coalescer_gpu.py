@@ -91,7 +91,7 @@ def test_hnsw_coalesced_lanes_by_k_and_ef(vsa):
     assert st.coalesced_queries == 2 * len(Q) and st.coalesced_batches < 2 * len(Q)
 
 
-def test_single_caller_is_not_stalled_beyond_the_wait(vsa):
+def test_single_caller_is_not_held_for_the_whole_window(vsa):
     import time
     rng = np.random.default_rng(13)
     X = rng.standard_normal((1000, 32)).astype(np.float32)
@@ -103,7 +103,7 @@ def test_single_caller_is_not_stalled_beyond_the_wait(vsa):
     d, l = ix.search_one(X[5], 3)
     dt = time.perf_counter() - t0
     assert l[0] == 5 and d[0] == 0.0
-    assert 0.015 < dt < 1.0
+    assert dt < 0.015          # arrivals stopped: gone after the quiet time (200 us here), not the whole window
 
 
 def test_64_callers_each_with_its_own_tag_filter(vsa, oracle):

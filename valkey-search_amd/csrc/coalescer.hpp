@@ -6,8 +6,8 @@
 // HBM-bound at any batch size up to ~dozens, the MFMA path wants >= 16 queries), so concurrent
 // single-query calls that are compatible (same k, same ef, no filter, no cancel flag) are merged
 // into one vk_index_search_batch: the first caller to arrive becomes the leader, waits until
-// `max_batch` requests are queued or `max_wait_us` elapsed, runs the batch, and hands every
-// follower its slice.  Latency/throughput knob, off by default (max_batch <= 1).
+// `max_batch` requests are queued, `max_wait_us` elapsed or arrivals have stopped, runs the batch,
+// and hands every follower its slice.  Latency/throughput knob, off by default (max_batch <= 1).
 #pragma once
 #include <string.h>
 
@@ -57,6 +57,7 @@ class Coalescer {
     const auto key = std::make_pair(k, ef);
     Lane &lane = lanes_[key];
     lane.q.push_back(me);
+    lane.last_arrival = std::chrono::steady_clock::now();
     // Every request waits on its own condition variable and is woken by name: the leader when its batch is full, the
     // members of a batch when their answers are in, the request at the head of the queue when the lane needs a new
     // leader.  (One shared variable and notify_all woke every waiting caller at every batch: with 1024 callers on 16
@@ -110,17 +111,25 @@ class Coalescer {
     std::deque<std::shared_ptr<Req>> q;
     bool leader_active = false;
     Req *leader = nullptr;      // valid while leader_active (the request lives on its caller's stack frame via `me`)
+    std::chrono::steady_clock::time_point last_arrival{};
   };
   void lead_one_batch(Index *ix, Lane &lane, uint64_t k, uint64_t ef, std::unique_lock<std::mutex> &lk,
                       const volatile int *leader_cancel, Req *self) {
     const uint32_t dim = ix->params().dim;
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(max_wait_us_);
+    const auto start = std::chrono::steady_clock::now();
+    const auto deadline = start + std::chrono::microseconds(max_wait_us_);
+    // The leader waits for company until the batch is full, max_wait_us has passed -- or nobody has arrived for a
+    // quarter of it (20-200 us): the callers of the batch that just finished come back within microseconds of each
+    // other, and once they are in, waiting out the rest of max_wait_us only idles the device.
     // (a leader whose own token is raised stops waiting for company and runs what is queued)
+    const auto quiet = std::chrono::microseconds(std::min<uint32_t>(200, std::max<uint32_t>(20, max_wait_us_ / 4)));
     while (lane.q.size() < batch_cap() && !(leader_cancel && *leader_cancel)) {
       const auto now = std::chrono::steady_clock::now();
       if (now >= deadline) break;
-      const auto slice = leader_cancel ? std::min<std::chrono::steady_clock::duration>(deadline - now, std::chrono::microseconds(100))
-                                       : deadline - now;
+      const auto since = now - std::max(lane.last_arrival, start);
+      if (since >= quiet) break;
+      auto slice = std::min<std::chrono::steady_clock::duration>(deadline - now, quiet - since);
+      if (leader_cancel) slice = std::min<std::chrono::steady_clock::duration>(slice, std::chrono::microseconds(100));
       self->cv.wait_for(lk, slice);
     }
     // (the limit is re-read: vk_index_set_coalescing(ix, 0, ..) while requests are queued must still drain them --
