@@ -2,7 +2,7 @@
 // back to back (what valkey-search's reader pool does, search.cc:886-910), against one FLAT index -- first with
 // coalescing off (one device pass per call), then on.  Prints queries/s and the mean device batch.
 //   g++ -O2 -std=c++17 -Iinclude scripts/coalescer_native.cc -Lvalkey-search_amd -lvkindex -lpthread \
-//       -Wl,-rpath,$PWD/valkey-search_amd -o /tmp/coalescer_native && /tmp/coalescer_native [rows] [dim] [threads] [calls]
+//       -Wl,-rpath,$PWD/valkey-search_amd -o /tmp/coalescer_native && /tmp/coalescer_native [rows] [dim] [threads] [calls] [hnsw]
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -37,9 +37,11 @@ static void unit_rows(float *x, size_t n, size_t dim, uint64_t seed) {
 int main(int argc, char **argv) {
   const size_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 2000000, dim = argc > 2 ? strtoull(argv[2], 0, 10) : 768, k = 10;
   const int threads = argc > 3 ? atoi(argv[3]) : 256, calls = argc > 4 ? atoi(argv[4]) : 100;
+  const bool hnsw = argc > 5 && !strcmp(argv[5], "hnsw");
   vk_index_params p{};
   p.struct_size = sizeof p; p.algo = VK_ALGO_FLAT; p.metric = VK_METRIC_COSINE; p.dim = (uint32_t)dim; p.initial_cap = n;
   p.block_size = 1024; p.device_id = 0;
+  if (hnsw) { p.algo = VK_ALGO_HNSW; p.m = 16; p.ef_construction = 100; p.ef_runtime = 64; }
   vk_index *ix = nullptr;
   if (vk_index_create(&p, &ix)) { printf("create: %s\n", vk_last_error()); return 1; }
   {
@@ -79,7 +81,7 @@ int main(int argc, char **argv) {
   vk_index_set_coalescing(ix, 0, 0);
   drive(8, 4);
   const double q0 = drive(threads < 32 ? threads : 32, 8);
-  printf("FLAT %zux%zu cosine k=%zu, single-query calls from native threads\n", n, dim, k);
+  printf("%s %zux%zu cosine k=%zu, single-query calls from native threads\n", hnsw ? "HNSW (M=16, ef=64)" : "FLAT", n, dim, k);
   printf("  coalescing off, %d callers: %.0f queries/s (one device pass per call)\n", threads < 32 ? threads : 32, q0);
   for (uint32_t wait_us : {100u, 300u, 1000u}) {
     vk_index_set_coalescing(ix, 256, wait_us);
