@@ -12,7 +12,7 @@ hx = x.cpu().numpy()
 h = vsa.Index("HNSW", D, "COSINE", initial_cap=N, m=16, ef_construction=200, ef_runtime=128)
 h.add_batch(hx); h.flush()
 Q = hx[:4096] + 0.01
-for nq in (1, 16, 64, 256, 512, 1024, 4096):
+for nq in (1, 16, 64, 256, 512, 1024, 2048, 4096):
     h.search_batch(Q[:nq], 10, ef=128)
     t0 = time.perf_counter(); reps = 10 if nq < 1024 else 3
     for _ in range(reps): h.search_batch(Q[:nq], 10, ef=128)
