@@ -731,7 +731,8 @@ int hnsw_waves_per_block(const HnswSearchArgs &a) {
   if (hnsw_list_in_lds(a)) return 1;
   // a batch too small to fill the device (the latency kernel): one query per block, so that 256 queries are on 256 CUs
   // and not four to a CU on 64 of them (1M x 768, ef = 128: 64 queries 1.42 -> 1.17 ms, 256 1.56 -> 1.32, 512 1.73 -> 1.56)
-  if (a.vis_hash_log2 == 0 && a.gpool_level == 0 && hnsw_latency_variant(a)) return 1;
+  // (the HBM-frontier kernels of a small filtered batch likewise)
+  if (a.vis_hash_log2 == 0 && hnsw_latency_variant(a)) return 1;
   const size_t pw = hnsw_lds_per_wave(a);
   return 4 * pw <= 160 * 1024 ? 4 : 2 * pw <= 160 * 1024 ? 2 : 1;
 }
