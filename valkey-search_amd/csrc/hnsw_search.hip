@@ -685,6 +685,12 @@ __global__ __launch_bounds__(256, 1) void hnsw_search_latency_kernel(HnswSearchA
   hnsw_search_body<kL2, kE, kBf16, 48, true>(a);
 }
 
+// ... and the same for a few FILTERED queries (HBM frontier)
+template <bool kL2, int kE, bool kBf16>
+__global__ __launch_bounds__(256, 1) void hnsw_search_gpool_latency_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, 48, true, 1>(a);
+}
+
 __global__ void scatter_u32_kernel(uint32_t *dst, const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t stride) {
   const uint64_t total = (uint64_t)n * stride;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -746,6 +752,9 @@ static const void *hnsw_fn(bool latency, int gpool, bool hash) {
     return gpool ? nullptr : reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE, kBf16>);
   } else {
     if (gpool == 2) return reinterpret_cast<const void *>(&hnsw_search_gpool2_kernel<kL2, kE, kBf16>);
+    if constexpr (kE >= 1 && kE <= 4) {
+      if (gpool && latency) return reinterpret_cast<const void *>(&hnsw_search_gpool_latency_kernel<kL2, kE, kBf16>);
+    }
     if (gpool) return reinterpret_cast<const void *>(&hnsw_search_gpool_kernel<kL2, kE, kBf16>);
     if constexpr (kE >= 1 && kE <= 4) {
       if (latency) return reinterpret_cast<const void *>(&hnsw_search_latency_kernel<kL2, kE, kBf16>);
