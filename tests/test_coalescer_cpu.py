@@ -63,3 +63,19 @@ def test_coalescing_switched_off_while_requests_are_queued(shim):
     its own), nobody spins forever"""
     bad, st = run(shim, threads=32, per_thread=20, max_batch=16, max_wait_us=2000, failing=2)
     assert bad == 0 and st["queries"] == 640 - sum(1 for i in range(640) if i % 17 == 5)
+
+
+def test_a_lone_caller_leaves_when_arrivals_have_stopped_and_many_callers_are_woken_by_name(shim):
+    """A caller alone in its lane is held for a quarter of the window at most (200 us), not for the window; and a
+    thousand waiting callers cost a batch no more than a handful do (each waits on its own condition variable)."""
+    import time
+    t0 = time.perf_counter()
+    bad, st = run(shim, threads=1, per_thread=40, max_batch=64, max_wait_us=50_000)     # 40 calls, 50 ms window each
+    dt = time.perf_counter() - t0
+    assert bad == 0 and st["max_batch"] == 1
+    assert dt < 0.5, dt                                   # 40 x 50 ms would be 2 s
+    t0 = time.perf_counter()
+    bad, st = run(shim, threads=1000, per_thread=4, max_batch=256, max_wait_us=500)
+    dt = time.perf_counter() - t0
+    assert bad == 0 and st["queries"] == 4000 - sum(1 for i in range(4000) if i % 17 == 5)
+    assert st["batches"] < 400 and dt < 20.0, (st, dt)
