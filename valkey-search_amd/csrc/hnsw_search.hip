@@ -18,8 +18,9 @@
 // What is organised differently (same answers, different machinery):
 //   * distances: 16 neighbours at a time, one per quad of lanes, bit-identical to the
 //     reference's SimSIMD order (device_common.hpp)
-//   * visited set: a per-wave bitmap in HBM (one bit per node, atomicOr = test-and-set),
-//     cleared by the wave at the start of each query, instead of a u16 tag array
+//   * visited set: one per resident wave in HBM instead of a u16 tag array -- a bitmap of the graph (atomicOr =
+//     test-and-set) or, for full batches on large graphs, an exact open-addressing hash set of the ids a search
+//     touches (atomicCAS); cleared by the wave at the start of each query
 //   * result list: sorted ascending in registers across the lanes (ef <= 64*kE); worst = last
 //   * frontier: unsorted pool in LDS with extract-min by a wave-wide scan; entries that can
 //     never be popped (farther than the bound once the result list is full -- the bound
