@@ -394,11 +394,20 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
           const float v = top_min[sidx];
           if (v < bd || bs == kNoneId) { bd = v; bs = sidx; }
         }
+        {   // (the distance alone first, like the LDS frontier below)
+          const float md = wave_min_f32(bd);
+          const uint64_t at_min = __ballot(bs != kNoneId && bd == md);
+          if (__popcll(at_min) == 1) {
+            bs = (uint32_t)__builtin_amdgcn_readlane((int)bs, __ffsll((unsigned long long)at_min) - 1);
+            bd = md;
+          } else {
 #pragma unroll
-        for (int m = 1; m < kWave; m <<= 1) {
-          const float od = __shfl_xor(bd, m);
-          const uint32_t os = __shfl_xor((int)bs, m);
-          if (os != kNoneId && (bs == kNoneId || od < bd || (od == bd && os < bs))) { bd = od; bs = os; }
+            for (int m = 1; m < kWave; m <<= 1) {
+              const float od = __shfl_xor(bd, m);
+              const uint32_t os = __shfl_xor((int)bs, m);
+              if (os != kNoneId && (bs == kNoneId || od < bd || (od == bd && os < bs))) { bd = od; bs = os; }
+            }
+          }
         }
         if constexpr (kGPool == 2) {   // one level down: the first segment of that group whose minimum it is
           const uint32_t si = bs * kWave + lane;
@@ -416,11 +425,20 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
           const float dv = c.ld_d(i);
           if (dv < bd || bi == kNoneId) { bd = dv; bi = i; }
         }
+        // the minimum distance alone first (a DPP reduction, not a ds_bpermute per step and value); only when several
+        // lanes hold it do the indices take part -- the smallest pool index among equal distances wins
+        const float md = wave_min_f32(bd);
+        const uint64_t at_min = __ballot(bi != kNoneId && bd == md);
+        if (__popcll(at_min) == 1) {
+          bi = (uint32_t)__builtin_amdgcn_readlane((int)bi, __ffsll((unsigned long long)at_min) - 1);
+          bd = md;
+        } else {
 #pragma unroll
-        for (int m = 1; m < kWave; m <<= 1) {
-          const float od = __shfl_xor(bd, m);
-          const uint32_t oi = __shfl_xor((int)bi, m);
-          if (oi != kNoneId && (bi == kNoneId || od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
+          for (int m = 1; m < kWave; m <<= 1) {
+            const float od = __shfl_xor(bd, m);
+            const uint32_t oi = __shfl_xor((int)bi, m);
+            if (oi != kNoneId && (bi == kNoneId || od < bd || (od == bd && oi < bi))) { bd = od; bi = oi; }
+          }
         }
       }
       const float cand_dist = bd;
@@ -470,6 +488,9 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
 
       // phase 1: unvisited neighbours, list order preserved
       const uint32_t *ll = a.links0 + (size_t)cur_id * a.l0_stride;
+      // (the first 64 ids are requested together with the count in front of them, not behind it: one trip to memory;
+      // slots past the count hold whatever the list held before -- never used)
+      const uint32_t nid_first = (uint32_t)lane + 1 < a.l0_stride ? ll[1 + lane] : 0u;
       const uint32_t size = ll[0] & 0xFFFFu;
       if constexpr (kHash) {   // the table must not fill up: this query goes to the launch with the bitmap
         if (q_vis + size > (3u << a.vis_hash_log2) / 4u) { abandoned = true; break; }
@@ -479,7 +500,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         const uint32_t i = base + lane;
         bool unv = false;
         uint32_t nid = 0;
-        if (i < size) { nid = ll[1 + i]; unv = visit(nid); }
+        if (i < size) { nid = base == 0 ? nid_first : ll[1 + i]; unv = visit(nid); }
         const uint64_t m = __ballot(unv);
         if (unv) nbr_id[nn + __popcll(m & ((1ull << lane) - 1ull))] = nid;
         nn += __popcll(m);
