@@ -1,5 +1,5 @@
 """Randomised sweep over the f16 candidate filter + exact re-rank (K4h): index size, dimension (padding, 1 to 25 pipeline
-stages per tile), batch size around the 32-query tiles and the 256-query launch groups, k up to 64, metric, row storage,
+stages per tile), batch size around the 32-query tiles and the 256-query launch groups, k up to 70, metric, row storage,
 row scales from 1e-3 to 1e2, duplicated rows (ties by label, survivor overflow), allow-bitmaps and deletions, one- and
 two-level bounds, drawn from a fixed seed.  The filter path must return exactly what the oracle returns -- ids and distance bits -- whatever it did on
 the way (vk_index_stats says whether it re-ranked its survivors or handed the batch to the exact kernel)."""
@@ -36,7 +36,7 @@ def test_random_shape_through_the_filter(vsa, oracle, seed):
     nq = int(rng.choice(BATCHES))
     metric = str(rng.choice(["L2", "IP", "COSINE"]))
     dtype = "bf16" if rng.random() < 0.3 else "f32"
-    k = int(rng.choice([1, 3, 10, 10, 10, 17, 32, 64]))
+    k = int(rng.choice([1, 3, 10, 10, 10, 17, 32, 64, 70]))
     scale = float(10.0 ** rng.uniform(-3, 2))
     nc = int(rng.integers(5, 60))
     centres = rng.standard_normal((nc, dim)).astype(np.float32)
