@@ -546,6 +546,25 @@ def lib_multi_gpu(args, world, rank, local_rank, dist, device):
     return out
 
 
+def native_coalescer_leg(rows=2_000_000, dim=768, threads=256, calls=50):
+    """The same experiment without the interpreter in the way: scripts/coalescer_native (C++ against include/vk_index.h,
+    built by __graft_entry__.build()) -- `threads` native threads of single-query vk_index_search calls on its own FLAT
+    index of `rows` x `dim` (the Python leg above is bound by 64 interpreter threads, not by the library)."""
+    import re
+    import subprocess
+    exe = ROOT / "scripts" / "coalescer_native"
+    if not exe.exists():
+        return None
+    txt = subprocess.run([str(exe), str(rows), str(dim), str(threads), str(calls)], capture_output=True, text=True, timeout=300).stdout
+    out = {"workload": f"FLAT {rows}x{dim} cosine k=10, {threads} native threads x {calls} single-query calls", "on": []}
+    m = re.search(r"coalescing off, (\d+) callers: (\d+) queries/s", txt)
+    if m:
+        out["off_qps"], out["off_callers"] = int(m.group(2)), int(m.group(1))
+    for m in re.finditer(r"max_wait (\d+) us\), \d+ callers x \d+ calls: (\d+) queries/s, (\d+) device batches, mean batch ([0-9.]+)", txt):
+        out["on"].append({"max_wait_us": int(m.group(1)), "qps": int(m.group(2)), "device_batches": int(m.group(3)), "mean_batch": float(m.group(4))})
+    return out
+
+
 def coalescer_leg(ix, hq, K, threads=64, per_thread=4):
     """N1: the reference issues one query per FT.SEARCH from a pool of reader threads (search.cc:886-910).
     `threads` callers each issue `per_thread` single-query vk_index_search calls, first one at a time per
@@ -898,6 +917,10 @@ def main():
             coalescer = coalescer_leg(ix, Q.cpu().numpy(), K)
         except Exception as e:   # noqa: BLE001
             coalescer = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            coalescer["native_callers"] = native_coalescer_leg()
+        except Exception as e:   # noqa: BLE001
+            coalescer["native_callers"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         dominant = "flat_filter_kernel" if filt_n else ("flat_gemm_kernel" if B >= 5 else "flat_scan_kernel")
