@@ -250,3 +250,32 @@ def test_k_up_to_256_through_the_filter(vsa, oracle, metric, dtype, seed_rows):
         for i in range(0, 36, 3):
             od, ol = o.search(Q[i], 100)
             assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "L2"])
+def test_k_up_to_1024_through_the_filter(vsa, oracle, metric):
+    """256 < k <= 1024: sixteen result slots per lane in the re-rank and the merge; for the inner-product space the exact
+    passes (the sample's bound, the overflow fall-back) are the scan kernel's, the matrix-core kernel stops at k = 256."""
+    rng = np.random.default_rng(1024)
+    n, dim = 900_000, 64
+    centres = rng.standard_normal((60, dim)).astype(np.float32)
+    x = centres[rng.integers(0, 60, n)] + 0.5 * rng.standard_normal((n, dim)).astype(np.float32)
+    if metric == "COSINE":
+        x = _unit(x)
+    x[70000:70900] = x[69999]                  # 900 copies: a run of equal distances longer than some of the k
+    f, e = _pair(vsa, dim, metric, x)
+    Q = centres[rng.integers(0, 60, 48)] + 0.5 * rng.standard_normal((48, dim)).astype(np.float32)
+    Q[2] = x[69999]
+    if metric == "COSINE":
+        Q = _unit(Q)
+    for nq, k in ((48, 300), (33, 1000), (40, 1024)):
+        got = f.search_batch(Q[:nq], k)
+        st = f.stats()
+        assert st.last_filter_candidates >= nq * k and st.last_filter_fallback == 0, (nq, k, st.last_filter_candidates)
+        _same(got, e.search_batch(Q[:nq], k))
+    o = oracle.Flat(dim, metric, max_elements=n)
+    o.add_many(x)
+    D, L, N = f.search_batch(Q[:33], 1000)
+    for i in (0, 2, 17):
+        od, ol = o.search(Q[i], 1000)
+        assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()

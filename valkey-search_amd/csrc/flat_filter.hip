@@ -637,7 +637,7 @@ size_t flat_filter_lds_bytes() {
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2) {
   (void)bf16;
   (void)l2;
-  return (row_stride_f % kFStageK) == 0 && k >= 1 && k <= 256;   // (the re-rank has 1 and 4 result slots per lane)
+  return (row_stride_f % kFStageK) == 0 && k >= 1 && k <= 1024;   // (the re-rank has 1, 4 and 16 result slots per lane)
 }
 
 hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {

@@ -597,7 +597,7 @@ class FlatIndex final : public Index {
     // K4h + exact re-rank: a batch large enough that the exact matrix-core kernel is the bottleneck, an index large
     // enough that the pre-pass sample is a small part of it
     if (!lb_dist_ && nq >= filter_min_queries_ && !(cancel && *cancel) && !force_scan_ && filter_enabled_ &&
-        flat_filter_supported(store_.stride_f(), k, store_.bf16(), l2()) && (l2() || flat_gemm_supported(store_.stride_f(), k)) &&
+        flat_filter_supported(store_.stride_f(), k, store_.bf16(), l2()) && (l2() || k > 10 || flat_gemm_supported(store_.stride_f(), k)) &&
         count >= 8 * filter_prepass_rows(k) && count >= filter_min_rows_) {
       const uint32_t *d_cancel = cancel_word;
       if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
@@ -1032,7 +1032,7 @@ class FlatIndex final : public Index {
     // 2. the filter over all rows + exact re-rank of the survivors ...
     VK_TRY(filter_pass(count, ovf, out_ld, true));
     // 3. ... or the exact kernel over everything (only when the flag is up: its blocks return at once otherwise)
-    if (l2()) VK_TRY(scan_k3(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld, ovf, 1));
+    if (l2() || !flat_gemm_supported(store_.stride_f(), k)) VK_TRY(scan_k3(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld, ovf, 1));
     else VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, bound, ovf, 1));
     filter_used_ = true;
     return Status::Ok();

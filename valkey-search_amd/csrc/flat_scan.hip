@@ -593,7 +593,7 @@ static hipError_t launch_scan_l2(bool l2, int qb, const FlatScanArgs &a, dim3 gr
   return l2 ? launch_scan_qb<true, kE, kBf16>(qb, a, grid, lds, s) : launch_scan_qb<false, kE, kBf16>(qb, a, grid, lds, s);
 }
 
-// re-rank launch: one query per block column (kQB = 1), k <= 256 (kE = 1 or 4), rows from the survivor lists
+// re-rank launch: one query per block column (kQB = 1), k <= 1024 (kE = 1, 4 or 16), rows from the survivor lists
 template <bool kL2, bool kBf16, int kE>
 static hipError_t launch_rerank_t(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
   if (lds > 48 * 1024) {
@@ -640,8 +640,9 @@ hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, i
   if (e == 1) lds = std::max<size_t>(lds, ((size_t)qb * 3 * a.k + 2) * 12);   // block-level merge buffers reuse it
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (a.cand_row) {  // re-rank of a survivor list
-    if ((e != 1 && e != 4) || qb != 1) return hipErrorInvalidValue;
-    return e == 1 ? launch_rerank_e<1>(a, l2, bf16, grid, lds, s) : launch_rerank_e<4>(a, l2, bf16, grid, lds, s);
+    if ((e != 1 && e != 4 && e != 16) || qb != 1) return hipErrorInvalidValue;
+    return e == 1 ? launch_rerank_e<1>(a, l2, bf16, grid, lds, s)
+                  : e == 4 ? launch_rerank_e<4>(a, l2, bf16, grid, lds, s) : launch_rerank_e<16>(a, l2, bf16, grid, lds, s);
   }
   if (a.lb_dist) {   // paged large-k scan
     if (e != 16 || qb != 1) return hipErrorInvalidValue;
