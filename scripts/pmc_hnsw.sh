@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counters of the HNSW search kernel only (--kernel-include-regex keeps the build's hundreds of launches out of the
-# counter collection; every group is its own pass).  Usage: pmc_hnsw.sh ROWS NQ
+# counter collection; every group is its own pass).  Usage: pmc_hnsw.sh ROWS NQ [EXTRA_COUNTER_GROUP] [KERNEL_REGEX]
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 ROWS=${1:-2000000}; NQ=${2:-8192}
 mkdir -p $ROOT/gpurun_out
@@ -9,7 +9,7 @@ i=0
 for CNT in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "$3"; do
   [ -z "$CNT" ] && continue
   i=$((i+1)); D=$ROOT/gpurun_out/pmc_hnsw_$i; rm -rf $D
-  timeout -s KILL 240 rocprofv3 --pmc $CNT --kernel-include-regex "hnsw_search_kernel" -d $D --output-format csv -- python $ROOT/scripts/hnsw_probe.py --rows $ROWS --nq $NQ > $D.log 2>&1
+  timeout -s KILL 240 rocprofv3 --pmc $CNT --kernel-include-regex "${4:-hnsw_search_kernel}" -d $D --output-format csv -- python $ROOT/scripts/hnsw_probe.py --rows $ROWS --nq $NQ > $D.log 2>&1
   echo "pass $i rc $?"; grep "ef=" $D.log
   python - $D <<'PY'
 import csv, glob, sys
