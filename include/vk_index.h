@@ -121,6 +121,10 @@ typedef struct vk_index_stats {
   /* query coalescer (vk_index_set_coalescing): device batches run / single queries they carried */
   uint64_t coalesced_batches;
   uint64_t coalesced_queries;
+  /* sharded index (n_shards >= 1), cumulative: searches fanned out to the shards and the HOST time their fan-out took
+   * (enqueue of every shard's work + gather + merge launch, one enqueue thread per shard; no device time) */
+  uint64_t fanout_calls;
+  uint64_t fanout_enqueue_ns;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------

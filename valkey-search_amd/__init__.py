@@ -46,7 +46,8 @@ class Stats(C.Structure):
                 ("last_n_hops", C.c_uint64), ("last_frontier_redo", C.c_uint64), ("last_frontier_dropped", C.c_uint64),
                 ("last_filter_candidates", C.c_uint64), ("last_filter_fallback", C.c_uint64),
                 ("filter_batches", C.c_uint64), ("filter_kernel_ns", C.c_uint64),
-                ("coalesced_batches", C.c_uint64), ("coalesced_queries", C.c_uint64)]
+                ("coalesced_batches", C.c_uint64), ("coalesced_queries", C.c_uint64),
+                ("fanout_calls", C.c_uint64), ("fanout_enqueue_ns", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)

@@ -64,7 +64,11 @@ class Coalescer {
     // CPUs a batch took 36 ms of wake-ups and lock hand-overs around 3 ms of device time.)
     if (lane.leader && lane.q.size() >= batch_cap()) lane.leader->cv.notify_one();  // batch full: wake the leader
     while (!me->done) {
-      if (cancel_flag && *cancel_flag) {   // leave; whoever runs the batch finds the request abandoned
+      // A raised token lets the caller leave only while its request is still QUEUED.  Once a leader has popped it into
+      // a batch (in_batch, set under this mutex) the leader reads the caller's query and allow-bitmap with the mutex
+      // released -- for tens of milliseconds on a filtered batch -- and the module frees both as soon as this call
+      // returns, so from then on the caller waits for `done` and only its answer is dropped.
+      if (cancel_raised(cancel_flag) && !me->in_batch) {
         me->abandoned = true;
         for (auto it = lane.q.begin(); it != lane.q.end(); ++it)
           if (it->get() == me.get()) { lane.q.erase(it); break; }
@@ -92,6 +96,12 @@ class Coalescer {
     // so the map does not grow by one entry per distinct pair ever seen
     auto it = lanes_.find(key);
     if (it != lanes_.end() && it->second.q.empty() && !it->second.leader_active) lanes_.erase(it);
+    if (me->st.ok() && cancel_raised(cancel_flag) && !partial_ok && ix->params().algo == VK_ALGO_HNSW) {
+      // cancelled while the batch it travelled in was on the device: the reference's answer for a raised token
+      // (vector_hnsw.cc:327-329), whatever the batch found
+      *out_n = 0;
+      return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
+    }
     return me->st;
   }
 
@@ -105,6 +115,7 @@ class Coalescer {
     uint64_t *on = nullptr;
     Status st;
     bool done = false, abandoned = false;
+    bool in_batch = false;   // popped by a leader: its input pointers are being read without the mutex
     std::condition_variable cv;
   };
   struct Lane {
@@ -123,7 +134,7 @@ class Coalescer {
     // other, and once they are in, waiting out the rest of max_wait_us only idles the device.
     // (a leader whose own token is raised stops waiting for company and runs what is queued)
     const auto quiet = std::chrono::microseconds(std::min<uint32_t>(200, std::max<uint32_t>(20, max_wait_us_ / 4)));
-    while (lane.q.size() < batch_cap() && !(leader_cancel && *leader_cancel)) {
+    while (lane.q.size() < batch_cap() && !cancel_raised(leader_cancel)) {
       const auto now = std::chrono::steady_clock::now();
       if (now >= deadline) break;
       const auto since = now - std::max(lane.last_arrival, start);
@@ -137,6 +148,7 @@ class Coalescer {
     const size_t cap = batch_cap();
     std::vector<std::shared_ptr<Req>> batch;
     while (!lane.q.empty() && batch.size() < cap) {
+      lane.q.front()->in_batch = true;
       batch.push_back(lane.q.front());
       lane.q.pop_front();
     }

@@ -94,7 +94,7 @@ Status SearchCtx::wait(const volatile int *caller_flag) {
     const hipError_t e = hipStreamQuery(stream);
     if (e == hipSuccess) return Status::Ok();
     if (e != hipErrorNotReady) return Status::Err(4, std::string("hipStreamQuery: ") + hipGetErrorString(e));
-    if (*caller_flag) *word = 1u;
+    if (cancel_raised(caller_flag)) *word = 1u;
     if (spins < 2000) __builtin_ia32_pause();
     else std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
@@ -596,7 +596,7 @@ class FlatIndex final : public Index {
     if (e == 0) return Status::Err(VK_ERR_INVALID, "k > 1024 needs the host entry points (vk_index_search / _batch), which page through the result in passes");
     // K4h + exact re-rank: a batch large enough that the exact matrix-core kernel is the bottleneck, an index large
     // enough that the pre-pass sample is a small part of it
-    if (!lb_dist_ && nq >= filter_min_queries_ && !(cancel && *cancel) && !force_scan_ && filter_enabled_ &&
+    if (!lb_dist_ && nq >= filter_min_queries_ && !cancel_raised(cancel) && !force_scan_ && filter_enabled_ &&
         flat_filter_supported(store_.stride_f(), k, store_.bf16(), l2()) && (l2() || k > 10 || flat_gemm_supported(store_.stride_f(), k)) &&
         count >= 8 * filter_prepass_rows(k) && count >= filter_min_rows_) {
       const uint32_t *d_cancel = cancel_word;
@@ -604,14 +604,14 @@ class FlatIndex final : public Index {
       return scan_filter(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel);
     }
     // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
-    if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !(cancel && *cancel) && flat_gemm_supported(store_.stride_f(), k) && !force_scan_) {
+    if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !cancel_raised(cancel) && flat_gemm_supported(store_.stride_f(), k) && !force_scan_) {
       const uint32_t *d_cancel = cancel_word;
       if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
       return scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel);
     }
     const uint32_t *d_cancel = cancel_word;
     uint64_t row_end = count;
-    if (cancel && *cancel) row_end = std::min<uint64_t>(count, k);          // (those rows are scanned whatever the flag says)
+    if (cancel_raised(cancel)) row_end = std::min<uint64_t>(count, k);          // (those rows are scanned whatever the flag says)
     else if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
     return scan_k3(ctx, d_q, nq, k, row_end, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld);
   }

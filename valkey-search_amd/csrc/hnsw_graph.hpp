@@ -147,7 +147,8 @@ class HnswGraph {
   uint32_t *links0_mut(uint32_t id) { return l0_.get() + (size_t)id * (maxM0_ + 1); }
   uint32_t *upper_mut(uint32_t id, int level) { return upper_[id] + (size_t)(level - 1) * (maxM_ + 1); }
   uint32_t *list_at(uint32_t id, int level) { return level == 0 ? links0_mut(id) : upper_mut(id, level); }
-  static unsigned list_count(const uint32_t *ll) { return *ll & 0xFFFFu; }
+  // (an atomic load: mark_delete sets the tombstone bit of the same word while searches read the count)
+  static unsigned list_count(const uint32_t *ll) { return __atomic_load_n(ll, __ATOMIC_RELAXED) & 0xFFFFu; }
   // word 0 of a level-0 list carries the neighbour count (low 16 bits, written under the node's link lock) AND the
   // tombstone bit (written by markDelete under the label lock only): both sides update it atomically, so neither a
   // count nor a tombstone can be lost when a remove overlaps an insert that re-links the node (hnswlib keeps them in

@@ -141,7 +141,7 @@ class HnswIndex final : public Index {
       for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
       return Status::Ok();
     }
-    if (rq.cancel_flag && *rq.cancel_flag && !rq.partial_ok)
+    if (cancel_raised(rq.cancel_flag) && !rq.partial_ok)
       return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
     CtxLease lease(pool_);
     SearchCtx *ctx = lease.ctx;
@@ -189,6 +189,9 @@ class HnswIndex final : public Index {
     }
     tab_ = d_tab;
     tab_nbits_ = d_tab_nbits;
+    // (launch() consumes and clears them; an early return before it must not leave this batch's table behind for the
+    // thread's next launch, e.g. a search_device or a device build)
+    struct TabReset { ~TabReset() { tab_ = nullptr; tab_nbits_ = nullptr; } } tab_reset;
     VK_TRY(ctx->h_out_d.ensure(rq.nq * rq.k * 4));
     VK_TRY(ctx->h_out_l.ensure(rq.nq * rq.k * 8));
     VK_TRY(ctx->h_out_n.ensure(rq.nq * 4 + 64));
@@ -219,7 +222,7 @@ class HnswIndex final : public Index {
       // (cannot happen: the LDS frontier holds at most 2*ef live entries, the graph-sized one every node)
       if (st[2]) return Status::Err(VK_ERR_INTERNAL, "HNSW search: frontier entries were dropped");
     }
-    if (rq.cancel_flag && *rq.cancel_flag && !rq.partial_ok)
+    if (cancel_raised(rq.cancel_flag) && !rq.partial_ok)
       return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
     for (uint64_t q = 0; q < rq.nq; ++q) {
       uint32_t n = ctx->h_out_n.as<uint32_t>()[q];
@@ -595,7 +598,11 @@ class HnswIndex final : public Index {
       VK_TRY(ctx->d_redo.ensure((nq + 1) * 4));
       b.pool_g = ctx->d_pool2.as<float>();
     }
-    VK_TRY(ctx->d_tmp.ensure(std::max(std::max(blocks * wpb, blocks2 * wpb2) * bm_bytes, blocks_h * wpb * (uint64_t)h.bitmap_words * 4)));
+    // visited-set scratch of the launches that actually run: hash tables (h) + the re-run's bitmaps (b) on the hash
+    // path -- the bitmap launch `a` is skipped there, and its blocks * wpb bitmaps are up to 4 GiB per context on
+    // exactly the large-graph, large-batch case the hash sets exist for -- else a (+ b)
+    const uint64_t vis_first = hash_log2 ? blocks_h * wpb * (uint64_t)h.bitmap_words * 4 : blocks * wpb * bm_bytes;
+    VK_TRY(ctx->d_tmp.ensure(std::max(vis_first, blocks2 * wpb2 * bm_bytes)));
     a.visited = ctx->d_tmp.as<uint32_t>();
     VK_TRY(ctx->d_stats.ensure(64));
     if (reset_stats) VK_HIP_TRY(hipMemsetAsync(ctx->d_stats.p, 0, 40, s));

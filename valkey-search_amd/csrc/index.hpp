@@ -100,6 +100,12 @@ struct CtxLease {
   ~CtxLease() { pool.release(ctx); }
 };
 
+// The caller's cancellation word (BaseCancellationFunctor, hnswlib.h:153-157; the reference's cancel::Token is an atomic
+// bool) is written by another thread while searches read it: a relaxed atomic load, not a plain read of a volatile int.
+inline bool cancel_raised(const volatile int *flag) {
+  return flag != nullptr && __atomic_load_n(const_cast<const int *>(flag), __ATOMIC_RELAXED) != 0;
+}
+
 struct SearchRequest {
   const float *queries = nullptr;   // host or device, [nq][dim] (host) / [nq][stride_f] padded (device)
   uint64_t nq = 0, k = 0, ef = 0;

@@ -18,7 +18,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <thread>
 
 #include "index.hpp"
@@ -65,6 +68,69 @@ struct MultiCtx {
   }
 };
 
+// One enqueue thread per shard.  The reference issues its per-shard requests concurrently (src/query/fanout.cc:69-160);
+// here a shard's search is a sequence of a dozen or two kernel launches, and enqueueing shard after shard from the
+// calling thread made the host the bottleneck of a fan-out: eight shards x ~20 launches of 4-6 us each before the last
+// device had anything to do, against well under a millisecond of device work per shard.  Each worker owns one shard's
+// lane (its device is the thread's current device once and for all) and runs the jobs handed to it in order; the caller
+// enqueues the serving device's shard itself and waits on a latch.
+class ShardWorkers {
+ public:
+  struct Latch {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t left = 0;
+    void done() {
+      std::lock_guard<std::mutex> g(mu);
+      if (--left == 0) cv.notify_one();
+    }
+    void wait() {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return left == 0; });
+    }
+  };
+  explicit ShardWorkers(size_t n) : w_(n) {
+    for (size_t i = 0; i < n; ++i) w_[i].th = std::thread([this, i] { run(i); });
+  }
+  ~ShardWorkers() {
+    for (Worker &w : w_) {
+      { std::lock_guard<std::mutex> g(w.mu); w.stop = true; }
+      w.cv.notify_one();
+    }
+    for (Worker &w : w_) w.th.join();
+  }
+  size_t size() const { return w_.size(); }
+  void post(size_t i, std::function<void()> job) {
+    Worker &w = w_[i];
+    { std::lock_guard<std::mutex> g(w.mu); w.jobs.push_back(std::move(job)); }
+    w.cv.notify_one();
+  }
+
+ private:
+  struct Worker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> jobs;
+    bool stop = false;
+    std::thread th;
+  };
+  void run(size_t i) {
+    Worker &w = w_[i];
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv.wait(lk, [&] { return w.stop || !w.jobs.empty(); });
+        if (w.jobs.empty()) return;
+        job = std::move(w.jobs.front());
+        w.jobs.pop_front();
+      }
+      job();
+    }
+  }
+  std::deque<Worker> w_;   // (deque: Worker is neither movable nor copyable)
+};
+
 }  // namespace
 
 class ShardedIndex final : public Index {
@@ -86,6 +152,8 @@ class ShardedIndex final : public Index {
       shards_.push_back(std::move(sub));
       shard_cap_.push_back(sp.initial_cap);
     }
+    static const bool threads_on = !(getenv("VK_SHARD_THREADS") && atoi(getenv("VK_SHARD_THREADS")) == 0);
+    if (S > 1 && threads_on) workers_ = std::make_unique<ShardWorkers>(S - 1);   // (shard 0 is enqueued by the caller)
     // peer access between the devices involved (a failure only means the copies are staged by the runtime)
     for (size_t a = 0; a < S; ++a)
       for (size_t b = 0; b < S; ++b)
@@ -123,6 +191,7 @@ class ShardedIndex final : public Index {
     // shard of every row: a known label stays where it is, new labels are dealt out in contiguous runs that even out
     // the shard sizes (an all-new bulk load of N rows: rows [s*N/S, (s+1)*N/S) to shard s)
     std::vector<uint32_t> shard_of(n);
+    std::vector<uint8_t> fresh_row(n, 0);   // rows whose label got its route in this call (rolled back if the shard fails)
     bool over_capacity = false;
     uint64_t n_used = n;
     {
@@ -157,7 +226,7 @@ class ShardedIndex final : public Index {
         if (quota == 0) { ++s; next_quota(); }
         // a label twice in one batch: the second occurrence follows the first
         auto ins = route_.emplace(labels[i], (uint32_t)s);
-        if (ins.second) { counts_[s]++; quota--; }
+        if (ins.second) { counts_[s]++; quota--; fresh_row[i] = 1; }
         shard_of[i] = ins.first->second;
       }
     }
@@ -189,6 +258,20 @@ class ShardedIndex final : public Index {
       });
     }
     for (auto &t : th) t.join();
+    // A shard that failed (out of memory, a resize that did not go through) may hold none, some or all of its rows: the
+    // fresh labels it does NOT hold lose their route again, so that contains / get_row / distance do not resolve to a
+    // shard without the row, the capacity accounting stays true and a retry does not meet its own leftovers.
+    for (size_t s = 0; s < S; ++s) {
+      if (res[s].ok()) continue;
+      std::unique_lock<std::shared_mutex> lk(rw_);
+      for (uint64_t i = 0; i < n_used; ++i) {
+        if (shard_of[i] != s || !fresh_row[i]) continue;
+        bool held = false;
+        if (shards_[s]->contains(labels[i], &held).ok() && held) continue;
+        auto it = route_.find(labels[i]);
+        if (it != route_.end() && it->second == s) { route_.erase(it); counts_[s]--; }
+      }
+    }
     for (const Status &st : res)
       if (!st.ok()) return st;
     if (over_capacity) return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
@@ -235,11 +318,18 @@ class ShardedIndex final : public Index {
       for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
       return Status::Ok();
     }
-    if (rq.cancel_flag && *rq.cancel_flag && !rq.partial_ok && params_.algo == VK_ALGO_HNSW)
+    if (cancel_raised(rq.cancel_flag) && !rq.partial_ok && params_.algo == VK_ALGO_HNSW)
       return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
     if (flat_scan_slots_per_lane(rq.k) == 0) return search_by_host_merge(rq, out_dist, out_label, out_n);
     MultiLease lease(*this);
     MultiCtx *mc = lease.mc;
+    // (whatever fails below, nothing of this call may still be in flight on the context's buffers when the lease ends)
+    Status st = search_on(mc, rq, out_dist, out_label, out_n);
+    if (!st.ok() && st.code != VK_ERR_CANCELLED) quiesce(mc, mc->s0);
+    return st;
+  }
+
+  Status search_on(MultiCtx *mc, const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) {
     (void)hipSetDevice(mc->dev0);
     const uint32_t dim = params_.dim;
     const size_t qbytes = (size_t)rq.nq * dim * 4, nk = (size_t)rq.nq * rq.k;
@@ -257,7 +347,7 @@ class ShardedIndex final : public Index {
     const uint32_t *d_cancel = nullptr;
     if (rq.cancel_flag) {
       VK_TRY(mc->h_cancel.ensure(64));
-      *mc->h_cancel.as<volatile uint32_t>() = *rq.cancel_flag ? 1u : 0u;
+      *mc->h_cancel.as<volatile uint32_t>() = cancel_raised(rq.cancel_flag) ? 1u : 0u;
       d_cancel = mc->h_cancel.as<uint32_t>();
     }
     VK_TRY(mc->d_fin_d.ensure(nk * 4));
@@ -284,11 +374,11 @@ class ShardedIndex final : public Index {
         const hipError_t e = hipStreamQuery(mc->s0);
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) return Status::Err(VK_ERR_INTERNAL, std::string("hipStreamQuery: ") + hipGetErrorString(e));
-        if (*rq.cancel_flag) *word = 1u;
+        if (cancel_raised(rq.cancel_flag)) *word = 1u;
         if (spins < 2000) __builtin_ia32_pause();
         else std::this_thread::sleep_for(std::chrono::microseconds(20));
       }
-      if (*rq.cancel_flag && !rq.partial_ok && params_.algo == VK_ALGO_HNSW)
+      if (cancel_raised(rq.cancel_flag) && !rq.partial_ok && params_.algo == VK_ALGO_HNSW)
         return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
     }
     for (uint64_t q = 0; q < rq.nq; ++q) {
@@ -372,6 +462,8 @@ class ShardedIndex final : public Index {
       out->max_level = std::max(out->max_level, t.max_level);
       if (s == 0) out->entry_point = t.entry_point;
     }
+    out->fanout_calls = fanout_calls_.load(std::memory_order_relaxed);
+    out->fanout_enqueue_ns = fanout_ns_.load(std::memory_order_relaxed);
     std::shared_lock<std::shared_mutex> lk(rw_);
     out->capacity = capacity_;
     out->host_bytes += route_.size() * 24;
@@ -398,13 +490,22 @@ class ShardedIndex final : public Index {
       uint64_t total = 0;
       for (uint64_t c : counts_) total += c;
       if (total + n > capacity_) return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
-      for (uint64_t i = 0; i < n; ++i)
-        if (route_.count(labels[i])) return Status::Err(VK_ERR_INVALID, "duplicate label in bulk load");
+      // (emplace, not count-then-insert: a label twice inside `labels` is a duplicate too, and counts_ must not count it)
       route_.reserve(route_.size() + n);
-      for (uint64_t i = 0; i < n; ++i) route_.emplace(labels[i], s);
+      for (uint64_t i = 0; i < n; ++i)
+        if (!route_.emplace(labels[i], s).second) {
+          for (uint64_t j = 0; j < i; ++j) route_.erase(labels[j]);
+          return Status::Err(VK_ERR_INVALID, "duplicate label in bulk load");
+        }
       counts_[s] += n;
     }
-    return shards_[s]->commit_device_rows(n, labels);
+    Status st = shards_[s]->commit_device_rows(n, labels);
+    if (!st.ok()) {   // the shard holds none of them (commit_device_rows is all-or-nothing): take the routes back
+      std::unique_lock<std::shared_mutex> lk(rw_);
+      for (uint64_t i = 0; i < n; ++i) route_.erase(labels[i]);
+      counts_[s] -= n;
+    }
+    return st;
   }
 
   Status save(vk_write_chunk_fn fn, void *user) override;
@@ -510,68 +611,122 @@ class ShardedIndex final : public Index {
     ~MultiLease() { ix.release(mc); }
   };
 
+  // One shard's part of a fan-out, enqueued on the shard's lane stream (any thread): wait for the queries, broadcast by
+  // peer copy unless the shard lives on the serving device, search, send the lists to their slice of the gathered array.
+  Status enqueue_shard(MultiCtx *mc, size_t s, const SearchRequest &rq) {
+    const uint32_t dim = params_.dim;
+    const size_t qbytes = (size_t)rq.nq * dim * 4, nk = (size_t)rq.nq * rq.k;
+    const size_t abytes = rq.allow_bits ? (size_t)((rq.allow_nbits + 63) / 64) * 8 : 0;
+    ShardLane &l = mc->lane[s];
+    VK_HIP_TRY(hipSetDevice(l.device));
+    VK_HIP_TRY(hipStreamWaitEvent(l.stream, mc->ready, 0));
+    SearchRequest srq = rq;
+    srq.cancel_flag = nullptr;
+    float *od = mc->d_all_d.as<float>() + s * nk;
+    uint64_t *ol = mc->d_all_l.as<uint64_t>() + s * nk;
+    uint32_t *on = mc->d_all_n.as<uint32_t>() + s * rq.nq;
+    const bool local = l.device == mc->dev0;
+    if (!local) {   // broadcast by peer copy, answer into the shard's own buffers
+      VK_TRY(l.d_q.ensure(qbytes));
+      VK_HIP_TRY(hipMemcpyPeerAsync(l.d_q.p, l.device, rq.queries, mc->dev0, qbytes, l.stream));
+      srq.queries = l.d_q.as<float>();
+      if (rq.allow_bits) {
+        VK_TRY(l.d_allow.ensure(std::max<size_t>(abytes, 8)));
+        if (abytes) VK_HIP_TRY(hipMemcpyPeerAsync(l.d_allow.p, l.device, rq.allow_bits, mc->dev0, abytes, l.stream));
+        srq.allow_bits = l.d_allow.as<uint64_t>();
+      }
+      VK_TRY(l.d_out_d.ensure(nk * 4));
+      VK_TRY(l.d_out_l.ensure(nk * 8));
+      VK_TRY(l.d_out_n.ensure(rq.nq * 4));
+      od = l.d_out_d.as<float>();
+      ol = l.d_out_l.as<uint64_t>();
+      on = l.d_out_n.as<uint32_t>();
+    }
+    VK_TRY(shards_[s]->search_device(srq, od, ol, on, l.stream));
+    VK_HIP_TRY(hipSetDevice(l.device));
+    if (!local) {   // the shard's lists -> their slice of the gathered array on the serving device
+      VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_d.as<float>() + s * nk, mc->dev0, od, l.device, nk * 4, l.stream));
+      VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_l.as<uint64_t>() + s * nk, mc->dev0, ol, l.device, nk * 8, l.stream));
+    }
+    VK_HIP_TRY(hipEventRecord(l.done, l.stream));
+    return Status::Ok();
+  }
+
+  // A fan-out that failed part-way leaves kernels and peer copies of the shards that WERE launched in flight on the
+  // context's buffers: they are waited for before the context goes back to the pool (its next user would otherwise
+  // reuse -- or DevBuf::ensure free -- memory they still write).
+  void quiesce(MultiCtx *mc, hipStream_t s0) {
+    for (ShardLane &l : mc->lane) {
+      (void)hipSetDevice(l.device);
+      (void)hipStreamSynchronize(l.stream);
+    }
+    (void)hipSetDevice(mc->dev0);
+    (void)hipStreamSynchronize(s0);
+  }
+
   // the fan-out itself: rq holds DEVICE pointers on the serving device, valid on stream s0; the merged answer is written
   // to d_out_* (serving device) by work enqueued on s0
   Status fan_out(MultiCtx *mc, const SearchRequest &rq, float *d_out_dist, uint64_t *d_out_label, uint32_t *d_out_n,
                  hipStream_t s0) {
+    const auto t0 = std::chrono::steady_clock::now();
     const size_t S = shards_.size();
-    const uint32_t dim = params_.dim;
-    const size_t qbytes = (size_t)rq.nq * dim * 4, nk = (size_t)rq.nq * rq.k;
-    const size_t abytes = rq.allow_bits ? (size_t)((rq.allow_nbits + 63) / 64) * 8 : 0;
+    const size_t nk = (size_t)rq.nq * rq.k;
     (void)hipSetDevice(mc->dev0);
     VK_TRY(mc->d_all_d.ensure(S * nk * 4));
     VK_TRY(mc->d_all_l.ensure(S * nk * 8));
     VK_TRY(mc->d_all_n.ensure(S * rq.nq * 4));
     VK_HIP_TRY(hipEventRecord(mc->ready, s0));   // queries (and filter) are in place on the serving device
-    for (size_t s = 0; s < S; ++s) {
-      ShardLane &l = mc->lane[s];
-      (void)hipSetDevice(l.device);
-      VK_HIP_TRY(hipStreamWaitEvent(l.stream, mc->ready, 0));
-      SearchRequest srq = rq;
-      srq.cancel_flag = nullptr;
-      float *od = mc->d_all_d.as<float>() + s * nk;
-      uint64_t *ol = mc->d_all_l.as<uint64_t>() + s * nk;
-      uint32_t *on = mc->d_all_n.as<uint32_t>() + s * rq.nq;
-      const bool local = l.device == mc->dev0;
-      if (!local) {   // broadcast by peer copy, answer into the shard's own buffers
-        VK_TRY(l.d_q.ensure(qbytes));
-        VK_HIP_TRY(hipMemcpyPeerAsync(l.d_q.p, l.device, rq.queries, mc->dev0, qbytes, l.stream));
-        srq.queries = l.d_q.as<float>();
-        if (rq.allow_bits) {
-          VK_TRY(l.d_allow.ensure(std::max<size_t>(abytes, 8)));
-          if (abytes) VK_HIP_TRY(hipMemcpyPeerAsync(l.d_allow.p, l.device, rq.allow_bits, mc->dev0, abytes, l.stream));
-          srq.allow_bits = l.d_allow.as<uint64_t>();
-        }
-        VK_TRY(l.d_out_d.ensure(nk * 4));
-        VK_TRY(l.d_out_l.ensure(nk * 8));
-        VK_TRY(l.d_out_n.ensure(rq.nq * 4));
-        od = l.d_out_d.as<float>();
-        ol = l.d_out_l.as<uint64_t>();
-        on = l.d_out_n.as<uint32_t>();
+    std::vector<Status> res(S);
+    if (workers_) {
+      ShardWorkers::Latch latch;
+      latch.left = (uint32_t)(S - 1);
+      for (size_t s = 1; s < S; ++s)
+        workers_->post(s - 1, [this, mc, s, &rq, &res, &latch] {
+          try {
+            res[s] = enqueue_shard(mc, s, rq);
+          } catch (const std::exception &e) {
+            res[s] = Status::Err(VK_ERR_INTERNAL, e.what());
+          }
+          latch.done();
+        });
+      res[0] = enqueue_shard(mc, 0, rq);
+      latch.wait();
+    } else {
+      for (size_t s = 0; s < S; ++s) {
+        res[s] = enqueue_shard(mc, s, rq);
+        if (!res[s].ok()) break;
       }
-      VK_TRY(shards_[s]->search_device(srq, od, ol, on, l.stream));
-      (void)hipSetDevice(l.device);
-      if (!local) {   // the shard's lists -> their slice of the gathered array on the serving device
-        VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_d.as<float>() + s * nk, mc->dev0, od, l.device, nk * 4, l.stream));
-        VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_l.as<uint64_t>() + s * nk, mc->dev0, ol, l.device, nk * 8, l.stream));
-      }
-      VK_HIP_TRY(hipEventRecord(l.done, l.stream));
     }
+    for (const Status &st : res)
+      if (!st.ok()) {
+        quiesce(mc, s0);
+        return st;
+      }
     (void)hipSetDevice(mc->dev0);
-    for (size_t s = 0; s < S; ++s) VK_HIP_TRY(hipStreamWaitEvent(s0, mc->lane[s].done, 0));
-    MergeArgs m{};
-    m.in_dist = mc->d_all_d.as<float>();
-    m.in_label = mc->d_all_l.as<uint64_t>();
-    m.part_stride = nk;
-    m.q_stride = rq.k;
-    m.parts = (uint32_t)S;
-    m.per_part = (uint32_t)rq.k;
-    m.k = (uint32_t)rq.k;
-    m.out_ld = (uint32_t)rq.k;
-    m.out_dist = d_out_dist;
-    m.out_label = d_out_label;
-    m.out_n = d_out_n;
-    VK_HIP_TRY(launch_merge_topk(m, flat_scan_slots_per_lane(rq.k), rq.nq, s0));
+    Status st = [&]() -> Status {
+      for (size_t s = 0; s < S; ++s) VK_HIP_TRY(hipStreamWaitEvent(s0, mc->lane[s].done, 0));
+      MergeArgs m{};
+      m.in_dist = mc->d_all_d.as<float>();
+      m.in_label = mc->d_all_l.as<uint64_t>();
+      m.part_stride = nk;
+      m.q_stride = rq.k;
+      m.parts = (uint32_t)S;
+      m.per_part = (uint32_t)rq.k;
+      m.k = (uint32_t)rq.k;
+      m.out_ld = (uint32_t)rq.k;
+      m.out_dist = d_out_dist;
+      m.out_label = d_out_label;
+      m.out_n = d_out_n;
+      VK_HIP_TRY(launch_merge_topk(m, flat_scan_slots_per_lane(rq.k), rq.nq, s0));
+      return Status::Ok();
+    }();
+    if (!st.ok()) {
+      quiesce(mc, s0);
+      return st;
+    }
+    fanout_calls_.fetch_add(1, std::memory_order_relaxed);
+    fanout_ns_.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+                         std::memory_order_relaxed);
     return Status::Ok();
   }
 
@@ -598,6 +753,8 @@ class ShardedIndex final : public Index {
   }
 
   std::vector<int> devices_;
+  std::unique_ptr<ShardWorkers> workers_;
+  std::atomic<uint64_t> fanout_calls_{0}, fanout_ns_{0};   // host time of fan_out (enqueue only), for vk_index_stats
   std::vector<std::unique_ptr<Index>> shards_;
   std::vector<uint64_t> shard_cap_;
   std::shared_mutex rw_;                              // route_, counts_, capacity_

@@ -167,7 +167,11 @@ int vk_index_search_batch_filters(vk_index *ix, const void *queries, uint64_t nq
 int vk_index_search(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, const uint64_t *allow_bits,
                     uint64_t allow_nbits, const volatile int *cancel_flag, int partial_ok, float *out_dist,
                     uint64_t *out_label, uint64_t *out_n) {
-  if (ix && ix->impl && ix->coalescer.enabled() && k && !(cancel_flag && *cancel_flag)) {
+  // A FLAT index serves one scan per distinct allow-bitmap (FlatIndex::search_grouped_by_filter): N filtered callers in
+  // one batch would each wait for N serial scans run by the leader, where N separate calls run concurrently on the
+  // index's search contexts.  Coalescing of filtered calls is therefore HNSW-only (one launch, a bitmap per query).
+  const bool flat_filtered = ix && ix->impl && allow_bits && ix->impl->params().algo == VK_ALGO_FLAT;
+  if (ix && ix->impl && ix->coalescer.enabled() && k && !flat_filtered && !vk::cancel_raised(cancel_flag)) {
     if (!query || !out_n || !out_dist || !out_label) return fail(VK_ERR_INVALID, "NULL argument");
     return guarded([&] {
       return ix->coalescer.search(ix->impl.get(), static_cast<const float *>(query), k, ef_runtime, allow_bits, allow_nbits,
