@@ -3,6 +3,7 @@
 // the hole), label-only updates, bulk writes, growth -- each published by flush() and compared with a plain model.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
