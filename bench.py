@@ -817,6 +817,13 @@ def main():
         single = {"ms_per_query": round(ms1, 4), "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
                   "bytes": n_local * stride}
 
+    # survivors of the candidate filter per query, and queries handed to the exact pass (one host-path call: the
+    # device-buffer entry point reports no statistics)
+    filt_stats = None
+    if filt_n and world == 1:
+        ix.search_batch(Q.cpu().numpy(), K)
+        st_f = ix.stats()
+        filt_stats = {"survivors_per_query": round(st_f.last_filter_candidates / B, 1), "queries_handed_over": int(st_f.last_filter_fallback)}
     result_d = (fin_d if world > 1 else out_d).cpu().numpy()
     result_l = (fin_l if world > 1 else out_l).cpu().numpy().view(np.uint64)
 
@@ -951,6 +958,7 @@ def main():
                           "kernel": "flat_filter_kernel", "per_launch_ms": round(filt_ms, 4), "launches_timed": int(filt_n),
                           "step_ms_on_stream": round(dev_ms, 4),
                           "hbm_frac_of_whole_step": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                          "filter": filt_stats,
                           "f16_mfma_tflops": round(flops / (filt_ms * 1e-3) / 1e12, 1),
                           "f16_mfma_frac_of_2500": round(flops / (filt_ms * 1e-3) / 1e12 / 2500.0, 4)}
                          if filt_n else

@@ -2,8 +2,9 @@
 
 The filter only decides WHICH rows get an exact distance; the distances and the selection are the exact path's.  So the
 answer must be bit-identical (ids and distance bits, ties by label) to the exact matrix-core kernel and to the oracle,
-for every shape the pipeline branches on -- and when the filter cannot bound its error or its survivor lists overflow,
-the exact kernel enqueued behind it must take over (decided on the device).  vk_index_stats says which happened."""
+for every shape the pipeline branches on -- and a query the filter cannot serve (more survivors than lists and spill
+pool hold, a query outside the f16 range) must be handed, alone, to the exact pass enqueued behind it (decided on the
+device).  vk_index_stats says how many survivors there were and how many queries were handed over."""
 import os
 
 import numpy as np
@@ -112,9 +113,11 @@ def test_filter_with_allow_bitmap_and_unnormalised_ip(vsa, oracle):
     assert (N == 0).all()
 
 
-def test_survivor_overflow_falls_back_to_the_exact_kernel(vsa, oracle):
-    """40 000 copies of one vector: every copy is within the filter's margin of the k-th best, far more than a survivor
-    list holds.  The answer (ties broken by label) must still be the exact one."""
+def test_a_query_on_40000_duplicates_keeps_its_survivors_in_spill_chunks(vsa, oracle):
+    """40 000 copies of one vector: every copy is within the filter's margin of the k-th best, five times what a private
+    survivor list holds.  The lists continue in spill chunks, nothing is handed over, and the answer (ties broken by
+    label) is the exact one.  With the spill pool taken away the affected queries -- and only they -- go to the exact
+    redo pass (r02: the whole batch went to the 7x slower exact kernel)."""
     rng = np.random.default_rng(5)
     n, dim = 70_000, 64
     x = _unit(rng.standard_normal((n, dim)).astype(np.float32))
@@ -124,31 +127,158 @@ def test_survivor_overflow_falls_back_to_the_exact_kernel(vsa, oracle):
     Q = np.vstack([x[7:8] + 0.01 * rng.standard_normal((40, dim)).astype(np.float32), rng.standard_normal((60, dim)).astype(np.float32)])
     Q = _unit(Q)
     got = f.search_batch(Q, 10)
-    assert f.stats().last_filter_fallback == 1
+    st = f.stats()
+    assert st.last_filter_fallback == 0 and st.last_filter_candidates >= 40 * 40_000
     _same(got, e.search_batch(Q, 10))
-    # only queries far from the duplicated vector: no overflow, same index
+    o = oracle.Flat(dim, "COSINE", max_elements=n)
+    o.add_many(x, labels)
+    for i in (0, 5, 39, 40, 99):
+        od, ol = o.search(Q[i], 10)
+        assert got[1][i].tolist() == ol.tolist() and got[0][i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+    # no spill pool: the 40 queries near the duplicated vector are handed over, the other 60 are not
+    f0, _ = _pair(vsa, dim, "COSINE", x, labels, VK_FILTER_SPILL_CHUNKS=0)
+    got0 = f0.search_batch(Q, 10)
+    assert f0.stats().last_filter_fallback == 40
+    _same(got0, got)
+    # a pool of three chunks: the first queries to overflow take them, the rest are handed over -- same answer
+    f3, _ = _pair(vsa, dim, "COSINE", x, labels, VK_FILTER_SPILL_CHUNKS=3)
+    got3 = f3.search_batch(Q, 10)
+    assert 37 <= f3.stats().last_filter_fallback <= 40
+    _same(got3, got)
+    # up to eight handed-over queries are re-scanned on their own, more take the whole batch through the exact kernel:
+    # both sides of that switch
+    for nbad in (1, 8, 9):
+        sub = np.vstack([Q[:nbad], Q[40:]])
+        g = f0.search_batch(sub, 10)
+        assert f0.stats().last_filter_fallback == nbad
+        _same(g, e.search_batch(sub, 10))
+    # only queries far from the duplicated vector: nothing to spill
     got = f.search_batch(Q[40:], 10)
     assert f.stats().last_filter_fallback == 0 and f.stats().last_filter_candidates > 0
     _same(got, e.search_batch(Q[40:], 10))
 
 
-def test_inputs_outside_the_f16_range_fall_back(vsa, oracle):
+def test_inputs_outside_the_f16_range(vsa, oracle):
+    """A row the f16 pipe cannot carry opens the gate of ITS 128-row tile (every pair of the tile goes to the exact
+    re-rank), a query it cannot carry is handed to the exact pass ALONE -- the rest of the batch stays on the fast path
+    (r02: one such value anywhere sent the whole batch to the exact kernel)."""
     rng = np.random.default_rng(6)
     n, dim = 50_000, 64
     x = rng.standard_normal((n, dim)).astype(np.float32)
     x[123, 5] = 1.0e6                                   # does not fit f16
+    x[40_000, 9] = np.float32(np.inf)
+    x[40_001, 3] = np.float32(np.nan)
     f, e = _pair(vsa, dim, "IP", x)
     Q = rng.standard_normal((64, dim)).astype(np.float32)
     got = f.search_batch(Q, 10)
-    assert f.stats().last_filter_fallback == 1
+    st = f.stats()
+    assert st.last_filter_fallback == 0 and st.last_filter_candidates >= 64 * 2 * 128     # two whole tiles per query
     _same(got, e.search_batch(Q, 10))
-    # a huge QUERY among ordinary ones (rows fine)
-    x[123, 5] = 1.0
+    # huge / non-finite QUERIES among ordinary ones (rows fine)
+    x[123, 5] = x[40_000, 9] = x[40_001, 3] = 1.0
     f2, e2 = _pair(vsa, dim, "IP", x)
     Q[3, 0] = 5.0e5
+    Q[17, 2] = np.float32(np.inf)
     got = f2.search_batch(Q, 10)
-    assert f2.stats().last_filter_fallback == 1
+    assert f2.stats().last_filter_fallback == 2
     _same(got, e2.search_batch(Q, 10))
+    # an index that is mostly such tiles stays off the filter path altogether
+    y = (x * 1.0e5).astype(np.float32)
+    f3, e3 = _pair(vsa, dim, "IP", y)
+    Q2 = rng.standard_normal((64, dim)).astype(np.float32)
+    _same(f3.search_batch(Q2, 10), e3.search_batch(Q2, 10))
+    assert f3.stats().last_filter_candidates == 0
+
+
+def test_one_long_row_widens_the_gate_of_its_own_tile_only(vsa, oracle):
+    """One row of norm 1e4 in an otherwise unit-norm IP index: the margin follows the largest row norm PER TILE, so the
+    other tiles keep the gate of a unit-norm index (r02: one global norm, every gate 1e4 times wider)."""
+    rng = np.random.default_rng(16)
+    n, dim = 120_000, 96
+    centres = rng.standard_normal((60, dim)).astype(np.float32)
+    x = _unit(centres[rng.integers(0, 60, n)] + 0.4 * rng.standard_normal((n, dim)).astype(np.float32))
+    f, e = _pair(vsa, dim, "IP", x)
+    Q = _unit(centres[rng.integers(0, 60, 200)] + 0.4 * rng.standard_normal((200, dim)).astype(np.float32))
+    clean = f.search_batch(Q, 10)
+    c0 = f.stats().last_filter_candidates
+    _same(clean, e.search_batch(Q, 10))
+    y = x.copy()
+    y[77_777] *= 1.0e4                                  # still inside f16 (elements ~ 1e3), norm 1e4
+    f2, e2 = _pair(vsa, dim, "IP", y)
+    got = f2.search_batch(Q, 10)
+    st = f2.stats()
+    _same(got, e2.search_batch(Q, 10))
+    assert st.last_filter_fallback == 0
+    # the long row's tile lets its 128 rows through for every query; everything else is gated as before
+    assert st.last_filter_candidates <= c0 + 200 * 128 + 200 * 10, (c0, st.last_filter_candidates)
+
+
+def test_rows_loaded_cluster_by_cluster(vsa, oracle):
+    """An index ingested in cluster (or time) order: the sample behind the bound is every s-th tile of the WHOLE index, so
+    every cluster is seen (r02 sampled the first rows: queries from the later clusters got a useless bound and their
+    survivor lists overflowed).  The reference's answer does not depend on row order (bruteforce.h:116-145)."""
+    rng = np.random.default_rng(21)
+    n, dim, nc = 200_000, 64, 40
+    centres = 3.0 * rng.standard_normal((nc, dim)).astype(np.float32)
+    cid = np.sort(rng.integers(0, nc, n))                 # rows sorted by cluster id
+    x = _unit(centres[cid] + 0.3 * rng.standard_normal((n, dim)).astype(np.float32))
+    # (128 sample tiles: the stride through the index is a third of a cluster's run of tiles)
+    f, e = _pair(vsa, dim, "COSINE", x, VK_FILTER_PREPASS=16384)
+    qc = np.r_[np.full(100, nc - 1), rng.integers(0, nc, 156)]      # many queries from the LAST cluster loaded
+    Q = _unit(centres[qc] + 0.3 * rng.standard_normal((256, dim)).astype(np.float32))
+    got = f.search_batch(Q, 10)
+    st = f.stats()
+    _same(got, e.search_batch(Q, 10))
+    assert st.last_filter_fallback == 0
+    # the bound is as good as on a shuffled copy of the same rows: survivors per query stay in the hundreds
+    assert st.last_filter_candidates < 256 * 4000, st.last_filter_candidates
+    perm = rng.permutation(n)
+    fs, _ = _pair(vsa, dim, "COSINE", x[perm], perm.astype(np.uint64), VK_FILTER_PREPASS=16384)
+    gs = fs.search_batch(Q, 10)
+    assert (gs[1] == got[1]).all() and (gs[0].view(np.uint32) == got[0].view(np.uint32)).all()
+    assert st.last_filter_candidates < 3 * fs.stats().last_filter_candidates + 256 * 64
+
+
+def test_a_heavy_query_costs_the_batch_little(vsa, oracle):
+    """One query of a 256-batch sits on 40 000 duplicates: the batch must take at most 1.3x the time of the clean batch
+    (its extra work is the exact re-rank of that query's 40 000 survivors, not an exact pass over the index)."""
+    import time
+    rng = np.random.default_rng(31)
+    n, dim = 1_000_000, 128
+    centres = rng.standard_normal((200, dim)).astype(np.float32)
+    x = np.empty((n, dim), np.float32)
+    for i in range(0, n, 100_000):
+        x[i:i + 100_000] = _unit(centres[rng.integers(0, 200, 100_000)] + 0.5 * rng.standard_normal((100_000, dim)).astype(np.float32))
+    dup = x[123].copy()
+    x[300_000:340_000] = dup
+    with _Env(**SMALL):
+        f = vsa.Index("FLAT", dim, "COSINE", initial_cap=n)
+    f.add_batch(x)
+    Q = _unit(centres[rng.integers(0, 200, 256)] + 0.5 * rng.standard_normal((256, dim)).astype(np.float32))
+    Qh = Q.copy()
+    Qh[77] = dup
+
+    def timed(q):
+        f.search_batch(q, 10)
+        ts = []
+        for _ in range(15):
+            t0 = time.perf_counter()
+            f.search_batch(q, 10)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    t_clean = timed(Q)
+    assert f.stats().last_filter_fallback == 0
+    t_heavy = timed(Qh)
+    st = f.stats()
+    assert st.last_filter_fallback == 0 and st.last_filter_candidates >= 40_000
+    D, L, N = f.search_batch(Qh, 10)
+    o = oracle.Flat(dim, "COSINE", max_elements=n)
+    o.add_many(x, borrowed=True)
+    for i in (0, 77, 200):
+        od, ol = o.search(Qh[i], 10)
+        assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+    assert t_heavy <= 1.3 * t_clean + 1e-4, (t_clean, t_heavy)
 
 
 def test_filter_sees_mutations(vsa, oracle):
@@ -212,12 +342,12 @@ def test_l2_through_the_filter(vsa, oracle, dim, dtype):
         for i in range(40):
             od, ol = o.search(Q[i], 10)
             assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
-    # rows too long for the f16 half norms: the exact scan takes over
+    # a row too long for the f16 half norms: its tile is let through whole, the exact re-rank settles it
     y = x.copy()
     y[17] *= 400.0
     f2, e2 = _pair(vsa, dim, "L2", y, dtype=dtype)
     got = f2.search_batch(Q[:64], 10)
-    assert f2.stats().last_filter_fallback == 1
+    assert f2.stats().last_filter_fallback == 0 and f2.stats().last_filter_candidates >= 64 * 128
     _same(got, e2.search_batch(Q[:64], 10))
 
 

@@ -281,6 +281,13 @@ __device__ __forceinline__ bool poll_cancel(const uint32_t *flag) {
   return flag != nullptr && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
 }
 
+// device-side conditional launch (FlatScanArgs::run_flag): true = this launch has nothing to do
+__device__ __forceinline__ bool launch_skipped(const uint32_t *run_flag, uint32_t run_if, uint32_t run_hi) {
+  if (run_flag == nullptr) return false;
+  const uint32_t v = __hip_atomic_load(run_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return run_hi != 0 ? (v < run_if || v > run_hi) : v != run_if;
+}
+
 __device__ __forceinline__ bool allow_bit(const uint64_t *__restrict__ bits, uint64_t nbits, uint64_t label) {
   if (!bits) return true;
   if (label >= nbits) return false;

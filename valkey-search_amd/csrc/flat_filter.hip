@@ -2,19 +2,25 @@
 //
 // The exact batched kernel (flat_gemm.hip) reproduces the reference's f32 arithmetic on the f32 MFMA pipe, which is
 // 1/16 of the f16 rate: 36.7 ms per 256-query batch at 10M x 768, where ONE pass over the rows costs 4.9 ms of HBM
-// time.  An exact answer does not need exact arithmetic for every row: this kernel computes an APPROXIMATE dot product
-// of every (row, query) pair with v_mfma_f32_32x32x16_f16 (rows converted f32 -> f16 on the way into LDS, queries
-// converted once) and keeps only the pairs that can still be among the query's k best:
+// time.  An exact answer does not need exact arithmetic for every row: this kernel computes an APPROXIMATE score
+// (dot product; for L2 dot - |x|^2/2) of every (row, query) pair with v_mfma_f32_32x32x16_f16 (rows converted f32 ->
+// f16 on the way into LDS, queries converted once) and keeps only the pairs that can still be among the query's k best:
 //
-//   approx >= 1 - bound_q - eps_q          (inner-product space: distance = 1 - dot)
+//   approx(x, q) >= L_q - E_q(R_t)
 //
-// where bound_q is a valid upper bound of the query's final k-th best EXACT distance (the exact kernel over a sample of
-// the rows provides it) and eps_q bounds |approx - exact| rigorously (below).  The survivors -- a few hundred to a few
-// thousand per query out of 10M -- are re-ranked by the exact quad kernel (flat_scan.hip with a row list) and selected
-// by (distance,label), so the answer is BIT-IDENTICAL to the exact path's; only the work is different.  If a query's
-// survivor list overflows (duplicates of one vector by the hundred thousand, a filter that leaves no bound, values
-// outside the f16 range) the launch raises a flag and the exact kernel, enqueued behind it, runs instead -- decided on
-// the device, no host round trip.
+// L_q is a lower bound of the query's k-th best EXACT score and E_q(R) bounds |approx - exact| (plus the reference's
+// own rounding) rigorously for a row of norm <= R; R_t is the largest row norm of the 128-row tile the row lives in.
+// The survivors -- a few hundred per query out of 10M -- are re-ranked by the exact quad kernel (flat_scan.hip with a
+// row list) and selected by (distance,label), so the answer is BIT-IDENTICAL to the exact path's; only the work differs.
+//
+// Where L_q comes from (r03; r02 ran the exact kernel over the first rows, a filter pass over a larger prefix and a
+// re-rank of that -- eleven launches, and a bound that depended on the order the index was loaded in): one pass of THIS
+// kernel in "sample mode" over every s-th row tile of the index writes, per (group of 64 rows, query), the group's best
+// approximate score minus its margin -- a lower bound of the exact score of SOME row of the group.  The k-th largest of
+// a query's group bounds (flat_bound_select_kernel) is reached by k distinct rows, hence bounds the k-th best exact
+// score from below.  No exact arithmetic is needed for the bound, and a strided sample sees every region of an index
+// that was loaded cluster by cluster or in time order (the reference's answer does not depend on row order:
+// bruteforce.h:116-145).
 //
 // Error bound.  x^ = rne_f16(x), q^ = rne_f16(q): |x^_i - x_i| <= 2^-11 |x_i| + 2^-25 (the second term covers f16
 // subnormals), same for q.  Products of f16 values are exact in f32; the MFMA accumulates in f32, allowed here 4 ulp
@@ -22,8 +28,18 @@
 // sum |x_i q_i| <= |x| |q| (Cauchy-Schwarz; tight exactly for the near neighbours that matter):
 //   |approx - dot_real| <= |x||q| (2^-11 + 2^-11 + 2^-22 + D 2^-22) + 2^-25 sqrt(D) (|x| + |q|) (1 + 2^-11)
 // and the reference's own f32 result differs from dot_real by at most (D/16 + 5) 2^-24 |x||q|, its 1 - dot by 2^-24
-// max(1, |dist|).  eps_q below adds these with |x| <= R = the largest row norm in the index (tracked by row_stats_kernel)
-// and rounds everything up.
+// max(1, |dist|).  As a polynomial in the row norm R with per-query coefficients (flat_qprep_kernel): E_q(R) = c2 R^2 +
+// c1 R + c0 (c2 = 0 for the inner-product space); the margin is applied once for the witness rows behind L_q and once
+// for the row at the gate.  Because R is per TILE, one long row in an un-normalised index widens the gate of its own
+// 128 rows only (r02: of every row).
+//
+// Nothing is dropped silently and no single query can take the batch down with it (r02: one overflowing list or one
+// value outside f16 anywhere in the index sent all 256 queries to the 36.7 ms exact kernel):
+//   * a tile holding a value the f16 pipe cannot carry (non-finite, beyond 32768, a half norm beyond f16) has
+//     R_t = +inf: every pair of that tile survives and the exact re-rank settles it;
+//   * a query with more survivors than its private list (duplicates of one vector by the ten thousand) continues in
+//     spill chunks handed out from a shared pool; only when that is exhausted -- or the query itself cannot go through
+//     f16 -- is the query (alone) marked for the exact redo pass that FlatIndex enqueues behind.
 //
 // Data movement per 128-row tile and block (eight waves with three different jobs, see the kernel):
 //   rows     393 KB f32 from HBM, once -> converted -> f16 in LDS (two stages of 18 KB, 144-B row stride: conflict-free
@@ -50,18 +66,21 @@ constexpr int kFStageK = 64;                 // k per pipeline stage: 4 MFMA K-s
 constexpr int kFAStride = 72;                // halfs per staged row: 64 + 8 pad = 144 B (conflict-free b128 reads)
 }  // namespace
 
-// ---- row statistics: the largest row norm and the largest |element| over rows [lo, hi) -------------------------------
-// stats[0] = max over rows of |x|^2 (f32 bits, rounded up), stats[1] = max |x_i| (f32 bits; +inf for a non-finite element):
-// both only ever grow (atomicMax on the bit patterns of non-negative floats), which keeps them valid bounds when rows
-// are overwritten or removed.
+// ---- row statistics: the largest row norm per 128-row tile (and of the index) over rows [lo, hi) ------------------------
+// tile_r2[t] = max over the tile's rows of |x|^2 (f32 bits, rounded up), or +inf when the tile holds a value the f16
+// pipe cannot carry (non-finite, |x_i| > 32768, for L2 a half norm beyond f16): the filter lets every pair of such a
+// tile through to the exact re-rank.  stats[0] / stats[1] = the same maxima over the whole index (|x|^2, |x_i|; reported,
+// not used by the gate), stats[2] = number of tiles flagged +inf (FlatIndex keeps an index that is mostly such tiles
+// off this path).  All of them only ever grow (atomicMax on the bit patterns of non-negative floats), which keeps them
+// valid bounds when rows are overwritten or removed.
 // hn16 (optional, L2 indexes): per row half its squared norm, split into two f16 (hi | lo << 16) -- the extra K-step
 // that turns the filter's dot product into dot - |x|^2 / 2.
-__global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32_t bf16, uint32_t stride_e, uint32_t chunks,
-                                                        uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *hn16) {
+__global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32_t bf16, uint32_t l2, uint32_t stride_e, uint32_t chunks,
+                                                        uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *tile_r2, uint32_t *hn16) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 3, rq = lane >> 2;
   const uint32_t total_waves = gridDim.x * 4, n_tiles = (hi - lo + kRowsPerWave - 1) / kRowsPerWave;
   float best_n2 = 0.f, best_abs = 0.f;
-  for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += total_waves) {
+  for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += total_waves) {   // (lo is a multiple of 128)
     const uint32_t row = lo + tile * kRowsPerWave + rq;
     const uint32_t lrow = row < hi ? row : hi - 1;
     float n2 = 0.f, mx = 0.f;
@@ -82,28 +101,69 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32
       const _Float16 h1 = (_Float16)(hn - (float)h0);
       hn16[row] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
     }
-    best_n2 = fmaxf(best_n2, n2);
-    best_abs = fmaxf(best_abs, mx);
+    // the 16 rows of this step lie in one 128-row tile
+    const float g_n2 = wave_max_f32(n2) * 1.0001f;   // (rounding of the sum itself: far below 1e-4)
+    const float g_abs = wave_max_f32(mx);
+    const bool g_bad = !(g_abs <= 32768.f) || !(g_n2 - g_n2 == 0.f) || (l2 && !(0.5f * g_n2 <= 60000.f));
+    if (lane == 0) {
+      const uint32_t v = g_bad ? 0x7F800000u : __float_as_uint(g_n2);
+      const uint32_t old = atomicMax(&tile_r2[(lo + tile * kRowsPerWave) / 128u], v);
+      if (g_bad && old != 0x7F800000u) atomicAdd(&stats[2], 1u);
+    }
+    best_n2 = fmaxf(best_n2, g_n2);
+    best_abs = fmaxf(best_abs, g_abs);
   }
-  best_n2 = wave_max_f32(best_n2) * 1.0001f;   // (rounding of the sum itself: far below 1e-4)
-  best_abs = wave_max_f32(best_abs);
   if (lane == 0) {
     atomicMax(&stats[0], __float_as_uint(best_n2));
     atomicMax(&stats[1], __float_as_uint(best_abs));
   }
 }
 
-hipError_t launch_row_stats(const void *rows, bool bf16, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *hn16,
-                            hipStream_t s) {
-  if (hi <= lo) return hipSuccess;
-  const uint32_t tiles = (hi - lo + kRowsPerWave - 1) / kRowsPerWave;
-  const uint32_t blocks = std::min<uint32_t>((tiles + 3) / 4, 2048);
-  hipLaunchKernelGGL(row_stats_kernel, dim3(blocks), dim3(256), 0, s, rows, bf16 ? 1u : 0u, stride_e, stride_e / 16, lo, hi, stats, hn16);
+// stats[3] = the norm cap of the sample's witnesses: the upper edge of the smallest |row|^2 bin (exponent + 3 mantissa
+// bits: 9 % wide) that 97 % of the finite tiles stay below.  A robust "largest ordinary norm": one row of norm 1e6 in a
+// unit-norm index moves the global maximum by six orders of magnitude and this not at all.  One block.
+__global__ __launch_bounds__(1024) void tile_cap_kernel(const uint32_t *tile_r2, uint32_t n_tiles, uint32_t *stats) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x;
+  hist[tid] = hist[tid + 1024] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n_tiles; i += 1024) {
+    const uint32_t v = tile_r2[i];
+    if (v < 0x7F800000u) atomicAdd(&hist[v >> 20], 1u);
+  }
+  __syncthreads();
+  part[tid] = hist[2 * tid] + hist[2 * tid + 1];
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < 1024; ++i) total += part[i];
+    const uint32_t want = total - total / 32;                     // 97 % of the finite tiles
+    uint32_t acc = 0, bin = 2047;
+    for (uint32_t b = 0; b < 2048 && total != 0; ++b) {
+      acc += hist[b];
+      if (acc >= want) { bin = b; break; }
+    }
+    stats[3] = total == 0 ? 0u : (bin >= 2039u ? 0x7F7FFFFFu : ((bin + 1u) << 20));
+  }
+}
+
+hipError_t launch_row_stats(const void *rows, bool bf16, bool l2, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t n_tiles,
+                            uint32_t *stats, uint32_t *tile_r2, uint32_t *hn16, hipStream_t s) {
+  lo &= ~127u;                                            // whole tiles: a step of 16 rows never straddles two of them
+  if (hi > lo) {
+    const uint32_t tiles = (hi - lo + kRowsPerWave - 1) / kRowsPerWave;
+    const uint32_t blocks = std::min<uint32_t>((tiles + 3) / 4, 2048);
+    hipLaunchKernelGGL(row_stats_kernel, dim3(blocks), dim3(256), 0, s, rows, bf16 ? 1u : 0u, l2 ? 1u : 0u, stride_e, stride_e / 16, lo, hi,
+                       stats, tile_r2, hn16);
+  }
+  hipLaunchKernelGGL(tile_cap_kernel, dim3(1), dim3(1024), 0, s, tile_r2, n_tiles, stats);
   return hipGetLastError();
 }
 
 // ---- query preparation -------------------------------------------------------------------------------------------------
-// One wave per query column of the (padded) batch: f16 copy in MFMA fragment order, and the gate in dot space.
+// One wave per query column of the (padded) batch: f16 copy in MFMA fragment order, the column's error polynomial, and
+// the reset of everything the passes of this batch count in (survivor counts, spill chunks, hand-over flags).
 // Fragment order: tile jt = j / 32 of 32 queries, K-step ks of 16 elements, lane l = g * 32 + (j % 32) holds elements
 // ks*16 + g*8 + 0..7 -- the B operand of v_mfma_f32_32x32x16_f16 as one 16-byte load per lane.
 __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
@@ -133,41 +193,91 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, m));
     bad = bad || __shfl_xor((int)bad, m);
   }
+  if (j < a.nq && lane < kSpillPerQuery) a.qchunk[(size_t)j * kSpillPerQuery + lane] = 0u;
   if (lane != 0) return;
-  float thr = __builtin_inff();                        // padding column: nothing passes
+  if (j == 0) *a.spill_next = 0u;
+  float4 co = make_float4(0.f, 0.f, 0.f, 1.f);          // padding column: closed
   if (j < a.nq) {
-    const float R = sqrtf(__uint_as_float(a.row_stats[0])) * 1.0001f, amax = __uint_as_float(a.row_stats[1]);
-    const float qn = sqrtf(n2) * 1.0001f, bound = a.bound[q];
+    a.cand_cnt[j] = 0u;
+    const float qn = sqrtf(n2) * 1.0001f;
     const float D = (float)a.row_stride_f;
-    // see the header: relative part, absolute (subnormal) part, the reference's own rounding, 1 - dot
+    // see the header: relative part, absolute (subnormal) part, the reference's own rounding, 1 - dot (2^-23 (1 + R |q|)
+    // covers both sides' 2^-24 max(1, |dist|)); everything rounded up by 1.001
     const float rel = (a.bf16 ? 0x1p-11f : 0x1p-10f) + 0x1p-22f + D * 0x1p-22f + (D / 16.f + 5.f) * 0x1p-24f;   // (bf16 rows convert exactly)
-    const float eps = (R * qn * rel + 0x1.01p-25f * sqrtf(D) * (R + qn) + 0x1p-23f * fmaxf(1.f, 1.f + R * qn)) * 1.001f;
-    bool f16_ok = !bad && mx <= 32768.f && amax <= 32768.f && (R - R == 0.f) && (eps - eps == 0.f);
-    // no bound yet (fewer than k allowed rows in the sample: the filter leaves only a few rows of the whole index): the
-    // gate is open, every ALLOWED row becomes a survivor and the re-rank settles it
-    if (!a.l2) {
-      thr = (bound - bound == 0.f) ? ((1.f - bound) - eps) - 0x1p-22f * fmaxf(1.f, fabsf(1.f - bound)) : -__builtin_inff();
-    } else {
+    const float sub = 0x1.01p-25f * sqrtf(D);
+    float c2 = 0.f, c1 = (qn * rel + sub + 0x1p-23f * qn) * 1.001f, c0 = (sub * qn + 0x1p-23f) * 1.001f;
+    if (a.l2) {
       // |x - q|^2 = 2 (|x|^2/2) + |q|^2 - 2 x.q: the kernel accumulates x.q - |x|^2/2 (half norms as one more K-step,
-      // split in two f16: 2^-21 relative), so a row stays iff  acc >= (|q|^2 - bound - eps2) / 2.  eps2: twice the dot
+      // split in two f16: 2^-21 relative), so in accumulator space the margin is eps2 / 2 with eps2 = twice the dot
       // product's margin, the f32 rounding of both norms (D 2^-23 relative, generously), the split of the half norm, and
-      // the reference's own rounding of its sum of squared differences ((D/16 + 6) 2^-24 of at most (R + |q|)^2).
-      const float nq2 = n2;
-      const float sumsq = R * R + qn * qn, top = (R + qn) * (R + qn);
-      const float eps2 = (2.f * eps + sumsq * (D * 0x1p-23f + 0x1p-20f) + top * (D / 16.f + 6.f) * 0x1p-23f) * 1.001f;
-      f16_ok = f16_ok && 0.5f * R * R <= 60000.f && (eps2 - eps2 == 0.f);
-      const float c = 0.5f * (nq2 - bound) - 0.5f * eps2;
-      thr = (bound - bound == 0.f) ? c - 0x1p-21f * fmaxf(1.f, fabsf(c)) : -__builtin_inff();
+      // the reference's own rounding of its sum of squared differences ((D/16 + 6) 2^-24 of at most (R + |q|)^2):
+      //   eps2 / 2 = E_ip(R) + (R^2 + |q|^2) al / 2 + (R + |q|)^2 be / 2
+      const float al = D * 0x1p-23f + 0x1p-20f, be = (D / 16.f + 6.f) * 0x1p-23f;
+      c2 = 0.5f * (al + be) * 1.001f;
+      c1 = (c1 + be * qn) * 1.001f;
+      c0 = (c0 + 0.5f * qn * qn * (al + be)) * 1.001f;
     }
-    // Inputs that cannot go through f16 (values beyond its range, non-finite rows or queries, half norms beyond 60000):
-    // the products may be NaN, and a NaN passes no gate, open or not -- so the hand-over to the exact kernel is
-    // requested here, outright, and this column's gate stays closed.
-    if (!f16_ok) {
-      thr = __builtin_inff();
-      __hip_atomic_store(a.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // a query that cannot go through f16 (values beyond its range, non-finite): its products may be NaN -- the column
+    // is closed and the query handed to the exact pass, alone
+    const bool f16_ok = !bad && mx <= 32768.f && (c0 - c0 == 0.f) && (c1 - c1 == 0.f);
+    co = make_float4(c2, c1, c0, f16_ok ? 0.f : 1.f);
+    a.ovf_q[j] = f16_ok ? 0u : 1u;
   }
-  a.thr[j] = thr;
+  a.qcoef[j] = co;
+  // the column's margin for the witnesses of the sample: rows of norm up to the cap (see FlatFilterArgs::r2_cap)
+  const float Rc = sqrtf(__uint_as_float(*a.r2_cap)) * 1.0001f;
+  a.qwit[j] = fmaf(fmaf(co.x, Rc, co.y), Rc, co.z);
+}
+
+// ---- bound selection --------------------------------------------------------------------------------------------------
+// qbound[q] = the k-th largest of the query's group bounds (sample pass), found by a binary descent over the
+// order-preserving keys: one block per query, up to 64 values per thread in registers, one barrier per bit.
+__device__ __forceinline__ uint32_t desc_key(float f) {   // larger float <-> larger key (NaN never reaches here)
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+template <int kPer>
+__global__ __launch_bounds__(256) void flat_bound_select_kernel(FlatBoundArgs a) {
+  __shared__ uint32_t s_cnt[2][4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+  const float *v = a.smax + (size_t)q * a.smax_ld;
+  uint32_t key[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const uint32_t i = tid + 256u * u;
+    key[u] = i < a.groups ? desc_key(v[i]) : 0u;          // (key 0 = below every float: never counted)
+  }
+  uint32_t phase = 0;
+  auto block_sum = [&](uint32_t mine) -> uint32_t {
+    if (lane == 0) s_cnt[phase][wave] = mine;
+    __syncthreads();
+    const uint32_t t = s_cnt[phase][0] + s_cnt[phase][1] + s_cnt[phase][2] + s_cnt[phase][3];
+    phase ^= 1;
+    return t;
+  };
+  // T = the largest key with count(key >= T) >= k, i.e. the k-th largest key (0 if there are fewer than k values)
+  uint32_t T = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = T | (1u << bit);
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) c += (uint32_t)__popcll(__ballot(key[u] >= cand));
+    if (block_sum(c) >= a.k) T = cand;
+  }
+  if (tid == 0) {
+    const uint32_t u = (T & 0x80000000u) ? (T & 0x7FFFFFFFu) : ~T;
+    float b = __uint_as_float(u);
+    if (T == 0 || !(b == b)) b = -__builtin_inff();       // fewer than k group bounds: no bound, the gate stays open
+    a.qbound[q] = b;
+  }
+}
+
+hipError_t launch_flat_bound_select(const FlatBoundArgs &a, hipStream_t s) {
+  if (a.nq == 0) return hipSuccess;
+  if (a.groups > kFilterMaxGroups) return hipErrorInvalidValue;
+  if (a.groups <= 256 * 16) hipLaunchKernelGGL((flat_bound_select_kernel<16>), dim3(a.nq), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((flat_bound_select_kernel<64>), dim3(a.nq), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 // ---- survivors, gate, stream position --------------------------------------------------------------------------------
@@ -179,34 +289,80 @@ struct SurvivorRing {
   uint32_t *row;   // [64] LDS
   uint32_t cnt;    // wave-uniform
 };
+// A query's private list is full: the survivor goes to the query's spill chunks, handed out from a pool shared by the
+// batch.  A chunk slot goes 0 (none) -> 1 (claimed: its chunk is being taken from the pool) -> id + 2, or kNoChunk when
+// the pool is empty.  Exactly one thread claims a slot, so no chunk is ever lost; the others wait for the id.  Inside
+// a wave the claims are made one (query, chunk) pair at a time by an elected lane BEFORE anybody waits, so a waiting
+// lane only ever waits for another wave.  A survivor that finds no chunk (the query used all its slots, the pool is
+// empty) is dropped -- and its query, alone, marked for the exact redo pass.
+constexpr uint32_t kChunkClaimed = 1u, kNoChunk = 0xFFFFFFFFu;
 __device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing &r, uint32_t lane) {
+  bool spill = false;
+  uint32_t q = 0, row = 0, j = 0;
   if (lane < r.cnt) {
-    const uint32_t q = r.q[lane], row = r.row[lane];
+    q = r.q[lane];
+    row = r.row[lane];
     const uint32_t at = atomicAdd(&a.cand_cnt[q], 1u);
     if (at < a.cap) a.cand_row[(size_t)q * a.cap + at] = row;
-    else __hip_atomic_store(a.ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else { spill = true; j = at - a.cap; }
   }
   r.cnt = 0;
+  if (__builtin_amdgcn_ballot_w64(spill) == 0) return;      // (the usual case)
+  const uint32_t c = j / kSpillChunk;
+  const bool has_slot = spill && c < kSpillPerQuery;
+  uint32_t *slot = a.qchunk + (size_t)q * kSpillPerQuery + (has_slot ? c : 0u);
+  bool need = has_slot && __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+  for (uint64_t m = __builtin_amdgcn_ballot_w64(need); m != 0; m = __builtin_amdgcn_ballot_w64(need)) {
+    const int leader = __builtin_ctzll(m);
+    const uint32_t lq = (uint32_t)__builtin_amdgcn_readlane((int)q, leader), lc = (uint32_t)__builtin_amdgcn_readlane((int)c, leader);
+    if ((int)lane == leader && atomicCAS(slot, 0u, kChunkClaimed) == 0u) {
+      const uint32_t fresh = atomicAdd(a.spill_next, 1u);
+      __hip_atomic_store(slot, fresh < a.n_chunks ? fresh + 2u : kNoChunk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    need = need && !(q == lq && c == lc);
+  }
+  uint32_t id = kNoChunk;
+  if (has_slot) {
+    while ((id = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == kChunkClaimed) __builtin_amdgcn_s_sleep(1);
+  }
+  if (spill) {
+    if (id != kNoChunk) a.spill[(size_t)(id - 2u) * kSpillChunk + j % kSpillChunk] = row;
+    else __hip_atomic_store(a.ovf_q + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The column's gate for a tile whose largest row norm is R (r2 = R^2 as f32 bits, +inf = a tile that cannot go through
+// f16: everything passes).  A pair stays unless approx < thr.
+struct GateCol { float c2, c1, c0, bound, slack; bool closed; };
+__device__ __forceinline__ float tile_margin(const GateCol &c, float R) { return fmaf(fmaf(c.c2, R, c.c1), R, c.c0); }
+__device__ __forceinline__ float tile_norm(uint32_t r2_bits) { return sqrtf(__uint_as_float(r2_bits)) * 1.0001f; }
+__device__ __forceinline__ float gate_thr(const GateCol &c, uint32_t r2_bits) {
+  const float R = tile_norm(r2_bits);
+  float thr = (c.bound - tile_margin(c, R)) - c.slack;
+  if (!(R < __builtin_inff()) || !(thr == thr)) thr = -__builtin_inff();
+  return c.closed ? __builtin_inff() : thr;
 }
 
 // Tile done: the gate.  Output register r of row tile rt is row rt*32 + (r&3) + 8*(r>>2) + 4*g, column li of the wave's
-// query tile.  Almost every 32 x 32 block has no survivor: one max over the lane's 16 values, one ballot.
+// query tile.  Almost every 32 x 32 block has no survivor: one max over the lane's 16 values, one ballot.  (The test is
+// "not below", so that a NaN -- a tile or a query outside f16 -- passes.)
 template <int kRt, bool kZero>
-__device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[kRt], float thr, uint32_t tile_row0,
+__device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[kRt], float thr, bool closed, uint32_t tile_row0,
                                             uint32_t wave, uint32_t li, uint32_t g, SurvivorRing &ring, uint32_t lane) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int rt = 0; rt < kRt; ++rt) {
+    // (fmaxf drops NaNs; they only occur in a tile outside f16, whose thr is -inf: "not below" then holds for any m)
     float m = acc[rt][0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
-    if (__builtin_amdgcn_ballot_w64(m >= thr) != 0) {   // (rare: a survivor somewhere in this 32 x 32 block)
+    if (__builtin_amdgcn_ballot_w64(!(m < thr)) != 0) {   // (rare: a survivor somewhere in this 32 x 32 block)
       const uint32_t q = wave * 32 + li;
       // the lane's passing registers as a bit mask, then one round per remaining bit of the busiest lane (usually one)
       uint32_t mk = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mk |= acc[rt][r] >= thr ? 1u << r : 0u;
-      if (q >= a.nq) mk = 0;
+      for (int r = 0; r < 16; ++r) mk |= !(acc[rt][r] < thr) ? 1u << r : 0u;
+      if (q >= a.nq || closed) mk = 0;
       while (__builtin_amdgcn_ballot_w64(mk != 0) != 0) {
         const uint32_t r = (uint32_t)__builtin_ctz(mk | 0x10000u);
         const uint32_t row = tile_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -230,15 +386,54 @@ __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&ac
   }
 }
 
+// Sample mode: instead of gating, the lane's best approximate score over its rows of the sample tile minus the margin at
+// the norm cap -- a lower bound of the exact score of one of those rows -- goes to smax[query][group].  Coarse groups (a
+// large sample): the lane's 64 rows of the tile (half g of all four 32-row blocks), group = 2 * sample tile + g.  Fine
+// groups (a small sample, where the k-th largest of few group bounds would be a poor bound): its 16 rows of each block,
+// group = (4 * sample tile + block) * 2 + g.  Rows that are no witnesses arrive as NaN (fmaxf ignores them); with a
+// filter only allowed rows count (a witness must be a row the search may return).
+template <int kRt>
+__device__ __forceinline__ void sample_max(const FlatFilterArgs &a, const f32x16 (&acc)[kRt], const GateCol &c, uint32_t tile, uint32_t q,
+                                           uint32_t g) {
+  const float margin = c.c0 + c.slack;
+  float best = -__builtin_inff();
+#pragma unroll
+  for (int rt = 0; rt < kRt; ++rt) {
+    float m = -__builtin_inff();
+    if (a.allow_bits == nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t i = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const size_t row = (size_t)(i * a.n_tiles + tile) * a.sample_gap;
+        if (allow_bit(a.allow_bits, a.allow_nbits, a.labels[row])) m = fmaxf(m, acc[rt][r]);
+      }
+    }
+    if (a.smax_fine) {
+      float lb = m - margin;
+      if (c.closed || !(lb == lb)) lb = -__builtin_inff();
+      if (q < a.nq) a.smax[(size_t)q * a.smax_ld + (tile * (uint32_t)kRt + rt) * 2u + g] = lb;
+    }
+    best = fmaxf(best, m);
+  }
+  if (!a.smax_fine) {
+    float lb = best - margin;
+    if (c.closed || !(lb == lb)) lb = -__builtin_inff();
+    if (q < a.nq) a.smax[(size_t)q * a.smax_ld + tile * 2u + g] = lb;
+  }
+}
+
 // position in a block's flattened (tile, stage) stream, advanced without divisions; it never moves past the last
 // stage (prefetches behind the end re-read it and are not used)
-struct FPos { uint32_t row0, st, left; };
+struct FPos { uint32_t row0, st, left, step; };   // step: rows from one tile of the stream to the next (sample mode: a stride)
 __device__ __forceinline__ void fpos_advance(FPos &p, uint32_t stages) {
   const bool go = p.left > 1;
   const bool wrap = go && p.st + 1 == stages;
   p.left -= p.left != 0 ? 1u : 0u;
   p.st = wrap ? 0u : p.st + (go ? 1u : 0u);
-  p.row0 += wrap ? (uint32_t)kFTileRows : 0u;
+  p.row0 += wrap ? p.step : 0u;
 }
 
 // ---- the filter, wave-specialised ---------------------------------------------------------------------------------------
@@ -267,8 +462,9 @@ __device__ __forceinline__ void fpos_advance(FPos &p, uint32_t stages) {
 // wave (it then waits with vmcnt(0) everywhere) and __syncthreads() in the producers (below).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-template <bool kBf16> struct WsRows { f32x4v v[16]; uint32_t hn; };    // row producer thread: 128 rows x 64 k / 128 threads
-template <> struct WsRows<true> { u32x4v v[8]; uint32_t hn; };         // bf16 rows: 8 elements per 16-byte load, half as many loads
+// (pz, sample mode: bit u = the row of piece u comes from a tile beyond the norm cap and is poisoned on its way into LDS)
+template <bool kBf16> struct WsRows { f32x4v v[16]; uint32_t hn, pz; };    // row producer thread: 128 rows x 64 k / 128 threads
+template <> struct WsRows<true> { u32x4v v[8]; uint32_t hn, pz; };         // bf16 rows: 8 elements per 16-byte load, half as many loads
 struct WsB { u32x4v v[16]; };                                          // query producer thread: 4 query tiles x 4 K-steps
 
 // idx = t + 128 u: row = idx / 16 = t / 16 + 8 u, 4-element column t % 16 of the row's stage slice.  The tile / stage /
@@ -302,9 +498,33 @@ __device__ __forceinline__ void ws_rows_load(WsRows<kBf16> &s, const FlatFilterA
       s.v[u] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(u * step), 2));
   }
 }
+// Sample mode: the 128 rows of sample tile `tile` are index rows (i * n_tiles + tile) * sample_gap, i = 0 .. 127 -- 64-bit
+// addresses (the rows span the whole table), which cost more to issue than the descriptor form above and do not matter
+// for a pass over a few per cent of the index.  With the first stage of a tile the thread also looks up whether its rows'
+// tiles lie beyond the norm cap.
+template <bool kBf16, bool kL2>
+__device__ __forceinline__ void ws_rows_load_sample(WsRows<kBf16> &s, const FlatFilterArgs &a, uint32_t tile, uint32_t st, uint32_t t,
+                                                    uint32_t cap_bits) {
+  constexpr size_t esz = kBf16 ? 2 : 4;
+  const size_t row_bytes = (size_t)a.row_stride_f * esz;
+  if constexpr (kL2) s.hn = a.hn16[(size_t)(t * a.n_tiles + tile) * a.sample_gap];
+  constexpr int kPieces = kBf16 ? 8 : 16, kRowStep = kBf16 ? 16 : 8;
+  const uint32_t i0 = kBf16 ? t >> 3 : t >> 4;
+  const char *base = static_cast<const char *>(a.rows) + (size_t)st * kFStageK * esz + (size_t)(kBf16 ? (t & 7) : (t & 15)) * 16;
+  uint32_t pz = 0;
+#pragma unroll
+  for (int u = 0; u < kPieces; ++u) {
+    const size_t row = (size_t)((i0 + (uint32_t)(kRowStep * u)) * a.n_tiles + tile) * a.sample_gap;
+    const u32x4v v = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(base + row * row_bytes));
+    if constexpr (kBf16) s.v[u] = v;
+    else s.v[u] = __builtin_bit_cast(f32x4v, v);
+    if (st == 0) pz |= (a.tile_r2[row >> 7] > cap_bits ? 1u : 0u) << u;
+  }
+  s.pz = pz;
+}
 // -> f16 in LDS.  f32 rows: round to nearest even.  bf16 rows: bf16 -> f32 is a shift and f32 -> f16 is then EXACT for
 // every value in f16's normal range (8 significant bits fit 11), so a bf16 index carries no row rounding error at all.
-template <bool kBf16, bool kL2>
+template <bool kBf16, bool kL2, bool kSample>
 __device__ __forceinline__ void ws_rows_store(_Float16 *buf, uint32_t *hn_buf, uint32_t t, const WsRows<kBf16> &s) {
   if constexpr (kL2) hn_buf[t] = s.hn;
   if constexpr (kBf16) {
@@ -317,6 +537,9 @@ __device__ __forceinline__ void ws_rows_store(_Float16 *buf, uint32_t *hn_buf, u
         h[2 * w] = (_Float16)__uint_as_float(s.v[u][w] << 16);
         h[2 * w + 1] = (_Float16)__uint_as_float(s.v[u][w] & 0xFFFF0000u);
       }
+      if constexpr (kSample) {
+        if ((t & 7) == 0 && ((s.pz >> u) & 1u)) h[0] = __builtin_bit_cast(_Float16, (uint16_t)0x7E00);   // NaN: no witness
+      }
       *reinterpret_cast<f16x8 *>(dst + u * 16 * kFAStride) = h;
     }
   } else {
@@ -328,6 +551,9 @@ __device__ __forceinline__ void ws_rows_store(_Float16 *buf, uint32_t *hn_buf, u
       h[1] = (_Float16)s.v[u][1];
       h[2] = (_Float16)s.v[u][2];
       h[3] = (_Float16)s.v[u][3];
+      if constexpr (kSample) {
+        if ((t & 15) == 0 && ((s.pz >> u) & 1u)) h[0] = __builtin_bit_cast(_Float16, (uint16_t)0x7E00);   // NaN: no witness
+      }
       *reinterpret_cast<f16x4 *>(dst + u * 8 * kFAStride) = h;
     }
   }
@@ -352,7 +578,7 @@ __device__ __forceinline__ void ws_b_store(uint4 *slot, uint32_t p, uint32_t lan
   for (int i = 0; i < 16; ++i) dst[i * kWave] = b.v[i];
 }
 
-template <bool kBf16, bool kL2, bool kTiming>
+template <bool kBf16, bool kL2, bool kTiming, bool kSample>
 __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   extern __shared__ _Float16 lds_a[];
   constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;                    // one A stage
@@ -367,20 +593,19 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t stages = a.row_stride_f / kFStageK;
 
-  const uint32_t n_tiles = (a.n_rows + kFTileRows - 1) / kFTileRows;
+  // a block's tiles: a contiguous range of the launch's tile sequence (sample mode: of the sample tiles, and what the
+  // stream positions below call a row is then the sample tile's number)
+  const uint32_t n_tiles = a.n_tiles;
   const uint32_t t_base = n_tiles / gridDim.x, t_rem = n_tiles % gridDim.x;
   const uint32_t first_tile = blockIdx.x * t_base + (blockIdx.x < t_rem ? blockIdx.x : t_rem);
   const uint32_t my_tiles = t_base + (blockIdx.x < t_rem ? 1u : 0u);
   if (my_tiles == 0) return;
+  const uint32_t row_step = kSample ? 1u : (uint32_t)kFTileRows;
   const uint32_t total = my_tiles * stages;
   uint32_t st_c = 0, tile_c = 0, left_c = total;
   bool stop = false;
   if (tid < 2) lds_stop[tid] = 0;
-  // the hand-over to the exact kernel was already requested (inputs outside f16, an earlier launch of this batch
-  // overflowed): nothing this pass finds would be used.  One thread looks, so that all eight waves agree.
-  if (tid == 0) lds_stop[2] = __hip_atomic_load(a.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (lds_stop[2] != 0) return;
 
   // Leaving early (cancellation) must be decided identically by all eight waves or the next barrier never completes: the
   // polling thread publishes what it saw during tile T in lds_stop[T & 1] before the tile's last barrier, everybody reads
@@ -420,7 +645,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     // iteration S: request B(S+2) into the register set B(S) left, write B(S+1) (requested one iteration ago) to slot
     // (S+1) & 1, barrier.  Past the end of the stream the loads re-read its last stage (no branch around a load).
     const uint32_t p = wave - 6;
-    FPos lb{first_tile * kFTileRows, 0, total};
+    FPos lb{first_tile * row_step, 0, total, row_step};
     WsB b0, b1;
     ws_b_load(b0, a, p, lb.st, lane);
     fpos_advance(lb, stages);
@@ -464,16 +689,24 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     // buffer (S+1) & 1, barrier.  Three stages of rows (96 KB per CU) are in flight.
     const uint32_t t = tid - 256;
     const uint32_t voff = kBf16 ? ((t >> 3) * a.row_stride_f + (t & 7) * 8) * 2u : ((t >> 4) * a.row_stride_f + (t & 15) * 4) * 4u;
-    FPos ld{first_tile * kFTileRows, 0, total};
+    FPos ld{first_tile * row_step, 0, total, row_step};
     WsRows<kBf16> x0, x1, x2;
     x0.hn = x1.hn = x2.hn = 0;
-    ws_rows_load<kBf16, kL2>(x0, a, ld.row0, ld.st, t, voff);
+    x0.pz = x1.pz = x2.pz = 0;
+    uint32_t cap_bits = 0;
+    if constexpr (kSample) cap_bits = *a.r2_cap;
+#define VK_WS_ROWS_LOAD(X)                                                                                          \
+    {                                                                                                               \
+      if constexpr (kSample) ws_rows_load_sample<kBf16, kL2>(X, a, ld.row0, ld.st, t, cap_bits);                    \
+      else ws_rows_load<kBf16, kL2>(X, a, ld.row0, ld.st, t, voff);                                                 \
+    }
+    VK_WS_ROWS_LOAD(x0)
     fpos_advance(ld, stages);
-    ws_rows_load<kBf16, kL2>(x1, a, ld.row0, ld.st, t, voff);
+    VK_WS_ROWS_LOAD(x1)
     fpos_advance(ld, stages);
-    ws_rows_load<kBf16, kL2>(x2, a, ld.row0, ld.st, t, voff);
+    VK_WS_ROWS_LOAD(x2)
     fpos_advance(ld, stages);
-    ws_rows_store<kBf16, kL2>(lds_a, hn_lds, t, x0);
+    ws_rows_store<kBf16, kL2, kSample>(lds_a, hn_lds, t, x0);
     VK_WS_PBARRIER()
     uint32_t ppar = 0;                                                       // S & 1
     unsigned long long ph[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -484,12 +717,12 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       if (live && st_c == 0 && t == 0 && a.cancel && (tile_c % kCancelPollTiles) == 0) {                            \
         if (__hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) lds_stop[tile_c & 1] = 1; \
       }                                                                                                             \
-      ws_rows_load<kBf16, kL2>(RLOAD, a, ld.row0, ld.st, t, voff);                                                  \
+      VK_WS_ROWS_LOAD(RLOAD)                                                                                        \
       fpos_advance(ld, stages);                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                            \
       VK_WS_TICK(0)                                                                                                 \
       ppar ^= 1;                                                                                                    \
-      ws_rows_store<kBf16, kL2>(lds_a + ppar * kBufHalfs, hn_lds + ppar * kFTileRows, t, RSTORE);                   \
+      ws_rows_store<kBf16, kL2, kSample>(lds_a + ppar * kBufHalfs, hn_lds + ppar * kFTileRows, t, RSTORE);                   \
       if constexpr (timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
       VK_WS_TICK(2)                                                                                                 \
       left_c -= live ? 1u : 0u;                                                                                     \
@@ -504,6 +737,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       VK_WS_PROD(x2, x0)
     }
 #undef VK_WS_PROD
+#undef VK_WS_ROWS_LOAD
     if constexpr (timing) {
       if (lane == 0 && a.dbg)
         for (int i = 0; i < 4; ++i) atomicAdd(&a.dbg[i], ph[i]);
@@ -519,17 +753,35 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   ring.row = ring.q + kWave;
   ring.cnt = 0;
   const bool has_q = wave * 2 < a.nqt;
-  float thr[2];
+  GateCol col[2];
 #pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2) thr[t2] = wave * 2 + t2 < a.nqt ? a.thr[(wave * 2 + t2) * 32 + li] : __builtin_inff();
+  for (int t2 = 0; t2 < 2; ++t2) {
+    const bool have = wave * 2 + t2 < a.nqt;
+    const uint32_t jc = have ? (wave * 2 + t2) * 32 + li : 0u;
+    const float4 co = a.qcoef[jc];
+    const float b = kSample ? 0.f : a.qbound[jc];
+    col[t2].c2 = kSample ? 0.f : co.x;
+    col[t2].c1 = kSample ? 0.f : co.y;
+    col[t2].c0 = kSample ? a.qwit[jc] : co.z;               // (sample mode: the margin at the norm cap, a constant)
+    col[t2].closed = !have || co.w != 0.f;
+    col[t2].bound = b;
+    // (the rounding of the subtractions that make the threshold out of bound and margin)
+    col[t2].slack = kSample ? 0x1p-21f : 0x1p-21f * fmaxf(1.f, fabsf(b));
+  }
   f32x16 acc[2][4];
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) acc[t2][rt] = zero;
-  uint32_t tile_row0 = first_tile * kFTileRows;
+  uint32_t tile_row0 = first_tile * row_step;
   uint32_t par = 0;
+  // The tile's |row|^2 bound: ONE vector-memory word per tile and wave, requested when the tile starts and looked at in
+  // its gate twelve stages later (a buffer load on purpose: a scalar load shares the LDS reads' counter, and every
+  // wait for a fragment behind it would become a wait for everything).
+  const __amdgpu_buffer_rsrc_t tile_rsrc = ws_rsrc(a.tile_r2);
+  uint32_t r2_bits = 0;
+  if constexpr (!kSample) r2_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
   __syncthreads();                                            // (the prologue's barrier)
 
   // iteration S: 32 MFMAs of stage S, operands from LDS (A: buffer S & 1, row li of each row tile; B: slot S & 1,
@@ -595,10 +847,17 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     par ^= 1;
     if (st_c == stages) {
       if (has_q) {
-        filter_gate<4, false>(a, acc[0], thr[0], tile_row0, wave * 2, li, g, ring, lane);
-        filter_gate<4, false>(a, acc[1], thr[1], tile_row0, wave * 2 + 1, li, g, ring, lane);
+        if constexpr (kSample) {
+          sample_max<4>(a, acc[0], col[0], tile_row0, (wave * 2) * 32 + li, g);
+          sample_max<4>(a, acc[1], col[1], tile_row0, (wave * 2 + 1) * 32 + li, g);
+        } else {
+          filter_gate<4, false>(a, acc[0], gate_thr(col[0], r2_bits), col[0].closed, tile_row0, wave * 2, li, g, ring, lane);
+          filter_gate<4, false>(a, acc[1], gate_thr(col[1], r2_bits), col[1].closed, tile_row0, wave * 2 + 1, li, g, ring, lane);
+        }
       }
-      tile_row0 += kFTileRows;
+      tile_row0 += row_step;
+      // (past the block's last tile this reads a word behind it: the table is padded, the value is not used)
+      if constexpr (!kSample) r2_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
       VK_WS_TICK(1)
       VK_WS_TILE_END(__syncthreads())
     } else {
@@ -620,13 +879,13 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
 
 template <bool kBf16, bool kL2, bool kTiming>
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_kernel(FlatFilterArgs a) {
-  flat_filter_body<kBf16, kL2, kTiming>(a);
+  flat_filter_body<kBf16, kL2, kTiming, false>(a);
 }
-// the same kernel under another name for the pass over the bound's sample (a few per cent of the rows), so that a
-// profile's per-kernel averages are averages over launches of one size
+// the pass over the bound's sample (every s-th tile of the index, a few per cent of the rows): the same pipeline, group
+// bounds instead of survivors
 template <bool kBf16, bool kL2>
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_sample_kernel(FlatFilterArgs a) {
-  flat_filter_body<kBf16, kL2, false>(a);
+  flat_filter_body<kBf16, kL2, false, true>(a);
 }
 
 size_t flat_filter_lds_bytes() {
@@ -646,19 +905,19 @@ hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s) {
-  if (a.nqt == 0 || a.nqt > 8 || blocks == 0) return hipErrorInvalidValue;
+  if (a.nqt == 0 || a.nqt > 8 || blocks == 0 || a.n_tiles == 0 || (a.mode == 1 && a.sample_gap == 0)) return hipErrorInvalidValue;
   const size_t lds = flat_filter_lds_bytes();
   const void *fn = a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, true, false>)
                                   : reinterpret_cast<const void *>(&flat_filter_kernel<true, false, false>))
                           : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_kernel<false, true, false>)
                                   : reinterpret_cast<const void *>(&flat_filter_kernel<false, false, false>));
-  if (a.sample_pass)
+  if (a.mode == 1)
     fn = a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_sample_kernel<true, true>)
                         : reinterpret_cast<const void *>(&flat_filter_sample_kernel<true, false>))
                 : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_sample_kernel<false, true>)
                         : reinterpret_cast<const void *>(&flat_filter_sample_kernel<false, false>));
   if (a.timing) {
-    if (a.bf16 || a.l2) return hipErrorInvalidValue;
+    if (a.bf16 || a.l2 || a.mode == 1) return hipErrorInvalidValue;
     fn = reinterpret_cast<const void *>(&flat_filter_kernel<false, false, true>);
   }
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (above the 64 KB default)

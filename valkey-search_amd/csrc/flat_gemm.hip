@@ -277,7 +277,7 @@ __device__ __forceinline__ void stage_mfma(f32x16 (&acc)[16], const Frag f) {
 template <int kAblate, int kMode, bool kRegList, bool kBf16>
 __device__ __forceinline__ void flat_gemm_body(const FlatGemmArgs &a) {
   extern __shared__ float lds[];
-  if (a.run_flag && __hip_atomic_load(a.run_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.run_if) return;
+  if (launch_skipped(a.run_flag, a.run_if, a.run_hi)) return;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it in a scalar register

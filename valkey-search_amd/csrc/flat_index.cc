@@ -109,7 +109,7 @@ SearchCtx::~SearchCtx() {
   if (busy) (void)hipEventDestroy(busy);
   if (stream) (void)hipStreamSynchronize(stream);
   for (DevBuf *b : {&d_q, &d_part_d, &d_part_l, &d_out_d, &d_out_l, &d_out_n, &d_allow, &d_idx, &d_tmp, &d_stats, &d_sync, &d_pool, &d_pool2, &d_redo,
-                    &d_fq16, &d_fthr, &d_fcnt, &d_fcand, &d_fpart_d, &d_fpart_l, &d_allow_tab})
+                    &d_fq16, &d_fthr, &d_fcnt, &d_fcand, &d_fspill, &d_fsmax, &d_fpart_d, &d_fpart_l, &d_allow_tab})
     b->release();
   for (PinBuf *b : {&h_q, &h_out_d, &h_out_l, &h_out_n, &h_tmp, &h_idx, &h_cancel}) b->release();
   if (stream) (void)hipStreamDestroy(stream);
@@ -394,9 +394,10 @@ class FlatIndex final : public Index {
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * k * 8, hipMemcpyDeviceToHost, ctx->stream));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.p, ctx->d_out_n.p, rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (filter_used_) {   // survivor counts + the overflow flag of the candidate filter, for vk_index_stats
-      VK_TRY(ctx->h_tmp.ensure(rq.nq * 4 + 4));
-      VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_fcnt.p, rq.nq * 4 + 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (filter_used_) {   // survivor counts + the number of handed-over queries of the candidate filter, for vk_index_stats
+      // (layout of the batch's words: scan_filter -- [nq] counts | [nq] flags | spill_next, redo_cnt, ...)
+      VK_TRY(ctx->h_tmp.ensure(rq.nq * 8 + 8));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_fcnt.p, rq.nq * 8 + 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     VK_TRY(ctx->wait(rq.cancel_flag));   // (a raised flag stops the kernels: the answer is what they had, bruteforce.h:129)
     if (filter_used_) {
@@ -404,7 +405,7 @@ class FlatIndex final : public Index {
       uint64_t sum = 0;
       for (uint64_t q = 0; q < rq.nq; ++q) sum += c[q];
       last_filter_cands_ = sum;
-      last_filter_fallback_ = c[rq.nq];
+      last_filter_fallback_ = c[2 * rq.nq + 1];   // queries the exact redo pass answered
     } else {
       last_filter_cands_ = 0;
       last_filter_fallback_ = 0;
@@ -597,11 +598,16 @@ class FlatIndex final : public Index {
     // K4h + exact re-rank: a batch large enough that the exact matrix-core kernel is the bottleneck, an index large
     // enough that the pre-pass sample is a small part of it
     if (!lb_dist_ && nq >= filter_min_queries_ && !cancel_raised(cancel) && !force_scan_ && filter_enabled_ &&
-        flat_filter_supported(store_.stride_f(), k, store_.bf16(), l2()) && (l2() || k > 10 || flat_gemm_supported(store_.stride_f(), k)) &&
+        flat_filter_supported(store_.stride_f(), k, store_.bf16(), l2()) &&
         count >= 8 * filter_prepass_rows(k) && count >= filter_min_rows_) {
-      const uint32_t *d_cancel = cancel_word;
-      if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
-      return scan_filter(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel);
+      VK_TRY(ensure_row_stats());
+      // (an index that is mostly tiles the f16 pipe cannot carry -- un-normalised rows with values beyond 32768 -- would
+      // send every pair to the re-rank: the exact kernels below serve it)
+      if ((uint64_t)filter_bad_tiles_.load(std::memory_order_relaxed) * 64 <= count / 128) {
+        const uint32_t *d_cancel = cancel_word;
+        if (!d_cancel) VK_TRY(ctx->arm_cancel(cancel, &d_cancel));
+        return scan_filter(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel);
+      }
     }
     // K4: enough queries to feed the matrix cores, inner-product space (IP / COSINE)
     if (!l2() && !lb_dist_ && nq >= kGemmMinQueries && !cancel_raised(cancel) && flat_gemm_supported(store_.stride_f(), k) && !force_scan_) {
@@ -619,7 +625,9 @@ class FlatIndex final : public Index {
   // K3 (+ merge) over rows [0, row_end): the VALU scan; run_flag: device-side conditional launch (kernels.hpp)
   Status scan_k3(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t row_end, const uint64_t *d_allow,
                  uint64_t allow_nbits, const uint32_t *d_cancel, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n,
-                 hipStream_t s, uint64_t out_ld, const uint32_t *run_flag = nullptr, uint32_t run_if = 0) {
+                 hipStream_t s, uint64_t out_ld, const uint32_t *run_flag = nullptr, uint32_t run_if = 0, uint32_t run_hi = 0,
+                 const uint32_t *q_index = nullptr) {
+    // q_index != nullptr: redo mode -- nq is the most queries the launch serves, *run_flag of them are listed in q_index
     int e = flat_scan_slots_per_lane(k);
     const uint32_t chunks = store_.stride_f() / 16;
     if ((size_t)chunks * 64 > 160 * 1024) return Status::Err(VK_ERR_INVALID, "dimension too large for the LDS query block");
@@ -660,6 +668,9 @@ class FlatIndex final : public Index {
       a.cancel = d_cancel;
       a.run_flag = run_flag;
       a.run_if = run_if;
+      a.run_hi = run_hi;
+      a.q_index = q_index;
+      a.nq_dev = q_index ? run_flag : nullptr;
       VK_HIP_TRY(launch_flat_scan(a, l2(), store_.bf16(), qb, e, s));
     }
     MergeArgs m{};
@@ -676,6 +687,9 @@ class FlatIndex final : public Index {
     m.out_n = d_out_n;
     m.run_flag = run_flag;
     m.run_if = run_if;
+    m.run_hi = run_hi;
+    m.q_index = q_index;
+    m.nq_dev = q_index ? run_flag : nullptr;
     VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
     return Status::Ok();
   }
@@ -737,14 +751,18 @@ class FlatIndex final : public Index {
   Status scan_gemm(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
                    uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
                    uint64_t out_ld = 0, const uint32_t *d_cancel = nullptr, const float *bound_given = nullptr,
-                   const uint32_t *run_flag = nullptr, uint32_t run_if = 0) {
+                   const uint32_t *run_flag = nullptr, uint32_t run_if = 0, uint32_t run_hi = 0) {
     if (out_ld == 0) out_ld = k;
+    // run_flag != nullptr: the candidate filter's whole-batch hand-over (k <= 10: lists in registers).  It is enqueued
+    // behind every filtered batch and almost never runs, so it takes nothing that would cost a launch of its own: no
+    // pre-pass bound, no lockstep window (whose progress words need clearing), no shared bound word.
+    const bool handover = run_flag != nullptr;
     // pre-pass (this kernel over the first rows): a valid bound on every query's k-th best distance, so the per-lane
     // lists of K4 start gated instead of accepting everything until they have filled
     const float *init_bound = bound_given;   // (the candidate-filter path has run its own, larger, pre-pass)
     // (more rows for a larger k: the bound is the k-th best of the sample, and the lists of K4 pay per insert)
     const uint64_t pre_rows = gemm_prepass_rows_ * ((k + 9) / 10);
-    if (!bound_given && pre_rows && count >= 8 * pre_rows && !in_prepass_) {
+    if (!bound_given && pre_rows && count >= 8 * pre_rows && !in_prepass_ && !handover) {
       in_prepass_ = true;   // the same kernel over the first rows only
       Status ps = scan_gemm(ctx, d_q, nq, k, pre_rows, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s);
       in_prepass_ = false;
@@ -778,21 +796,24 @@ class FlatIndex final : public Index {
     VK_TRY(ctx->d_part_l.ensure((size_t)nq * per_q * 8));
     g.part_dist = ctx->d_part_d.as<float>();
     g.part_label = ctx->d_part_l.as<uint64_t>();
-    g.lockstep = g.nqt > 1 && g.nqt <= 32 ? gemm_lockstep_ : 0;
+    g.lockstep = g.nqt > 1 && g.nqt <= 32 && !handover ? gemm_lockstep_ : 0;
     g.contig = gemm_contig_;
     g.cancel = in_prepass_ ? nullptr : d_cancel;
     g.run_flag = run_flag;
     g.run_if = run_if;
+    g.run_hi = run_hi;
     // [ progress words | per-query bounds ]
     const size_t sync_bytes = (size_t)nrp * 4 * 32 * 4;
     VK_TRY(ctx->d_sync.ensure(sync_bytes + nq * 4));
     g.sync = ctx->d_sync.as<uint32_t>();
     g.qbound = g.sync + sync_bytes / 4;
-    VK_HIP_TRY(hipMemsetAsync(g.sync, 0, sync_bytes, s));
-    if (init_bound)   // lists kept in HBM (k > 10) read the shared bound once per tile: start it at the pre-pass bound
-      VK_HIP_TRY(hipMemcpyAsync(g.qbound, reinterpret_cast<const uint32_t *>(init_bound) + nq, nq * 4, hipMemcpyDeviceToDevice, s));
-    else
-      VK_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g.qbound), (int)0xFF800000u, nq, s));   // key of +inf
+    if (!handover) {   // (the hand-over launch neither waits on the progress words nor reads the shared bound)
+      VK_HIP_TRY(hipMemsetAsync(g.sync, 0, sync_bytes, s));
+      if (init_bound)   // lists kept in HBM (k > 10) read the shared bound once per tile: start it at the pre-pass bound
+        VK_HIP_TRY(hipMemcpyAsync(g.qbound, reinterpret_cast<const uint32_t *>(init_bound) + nq, nq * 4, hipMemcpyDeviceToDevice, s));
+      else
+        VK_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g.qbound), (int)0xFF800000u, nq, s));   // key of +inf
+    }
     VK_HIP_TRY(launch_flat_gemm(g, s));
     MergeArgs m{};
     m.in_dist = g.part_dist;
@@ -808,6 +829,7 @@ class FlatIndex final : public Index {
     m.out_n = d_out_n;
     m.run_flag = run_flag;
     m.run_if = run_if;
+    m.run_hi = run_hi;
     VK_HIP_TRY(launch_merge_topk(m, flat_scan_slots_per_lane(k), nq, s));
     return Status::Ok();
   }
@@ -823,69 +845,92 @@ class FlatIndex final : public Index {
     tp.pending = false;
   }
 
-  // The sample whose exact k-th best distance bounds the whole index's, for the candidate filter: the final pass keeps
-  // about count * k / sample rows per query (380 at 10M rows, k = 10).  At most 1/32 of the index, so that finding the
-  // sample's own k-th best -- a filter pass over it -- stays a few per cent of the batch.
+  // The sample behind the candidate filter's bound: every s-th 128-row tile of the index, about `filter_prepass_rows_`
+  // rows per 10 of k and at most 1/32 of the index (so that the pass over it stays a few per cent of the batch).  The
+  // final pass keeps about count * k / sample rows per query (380 at 10M rows, k = 10).
   uint64_t filter_prepass_rows(uint64_t k) const {
     const uint64_t kk = (k + 9) / 10, cap = filter_prepass_rows_ * kk;
     return std::max<uint64_t>(std::min<uint64_t>(cap, count_ / 32), std::min<uint64_t>(cap, 1024 * kk));
   }
-  // ... and the seed: the first rows of the sample, the only ones the exact matrix-core kernel (1/16 of the f16 rate)
-  // looks at; their k-th best bounds the sample's (sample * k / seed candidates per query there)
-  uint64_t filter_seed_rows(uint64_t k, uint64_t sample) const {
-    const uint64_t seed = filter_seed_rows_ * ((k + 9) / 10);
-    return sample >= 2 * seed ? seed : sample;
-  }
 
-  // the largest row norm / element of the index, brought up to date for the rows written since the last call (once
-  // after a writer phase; the searches of a reader phase find nothing to do)
+  // Row statistics for the candidate filter -- per 128-row tile the largest row norm (or "not an f16 tile"), for L2 the
+  // half norms -- brought up to date for the rows written since the last call (once after a writer phase; the searches
+  // of a reader phase find nothing to do).  filter_bad_tiles_ = tiles the f16 pipe cannot carry.
   Status ensure_row_stats() {
     std::lock_guard<std::mutex> g(stats_mu_);
     uint64_t lo, hi;
-    const bool first = d_rowstats_.p == nullptr;
-    if (first) {
+    bool all = false;
+    if (d_rowstats_.p == nullptr) {
       VK_TRY(d_rowstats_.ensure(64));
       VK_HIP_TRY(hipMemsetAsync(d_rowstats_.p, 0, 64, store_.stream()));
+      all = true;
     }
-    bool all = first;
-    if (l2() && d_hn16_.cap < store_.alloc_rows() * 4) {   // (the half-norm table follows the row table's size)
+    const size_t tile_bytes = (size_t)((store_.alloc_rows() + RowStore::kRowSlack + 127) / 128) * 4;
+    if (d_tile_r2_.cap < tile_bytes) {   // (the per-tile table follows the row table's size)
+      VK_TRY(d_tile_r2_.ensure(tile_bytes));
+      VK_HIP_TRY(hipMemsetAsync(d_tile_r2_.p, 0, d_tile_r2_.cap, store_.stream()));
+      VK_HIP_TRY(hipMemsetAsync(d_rowstats_.p, 0, 64, store_.stream()));
+      all = true;
+    }
+    if (l2() && d_hn16_.cap < store_.alloc_rows() * 4) {
       VK_TRY(d_hn16_.ensure(store_.alloc_rows() * 4));
       all = true;
     }
     if (store_.take_written(&lo, &hi) || all) {
       if (all) { lo = 0; hi = count_; }
       hi = std::min<uint64_t>(hi, store_.alloc_rows());
-      VK_HIP_TRY(launch_row_stats(store_.d_rows(), store_.bf16(), store_.stride_f(), (uint32_t)lo, (uint32_t)hi,
-                                  d_rowstats_.as<uint32_t>(), l2() ? d_hn16_.as<uint32_t>() : nullptr, store_.stream()));
+      VK_HIP_TRY(launch_row_stats(store_.d_rows(), store_.bf16(), l2(), store_.stride_f(), (uint32_t)lo, (uint32_t)hi,
+                                  (uint32_t)((count_ + 127) / 128), d_rowstats_.as<uint32_t>(), d_tile_r2_.as<uint32_t>(),
+                                  l2() ? d_hn16_.as<uint32_t>() : nullptr, store_.stream()));
+      uint32_t h[3] = {0, 0, 0};
+      VK_HIP_TRY(hipMemcpyAsync(h, d_rowstats_.p, sizeof h, hipMemcpyDeviceToHost, store_.stream()));
       VK_HIP_TRY(hipStreamSynchronize(store_.stream()));
+      filter_bad_tiles_.store(h[2], std::memory_order_relaxed);
     }
     return Status::Ok();
   }
 
-  // K4h pipeline (flat_filter.hip): exact pre-pass over a sample -> bound; f16 matrix-core filter over all rows ->
-  // survivor lists; exact re-rank of the survivors + selection.  Same answer as scan_gemm, bit for bit; when a survivor
-  // list overflows, the exact kernel enqueued behind runs instead (device-side flag, no host round trip).
+  // K4h pipeline (flat_filter.hip), six launches for a batch that needs no hand-over:
+  //   qprep    queries -> f16 fragments, per-query error polynomials, counters cleared
+  //   sample   the filter kernel over every s-th tile: per (64 rows, query) a lower bound of the group's best exact score
+  //   select   per query the k-th largest group bound = a lower bound of its k-th best exact score
+  //   filter   one pass over all rows: the pairs that can still be among a query's k best -> survivor lists
+  //   re-rank  exact distances of the survivors (quad kernel in list mode)
+  //   merge    (distance, label) selection; queries that lost survivors are listed for the redo
+  // and behind them, returning at once unless the redo list is non-empty: the exact scan over the listed queries (up to
+  // kFilterRedoMax), or the exact kernels over the whole batch (more).  Same answer as the exact path, bit for bit.
   Status scan_filter(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t count, const uint64_t *d_allow,
                      uint64_t allow_nbits, float *d_out_d, uint64_t *d_out_l, uint32_t *d_out_n, hipStream_t s,
                      uint64_t out_ld, const uint32_t *d_cancel) {
-    VK_TRY(ensure_row_stats());
     const uint32_t dp = store_.stride_f();
     const uint32_t nqt = (uint32_t)((nq + 31) / 32);
     const uint32_t cap = (uint32_t)std::max<uint64_t>(filter_cap_, 64 * k);
     const int e = flat_scan_slots_per_lane(k);
     const uint32_t nrp = 8;
     const uint64_t per_q = (uint64_t)nrp * (e == 1 ? 1 : 4) * k;   // e == 1: one list per block (merged in LDS), else per wave
-    VK_TRY(ctx->d_stats.ensure(std::max<size_t>(64, nq * 8)));
+    // the sample: n_s sample tiles of 128 rows, row (i * n_s + t) * gap of the index being row i of sample tile t
+    uint64_t n_s = std::min<uint64_t>(std::max<uint64_t>(1, filter_prepass_rows(k) / 128), (uint64_t)kFilterMaxGroups / 2);
+    n_s = std::min<uint64_t>(n_s, count / 128);
+    const uint32_t gap = (uint32_t)std::max<uint64_t>(1, count / (128 * n_s));
+    // group bounds per query: two per sample tile (64 rows each), eight (16 rows each) while that stays within what the
+    // selection holds at 16 values per thread -- the k-th largest of MANY narrow groups is a tighter bound than of few wide
+    // ones, which is what a small sample needs
+    const bool fine = n_s * 8 <= 4096;
+    const uint32_t groups = (uint32_t)n_s * (fine ? 8 : 2);
+    const uint32_t smax_ld = (groups + 63) & ~63u;
+    const uint32_t n_chunks = filter_spill_chunks_;
+    // per-batch words: [nq] survivor counts | [nq] hand-over flags | [4] spill_next, redo_cnt | [nq] redo list | [nq][32] chunk slots
+    const size_t w_cnt = 0, w_ovf = nq, w_misc = 2 * nq, w_redo = 2 * nq + 4, w_chunk = 3 * nq + 4;
+    VK_TRY(ctx->d_fcnt.ensure((w_chunk + nq * kSpillPerQuery) * 4));
     VK_TRY(ctx->d_fq16.ensure((size_t)nqt * 32 * dp * 2));
-    VK_TRY(ctx->d_fthr.ensure((size_t)nqt * 32 * 4));
-    VK_TRY(ctx->d_fcnt.ensure(nq * 4 + 8));
+    VK_TRY(ctx->d_fthr.ensure((size_t)nqt * 32 * (16 + 4 + 4)));      // error polynomials, then bounds, then witness margins
     VK_TRY(ctx->d_fcand.ensure(nq * (size_t)cap * 4));
+    VK_TRY(ctx->d_fspill.ensure((size_t)n_chunks * kSpillChunk * 4));
+    VK_TRY(ctx->d_fsmax.ensure(nq * (size_t)smax_ld * 4));
     VK_TRY(ctx->d_fpart_d.ensure(nq * per_q * 4));
     VK_TRY(ctx->d_fpart_l.ensure(nq * per_q * 8));
-    float *bound = ctx->d_stats.as<float>();
-    uint32_t *ovf = ctx->d_fcnt.as<uint32_t>() + nq;       // the final pass's flag: the exact kernel answers the batch
-    uint32_t *ovf_mid = ovf + 1;                           // the sample pass's flag: the exact kernel bounds the sample
-    VK_HIP_TRY(hipMemsetAsync(ovf, 0, 8, s));
+    uint32_t *words = ctx->d_fcnt.as<uint32_t>();
+    uint32_t *redo_cnt = words + w_misc + 1;
     if (filter_blocks_ == 0) {
       int cus = 0;
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, store_.device());
@@ -893,78 +938,112 @@ class FlatIndex final : public Index {
     }
     static const bool timing = getenv("VK_FILTER_TIMING") && atoi(getenv("VK_FILTER_TIMING")) != 0;
 
-    // the exact kernel over the first `rows_n` rows (for L2, which has no exact matrix-core kernel, the VALU scan);
-    // answers land in the output arrays, k per query
-    auto exact_prefix = [&](uint64_t rows_n, const uint32_t *run_flag, uint32_t run_if) -> Status {
-      // (k > 10: the matrix-core kernel keeps its per-lane lists in HBM scratch and pays O(k) per insert -- over a prefix,
-      // where every row is a candidate at first, 6.6 ms for 81920 rows at k = 100; the scan does it in under a millisecond)
-      if (l2() || k > 10) return scan_k3(ctx, d_q, nq, k, rows_n, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, k, run_flag, run_if);
-      in_prepass_ = true;
-      Status ps = scan_gemm(ctx, d_q, nq, k, rows_n, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, 0, nullptr, nullptr, run_flag, run_if);
-      in_prepass_ = false;
-      return ps;
-    };
-    // queries -> f16 fragments + gates from `bound`; f16 filter over the first `rows_n` rows (one launch per 256
-    // queries, every launch one pass over those rows); exact re-rank of the survivors + selection into the output
-    // arrays (ld entries per query) unless a list overflowed (*flag raised: nothing is written)
-    auto filter_pass = [&](uint64_t rows_n, uint32_t *flag, uint64_t ld, bool timed) -> Status {
-      VK_HIP_TRY(hipMemsetAsync(ctx->d_fcnt.p, 0, nq * 4, s));
-      FlatFilterArgs f{};
-      f.rows = store_.d_rows();
-      f.bf16 = store_.bf16() ? 1 : 0;
-      f.l2 = l2() ? 1 : 0;
-      f.hn16 = l2() ? d_hn16_.as<uint32_t>() : nullptr;
-      f.labels = store_.d_labels();
-      f.allow_bits = d_allow;
-      f.allow_nbits = allow_nbits;
-      f.queries = d_q;
-      f.q_stride_f = dp;
-      f.q16 = ctx->d_fq16.p;
-      f.thr = ctx->d_fthr.as<float>();
-      f.bound = bound;
-      f.row_stats = d_rowstats_.as<uint32_t>();
-      f.cand_cnt = ctx->d_fcnt.as<uint32_t>();
-      f.cand_row = ctx->d_fcand.as<uint32_t>();
-      f.cap = cap;
-      f.ovf = flag;
-      f.row_stride_f = dp;
-      f.n_rows = (uint32_t)rows_n;
-      f.nq = (uint32_t)nq;
-      f.nqt = nqt;
-      f.cancel = d_cancel;
-      f.sample_pass = timed ? 0 : 1;
-      f.timing = timed && timing && !store_.bf16() && !l2();
-      if (f.timing) {   // phase timing experiment: nine counters
-        VK_TRY(ctx->d_idx.ensure(128));
-        VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
-        f.dbg = ctx->d_idx.as<unsigned long long>();
-      }
-      VK_HIP_TRY(launch_flat_qprep(f, s));
-      SearchCtx::TimedPair *tp = nullptr;
-      if (timed) {
-        tp = &ctx->timed[ctx->timed_next++ % 32];
-        drain_timed(*tp);
-        if (!tp->t0) {
-          VK_HIP_TRY(hipEventCreate(&tp->t0));
-          VK_HIP_TRY(hipEventCreate(&tp->t1));
-        }
-        VK_HIP_TRY(hipEventRecord(tp->t0, s));
-      }
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>(filter_blocks_, (rows_n + 127) / 128);
+    FlatFilterArgs f{};
+    f.rows = store_.d_rows();
+    f.bf16 = store_.bf16() ? 1 : 0;
+    f.l2 = l2() ? 1 : 0;
+    f.hn16 = l2() ? d_hn16_.as<uint32_t>() : nullptr;
+    f.labels = store_.d_labels();
+    f.allow_bits = d_allow;
+    f.allow_nbits = allow_nbits;
+    f.queries = d_q;
+    f.q_stride_f = dp;
+    f.q16 = ctx->d_fq16.p;
+    f.qcoef = ctx->d_fthr.as<float4>();
+    f.qbound = reinterpret_cast<float *>(ctx->d_fthr.as<char>() + (size_t)nqt * 32 * 16);
+    f.qwit = f.qbound + (size_t)nqt * 32;
+    f.r2_cap = d_rowstats_.as<uint32_t>() + 3;
+    f.sample_gap = gap;
+    f.tile_r2 = d_tile_r2_.as<uint32_t>();
+    f.cand_cnt = words + w_cnt;
+    f.cand_row = ctx->d_fcand.as<uint32_t>();
+    f.cap = cap;
+    f.qchunk = words + w_chunk;
+    f.spill = ctx->d_fspill.as<uint32_t>();
+    f.spill_next = words + w_misc;
+    f.n_chunks = n_chunks;
+    f.ovf_q = words + w_ovf;
+    f.smax = ctx->d_fsmax.as<float>();
+    f.smax_ld = smax_ld;
+    f.smax_fine = fine ? 1 : 0;
+    f.row_stride_f = dp;
+    f.n_rows = (uint32_t)count;
+    f.nq = (uint32_t)nq;
+    f.nqt = nqt;
+    f.cancel = d_cancel;
+    // (redo_cnt is cleared by a memset node: qprep's blocks do not order among themselves with the merge that counts)
+    VK_HIP_TRY(hipMemsetAsync(redo_cnt, 0, 4, s));
+    VK_HIP_TRY(launch_flat_qprep(f, s));
+    // one launch per 256 queries, every launch one pass over its tiles
+    auto filter_launches = [&](FlatFilterArgs base, uint32_t blocks) -> Status {
       for (uint32_t g0 = 0; g0 < nqt; g0 += 8) {
-        FlatFilterArgs fg = f;
+        FlatFilterArgs fg = base;
+        const size_t c0 = (size_t)g0 * 32;
         fg.nqt = std::min<uint32_t>(8, nqt - g0);
-        fg.nq = (uint32_t)std::min<uint64_t>(256, nq - (uint64_t)g0 * 32);
-        fg.q16 = static_cast<char *>(f.q16) + (size_t)g0 * 32 * dp * 2;
-        fg.thr = f.thr + (size_t)g0 * 32;
-        fg.cand_cnt = f.cand_cnt + (size_t)g0 * 32;
-        fg.cand_row = f.cand_row + (size_t)g0 * 32 * cap;
+        fg.nq = (uint32_t)std::min<uint64_t>(256, nq - c0);
+        fg.q16 = static_cast<char *>(base.q16) + c0 * dp * 2;
+        fg.qcoef = base.qcoef + c0;
+        fg.qbound = base.qbound + c0;
+        fg.qwit = base.qwit + c0;
+        fg.cand_cnt = base.cand_cnt + c0;
+        fg.cand_row = base.cand_row + c0 * cap;
+        fg.qchunk = base.qchunk + c0 * kSpillPerQuery;
+        fg.ovf_q = base.ovf_q + c0;
+        fg.smax = base.smax + c0 * smax_ld;
         VK_HIP_TRY(launch_flat_filter(fg, blocks, s));
       }
-      if (timed) {
-        VK_HIP_TRY(hipEventRecord(tp->t1, s));
-        tp->pending = true;
+      return Status::Ok();
+    };
+    // 1. the bound: group bounds over the sample, then the k-th largest per query
+    {
+      FlatFilterArgs fs = f;
+      fs.mode = 1;
+      fs.n_tiles = (uint32_t)n_s;
+      fs.cancel = nullptr;
+      VK_TRY(filter_launches(fs, (uint32_t)std::min<uint64_t>(filter_blocks_, n_s)));
+      FlatBoundArgs b{};
+      b.smax = f.smax;
+      b.smax_ld = smax_ld;
+      b.groups = groups;
+      b.k = (uint32_t)k;
+      b.nq = (uint32_t)nq;
+      b.qbound = f.qbound;
+      VK_HIP_TRY(launch_flat_bound_select(b, s));
+    }
+    // 2. the filter over all rows
+    {
+      FlatFilterArgs fm = f;
+      fm.mode = 0;
+      fm.n_tiles = (uint32_t)((count + 127) / 128);
+      fm.timing = timing && !store_.bf16() && !l2();
+      if (fm.timing) {   // phase timing experiment: nine counters
+        VK_TRY(ctx->d_idx.ensure(128));
+        VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
+        fm.dbg = ctx->d_idx.as<unsigned long long>();
       }
+      SearchCtx::TimedPair *tp = &ctx->timed[ctx->timed_next++ % 32];
+      drain_timed(*tp);
+      if (!tp->t0) {
+        VK_HIP_TRY(hipEventCreate(&tp->t0));
+        VK_HIP_TRY(hipEventCreate(&tp->t1));
+      }
+      VK_HIP_TRY(hipEventRecord(tp->t0, s));
+      VK_TRY(filter_launches(fm, (uint32_t)std::min<uint64_t>(filter_blocks_, fm.n_tiles)));
+      VK_HIP_TRY(hipEventRecord(tp->t1, s));
+      tp->pending = true;
+      if (fm.timing) {
+        unsigned long long h[9];
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(filter_blocks_, fm.n_tiles);
+        VK_HIP_TRY(hipStreamSynchronize(s));
+        VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, sizeof h, hipMemcpyDeviceToHost));
+        const double w2 = (double)blocks * 2, w4 = (double)blocks * 4;
+        fprintf(stderr, "[vk] filter phases, cycles per wave: row producers issue %.0f  wait+convert+store %.0f  barrier %.0f | "
+                        "query producers issue+wait+store %.0f  barrier %.0f | consumers mfma %.0f  gate %.0f  barrier %.0f\n",
+                h[0] / w2, h[2] / w2, h[3] / w2, h[4] / w2, h[8] / w2, h[5] / w4, h[6] / w4, h[7] / w4);
+      }
+    }
+    // 3. exact re-rank of the survivors + selection
+    {
       FlatScanArgs r{};
       r.rows = store_.d_rows();
       r.labels = store_.d_labels();
@@ -976,7 +1055,7 @@ class FlatIndex final : public Index {
       r.row_stride_f = r.q_stride_f = dp;
       r.chunks = dp / 16;
       r.row_begin = 0;
-      r.row_end = (uint32_t)rows_n;
+      r.row_end = (uint32_t)count;
       r.nq = (uint32_t)nq;
       r.k = (uint32_t)k;
       r.nrp = nrp;
@@ -984,8 +1063,9 @@ class FlatIndex final : public Index {
       r.cand_cnt = f.cand_cnt;
       r.cand_row = f.cand_row;
       r.cand_cap = cap;
-      r.run_flag = flag;
-      r.run_if = 0;
+      r.cand_qchunk = f.qchunk;
+      r.cand_spill = f.spill;
+      r.cand_ovf = f.ovf_q;
       VK_HIP_TRY(launch_flat_scan(r, l2(), store_.bf16(), 1, e, s));
       MergeArgs m{};
       m.in_dist = r.part_dist;
@@ -995,45 +1075,25 @@ class FlatIndex final : public Index {
       m.parts = 1;
       m.per_part = (uint32_t)per_q;
       m.k = (uint32_t)k;
-      m.out_ld = (uint32_t)ld;
+      m.out_ld = (uint32_t)out_ld;
       m.out_dist = d_out_d;
       m.out_label = d_out_l;
       m.out_n = d_out_n;
-      m.run_flag = flag;
-      m.run_if = 0;
+      m.ovf_q = f.ovf_q;
+      m.redo_cnt = redo_cnt;
+      m.redo_list = words + w_redo;
       VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
-      if (f.timing) {
-        unsigned long long h[9];
-        VK_HIP_TRY(hipStreamSynchronize(s));
-        VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, sizeof h, hipMemcpyDeviceToHost));
-        const double w2 = (double)blocks * 2, w4 = (double)blocks * 4;
-        fprintf(stderr, "[vk] filter phases, cycles per wave: row producers issue %.0f  wait+convert+store %.0f  barrier %.0f | "
-                        "query producers issue+wait+store %.0f  barrier %.0f | consumers mfma %.0f  gate %.0f  barrier %.0f\n",
-                h[0] / w2, h[2] / w2, h[3] / w2, h[4] / w2, h[8] / w2, h[5] / w4, h[6] / w4, h[7] / w4);
-      }
-      return Status::Ok();
-    };
-
-    // 1. bound: an upper bound of every query's final k-th best exact distance = its exact k-th best over a sample (the
-    //    first `sample` rows).  The exact kernel runs at 1/16 of the f16 rate, so it only looks at a seed (the first
-    //    `seed` rows); the sample's own k-th best is then found the way the whole index's is: filter the sample with the
-    //    seed's bound, re-rank exactly.  Should that overflow (it holds sample * k / seed candidates per query when all
-    //    goes well), the exact kernel bounds the sample after all.
-    const uint64_t sample = filter_prepass_rows(k), seed = filter_seed_rows(k, sample);
-    if (seed < sample) {
-      VK_TRY(exact_prefix(seed, nullptr, 0));
-      VK_HIP_TRY(launch_kth_bound(d_out_d, d_out_n, (uint32_t)k, (uint32_t)nq, bound, s));
-      VK_TRY(filter_pass(sample, ovf_mid, k, false));
-      VK_TRY(exact_prefix(sample, ovf_mid, 1));
-    } else {
-      VK_TRY(exact_prefix(sample, nullptr, 0));
     }
-    VK_HIP_TRY(launch_kth_bound(d_out_d, d_out_n, (uint32_t)k, (uint32_t)nq, bound, s));
-    // 2. the filter over all rows + exact re-rank of the survivors ...
-    VK_TRY(filter_pass(count, ovf, out_ld, true));
-    // 3. ... or the exact kernel over everything (only when the flag is up: its blocks return at once otherwise)
-    if (l2() || !flat_gemm_supported(store_.stride_f(), k)) VK_TRY(scan_k3(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld, ovf, 1));
-    else VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, bound, ovf, 1));
+    // 4. the hand-over (decided on the device; these launches return at once when the redo list is empty): the exact
+    //    scan over the listed queries alone, or -- more than kFilterRedoMax of them -- the exact kernels over the batch
+    VK_TRY(scan_k3(ctx, d_q, kFilterRedoMax, k, count, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld, redo_cnt, 1,
+                   kFilterRedoMax, words + w_redo));
+    if (!l2() && k <= 10 && flat_gemm_supported(store_.stride_f(), k))
+      VK_TRY(scan_gemm(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_out_d, d_out_l, d_out_n, s, out_ld, d_cancel, nullptr, redo_cnt,
+                       kFilterRedoMax + 1, 0xFFFFFFFFu));
+    else
+      VK_TRY(scan_k3(ctx, d_q, nq, k, count, d_allow, allow_nbits, d_cancel, d_out_d, d_out_l, d_out_n, s, out_ld, redo_cnt,
+                     kFilterRedoMax + 1, 0xFFFFFFFFu));
     filter_used_ = true;
     return Status::Ok();
   }
@@ -1043,10 +1103,12 @@ class FlatIndex final : public Index {
   uint64_t filter_min_queries_ = getenv("VK_FILTER_MIN_QUERIES") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_QUERIES")) : 5;
   uint64_t filter_min_rows_ = getenv("VK_FILTER_MIN_ROWS") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_ROWS")) : 262144;
   uint64_t filter_prepass_rows_ = getenv("VK_FILTER_PREPASS") ? (uint64_t)atoll(getenv("VK_FILTER_PREPASS")) : 262144;
-  uint64_t filter_seed_rows_ = getenv("VK_FILTER_SEED") ? (uint64_t)atoll(getenv("VK_FILTER_SEED")) : 8192;
   uint64_t filter_cap_ = getenv("VK_FILTER_CAP") ? (uint64_t)atoll(getenv("VK_FILTER_CAP")) : 8192;
+  // spill chunks (of kSpillChunk survivors) a batch's queries share beyond their private lists: 16 MB per context
+  uint32_t filter_spill_chunks_ = getenv("VK_FILTER_SPILL_CHUNKS") ? (uint32_t)atoi(getenv("VK_FILTER_SPILL_CHUNKS")) : 1024;
   uint32_t filter_blocks_ = 0;
-  DevBuf d_rowstats_, d_hn16_;
+  DevBuf d_rowstats_, d_hn16_, d_tile_r2_;
+  std::atomic<uint32_t> filter_bad_tiles_{0};   // tiles the f16 pipe cannot carry (row_stats_kernel)
   std::mutex stats_mu_;
   std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0}, filter_ns_total_{0}, filter_batches_{0};
   static thread_local bool filter_used_;

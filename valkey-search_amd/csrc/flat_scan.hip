@@ -32,7 +32,7 @@ namespace vk {
 template <int kQB, bool kL2, int kE, bool kBf16, bool kLb = false, bool kIdx = false>
 __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   extern __shared__ float4 qs[];  // [kQB][chunks][4] float4 == kQB padded queries
-  if (a.run_flag && __hip_atomic_load(a.run_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.run_if) return;
+  if (launch_skipped(a.run_flag, a.run_if, a.run_hi)) return;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 3;
@@ -45,13 +45,25 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
   const uint32_t rp = (seq / a.nqg) * 8u + xcd;
   const uint32_t qbase = (seq % a.nqg) * kQB;
+  // redo mode: the launch serves the *nq_dev queries listed in q_index (compact numbering from here on)
+  uint32_t nq = a.nq;
+  if constexpr (!kLb && !kIdx) {
+    if (a.nq_dev) {
+      const uint32_t n = *a.nq_dev;
+      nq = n < nq ? n : nq;
+      if (qbase >= nq) return;
+    }
+  }
 
   // stage the query block: queries past nq replicate the last one (results discarded)
   {
     const uint32_t per_q = chunks * 4;
     for (uint32_t i = threadIdx.x; i < per_q * kQB; i += blockDim.x) {
       uint32_t qi = i / per_q, off = i - qi * per_q;
-      uint32_t q = qbase + qi < a.nq ? qbase + qi : a.nq - 1;
+      uint32_t q = qbase + qi < nq ? qbase + qi : nq - 1;
+      if constexpr (!kLb && !kIdx) {
+        if (a.q_index) q = a.q_index[q];
+      }
       qs[i] = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f)[off];
     }
   }
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
 #pragma unroll
   for (int qi = 0; qi < kQB; ++qi) {
     top[qi].init(a.k);
-    const uint32_t q = qbase + qi < a.nq ? qbase + qi : a.nq - 1;
+    const uint32_t q = qbase + qi < nq ? qbase + qi : nq - 1;
     lbd[qi] = kLb ? a.lb_dist[q] : -__builtin_inff();
     lbl[qi] = kLb ? a.lb_label[q] : 0;
   }
@@ -71,13 +83,22 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   const uint32_t total_waves = a.nrp * 4;   // nrp is a multiple of 8
   const uint32_t wave_gid = rp * 4 + wave;
   uint32_t n_rows = a.row_end - a.row_begin;
-  const uint32_t *cand = nullptr;
+  const uint32_t *cand = nullptr, *cand_chunks = nullptr;
   if constexpr (kIdx) {
-    const uint32_t q = qbase < a.nq ? qbase : a.nq - 1;
+    const uint32_t q = qbase < nq ? qbase : nq - 1;
     const uint32_t c = a.cand_cnt[q];
-    n_rows = c < a.cand_cap ? c : a.cand_cap;
+    const uint32_t most = a.cand_cap + (a.cand_qchunk ? kSpillPerQuery * kSpillChunk : 0u);
+    n_rows = c < most ? c : most;
+    if (a.cand_ovf && a.cand_ovf[q]) n_rows = 0;   // survivors were lost: the exact redo pass answers this query
     cand = a.cand_row + (size_t)q * a.cand_cap;
+    cand_chunks = a.cand_qchunk ? a.cand_qchunk + (size_t)q * kSpillPerQuery : nullptr;
   }
+  // entry i of the block's survivor list: the private list, then the query's spill chunks
+  auto cand_at = [&](uint32_t i) -> uint32_t {
+    if (i < a.cand_cap) return cand[i];
+    const uint32_t jj = i - a.cand_cap;
+    return a.cand_spill[(size_t)(cand_chunks[jj / kSpillChunk] - 2u) * kSpillChunk + jj % kSpillChunk];   // (slot = chunk + 2)
+  };
   const uint32_t n_tiles = (n_rows + kRowsPerWave - 1) / kRowsPerWave;
 
   uint32_t polled = 0;
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
     if constexpr (kIdx) {
       const uint32_t i = tile * kRowsPerWave + rq;
       valid = i < n_rows;
-      row = lrow = cand[valid ? i : n_rows - 1];
+      row = lrow = cand_at(valid ? i : n_rows - 1);
     } else {
       row = a.row_begin + tile * kRowsPerWave + rq;
       valid = row < a.row_end;
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
           }
         }
         const uint32_t q = qbase + qi;
-        if (q < a.nq) {
+        if (q < nq) {
           const size_t base = ((size_t)q * a.nrp + rp) * a.k;
           top[qi].store(a.part_dist + base, a.part_label + base, lane);
         }
@@ -193,12 +214,31 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
 #pragma unroll
     for (int qi = 0; qi < kQB; ++qi) {
       const uint32_t q = qbase + qi;
-      if (q < a.nq) {
+      if (q < nq) {
         const size_t base = ((size_t)q * total_waves + wave_gid) * a.k;
         top[qi].store(a.part_dist + base, a.part_label + base, lane);
       }
     }
   }
+}
+
+// Which query a merge block serves, and whether it has anything to do.  Plain launch: block b = query b.  Redo mode
+// (MergeArgs::q_index): block b = compact query b < *nq_dev, lists at index b, output of query q_index[b].  A query the
+// candidate filter handed over (ovf_q) is appended to the redo list and left to the exact pass.
+__device__ __forceinline__ bool merge_block_query(const MergeArgs &a, uint64_t *q_in, uint64_t *q_out) {
+  if (launch_skipped(a.run_flag, a.run_if, a.run_hi)) return false;
+  uint64_t qi = blockIdx.x, qo = blockIdx.x;
+  if (a.nq_dev) {
+    if (qi >= *a.nq_dev) return false;
+    qo = a.q_index[qi];
+  }
+  if (a.ovf_q && a.ovf_q[qo]) {
+    if (threadIdx.x == 0) a.redo_list[atomicAdd(a.redo_cnt, 1u)] = (uint32_t)qo;
+    return false;
+  }
+  *q_in = qi;
+  *q_out = qo;
+  return true;
 }
 
 // One wave per query: k best of `n_entries` (distance,label) pairs, written ascending.
@@ -208,10 +248,10 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
   // one block of four waves per query: each wave merges every fourth 256-entry slab into its own list, then
   // waves 1..3 hand their lists to wave 0 through LDS (a lone wave spent its time waiting for dependent loads)
   extern __shared__ float merge_lds[];
-  if (a.run_flag && __hip_atomic_load(a.run_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.run_if) return;
+  uint64_t q, q_out;
+  if (!merge_block_query(a, &q, &q_out)) return;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const uint64_t q = blockIdx.x;
   WaveTopK<kE> top;
   top.init(a.k);
   for (uint32_t part = 0; part < a.parts; ++part) {
@@ -267,8 +307,8 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
   }
   // rank sort of the kept entries (all keys distinct: labels are unique)
   const uint32_t cnt = top.cnt;
-  float *od = a.out_dist + q * a.out_ld;
-  uint64_t *ol = a.out_label + q * a.out_ld;
+  float *od = a.out_dist + q_out * a.out_ld;
+  uint64_t *ol = a.out_label + q_out * a.out_ld;
   for (uint32_t s = a.k + lane; s < a.out_ld; s += kWave) { od[s] = __builtin_inff(); ol[s] = kNoLabel; }
 #pragma unroll
   for (int e = 0; e < kE; ++e) {
@@ -287,7 +327,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs a) {
     if (s < cnt) { od[rank] = top.d[e]; ol[rank] = top.lab[e]; }
     if (s >= cnt && s < a.k) { od[s] = __builtin_inff(); ol[s] = kNoLabel; }
   }
-  if (lane == 0) a.out_n[q] = cnt;
+  if (lane == 0) a.out_n[q_out] = cnt;
 }
 
 // Distances of an explicit row list (K8).  out[i] = distance(query, rows[idx[i]]).
@@ -371,9 +411,9 @@ __global__ __launch_bounds__(256) void merge_select_kernel(MergeArgs a) {
   __shared__ uint64_t c_l[64];
   __shared__ float v_d[kSelSurvivors];
   __shared__ uint64_t v_l[kSelSurvivors];
-  if (a.run_flag && __hip_atomic_load(a.run_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.run_if) return;
+  uint64_t q, q_out;
+  if (!merge_block_query(a, &q, &q_out)) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t q = blockIdx.x;
   const uint32_t total = a.parts * a.per_part;
 
   uint32_t key[kSelPerThread];
@@ -422,11 +462,11 @@ __global__ __launch_bounds__(256) void merge_select_kernel(MergeArgs a) {
   for (int u = 0; u < kSelPerThread; ++u) c += (uint32_t)__popcll(__ballot(lab[u] != kNoLabel));
   const uint32_t real = block_sum(c);
   const uint32_t k = real < a.k ? real : a.k;
-  float *od = a.out_dist + q * a.out_ld;
-  uint64_t *ol = a.out_label + q * a.out_ld;
+  float *od = a.out_dist + q_out * a.out_ld;
+  uint64_t *ol = a.out_label + q_out * a.out_ld;
   for (uint32_t s = tid; s < a.out_ld; s += 256)
     if (s >= k) { od[s] = __builtin_inff(); ol[s] = kNoLabel; }
-  if (tid == 0) a.out_n[q] = k;
+  if (tid == 0) a.out_n[q_out] = k;
   if (k == 0) return;
 
   // Fast path.  Wave 0 finds the k-th smallest key U of 256 of its entries (a sample; wave-local, no barriers);

@@ -45,7 +45,7 @@ constexpr uint64_t kZeroCopyEntries = 4096;   // nq * k
 struct SearchCtx {
   hipStream_t stream = nullptr;
   DevBuf d_q, d_part_d, d_part_l, d_out_d, d_out_l, d_out_n, d_allow, d_idx, d_tmp, d_stats, d_sync, d_pool, d_pool2, d_redo,
-      d_fq16, d_fthr, d_fcnt, d_fcand, d_fpart_d, d_fpart_l,   // candidate filter (flat_filter.hip)
+      d_fq16, d_fthr, d_fcnt, d_fcand, d_fspill, d_fsmax, d_fpart_d, d_fpart_l,   // candidate filter (flat_filter.hip)
       d_allow_tab;                                             // per-query filter table + the bitmaps behind it
   PinBuf h_q, h_out_d, h_out_l, h_out_n, h_tmp, h_idx, h_cancel;
   // In-kernel cancellation: the caller's flag (any host memory) cannot be read by the device, so the thread that

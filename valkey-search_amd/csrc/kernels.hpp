@@ -31,10 +31,25 @@ struct FlatScanArgs {
   const uint32_t *cand_cnt;
   const uint32_t *cand_row;
   uint32_t cand_cap;
-  // device-side conditional launch: the kernel returns at once unless *run_flag == run_if (run_flag == nullptr: always runs)
+  // ... continued, for the queries that have more survivors than cand_cap, in spill chunks of kSpillChunk entries:
+  // entry cand_cap + j of query q is cand_spill[(cand_qchunk[q * kSpillPerQuery + j / kSpillChunk] - 2) * kSpillChunk +
+  // j % kSpillChunk]; a query whose cand_ovf word is up lost survivors (spill exhausted) and is skipped here -- the
+  // exact redo pass answers it
+  const uint32_t *cand_qchunk;
+  const uint32_t *cand_spill;
+  const uint32_t *cand_ovf;
+  // redo mode (the exact pass over the queries the candidate filter handed over): the launch serves *nq_dev <= nq
+  // queries, compact query i being query q_index[i] of the batch (its row in `queries`); partial lists are indexed by i
+  const uint32_t *q_index;
+  const uint32_t *nq_dev;
+  // device-side conditional launch (run_flag == nullptr: always runs): the kernel returns at once unless
+  // *run_flag == run_if, or -- with run_hi != 0 -- unless run_if <= *run_flag <= run_hi
   const uint32_t *run_flag;
-  uint32_t run_if;
+  uint32_t run_if, run_hi;
 };
+constexpr uint32_t kSpillChunk = 4096;      // entries per spill chunk of the candidate filter's survivor lists
+constexpr uint32_t kSpillPerQuery = 32;     // chunks one query may take (131072 survivors beyond its private list)
+constexpr uint32_t kFilterRedoMax = 8;      // up to this many handed-over queries are re-scanned on their own; more: the whole batch
 constexpr uint32_t kCancelPollTiles = 16;
 constexpr uint32_t kCancelPollHops = 16;
 
@@ -65,7 +80,7 @@ struct FlatGemmArgs {
   uint32_t contig;            // 1: a row partition owns a contiguous range of tiles, 0: tiles rp, rp+nrp, ...
   const uint32_t *cancel;     // optional, as FlatScanArgs::cancel (polled every kCancelPollTiles 128-row tiles)
   const uint32_t *run_flag;   // as FlatScanArgs::run_flag
-  uint32_t run_if;
+  uint32_t run_if, run_hi;
 };
 // K4h (flat_filter.hip): candidate stage of the batched FLAT search on the f16 matrix cores
 struct FlatFilterArgs {
@@ -79,24 +94,62 @@ struct FlatFilterArgs {
   const float *queries;       // [nq][q_stride_f] f32, padded (input of flat_qprep_kernel)
   uint32_t q_stride_f;
   void *q16;                  // [nqt][row_stride_f/16][64][8] f16: the queries in MFMA fragment order (written by qprep)
-  float *thr;                 // [nqt*32] gate in dot space per query column (+inf = closed, -inf = open)
-  const float *bound;         // [nq] upper bound of each query's final k-th best exact distance (+inf = none)
-  const uint32_t *row_stats;  // [2] f32 bits: largest |row|^2, largest |element| (row_stats_kernel)
-  uint32_t *cand_cnt;         // [nq] survivors per query (zeroed before the launch; may exceed cap)
-  uint32_t *cand_row;         // [nq][cap] their row slots
+  // per query column (written by qprep): the error margin of an approximate score against a row of norm R as a
+  // polynomial  E(R) = c2 R^2 + c1 R + c0  (x, y, z), and the column's state (w: 0 = live, 1 = closed -- a padding
+  // column, or a query that cannot go through f16 and was handed to the exact pass)
+  float4 *qcoef;
+  // per query column: a lower bound of the k-th best exact score in accumulator space (written by the bound
+  // selection from the sample's group maxima; -inf = no bound, the gate is open)
+  float *qbound;
+  // per 128-row tile (row_stats_kernel): the largest |row|^2 of the tile as f32 bits, rounded up; +inf for a tile with
+  // a value the f16 pipe cannot carry (non-finite, beyond 32768, half norm beyond f16 for L2): every pair of such a
+  // tile survives and is settled by the exact re-rank
+  const uint32_t *tile_r2;
+  uint32_t *cand_cnt;         // [nq] survivors per query (zeroed by qprep; may exceed what was stored)
+  uint32_t *cand_row;         // [nq][cap] their row slots ...
   uint32_t cap;
-  uint32_t *ovf;              // [1] raised when a list overflowed: the exact kernel answers the batch
+  uint32_t *qchunk;           // [nq][kSpillPerQuery] ... continued in spill chunks (2 + chunk index, 0 = none, 1 = being claimed; zeroed by qprep)
+  uint32_t *spill;            // [n_chunks][kSpillChunk]
+  uint32_t *spill_next;       // [1] chunks handed out (zeroed by qprep)
+  uint32_t n_chunks;
+  uint32_t *ovf_q;            // [nq] raised for a query that lost survivors (or cannot go through f16): the exact pass answers it
+  // sample pass (mode 1): instead of gating, every (group of 64 rows, query) writes a LOWER BOUND of the group's best
+  // exact score -- its best approximate score minus the margin -- to smax[q * smax_ld + group]; the k-th largest
+  // of a query's group bounds bounds its k-th best exact score from below (k distinct rows reach it)
+  uint32_t mode;
+  float *smax;
+  uint32_t smax_ld;
+  uint32_t smax_fine;         // 1: eight groups of 16 rows per tile and query instead of two of 64 (a small sample)
+  // The sample is made of n_tiles "sample tiles" of 128 rows spread over the WHOLE index: local row i of sample tile t is
+  // index row (i * n_tiles + t) * sample_gap, so rows that are neighbours in the index land in different sample tiles,
+  // hence in different groups -- a narrow run of similar rows (an index loaded cluster by cluster) still puts k of its
+  // rows into k distinct groups.  Witness rows carry the margin of the norm cap *r2_cap (row_stats: a robust upper norm
+  // of the index's tiles); a row from a tile beyond the cap is no witness (the producers poison it with a NaN, which
+  // the group maximum ignores).  qwit[j] = the column's margin at the cap (qprep).
+  uint32_t sample_gap;
+  const uint32_t *r2_cap;
+  float *qwit;
+  uint32_t n_tiles;           // tiles this launch walks (mode 0: ceil(n_rows / 128); mode 1: sample tiles)
   uint32_t row_stride_f, n_rows, nq;
   uint32_t nqt;               // query tiles of 32 (<= 8 per launch)
   const uint32_t *cancel;
-  uint32_t sample_pass;       // the pass over the bound's sample: same code, launched as flat_filter_sample_kernel
   uint32_t timing;            // VK_FILTER_TIMING=1: the kernel variant with cycle counters per phase (f32 rows, IP only)
   unsigned long long *dbg;    // timing: [9] cycles per phase, summed over the waves (see the kernel)
 };
+// bound selection: qbound[q] = the k-th largest of smax[q][0 .. groups) (-inf when fewer than k are finite)
+struct FlatBoundArgs {
+  const float *smax;
+  uint32_t smax_ld, groups, k, nq;
+  float *qbound;
+};
 size_t flat_filter_lds_bytes();
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2);
-hipError_t launch_row_stats(const void *rows, bool bf16, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *hn16,
-                            hipStream_t s);
+// stats: [0] largest |row|^2, [1] largest |element| of the index (f32 bits), [2] tiles flagged +inf so far, [3] the norm
+// cap of the sample's witnesses: |row|^2 bits that 97 % of the finite tiles stay below (recomputed over n_tiles tiles)
+hipError_t launch_row_stats(const void *rows, bool bf16, bool l2, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t n_tiles,
+                            uint32_t *stats, uint32_t *tile_r2, uint32_t *hn16, hipStream_t s);
+hipError_t launch_flat_bound_select(const FlatBoundArgs &a, hipStream_t s);
+constexpr uint32_t kFilterMaxGroups = 16384;   // group bounds per query the selection holds in registers (8192 sample tiles)
 hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s);
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s);
 
@@ -116,7 +169,16 @@ struct MergeArgs {
   uint64_t *out_label;
   uint32_t *out_n;            // [nq]
   const uint32_t *run_flag;   // as FlatScanArgs::run_flag
-  uint32_t run_if;
+  uint32_t run_if, run_hi;
+  // candidate-filter bookkeeping (optional): the block of a query whose ovf_q word is up appends it to redo_list
+  // (redo_cnt = its length) and writes nothing -- the exact redo pass owns that query's output
+  const uint32_t *ovf_q;
+  uint32_t *redo_cnt;
+  uint32_t *redo_list;
+  // redo mode (as FlatScanArgs): block i serves compact query i < *nq_dev, reading lists at index i and writing the
+  // output of query q_index[i]
+  const uint32_t *q_index;
+  const uint32_t *nq_dev;
 };
 
 struct GatherArgs {
