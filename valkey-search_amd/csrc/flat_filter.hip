@@ -176,22 +176,30 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
   for (uint32_t k8 = lane; k8 < a.row_stride_f / 8; k8 += kWave) {
     const float4 u = reinterpret_cast<const float4 *>(src)[k8 * 2], v = reinterpret_cast<const float4 *>(src)[k8 * 2 + 1];
     const float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-    f16x8 h;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      h[t] = (_Float16)e[t];                            // round to nearest even
       n2 = fmaf(e[t], e[t], n2);
       mx = fmaxf(mx, fabsf(e[t]));
       bad = bad || !(e[t] - e[t] == 0.f);
     }
-    const uint32_t ks = k8 >> 1, g = k8 & 1;
-    reinterpret_cast<f16x8 *>(a.q16)[((size_t)(jt * ks_n + ks) * kWave + g * 32 + jj)] = h;
   }
 #pragma unroll
   for (int m = 1; m < kWave; m <<= 1) {
     n2 += __shfl_xor(n2, m);
     mx = fmaxf(mx, __shfl_xor(mx, m));
     bad = bad || __shfl_xor((int)bad, m);
+  }
+  // a query that cannot go through f16 (values beyond its range, non-finite): its products could be NaN, which passes
+  // every gate -- the column gets ZERO fragments and a closed gate, and the query is handed to the exact pass, alone
+  const bool f16_ok = !bad && mx <= 32768.f;
+  for (uint32_t k8 = lane; k8 < a.row_stride_f / 8; k8 += kWave) {
+    const float4 u = reinterpret_cast<const float4 *>(src)[k8 * 2], v = reinterpret_cast<const float4 *>(src)[k8 * 2 + 1];
+    const float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    f16x8 h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) h[t] = f16_ok ? (_Float16)e[t] : (_Float16)0.f;   // round to nearest even
+    const uint32_t ks = k8 >> 1, g = k8 & 1;
+    reinterpret_cast<f16x8 *>(a.q16)[((size_t)(jt * ks_n + ks) * kWave + g * 32 + jj)] = h;
   }
   if (j < a.nq && lane < kSpillPerQuery) a.qchunk[(size_t)j * kSpillPerQuery + lane] = 0u;
   if (lane != 0) return;
@@ -217,11 +225,9 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
       c1 = (c1 + be * qn) * 1.001f;
       c0 = (c0 + 0.5f * qn * qn * (al + be)) * 1.001f;
     }
-    // a query that cannot go through f16 (values beyond its range, non-finite): its products may be NaN -- the column
-    // is closed and the query handed to the exact pass, alone
-    const bool f16_ok = !bad && mx <= 32768.f && (c0 - c0 == 0.f) && (c1 - c1 == 0.f);
-    co = make_float4(c2, c1, c0, f16_ok ? 0.f : 1.f);
-    a.ovf_q[j] = f16_ok ? 0u : 1u;
+    const bool live = f16_ok && (c0 - c0 == 0.f) && (c1 - c1 == 0.f);
+    co = make_float4(c2, c1, c0, live ? 0.f : 1.f);
+    a.ovf_q[j] = live ? 0u : 1u;
   }
   a.qcoef[j] = co;
   // the column's margin for the witnesses of the sample: rows of norm up to the cap (see FlatFilterArgs::r2_cap)
@@ -333,21 +339,27 @@ __device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing
 
 // The column's gate for a tile whose largest row norm is R (r2 = R^2 as f32 bits, +inf = a tile that cannot go through
 // f16: everything passes).  A pair stays unless approx < thr.
-struct GateCol { float c2, c1, c0, bound, slack; bool closed; };
-__device__ __forceinline__ float tile_margin(const GateCol &c, float R) { return fmaf(fmaf(c.c2, R, c.c1), R, c.c0); }
+// (bound = +inf closes the column: a padding column, or a query handed to the exact pass)
+template <bool kL2> struct GateCol { float c1, c0, bound; };
+template <> struct GateCol<true> { float c2, c1, c0, bound; };
+template <bool kL2> __device__ __forceinline__ float tile_margin(const GateCol<kL2> &c, float R) {
+  if constexpr (kL2) return fmaf(fmaf(c.c2, R, c.c1), R, c.c0);
+  else return fmaf(c.c1, R, c.c0);
+}
 __device__ __forceinline__ float tile_norm(uint32_t r2_bits) { return sqrtf(__uint_as_float(r2_bits)) * 1.0001f; }
-__device__ __forceinline__ float gate_thr(const GateCol &c, uint32_t r2_bits) {
+template <bool kL2> __device__ __forceinline__ float gate_thr(const GateCol<kL2> &c, uint32_t r2_bits) {
   const float R = tile_norm(r2_bits);
-  float thr = (c.bound - tile_margin(c, R)) - c.slack;
-  if (!(R < __builtin_inff()) || !(thr == thr)) thr = -__builtin_inff();
-  return c.closed ? __builtin_inff() : thr;
+  // (2^-21 max(1, |bound|): the rounding of the subtractions that make the threshold out of bound and margin)
+  float thr = (c.bound - tile_margin<kL2>(c, R)) - 0x1p-21f * fmaxf(1.f, fabsf(c.bound));
+  if (!(thr == thr)) thr = -__builtin_inff();                       // (a tile beyond f16: R = +inf)
+  return c.bound == __builtin_inff() ? __builtin_inff() : thr;
 }
 
 // Tile done: the gate.  Output register r of row tile rt is row rt*32 + (r&3) + 8*(r>>2) + 4*g, column li of the wave's
 // query tile.  Almost every 32 x 32 block has no survivor: one max over the lane's 16 values, one ballot.  (The test is
 // "not below", so that a NaN -- a tile or a query outside f16 -- passes.)
 template <int kRt, bool kZero>
-__device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[kRt], float thr, bool closed, uint32_t tile_row0,
+__device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[kRt], float thr, uint32_t tile_row0,
                                             uint32_t wave, uint32_t li, uint32_t g, SurvivorRing &ring, uint32_t lane) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -362,7 +374,7 @@ __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&ac
       uint32_t mk = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) mk |= !(acc[rt][r] < thr) ? 1u << r : 0u;
-      if (q >= a.nq || closed) mk = 0;
+      if (q >= a.nq) mk = 0;
       while (__builtin_amdgcn_ballot_w64(mk != 0) != 0) {
         const uint32_t r = (uint32_t)__builtin_ctz(mk | 0x10000u);
         const uint32_t row = tile_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -386,16 +398,16 @@ __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&ac
   }
 }
 
+template <bool kBf16> __device__ __forceinline__ size_t sample_row(const FlatFilterArgs &a, uint32_t tile, uint32_t i);
 // Sample mode: instead of gating, the lane's best approximate score over its rows of the sample tile minus the margin at
 // the norm cap -- a lower bound of the exact score of one of those rows -- goes to smax[query][group].  Coarse groups (a
 // large sample): the lane's 64 rows of the tile (half g of all four 32-row blocks), group = 2 * sample tile + g.  Fine
 // groups (a small sample, where the k-th largest of few group bounds would be a poor bound): its 16 rows of each block,
 // group = (4 * sample tile + block) * 2 + g.  Rows that are no witnesses arrive as NaN (fmaxf ignores them); with a
 // filter only allowed rows count (a witness must be a row the search may return).
-template <int kRt>
-__device__ __forceinline__ void sample_max(const FlatFilterArgs &a, const f32x16 (&acc)[kRt], const GateCol &c, uint32_t tile, uint32_t q,
-                                           uint32_t g) {
-  const float margin = c.c0 + c.slack;
+template <int kRt, bool kBf16>
+__device__ __forceinline__ void sample_max(const FlatFilterArgs &a, const f32x16 (&acc)[kRt], float margin, bool closed, uint32_t tile,
+                                           uint32_t q, uint32_t g) {
   float best = -__builtin_inff();
 #pragma unroll
   for (int rt = 0; rt < kRt; ++rt) {
@@ -407,20 +419,19 @@ __device__ __forceinline__ void sample_max(const FlatFilterArgs &a, const f32x16
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t i = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const size_t row = (size_t)(i * a.n_tiles + tile) * a.sample_gap;
-        if (allow_bit(a.allow_bits, a.allow_nbits, a.labels[row])) m = fmaxf(m, acc[rt][r]);
+        if (allow_bit(a.allow_bits, a.allow_nbits, a.labels[sample_row<kBf16>(a, tile, i)])) m = fmaxf(m, acc[rt][r]);
       }
     }
     if (a.smax_fine) {
       float lb = m - margin;
-      if (c.closed || !(lb == lb)) lb = -__builtin_inff();
+      if (closed || !(lb == lb)) lb = -__builtin_inff();
       if (q < a.nq) a.smax[(size_t)q * a.smax_ld + (tile * (uint32_t)kRt + rt) * 2u + g] = lb;
     }
     best = fmaxf(best, m);
   }
   if (!a.smax_fine) {
     float lb = best - margin;
-    if (c.closed || !(lb == lb)) lb = -__builtin_inff();
+    if (closed || !(lb == lb)) lb = -__builtin_inff();
     if (q < a.nq) a.smax[(size_t)q * a.smax_ld + tile * 2u + g] = lb;
   }
 }
@@ -498,29 +509,44 @@ __device__ __forceinline__ void ws_rows_load(WsRows<kBf16> &s, const FlatFilterA
       s.v[u] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(u * step), 2));
   }
 }
-// Sample mode: the 128 rows of sample tile `tile` are index rows (i * n_tiles + tile) * sample_gap, i = 0 .. 127 -- 64-bit
-// addresses (the rows span the whole table), which cost more to issue than the descriptor form above and do not matter
-// for a pass over a few per cent of the index.  With the first stage of a tile the thread also looks up whether its rows'
-// tiles lie beyond the norm cap.
+// Sample mode: local row i of sample tile `tile` is index row sample_row(i) = ((u * n_tiles + tile) * kR + i0) * gap with
+// i = u * kR + i0 and kR = the rows one load instruction of the producers covers (8 for f32 rows, 16 for bf16): a run
+// of kR neighbouring sample rows, and the tile's 128 / kR runs spread over the whole index -- the descriptor of piece u
+// carries the run's 64-bit base, the thread's 32-bit offset stays inside the run.  With the first stage of a tile the
+// thread also looks up whether its rows' tiles lie beyond the norm cap.
+template <bool kBf16> __device__ __forceinline__ size_t sample_row(const FlatFilterArgs &a, uint32_t tile, uint32_t i) {
+  constexpr uint32_t kR = kBf16 ? 16 : 8;
+  return ((size_t)((i / kR) * a.n_tiles + tile) * kR + i % kR) * a.sample_gap;
+}
 template <bool kBf16, bool kL2>
 __device__ __forceinline__ void ws_rows_load_sample(WsRows<kBf16> &s, const FlatFilterArgs &a, uint32_t tile, uint32_t st, uint32_t t,
                                                     uint32_t cap_bits) {
   constexpr size_t esz = kBf16 ? 2 : 4;
+  constexpr int kPieces = kBf16 ? 8 : 16;
+  constexpr uint32_t kR = kBf16 ? 16 : 8;
   const size_t row_bytes = (size_t)a.row_stride_f * esz;
-  if constexpr (kL2) s.hn = a.hn16[(size_t)(t * a.n_tiles + tile) * a.sample_gap];
-  constexpr int kPieces = kBf16 ? 8 : 16, kRowStep = kBf16 ? 16 : 8;
+  if constexpr (kL2) s.hn = a.hn16[sample_row<kBf16>(a, tile, t)];
   const uint32_t i0 = kBf16 ? t >> 3 : t >> 4;
-  const char *base = static_cast<const char *>(a.rows) + (size_t)st * kFStageK * esz + (size_t)(kBf16 ? (t & 7) : (t & 15)) * 16;
+  const uint32_t voff = i0 * a.sample_gap * (uint32_t)row_bytes + (kBf16 ? (t & 7) : (t & 15)) * 16u;
+  const char *base = static_cast<const char *>(a.rows) + (size_t)st * kFStageK * esz;
+  // (the tile look-ups are requested BEFORE the rows: loads return in order, so waiting for them leaves the rows in flight)
   uint32_t pz = 0;
+  if (st == 0) {
+    uint32_t r2[kPieces];
 #pragma unroll
-  for (int u = 0; u < kPieces; ++u) {
-    const size_t row = (size_t)((i0 + (uint32_t)(kRowStep * u)) * a.n_tiles + tile) * a.sample_gap;
-    const u32x4v v = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(base + row * row_bytes));
-    if constexpr (kBf16) s.v[u] = v;
-    else s.v[u] = __builtin_bit_cast(f32x4v, v);
-    if (st == 0) pz |= (a.tile_r2[row >> 7] > cap_bits ? 1u : 0u) << u;
+    for (int u = 0; u < kPieces; ++u)
+      r2[u] = a.tile_r2[((size_t)((uint32_t)u * a.n_tiles + tile) * kR + i0) * a.sample_gap >> 7];
+#pragma unroll
+    for (int u = 0; u < kPieces; ++u) pz |= (r2[u] > cap_bits ? 1u : 0u) << u;
   }
   s.pz = pz;
+#pragma unroll
+  for (int u = 0; u < kPieces; ++u) {
+    const size_t run = (size_t)((uint32_t)u * a.n_tiles + tile) * kR * a.sample_gap;       // first index row of the run
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(ws_rsrc(base + run * row_bytes), (int)voff, 0, 2);
+    if constexpr (kBf16) s.v[u] = v;
+    else s.v[u] = __builtin_bit_cast(f32x4v, v);
+  }
 }
 // -> f16 in LDS.  f32 rows: round to nearest even.  bf16 rows: bf16 -> f32 is a shift and f32 -> f16 is then EXACT for
 // every value in f16's normal range (8 significant bits fit 11), so a bf16 index carries no row rounding error at all.
@@ -753,20 +779,27 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   ring.row = ring.q + kWave;
   ring.cnt = 0;
   const bool has_q = wave * 2 < a.nqt;
-  GateCol col[2];
+  // per query tile of the wave: the column's gate (bound + error polynomial), or in sample mode its margin at the norm cap
+  GateCol<kL2> col[2];
+  float wit[2];
+  bool closed[2];
 #pragma unroll
   for (int t2 = 0; t2 < 2; ++t2) {
     const bool have = wave * 2 + t2 < a.nqt;
     const uint32_t jc = have ? (wave * 2 + t2) * 32 + li : 0u;
     const float4 co = a.qcoef[jc];
-    const float b = kSample ? 0.f : a.qbound[jc];
-    col[t2].c2 = kSample ? 0.f : co.x;
-    col[t2].c1 = kSample ? 0.f : co.y;
-    col[t2].c0 = kSample ? a.qwit[jc] : co.z;               // (sample mode: the margin at the norm cap, a constant)
-    col[t2].closed = !have || co.w != 0.f;
-    col[t2].bound = b;
-    // (the rounding of the subtractions that make the threshold out of bound and margin)
-    col[t2].slack = kSample ? 0x1p-21f : 0x1p-21f * fmaxf(1.f, fabsf(b));
+    closed[t2] = !have || co.w != 0.f;
+    if constexpr (kSample) {
+      wit[t2] = a.qwit[jc] + 0x1p-21f;
+      col[t2].c1 = col[t2].c0 = col[t2].bound = 0.f;
+      if constexpr (kL2) col[t2].c2 = 0.f;
+    } else {
+      wit[t2] = 0.f;
+      if constexpr (kL2) col[t2].c2 = co.x;
+      col[t2].c1 = co.y;
+      col[t2].c0 = co.z;
+      col[t2].bound = closed[t2] ? __builtin_inff() : a.qbound[jc];
+    }
   }
   f32x16 acc[2][4];
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -848,11 +881,11 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     if (st_c == stages) {
       if (has_q) {
         if constexpr (kSample) {
-          sample_max<4>(a, acc[0], col[0], tile_row0, (wave * 2) * 32 + li, g);
-          sample_max<4>(a, acc[1], col[1], tile_row0, (wave * 2 + 1) * 32 + li, g);
+          sample_max<4, kBf16>(a, acc[0], wit[0], closed[0], tile_row0, (wave * 2) * 32 + li, g);
+          sample_max<4, kBf16>(a, acc[1], wit[1], closed[1], tile_row0, (wave * 2 + 1) * 32 + li, g);
         } else {
-          filter_gate<4, false>(a, acc[0], gate_thr(col[0], r2_bits), col[0].closed, tile_row0, wave * 2, li, g, ring, lane);
-          filter_gate<4, false>(a, acc[1], gate_thr(col[1], r2_bits), col[1].closed, tile_row0, wave * 2 + 1, li, g, ring, lane);
+          filter_gate<4, false>(a, acc[0], gate_thr<kL2>(col[0], r2_bits), tile_row0, wave * 2, li, g, ring, lane);
+          filter_gate<4, false>(a, acc[1], gate_thr<kL2>(col[1], r2_bits), tile_row0, wave * 2 + 1, li, g, ring, lane);
         }
       }
       tile_row0 += row_step;

@@ -120,10 +120,10 @@ struct FlatFilterArgs {
   float *smax;
   uint32_t smax_ld;
   uint32_t smax_fine;         // 1: eight groups of 16 rows per tile and query instead of two of 64 (a small sample)
-  // The sample is made of n_tiles "sample tiles" of 128 rows spread over the WHOLE index: local row i of sample tile t is
-  // index row (i * n_tiles + t) * sample_gap, so rows that are neighbours in the index land in different sample tiles,
-  // hence in different groups -- a narrow run of similar rows (an index loaded cluster by cluster) still puts k of its
-  // rows into k distinct groups.  Witness rows carry the margin of the norm cap *r2_cap (row_stats: a robust upper norm
+  // The sample is made of n_tiles "sample tiles" of 128 rows spread over the WHOLE index: a sample tile is 16 (bf16
+  // rows: 8) runs of 8 (16) rows sample_gap apart, the runs n_tiles * 8 * sample_gap rows apart (sample_row() in
+  // flat_filter.hip), so index neighbours beyond a run land in different sample tiles, hence in different groups -- a
+  // narrow stretch of similar rows (an index loaded cluster by cluster) still puts k of its rows into k distinct groups.  Witness rows carry the margin of the norm cap *r2_cap (row_stats: a robust upper norm
   // of the index's tiles); a row from a tile beyond the cap is no witness (the producers poison it with a NaN, which
   // the group maximum ignores).  qwit[j] = the column's margin at the cap (qprep).
   uint32_t sample_gap;
