@@ -67,7 +67,7 @@ constexpr int kFAStride = 72;                // halfs per staged row: 64 + 8 pad
 }  // namespace
 
 // ---- row statistics: the largest row norm per 128-row tile (and of the index) over rows [lo, hi) ------------------------
-// tile_r2[t] = max over the tile's rows of |x|^2 (f32 bits, rounded up), or +inf when the tile holds a value the f16
+// tile_r2[t] = max over the tile's rows of |x| (the norm, f32 bits, rounded up), or +inf when the tile holds a value the f16
 // pipe cannot carry (non-finite, |x_i| > 32768, for L2 a half norm beyond f16): the filter lets every pair of such a
 // tile through to the exact re-rank.  stats[0] / stats[1] = the same maxima over the whole index (|x|^2, |x_i|; reported,
 // not used by the gate), stats[2] = number of tiles flagged +inf (FlatIndex keeps an index that is mostly such tiles
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32
     const float g_abs = wave_max_f32(mx);
     const bool g_bad = !(g_abs <= 32768.f) || !(g_n2 - g_n2 == 0.f) || (l2 && !(0.5f * g_n2 <= 60000.f));
     if (lane == 0) {
-      const uint32_t v = g_bad ? 0x7F800000u : __float_as_uint(g_n2);
+      const uint32_t v = g_bad ? 0x7F800000u : __float_as_uint(sqrtf(g_n2) * 1.0001f);   // the NORM, rounded up
       const uint32_t old = atomicMax(&tile_r2[(lo + tile * kRowsPerWave) / 128u], v);
       if (g_bad && old != 0x7F800000u) atomicAdd(&stats[2], 1u);
     }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32
   }
 }
 
-// stats[3] = the norm cap of the sample's witnesses: the upper edge of the smallest |row|^2 bin (exponent + 3 mantissa
+// stats[3] = the norm cap of the sample's witnesses: the upper edge of the smallest tile-norm bin (exponent + 3 mantissa
 // bits: 9 % wide) that 97 % of the finite tiles stay below.  A robust "largest ordinary norm": one row of norm 1e6 in a
 // unit-norm index moves the global maximum by six orders of magnitude and this not at all.  One block.
 __global__ __launch_bounds__(1024) void tile_cap_kernel(const uint32_t *tile_r2, uint32_t n_tiles, uint32_t *stats) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
   }
   a.qcoef[j] = co;
   // the column's margin for the witnesses of the sample: rows of norm up to the cap (see FlatFilterArgs::r2_cap)
-  const float Rc = sqrtf(__uint_as_float(*a.r2_cap)) * 1.0001f;
+  const float Rc = __uint_as_float(*a.r2_cap);
   a.qwit[j] = fmaf(fmaf(co.x, Rc, co.y), Rc, co.z);
 }
 
@@ -346,7 +346,7 @@ template <bool kL2> __device__ __forceinline__ float tile_margin(const GateCol<k
   if constexpr (kL2) return fmaf(fmaf(c.c2, R, c.c1), R, c.c0);
   else return fmaf(c.c1, R, c.c0);
 }
-__device__ __forceinline__ float tile_norm(uint32_t r2_bits) { return sqrtf(__uint_as_float(r2_bits)) * 1.0001f; }
+__device__ __forceinline__ float tile_norm(uint32_t r_bits) { return __uint_as_float(r_bits); }   // (row_stats rounded it up)
 template <bool kL2> __device__ __forceinline__ float gate_thr(const GateCol<kL2> &c, uint32_t r2_bits) {
   const float R = tile_norm(r2_bits);
   // (2^-21 max(1, |bound|): the rounding of the subtractions that make the threshold out of bound and margin)

@@ -101,7 +101,7 @@ struct FlatFilterArgs {
   // per query column: a lower bound of the k-th best exact score in accumulator space (written by the bound
   // selection from the sample's group maxima; -inf = no bound, the gate is open)
   float *qbound;
-  // per 128-row tile (row_stats_kernel): the largest |row|^2 of the tile as f32 bits, rounded up; +inf for a tile with
+  // per 128-row tile (row_stats_kernel): the largest row NORM of the tile as f32 bits, rounded up; +inf for a tile with
   // a value the f16 pipe cannot carry (non-finite, beyond 32768, half norm beyond f16 for L2): every pair of such a
   // tile survives and is settled by the exact re-rank
   const uint32_t *tile_r2;
