@@ -387,40 +387,62 @@ def hnsw_sharded_leg(args, flat_ix, table, A, device, stream_ptr, world, rank, r
             "recall_at_10": round(recall, 4), "merge": "all-gather + (distance,label) merge on every rank"}
 
 
-def lib_multi_gpu(args, world, rank, local_rank, dist, device):
-    """--gpus N through the PRODUCT's multi-GPU path: rank 0 holds ONE vk_index with n_shards = N (shard s on HIP device
-    s; vk_index_params.shard_devices), built and searched from this one process like valkey-server would; the other
-    ranks only keep the launch contract (barriers, max-over-ranks timing).  A step = one
-    vk_index_search_batch_device on the sharded index: queries broadcast by peer copy, every shard scans its rows on its
-    own device and stream, per-shard top-k lists gathered on device 0, (distance,label) merge.  Returns the JSON dict
-    on rank 0 (None elsewhere), or raises on rank 0 before any collective if the sharded index cannot be set up."""
+def _fill_shard(ix, shard, r0, n, D, sdev, bf16):
+    """rows [r0, r0 + n) of the synthetic table generated on the shard's own device straight into its HBM row table"""
+    esz = 2 if bf16 else 4
+    ptr, stride = ix.shard_device_rows(shard, n)
+    tab = (device_view_typed(ptr, (n, stride // 2), sdev, "<i2").view(torch.bfloat16) if bf16 else device_view(ptr, (n, stride // 4), sdev))
+    if stride != D * esz:
+        tab[:, D:] = 0
+    for lo, x in gen_rows(r0, n, D, sdev):
+        tab[lo - r0: lo - r0 + x.shape[0], :D] = x
+    torch.cuda.synchronize(sdev)
+    ix.shard_commit_device_rows(shard, n, np.arange(r0, r0 + n, dtype=np.uint64))
+    return tab
+
+
+def _timed_steps(step, steps, warmup):
+    """HIP events on the current stream + the wall clock around `steps` calls (after `warmup` untimed ones)"""
+    for _ in range(max(1, warmup)):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps, (time.perf_counter() - t0) / steps * 1e3
+
+
+def lib_multi_gpu(args, world, rank, dist, device):
+    """--gpus N through the PRODUCT's multi-GPU path: ONE vk_index with n_shards = N (shard s on HIP device s;
+    vk_index_params.shard_devices), built and searched from ONE process like valkey-server would -- `python bench.py
+    --gpus N` needs no launcher; under torch.distributed.run rank 0 does the work and the other ranks only keep the launch
+    contract (barriers, max-over-ranks timing).  A step = one vk_index_search_batch_device on the sharded index: queries
+    broadcast by peer copy, every shard scans its rows on its own device and stream (one enqueue thread per shard),
+    per-shard top-k lists gathered on device 0, (distance,label) merge.  The headline is BASELINE.json configs[1] with
+    the 10M rows dealt over the N GPUs (strong scaling); configs[3] (N x 10M bf16 rows, IP) and configs[4] (one HNSW
+    graph of 1.25M rows per GPU + a TAG filter) run as legs of the same line.  Returns the JSON dict on rank 0 (None
+    elsewhere), or "fallback" if the sharded index cannot be set up and there are ranks to fall back to."""
     N, D, B, K = args.rows, args.dim, args.batch, args.k
     bf16 = args.dtype == "bf16"
     esz = 2 if bf16 else 4
     devs = [0] * world if args.same_device else list(range(world))
-    out = None
+    multi_proc = dist is not None
     state = {}
-    ok = torch.ones(1, device=device if args.backend == "nccl" else "cpu")
+    ok = torch.ones(1, device=device if (multi_proc and args.backend == "nccl") else "cpu")
     if rank == 0:
         try:
             if vsa.lib().vk_device_count() < (1 if args.same_device else world):
-                raise RuntimeError(f"rank 0 sees {vsa.lib().vk_device_count()} HIP devices, needs {world}")
+                raise RuntimeError(f"this process sees {vsa.lib().vk_device_count()} HIP devices, needs {world}")
             t_build = time.time()
             ix = vsa.Index("FLAT", D, "COSINE", initial_cap=N, dtype=args.dtype, shard_devices=devs)
+            tabs = []
             for s_i, dv in enumerate(devs):
                 r0, r1 = s_i * N // world, (s_i + 1) * N // world
-                sdev = torch.device("cuda", dv)
-                ptr, stride = ix.shard_device_rows(s_i, r1 - r0)
-                if bf16:
-                    tab = device_view_typed(ptr, (r1 - r0, stride // 2), sdev, "<i2").view(torch.bfloat16)
-                else:
-                    tab = device_view(ptr, (r1 - r0, stride // 4), sdev)
-                if stride != D * esz:
-                    tab[:, D:] = 0
-                for lo, x in gen_rows(r0, r1 - r0, D, sdev):
-                    tab[lo - r0: lo - r0 + x.shape[0], :D] = x
-                torch.cuda.synchronize(sdev)
-                ix.shard_commit_device_rows(s_i, r1 - r0, np.arange(r0, r1, dtype=np.uint64))
+                tabs.append(_fill_shard(ix, s_i, r0, r1 - r0, D, torch.device("cuda", dv), bf16))
             state["build_s"] = time.time() - t_build
             gA = torch.Generator(device=device)
             gA.manual_seed(1234)
@@ -431,7 +453,7 @@ def lib_multi_gpu(args, world, rank, local_rank, dist, device):
             on = torch.empty(B, device=device, dtype=torch.int32)
             ws = torch.cuda.Stream(device=device)
             torch.cuda.set_stream(ws)
-            state.update(ix=ix, A=A, Q=Q, od=od, ol=ol, on=on, ws=ws)
+            state.update(ix=ix, A=A, Q=Q, od=od, ol=ol, on=on, ws=ws, tabs=tabs)
 
             def step():
                 ix.search_batch_device(Q.data_ptr(), B, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), stream=ws.cuda_stream)
@@ -443,8 +465,11 @@ def lib_multi_gpu(args, world, rank, local_rank, dist, device):
         except Exception as e:   # noqa: BLE001
             ok.zero_()
             state["error"] = f"{type(e).__name__}: {e}"
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if multi_proc:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if float(ok.item()) == 0.0:
+        if not multi_proc:
+            raise RuntimeError(f"bench: the library's multi-GPU path is unavailable: {state.get('error')}")
         if rank == 0:
             print(f"bench: library multi-GPU path unavailable ({state.get('error')}); falling back to one process per GPU",
                   file=sys.stderr)
@@ -453,10 +478,12 @@ def lib_multi_gpu(args, world, rank, local_rank, dist, device):
         return "fallback"
 
     def barrier():
-        dist.barrier()
+        if multi_proc:
+            dist.barrier()
         torch.cuda.synchronize()
 
     barrier()
+    st0 = state["ix"].stats() if rank == 0 else None
     t0 = time.perf_counter()
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -466,17 +493,80 @@ def lib_multi_gpu(args, world, rank, local_rank, dist, device):
         e1.record()
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    if multi_proc:
+        t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    out = None
     if rank == 0:
-        ix, Q, od, ol = state["ix"], state["Q"], state["od"], state["ol"]
+        ix, A, Q, od, ol, tabs = state["ix"], state["A"], state["Q"], state["od"], state["ol"], state["tabs"]
+        st1 = ix.stats()
         dev_ms = e0.elapsed_time(e1) / args.steps
         res_d, res_l = od.cpu().numpy(), ol.cpu().numpy().view(np.uint64)
+        n_local = N // world
+        stride = ((D + 63) // 64) * 64 * esz
+        scan_bytes = n_local * stride                  # algorithmic bytes of one pass over ONE GPU's shard
+        # the dominant kernel per shard: the candidate filter; its duration = the SLOWEST shard's HIP events (the library
+        # records them around the launches on each shard's stream; vk_index_stats of a sharded index reports the maximum)
+        filt_n = st1.filter_batches - st0.filter_batches
+        filt_ms = (st1.filter_kernel_ns - st0.filter_kernel_ns) / 1e6 / filt_n if filt_n else None
+        fan_calls = st1.fanout_calls - st0.fanout_calls
+        fan_us = (st1.fanout_enqueue_ns - st0.fanout_enqueue_ns) / 1e3 / fan_calls if fan_calls else None
+        kern_ms = filt_ms if filt_ms else dev_ms
+        roofline = {"bound": "hbm", "achieved": round(scan_bytes / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(scan_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                    "per_gpu": True, "algorithmic_bytes": scan_bytes,
+                    "kernel": "flat_filter_kernel (slowest shard)" if filt_ms else "whole step (small shard: the exact kernels)",
+                    "per_launch_ms": round(kern_ms, 4), "launches_timed": int(filt_n), "step_ms_on_stream": round(dev_ms, 4),
+                    "hbm_frac_of_whole_step": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "aggregate_gbs": round(world * scan_bytes / (dev_ms * 1e-3) / 1e9, 1),
+                    "host_fanout_enqueue_us_per_step": round(fan_us, 1) if fan_us else None}
+
+        def leg(fn, *a):
+            try:
+                return fn(*a)
+            except Exception as e:   # noqa: BLE001
+                import traceback
+                return {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().strip().splitlines()[-3:]}
+
+        # ---- CPU baseline (same oracle leg as N = 1) + parity of the merged answer on the queries it scanned ----
+        cpu = parity = None
+        host_rows = None
+        need_host = not args.no_cpu_baseline or args.hnsw_rows > 0 or args.hybrid_rows > 0
+        if need_host and not bf16:
+            host_rows = np.empty((N, D), np.float32)
+            for s_i, tab in enumerate(tabs):
+                r0 = s_i * N // world
+                host_rows[r0: r0 + tab.shape[0]] = tab[:, :D].cpu().numpy()
+        if not args.no_cpu_baseline and host_rows is not None:
+            from oracle import oracle as O
+            S = N if args.cpu_rows <= 0 else min(args.cpu_rows, N)
+            flat = O.Flat(D, "COSINE", isa="skylake", max_elements=S)
+            flat.add_many(host_rows[:S], np.arange(S, dtype=np.uint64), borrowed=True)
+            hq = Q.cpu().numpy()
+            threads = effective_cpus()
+            nqt = threads * args.cpu_queries_per_thread
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(threads) as ex:
+                res = list(ex.map(lambda i: flat.search(hq[i % B], K), range(nqt)))
+            cdt = time.perf_counter() - t1
+            full = S == N
+            cpu = {"value": round(nqt / cdt * S / N, 4), "unit": "queries/s", "cores": threads, "kind": "port",
+                   "seconds": round(cdt, 2), "host_gbs": round(nqt * S * D * 4 / cdt / 1e9, 1),
+                   "sample": f"oracle FLAT scan ({O.cpu_path()} clone of the SimSIMD skylake order), {nqt} queries, each a pass over "
+                             f"{'all' if full else 'the first'} {S} rows, one query per thread on {threads} threads (the container's CPU quota)"
+                             + ("" if full else f", scaled linearly to {N} rows")}
+            if full:   # the merged N-shard answer of the timed step against the CPU path: ids and distance bits
+                okp = True
+                for i in range(min(B, len(res))):
+                    e_d, e_l = res[i]
+                    okp = okp and res_l[i].tolist() == e_l.tolist() and res_d[i].view(np.uint32).tolist() == e_d.view(np.uint32).tolist()
+                parity = "bit-exact" if okp else "MISMATCH"
+            del flat
         verify = None
-        if args.verify_merge:   # the N-shard answer must be bit-identical to the 1-shard answer
-            full = vsa.Index("FLAT", D, "COSINE", initial_cap=N, device_id=0, dtype=args.dtype)
-            fp, fstride = full.device_rows(N)
+        if args.verify_merge:   # test aid (small --rows): the N-shard answer must be bit-identical to the 1-shard answer
+            full_ix = vsa.Index("FLAT", D, "COSINE", initial_cap=N, device_id=0, dtype=args.dtype)
+            fp, fstride = full_ix.device_rows(N)
             ft = (device_view_typed(fp, (N, fstride // 2), device, "<i2").view(torch.bfloat16) if bf16
                   else device_view(fp, (N, fstride // 4), device))
             if fstride != D * esz:
@@ -484,65 +574,210 @@ def lib_multi_gpu(args, world, rank, local_rank, dist, device):
             for lo, x in gen_rows(0, N, D, device):
                 ft[lo: lo + x.shape[0], :D] = x
             torch.cuda.synchronize()
-            full.commit_device_rows(N, np.arange(N, dtype=np.uint64))
-            fd, fl, fn = full.search_batch(Q.cpu().numpy(), K)
+            full_ix.commit_device_rows(N, np.arange(N, dtype=np.uint64))
+            fd, fl, fn = full_ix.search_batch(Q.cpu().numpy(), K)
             same = bool((fl == res_l).all() and (fd.view(np.uint32) == res_d.view(np.uint32)).all())
             verify = "bit-identical" if same else "MISMATCH"
-            del full
-        hnsw = None
-        if args.hnsw_sharded and args.hnsw_rows > 0 and not bf16:
-            # one HNSW graph per shard inside ONE index; recall against the sharded FLAT answer over the same rows
-            Nh = min(args.hnsw_rows, N)
-            nq = min(args.hnsw_queries, 2048)
-            Qh = make_queries(state["A"], nq, D, device, 9090)
-            rows = torch.cat([x for _, x in gen_rows(0, Nh, D, device)])[:Nh]
-            host_rows = np.ascontiguousarray(rows.cpu().numpy())
-            del rows
-            t1 = time.perf_counter()
-            h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=args.hnsw_ef, shard_devices=devs)
-            h.add_batch(host_rows)
-            h.flush()
-            hb = time.perf_counter() - t1
-            hd = torch.empty(nq, K, device=device, dtype=torch.float32)
-            hl = torch.empty(nq, K, device=device, dtype=torch.int64)
-            hn = torch.empty(nq, device=device, dtype=torch.int32)
-            ms = timed(lambda: h.search_batch_device(Qh.data_ptr(), nq, K, hd.data_ptr(), hl.data_ptr(), hn.data_ptr(),
-                                                     ef=args.hnsw_ef, stream=state["ws"].cuda_stream), 3)
-            from oracle import oracle as O
-            bits = O.allow_bitmap(np.arange(Nh, dtype=np.uint64), Nh) if Nh < N else None
-            gt = np.empty((nq, K), np.uint64)
-            hq = Qh.cpu().numpy()
-            for i in range(0, nq, 256):
-                _, L, _ = ix.search_batch(hq[i:i + 256], K, allow=bits, allow_nbits=Nh if bits is not None else None)
-                gt[i:i + 256] = L
-            hnsw = {"shards": world, "rows_per_shard": Nh // world, "rows": Nh, "M": 16, "ef_construction": 200, "ef": args.hnsw_ef,
-                    "k": K, "queries_per_batch": nq, "build_s": round(hb, 2), "gpu_qps": round(nq / (ms * 1e-3), 1),
-                    "recall_at_10": round(recall_of(hl.cpu().numpy().view(np.uint64), gt, K), 4),
-                    "merge": "one graph per shard inside one vk_index; per-shard top-k gathered on device 0, (distance,label) merge"}
+            del full_ix
+        hnsw = hybrid = None
+        if args.hnsw_sharded and args.hnsw_rows > 0 and host_rows is not None:
+            hnsw = leg(sharded_hnsw_leg, args, ix, host_rows[:min(args.hnsw_rows, N)], A, device, state["ws"], devs, N)
+        if args.hybrid_rows > 0 and host_rows is not None:
+            hybrid = leg(sharded_hybrid_leg, args, ix, host_rows[:min(args.hybrid_rows * world, N)], A, device, state["ws"], devs, N)
+        host_rows = None
+        cfg3 = None
+        if args.bf16_rows > 0 and not bf16:
+            state.pop("tabs", None)
+            tabs = None
+            cfg3 = leg(sharded_bf16_ip_leg, args, A, device, state["ws"], devs)
         qps = B * args.steps / dt
-        n_local = N // world
-        stride = ((D + 63) // 64) * 64 * esz
-        flops = 2.0 * N * D * B
         out = {"metric": BASELINE_METRIC if not bf16 else "kNN queries/sec, FLAT 10Mx768 bf16-stored cosine k=10 batch=256",
                "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "row_storage": args.dtype, "data": "synthetic",
-               "config": {"workload": f"FLAT {N}x{D} {'bf16 rows' if bf16 else 'fp32'} COSINE k={K} batch={B} (BASELINE.json configs[1])",
-                          "rows_per_gpu": n_local, "sharding": f"rows/{world}", "recall_at_10": 1.0,
-                          "parallelism": f"one vk_index with n_shards={world} in ONE process (rank 0): queries broadcast by peer copy, "
-                                         f"per-shard top-k gathered on device 0, (distance,label) merge; ranks 1..{world - 1} idle",
+               "config": {"workload": f"FLAT {N}x{D} {'bf16 rows' if bf16 else 'fp32'} COSINE k={K} batch={B} (BASELINE.json configs[1]), "
+                                      f"rows dealt over {world} GPUs",
+                          "rows_per_gpu": n_local, "sharding": f"rows/{world}", "recall_at_10": 1.0, "parity_vs_oracle": parity,
+                          "parallelism": f"one vk_index with n_shards={world} in ONE process"
+                                         + (" (rank 0 of the launcher's ranks; the others idle)" if multi_proc else "")
+                                         + ": queries broadcast by peer copy, one enqueue thread per shard, per-shard top-k "
+                                           "gathered on device 0, (distance,label) merge",
                           "devices": devs, "verify_merge": verify},
-               "roofline": {"bound": "mfma", "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 3), "peak": F32_MFMA_PEAK_TF * world,
-                            "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF * world), 5),
-                            "traffic": None, "kernel": "flat_gemm_kernel (per shard)", "per_launch_ms": round(dev_ms, 4),
-                            "algorithmic_bytes": n_local * stride},
-               "cpu_baseline": None, "hnsw": hnsw, "build_s": round(state["build_s"], 2)}
+               "roofline": roofline, "cpu_baseline": cpu, "hnsw": hnsw, "config4_sharded_hybrid": hybrid,
+               "config3_sharded_bf16_ip": cfg3, "build_s": round(state["build_s"], 2)}
         print(json.dumps(out))
         if verify is not None:
             print(json.dumps({"verify_merge": verify, "shards": world, "rows": N}))
             assert verify == "bit-identical"
-    dist.barrier()
-    dist.destroy_process_group()
+    if multi_proc:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def sharded_bf16_ip_leg(args, A, device, ws, devs):
+    """BASELINE.json configs[3]: FLAT, N GPUs x 10M rows of 768 bf16 (weak scaling: 80M rows on 8 GPUs), IP, k=10,
+    batch=256, rows generated per shard on its own device (L2-normalised by the generator, so IP == cosine here).  QPS
+    over the whole index, per-GPU HBM roofline from the slowest shard's filter kernel, and a parity spot check: the
+    answer restricted by a filter to the first rows must equal the oracle's IP answer over the RNE-rounded rows."""
+    from oracle import oracle as O
+    n, D, B, K, S = args.bf16_rows, args.dim, args.batch, args.k, len(devs)
+    t_leg = time.perf_counter()
+    ix = vsa.Index("FLAT", D, "IP", initial_cap=n * S, dtype="bf16", shard_devices=devs)
+    first = None
+    for s_i, dv in enumerate(devs):
+        tab = _fill_shard(ix, s_i, s_i * n, n, D, torch.device("cuda", dv), True)
+        if s_i == 0:
+            first = np.ascontiguousarray(tab[:min(100_000, n), :D].float().cpu().numpy())
+        del tab
+    build_s = time.perf_counter() - t_leg
+    Q = make_queries(A, B, D, device, 4242)
+    od = torch.empty(B, K, device=device, dtype=torch.float32)
+    ol = torch.empty(B, K, device=device, dtype=torch.int64)
+    on = torch.empty(B, device=device, dtype=torch.int32)
+    st0 = ix.stats()
+    ms, wall_ms = _timed_steps(lambda: ix.search_batch_device(Q.data_ptr(), B, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(),
+                                                              stream=ws.cuda_stream), args.steps, args.warmup)
+    st1 = ix.stats()
+    fb = st1.filter_batches - st0.filter_batches
+    fms = (st1.filter_kernel_ns - st0.filter_kernel_ns) / 1e6 / fb if fb else None
+    Sn = first.shape[0]
+    o = O.Flat(D, "IP", isa="skylake", max_elements=Sn)
+    o.add_many(first, np.arange(Sn, dtype=np.uint64), borrowed=True)
+    bits = O.allow_bitmap(np.arange(Sn, dtype=np.uint64), Sn)
+    hq = Q.cpu().numpy()
+    okp = True
+    bd, bl, bn = ix.search_batch(hq[:32], K, allow=bits, allow_nbits=Sn)
+    for i in range(32):
+        e_d, e_l = o.search(hq[i], K)
+        okp = okp and bl[i, :bn[i]].tolist() == e_l.tolist() and bd[i, :bn[i]].view(np.uint32).tolist() == e_d.view(np.uint32).tolist()
+    stride = ((D + 63) // 64) * 64 * 2
+    kern = fms if fms else ms
+    return {"workload": f"BASELINE.json configs[3]: FLAT {n * S}x{D} bf16 rows over {S} GPUs ({n} per GPU), IP, k={K}, batch={B}",
+            "scaling": "weak", "rows": n * S, "rows_per_gpu": n, "gpu_qps": round(B / (wall_ms * 1e-3), 1), "ms_per_step": round(wall_ms, 3),
+            "step_ms_on_stream": round(ms, 3),
+            "roofline": {"bound": "hbm", "per_gpu": True, "algorithmic_bytes": n * stride, "achieved": round(n * stride / (kern * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * stride / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "kernel": "flat_filter_kernel<bf16> (slowest shard)" if fms else "whole step", "per_launch_ms": round(kern, 4)},
+            "aggregate_scan_gbs": round(S * n * stride / (ms * 1e-3) / 1e9, 1),
+            "parity_vs_oracle": "bit-exact" if okp else "MISMATCH", "build_s": round(build_s, 2),
+            "leg_s": round(time.perf_counter() - t_leg, 1)}
+
+
+def _exact_gt(flat_ix, hq, K, bits, nbits):
+    out = np.empty((hq.shape[0], K), np.uint64)
+    for i in range(0, hq.shape[0], 256):
+        _, L, _ = flat_ix.search_batch(hq[i:i + 256], K, allow=bits, allow_nbits=nbits)
+        out[i:i + 256] = L
+    return out
+
+
+def sharded_hybrid_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows):
+    """BASELINE.json configs[4]: one HNSW graph (M=16, efC=200) of --hybrid-rows rows per GPU inside ONE sharded index +
+    a TAG-like filter as an allow-bitmap (10 % selectivity: the inline-filter branch of planner.cc:21-45), efSearch=256,
+    k=10.  QPS of the sharded search and recall@10 against the exact filtered answer of the sharded FLAT index."""
+    from oracle import oracle as O
+    Nh, D, K, ef_h, S = host_rows.shape[0], args.dim, args.k, 256, len(devs)
+    t_leg = time.perf_counter()
+    h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=ef_h, shard_devices=devs)
+    h.add_batch(host_rows)
+    h.flush()
+    build_s = time.perf_counter() - t_leg
+    nq = min(args.hybrid_queries, 4096)
+    Qh = make_queries(A, nq, D, device, 7070)
+    hq = Qh.cpu().numpy()
+    tag = np.arange(3, Nh, 10, dtype=np.uint64)                                # "tag t3": 10 % of the rows
+    tag_bits = O.allow_bitmap(tag, Nh)
+    d_bits = torch.from_numpy(tag_bits.view(np.int64)).to(device)
+    gt = _exact_gt(flat_ix, hq, K, tag_bits, Nh)
+    od = torch.empty(nq, K, device=device, dtype=torch.float32)
+    ol = torch.empty(nq, K, device=device, dtype=torch.int64)
+    on = torch.empty(nq, device=device, dtype=torch.int32)
+    ms, wall_ms = _timed_steps(lambda: h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef_h,
+                                                             d_allow=d_bits.data_ptr(), allow_nbits=Nh, stream=ws.cuda_stream), 3, 1)
+    rec = recall_of(ol.cpu().numpy().view(np.uint64), gt, K)
+    return {"workload": f"BASELINE.json configs[4]: HNSW M=16 efC=200, {Nh}x{D} fp32 COSINE over {S} GPUs ({Nh // S} rows per graph) "
+                        f"+ TAG filter (10 %), efSearch={ef_h}, k={K}",
+            "shards": S, "rows": Nh, "rows_per_shard": Nh // S, "queries_per_batch": nq, "build_s": round(build_s, 2),
+            "gpu_qps": round(nq / (wall_ms * 1e-3), 1), "ms_per_batch": round(wall_ms, 3), "recall_at_10": round(rec, 4),
+            "merge": "one graph per shard inside one vk_index; per-shard top-k gathered on device 0, (distance,label) merge",
+            "leg_s": round(time.perf_counter() - t_leg, 1)}
+
+
+def sharded_hnsw_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows):
+    """configs[2] over N GPUs: one independent graph per shard (as one per cluster shard in the reference), searched with
+    the same ef ("matched ef": about N times the hops of one graph, recall above the single graph's) and with the
+    smallest per-shard ef whose merged recall@10 reaches the SINGLE graph's at efSearch=128 and at its 0.95 point
+    ("matched recall": SURVEY 8e, docs/topics/search.md:84) -- the per-shard ef policy vk_index_params.shard_ef_pct
+    stands for.  The single graph over the same rows is built on device 0 for the reference recalls."""
+    Nh, D, K, ef, S = host_rows.shape[0], args.dim, args.k, args.hnsw_ef, len(devs)
+    t_leg = time.perf_counter()
+    nq = min(args.hnsw_queries, 4096)
+    Qh = make_queries(A, nq, D, device, 9090)
+    hq = Qh.cpu().numpy()
+    bits = nb = None
+    if Nh < total_rows:
+        from oracle import oracle as O
+        bits, nb = O.allow_bitmap(np.arange(Nh, dtype=np.uint64), Nh), Nh
+    gt = _exact_gt(flat_ix, hq, K, bits, nb)
+    od = torch.empty(nq, K, device=device, dtype=torch.float32)
+    ol = torch.empty(nq, K, device=device, dtype=torch.int64)
+    on = torch.empty(nq, device=device, dtype=torch.int32)
+
+    def point(ix, ef_s, reps=3):
+        ms, wall = _timed_steps(lambda: ix.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(),
+                                                               ef=ef_s, stream=ws.cuda_stream), reps, 1)
+        return {"ef": ef_s, "gpu_qps": round(nq / (wall * 1e-3), 1), "ms_per_batch": round(wall, 3),
+                "recall_at_10": round(recall_of(ol.cpu().numpy().view(np.uint64), gt, K), 4)}
+
+    single = None
+    if args.hnsw_single_ref:
+        t0 = time.perf_counter()
+        g1 = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=ef, device_id=devs[0])
+        g1.add_batch(host_rows)
+        g1.flush()
+        sb = time.perf_counter() - t0
+        p128 = point(g1, ef)
+        p95 = None
+        for ef_s in (192, 256, 384, 512, 768, 1024, 1536, 2048):
+            p = point(g1, ef_s, reps=2)
+            if p["recall_at_10"] >= 0.95:
+                p95 = p
+                break
+        single = {"build_s": round(sb, 2), "at_ef": p128, "at_recall_0.95": p95}
+        del g1
+        torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=ef, shard_devices=devs)
+    h.add_batch(host_rows)
+    h.flush()
+    hb = time.perf_counter() - t0
+    matched_ef = point(h, ef)
+    out = {"workload": f"HNSW {Nh}x{D} fp32 COSINE M=16 efC=200 k={K}: one graph per GPU over {S} GPUs ({Nh // S} rows each)",
+           "shards": S, "rows": Nh, "rows_per_shard": Nh // S, "M": 16, "ef_construction": 200, "k": K, "queries_per_batch": nq,
+           "build_s": round(hb, 2), "matched_ef": matched_ef, "single_graph": single,
+           "merge": "one graph per shard inside one vk_index; per-shard top-k gathered on device 0, (distance,label) merge"}
+    if single:
+        def smallest(target, top):
+            best = None
+            for ef_s in sorted({max(K, x) for x in (top, top * 3 // 4, top // 2, top * 3 // 8, top // 4, top * 3 // 16, top // 8, top // 16)}, reverse=True):
+                p = point(h, ef_s, reps=2)
+                if p["recall_at_10"] >= target:
+                    best = p
+                else:
+                    break
+            return best
+        m128 = smallest(single["at_ef"]["recall_at_10"], ef)
+        out["matched_recall_of_single_graph_at_ef"] = None if m128 is None else {
+            **m128, "target_recall": single["at_ef"]["recall_at_10"], "shard_ef_pct": round(100.0 * m128["ef"] / ef, 1),
+            "single_graph_qps": single["at_ef"]["gpu_qps"]}
+        if single["at_recall_0.95"]:
+            top = single["at_recall_0.95"]["ef"]
+            m95 = smallest(0.95, top)
+            out["matched_recall_0.95"] = None if m95 is None else {
+                **m95, "single_graph_ef": top, "shard_ef_pct": round(100.0 * m95["ef"] / top, 1),
+                "single_graph_qps": single["at_recall_0.95"]["gpu_qps"]}
+    out["leg_s"] = round(time.perf_counter() - t_leg, 1)
     return out
 
 
@@ -664,13 +899,15 @@ def main():
     ap.add_argument("--hnsw-ef", type=int, default=128)
     ap.add_argument("--hnsw-queries", type=int, default=8192)
     ap.add_argument("--hnsw-cpu-queries-per-thread", type=int, default=32)
-    ap.add_argument("--hybrid-rows", type=int, default=1_250_000,
-                    help="one shard of BASELINE.json configs[4] (HNSW + TAG filter, efSearch=256): rows (0 = skip)")
+    ap.add_argument("--hybrid-rows", type=int, default=-1,
+                    help="BASELINE.json configs[4] (HNSW + TAG filter, efSearch=256): rows PER GPU, -1 = 1 250 000, 0 = skip")
     ap.add_argument("--hybrid-queries", type=int, default=4096)
     ap.add_argument("--bf16-rows", type=int, default=-1,
                     help="one shard of BASELINE.json configs[3] (FLAT bf16 IP): rows, -1 = as --rows, 0 = skip")
-    ap.add_argument("--hnsw-sharded", action="store_true",
-                    help="N > 1: also run the sharded HNSW leg (one graph per rank; extra collectives after the timed region)")
+    ap.add_argument("--hnsw-sharded", action=argparse.BooleanOptionalAction, default=True,
+                    help="N > 1: the sharded HNSW leg (one graph per GPU; matched-ef and matched-recall points)")
+    ap.add_argument("--hnsw-single-ref", action=argparse.BooleanOptionalAction, default=True,
+                    help="N > 1: build the single graph over the same rows too (the reference recalls of the matched-recall points)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--multi-gpu", choices=["lib", "ranks"], default="lib",
                     help="N > 1: 'lib' = the product's own multi-GPU index (n_shards = N inside one process, rank 0), falling back to "
@@ -681,13 +918,18 @@ def main():
                     help="test aid (N > 1, small --rows): rank 0 also builds the unsharded index and checks the merged answer against it")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    procs = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # --gpus N without a launcher: ONE process drives all N GPUs through the library's sharded index (valkey-server is
+    # one process too).  Under torch.distributed.run (WORLD_SIZE == N) rank 0 does the same and the others keep the
+    # barriers; "--multi-gpu ranks" is the one-process-per-GPU variant (RCCL all-gather of the per-shard top-k).
+    assert procs in (1, args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={procs}"
+    world = args.gpus
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    dist = None
+    if procs > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -700,8 +942,12 @@ def main():
         args.hnsw_rows = N
     if args.bf16_rows < 0:
         args.bf16_rows = N
-    if world > 1 and args.multi_gpu == "lib":
-        if lib_multi_gpu(args, world, rank, local_rank, dist, device) != "fallback":
+    if args.hybrid_rows < 0:
+        args.hybrid_rows = 1_250_000
+    if world > 1 and (args.multi_gpu == "lib" or procs == 1):
+        if procs == 1 and args.multi_gpu != "lib":
+            raise SystemExit("--multi-gpu ranks needs one process per GPU (torch.distributed.run)")
+        if lib_multi_gpu(args, world, rank, dist, device) != "fallback":
             return
     r0 = rank * N // world
     r1 = (rank + 1) * N // world

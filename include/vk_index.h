@@ -87,6 +87,13 @@ typedef struct vk_index_params {
    * shard, like one per cluster shard.  0 = a plain single-device index on device_id. */
   uint32_t n_shards;
   int32_t shard_devices[VK_MAX_SHARDS];
+  /* Sharded HNSW: every shard holds an independent graph over 1/n_shards of the rows and is searched with
+   * ef * shard_ef_pct / 100 (at least k), 0 = 100.  Searching every shard with the full ef costs n_shards times the hops of
+   * one graph for a merged recall ABOVE the single graph's ("may scale sub-linearly", docs/topics/search.md:84); the
+   * percentage that brings the merged recall back to the single graph's is a property of the data (bench.py measures
+   * it: "matched-recall" against "matched-ef"). */
+  uint32_t shard_ef_pct;
+  uint32_t reserved0;
 } vk_index_params;
 
 typedef struct vk_index_stats {

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header(vsa, tmp_path):
     """The ctypes mirrors against what a C compiler makes of include/vk_index.h: size and the
     offset of every field (gcc compiles a probe that prints them)."""
     import subprocess
-    assert C.sizeof(vsa.Params) == 136
+    assert C.sizeof(vsa.Params) == 144
     assert C.sizeof(vsa.Stats) == 152
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vk_index.h"', 'int main(void){']
     for cname, mirror in (("vk_index_params", vsa.Params), ("vk_index_stats", vsa.Stats)):

@@ -461,6 +461,11 @@ class ShardedIndex final : public Index {
       out->staged_ops += t.staged_ops;
       out->max_level = std::max(out->max_level, t.max_level);
       if (s == 0) out->entry_point = t.entry_point;
+      // candidate-filter timing of a fan-out: the shards run side by side, the step waits for the slowest
+      out->filter_batches = s == 0 ? t.filter_batches : std::min(out->filter_batches, t.filter_batches);
+      out->filter_kernel_ns = std::max(out->filter_kernel_ns, t.filter_kernel_ns);
+      out->last_n_eval += t.last_n_eval;
+      out->last_n_hops += t.last_n_hops;
     }
     out->fanout_calls = fanout_calls_.load(std::memory_order_relaxed);
     out->fanout_enqueue_ns = fanout_ns_.load(std::memory_order_relaxed);
@@ -622,6 +627,12 @@ class ShardedIndex final : public Index {
     VK_HIP_TRY(hipStreamWaitEvent(l.stream, mc->ready, 0));
     SearchRequest srq = rq;
     srq.cancel_flag = nullptr;
+    if (params_.algo == VK_ALGO_HNSW && params_.shard_ef_pct != 0 && params_.shard_ef_pct != 100) {
+      // per-shard ef policy (vk_index_params.shard_ef_pct): a fraction of the ef one graph over all rows would be given
+      uint64_t ef = rq.ef ? rq.ef : (params_.ef_runtime ? params_.ef_runtime : 10);
+      ef = (ef * params_.shard_ef_pct + 99) / 100;
+      srq.ef = std::max<uint64_t>(std::max<uint64_t>(ef, rq.k), 1);
+    }
     float *od = mc->d_all_d.as<float>() + s * nk;
     uint64_t *ol = mc->d_all_l.as<uint64_t>() + s * nk;
     uint32_t *on = mc->d_all_n.as<uint32_t>() + s * rq.nq;
