@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
   }
   if (j < a.nq && lane < kSpillPerQuery) a.qchunk[(size_t)j * kSpillPerQuery + lane] = 0u;
   if (lane != 0) return;
-  if (j == 0) *a.spill_next = 0u;
+  if (j == 0) { *a.spill_next = 0u; *a.redo_cnt = 0u; }
   float4 co = make_float4(0.f, 0.f, 0.f, 1.f);          // padding column: closed
   if (j < a.nq) {
     a.cand_cnt[j] = 0u;

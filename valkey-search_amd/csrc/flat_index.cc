@@ -971,8 +971,7 @@ class FlatIndex final : public Index {
     f.nq = (uint32_t)nq;
     f.nqt = nqt;
     f.cancel = d_cancel;
-    // (redo_cnt is cleared by a memset node: qprep's blocks do not order among themselves with the merge that counts)
-    VK_HIP_TRY(hipMemsetAsync(redo_cnt, 0, 4, s));
+    f.redo_cnt = redo_cnt;                   // (cleared by qprep, counted by the merge four launches later)
     VK_HIP_TRY(launch_flat_qprep(f, s));
     // one launch per 256 queries, every launch one pass over its tiles
     auto filter_launches = [&](FlatFilterArgs base, uint32_t blocks) -> Status {

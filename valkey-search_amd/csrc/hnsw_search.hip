@@ -686,9 +686,12 @@ __global__ __launch_bounds__(256, kE == 16 ? 3 : 4) void hnsw_search_kernel(Hnsw
 // (row pieces in flight per lane x waves per SIMD, same 10M graph and batch: 8 x 4 here; 12 x 3 and 24 x 2 +2.5 %,
 // 16 x 3 the same, 16 x 4 and 12 x 4 -- spilling -- 2-4 % slower: the batch is bound by what the memory system does
 // with this mix of accesses, not by one wave's chain of round trips)
+// r03: three waves per SIMD (<= 168 VGPRs) with 12 pieces in flight for every list size -- the 128-register build of the
+// f32 instantiations the 10M bench runs (kE = 2, 4) kept 20-24 registers in scratch, and scratch traffic is exactly the
+// kind of access this kernel has no bandwidth to spare for.
 template <bool kL2, int kE, bool kBf16>
-__global__ __launch_bounds__(256, kE == 16 ? 3 : 4) void hnsw_search_hash_kernel(HnswSearchArgs a) {
-  hnsw_search_body<kL2, kE, kBf16, 8, false, 0, true>(a);
+__global__ __launch_bounds__(256, 3) void hnsw_search_hash_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, (kE <= 4 ? 12 : 8), false, 0, true>(a);   // (8 and 16 slots per lane leave room for 8 pieces only)
 }
 // searches with a filter or tombstones: the frontier lives in HBM (HnswSearchArgs::pool_g)
 template <bool kL2, int kE, bool kBf16>

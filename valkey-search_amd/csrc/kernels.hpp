@@ -112,6 +112,7 @@ struct FlatFilterArgs {
   uint32_t *spill;            // [n_chunks][kSpillChunk]
   uint32_t *spill_next;       // [1] chunks handed out (zeroed by qprep)
   uint32_t n_chunks;
+  uint32_t *redo_cnt;         // [1] length of the redo list the final merge builds (zeroed by qprep)
   uint32_t *ovf_q;            // [nq] raised for a query that lost survivors (or cannot go through f16): the exact pass answers it
   // sample pass (mode 1): instead of gating, every (group of 64 rows, query) writes a LOWER BOUND of the group's best
   // exact score -- its best approximate score minus the margin -- to smax[q * smax_ld + group]; the k-th largest
