@@ -93,7 +93,12 @@ typedef struct vk_index_params {
    * percentage that brings the merged recall back to the single graph's is a property of the data (bench.py measures
    * it: "matched-recall" against "matched-ef"). */
   uint32_t shard_ef_pct;
-  uint32_t reserved0;
+  /* vk_index_load only: 1 = the reference's kill switch `hnsw-validation-enable no` (src/valkey_search_options.cc:
+   * 156-162, hnswalg.h:872-885 loadCheck) for a validation rule that rejects a stream the field needs to load.  The
+   * reference then skips EVERY check; this library still refuses what its device kernels could not survive (sizes,
+   * counts, neighbour ids out of range, links to levels a node does not have) and skips the graph-invariant checks
+   * that are not memory-unsafe: self-loops, mult against M, the entry point's level. */
+  uint32_t load_skip_validation;
 } vk_index_params;
 
 typedef struct vk_index_stats {

@@ -36,7 +36,7 @@ class Params(C.Structure):
                 ("dim", C.c_uint32), ("block_size", C.c_uint32), ("initial_cap", C.c_uint64), ("m", C.c_uint32),
                 ("ef_construction", C.c_uint32), ("ef_runtime", C.c_uint32), ("allow_replace_deleted", C.c_uint32),
                 ("random_seed", C.c_uint64), ("device_id", C.c_int32), ("build_threads", C.c_uint32),
-                ("n_shards", C.c_uint32), ("shard_devices", C.c_int32 * 16), ("shard_ef_pct", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("n_shards", C.c_uint32), ("shard_devices", C.c_int32 * 16), ("shard_ef_pct", C.c_uint32), ("load_skip_validation", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -122,11 +122,12 @@ DTYPE = {"f32": 0, "bf16": 1}
 
 def make_params(algo, dim, metric, initial_cap, block_size=1024, m=16, ef_construction=200, ef_runtime=10,
                 seed=100, allow_replace_deleted=False, device_id=-1, build_threads=0, dtype="f32", shard_devices=None,
-                shard_ef_pct=0) -> Params:
+                shard_ef_pct=0, load_skip_validation=False) -> Params:
     """shard_devices: list of HIP device ordinals, one sub-index per entry (a device may repeat: logical shards)"""
     p = Params(C.sizeof(Params), ALGO[algo], METRIC[metric], DTYPE[dtype], dim, block_size, initial_cap, m, ef_construction,
                ef_runtime, int(allow_replace_deleted), seed, device_id, build_threads)
     p.shard_ef_pct = int(shard_ef_pct)
+    p.load_skip_validation = int(bool(load_skip_validation))
     if shard_devices:
         p.n_shards = len(shard_devices)
         for i, d in enumerate(shard_devices):

@@ -971,12 +971,20 @@ Status HnswIndex::save(vk_write_chunk_fn fn, void *user) {
 
 #define VK_LOAD_CHECK(ok, msg) \
   if (!(ok)) return Status::Err(VK_ERR_INTERNAL, std::string("HNSW index load validation failed: ") + (msg))
+// ... a graph-invariant check whose violation the device kernels survive: skipped under the kill switch
+// (vk_index_params.load_skip_validation = the reference's hnsw-validation-enable no, hnswalg.h:872-885)
+#define VK_LOAD_CHECK_SOFT(ok, msg) \
+  if (!skip_soft) VK_LOAD_CHECK(ok, msg)
 
 Status HnswIndex::load_from(vk_read_chunk_fn fn, void *user) {
   const size_t vec = (size_t)params_.dim * 4;
+  const bool skip_soft = params_.load_skip_validation != 0;
   std::vector<char> buf(std::max<size_t>(vec + 8 + 4 + 8 * 10000, 4096));
   uint64_t len = 0;
   if (fn(user, buf.data(), buf.size(), &len)) return Status::Err(VK_ERR_INTERNAL, "read_chunk failed");
+  // (label_offset and offset_data, fields 5 and 6, are not read at all: like the reference -- hnswalg.h:921-930 -- the
+  // geometry is recomputed from M and the vector size, so a snapshot written before the 8-byte padding of the record
+  // (offset_data = 132 at M = 16, testing/vector_test.cc:764-800) loads like a new one)
   uint64_t f[14] = {0};
   double mult = 0;
   int64_t max_level = 0;
@@ -1002,7 +1010,7 @@ Status HnswIndex::load_from(vk_read_chunk_fn fn, void *user) {
   VK_LOAD_CHECK(f[1] == 0, "offset_level_0 must be 0");
   if (M >= 2) {
     const double expected = 1.0 / log((double)M);
-    VK_LOAD_CHECK(mult > 0.0 && fabs(mult - expected) <= 1e-6 * expected, "mult is inconsistent with M");
+    VK_LOAD_CHECK_SOFT(mult > 0.0 && fabs(mult - expected) <= 1e-6 * expected, "mult is inconsistent with M");
   }
   const size_t max_elements = std::max<size_t>(cur, std::max<size_t>(params_.initial_cap, f[2]));
   VK_LOAD_CHECK(cur <= max_elements, "curr_element_count exceeds max_elements");
@@ -1029,7 +1037,7 @@ Status HnswIndex::load_from(vk_read_chunk_fn fn, void *user) {
     VK_LOAD_CHECK(cnt <= maxM0, "level-0 neighbor count exceeds 2*M");
     for (size_t jn = 0; jn < cnt; ++jn) {
       VK_LOAD_CHECK(ll[1 + jn] < cur, "level-0 neighbor id out of range");
-      VK_LOAD_CHECK(ll[1 + jn] != i, "level-0 self-loop");
+      VK_LOAD_CHECK_SOFT(ll[1 + jn] != i, "level-0 self-loop");
     }
     uint64_t lab;
     memcpy(&lab, buf.data() + sl0 + vec, 8);
@@ -1053,7 +1061,12 @@ Status HnswIndex::load_from(vk_read_chunk_fn fn, void *user) {
     for (int64_t l = 0; l < level; ++l) VK_LOAD_CHECK((w[l * (maxM + 1)] & 0xFFFFu) <= maxM, "upper-level neighbor count exceeds M");
     VK_TRY(graph_->load_upper(i, w, sz / 4));
   }
-  if (cur > 0) VK_LOAD_CHECK(graph_->level_of(enterpoint) == max_level, "enterpoint node is not at max_level");
+  // (under the kill switch a shorter entry point is still refused when it would send the descent through levels it
+  // does not have; a TALLER graph than the header says only means levels the search never enters)
+  if (cur > 0) {
+    VK_LOAD_CHECK_SOFT(graph_->level_of(enterpoint) == max_level, "enterpoint node is not at max_level");
+    VK_LOAD_CHECK(graph_->level_of(enterpoint) >= max_level, "enterpoint node is not at max_level");
+  }
   for (uint32_t i = 0; i < cur; ++i)
     for (int level = 1; level <= graph_->level_of(i); ++level) {
       const uint32_t *ll = graph_->upper(i, level);
@@ -1061,7 +1074,7 @@ Status HnswIndex::load_from(vk_read_chunk_fn fn, void *user) {
       for (size_t jn = 0; jn < cnt; ++jn) {
         const uint32_t e = ll[1 + jn];
         VK_LOAD_CHECK(e < cur, "upper-level neighbor id out of range");
-        VK_LOAD_CHECK(e != i, "upper-level self-loop");
+        VK_LOAD_CHECK_SOFT(e != i, "upper-level self-loop");
         VK_LOAD_CHECK(graph_->level_of(e) >= level, "upper-level neighbor is absent at that level");
       }
     }
