@@ -668,26 +668,32 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   }
   if (wave >= 6) {
     // ================================ query producer =====================================================
-    // iteration S: request B(S+2) into the register set B(S) left, write B(S+1) (requested one iteration ago) to slot
-    // (S+1) & 1, barrier.  Past the end of the stream the loads re-read its last stage (no branch around a load).
+    // Stage s lives in register set s % 3.  Iteration S: request B(S+3) into the set B(S) left (written to LDS one iteration
+    // ago), write B(S+1) -- requested two iterations ago -- to slot (S+1) & 1, barrier.  Past the end of the stream the
+    // loads re-read its last stage (no branch around a load).  (r02 had two sets, i.e. ONE iteration between request
+    // and use: over bf16 rows, where a stage is half the HBM time, the L2 round trip of the B block was the stage.)
     const uint32_t p = wave - 6;
     FPos lb{first_tile * row_step, 0, total, row_step};
-    WsB b0, b1;
+    WsB b0, b1, b2;
     ws_b_load(b0, a, p, lb.st, lane);
     fpos_advance(lb, stages);
     ws_b_load(b1, a, p, lb.st, lane);
     fpos_advance(lb, stages);
+    ws_b_load(b2, a, p, lb.st, lane);
+    fpos_advance(lb, stages);
     ws_b_store(lds_b, p, lane, b0);
     VK_WS_PBARRIER()
+    uint32_t bpar = 0;                                                       // S & 1
     unsigned long long ph[2] = {0, 0}, tlast = __builtin_readcyclecounter();
-#define VK_WS_BPROD(PAR, BLOAD, BSTORE)                                                                             \
+#define VK_WS_BPROD(BLOAD, BSTORE)                                                                                  \
     {                                                                                                               \
       const bool live = left_c != 0;                                                                                \
       VK_WS_TICK(1)                                                                                                 \
       ws_b_load(BLOAD, a, p, lb.st, lane);                                                                          \
       fpos_advance(lb, stages);                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                            \
-      ws_b_store(lds_b + ((PAR) ^ 1) * kWsBStage, p, lane, BSTORE);                                                 \
+      bpar ^= 1;                                                                                                    \
+      ws_b_store(lds_b + bpar * kWsBStage, p, lane, BSTORE);                                                        \
       if constexpr (timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
       VK_WS_TICK(0)                                                                                                 \
       left_c -= live ? 1u : 0u;                                                                                     \
@@ -695,9 +701,11 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       if (live && st_c == stages) VK_WS_TILE_END(VK_WS_PBARRIER()) else VK_WS_PBARRIER();                           \
     }
     while (left_c != 0 && !stop) {
-      VK_WS_BPROD(0, b0, b1)
+      VK_WS_BPROD(b0, b1)
       if (stop) break;
-      VK_WS_BPROD(1, b1, b0)
+      VK_WS_BPROD(b1, b2)
+      if (stop) break;
+      VK_WS_BPROD(b2, b0)
     }
 #undef VK_WS_BPROD
     if constexpr (timing) {
@@ -950,8 +958,9 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
                 : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_sample_kernel<false, true>)
                         : reinterpret_cast<const void *>(&flat_filter_sample_kernel<false, false>));
   if (a.timing) {
-    if (a.bf16 || a.l2 || a.mode == 1) return hipErrorInvalidValue;
-    fn = reinterpret_cast<const void *>(&flat_filter_kernel<false, false, true>);
+    if (a.l2 || a.mode == 1) return hipErrorInvalidValue;
+    fn = a.bf16 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, false, true>)
+                : reinterpret_cast<const void *>(&flat_filter_kernel<false, false, true>);
   }
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (above the 64 KB default)
   if (e != hipSuccess) return e;

@@ -1014,7 +1014,7 @@ class FlatIndex final : public Index {
       FlatFilterArgs fm = f;
       fm.mode = 0;
       fm.n_tiles = (uint32_t)((count + 127) / 128);
-      fm.timing = timing && !store_.bf16() && !l2();
+      fm.timing = timing && !l2();
       if (fm.timing) {   // phase timing experiment: nine counters
         VK_TRY(ctx->d_idx.ensure(128));
         VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
