@@ -1014,7 +1014,13 @@ class FlatIndex final : public Index {
       FlatFilterArgs fm = f;
       fm.mode = 0;
       fm.n_tiles = (uint32_t)((count + 127) / 128);
-      fm.timing = timing && !l2();
+      static const bool fat_dbg = getenv("VK_FAT_DBG") != nullptr;   // cycle counters of the four-fat-waves kernel
+      fm.timing = timing && !l2() && !fat_dbg;
+      if (fat_dbg) {
+        VK_TRY(ctx->d_idx.ensure(128));
+        VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
+        fm.dbg = ctx->d_idx.as<unsigned long long>();
+      }
       if (fm.timing) {   // phase timing experiment: nine counters
         VK_TRY(ctx->d_idx.ensure(128));
         VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
@@ -1030,6 +1036,13 @@ class FlatIndex final : public Index {
       VK_TRY(filter_launches(fm, (uint32_t)std::min<uint64_t>(filter_blocks_, fm.n_tiles)));
       VK_HIP_TRY(hipEventRecord(tp->t1, s));
       tp->pending = true;
+      if (fat_dbg) {
+        unsigned long long h[3];
+        VK_HIP_TRY(hipStreamSynchronize(s));
+        VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, sizeof h, hipMemcpyDeviceToHost));
+        const double w = (double)std::min<uint64_t>(filter_blocks_, (count + 255) / 256) * 4;
+        fprintf(stderr, "[vk] fat filter, ticks per wave: total %.0f  barrier %.0f  gate %.0f\n", h[2] / w, h[0] / w, h[1] / w);
+      }
       if (fm.timing) {
         unsigned long long h[9];
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(filter_blocks_, fm.n_tiles);

@@ -45,7 +45,7 @@ inline uint32_t padded_dim(uint32_t dim) { return (dim + 63u) & ~63u; }
 
 class RowStore {
  public:
-  static constexpr uint64_t kRowSlack = 128;   // readable rows past the capacity (see reserve())
+  static constexpr uint64_t kRowSlack = 256;   // readable rows past the capacity (see reserve()): one tile of the widest kernel
   RowStore(int device, uint32_t dim, bool bf16 = false);
   ~RowStore();
   RowStore(const RowStore &) = delete;
