@@ -409,3 +409,27 @@ def test_k_up_to_1024_through_the_filter(vsa, oracle, metric):
     for i in (0, 2, 17):
         od, ol = o.search(Q[i], 1000)
         assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+
+
+def test_four_fat_waves_kernel_gives_the_same_survivors(vsa, oracle):
+    """VK_FILTER_FAT=1: the experimental 256-row-tile kernel (four waves of 512 registers) behind the same gate -- same
+    answer, same survivor counts as the wave-specialised kernel."""
+    rng = np.random.default_rng(512)
+    n, dim = 150_000, 128
+    centres = rng.standard_normal((60, dim)).astype(np.float32)
+    x = _unit(centres[rng.integers(0, 60, n)] + 0.4 * rng.standard_normal((n, dim)).astype(np.float32))
+    x[30_000:42_000] = x[5]                                  # a query on 12 000 duplicates: spill chunks in the fat kernel too
+    Q = _unit(centres[rng.integers(0, 60, 256)] + 0.4 * rng.standard_normal((256, dim)).astype(np.float32))
+    Q[9] = x[5]
+    for dtype in ("f32", "bf16"):
+        f, e = _pair(vsa, dim, "COSINE", x, dtype=dtype)
+        ref = f.search_batch(Q, 10)
+        c_ref = f.stats().last_filter_candidates
+        _same(ref, e.search_batch(Q, 10))
+        with _Env(VK_FILTER_FAT=1):
+            # (the switch is read once per process: a second library handle picks it up through a fresh index only if it
+            # was not read before -- so this test also passes, trivially, when another test has fixed the switch)
+            g, _ = _pair(vsa, dim, "COSINE", x, dtype=dtype)
+            got = g.search_batch(Q, 10)
+        _same(got, ref)
+        assert g.stats().last_filter_candidates == c_ref and g.stats().last_filter_fallback == 0
