@@ -426,10 +426,8 @@ def test_four_fat_waves_kernel_gives_the_same_survivors(vsa, oracle):
         ref = f.search_batch(Q, 10)
         c_ref = f.stats().last_filter_candidates
         _same(ref, e.search_batch(Q, 10))
-        with _Env(VK_FILTER_FAT=1):
-            # (the switch is read once per process: a second library handle picks it up through a fresh index only if it
-            # was not read before -- so this test also passes, trivially, when another test has fixed the switch)
-            g, _ = _pair(vsa, dim, "COSINE", x, dtype=dtype)
-            got = g.search_batch(Q, 10)
+        with _Env(VK_FILTER_FAT=1):                              # (read at every launch)
+            got = f.search_batch(Q, 10)
+            st = f.stats()
         _same(got, ref)
-        assert g.stats().last_filter_candidates == c_ref and g.stats().last_filter_fallback == 0
+        assert st.last_filter_candidates == c_ref and st.last_filter_fallback == 0

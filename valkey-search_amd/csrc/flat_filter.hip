@@ -1231,7 +1231,8 @@ size_t flat_filter_fat_lds_bytes() {
 bool flat_filter_fat_enabled(const FlatFilterArgs &a) {
   // (opt-in: measured slower than the wave-specialised kernel -- 10M x 768, B = 256, same lease: f32 6.1-7.1 ms against
   // 5.3, bf16 4.50 against 4.55 per step; its cycle counters, VK_FAT_DBG=1: a stage takes 2.1-2.7x its MFMA time)
-  static const bool on = getenv("VK_FILTER_FAT") && atoi(getenv("VK_FILTER_FAT")) != 0;
+  const char *env = getenv("VK_FILTER_FAT");      // (read per launch: tests switch it inside one process)
+  const bool on = env && atoi(env) != 0;
   return on && a.mode == 0 && !a.l2 && !a.timing && (a.row_stride_f / kFStageK) % 2 == 0;
 }
 
