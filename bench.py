@@ -860,20 +860,20 @@ def source_sha256():
 
 def pmc_traffic(N, D, B, world, kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc is a separate run by
-    rule, so bench.py cannot collect it live): profiles/r02_pmc_fetch_size.json, written by scripts/pmc_traffic.sh and
+    rule, so bench.py cannot collect it live): profiles/r03_pmc_fetch_size.json, written by scripts/pmc_traffic.sh and
     stamped with the hash of the sources it measured.  Printed only for the default single-GPU workload AND only while
     that hash equals the current sources' -- a stale file yields null, never an old number."""
-    path = ROOT / "profiles" / "r02_pmc_fetch_size.json"
+    path = ROOT / "profiles" / "r03_pmc_fetch_size.json"
     if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not path.exists() or "bf16" in sys.argv:
         return None, None
     if any(os.environ.get(v) for v in ("VK_FLAT_FORCE_SCAN", "VK_GEMM_MODE", "VK_GEMM_ABLATE", "VK_GEMM_LOCKSTEP", "VK_FILTER_TIMING", "VK_FLAT_FILTER")):
         return None, None
     j = json.load(open(path))
     if j.get("src_sha256") != source_sha256():
-        return None, "profiles/r02_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
+        return None, "profiles/r03_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
     for name, v in j.get("kernels", {}).items():
         if kernel_prefix in name and "prepass" not in name and "[small]" not in name:
-            return round(v["hbm_bytes_per_launch"]), "profiles/r02_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
+            return round(v["hbm_bytes_per_launch"]), "profiles/r03_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
     return None, None
 
 
@@ -890,8 +890,9 @@ def main():
                     help="row storage (bf16 = BASELINE.json configs[3] storage; queries and arithmetic stay f32)")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="rows the CPU baseline scans per query (0 = the whole index: a full-size pass, no scaling)")
-    ap.add_argument("--cpu-queries-per-thread", type=int, default=1,
-                    help="CPU baseline: queries per host thread (1 x 16 threads x a 10M-row scan is about 30 s of CPU work)")
+    ap.add_argument("--cpu-queries-per-thread", type=int, default=16,
+                    help="CPU baseline: queries per host thread (16 x 16 threads = all 256 queries of the timed batch, each a full "
+                         "10M-row scan: about 30 s of CPU work, and every row of the timed step's answer is compared)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-query-steps", type=int, default=5, help="extra: B=1 scan timing (HBM roofline)")
     ap.add_argument("--hnsw-rows", type=int, default=-1,
