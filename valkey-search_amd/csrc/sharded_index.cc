@@ -68,12 +68,11 @@ struct MultiCtx {
   }
 };
 
-// One enqueue thread per shard.  The reference issues its per-shard requests concurrently (src/query/fanout.cc:69-160);
-// here a shard's search is a sequence of a dozen or two kernel launches, and enqueueing shard after shard from the
-// calling thread made the host the bottleneck of a fan-out: eight shards x ~20 launches of 4-6 us each before the last
-// device had anything to do, against well under a millisecond of device work per shard.  Each worker owns one shard's
-// lane (its device is the thread's current device once and for all) and runs the jobs handed to it in order; the caller
-// enqueues the serving device's shard itself and waits on a latch.
+// One enqueue thread per device.  The reference issues its per-shard requests concurrently (src/query/fanout.cc:69-160);
+// here a shard's search is a sequence of a dozen kernel launches (r02: two dozen), and enqueueing shard after shard
+// from the calling thread made the host the bottleneck of a fan-out: eight shards x ~40 us before the last device had
+// anything to do, against well under a millisecond of device work per shard.  Each worker owns the shards of one device
+// and runs the jobs handed to it in order; the caller enqueues the serving device's shards itself and waits on a latch.
 class ShardWorkers {
  public:
   struct Latch {
@@ -152,8 +151,19 @@ class ShardedIndex final : public Index {
       shards_.push_back(std::move(sub));
       shard_cap_.push_back(sp.initial_cap);
     }
+    // One enqueue thread per DEVICE, not per shard: launches into one device go through one runtime lock, and threads that
+    // share it only queue up behind each other (8 logical shards on one GPU: 330 us enqueued one after the other from one
+    // thread, 230-620 us from eight threads); across devices the enqueueing does run side by side.  The caller's thread
+    // takes the serving device's shards.
     static const bool threads_on = !(getenv("VK_SHARD_THREADS") && atoi(getenv("VK_SHARD_THREADS")) == 0);
-    if (S > 1 && threads_on) workers_ = std::make_unique<ShardWorkers>(S - 1);   // (shard 0 is enqueued by the caller)
+    for (size_t s = 0; s < S; ++s) {
+      size_t gi = 0;
+      for (; gi < dev_groups_.size(); ++gi)
+        if (devices_[dev_groups_[gi][0]] == devices_[s]) break;
+      if (gi == dev_groups_.size()) dev_groups_.emplace_back();
+      dev_groups_[gi].push_back(s);
+    }
+    if (dev_groups_.size() > 1 && threads_on) workers_ = std::make_unique<ShardWorkers>(dev_groups_.size() - 1);
     // peer access between the devices involved (a failure only means the copies are staged by the runtime)
     for (size_t a = 0; a < S; ++a)
       for (size_t b = 0; b < S; ++b)
@@ -690,17 +700,23 @@ class ShardedIndex final : public Index {
     std::vector<Status> res(S);
     if (workers_) {
       ShardWorkers::Latch latch;
-      latch.left = (uint32_t)(S - 1);
-      for (size_t s = 1; s < S; ++s)
-        workers_->post(s - 1, [this, mc, s, &rq, &res, &latch] {
+      latch.left = (uint32_t)(dev_groups_.size() - 1);
+      auto run_group = [this, mc, &rq, &res](size_t gi) {
+        for (size_t s : dev_groups_[gi]) {
           try {
             res[s] = enqueue_shard(mc, s, rq);
           } catch (const std::exception &e) {
             res[s] = Status::Err(VK_ERR_INTERNAL, e.what());
           }
+          if (!res[s].ok()) break;
+        }
+      };
+      for (size_t gi = 1; gi < dev_groups_.size(); ++gi)
+        workers_->post(gi - 1, [gi, &run_group, &latch] {
+          run_group(gi);
           latch.done();
         });
-      res[0] = enqueue_shard(mc, 0, rq);
+      run_group(0);
       latch.wait();
     } else {
       for (size_t s = 0; s < S; ++s) {
@@ -765,6 +781,7 @@ class ShardedIndex final : public Index {
 
   std::vector<int> devices_;
   std::unique_ptr<ShardWorkers> workers_;
+  std::vector<std::vector<size_t>> dev_groups_;           // shards by device, the serving device's group first
   std::atomic<uint64_t> fanout_calls_{0}, fanout_ns_{0};   // host time of fan_out (enqueue only), for vk_index_stats
   std::vector<std::unique_ptr<Index>> shards_;
   std::vector<uint64_t> shard_cap_;
