@@ -430,4 +430,10 @@ def test_four_fat_waves_kernel_gives_the_same_survivors(vsa, oracle):
             got = f.search_batch(Q, 10)
             st = f.stats()
         _same(got, ref)
-        assert st.last_filter_candidates == c_ref and st.last_filter_fallback == 0
+        assert st.last_filter_fallback == 0
+        if dtype == "f32":
+            assert st.last_filter_candidates == c_ref
+        else:                                                    # (bf16 rows: the default kernel multiplies in bf16, this one in f16)
+            with _Env(VK_FILTER_BF16_MFMA=0):
+                f.search_batch(Q, 10)
+                assert f.stats().last_filter_candidates == st.last_filter_candidates

@@ -196,8 +196,16 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
     const float4 u = reinterpret_cast<const float4 *>(src)[k8 * 2], v = reinterpret_cast<const float4 *>(src)[k8 * 2 + 1];
     const float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
     f16x8 h;
+    if (a.qbf16) {   // bf16 fragments (round to nearest even) for the bf16 matrix-core path over bf16 rows
 #pragma unroll
-    for (int t = 0; t < 8; ++t) h[t] = f16_ok ? (_Float16)e[t] : (_Float16)0.f;   // round to nearest even
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t u = __float_as_uint(e[t]);
+        h[t] = __builtin_bit_cast(_Float16, (uint16_t)(f16_ok ? (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16 : 0u));
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) h[t] = f16_ok ? (_Float16)e[t] : (_Float16)0.f;   // round to nearest even
+    }
     const uint32_t ks = k8 >> 1, g = k8 & 1;
     reinterpret_cast<f16x8 *>(a.q16)[((size_t)(jt * ks_n + ks) * kWave + g * 32 + jj)] = h;
   }
@@ -211,7 +219,9 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
     const float D = (float)a.row_stride_f;
     // see the header: relative part, absolute (subnormal) part, the reference's own rounding, 1 - dot (2^-23 (1 + R |q|)
     // covers both sides' 2^-24 max(1, |dist|)); everything rounded up by 1.001
-    const float rel = (a.bf16 ? 0x1p-11f : 0x1p-10f) + 0x1p-22f + D * 0x1p-22f + (D / 16.f + 5.f) * 0x1p-24f;   // (bf16 rows convert exactly)
+    // (bf16 rows convert to f16 exactly; on the bf16 matrix-core path the rows are not converted at all and the query is
+    //  rounded to bf16: 2^-9 relative per element)
+    const float rel = (a.qbf16 ? 0x1p-9f : a.bf16 ? 0x1p-11f : 0x1p-10f) + 0x1p-22f + D * 0x1p-22f + (D / 16.f + 5.f) * 0x1p-24f;
     const float sub = 0x1.01p-25f * sqrtf(D);
     float c2 = 0.f, c1 = (qn * rel + sub + 0x1p-23f * qn) * 1.001f, c0 = (sub * qn + 0x1p-23f) * 1.001f;
     if (a.l2) {
@@ -550,11 +560,22 @@ __device__ __forceinline__ void ws_rows_load_sample(WsRows<kBf16> &s, const Flat
 }
 // -> f16 in LDS.  f32 rows: round to nearest even.  bf16 rows: bf16 -> f32 is a shift and f32 -> f16 is then EXACT for
 // every value in f16's normal range (8 significant bits fit 11), so a bf16 index carries no row rounding error at all.
-template <bool kBf16, bool kL2, bool kSample>
-__device__ __forceinline__ void ws_rows_store(_Float16 *buf, uint32_t *hn_buf, uint32_t t, const WsRows<kBf16> &s) {
+template <bool kBf16, bool kL2, bool kSample, bool kBfMma = false>
+__device__ __forceinline__ void ws_rows_store(_Float16 *buf, uint32_t *hn_buf, uint32_t t, const WsRows<kBf16> &s, bool raw = false) {
   if constexpr (kL2) hn_buf[t] = s.hn;
   if constexpr (kBf16) {
     _Float16 *dst = buf + (t >> 3) * kFAStride + (t & 7) * 8;
+    if (kBfMma || raw) {   // bf16 matrix-core path: the bytes as they are (raw: the same as an experiment of the f16 path)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        u32x4v v = s.v[u];
+        if constexpr (kSample) {
+          if ((t & 7) == 0 && ((s.pz >> u) & 1u)) v[0] = (v[0] & 0xFFFF0000u) | 0x7FC0u;   // bf16 NaN: no witness
+        }
+        *reinterpret_cast<u32x4v *>(dst + u * 16 * kFAStride) = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       f16x8 h;
@@ -604,8 +625,19 @@ __device__ __forceinline__ void ws_b_store(uint4 *slot, uint32_t p, uint32_t lan
   for (int i = 0; i < 16; ++i) dst[i * kWave] = b.v[i];
 }
 
-template <bool kBf16, bool kL2, bool kTiming, bool kSample>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <bool kBfMma> __device__ __forceinline__ f32x16 ws_mfma(f16x8 x, f16x8 y, f32x16 c) {
+  if constexpr (kBfMma) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
+}
+// kBfMma (bf16 rows, inner-product space): rows and queries stay bf16 -- no conversion on the way into LDS, the bf16
+// matrix-core instruction, a query rounding of 2^-9 in the margin (flat_qprep_kernel)
+template <bool kBf16, bool kL2, bool kTiming, bool kSample, int kAbl = 0, bool kBfMma = false>
 __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
+  // (experiment kernels only, kAbl != 0: a.ablate switches pieces of the pipeline OFF -- results invalid, times tell what bounds a stage:
+  //  1 B producers do not store, 2 nor load; 4 row producers do not store, 8 nor load; kAbl 16 / 32: the consumers keep
+  //  the B / A fragments they read first)
+  const uint32_t abl = kAbl != 0 ? a.ablate : 0u;
   extern __shared__ _Float16 lds_a[];
   constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;                    // one A stage
   uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + 2 * kBufHalfs);          // [2][kWsBStage]
@@ -631,6 +663,11 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   uint32_t st_c = 0, tile_c = 0, left_c = total;
   bool stop = false;
   if (tid < 2) lds_stop[tid] = 0;
+  if constexpr (kAbl != 0) {
+    if (abl != 0) {   // (stages that are never written must not hold NaNs: every pair would pass the gate)
+      for (uint32_t i = tid; i < (2 * kBufHalfs * 2 + 2 * kWsBStage * 16) / 16; i += kWsThreads) reinterpret_cast<uint4 *>(lds_a)[i] = make_uint4(0, 0, 0, 0);
+    }
+  }
   __syncthreads();
 
   // Leaving early (cancellation) must be decided identically by all eight waves or the next barrier never completes: the
@@ -666,6 +703,14 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     __builtin_amdgcn_s_barrier();                                                                                   \
     asm volatile("" ::: "memory");                                                                                  \
   }
+  // wave priorities (VK_FILTER_PRIO = row producers | query producers << 2 | consumers << 4): the two waves of a SIMD share
+  // its issue slots by priority, then age -- and the producers are the younger half of the block
+  {
+    const uint32_t pr = (a.prio >> (wave >= 6 ? 2 : wave >= 4 ? 0 : 4)) & 3u;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
   if (wave >= 6) {
     // ================================ query producer =====================================================
     // Stage s lives in register set s % 3.  Iteration S: request B(S+3) into the set B(S) left (written to LDS one iteration
@@ -689,11 +734,11 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     {                                                                                                               \
       const bool live = left_c != 0;                                                                                \
       VK_WS_TICK(1)                                                                                                 \
-      ws_b_load(BLOAD, a, p, lb.st, lane);                                                                          \
+      if (!(abl & 2u)) ws_b_load(BLOAD, a, p, lb.st, lane);                                                         \
       fpos_advance(lb, stages);                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                            \
       bpar ^= 1;                                                                                                    \
-      ws_b_store(lds_b + bpar * kWsBStage, p, lane, BSTORE);                                                        \
+      if (!(abl & 1u)) ws_b_store(lds_b + bpar * kWsBStage, p, lane, BSTORE);                                       \
       if constexpr (timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
       VK_WS_TICK(0)                                                                                                 \
       left_c -= live ? 1u : 0u;                                                                                     \
@@ -751,7 +796,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       VK_WS_ROWS_LOAD(x5)
       fpos_advance(ld, stages);
     }
-    ws_rows_store<kBf16, kL2, kSample>(lds_a, hn_lds, t, x0);
+    ws_rows_store<kBf16, kL2, kSample, kBfMma>(lds_a, hn_lds, t, x0);
     VK_WS_PBARRIER()
     uint32_t ppar = 0;                                                       // S & 1
     unsigned long long ph[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -762,12 +807,12 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       if (live && st_c == 0 && t == 0 && a.cancel && (tile_c % kCancelPollTiles) == 0) {                            \
         if (__hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) lds_stop[tile_c & 1] = 1; \
       }                                                                                                             \
-      VK_WS_ROWS_LOAD(RLOAD)                                                                                        \
+      if (!(abl & 8u)) VK_WS_ROWS_LOAD(RLOAD)                                                                       \
       fpos_advance(ld, stages);                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                            \
       VK_WS_TICK(0)                                                                                                 \
       ppar ^= 1;                                                                                                    \
-      ws_rows_store<kBf16, kL2, kSample>(lds_a + ppar * kBufHalfs, hn_lds + ppar * kFTileRows, t, RSTORE);                   \
+      if (!(abl & 4u)) ws_rows_store<kBf16, kL2, kSample, kBfMma>(lds_a + ppar * kBufHalfs, hn_lds + ppar * kFTileRows, t, RSTORE, (abl & 512u) != 0); \
       if constexpr (timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
       VK_WS_TICK(2)                                                                                                 \
       left_c -= live ? 1u : 0u;                                                                                     \
@@ -827,7 +872,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       if constexpr (kL2) col[t2].c2 = co.x;
       col[t2].c1 = co.y;
       col[t2].c0 = co.z;
-      col[t2].bound = closed[t2] ? __builtin_inff() : a.qbound[jc];
+      col[t2].bound = (closed[t2] || abl != 0) ? __builtin_inff() : a.qbound[jc];   // (experiments: nothing survives)
     }
   }
   f32x16 acc[2][4];
@@ -851,19 +896,19 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   // the slot are offsets in a register): one copy of the gate's code.
 #define VK_WS_AB(FA, FB0, FB1, KK)                                                                                  \
   _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
-    FA[rt] = *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + (KK) * 16);                                \
-  FB0 = bb[(KK) * kWave];                                                                                           \
-  FB1 = bb[(4 + (KK)) * kWave];
+    FA[rt] = (kAbl & 32) ? abl_a[rt] : *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + (KK) * 16);      \
+  FB0 = (kAbl & 16) ? abl_b[0] : bb[(KK) * kWave];                                                                  \
+  FB1 = (kAbl & 16) ? abl_b[1] : bb[(4 + (KK)) * kWave];
 #define VK_WS_MM(FA, FB0, FB1)                                                                                      \
   _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                                                \
-    acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB0, acc[0][rt], 0, 0, 0);                          \
-    acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB1, acc[1][rt], 0, 0, 0);                          \
+    acc[0][rt] = ws_mfma<kBfMma>(FA[rt], FB0, acc[0][rt]);                                                          \
+    acc[1][rt] = ws_mfma<kBfMma>(FA[rt], FB1, acc[1][rt]);                                                          \
   }
   // (first K-step of a tile: the accumulators are not cleared -- 128 register moves -- but started from the constant 0)
 #define VK_WS_MMZ(FA, FB0, FB1)                                                                                     \
   _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                                                \
-    acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB0, zero, 0, 0, 0);                                \
-    acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB1, zero, 0, 0, 0);                                \
+    acc[0][rt] = ws_mfma<kBfMma>(FA[rt], FB0, zero);                                                                \
+    acc[1][rt] = ws_mfma<kBfMma>(FA[rt], FB1, zero);                                                                \
   }
 #define VK_WS_STAGE(MM0)                                                                                            \
   {                                                                                                                 \
@@ -883,6 +928,13 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                              \
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                                             \
   }
+  f16x8 abl_a[4], abl_b[2];
+  if constexpr (kAbl != 0) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) abl_a[rt] = *reinterpret_cast<const f16x8 *>(lds_a + li * kFAStride + g * 8 + rt * 32 * kFAStride);
+    abl_b[0] = reinterpret_cast<const f16x8 *>(lds_b)[lane];
+    abl_b[1] = reinterpret_cast<const f16x8 *>(lds_b)[lane + kWave];
+  }
   unsigned long long ph[3] = {0, 0, 0}, tlast = __builtin_readcyclecounter();
   while (left_c != 0 && !stop) {
     VK_WS_TICK(2)
@@ -890,6 +942,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     const f16x8 *bb = reinterpret_cast<const f16x8 *>(lds_b + par * kWsBStage + (wave * 2) * 4 * kWave) + lane;
     if (has_q) {
       if (st_c == 0) VK_WS_STAGE(VK_WS_MMZ) else VK_WS_STAGE(VK_WS_MM)
+      if constexpr ((kAbl & 128) != 0) VK_WS_STAGE(VK_WS_MM)   // (experiment: a stage's MFMAs twice per barrier)
       if constexpr (kL2) {
         if (st_c + 1 == stages) {   // one more K-step: (hn_hi, hn_lo, 0 ...) x (-1, -1, 0 ...) = - |x|^2 / 2
           const uint4 nb = make_uint4(g == 0 ? 0xBC00BC00u : 0u, 0u, 0u, 0u);
@@ -912,6 +965,9 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
         if constexpr (kSample) {
           sample_max<4, kBf16>(a, acc[0], wit[0], closed[0], tile_row0, (wave * 2) * 32 + li, g);
           sample_max<4, kBf16>(a, acc[1], wit[1], closed[1], tile_row0, (wave * 2 + 1) * 32 + li, g);
+        } else if constexpr ((kAbl & 64) != 0) {   // (experiment: no gate; the accumulators stay alive)
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) asm volatile("" ::"v"(acc[0][rt]), "v"(acc[1][rt]));
         } else {
           filter_gate<4, false>(a, acc[0], gate_thr<kL2>(col[0], r2_bits), tile_row0, wave * 2, li, g, ring, lane);
           filter_gate<4, false>(a, acc[1], gate_thr<kL2>(col[1], r2_bits), tile_row0, wave * 2 + 1, li, g, ring, lane);
@@ -1197,9 +1253,16 @@ __global__ __launch_bounds__(kFatThreads, 1) void flat_filter_fat_kernel(FlatFil
   }
 }
 
-template <bool kBf16, bool kL2, bool kTiming>
+template <bool kBf16, bool kL2, bool kTiming, int kAbl = 0>
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_kernel(FlatFilterArgs a) {
-  flat_filter_body<kBf16, kL2, kTiming, false>(a);
+  flat_filter_body<kBf16, kL2, kTiming, false, kAbl>(a);
+}
+// bf16 rows on the bf16 matrix cores (inner-product space): final pass and sample pass
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_kernel(FlatFilterArgs a) {
+  flat_filter_body<true, false, false, false, 0, true>(a);
+}
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_sample_kernel(FlatFilterArgs a) {
+  flat_filter_body<true, false, false, true, 0, true>(a);
 }
 // the pass over the bound's sample (every s-th tile of the index, a few per cent of the rows): the same pipeline, group
 // bounds instead of survivors
@@ -1233,7 +1296,7 @@ bool flat_filter_fat_enabled(const FlatFilterArgs &a) {
   // 5.3, bf16 4.50 against 4.55 per step; its cycle counters, VK_FAT_DBG=1: a stage takes 2.1-2.7x its MFMA time)
   const char *env = getenv("VK_FILTER_FAT");      // (read per launch: tests switch it inside one process)
   const bool on = env && atoi(env) != 0;
-  return on && a.mode == 0 && !a.l2 && !a.timing && (a.row_stride_f / kFStageK) % 2 == 0;
+  return on && a.mode == 0 && !a.l2 && !a.timing && !a.qbf16 && (a.row_stride_f / kFStageK) % 2 == 0;
 }
 
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s) {
@@ -1260,10 +1323,28 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
                         : reinterpret_cast<const void *>(&flat_filter_sample_kernel<true, false>))
                 : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_sample_kernel<false, true>)
                         : reinterpret_cast<const void *>(&flat_filter_sample_kernel<false, false>));
+  if (a.qbf16) {
+    if (!a.bf16 || a.l2) return hipErrorInvalidValue;
+    fn = a.mode == 1 ? reinterpret_cast<const void *>(&flat_filter_bfmma_sample_kernel) : reinterpret_cast<const void *>(&flat_filter_bfmma_kernel);
+  }
   if (a.timing) {
-    if (a.l2 || a.mode == 1) return hipErrorInvalidValue;
+    if (a.l2 || a.mode == 1 || a.qbf16) return hipErrorInvalidValue;
     fn = a.bf16 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, false, true>)
                 : reinterpret_cast<const void *>(&flat_filter_kernel<false, false, true>);
+  }
+  if (a.ablate_on) {   // VK_FILTER_ABLATE: the experiment kernels (results invalid)
+    if (a.l2 || a.mode == 1 || a.qbf16) return hipErrorInvalidValue;
+#define VK_ABL(T, N) (a.bf16 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, false, T, N>) : reinterpret_cast<const void *>(&flat_filter_kernel<false, false, T, N>))
+    switch (a.ablate & 240u) {
+      case 240: fn = VK_ABL(false, 241); break;
+      case 16: fn = VK_ABL(false, 17); break;
+      case 32: fn = VK_ABL(false, 33); break;
+      case 48: fn = VK_ABL(false, 49); break;
+      case 64: fn = VK_ABL(false, 65); break;
+      case 112: fn = VK_ABL(false, 113); break;
+      default: fn = a.timing ? VK_ABL(true, 1) : VK_ABL(false, 1); break;
+    }
+#undef VK_ABL
   }
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (above the 64 KB default)
   if (e != hipSuccess) return e;

@@ -942,6 +942,11 @@ class FlatIndex final : public Index {
     f.rows = store_.d_rows();
     f.bf16 = store_.bf16() ? 1 : 0;
     f.l2 = l2() ? 1 : 0;
+    const bool bfmma_off = getenv("VK_FILTER_BF16_MFMA") && atoi(getenv("VK_FILTER_BF16_MFMA")) == 0;   // (A/B: the f16 kernels)
+    // (the experiment kernels -- phase timing, ablations, the four-fat-waves kernel -- are f16 kernels; read per call)
+    const bool filter_experiment = getenv("VK_FILTER_TIMING") || getenv("VK_FILTER_ABLATE") || getenv("VK_FAT_DBG") ||
+                                   (getenv("VK_FILTER_FAT") && atoi(getenv("VK_FILTER_FAT")) != 0);
+    f.qbf16 = (store_.bf16() && !l2() && !bfmma_off && !filter_experiment) ? 1 : 0;
     f.hn16 = l2() ? d_hn16_.as<uint32_t>() : nullptr;
     f.labels = store_.d_labels();
     f.allow_bits = d_allow;
@@ -1016,6 +1021,11 @@ class FlatIndex final : public Index {
       fm.n_tiles = (uint32_t)((count + 127) / 128);
       static const bool fat_dbg = getenv("VK_FAT_DBG") != nullptr;   // cycle counters of the four-fat-waves kernel
       fm.timing = timing && !l2() && !fat_dbg;
+      fm.prio = getenv("VK_FILTER_PRIO") ? (uint32_t)atoi(getenv("VK_FILTER_PRIO")) : 0u;   // (read per launch)
+      if (!l2() && getenv("VK_FILTER_ABLATE")) {   // (experiments, read per launch)
+        fm.ablate_on = 1;
+        fm.ablate = (uint32_t)atoi(getenv("VK_FILTER_ABLATE"));
+      }
       if (fat_dbg) {
         VK_TRY(ctx->d_idx.ensure(128));
         VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));

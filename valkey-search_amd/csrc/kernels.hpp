@@ -93,6 +93,7 @@ struct FlatFilterArgs {
   uint64_t allow_nbits;
   const float *queries;       // [nq][q_stride_f] f32, padded (input of flat_qprep_kernel)
   uint32_t q_stride_f;
+  uint32_t qbf16;             // bf16 rows, inner-product space: q16 holds bf16 fragments and the bf16 matrix-core instruction multiplies
   void *q16;                  // [nqt][row_stride_f/16][64][8] f16: the queries in MFMA fragment order (written by qprep)
   // per query column (written by qprep): the error margin of an approximate score against a row of norm R as a
   // polynomial  E(R) = c2 R^2 + c1 R + c0  (x, y, z), and the column's state (w: 0 = live, 1 = closed -- a padding
@@ -136,6 +137,8 @@ struct FlatFilterArgs {
   const uint32_t *cancel;
   uint32_t timing;            // VK_FILTER_TIMING=1: the kernel variant with cycle counters per phase (f32 rows, IP only)
   unsigned long long *dbg;    // timing: [9] cycles per phase, summed over the waves (see the kernel)
+  uint32_t prio;              // wave priorities of the three roles, 2 bits each (rows | queries << 2 | consumers << 4)
+  uint32_t ablate_on, ablate; // VK_FILTER_ABLATE (experiments): pieces of the pipeline switched off, see flat_filter_body
 };
 // bound selection: qbound[q] = the k-th largest of smax[q][0 .. groups) (-inf when fewer than k are finite)
 struct FlatBoundArgs {
