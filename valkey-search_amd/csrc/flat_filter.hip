@@ -632,15 +632,23 @@ template <bool kBfMma> __device__ __forceinline__ f32x16 ws_mfma(f16x8 x, f16x8 
 }
 // kBfMma (bf16 rows, inner-product space): rows and queries stay bf16 -- no conversion on the way into LDS, the bf16
 // matrix-core instruction, a query rounding of 2^-9 in the margin (flat_qprep_kernel)
-template <bool kBf16, bool kL2, bool kTiming, bool kSample, int kAbl = 0, bool kBfMma = false>
+// kDma (with kBfMma, final pass): the rows go HBM -> LDS directly (buffer_load ... lds), no registers and no LDS store
+// instructions in between.  A stage is 128 rows x 128 B without padding; the 16-byte piece c of row r sits at piece
+// c ^ ((r >> 1) & 7) of the row (the DMA writes a wave's 64 x 16 B to consecutive LDS bytes, so the swizzle is applied to
+// the SOURCE address of each lane; with it the consumers' ds_read_b128 are conflict-free).  A ring of kDmaRing stages: while
+// the consumers read stage S, stages S+1 .. S+4 are landing or in flight.
+constexpr int kDmaRing = 5;
+constexpr uint32_t kDmaStageBytes = kFTileRows * 128;
+template <bool kBf16, bool kL2, bool kTiming, bool kSample, int kAbl = 0, bool kBfMma = false, bool kDma = false>
 __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
+  static_assert(!kDma || (kBfMma && kBf16 && !kL2 && !kSample && !kTiming), "the DMA row path serves the bf16 final pass");
   // (experiment kernels only, kAbl != 0: a.ablate switches pieces of the pipeline OFF -- results invalid, times tell what bounds a stage:
   //  1 B producers do not store, 2 nor load; 4 row producers do not store, 8 nor load; kAbl 16 / 32: the consumers keep
   //  the B / A fragments they read first)
   const uint32_t abl = kAbl != 0 ? a.ablate : 0u;
   extern __shared__ _Float16 lds_a[];
   constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;                    // one A stage
-  uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + 2 * kBufHalfs);          // [2][kWsBStage]
+  uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + (kDma ? kDmaRing * kDmaStageBytes / 2 : 2 * kBufHalfs));   // [2][kWsBStage]
   uint32_t *lds_ring = reinterpret_cast<uint32_t *>(lds_b + 2 * kWsBStage); // [4 consumer waves][2][64]
   uint32_t *hn_lds = lds_ring + 4 * 2 * kWave;                              // [2][128] (kL2)
   // [2]: cancellation seen during tile T -> word T & 1.  (An LDS-qualified pointer: through a generic one the accesses
@@ -665,7 +673,8 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   if (tid < 2) lds_stop[tid] = 0;
   if constexpr (kAbl != 0) {
     if (abl != 0) {   // (stages that are never written must not hold NaNs: every pair would pass the gate)
-      for (uint32_t i = tid; i < (2 * kBufHalfs * 2 + 2 * kWsBStage * 16) / 16; i += kWsThreads) reinterpret_cast<uint4 *>(lds_a)[i] = make_uint4(0, 0, 0, 0);
+      constexpr uint32_t a_bytes = kDma ? kDmaRing * kDmaStageBytes : 2 * kBufHalfs * 2;
+      for (uint32_t i = tid; i < (a_bytes + 2 * kWsBStage * 16) / 16; i += kWsThreads) reinterpret_cast<uint4 *>(lds_a)[i] = make_uint4(0, 0, 0, 0);
     }
   }
   __syncthreads();
@@ -711,7 +720,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     else if (pr == 2) __builtin_amdgcn_s_setprio(2);
     else if (pr == 3) __builtin_amdgcn_s_setprio(3);
   }
-  if (wave >= 6) {
+  if (!kDma && wave >= 6) {
     // ================================ query producer =====================================================
     // Stage s lives in register set s % 3.  Iteration S: request B(S+3) into the set B(S) left (written to LDS one iteration
     // ago), write B(S+1) -- requested two iterations ago -- to slot (S+1) & 1, barrier.  Past the end of the stream the
@@ -761,7 +770,99 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     }
     return;
   }
-  if (wave >= 4) {
+  if constexpr (kDma) {
+    if (wave >= 4) {
+      // ================================ producers of the DMA kernel ====================================
+      // With the rows going HBM -> LDS by DMA there is little left of a row producer, and the B operands were what a
+      // stage waited for (ablations: 3.45 ms without them, 4.08 with, 10M x 768): all four producer waves do a quarter
+      // of both.  Wave pw: the B operands of query tiles 2 pw, 2 pw + 1 (8 loads and 8 LDS stores per stage, three stages
+      // in flight) and pieces 4 pw .. 4 pw + 3 of the row stage (piece j = rows 8 j .. 8 j + 7 of the tile, 1 KB: lane l
+      // lands on slot l & 7 of row 8 j + l / 8 and therefore fetches the row's piece (l & 7) ^ swizzle(row)).
+      // Loads return in order, so the ORDER of the requests decides what a wait costs: B(S+3) is requested BEFORE the rows
+      // of stage S+4, and the wait for B(S+1) and the rows of S+1 then leaves rows(S+2), B(S+2), rows(S+3), B(S+3) and
+      // rows(S+4) -- 28 requests -- in flight: nothing is waited for earlier than it is needed.  The B stores are inline
+      // assembly: behind a DMA in flight the compiler would put vmcnt(0) in front of every LDS store it knows about.
+      const uint32_t pw = wave - 4;
+      const uint32_t rpart = ((32u * pw + (lane >> 3)) * a.row_stride_f) * 2u;
+      const uint32_t voff_e = rpart + (((lane & 7u) ^ (lane >> 4)) * 16u), voff_o = rpart + (((lane & 7u) ^ (4u + (lane >> 4))) * 16u);
+      const uint32_t step = 8u * a.row_stride_f * 2u;
+      __attribute__((address_space(3))) char *ring0 = (__attribute__((address_space(3))) char *)lds_a;
+      const uint32_t b_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)lds_b) + (pw * 8u * kWave + lane) * 16u;
+      const uint32_t ks_n = a.row_stride_f / 16;
+      FPos ld{first_tile * row_step, 0, total, row_step}, lb = ld;
+      uint32_t slot_i = 0;                                                   // ring slot of the next row request (bytes)
+      struct B8 { u32x4v v[8]; } b0, b1, b2;
+#define VK_WS_DMA_ROWS()                                                                                            \
+      {                                                                                                             \
+        const __amdgpu_buffer_rsrc_t r_ =                                                                           \
+            ws_rsrc(static_cast<const char *>(a.rows) + ((size_t)ld.row0 * a.row_stride_f + (size_t)ld.st * kFStageK) * 2u); \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                               \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (__attribute__((address_space(3))) void *)(ring0 + slot_i + (pw * 4u + u) * 1024u), 16, \
+                                                   (int)((u & 1) ? voff_o : voff_e), (int)(u * step), 0, 2);         \
+        fpos_advance(ld, stages);                                                                                   \
+        slot_i = slot_i + kDmaStageBytes == kDmaRing * kDmaStageBytes ? 0u : slot_i + kDmaStageBytes;               \
+      }
+#define VK_WS_DMA_BLOAD(B)                                                                                          \
+      {                                                                                                             \
+        _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                                                          \
+          const uint32_t jt0 = pw * 2 + t2, jt = jt0 < a.nqt ? jt0 : a.nqt - 1;                                     \
+          const __amdgpu_buffer_rsrc_t r_ = ws_rsrc(reinterpret_cast<const char *>(a.q16) + ((size_t)jt * ks_n + lb.st * 4) * kWave * 16); \
+          _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
+            B.v[t2 * 4 + kk] = __builtin_amdgcn_raw_buffer_load_b128(r_, (int)(lane * 16 + kk * 1024), 0, 0);       \
+        }                                                                                                           \
+        fpos_advance(lb, stages);                                                                                   \
+      }
+#define VK_WS_DMA_BSTORE(B, PAR)                                                                                    \
+      {                                                                                                             \
+        const uint32_t at_ = b_lds + (PAR) * (kWsBStage * 16u);                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                            \
+          asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(at_), "v"(B.v[i_]), "n"(i_ * 1024) : "memory");       \
+      }
+      VK_WS_DMA_BLOAD(b0)
+      VK_WS_DMA_ROWS()
+      VK_WS_DMA_BLOAD(b1)
+      VK_WS_DMA_ROWS()
+      VK_WS_DMA_BLOAD(b2)
+      VK_WS_DMA_ROWS()
+      VK_WS_DMA_ROWS()
+      asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+      VK_WS_DMA_BSTORE(b0, 0u)
+      VK_WS_PBARRIER()
+      uint32_t bpar = 0;                                                     // S & 1
+      // iteration S: B(S+3) -> the set B(S) left, rows(S+4) -> the ring slot stage S-1 left; B(S+1) -> LDS slot (S+1) & 1
+#define VK_WS_DMA_PROD(BLOAD, BSTORE)                                                                               \
+      {                                                                                                             \
+        const bool live = left_c != 0;                                                                              \
+        if (live && st_c == 0 && lane == 0 && pw == 0 && a.cancel && (tile_c % kCancelPollTiles) == 0) {            \
+          if (__hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) lds_stop[tile_c & 1] = 1; \
+        }                                                                                                           \
+        const bool b_on = !(abl & 2u), r_on = !(abl & 8u);                                                          \
+        if (kAbl == 0 || b_on) VK_WS_DMA_BLOAD(BLOAD)                                                               \
+        if (kAbl == 0 || r_on) VK_WS_DMA_ROWS()                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        asm volatile("s_waitcnt vmcnt(28)" ::: "memory");                                                           \
+        bpar ^= 1;                                                                                                  \
+        if (kAbl == 0 || !(abl & 1u)) VK_WS_DMA_BSTORE(BSTORE, bpar)                                                \
+        left_c -= live ? 1u : 0u;                                                                                   \
+        st_c += 1;                                                                                                  \
+        if (live && st_c == stages) VK_WS_TILE_END(VK_WS_PBARRIER()) else VK_WS_PBARRIER();                         \
+      }
+      while (left_c != 0 && !stop) {
+        VK_WS_DMA_PROD(b0, b1)
+        if (stop) break;
+        VK_WS_DMA_PROD(b1, b2)
+        if (stop) break;
+        VK_WS_DMA_PROD(b2, b0)
+      }
+#undef VK_WS_DMA_PROD
+#undef VK_WS_DMA_BSTORE
+#undef VK_WS_DMA_BLOAD
+#undef VK_WS_DMA_ROWS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (nothing may land in LDS after the block has gone)
+      return;
+    }
+  }
+  if (!kDma && wave >= 4) {
     // ================================ row producer =======================================================
     // Rows of stage s live in register set s % N (N = 3, bf16: 6).  Iteration S: request the rows of stage S+N into the
     // set stage S left (converted one iteration ago), convert stage S+1 (the loads of S+2 .. S+N stay outstanding) into
@@ -896,7 +997,9 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   // the slot are offsets in a register): one copy of the gate's code.
 #define VK_WS_AB(FA, FB0, FB1, KK)                                                                                  \
   _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
-    FA[rt] = (kAbl & 32) ? abl_a[rt] : *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + (KK) * 16);      \
+    FA[rt] = (kAbl & 32) ? abl_a[rt]                                                                                \
+             : kDma      ? *reinterpret_cast<const f16x8 *>(dma_ab + (dma_off ^ ((KK) * 32u)) + rt * 4096)           \
+                         : *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + (KK) * 16);                  \
   FB0 = (kAbl & 16) ? abl_b[0] : bb[(KK) * kWave];                                                                  \
   FB1 = (kAbl & 16) ? abl_b[1] : bb[(4 + (KK)) * kWave];
 #define VK_WS_MM(FA, FB0, FB1)                                                                                      \
@@ -935,10 +1038,15 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     abl_b[0] = reinterpret_cast<const f16x8 *>(lds_b)[lane];
     abl_b[1] = reinterpret_cast<const f16x8 *>(lds_b)[lane + kWave];
   }
+  // (kDma: byte offset of the lane's fragment of K-step kk inside a ring slot -- row li, piece (2 kk + g) ^ swizzle)
+  // (piece 2 kk + g = 2 kk | g, so K-step kk is the offset of K-step 0 with bits 5-6 flipped by kk)
+  const uint32_t dma_off = li * 128u + ((g ^ ((li >> 1) & 7u)) * 16u);
+  uint32_t dma_slot = 0;
   unsigned long long ph[3] = {0, 0, 0}, tlast = __builtin_readcyclecounter();
   while (left_c != 0 && !stop) {
     VK_WS_TICK(2)
     const _Float16 *ab = lds_a + par * kBufHalfs + li * kFAStride + g * 8;
+    const char *dma_ab = reinterpret_cast<const char *>(lds_a) + dma_slot;
     const f16x8 *bb = reinterpret_cast<const f16x8 *>(lds_b + par * kWsBStage + (wave * 2) * 4 * kWave) + lane;
     if (has_q) {
       if (st_c == 0) VK_WS_STAGE(VK_WS_MMZ) else VK_WS_STAGE(VK_WS_MM)
@@ -960,6 +1068,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     left_c -= 1;
     st_c += 1;
     par ^= 1;
+    if constexpr (kDma) dma_slot = dma_slot + kDmaStageBytes == kDmaRing * kDmaStageBytes ? 0u : dma_slot + kDmaStageBytes;
     if (st_c == stages) {
       if (has_q) {
         if constexpr (kSample) {
@@ -1261,6 +1370,13 @@ __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_kernel(FlatFilterAr
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_kernel(FlatFilterArgs a) {
   flat_filter_body<true, false, false, false, 0, true>(a);
 }
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_dma_kernel(FlatFilterArgs a) {
+  flat_filter_body<true, false, false, false, 0, true, true>(a);
+}
+template <int kAbl>   // (experiments, VK_FILTER_ABLATE)
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_dma_abl_kernel(FlatFilterArgs a) {
+  flat_filter_body<true, false, false, false, kAbl, true, true>(a);
+}
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_sample_kernel(FlatFilterArgs a) {
   flat_filter_body<true, false, false, true, 0, true>(a);
 }
@@ -1271,6 +1387,9 @@ __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_sample_kernel(FlatF
   flat_filter_body<kBf16, kL2, false, true>(a);
 }
 
+size_t flat_filter_dma_lds_bytes() {
+  return (size_t)kDmaRing * kDmaStageBytes + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 + (size_t)2 * kFTileRows * 4 + 16;
+}
 size_t flat_filter_lds_bytes() {
   return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 +
          (size_t)2 * kFTileRows * 4 + 16;   // (+ the stop words)
@@ -1313,7 +1432,7 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
     const uint32_t nb = blocks < args.n_tiles ? blocks : args.n_tiles;
     return hipLaunchKernel(fn, dim3(nb), dim3(kFatThreads), params, lds, s);
   }
-  const size_t lds = flat_filter_lds_bytes();
+  size_t lds = flat_filter_lds_bytes();
   const void *fn = a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, true, false>)
                                   : reinterpret_cast<const void *>(&flat_filter_kernel<true, false, false>))
                           : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_kernel<false, true, false>)
@@ -1326,13 +1445,19 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
   if (a.qbf16) {
     if (!a.bf16 || a.l2) return hipErrorInvalidValue;
     fn = a.mode == 1 ? reinterpret_cast<const void *>(&flat_filter_bfmma_sample_kernel) : reinterpret_cast<const void *>(&flat_filter_bfmma_kernel);
+    if (a.mode == 0 && a.dma) {
+      fn = reinterpret_cast<const void *>(&flat_filter_bfmma_dma_kernel);
+      if (a.ablate_on) fn = (a.ablate & 112u) == 112u ? reinterpret_cast<const void *>(&flat_filter_bfmma_dma_abl_kernel<113>)
+                                                        : reinterpret_cast<const void *>(&flat_filter_bfmma_dma_abl_kernel<1>);
+      lds = flat_filter_dma_lds_bytes();
+    }
   }
   if (a.timing) {
     if (a.l2 || a.mode == 1 || a.qbf16) return hipErrorInvalidValue;
     fn = a.bf16 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, false, true>)
                 : reinterpret_cast<const void *>(&flat_filter_kernel<false, false, true>);
   }
-  if (a.ablate_on) {   // VK_FILTER_ABLATE: the experiment kernels (results invalid)
+  if (a.ablate_on && !(a.qbf16 && a.dma && a.mode == 0)) {   // VK_FILTER_ABLATE: the experiment kernels (results invalid)
     if (a.l2 || a.mode == 1 || a.qbf16) return hipErrorInvalidValue;
 #define VK_ABL(T, N) (a.bf16 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, false, T, N>) : reinterpret_cast<const void *>(&flat_filter_kernel<false, false, T, N>))
     switch (a.ablate & 240u) {

@@ -944,9 +944,10 @@ class FlatIndex final : public Index {
     f.l2 = l2() ? 1 : 0;
     const bool bfmma_off = getenv("VK_FILTER_BF16_MFMA") && atoi(getenv("VK_FILTER_BF16_MFMA")) == 0;   // (A/B: the f16 kernels)
     // (the experiment kernels -- phase timing, ablations, the four-fat-waves kernel -- are f16 kernels; read per call)
-    const bool filter_experiment = getenv("VK_FILTER_TIMING") || getenv("VK_FILTER_ABLATE") || getenv("VK_FAT_DBG") ||
+    const bool filter_experiment = getenv("VK_FILTER_TIMING") || (getenv("VK_FILTER_ABLATE") && !getenv("VK_FILTER_ABLATE_DMA")) || getenv("VK_FAT_DBG") ||
                                    (getenv("VK_FILTER_FAT") && atoi(getenv("VK_FILTER_FAT")) != 0);
     f.qbf16 = (store_.bf16() && !l2() && !bfmma_off && !filter_experiment) ? 1 : 0;
+    f.dma = (f.qbf16 && !(getenv("VK_FILTER_DMA") && atoi(getenv("VK_FILTER_DMA")) == 0)) ? 1 : 0;   // (read per call: A/B)
     f.hn16 = l2() ? d_hn16_.as<uint32_t>() : nullptr;
     f.labels = store_.d_labels();
     f.allow_bits = d_allow;
@@ -1022,7 +1023,7 @@ class FlatIndex final : public Index {
       static const bool fat_dbg = getenv("VK_FAT_DBG") != nullptr;   // cycle counters of the four-fat-waves kernel
       fm.timing = timing && !l2() && !fat_dbg;
       fm.prio = getenv("VK_FILTER_PRIO") ? (uint32_t)atoi(getenv("VK_FILTER_PRIO")) : 0u;   // (read per launch)
-      if (!l2() && getenv("VK_FILTER_ABLATE")) {   // (experiments, read per launch)
+      if (!l2() && getenv("VK_FILTER_ABLATE") && (!fm.qbf16 || fm.dma)) {   // (experiments, read per launch)
         fm.ablate_on = 1;
         fm.ablate = (uint32_t)atoi(getenv("VK_FILTER_ABLATE"));
       }
