@@ -516,7 +516,7 @@ def lib_multi_gpu(args, world, rank, dist, device):
         roofline = {"bound": "hbm", "achieved": round(scan_bytes / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(scan_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                     "per_gpu": True, "algorithmic_bytes": scan_bytes,
-                    "kernel": "flat_filter_kernel (slowest shard)" if filt_ms else "whole step (small shard: the exact kernels)",
+                    "kernel": "flat_filter_bdma_kernel (slowest shard)" if filt_ms else "whole step (small shard: the exact kernels)",
                     "per_launch_ms": round(kern_ms, 4), "launches_timed": int(filt_n), "step_ms_on_stream": round(dev_ms, 4),
                     "hbm_frac_of_whole_step": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "aggregate_gbs": round(world * scan_bytes / (dev_ms * 1e-3) / 1e9, 1),
@@ -658,7 +658,7 @@ def sharded_bf16_ip_leg(args, A, device, ws, devs):
             "step_ms_on_stream": round(ms, 3),
             "roofline": {"bound": "hbm", "per_gpu": True, "algorithmic_bytes": n * stride, "achieved": round(n * stride / (kern * 1e-3) / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * stride / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "kernel": "flat_filter_kernel<bf16> (slowest shard)" if fms else "whole step", "per_launch_ms": round(kern, 4)},
+                         "kernel": "flat_filter_bfmma_dma_kernel (slowest shard)" if fms else "whole step", "per_launch_ms": round(kern, 4)},
             "aggregate_scan_gbs": round(S * n * stride / (ms * 1e-3) / 1e9, 1),
             "parity_vs_oracle": "bit-exact" if okp else "MISMATCH", "build_s": round(build_s, 2),
             "leg_s": round(time.perf_counter() - t_leg, 1)}
@@ -1177,7 +1177,9 @@ def main():
             coalescer["native_callers"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        dominant = "flat_filter_kernel" if filt_n else ("flat_gemm_kernel" if B >= 5 else "flat_scan_kernel")
+        # (the final pass: B operands by DMA; bf16 rows in the inner-product space: bf16 MFMA, rows by DMA)
+        filter_name = "flat_filter_bfmma_dma_kernel" if args.dtype == "bf16" else "flat_filter_bdma_kernel"
+        dominant = filter_name if filt_n else ("flat_gemm_kernel" if B >= 5 else "flat_scan_kernel")
         traffic, traffic_src = pmc_traffic(N, D, B, world, dominant)
         qps = B * args.steps / dt
         scan_bytes = n_local * stride                       # algorithmic bytes of one pass over the shard
@@ -1202,7 +1204,7 @@ def main():
             "roofline": ({"bound": "hbm", "achieved": round(scan_bytes / (filt_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(scan_bytes / (filt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                           "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src, "algorithmic_bytes": scan_bytes,
-                          "kernel": "flat_filter_kernel", "per_launch_ms": round(filt_ms, 4), "launches_timed": int(filt_n),
+                          "kernel": filter_name, "per_launch_ms": round(filt_ms, 4), "launches_timed": int(filt_n),
                           "step_ms_on_stream": round(dev_ms, 4),
                           "hbm_frac_of_whole_step": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                           "filter": filt_stats,

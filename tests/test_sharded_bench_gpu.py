@@ -35,7 +35,7 @@ def test_single_process_two_shards():
     assert b["n_gpus"] == 2 and b["config"]["sharding"] == "rows/2" and "n_shards=2" in b["config"]["parallelism"]
     rf = b["roofline"]
     assert rf["bound"] == "hbm" and 0.0 < rf["frac"] <= 1.0 and rf["algorithmic_bytes"] == 300000 * 768 * 4
-    assert "flat_filter_kernel" in rf["kernel"] and rf["launches_timed"] == 3
+    assert "flat_filter_bdma_kernel" in rf["kernel"] and rf["launches_timed"] == 3
     assert rf["host_fanout_enqueue_us_per_step"] is not None
     assert b["cpu_baseline"] and b["cpu_baseline"]["value"] > 0 and b["cpu_baseline"]["kind"] == "port"
     assert b["config"]["parity_vs_oracle"] == "bit-exact"

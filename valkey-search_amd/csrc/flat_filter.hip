@@ -639,8 +639,15 @@ template <bool kBfMma> __device__ __forceinline__ f32x16 ws_mfma(f16x8 x, f16x8 
 // the consumers read stage S, stages S+1 .. S+4 are landing or in flight.
 constexpr int kDmaRing = 5;
 constexpr uint32_t kDmaStageBytes = kFTileRows * 128;
-template <bool kBf16, bool kL2, bool kTiming, bool kSample, int kAbl = 0, bool kBfMma = false, bool kDma = false>
+// kBDma: the B operands go L2 -> LDS by DMA as well -- a (query tile, K-step) block of the fragment-major query copy is
+// 1 KB, one DMA piece, and lands as the consumers read it; a ring of three B stages (the stage being read, the next one
+// landed or landing, one more in flight: the same two iterations between request and use as through three register sets)
+// and no registers, no LDS store instructions (which were most of what the B operands cost a stage: the VGPR -> LDS path
+// moves ~80 B per clock, 410 clocks for a 32 KB stage).  The query producers only issue the requests.
+constexpr int kBRing = 3;
+template <bool kBf16, bool kL2, bool kTiming, bool kSample, int kAbl = 0, bool kBfMma = false, bool kDma = false, bool kBDma = false>
 __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
+  static_assert(!kBDma || (!kDma && !kTiming && !kSample && kAbl == 0), "B by DMA: rows through registers, final pass, no experiment variants");
   static_assert(!kDma || (kBfMma && kBf16 && !kL2 && !kSample && !kTiming), "the DMA row path serves the bf16 final pass");
   // (experiment kernels only, kAbl != 0: a.ablate switches pieces of the pipeline OFF -- results invalid, times tell what bounds a stage:
   //  1 B producers do not store, 2 nor load; 4 row producers do not store, 8 nor load; kAbl 16 / 32: the consumers keep
@@ -649,7 +656,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   extern __shared__ _Float16 lds_a[];
   constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;                    // one A stage
   uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + (kDma ? kDmaRing * kDmaStageBytes / 2 : 2 * kBufHalfs));   // [2][kWsBStage]
-  uint32_t *lds_ring = reinterpret_cast<uint32_t *>(lds_b + 2 * kWsBStage); // [4 consumer waves][2][64]
+  uint32_t *lds_ring = reinterpret_cast<uint32_t *>(lds_b + (kBDma ? kBRing : 2) * kWsBStage); // [4 consumer waves][2][64]
   uint32_t *hn_lds = lds_ring + 4 * 2 * kWave;                              // [2][128] (kL2)
   // [2]: cancellation seen during tile T -> word T & 1.  (An LDS-qualified pointer: through a generic one the accesses
   // become FLAT instructions, whose out-of-order return forces every later wait for a load to be vmcnt(0).)
@@ -720,7 +727,45 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     else if (pr == 2) __builtin_amdgcn_s_setprio(2);
     else if (pr == 3) __builtin_amdgcn_s_setprio(3);
   }
-  if (!kDma && wave >= 6) {
+  if constexpr (kBDma) {
+    if (wave >= 6) {
+      // ================================ query producer, LDS-DMA ========================================
+      // wave p: query tiles 4p .. 4p+3, sixteen 1 KB pieces per stage.  Iteration S: request B(S+2) into the ring slot
+      // B(S-1) left, wait for B(S+1), barrier.
+      const uint32_t p = wave - 6, ks_n = a.row_stride_f / 16;
+      __attribute__((address_space(3))) char *bring = (__attribute__((address_space(3))) char *)lds_b;
+      FPos lb{first_tile * row_step, 0, total, row_step};
+      uint32_t slot_b = 0;                                                   // ring slot of the next request (bytes)
+#define VK_WS_BDMA_ISSUE()                                                                                          \
+      {                                                                                                             \
+        _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) {                                                          \
+          const uint32_t jt0 = p * 4 + t4, jt = jt0 < a.nqt ? jt0 : a.nqt - 1;                                      \
+          const __amdgpu_buffer_rsrc_t r_ = ws_rsrc(reinterpret_cast<const char *>(a.q16) + ((size_t)jt * ks_n + lb.st * 4) * kWave * 16); \
+          _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_, (__attribute__((address_space(3))) void *)(bring + slot_b + ((p * 4u + t4) * 4u + kk) * 1024u), \
+                                                     16, (int)(lane * 16), (int)(kk * 1024), 0, 0);                 \
+        }                                                                                                           \
+        fpos_advance(lb, stages);                                                                                   \
+        slot_b = slot_b + kWsBStage * 16u == kBRing * kWsBStage * 16u ? 0u : slot_b + kWsBStage * 16u;              \
+      }
+      VK_WS_BDMA_ISSUE()
+      VK_WS_BDMA_ISSUE()
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      VK_WS_PBARRIER()
+      while (left_c != 0 && !stop) {
+        const bool live = left_c != 0;
+        VK_WS_BDMA_ISSUE()
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        left_c -= live ? 1u : 0u;
+        st_c += 1;
+        if (live && st_c == stages) VK_WS_TILE_END(VK_WS_PBARRIER()) else VK_WS_PBARRIER();
+      }
+#undef VK_WS_BDMA_ISSUE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (nothing may land in LDS after the block has gone)
+      return;
+    }
+  }
+  if (!kDma && !kBDma && wave >= 6) {
     // ================================ query producer =====================================================
     // Stage s lives in register set s % 3.  Iteration S: request B(S+3) into the set B(S) left (written to LDS one iteration
     // ago), write B(S+1) -- requested two iterations ago -- to slot (S+1) & 1, barrier.  Past the end of the stream the
@@ -1041,13 +1086,13 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   // (kDma: byte offset of the lane's fragment of K-step kk inside a ring slot -- row li, piece (2 kk + g) ^ swizzle)
   // (piece 2 kk + g = 2 kk | g, so K-step kk is the offset of K-step 0 with bits 5-6 flipped by kk)
   const uint32_t dma_off = li * 128u + ((g ^ ((li >> 1) & 7u)) * 16u);
-  uint32_t dma_slot = 0;
+  uint32_t dma_slot = 0, b_slot = 0;                          // ring slots being read (kDma: bytes; kBDma: 16-byte units)
   unsigned long long ph[3] = {0, 0, 0}, tlast = __builtin_readcyclecounter();
   while (left_c != 0 && !stop) {
     VK_WS_TICK(2)
     const _Float16 *ab = lds_a + par * kBufHalfs + li * kFAStride + g * 8;
     const char *dma_ab = reinterpret_cast<const char *>(lds_a) + dma_slot;
-    const f16x8 *bb = reinterpret_cast<const f16x8 *>(lds_b + par * kWsBStage + (wave * 2) * 4 * kWave) + lane;
+    const f16x8 *bb = reinterpret_cast<const f16x8 *>(lds_b + (kBDma ? b_slot : par * kWsBStage) + (wave * 2) * 4 * kWave) + lane;
     if (has_q) {
       if (st_c == 0) VK_WS_STAGE(VK_WS_MMZ) else VK_WS_STAGE(VK_WS_MM)
       if constexpr ((kAbl & 128) != 0) VK_WS_STAGE(VK_WS_MM)   // (experiment: a stage's MFMAs twice per barrier)
@@ -1069,6 +1114,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     st_c += 1;
     par ^= 1;
     if constexpr (kDma) dma_slot = dma_slot + kDmaStageBytes == kDmaRing * kDmaStageBytes ? 0u : dma_slot + kDmaStageBytes;
+    if constexpr (kBDma) b_slot = b_slot + kWsBStage == kBRing * kWsBStage ? 0u : b_slot + kWsBStage;
     if (st_c == stages) {
       if (has_q) {
         if constexpr (kSample) {
@@ -1373,6 +1419,11 @@ __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_kernel(FlatFi
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_dma_kernel(FlatFilterArgs a) {
   flat_filter_body<true, false, false, false, 0, true, true>(a);
 }
+// B operands by DMA (rows through registers): the final pass of every row format and space except the bf16 DMA kernel
+template <bool kBf16, bool kL2, bool kBfMma>
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bdma_kernel(FlatFilterArgs a) {
+  flat_filter_body<kBf16, kL2, false, false, 0, kBfMma, false, true>(a);
+}
 template <int kAbl>   // (experiments, VK_FILTER_ABLATE)
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_dma_abl_kernel(FlatFilterArgs a) {
   flat_filter_body<true, false, false, false, kAbl, true, true>(a);
@@ -1389,6 +1440,10 @@ __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_sample_kernel(FlatF
 
 size_t flat_filter_dma_lds_bytes() {
   return (size_t)kDmaRing * kDmaStageBytes + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 + (size_t)2 * kFTileRows * 4 + 16;
+}
+size_t flat_filter_bdma_lds_bytes() {
+  return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)kBRing * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 +
+         (size_t)2 * kFTileRows * 4 + 16;
 }
 size_t flat_filter_lds_bytes() {
   return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 +
@@ -1451,6 +1506,14 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
                                                         : reinterpret_cast<const void *>(&flat_filter_bfmma_dma_abl_kernel<1>);
       lds = flat_filter_dma_lds_bytes();
     }
+  }
+  if (a.bdma && a.mode == 0 && !a.timing && !a.ablate_on && !(a.qbf16 && a.dma)) {
+    fn = a.qbf16 ? reinterpret_cast<const void *>(&flat_filter_bdma_kernel<true, false, true>)
+         : a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_bdma_kernel<true, true, false>)
+                          : reinterpret_cast<const void *>(&flat_filter_bdma_kernel<true, false, false>))
+                  : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_bdma_kernel<false, true, false>)
+                          : reinterpret_cast<const void *>(&flat_filter_bdma_kernel<false, false, false>));
+    lds = flat_filter_bdma_lds_bytes();
   }
   if (a.timing) {
     if (a.l2 || a.mode == 1 || a.qbf16) return hipErrorInvalidValue;

@@ -948,6 +948,7 @@ class FlatIndex final : public Index {
                                    (getenv("VK_FILTER_FAT") && atoi(getenv("VK_FILTER_FAT")) != 0);
     f.qbf16 = (store_.bf16() && !l2() && !bfmma_off && !filter_experiment) ? 1 : 0;
     f.dma = (f.qbf16 && !(getenv("VK_FILTER_DMA") && atoi(getenv("VK_FILTER_DMA")) == 0)) ? 1 : 0;   // (read per call: A/B)
+    f.bdma = (getenv("VK_FILTER_BDMA") && atoi(getenv("VK_FILTER_BDMA")) == 0) ? 0u : 1u;                // (read per call: A/B)
     f.hn16 = l2() ? d_hn16_.as<uint32_t>() : nullptr;
     f.labels = store_.d_labels();
     f.allow_bits = d_allow;
