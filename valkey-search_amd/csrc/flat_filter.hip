@@ -732,13 +732,14 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       // ================================ query producer, LDS-DMA ========================================
       // wave p: query tiles 4p .. 4p+3, sixteen 1 KB pieces per stage.  Iteration S: request B(S+2) into the ring slot
       // B(S-1) left, wait for B(S+1), barrier.
+      constexpr int kTiles = 4;
       const uint32_t p = wave - 6, ks_n = a.row_stride_f / 16;
       __attribute__((address_space(3))) char *bring = (__attribute__((address_space(3))) char *)lds_b;
       FPos lb{first_tile * row_step, 0, total, row_step};
       uint32_t slot_b = 0;                                                   // ring slot of the next request (bytes)
 #define VK_WS_BDMA_ISSUE()                                                                                          \
       {                                                                                                             \
-        _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) {                                                          \
+        _Pragma("unroll") for (int t4 = 0; t4 < kTiles; ++t4) {                                                     \
           const uint32_t jt0 = p * 4 + t4, jt = jt0 < a.nqt ? jt0 : a.nqt - 1;                                      \
           const __amdgpu_buffer_rsrc_t r_ = ws_rsrc(reinterpret_cast<const char *>(a.q16) + ((size_t)jt * ks_n + lb.st * 4) * kWave * 16); \
           _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
@@ -959,6 +960,9 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       VK_WS_TICK(0)                                                                                                 \
       ppar ^= 1;                                                                                                    \
       if (!(abl & 4u)) ws_rows_store<kBf16, kL2, kSample, kBfMma>(lds_a + ppar * kBufHalfs, hn_lds + ppar * kFTileRows, t, RSTORE, (abl & 512u) != 0); \
+      else if (abl & 1024u) {   /* (experiment: wait for the stage's rows, neither convert nor store them) */      \
+        _Pragma("unroll") for (int u_ = 0; u_ < (kBf16 ? 8 : 16); ++u_) asm volatile("" ::"v"(RSTORE.v[u_]));       \
+      }                                                                                                             \
       if constexpr (timing) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
       VK_WS_TICK(2)                                                                                                 \
       left_c -= live ? 1u : 0u;                                                                                     \
