@@ -320,6 +320,51 @@ def test_bf16_rows_through_the_filter(vsa, oracle, metric):
         _same(got, e.search_batch(Q[:nq], k))
 
 
+@pytest.mark.parametrize("metric", ["COSINE", "IP"])
+def test_the_final_pass_kernels_agree(vsa, oracle, metric):
+    """The final pass has several kernels behind one gate: B operands by DMA or through registers (VK_FILTER_BDMA), bf16 rows
+    on the bf16 matrix cores with the rows by DMA or through registers (VK_FILTER_DMA), or converted to f16
+    (VK_FILTER_BF16_MFMA=0).  Same answer from each -- the exact kernel's, bit for bit -- and, where the arithmetic is the
+    same, the same survivors.  Rows of very different scales next to each other (the margins are per tile), a stretch of
+    near-duplicates around one query (many pairs close to the gate), stage counts of 1, 3 and 12."""
+    rng = np.random.default_rng(2024)
+    for dim, n in ((64, 90_000), (192, 70_000), (768, 40_000)):
+        centres = rng.standard_normal((30, dim)).astype(np.float32)
+        x = centres[rng.integers(0, 30, n)] + 0.4 * rng.standard_normal((n, dim)).astype(np.float32)
+        if metric == "COSINE":
+            x = _unit(x)
+        else:
+            x *= np.exp(rng.uniform(np.log(1e-3), np.log(30.0), (n, 1))).astype(np.float32)     # row norms over four decades
+        x[5000:7000] = x[4999] * (1.0 + 1e-3 * rng.standard_normal((2000, 1))).astype(np.float32) + \
+            1e-3 * rng.standard_normal((2000, dim)).astype(np.float32) * np.abs(x[4999]).max()
+        Q = centres[rng.integers(0, 30, 160)] + 0.4 * rng.standard_normal((160, dim)).astype(np.float32)
+        Q[3] = x[4999]
+        if metric == "COSINE":
+            Q = _unit(Q)
+        for dtype, variants in (("f32", [dict(VK_FILTER_BDMA=0)]),
+                                ("bf16", [dict(VK_FILTER_DMA=0), dict(VK_FILTER_DMA=0, VK_FILTER_BDMA=0),
+                                          dict(VK_FILTER_BF16_MFMA=0), dict(VK_FILTER_BF16_MFMA=0, VK_FILTER_BDMA=0)])):
+            f, e = _pair(vsa, dim, metric, x, dtype=dtype)
+            for nq, k in ((160, 10), (37, 3)):
+                want = e.search_batch(Q[:nq], k)
+                got = f.search_batch(Q[:nq], k)
+                c0 = f.stats().last_filter_candidates
+                assert c0 >= nq * k and f.stats().last_filter_fallback == 0
+                _same(got, want)
+                counts = {}
+                for env in variants:
+                    with _Env(**env):
+                        _same(f.search_batch(Q[:nq], k), want)
+                        st = f.stats()
+                    assert st.last_filter_candidates >= nq * k and st.last_filter_fallback == 0, env
+                    counts[tuple(sorted(env))] = st.last_filter_candidates
+                if dtype == "f32":
+                    assert counts[("VK_FILTER_BDMA",)] == c0                      # same arithmetic, same survivors
+                else:
+                    assert counts[("VK_FILTER_DMA",)] == c0 == counts[("VK_FILTER_BDMA", "VK_FILTER_DMA")]
+                    assert counts[("VK_FILTER_BF16_MFMA",)] == counts[("VK_FILTER_BDMA", "VK_FILTER_BF16_MFMA")]
+
+
 @pytest.mark.parametrize("dim,dtype", [(64, "f32"), (200, "f32"), (768, "f32"), (128, "bf16")])
 def test_l2_through_the_filter(vsa, oracle, dim, dtype):
     """L2: the filter accumulates x.q - |x|^2/2 (the half norms ride along as one more K-step), the gate and the exact
