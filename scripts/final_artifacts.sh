@@ -44,3 +44,10 @@ timeout 300 python scripts/fanout_probe.py --rows 10000000 --shards 8 > gpurun_o
 VK_SHARD_THREADS=0 timeout 300 python scripts/fanout_probe.py --rows 10000000 --shards 8 --skip-unsharded > gpurun_out/r03_fanout_probe_serial.json 2>/dev/null; cat gpurun_out/r03_fanout_probe_serial.json
 # the N > 1 bench line, 8 logical shards on one GPU (the driver's multi-GPU run uses 8 physical ones)
 timeout 1500 python bench.py --gpus 8 --same-device --bf16-rows 1250000 --steps 20 --warmup 5 > gpurun_out/r03_bench_8_logical_shards.log 2> gpurun_out/r03_bench_8_logical_shards.err; tail -c 400 gpurun_out/r03_bench_8_logical_shards.log
+# what bounds a stage of the candidate filter: the ablation matrix (f16 experiment kernels over f32 / bf16 rows, the bf16
+# DMA kernel's own) and the A/B switches of the final-pass kernels, all on this one lease
+timeout 600 python scripts/filter_ablate.py --steps 30 --ablate=-1,0,1,3,7,1031,12,15,115,119,127 2>/dev/null > gpurun_out/r03_filter_ablations.log; cat gpurun_out/r03_filter_ablations.log | cut -c1-120
+VK_FILTER_ABLATE_DMA=1 timeout 300 python scripts/filter_ablate.py --dtypes bf16 --steps 30 --ablate=-1,0,1,3,8,11,115,120,123 2>/dev/null > gpurun_out/r03_filter_ablations_bf16_dma.log; cat gpurun_out/r03_filter_ablations_bf16_dma.log | cut -c1-120
+( for e in "" "VK_FILTER_BDMA=0" "VK_FILTER_DMA=0" "VK_FILTER_DMA=0 VK_FILTER_BDMA=0" "VK_FILTER_BF16_MFMA=0" "VK_FILTER_BF16_MFMA=0 VK_FILTER_BDMA=0"; do
+    echo "== switches: ${e:-(defaults)}"; env $e timeout 300 python scripts/filter_ablate.py --steps 30 --ablate=-1 2>/dev/null | cut -c1-120; done ) > gpurun_out/r03_filter_kernel_ab.log; cat gpurun_out/r03_filter_kernel_ab.log
+timeout 300 python scripts/flat_l2_batch.py > gpurun_out/r03_flat_l2_batch.log 2>/dev/null; cat gpurun_out/r03_flat_l2_batch.log
