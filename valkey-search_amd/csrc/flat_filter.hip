@@ -45,10 +45,14 @@
 //   rows     393 KB f32 from HBM, once -> converted -> f16 in LDS (two stages of 18 KB, 144-B row stride: conflict-free
 //            ds_read_b128) -> A operands of the four multiplying waves
 //   queries  the batch's f16 copy in MFMA fragment order (flat_qprep_kernel, 384 KB at 256 x 768) comes from L2, one
-//            32 KB stage at a time, through LDS -> B operands
+//            32 KB stage at a time, through LDS -> B operands; in the final pass by DMA (buffer_load ... lds) into a ring
+//            of three stages, no registers and no LDS store instructions in between (kBDma)
 // so HBM traffic is the row bytes and L2 traffic twice that (PMC: TCC misses 30.8 GB, hits 30.8 GB per launch).
-// Roofline: HBM (30.72 GB per launch at 10M x 768 f32); the matrix cores are about one third busy (3.9 TFLOP of f16
-// per launch against 2.5 PFLOP/s).
+// bf16 rows in the inner-product space (kBfMma, kDma): rows and queries stay bf16, the bf16 matrix-core instruction
+// multiplies (query rounding 2^-9 in the margin), and the ROWS go HBM -> LDS by DMA (swizzled 128-B rows, ring of five).
+// Roofline: HBM (30.72 GB per launch at 10M x 768 f32).  The matrix cores: 3.9 PFLOP of f16 per launch; their stream alone
+// (no operands fetched, no gate) takes 2.3-2.4 ms of a 5.1-5.2 ms launch at the clock the chip sustains under it --
+// scripts/filter_ablate.py and DESIGN.md section 5 have the whole ablation matrix (VK_FILTER_ABLATE below).
 #include <stdlib.h>
 
 #include "device_common.hpp"

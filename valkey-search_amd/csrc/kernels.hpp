@@ -96,7 +96,7 @@ struct FlatFilterArgs {
   uint32_t qbf16;             // bf16 rows, inner-product space: q16 holds bf16 fragments and the bf16 matrix-core instruction multiplies
   uint32_t bdma;              // final pass: the B operands go L2 -> LDS by DMA, a ring of three stages (VK_FILTER_BDMA=0: through registers)
   uint32_t dma;               // with qbf16, final pass: the rows go HBM -> LDS by DMA (VK_FILTER_DMA=0: through registers)
-  void *q16;                  // [nqt][row_stride_f/16][64][8] f16: the queries in MFMA fragment order (written by qprep)
+  void *q16;                  // [nqt][row_stride_f/16][64][8] f16 (qbf16: bf16): the queries in MFMA fragment order (written by qprep)
   // per query column (written by qprep): the error margin of an approximate score against a row of norm R as a
   // polynomial  E(R) = c2 R^2 + c1 R + c0  (x, y, z), and the column's state (w: 0 = live, 1 = closed -- a padding
   // column, or a query that cannot go through f16 and was handed to the exact pass)
