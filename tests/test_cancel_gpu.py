@@ -84,20 +84,29 @@ def test_hnsw_cancel_interrupts_a_long_filtered_batch(vsa, oracle):
     assert lag is not None and lag < 0.02
 
 
-@pytest.mark.parametrize("metric,nq,filt", [("L2", 2048, 0), ("COSINE", 4096, 0), ("COSINE", 4096, 1), ("L2", 4096, 1), ("COSINE", 32768, 1)])
-def test_flat_cancel_returns_what_it_has(vsa, oracle, metric, nq, filt):
+def _bf16_rne(x):
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("metric,nq,filt,dtype", [("L2", 2048, 0, "f32"), ("COSINE", 4096, 0, "f32"), ("COSINE", 4096, 1, "f32"),
+                                                  ("L2", 4096, 1, "f32"), ("COSINE", 32768, 1, "f32"), ("COSINE", 32768, 1, "bf16")])
+def test_flat_cancel_returns_what_it_has(vsa, oracle, metric, nq, filt, dtype):
     """filt = 0: the exact kernels (VALU scan / f32 matrix-core kernel: batches long enough to time the reaction);
-    filt = 1: the f16 candidate filter + re-rank (a batch of a few milliseconds: only the answer is checked)"""
+    filt = 1: the matrix-core candidate filter + re-rank (a batch of a few milliseconds: only the answer is checked);
+    bf16 rows: the kernel whose rows arrive by DMA (requests in flight when the block leaves must not land in LDS later)"""
     import os
     rng = np.random.default_rng(32)
     n, dim, k = 1_000_000, 128, 10
     x = rng.standard_normal((n, dim)).astype(np.float32)
     if metric == "COSINE":
         x /= np.linalg.norm(x, axis=1, keepdims=True)
+    if dtype == "bf16":
+        x = _bf16_rne(x)                                   # (what the index stores; the oracle distances below are over these)
     old = os.environ.get("VK_FLAT_FILTER")
     os.environ["VK_FLAT_FILTER"] = str(filt)
     try:
-        g = vsa.Index("FLAT", dim, metric, initial_cap=n)
+        g = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype)
     finally:
         if old is None:
             os.environ.pop("VK_FLAT_FILTER")
