@@ -89,6 +89,51 @@ def test_filter_path_equals_exact_matrix_core_kernel_at_full_size(world):
         assert (Nf == Ne).all() and (Lf == Le).all() and (Df.view(np.uint32) == De.view(np.uint32)).all()
 
 
+def test_bf16_shard_of_config3_at_full_size(world, oracle):
+    """One GPU's shard of BASELINE configs[3] (FLAT 10M x 768, bf16 rows, IP) at full size: the batched path (bf16
+    matrix-core filter, rows by DMA, + exact re-rank) agrees bit for bit with the single-query scan, with the same filter's
+    other final-pass kernels (rows through registers; converted to f16) and -- restricted to a sample of rows -- with the
+    oracle over the rounded rows."""
+    import os
+    import torch
+    from bench import gen_rows, device_view_typed
+    vsa, _, _, Q = world
+    dev = torch.device("cuda", 0)
+    ix = vsa.Index("FLAT", D, "IP", initial_cap=N, device_id=0, dtype="bf16")
+    ptr, stride = ix.device_rows(N)
+    table = device_view_typed(ptr, (N, stride // 2), dev, "<i2").view(torch.bfloat16)
+    for lo, x in gen_rows(0, N, D, dev):
+        table[lo:lo + x.shape[0], :D] = x              # round to nearest even, as the library's ingest does
+    torch.cuda.synchronize()
+    ix.commit_device_rows(N, np.arange(N, dtype=np.uint64))
+    Db, Lb, Nb = ix.search_batch(Q, K)
+    st = ix.stats()
+    assert (Nb == K).all() and st.last_filter_candidates >= B * K and st.last_filter_fallback == 0
+    for i in range(0, B, 8):                           # one query per call: the scan kernel
+        d, l = ix.search(Q[i], K)
+        assert l.tolist() == Lb[i].tolist() and d.view(np.uint32).tolist() == Db[i].view(np.uint32).tolist()
+    for env in ({"VK_FILTER_DMA": "0"}, {"VK_FILTER_BF16_MFMA": "0"}):
+        os.environ.update(env)
+        try:
+            D2, L2, _ = ix.search_batch(Q, K)
+        finally:
+            for k_ in env:
+                os.environ.pop(k_)
+        assert (L2 == Lb).all() and (D2.view(np.uint32) == Db.view(np.uint32)).all(), env
+    S = 60_000
+    sample = np.arange(0, N, N // S, dtype=np.uint64)[:S]
+    host = np.ascontiguousarray(table[torch.from_numpy(sample.astype(np.int64)).to(dev), :D].float().cpu().numpy())
+    o = oracle.Flat(D, "IP", max_elements=S)
+    o.add_many(host, sample)
+    bits = oracle.allow_bitmap(sample, N)
+    Df, Lf, Nf = ix.search_batch(Q[:16], K, allow=bits, allow_nbits=N)
+    for i in range(16):
+        od, ol = o.search(Q[i], K)
+        assert Lf[i, :Nf[i]].tolist() == ol.tolist() and Df[i, :Nf[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+    del ix, table
+    torch.cuda.empty_cache()
+
+
 def test_filtered_answer_equals_oracle_on_the_sample(world, oracle):
     vsa, ix, table, Q = world
     S = 60_000
