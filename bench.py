@@ -179,6 +179,12 @@ def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
     for i in range(64):
         h.search(hq[i], K, ef=ef)
     lat_ms = (time.perf_counter() - t1) / 64 * 1e3
+    # single-query traffic through the dispatcher (submit: 8 producers, 4 batches of 8192 outstanding; blocking: 256 callers)
+    try:
+        serving = serving_leg(h, hq, K, head["gpu_qps"], max_batch=nq, wait_us=2000, producers=8, window=4 * nq, total=16 * nq,
+                              threads=256, calls=64, ef=ef)
+    except Exception as e:   # noqa: BLE001
+        serving = {"error": f"{type(e).__name__}: {e}"}
     # CPU: the oracle searches the very same graph (SaveIndex chunk stream straight into its C loader), one query per
     # thread on every quota thread, each thread with its own visited list like hnswlib's pool
     t1 = time.perf_counter()
@@ -208,7 +214,7 @@ def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
                          "frac": head["frac_of_hbm_peak"], "kernel": "hnsw_search_hash_kernel",
                          "bytes": "n_eval*(D*4+4) + n_hops*132 per query, counted by the kernel",
                          "gather_ceiling_gbs": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r01_gather_ceiling_10Mx768.log"},
-            "matched_recall_0.95": matched, "ef_sweep": sweep,
+            "matched_recall_0.95": matched, "ef_sweep": sweep, "single_query_serving": serving,
             "cpu": {"kind": "port", "threads": threads, "qps": round(ncq / cdt, 1), "qps_per_thread": round(ncq / cdt / threads, 1),
                     "queries": ncq, "ef": ef, "recall_at_10": round(cpu_recall, 4), "same_graph": True,
                     "ids_identical_to_gpu": f"{same}/{ncq}", "graph_export_s": round(export_s, 2)},
@@ -280,7 +286,7 @@ def bf16_ip_leg(args, A, device, stream_ptr, local_rank):
     from oracle import oracle as O
     N, D, B, K = args.bf16_rows, args.dim, args.batch, args.k
     t_leg = time.perf_counter()
-    ix = vsa.Index("FLAT", D, "IP", initial_cap=N, device_id=local_rank, dtype="bf16")
+    ix = vsa.Index("FLAT", D, "IP", initial_cap=N, device_id=local_rank, dtype="bf16", options={"kernel-timing": 1})
     base_ptr, stride = ix.device_rows(N)
     table = device_view_typed(base_ptr, (N, stride // 2), device, "<i2").view(torch.bfloat16)
     if stride != D * 2:
@@ -401,9 +407,26 @@ def _fill_shard(ix, shard, r0, n, D, sdev, bf16):
     return tab
 
 
+def _shard_filter_ms(ix, before, after=None):
+    """the SLOWEST shard's final-pass time per launch: max over shards of a shard's own delta(ns) / delta(batches)
+    (vk_index_shard_stats; a difference of maxima over shards would not be any shard's time).  With after=None returns the
+    per-shard snapshot to pass back in as `before`."""
+    snap = [ix.shard_stats(s) for s in range(ix.shard_count())]
+    if before is None:
+        return snap
+    best, n = None, 0
+    for b, a in zip(before, snap):
+        db = a.filter_batches - b.filter_batches
+        if db:
+            ms = (a.filter_kernel_ns - b.filter_kernel_ns) / 1e6 / db
+            best = ms if best is None else max(best, ms)
+            n = max(n, db)
+    return best, n
+
+
 def _timed_steps(step, steps, warmup):
     """HIP events on the current stream + the wall clock around `steps` calls (after `warmup` untimed ones)"""
-    for _ in range(max(1, warmup)):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -438,7 +461,7 @@ def lib_multi_gpu(args, world, rank, dist, device):
             if vsa.lib().vk_device_count() < (1 if args.same_device else world):
                 raise RuntimeError(f"this process sees {vsa.lib().vk_device_count()} HIP devices, needs {world}")
             t_build = time.time()
-            ix = vsa.Index("FLAT", D, "COSINE", initial_cap=N, dtype=args.dtype, shard_devices=devs)
+            ix = vsa.Index("FLAT", D, "COSINE", initial_cap=N, dtype=args.dtype, shard_devices=devs, options={"kernel-timing": 1})
             tabs = []
             for s_i, dv in enumerate(devs):
                 r0, r1 = s_i * N // world, (s_i + 1) * N // world
@@ -484,6 +507,7 @@ def lib_multi_gpu(args, world, rank, dist, device):
 
     barrier()
     st0 = state["ix"].stats() if rank == 0 else None
+    sh0 = _shard_filter_ms(state["ix"], None) if rank == 0 else None
     t0 = time.perf_counter()
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -508,8 +532,7 @@ def lib_multi_gpu(args, world, rank, dist, device):
         scan_bytes = n_local * stride                  # algorithmic bytes of one pass over ONE GPU's shard
         # the dominant kernel per shard: the candidate filter; its duration = the SLOWEST shard's HIP events (the library
         # records them around the launches on each shard's stream; vk_index_stats of a sharded index reports the maximum)
-        filt_n = st1.filter_batches - st0.filter_batches
-        filt_ms = (st1.filter_kernel_ns - st0.filter_kernel_ns) / 1e6 / filt_n if filt_n else None
+        filt_ms, filt_n = _shard_filter_ms(ix, sh0)
         fan_calls = st1.fanout_calls - st0.fanout_calls
         fan_us = (st1.fanout_enqueue_ns - st0.fanout_enqueue_ns) / 1e3 / fan_calls if fan_calls else None
         kern_ms = filt_ms if filt_ms else dev_ms
@@ -623,7 +646,7 @@ def sharded_bf16_ip_leg(args, A, device, ws, devs):
     from oracle import oracle as O
     n, D, B, K, S = args.bf16_rows, args.dim, args.batch, args.k, len(devs)
     t_leg = time.perf_counter()
-    ix = vsa.Index("FLAT", D, "IP", initial_cap=n * S, dtype="bf16", shard_devices=devs)
+    ix = vsa.Index("FLAT", D, "IP", initial_cap=n * S, dtype="bf16", shard_devices=devs, options={"kernel-timing": 1})
     first = None
     for s_i, dv in enumerate(devs):
         tab = _fill_shard(ix, s_i, s_i * n, n, D, torch.device("cuda", dv), True)
@@ -635,12 +658,13 @@ def sharded_bf16_ip_leg(args, A, device, ws, devs):
     od = torch.empty(B, K, device=device, dtype=torch.float32)
     ol = torch.empty(B, K, device=device, dtype=torch.int64)
     on = torch.empty(B, device=device, dtype=torch.int32)
-    st0 = ix.stats()
-    ms, wall_ms = _timed_steps(lambda: ix.search_batch_device(Q.data_ptr(), B, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(),
-                                                              stream=ws.cuda_stream), args.steps, args.warmup)
-    st1 = ix.stats()
-    fb = st1.filter_batches - st0.filter_batches
-    fms = (st1.filter_kernel_ns - st0.filter_kernel_ns) / 1e6 / fb if fb else None
+    step = lambda: ix.search_batch_device(Q.data_ptr(), B, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), stream=ws.cuda_stream)   # noqa: E731
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    sh0 = _shard_filter_ms(ix, None)
+    ms, wall_ms = _timed_steps(step, args.steps, 0)
+    fms, _fb = _shard_filter_ms(ix, sh0)
     Sn = first.shape[0]
     o = O.Flat(D, "IP", isa="skylake", max_elements=Sn)
     o.add_many(first, np.arange(Sn, dtype=np.uint64), borrowed=True)
@@ -781,60 +805,35 @@ def sharded_hnsw_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows):
     return out
 
 
-def native_coalescer_leg(rows=2_000_000, dim=768, threads=256, calls=50):
-    """The same experiment without the interpreter in the way: scripts/coalescer_native (C++ against include/vk_index.h,
-    built by __graft_entry__.build()) -- `threads` native threads of single-query vk_index_search calls on its own FLAT
-    index of `rows` x `dim` (the Python leg above is bound by 64 interpreter threads, not by the library)."""
-    import re
-    import subprocess
-    exe = ROOT / "scripts" / "coalescer_native"
-    if not exe.exists():
-        return None
-    txt = subprocess.run([str(exe), str(rows), str(dim), str(threads), str(calls)], capture_output=True, text=True, timeout=300).stdout
-    out = {"workload": f"FLAT {rows}x{dim} cosine k=10, {threads} native threads x {calls} single-query calls", "on": []}
-    m = re.search(r"coalescing off, (\d+) callers: (\d+) queries/s", txt)
-    if m:
-        out["off_qps"], out["off_callers"] = int(m.group(2)), int(m.group(1))
-    for m in re.finditer(r"max_wait (\d+) us\), \d+ callers x \d+ calls: (\d+) queries/s, (\d+) device batches, mean batch ([0-9.]+)", txt):
-        out["on"].append({"max_wait_us": int(m.group(1)), "qps": int(m.group(2)), "device_batches": int(m.group(3)), "mean_batch": float(m.group(4))})
-    return out
+def serving_leg(ix, hq, K, device_qps, max_batch, wait_us, producers, window, total, threads, calls, ef=0):
+    """N1, the path a real FT.SEARCH takes: SINGLE-QUERY requests against the index of the headline / HNSW leg, driven
+    natively (scripts/serving_probe.cc through ctypes, no interpreter in the loop).
+      submit    vk_index_search_submit: `producers` threads keep `window` requests outstanding -- query::SearchAsync's shape
+                (search.cc:886-910: the queue holds up to max-query-queue-depth requests whatever the number of reader threads)
+      blocking  `threads` callers of vk_index_search back to back (the reader pool as it is today)
+    Every answer is compared (ids and distance bits) with the answer of the same query in one vk_index_search_batch call;
+    device_qps = what the device does on a full resident batch (the headline number), for the ratio."""
+    rd, rl, rn = ix.search_batch(hq, K, ef=ef)
+    assert (rn == K).all()
+    ix.set_coalescing(max_batch, wait_us)
+    try:
+        vsa.probe_submit(ix, hq, K, min(total, 4 * max_batch), producers, window, ef, ref=(rd, rl))     # warm-up: runner threads, contexts
+        sub = vsa.probe_submit(ix, hq, K, total, producers, window, ef, ref=(rd, rl))
+        blk = vsa.probe_blocking(ix, hq, K, threads, calls, ef, ref=(rd, rl))
+    finally:
+        ix.set_coalescing(0, 0)
+    st = ix.stats()
 
+    def row(r, **kw):
+        return {**kw, "qps": round(r.qps, 1), "of_device_batch_rate": round(r.qps / device_qps, 3) if device_qps else None,
+                "requests": int(r.completed), "answers_identical": bool(r.mismatches == 0 and r.errors == 0), "rejected_busy": int(r.rejected),
+                "device_batches": int(r.device_batches), "mean_batch": round(r.mean_batch, 1), "batches_in_flight": int(r.max_batches_in_flight),
+                "latency_us": {"p50": round(r.p50_us, 1), "p99": round(r.p99_us, 1), "max": round(r.max_us, 1)}}
 
-def coalescer_leg(ix, hq, K, threads=64, per_thread=4):
-    """N1: the reference issues one query per FT.SEARCH from a pool of reader threads (search.cc:886-910).
-    `threads` callers each issue `per_thread` single-query vk_index_search calls, first one at a time per
-    call (a device pass each), then with vk_index_set_coalescing merging concurrent calls into batches."""
-    import threading
-
-    def drive(n_threads):
-        out = [None] * (n_threads * per_thread)
-
-        def worker(t):
-            for r in range(per_thread):
-                i = t * per_thread + r
-                out[i] = ix.search_one(hq[i % len(hq)], K)
-
-        ts = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
-        t0 = time.perf_counter()
-        [t.start() for t in ts]
-        [t.join() for t in ts]
-        return time.perf_counter() - t0, out
-
-    ix.set_coalescing(0, 0)
-    dt0, ref = drive(threads)
-    before = ix.stats()
-    wait_us = int(os.environ.get("VK_BENCH_COALESCE_WAIT_US", "300"))
-    ix.set_coalescing(threads, wait_us)
-    dt1, got = drive(threads)
-    after = ix.stats()
-    ix.set_coalescing(0, 0)
-    same = all(a[1].tolist() == b[1].tolist() and a[0].view(np.uint32).tolist() == b[0].view(np.uint32).tolist()
-               for a, b in zip(ref, got))
-    nq = threads * per_thread
-    batches = after.coalesced_batches - before.coalesced_batches
-    return {"callers": threads, "queries": nq, "uncoalesced_qps": round(nq / dt0, 1), "coalesced_qps": round(nq / dt1, 1),
-            "device_batches": int(batches), "mean_batch": round(nq / max(1, batches), 1), "max_wait_us": wait_us,
-            "answers_identical": bool(same)}
+    return {"max_batch": max_batch, "max_wait_us": wait_us, "device_batch_qps": round(device_qps, 1) if device_qps else None,
+            "submit": row(sub, producers=producers, outstanding=window),
+            "blocking": row(blk, callers=threads, calls_per_caller=calls),
+            "latency_hist_us_pow2_from_64": list(st.latency_hist)}
 
 
 def _baseline_metric():
@@ -905,6 +904,10 @@ def main():
     ap.add_argument("--hybrid-queries", type=int, default=4096)
     ap.add_argument("--bf16-rows", type=int, default=-1,
                     help="one shard of BASELINE.json configs[3] (FLAT bf16 IP): rows, -1 = as --rows, 0 = skip")
+    ap.add_argument("--config-shards", type=int, default=8,
+                    help="N = 1: run BASELINE.json configs[3] / configs[4] AT THEIR STATED SIZE as this many LOGICAL shards of one "
+                         "vk_index on the one GPU (8 x --bf16-rows bf16 rows = 80M x 768 = 122.9 GB; 8 graphs of --hybrid-rows rows); "
+                         "0 or 1 = one shard of each instead")
     ap.add_argument("--hnsw-sharded", action=argparse.BooleanOptionalAction, default=True,
                     help="N > 1: the sharded HNSW leg (one graph per GPU; matched-ef and matched-recall points)")
     ap.add_argument("--hnsw-single-ref", action=argparse.BooleanOptionalAction, default=True,
@@ -958,7 +961,8 @@ def main():
     t_build = time.time()
     bf16 = args.dtype == "bf16"
     esz = 2 if bf16 else 4
-    ix = vsa.Index("FLAT", D, "COSINE", initial_cap=n_local, device_id=local_rank, dtype=args.dtype)
+    ix = vsa.Index("FLAT", D, "COSINE", initial_cap=n_local, device_id=local_rank, dtype=args.dtype,
+                   options={"kernel-timing": 1})   # (HIP event pairs around the final pass: opt-in, for the roofline figure)
     base_ptr, stride = ix.device_rows(n_local)
     assert stride == ((D + 63) // 64) * 64 * esz   # rows are zero padded to whole 64-element groups
     if bf16:   # torch cannot import bf16 through __cuda_array_interface__: map as int16 and reinterpret
@@ -1091,6 +1095,9 @@ def main():
         S = n_local if args.cpu_rows <= 0 else min(args.cpu_rows, n_local)
         flat = O.Flat(D, "COSINE", isa="skylake", max_elements=S)
         flat.add_many(host_rows[:S], np.arange(r0, r0 + S, dtype=np.uint64), borrowed=True)
+        # distances by the COMPILED REFERENCE's fstdistfunc_ (oracle/_ref: hnswlib/simsimd.h over SimSIMD 5.0.1 built from the
+        # reference's own sources, travels to the GPU box prebuilt) when it is there; else the restated kernels
+        ref_dist = flat.use_reference_distance()
         hq = Q.cpu().numpy()
         threads = effective_cpus()
         nqt = threads * args.cpu_queries_per_thread
@@ -1102,11 +1109,15 @@ def main():
         cdt = time.perf_counter() - t1
         qps_sample = nqt / cdt
         full = S == N
-        cpu = {"value": round(qps_sample * S / N, 4), "unit": "queries/s", "cores": threads, "kind": "port",
+        dist_src = ("distances by the reference's own compiled SimSIMD 5.0.1 (oracle/_ref: simsimd_dot_f32 through third_party/hnswlib/simsimd.h)"
+                    if ref_dist else f"distances by the restated kernel ({O.cpu_path()} clone of the SimSIMD skylake order)")
+        cpu = {"value": round(qps_sample * S / N, 4), "unit": "queries/s", "cores": threads, "kind": "reference" if ref_dist else "port",
+               "host_cpus_total": os.cpu_count(), "cores_note": f"{threads} = the container's cgroup CPU quota; the host has {os.cpu_count()} logical CPUs",
                "seconds": round(cdt, 2), "host_gbs": round(nqt * S * D * 4 / cdt / 1e9, 1),
-               "sample": (f"oracle FLAT scan ({O.cpu_path()} clone of the SimSIMD skylake order), {nqt} queries, each a full pass "
-                          f"over all {S} rows, one query per thread on {threads} threads (the container's CPU quota)" if full else
-                          f"oracle FLAT scan ({O.cpu_path()} clone of the SimSIMD skylake order), {nqt} queries over "
+               "loop": "bruteforce.h:116-145 restated (hnswlib itself is unbuildable here: abseil / protobuf headers absent)",
+               "sample": (f"FLAT scan, {dist_src}, {nqt} queries, each a full pass "
+                          f"over all {S} rows, one query per thread on {threads} threads" if full else
+                          f"FLAT scan, {dist_src}, {nqt} queries over "
                           f"the first {S} rows on {threads} threads ({qps_sample:.1f} q/s on the sample), scaled "
                           f"linearly to {N} rows")}
         # parity at full index size: the GPU answer must equal the oracle's, ids and distance bits -- through the
@@ -1142,15 +1153,24 @@ def main():
     hnsw = None
     if extras and args.hnsw_rows > 0 and not bf16:
         hnsw = leg(hnsw_leg, args, ix, host_rows[:min(args.hnsw_rows, n_local)], A, device, stream_ptr, n_local)
-    # ---- one shard of configs[4]: HNSW + TAG filter ----
+    # ---- configs[4]: HNSW + TAG filter -- at its stated size as `--config-shards` graphs inside ONE sharded index on this GPU
+    #      (8 x 1.25M rows = the 10M rows), or one shard of it ----
+    cs = args.config_shards if args.config_shards > 1 else 0
     hybrid = None
     if extras and args.hybrid_rows > 0 and not bf16:
-        hybrid = leg(hybrid_leg, args, ix, host_rows[:min(args.hybrid_rows, n_local)], A, device, stream_ptr, n_local)
+        if cs and args.hybrid_rows * cs <= n_local:
+            hybrid = leg(sharded_hybrid_leg, args, ix, host_rows[:args.hybrid_rows * cs], A, device, work_stream, [local_rank] * cs, n_local)
+        else:
+            hybrid = leg(hybrid_leg, args, ix, host_rows[:min(args.hybrid_rows, n_local)], A, device, stream_ptr, n_local)
     host_rows = None
-    # ---- one shard of configs[3]: FLAT bf16 IP ----
+    # ---- configs[3]: FLAT bf16 IP -- 8 logical shards x 10M rows = 80M x 768 bf16 (122.9 GB) on this one GPU, or one shard ----
     bf16_shard = None
     if extras and args.bf16_rows > 0 and not bf16:
-        bf16_shard = leg(bf16_ip_leg, args, A, device, stream_ptr, local_rank)
+        free_b, _tot = torch.cuda.mem_get_info(device)
+        if cs and free_b > cs * args.bf16_rows * D * 2 + (16 << 30):
+            bf16_shard = leg(sharded_bf16_ip_leg, args, A, device, work_stream, [local_rank] * cs)
+        else:
+            bf16_shard = leg(bf16_ip_leg, args, A, device, stream_ptr, local_rank)
     if world > 1 and args.hnsw_sharded and args.hnsw_rows > 0 and not bf16:
         def gather(dst, src):
             if args.backend == "nccl":
@@ -1165,16 +1185,10 @@ def main():
         except Exception as e:   # noqa: BLE001
             hnsw = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- single-query traffic against THIS index (10M x 768 in the default run): submit with 1024 outstanding, 256 blocking callers ----
     coalescer = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            coalescer = coalescer_leg(ix, Q.cpu().numpy(), K)
-        except Exception as e:   # noqa: BLE001
-            coalescer = {"error": f"{type(e).__name__}: {e}"}
-        try:
-            coalescer["native_callers"] = native_coalescer_leg()
-        except Exception as e:   # noqa: BLE001
-            coalescer["native_callers"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and B >= 5:
+        coalescer = leg(serving_leg, ix, Q.cpu().numpy(), K, B * args.steps / dt, B, 500, 4, 4 * B, 40 * B, 256, 24)
 
     if rank == 0:
         # (the final pass: B operands by DMA; bf16 rows in the inner-product space: bf16 MFMA, rows by DMA)
@@ -1226,10 +1240,10 @@ def main():
                           "tflops_f32": round(flops / (dev_ms * 1e-3) / 1e12, 3)}),
             "cpu_baseline": cpu,
             "single_query_scan": single,
-            "coalescer": coalescer,
+            "single_query_serving": coalescer,
             "hnsw": hnsw,
-            "config4_shard_hybrid": hybrid,
-            "config3_shard_bf16_ip": bf16_shard,
+            "config4_hnsw_tag": hybrid,
+            "config3_flat_bf16_ip": bf16_shard,
             "build_s": round(t_build, 2),
         }
         print(json.dumps(out))

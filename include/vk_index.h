@@ -51,8 +51,11 @@ typedef enum {
   VK_ERR_NOT_FOUND = 3,  /* unknown / tombstoned label */
   VK_ERR_INTERNAL = 4,   /* absl::InternalError: device or library failure */
   VK_ERR_CANCELLED = 5,  /* search cancelled and partial results not wanted (vector_hnsw.cc:327-329) */
-  VK_ERR_NO_DEVICE = 6   /* no usable gfx950 device */
+  VK_ERR_NO_DEVICE = 6,  /* no usable gfx950 device */
+  VK_ERR_BUSY = 7        /* vk_index_search_submit: the query queue is full (max-query-queue-depth,
+                            src/valkey_search_options.cc:231-234: FT.SEARCH is rejected before it is queued) */
 } vk_status;
+#define VK_STATUS_COUNT 8
 
 typedef enum { VK_ALGO_FLAT = 0, VK_ALGO_HNSW = 1 } vk_algo;          /* IndexerType kFlat / kHNSW */
 typedef enum { VK_METRIC_L2 = 0, VK_METRIC_IP = 1, VK_METRIC_COSINE = 2 } vk_metric; /* index_schema.proto DistanceMetric */
@@ -125,18 +128,39 @@ typedef struct vk_index_stats {
    * overflowed so that the exact matrix-core kernel answered instead */
   uint64_t last_filter_candidates;
   uint64_t last_filter_fallback;
-  /* cumulative: batches that went through the candidate filter and the device time of its kernel launches (HIP events
-   * on the stream they ran on; a batch counts once its events have completed) -- the per-launch duration behind
-   * bench.py's HBM roofline figure */
+  /* cumulative: batches that went through the candidate filter, and -- while the option kernel-timing is 1 (off by
+   * default: two event records per batch) -- the device time of their final-pass launches (HIP events on the stream they
+   * ran on): with the option on over a window, delta(filter_kernel_ns) / delta(filter_batches) is the per-launch
+   * duration behind bench.py's HBM roofline figure.  A sharded index reports min(batches) / max(ns) over its shards;
+   * per-shard deltas come from vk_index_shard_stats */
   uint64_t filter_batches;
   uint64_t filter_kernel_ns;
   /* query coalescer (vk_index_set_coalescing): device batches run / single queries they carried */
   uint64_t coalesced_batches;
   uint64_t coalesced_queries;
   /* sharded index (n_shards >= 1), cumulative: searches fanned out to the shards and the HOST time their fan-out took
-   * (enqueue of every shard's work + gather + merge launch, one enqueue thread per shard; no device time) */
+   * (enqueue of every shard's work + gather + merge launch, one enqueue thread per DEVICE; no device time) */
   uint64_t fanout_calls;
   uint64_t fanout_enqueue_ns;
+  /* ---- cumulative since creation: what the adaptor's RespondWithInfoImpl (src/indexes/vector_base.cc:385-409) and the
+   * module's metrics (src/metrics.h:40-50 query counters, :75-80 hnsw/flat exception counters; latency samples taken at
+   * src/query/search.cc:149,160) are fed from ---------------------------------------------------------------------- */
+  uint64_t searches;                       /* queries answered, all entry points */
+  uint64_t search_calls;                   /* ABI search calls / dispatcher batches that carried them */
+  uint64_t search_errors[VK_STATUS_COUNT]; /* failed search calls by vk_status ([VK_ERR_CANCELLED] = timeouts, ...) */
+  uint64_t total_n_eval;                   /* HNSW: distance evaluations (metric_distance_computations, hnswalg.h:98) */
+  uint64_t total_n_hops;                   /* HNSW: expanded nodes (metric_hops, hnswalg.h:99) */
+  uint64_t tombstoned_bytes;               /* HNSW: rows + link lists of mark-deleted elements (reclaimable_memory, hnswalg.h:1199) */
+  /* latency of a search as its caller saw it (call -> answer in host memory; through the dispatcher: submit -> completion),
+   * per QUERY: bucket 0 = under 64 us, bucket i = [64 << (i-1), 64 << i) us, the last bucket is open-ended (>= 1 s) */
+  uint64_t latency_hist[16];
+  uint64_t latency_sum_ns;
+  /* dispatcher (vk_index_search_submit / coalesced vk_index_search): requests accepted, rejected with VK_ERR_BUSY, waiting
+   * right now, and the largest number of device batches that were in flight at once */
+  uint64_t submitted;
+  uint64_t rejected;
+  uint64_t queued_now;
+  uint64_t max_batches_in_flight;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------
@@ -234,6 +258,33 @@ int vk_index_distance(vk_index *ix, uint64_t label, const void *query, float *ou
  * the batch and hands each caller its own answer (identical to the answer it would have got alone).
  * max_batch <= 1 turns it off (the default). */
 int vk_index_set_coalescing(vk_index *ix, uint32_t max_batch, uint32_t max_wait_us);
+/* NON-BLOCKING single-query search: the shape of query::SearchAsync (src/query/search.cc:886-910), which queues the
+ * request (up to max-query-queue-depth = 100 000 of them, src/valkey_search_options.cc:231-234) and continues on the
+ * main thread when it completes.  The request joins the same (k, ef_runtime) lanes as coalesced vk_index_search calls;
+ * the library keeps `batches-in-flight` device batches going (option, default 2: batch N+1 is collected, uploaded and
+ * enqueued while batch N runs), so the number of queries in flight is bounded by the queue depth, not by the number
+ * of reader threads.  Coalescing must be on (vk_index_set_coalescing with max_batch > 1), else VK_ERR_INVALID.
+ *   done(user, status) is called exactly once, from a library thread, after out_dist / out_label / *out_n have been
+ *   written; status is the vk_status of the batch the request travelled in (VK_ERR_CANCELLED as for vk_index_search).
+ *   It must not block for long (it holds up the other completions of its batch) and must not destroy the index.
+ *   query, allow_bits, cancel_flag and the output buffers must stay valid until then.
+ * Returns VK_OK when the request was queued (the callback WILL fire), VK_ERR_BUSY when the queue is full (it will not).
+ * vk_index_destroy answers what is still queued and waits for the callbacks; do not submit concurrently with it. */
+typedef void (*vk_search_done_fn)(void *user, int status);
+int vk_index_search_submit(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime,
+                           const uint64_t *allow_bits, uint64_t allow_nbits,
+                           const volatile int *cancel_flag, int partial_ok,
+                           float *out_dist, uint64_t *out_label, uint64_t *out_n,
+                           vk_search_done_fn done, void *user);
+/* Run-time options: the analogue of `CONFIG SET search.<name>` (src/valkey_search_options.cc:74-81 hnsw-block-size,
+ * :150-162 hnsw-allow-replace-deleted / hnsw-validation-enable, :231-234 max-query-queue-depth, :363-390
+ * prefiltering-threshold-ratio).  Names (csrc/options.hpp has the table with defaults and ranges), e.g.
+ *   coalesce-max-batch, coalesce-max-wait-us, max-query-queue-depth, batches-in-flight, shard-ef-pct, shard-gather,
+ *   kernel-timing, flat-filter, filter-spill-chunks, hnsw-visited-bytes, hnsw-pool-bytes, ...
+ * A sharded index applies an option to itself and to every shard.  Unknown name or value out of range: VK_ERR_INVALID.
+ * Options take effect for searches that START after the call; no search path reads the environment. */
+int vk_index_set_option(vk_index *ix, const char *name, uint64_t value);
+int vk_index_get_option(vk_index *ix, const char *name, uint64_t *out_value);
 int vk_index_get_row(vk_index *ix, uint64_t label, void *out_row);
 int vk_index_contains(vk_index *ix, uint64_t label, int *out_found);
 int vk_index_get_stats(vk_index *ix, vk_index_stats *out);
@@ -247,6 +298,9 @@ int vk_index_commit_device_rows(vk_index *ix, uint64_t n_rows, const uint64_t *l
 /* the same for ONE shard of a sharded index (rows on that shard's device; labels are required and must be unique
  * across the shards); vk_index_shard_count is 0 for a plain index */
 int vk_index_shard_count(vk_index *ix, uint32_t *out_n);
+/* the statistics of ONE shard (vk_index_get_stats of a sharded index sums the shards' cumulative counters; a per-shard
+ * rate -- the slowest shard's kernel time per launch -- needs the shards' own deltas) */
+int vk_index_shard_stats(vk_index *ix, uint32_t shard, vk_index_stats *out);
 int vk_index_shard_device_rows(vk_index *ix, uint32_t shard, uint64_t n_rows, void **d_rows, uint64_t *row_stride_bytes);
 int vk_index_shard_commit_device_rows(vk_index *ix, uint32_t shard, uint64_t n_rows, const uint64_t *labels);
 

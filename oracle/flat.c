@@ -25,7 +25,16 @@ struct vko_flat {
     uint8_t *owned;     /* row storage owned by the oracle (copy) */
     uint64_t *labels;
     vko_map ext2int;    /* dict_external_to_internal */
+    /* optional: fstdistfunc_ taken from the COMPILED REFERENCE (oracle/_ref: ref_InnerProductDistanceSimsimd /
+     * ref_L2SqrSimsimd, i.e. third_party/hnswlib/simsimd.h:16-34 over SimSIMD 5.0.1 as the reference builds it) instead of
+     * the restated kernels -- what bench.py's cpu_baseline times when _ref is present */
+    float (*distfn)(const float *, const float *, size_t);
 };
+
+void vko_flat_set_distfn(vko_flat *f, float (*fn)(const float *, const float *, size_t)) { f->distfn = fn; }
+static inline float flat_dist(const vko_flat *f, const float *q, const float *row) {
+    return f->distfn ? f->distfn(q, row, f->dim) : vko_distance(f->space, f->isa, q, row, f->dim);
+}
 
 vko_flat *vko_flat_new(size_t dim, vko_space_t space, vko_isa_t isa, size_t max_elements) {
     vko_flat *f = (vko_flat *)calloc(1, sizeof(*f));
@@ -121,13 +130,13 @@ size_t vko_flat_search(const vko_flat *f, const float *q, size_t k, const uint64
     vko_cancel cancel = {cancel_after, 0};
     /* bruteforce.h:120-127: the first k rows are pushed unconditionally */
     for (size_t i = 0; i < k; i++) {
-        float dist = vko_distance(f->space, f->isa, q, f->rows[i], f->dim);
+        float dist = flat_dist(f, q, f->rows[i]);
         if (vko_allowed(allow_bits, allow_nbits, f->labels[i])) vko_dlheap_push(&top, dist, f->labels[i]);
     }
     float lastdist = top.n == 0 ? 3.402823466e+38F : top.v[0].d;
     /* bruteforce.h:129-143 */
     for (size_t i = k; i < f->count && !vko_cancelled(&cancel); i++) {
-        float dist = vko_distance(f->space, f->isa, q, f->rows[i], f->dim);
+        float dist = flat_dist(f, q, f->rows[i]);
         if (dist <= lastdist) {
             if (vko_allowed(allow_bits, allow_nbits, f->labels[i])) vko_dlheap_push(&top, dist, f->labels[i]);
             if (top.n > k) vko_dlheap_pop(&top);

@@ -788,3 +788,60 @@ vko_hnsw *vko_sink_finish(vko_sink *s) {
     free(s);
     return h;
 }
+
+/* ---- a SHARDED product index's stream: a 16-byte marker chunk ("VKSHARDS", u64 shard count -- the product's own
+ * framing, csrc/sharded_index.cc; the reference has one graph per cluster shard and no such stream) followed by the
+ * shards' SaveIndex streams back to back.  Splits it into one oracle graph per shard so that a test can search each
+ * shard's very graph on the CPU and merge with vko_merge_topk (the role of fanout.cc:162-175). */
+#define VKO_MSINK_MAX 16
+struct vko_msink {
+    size_t dim, M, efC;
+    vko_space_t space;
+    vko_isa_t isa;
+    uint64_t n_shards, cur;
+    int started, failed;
+    vko_sink *sink;
+    vko_hnsw *graphs[VKO_MSINK_MAX];
+};
+typedef struct vko_msink vko_msink;
+
+vko_msink *vko_msink_new(size_t dim, vko_space_t space, vko_isa_t isa, size_t M, size_t ef_construction) {
+    vko_msink *m = (vko_msink *)calloc(1, sizeof(*m));
+    m->dim = dim; m->space = space; m->isa = isa; m->M = M; m->efC = ef_construction;
+    return m;
+}
+
+int vko_msink_write(void *user, const void *data, uint64_t len) {
+    vko_msink *m = (vko_msink *)user;
+    if (m->failed) return 1;
+    if (!m->started) {
+        if (len != 16 || memcmp(data, "VKSHARDS", 8) != 0) { vko_set_error("msink: no shard marker chunk"); m->failed = 1; return 1; }
+        memcpy(&m->n_shards, (const uint8_t *)data + 8, 8);
+        if (m->n_shards == 0 || m->n_shards > VKO_MSINK_MAX) { vko_set_error("msink: shard count out of range"); m->failed = 1; return 1; }
+        m->started = 1;
+        return 0;
+    }
+    if (m->cur >= m->n_shards) { vko_set_error("msink: chunk after the last shard"); m->failed = 1; return 1; }
+    if (!m->sink) m->sink = vko_sink_new(m->dim, m->space, m->isa, m->M, m->efC);
+    if (vko_sink_write(m->sink, data, len)) { m->failed = 1; return 1; }
+    if (m->sink->state == 4) {
+        m->graphs[m->cur++] = vko_sink_finish(m->sink);
+        m->sink = NULL;
+    }
+    return 0;
+}
+
+/* number of complete shard graphs (0 on failure); vko_msink_take hands one over (ownership passes to the caller) */
+uint64_t vko_msink_count(vko_msink *m) { return m->failed || m->cur != m->n_shards ? 0 : m->n_shards; }
+vko_hnsw *vko_msink_take(vko_msink *m, uint64_t i) {
+    if (i >= m->cur) return NULL;
+    vko_hnsw *h = m->graphs[i];
+    m->graphs[i] = NULL;
+    return h;
+}
+void vko_msink_free(vko_msink *m) {
+    if (!m) return;
+    if (m->sink) { vko_hnsw *h = vko_sink_finish(m->sink); if (h) vko_hnsw_free(h); }
+    for (int i = 0; i < VKO_MSINK_MAX; ++i) if (m->graphs[i]) vko_hnsw_free(m->graphs[i]);
+    free(m);
+}

@@ -110,6 +110,16 @@ def _load():
     lib.vko_sink_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.vko_sink_finish.restype = C.c_void_p
     lib.vko_sink_finish.argtypes = [C.c_void_p]
+    lib.vko_msink_new.restype = C.c_void_p
+    lib.vko_msink_new.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t]
+    lib.vko_msink_write.restype = C.c_int
+    lib.vko_msink_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.vko_msink_count.restype = C.c_uint64
+    lib.vko_msink_count.argtypes = [C.c_void_p]
+    lib.vko_msink_take.restype = C.c_void_p
+    lib.vko_msink_take.argtypes = [C.c_void_p, C.c_uint64]
+    lib.vko_msink_free.restype = None
+    lib.vko_msink_free.argtypes = [C.c_void_p]
     lib.vko_merge_topk.restype = C.c_size_t
     lib.vko_merge_topk.argtypes = [_f32p, _u64p, _u32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p, _u64p]
     return lib
@@ -195,6 +205,19 @@ class Flat:
                                    rows.shape[0], int(borrowed))
         if rc:
             raise RuntimeError(last_error())
+
+    def use_reference_distance(self) -> bool:
+        """distances by the COMPILED REFERENCE's fstdistfunc_ (oracle/_ref/libsimsimd_ref.so: third_party/hnswlib/simsimd.h over
+        SimSIMD as the reference builds it) instead of the restated kernels; False when _ref is not there"""
+        if not Ref.available():
+            return False
+        ref = Ref()
+        fn = ref.lib.ref_L2SqrSimsimd if self.space == "L2" else ref.lib.ref_InnerProductDistanceSimsimd
+        LIB.vko_flat_set_distfn.argtypes = [C.c_void_p, C.c_void_p]
+        LIB.vko_flat_set_distfn.restype = None
+        LIB.vko_flat_set_distfn(self._h, C.cast(fn, C.c_void_p))
+        self._keep.append(ref)
+        return True
 
     def remove(self, label):
         LIB.vko_flat_remove(self._h, int(label))
@@ -314,6 +337,26 @@ class HNSW:
         self = cls._adopt(h, dim, space, M)
         LIB.vko_hnsw_set_ef(self._h, ef)
         return self
+
+    @classmethod
+    def shards_from_product_index(cls, save_fn, dim, space, M, ef_construction=200, isa="skylake", ef=10):
+        """The graphs of a SHARDED product index (vk_index_params.n_shards >= 1), one oracle graph per shard, from its
+        own save stream (a marker chunk, then every shard's SaveIndex stream): the CPU side of a sharded-search parity
+        check searches each shard's very graph and merges with merge_topk."""
+        ms = LIB.vko_msink_new(dim, SPACE[space], ISA[isa], M, ef_construction)
+        try:
+            rc = save_fn(C.cast(LIB.vko_msink_write, C.c_void_p), C.c_void_p(ms))
+            n = LIB.vko_msink_count(ms)
+            if rc or not n:
+                raise RuntimeError(f"save into the oracle shard sink failed (rc={rc}): {last_error()}")
+            out = []
+            for i in range(n):
+                g = cls._adopt(LIB.vko_msink_take(ms, i), dim, space, M)
+                LIB.vko_hnsw_set_ef(g._h, ef)
+                out.append(g)
+            return out
+        finally:
+            LIB.vko_msink_free(ms)
 
     @classmethod
     def from_saved_chunks(cls, chunks, dim, space, M, ef_construction=200, isa="skylake", ef=10):

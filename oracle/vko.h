@@ -60,6 +60,8 @@ void vko_flat_remove(vko_flat *f, uint64_t label);
 void vko_flat_resize(vko_flat *f, size_t new_max);
 size_t vko_flat_count(const vko_flat *f);
 size_t vko_flat_capacity(const vko_flat *f);
+/* distances through an external function (the compiled reference's fstdistfunc_ from oracle/_ref) instead of the restatement */
+void vko_flat_set_distfn(vko_flat *f, float (*fn)(const float *, const float *, size_t));
 /* searchKnn (bruteforce.h:116-145).  allow_bits: optional bitmap indexed by
  * LABEL (bit set = allowed, labels >= allow_nbits are rejected); cancel_after:
  * isCancelled() returns true from its (cancel_after+1)-th poll on, <0 = never.
@@ -122,6 +124,13 @@ typedef struct vko_sink vko_sink;
 vko_sink *vko_sink_new(size_t dim, vko_space_t space, vko_isa_t isa, size_t M, size_t ef_construction);
 int vko_sink_write(void *user, const void *data, uint64_t len);
 vko_hnsw *vko_sink_finish(vko_sink *s);
+/* the stream of a SHARDED product index (marker chunk + one SaveIndex stream per shard) -> one oracle graph per shard */
+typedef struct vko_msink vko_msink;
+vko_msink *vko_msink_new(size_t dim, vko_space_t space, vko_isa_t isa, size_t M, size_t ef_construction);
+int vko_msink_write(void *user, const void *data, uint64_t len);
+uint64_t vko_msink_count(vko_msink *m);
+vko_hnsw *vko_msink_take(vko_msink *m, uint64_t i);
+void vko_msink_free(vko_msink *m);
 
 /* ---- cluster / shard merge (fanout.cc:162-175 semantics, made total) ------- */
 /* k smallest by (dist,label) over `parts` lists of `per` entries each */

@@ -5,6 +5,14 @@ index (bf16 rows / IP and f32 rows / COSINE, B = 256, k = 10) with pieces of the
     python scripts/filter_ablate.py [--rows N] [--dtypes bf16,f32] [--ablate 0,1,3,...]
 Prints one JSON line per (dtype, ablation): kernel ms (HIP events of the library) and the phase counters' stderr line."""
 import argparse, json, os, sys
+# the experiment kernels exist only in the -DVK_EXPERIMENTS build of the library (csrc/Makefile `experiments`): build it and
+# load it INSTEAD of libvkindex.so (the binding reads VKINDEX_LIB at import)
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if not os.environ.get("VKINDEX_LIB"):
+    import subprocess
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(_ROOT, "valkey-search_amd", "csrc"), "experiments"])
+    os.environ["VKINDEX_LIB"] = os.path.join(_ROOT, "valkey-search_amd", "libvkindex_exp.so")
+os.environ.setdefault("VK_KERNEL_TIMING", "1")   # (HIP event pairs around the final pass: this script reads filter_kernel_ns)
 if "--timing" in sys.argv:
     os.environ["VK_FILTER_TIMING"] = "1"     # (cycle counters per phase on stderr; the ticks themselves cost 15-25 %)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

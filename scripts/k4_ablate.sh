@@ -1,4 +1,6 @@
 #!/bin/bash
+# (VK_GEMM_ABLATE / VK_GEMM_MODE are read by the -DVK_EXPERIMENTS build of the library only)
+make -s -j8 -C "$(dirname "$0")/../valkey-search_amd/csrc" experiments && export VKINDEX_LIB="$(cd "$(dirname "$0")/.." && pwd)/valkey-search_amd/libvkindex_exp.so"
 # K4 ablation ladder (VK_GEMM_ABLATE, see flat_gemm.hip): where the time of a stage goes.
 for A in ${1:-0 1 2 3 4 5}; do
   echo "== VK_GEMM_ABLATE=$A"

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (VK_GEMM_ABLATE / VK_GEMM_MODE are read by the -DVK_EXPERIMENTS build of the library only)
+make -s -j8 -C "$(dirname "$0")/../valkey-search_amd/csrc" experiments && export VKINDEX_LIB="$(cd "$(dirname "$0")/.." && pwd)/valkey-search_amd/libvkindex_exp.so"
 # K4 (MFMA FLAT) A/B runs on one box.  Usage: scripts/k4_sweep.sh "mode:lockstep ..."   e.g. "0:0 0:1 2:1"
 mkdir -p gpurun_out
 for cfg in ${1:-0:0 0:1 2:1}; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (VK_GEMM_ABLATE / VK_GEMM_MODE are read by the -DVK_EXPERIMENTS build of the library only)
+make -s -j8 -C "$(dirname "$0")/../valkey-search_amd/csrc" experiments && export VKINDEX_LIB="$(cd "$(dirname "$0")/.." && pwd)/valkey-search_amd/libvkindex_exp.so"
 # HBM-side traffic of the bench kernels: one rocprofv3 --pmc FETCH_SIZE pass per K4 configuration.
 # Usage: scripts/pmc_fetch.sh "mode:lockstep ..."
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (VK_GEMM_ABLATE / VK_GEMM_MODE are read by the -DVK_EXPERIMENTS build of the library only)
+make -s -j8 -C "$(dirname "$0")/../valkey-search_amd/csrc" experiments && export VKINDEX_LIB="$(cd "$(dirname "$0")/.." && pwd)/valkey-search_amd/libvkindex_exp.so"
 # One rocprofv3 --pmc pass over a short bench run.  Usage: scripts/pmc_pass.sh TAG "COUNTER ..." [mode:lockstep]
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; CNT=$2; cfg=${3:-0:1}

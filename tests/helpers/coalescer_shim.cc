@@ -1,28 +1,40 @@
-// CPU-side harness for csrc/coalescer.hpp (N1): a fake index whose batched search answers every query with
+// CPU-side harness for csrc/dispatcher.hpp (N1): a fake index whose batched search answers every query with
 // a function of the query alone and records the batch sizes it was called with.  Many threads issue
-// single-query requests through the Coalescer; each must get exactly its own answer, every request must be
-// served exactly once, and concurrent requests must actually travel together.
+// single-query requests through the Dispatcher -- blocking (search) and non-blocking (submit + callback); each must
+// get exactly its own answer, every request must be served exactly once, concurrent requests must actually travel
+// together, and with two runners two batches must be in flight at once.
 #include <atomic>
 #include <cstdio>
 #include <thread>
 #include <vector>
 
-#include "coalescer.hpp"
+#include "dispatcher.hpp"
 
 namespace {
 struct FakeIndex final : vk::Index {
   explicit FakeIndex(const vk_index_params &p) : Index(p) {}
-  std::atomic<uint64_t> calls{0}, queries{0}, max_batch{0};
+  std::atomic<uint64_t> calls{0}, queries{0}, max_batch{0}, concurrent{0}, max_concurrent{0}, cancelled_batches{0};
   int delay_us = 200;   // a device pass takes a while: requests pile up behind it
   vk::Status search(const vk::SearchRequest &rq, float *od, uint64_t *ol, uint64_t *on) override {
     calls += 1;
     queries += rq.nq;
     uint64_t m = max_batch.load();
     while (rq.nq > m && !max_batch.compare_exchange_weak(m, rq.nq)) {}
-    std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
+    const uint64_t c = concurrent.fetch_add(1) + 1;
+    uint64_t mc = max_concurrent.load();
+    while (c > mc && !max_concurrent.compare_exchange_weak(mc, c)) {}
+    // the "device pass": like the real kernels it polls the batch's cancellation word and stops early when it goes up
+    const auto end = std::chrono::steady_clock::now() + std::chrono::microseconds(delay_us);
+    bool stopped = false;
+    while (std::chrono::steady_clock::now() < end) {
+      if (vk::cancel_raised(rq.cancel_flag)) { stopped = true; break; }
+      std::this_thread::sleep_for(std::chrono::microseconds(delay_us > 1000 ? 100 : 20));
+    }
+    if (stopped) cancelled_batches += 1;
+    concurrent.fetch_sub(1);
     if (rq.k == 13) return vk::Status::Err(VK_ERR_INTERNAL, "k = 13 fails on purpose");
     for (uint64_t q = 0; q < rq.nq; ++q) {
-      const float *v = rq.queries + q * params_.dim;
+      const float *v = rq.query_tab ? rq.query_tab[q] : rq.queries + q * params_.dim;
       const uint64_t n = rq.k < 3 ? rq.k : 3;            // "fewer than k found" is part of the contract
       on[q] = n;
       // a per-query filter shows in the answer: word 0 of the query's own bitmap is added to every label
@@ -63,7 +75,7 @@ extern "C" int coalescer_run(int threads, int per_thread, uint32_t max_batch, ui
   p.struct_size = sizeof p;
   p.dim = 4;
   FakeIndex ix(p);
-  vk::Coalescer co;
+  vk::Dispatcher co(&ix);
   co.configure(max_batch, max_wait_us);
   std::atomic<int> bad{0};
   auto worker = [&](int t) {
@@ -83,7 +95,7 @@ extern "C" int coalescer_run(int threads, int per_thread, uint32_t max_batch, ui
       const uint64_t nbits = 64 + (uint64_t)(id % 5);
       volatile int flag = cancelled ? 1 : 0;
       if (toggle && id == threads * per_thread / 2) co.configure(0, 0);      // coalescing switched off under load
-      vk::Status st = co.search(&ix, q, k, ef, filtered ? bits : nullptr, filtered ? nbits : 0, &flag, true, d, l, &n);
+      vk::Status st = co.search(q, k, ef, filtered ? bits : nullptr, filtered ? nbits : 0, &flag, true, d, l, &n);
       if (cancelled) {
         if (!st.ok() || n != 0) bad += 1;
         continue;
@@ -107,5 +119,179 @@ extern "C" int coalescer_run(int threads, int per_thread, uint32_t max_batch, ui
   out[2] = ix.max_batch;
   out[3] = co.batches();
   out[4] = co.queries();
+  return bad.load();
+}
+
+// ---- the non-blocking entry: `producers` threads submit `per_producer` requests each without waiting (up to
+// `window` outstanding per producer), completions arrive through the callback.  Checks: every accepted request completes
+// exactly once with its own answer; a full queue rejects with VK_ERR_BUSY and that request's callback never fires; with
+// two runners two "device passes" overlap.  out[0..5] = device calls, largest batch, most concurrent passes, rejected,
+// completions, cancelled completions.
+namespace {
+struct AsyncSlot {
+  float q[4];
+  float d[16];
+  uint64_t l[16], n;
+  uint64_t bits[1];
+  volatile int flag;
+  std::atomic<int> done{0};
+  int status = -1;
+  int id = 0;
+  bool filtered = false, cancelled = false;
+  std::atomic<uint64_t> *completions;
+};
+void async_done(void *user, int status) {
+  AsyncSlot *s = static_cast<AsyncSlot *>(user);
+  s->status = status;
+  s->completions->fetch_add(1);
+  s->done.fetch_add(1, std::memory_order_release);
+}
+}  // namespace
+
+extern "C" int dispatcher_async_run(int producers, int per_producer, int window, uint32_t max_batch, uint32_t max_wait_us,
+                                    uint32_t in_flight, uint64_t queue_depth, int delay_us, int hnsw, uint64_t *out) {
+  vk_index_params p{};
+  p.struct_size = sizeof p;
+  p.dim = 4;
+  p.algo = hnsw ? VK_ALGO_HNSW : VK_ALGO_FLAT;
+  FakeIndex ix(p);
+  ix.delay_us = delay_us;
+  std::atomic<int> bad{0};
+  std::atomic<uint64_t> completions{0}, rejected{0}, cancelled_done{0};
+  {
+    vk::Dispatcher dp(&ix);
+    dp.configure(max_batch, max_wait_us);
+    dp.set_in_flight(in_flight);
+    dp.set_queue_depth(queue_depth);
+    auto producer = [&](int t) {
+      std::vector<std::unique_ptr<AsyncSlot>> slots;
+      size_t checked = 0;
+      auto check = [&](AsyncSlot &s) {
+        while (s.done.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+        if (s.done.load() != 1) bad += 1;
+        const uint64_t k = 3, ef = 100;
+        if (s.cancelled) {   // token up before the batch formed: answered without a search
+          cancelled_done += 1;
+          if (hnsw ? s.status != VK_ERR_CANCELLED : (s.status != VK_OK || s.n != 0)) bad += 1;
+          return;
+        }
+        if (s.status != VK_OK || s.n != 3) { bad += 1; return; }
+        for (uint64_t i = 0; i < s.n; ++i)
+          if (s.d[i] != (float)s.id * 1000.f + (float)i + (float)ef * 0.001f ||
+              s.l[i] != (uint64_t)(s.id + 7) * 10 + i + (s.filtered ? s.bits[0] + 64 : 0)) bad += 1;
+        (void)k;
+      };
+      for (int r = 0; r < per_producer; ++r) {
+        auto s = std::make_unique<AsyncSlot>();
+        s->id = t * per_producer + r;
+        s->q[0] = (float)s->id; s->q[1] = (float)(s->id + 7); s->q[2] = s->q[3] = 0.f;
+        s->filtered = s->id % 3 == 0;
+        s->cancelled = s->id % 29 == 11;
+        s->bits[0] = (uint64_t)s->id * 1000;
+        s->flag = s->cancelled ? 1 : 0;
+        s->n = 99;
+        s->completions = &completions;
+        vk::Status st = dp.submit(s->q, 3, 100, s->filtered ? s->bits : nullptr, s->filtered ? 64 : 0, s->id % 2 ? &s->flag : (s->cancelled ? &s->flag : nullptr),
+                                  /*partial_ok=*/false, s->d, s->l, &s->n, async_done, s.get());
+        if (!st.ok()) {
+          if (st.code != VK_ERR_BUSY) bad += 1;
+          rejected += 1;
+          std::this_thread::sleep_for(std::chrono::microseconds(50));
+          // (a rejected request's callback must never fire: its slot is checked for done == 0 at the end)
+          s->id = -1;
+        }
+        slots.push_back(std::move(s));
+        while (slots.size() - checked > (size_t)window) {
+          if (slots[checked]->id >= 0) check(*slots[checked]);
+          ++checked;
+        }
+      }
+      for (; checked < slots.size(); ++checked)
+        if (slots[checked]->id >= 0) check(*slots[checked]);
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      for (auto &s : slots)
+        if (s->id < 0 && s->done.load() != 0) bad += 1;
+    };
+    std::vector<std::thread> ts;
+    for (int t = 0; t < producers; ++t) ts.emplace_back(producer, t);
+    for (auto &t : ts) t.join();
+    if (dp.rejected() != rejected.load()) bad += 1;
+    if (dp.submitted() != completions.load()) bad += 1;
+    out[2] = dp.max_in_flight_seen();
+  }   // (the dispatcher is destroyed with nothing queued)
+  out[0] = ix.calls;
+  out[1] = ix.max_batch;
+  out[3] = rejected;
+  out[4] = completions;
+  out[5] = cancelled_done;
+  out[6] = ix.max_concurrent;
+  return bad.load();
+}
+
+// destroy with requests still queued and batches on the "device": every accepted request's callback fires exactly once
+// before the destructor returns, nothing is touched afterwards (ASAN), and no runner outlives the dispatcher (TSAN).
+extern "C" int dispatcher_destroy_run(int rounds, int n_req) {
+  std::atomic<int> bad{0};
+  for (int r = 0; r < rounds; ++r) {
+    vk_index_params p{};
+    p.struct_size = sizeof p;
+    p.dim = 4;
+    FakeIndex ix(p);
+    ix.delay_us = 1500;
+    std::atomic<uint64_t> completions{0};
+    std::vector<std::unique_ptr<AsyncSlot>> slots;
+    uint64_t accepted = 0;
+    {
+      vk::Dispatcher dp(&ix);
+      dp.configure(8, 5000);
+      dp.set_in_flight(2);
+      for (int i = 0; i < n_req; ++i) {
+        auto s = std::make_unique<AsyncSlot>();
+        s->id = i;
+        s->q[0] = (float)i; s->q[1] = (float)(i + 7); s->q[2] = s->q[3] = 0.f;
+        s->flag = 0;
+        s->completions = &completions;
+        if (dp.submit(s->q, 3, 100 + (uint64_t)(i % 2), nullptr, 0, nullptr, true, s->d, s->l, &s->n, async_done, s.get()).ok()) accepted += 1;
+        slots.push_back(std::move(s));
+      }
+      if (r % 2) std::this_thread::sleep_for(std::chrono::microseconds(700));   // some batches are on the device by now
+    }   // ~Dispatcher: answers what is queued, waits for the callbacks
+    if (completions.load() != accepted) bad += 1;
+    for (auto &s : slots)
+      if (s->done.load() != 1 || s->status != VK_OK || s->n != 3 || s->l[0] != (uint64_t)(s->id + 7) * 10) bad += 1;
+  }
+  return bad.load();
+}
+
+// Every member of a batch carries a token and all of them go up while the batch is on the device: the batch's own
+// cancellation word must go up (the fake device pass polls it like the kernels do) and the callers come back long before
+// the pass would have ended; with one live member among them the batch must run to its end.
+extern "C" int dispatcher_batch_cancel_run(int all_cancel, uint64_t *out) {
+  vk_index_params p{};
+  p.struct_size = sizeof p;
+  p.dim = 4;
+  p.algo = VK_ALGO_HNSW;
+  FakeIndex ix(p);
+  ix.delay_us = 300000;   // 0.3 s
+  vk::Dispatcher dp(&ix);
+  dp.configure(8, 20000);
+  std::atomic<int> bad{0};
+  std::vector<std::thread> ts;
+  volatile int flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < 8; ++t)
+    ts.emplace_back([&, t] {
+      float q[4] = {(float)t, (float)(t + 7), 0.f, 0.f}, d[16];
+      uint64_t l[16], n = 99;
+      vk::Status st = dp.search(q, 3, 100, nullptr, 0, &flags[t], /*partial_ok=*/false, d, l, &n);
+      const bool mine_up = all_cancel || t != 0;
+      if (mine_up ? st.code != VK_ERR_CANCELLED : (!st.ok() || n != 3)) bad += 1;
+    });
+  std::this_thread::sleep_for(std::chrono::milliseconds(40));     // the batch of eight is on the device
+  for (int t = all_cancel ? 0 : 1; t < 8; ++t) __atomic_store_n(const_cast<int *>(&flags[t]), 1, __ATOMIC_RELAXED);
+  for (auto &t : ts) t.join();
+  out[0] = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+  out[1] = ix.cancelled_batches;
+  out[2] = ix.calls;
   return bad.load();
 }

@@ -1,4 +1,4 @@
-// Sanitizer harness (ASAN and TSAN builds, tests/test_host_sanitizers.py) for csrc/coalescer.hpp: the scenarios of
+// Sanitizer harness (ASAN and TSAN builds, tests/test_host_sanitizers.py) for csrc/dispatcher.hpp: the scenarios of
 // coalescer_shim.cc as an executable, plus the one ADVICE r02 found by reading -- a FILTERED follower whose
 // cancellation token goes up while the batch it was popped into is on the device.  The module frees the query and the
 // bitmap as soon as vk_index_search returns (the reference's SearchParameters own both, src/query/search.h), so the
@@ -16,7 +16,7 @@ static int cancel_mid_batch(int rounds) {
   p.algo = VK_ALGO_HNSW;
   FakeIndex ix(p);
   ix.delay_us = 3000;                       // a long device pass: the followers' flags go up in the middle of it
-  vk::Coalescer co;
+  vk::Dispatcher co(&ix);
   co.configure(8, 20000);
   std::atomic<int> bad{0};
   for (int r = 0; r < rounds; ++r) {
@@ -34,7 +34,7 @@ static int cancel_mid_batch(int rounds) {
         std::thread raiser;
         const bool cancels = t % 2 == 1;
         if (cancels) raiser = std::thread([&flag] { std::this_thread::sleep_for(std::chrono::microseconds(1200)); __atomic_store_n(const_cast<int *>(&flag), 1, __ATOMIC_RELAXED); });
-        vk::Status st = co.search(&ix, q.get(), 3, 100, bits.get(), 64, &flag, /*partial_ok=*/t % 4 == 1, d, l, &n);
+        vk::Status st = co.search(q.get(), 3, 100, bits.get(), 64, &flag, /*partial_ok=*/t % 4 == 1, d, l, &n);
         q.reset();                           // the module's buffers die with the call
         bits.reset();
         if (raiser.joinable()) raiser.join();
@@ -61,6 +61,12 @@ int main(int argc, char **argv) {
   bad += coalescer_run(12 * scale, 16, 8, 1000, 4, 1, out);
   bad += coalescer_run(16 * scale, 20, 16, 2000, 1, 2, out);
   bad += cancel_mid_batch(6 * scale);
+  // the non-blocking entry: submit / completion callbacks / VK_ERR_BUSY / destroy with work in flight / the batch's own token
+  bad += dispatcher_async_run(6 * scale, 300, 64, 32, 500, 2, 100000, 300, 0, out);
+  bad += dispatcher_async_run(4 * scale, 200, 200, 16, 500, 3, 40, 300, 1, out);   // a shallow queue: rejections
+  bad += dispatcher_destroy_run(6 * scale, 50);
+  bad += dispatcher_batch_cancel_run(1, out);
+  bad += dispatcher_batch_cancel_run(0, out);
   printf("bad=%d\n", bad);
   return bad ? 1 : 0;
 }

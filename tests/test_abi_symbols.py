@@ -29,7 +29,8 @@ def test_header_declares_the_expected_surface():
     names = declared_functions()
     for must in ("vk_index_create", "vk_index_add", "vk_index_remove", "vk_index_search", "vk_index_search_batch",
                  "vk_index_search_batch_device", "vk_index_search_labels", "vk_index_distance", "vk_index_save",
-                 "vk_index_load", "vk_merge_topk_device", "vk_last_error"):
+                 "vk_index_load", "vk_merge_topk_device", "vk_last_error", "vk_index_search_submit", "vk_index_set_option",
+                 "vk_index_get_option", "vk_index_shard_stats"):
         assert must in names
 
 
@@ -44,7 +45,7 @@ def test_struct_layouts_match_header(vsa, tmp_path):
     offset of every field (gcc compiles a probe that prints them)."""
     import subprocess
     assert C.sizeof(vsa.Params) == 144
-    assert C.sizeof(vsa.Stats) == 152
+    assert C.sizeof(vsa.Stats) == 424
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vk_index.h"', 'int main(void){']
     for cname, mirror in (("vk_index_params", vsa.Params), ("vk_index_stats", vsa.Stats)):
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -1,5 +1,7 @@
-"""N1 on the CPU: csrc/coalescer.hpp driven by many threads against a fake index (tests/helpers/
-coalescer_shim.cc).  Every request must be answered exactly once with its own answer; concurrent
+"""N1 on the CPU: csrc/dispatcher.hpp driven by many threads against a fake index (tests/helpers/
+coalescer_shim.cc) -- the blocking entry (vk_index_search with coalescing) and the non-blocking one
+(vk_index_search_submit: callbacks, queue depth, several batches in flight, destroy with work queued, the batch's own
+cancellation word).  Every request must be answered exactly once with its own answer; concurrent
 requests of one (k, ef) lane must travel in shared device batches; lanes never mix; an error of a batch
 reaches every request that travelled in it."""
 import ctypes as C
@@ -20,6 +22,10 @@ def shim(tmp_path_factory):
                            str(ROOT / "tests" / "helpers" / "coalescer_shim.cc"), "-lpthread", "-o", str(out)])
     lib = C.CDLL(str(out))
     lib.coalescer_run.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    lib.dispatcher_async_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int,
+                                         C.POINTER(C.c_uint64)]
+    lib.dispatcher_destroy_run.argtypes = [C.c_int, C.c_int]
+    lib.dispatcher_batch_cancel_run.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     return lib
 
 
@@ -79,3 +85,48 @@ def test_a_lone_caller_leaves_when_arrivals_have_stopped_and_many_callers_are_wo
     dt = time.perf_counter() - t0
     assert bad == 0 and st["queries"] == 4000 - sum(1 for i in range(4000) if i % 17 == 5)
     assert st["batches"] < 400 and dt < 20.0, (st, dt)
+
+
+def arun(lib, producers, per, window, max_batch, wait_us, in_flight, depth, delay_us=300, hnsw=0):
+    out = (C.c_uint64 * 8)()
+    bad = lib.dispatcher_async_run(producers, per, window, max_batch, wait_us, in_flight, depth, delay_us, hnsw, out)
+    return bad, {"calls": out[0], "max_batch": out[1], "in_flight": out[2], "rejected": out[3], "completions": out[4],
+                 "cancelled": out[5], "concurrent_passes": out[6]}
+
+
+def test_submit_completes_every_request_once_with_two_batches_in_flight(shim):
+    """8 producers x 400 non-blocking submissions, up to 128 outstanding each: every request completes exactly once with its
+    own answer (filters and all), batches form, and with batches-in-flight = 2 two device passes overlap
+    (src/query/search.cc:886-910: the number of queries in flight is not bounded by the caller threads)."""
+    bad, st = arun(shim, 8, 400, 128, 64, 500, 2, 100000)
+    assert bad == 0 and st["completions"] == 3200 and st["rejected"] == 0
+    assert st["calls"] < 3200 // 8 and 8 < st["max_batch"] <= 64
+    assert st["in_flight"] == 2 and st["concurrent_passes"] == 2
+    assert st["cancelled"] == sum(1 for i in range(3200) if i % 29 == 11)
+
+
+def test_one_batch_in_flight_when_asked(shim):
+    bad, st = arun(shim, 4, 200, 64, 32, 500, 1, 100000)
+    assert bad == 0 and st["in_flight"] == 1 and st["concurrent_passes"] == 1 and st["completions"] == 800
+
+
+def test_a_full_queue_rejects_with_busy_and_its_callback_never_fires(shim):
+    """max-query-queue-depth (valkey_search_options.cc:231-234): a shallow queue under 4 x 300 submissions rejects some;
+    accepted + rejected = submitted, every accepted request completes, no rejected one does"""
+    bad, st = arun(shim, 4, 300, 300, 8, 500, 2, 24, delay_us=500, hnsw=1)
+    assert bad == 0 and st["rejected"] > 0 and st["completions"] + st["rejected"] == 1200
+
+
+def test_destroy_answers_what_is_queued(shim):
+    assert shim.dispatcher_destroy_run(8, 60) == 0
+
+
+def test_a_batch_whose_members_are_all_cancelled_stops_on_the_device(shim):
+    """a batch carries its own cancellation word, raised when every member's token is up -- the 0.3 s device
+    pass ends within milliseconds; with one live member the batch runs to its end and only the cancelled members get
+    VK_ERR_CANCELLED (vector_hnsw.cc:327-329)."""
+    out = (C.c_uint64 * 8)()
+    assert shim.dispatcher_batch_cancel_run(1, out) == 0
+    assert out[0] < 200 and out[1] >= 1, list(out)[:3]
+    assert shim.dispatcher_batch_cancel_run(0, out) == 0
+    assert out[0] >= 290, list(out)[:3]

@@ -35,6 +35,22 @@ class _Env:
                 os.environ[k] = v
 
 
+class _Opt:
+    """run-time options of one index (vk_index_set_option), restored on exit"""
+
+    def __init__(self, ix, **kv):
+        self.ix, self.kv = ix, kv
+
+    def __enter__(self):
+        self.old = {k: self.ix.get_option(k) for k in self.kv}
+        for k, v in self.kv.items():
+            self.ix.set_option(k, v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            self.ix.set_option(k, v)
+
+
 SMALL = dict(VK_FILTER_PREPASS=1024, VK_FILTER_MIN_ROWS=32768)     # let mid-sized test indexes take the filter path
 
 
@@ -322,9 +338,9 @@ def test_bf16_rows_through_the_filter(vsa, oracle, metric):
 
 @pytest.mark.parametrize("metric", ["COSINE", "IP"])
 def test_the_final_pass_kernels_agree(vsa, oracle, metric):
-    """The final pass has several kernels behind one gate: B operands by DMA or through registers (VK_FILTER_BDMA), bf16 rows
-    on the bf16 matrix cores with the rows by DMA or through registers (VK_FILTER_DMA), or converted to f16
-    (VK_FILTER_BF16_MFMA=0).  Same answer from each -- the exact kernel's, bit for bit -- and, where the arithmetic is the
+    """The final pass has several kernels behind one gate: B operands by DMA or through registers (option filter-bdma), bf16
+    rows on the bf16 matrix cores with the rows by DMA or through registers (filter-row-dma), or converted to f16
+    (filter-bf16-mfma = 0); the options are switched per search with vk_index_set_option.  Same answer from each -- the exact kernel's, bit for bit -- and, where the arithmetic is the
     same, the same survivors.  Rows of very different scales next to each other (the margins are per tile), a stretch of
     near-duplicates around one query (many pairs close to the gate), stage counts of 1, 3 and 12."""
     rng = np.random.default_rng(2024)
@@ -341,9 +357,9 @@ def test_the_final_pass_kernels_agree(vsa, oracle, metric):
         Q[3] = x[4999]
         if metric == "COSINE":
             Q = _unit(Q)
-        for dtype, variants in (("f32", [dict(VK_FILTER_BDMA=0)]),
-                                ("bf16", [dict(VK_FILTER_DMA=0), dict(VK_FILTER_DMA=0, VK_FILTER_BDMA=0),
-                                          dict(VK_FILTER_BF16_MFMA=0), dict(VK_FILTER_BF16_MFMA=0, VK_FILTER_BDMA=0)])):
+        for dtype, variants in (("f32", [dict(filter_bdma=0)]),
+                                ("bf16", [dict(filter_row_dma=0), dict(filter_row_dma=0, filter_bdma=0),
+                                          dict(filter_bf16_mfma=0), dict(filter_bf16_mfma=0, filter_bdma=0)])):
             f, e = _pair(vsa, dim, metric, x, dtype=dtype)
             for nq, k in ((160, 10), (37, 3)):
                 want = e.search_batch(Q[:nq], k)
@@ -353,16 +369,16 @@ def test_the_final_pass_kernels_agree(vsa, oracle, metric):
                 _same(got, want)
                 counts = {}
                 for env in variants:
-                    with _Env(**env):
+                    with _Opt(f, **env):
                         _same(f.search_batch(Q[:nq], k), want)
                         st = f.stats()
                     assert st.last_filter_candidates >= nq * k and st.last_filter_fallback == 0, env
                     counts[tuple(sorted(env))] = st.last_filter_candidates
                 if dtype == "f32":
-                    assert counts[("VK_FILTER_BDMA",)] == c0                      # same arithmetic, same survivors
+                    assert counts[("filter_bdma",)] == c0                      # same arithmetic, same survivors
                 else:
-                    assert counts[("VK_FILTER_DMA",)] == c0 == counts[("VK_FILTER_BDMA", "VK_FILTER_DMA")]
-                    assert counts[("VK_FILTER_BF16_MFMA",)] == counts[("VK_FILTER_BDMA", "VK_FILTER_BF16_MFMA")]
+                    assert counts[("filter_row_dma",)] == c0 == counts[("filter_bdma", "filter_row_dma")]
+                    assert counts[("filter_bf16_mfma",)] == counts[("filter_bdma", "filter_bf16_mfma")]
 
 
 @pytest.mark.parametrize("dim,dtype", [(64, "f32"), (200, "f32"), (768, "f32"), (128, "bf16")])
@@ -456,29 +472,41 @@ def test_k_up_to_1024_through_the_filter(vsa, oracle, metric):
         assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
 
 
-def test_four_fat_waves_kernel_gives_the_same_survivors(vsa, oracle):
-    """VK_FILTER_FAT=1: the experimental 256-row-tile kernel (four waves of 512 registers) behind the same gate -- same
-    answer, same survivor counts as the wave-specialised kernel."""
-    rng = np.random.default_rng(512)
-    n, dim = 150_000, 128
-    centres = rng.standard_normal((60, dim)).astype(np.float32)
-    x = _unit(centres[rng.integers(0, 60, n)] + 0.4 * rng.standard_normal((n, dim)).astype(np.float32))
-    x[30_000:42_000] = x[5]                                  # a query on 12 000 duplicates: spill chunks in the fat kernel too
-    Q = _unit(centres[rng.integers(0, 60, 256)] + 0.4 * rng.standard_normal((256, dim)).astype(np.float32))
-    Q[9] = x[5]
-    for dtype in ("f32", "bf16"):
-        f, e = _pair(vsa, dim, "COSINE", x, dtype=dtype)
-        ref = f.search_batch(Q, 10)
-        c_ref = f.stats().last_filter_candidates
-        _same(ref, e.search_batch(Q, 10))
-        with _Env(VK_FILTER_FAT=1):                              # (read at every launch)
-            got = f.search_batch(Q, 10)
-            st = f.stats()
-        _same(got, ref)
-        assert st.last_filter_fallback == 0
-        if dtype == "f32":
-            assert st.last_filter_candidates == c_ref
-        else:                                                    # (bf16 rows: the default kernel multiplies in bf16, this one in f16)
-            with _Env(VK_FILTER_BF16_MFMA=0):
-                f.search_batch(Q, 10)
-                assert f.stats().last_filter_candidates == st.last_filter_candidates
+def test_four_fat_waves_kernel_gives_the_same_survivors():
+    """The experimental 256-row-tile kernel (four waves of 512 registers) lives in the -DVK_EXPERIMENTS build of the
+    library only (libvkindex_exp.so, VK_FILTER_FAT=1 read per launch there): behind the same gate it must give the same
+    answer and the same survivor counts as the wave-specialised kernel.  Runs in its own process with that library."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exp = root / "valkey-search_amd" / "libvkindex_exp.so"
+    if not exp.exists():
+        pytest.skip("libvkindex_exp.so not built (make -C valkey-search_amd/csrc experiments)")
+    r = subprocess.run([sys.executable, str(root / "tests" / "helpers" / "exp_fat_check.py")], cwd=root, capture_output=True, text=True,
+                       env=dict(os.environ, VKINDEX_LIB=str(exp)), timeout=600)
+    assert r.returncode == 0 and "fat kernel ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_experiment_switches_do_nothing_in_the_product_library(vsa):
+    """An environment variable must not be able to make a drop-in index return wrong neighbours: the ablation / timing /
+    fat-kernel switches of the experiments build are not compiled into libvkindex.so -- no such kernels in the binary, and
+    with every one of them set the answer is the exact one."""
+    import subprocess
+    from pathlib import Path
+    lib = Path(vsa.LIB_PATH)
+    names = subprocess.run(["strings", str(lib)], capture_output=True, text=True).stdout
+    for needle in ("abl_kernel", "filter_fat_kernel", "VK_FILTER_ABLATE", "VK_GEMM_ABLATE", "VK_FILTER_TIMING", "VK_FAT_DBG", "VK_FILTER_FAT"):
+        assert needle not in names, needle
+    rng = np.random.default_rng(77)
+    n, dim = 60_000, 128
+    x = _unit(rng.standard_normal((n, dim)).astype(np.float32))
+    Q = _unit(rng.standard_normal((64, dim)).astype(np.float32))
+    f, e = _pair(vsa, dim, "COSINE", x)
+    want = e.search_batch(Q, 10)
+    with _Env(VK_FILTER_ABLATE=1, VK_GEMM_ABLATE=3, VK_FILTER_TIMING=1, VK_FILTER_FAT=1, VK_FAT_DBG=1, VK_FILTER_PRIO=21):
+        f2, e2 = _pair(vsa, dim, "COSINE", x)                     # (even an index CREATED under them)
+        _same(f.search_batch(Q, 10), want)
+        _same(f2.search_batch(Q, 10), want)
+        _same(e2.search_batch(Q, 10), want)
+        assert f.stats().last_filter_candidates >= 64 * 10

@@ -112,14 +112,13 @@ def test_bf16_shard_of_config3_at_full_size(world, oracle):
     for i in range(0, B, 8):                           # one query per call: the scan kernel
         d, l = ix.search(Q[i], K)
         assert l.tolist() == Lb[i].tolist() and d.view(np.uint32).tolist() == Db[i].view(np.uint32).tolist()
-    for env in ({"VK_FILTER_DMA": "0"}, {"VK_FILTER_BF16_MFMA": "0"}):
-        os.environ.update(env)
+    for opt in ("filter-row-dma", "filter-bf16-mfma"):       # the same filter's other final-pass kernels (vk_index_set_option)
+        ix.set_option(opt, 0)
         try:
             D2, L2, _ = ix.search_batch(Q, K)
         finally:
-            for k_ in env:
-                os.environ.pop(k_)
-        assert (L2 == Lb).all() and (D2.view(np.uint32) == Db.view(np.uint32)).all(), env
+            ix.set_option(opt, 1)
+        assert (L2 == Lb).all() and (D2.view(np.uint32) == Db.view(np.uint32)).all(), opt
     S = 60_000
     sample = np.arange(0, N, N // S, dtype=np.uint64)[:S]
     host = np.ascontiguousarray(table[torch.from_numpy(sample.astype(np.int64)).to(dev), :D].float().cpu().numpy())

@@ -19,7 +19,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["VKINDEX_LIB"]) if os.environ.get("VKINDEX_LIB") else PKG_DIR / "libvkindex.so"
 HOST_LIB_PATH = PKG_DIR / "libvkhost.so"
 
-VK_OK, VK_ERR_INVALID, VK_ERR_CAPACITY, VK_ERR_NOT_FOUND, VK_ERR_INTERNAL, VK_ERR_CANCELLED, VK_ERR_NO_DEVICE = range(7)
+VK_OK, VK_ERR_INVALID, VK_ERR_CAPACITY, VK_ERR_NOT_FOUND, VK_ERR_INTERNAL, VK_ERR_CANCELLED, VK_ERR_NO_DEVICE, VK_ERR_BUSY = range(8)
 ALGO = {"FLAT": 0, "HNSW": 1}
 METRIC = {"L2": 0, "IP": 1, "COSINE": 2}
 
@@ -47,11 +47,28 @@ class Stats(C.Structure):
                 ("last_filter_candidates", C.c_uint64), ("last_filter_fallback", C.c_uint64),
                 ("filter_batches", C.c_uint64), ("filter_kernel_ns", C.c_uint64),
                 ("coalesced_batches", C.c_uint64), ("coalesced_queries", C.c_uint64),
-                ("fanout_calls", C.c_uint64), ("fanout_enqueue_ns", C.c_uint64)]
+                ("fanout_calls", C.c_uint64), ("fanout_enqueue_ns", C.c_uint64),
+                ("searches", C.c_uint64), ("search_calls", C.c_uint64), ("search_errors", C.c_uint64 * 8),
+                ("total_n_eval", C.c_uint64), ("total_n_hops", C.c_uint64), ("tombstoned_bytes", C.c_uint64),
+                ("latency_hist", C.c_uint64 * 16), ("latency_sum_ns", C.c_uint64),
+                ("submitted", C.c_uint64), ("rejected", C.c_uint64), ("queued_now", C.c_uint64),
+                ("max_batches_in_flight", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 READ_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
+SEARCH_DONE = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+
+
+EXP_LIB_PATH = PKG_DIR / "libvkindex_exp.so"
+
+
+def build_experiments(verbose: bool = False) -> Path:
+    """The -DVK_EXPERIMENTS build of the library (ablation / cycle-counter kernels whose answers are invalid, A/B
+    constants from the environment): scripts/ only -- select it with VKINDEX_LIB=<this path> in a fresh process."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-s", "-j8", "-C", str(PKG_DIR / "csrc"), "experiments"], stdout=out)
+    return EXP_LIB_PATH
 
 
 def build(verbose: bool = False) -> None:
@@ -87,6 +104,10 @@ def lib() -> C.CDLL:
     L.vk_index_set_ef.argtypes = [vp, u32]
     L.vk_index_flush.argtypes = [vp]
     L.vk_index_set_coalescing.argtypes = [vp, u32, u32]
+    L.vk_index_set_option.argtypes = [vp, C.c_char_p, u64]
+    L.vk_index_get_option.argtypes = [vp, C.c_char_p, u64p]
+    L.vk_index_search_submit.argtypes = [vp, vp, u64, u64, vp, u64, vp, i32, vp, vp, vp, SEARCH_DONE, vp]
+    L.vk_index_shard_stats.argtypes = [vp, u32, C.POINTER(Stats)]
     L.vk_index_search.argtypes = [vp, vp, u64, u64, vp, u64, vp, i32, vp, vp, u64p]
     L.vk_index_search_batch.argtypes = [vp, vp, u64, u64, u64, vp, u64, vp, i32, vp, vp, vp]
     L.vk_index_search_batch_filters.argtypes = [vp, vp, u64, u64, u64, vp, vp, vp, i32, vp, vp, vp]
@@ -135,15 +156,72 @@ def make_params(algo, dim, metric, initial_cap, block_size=1024, m=16, ef_constr
     return p
 
 
+class _Pending:
+    """buffers of one submitted request"""
+
+    def __init__(self, q, k, allow, cancel):
+        self.q, self.allow, self.cancel = q, allow, cancel
+        self.d = np.empty(k, np.float32)
+        self.l = np.empty(k, np.uint64)
+        self.n = np.zeros(1, np.uint64)
+        self.status = None
+        self.cb = None
+
+    def result(self):
+        m = int(self.n[0])
+        return self.d[:m], self.l[:m]
+
+
+_PENDING = set()
+
+
 class Index:
     """Thin RAII wrapper over vk_index_* (one per hnswlib algorithm object)."""
 
-    def __init__(self, algo, dim, metric="L2", initial_cap=1024, **kw):
+    def __init__(self, algo, dim, metric="L2", initial_cap=1024, options=None, **kw):
+        """options: {name: value} applied with vk_index_set_option right after creation (csrc/options.hpp)"""
         self.algo, self.dim, self.metric = algo, dim, metric
         self.params = make_params(algo, dim, metric, initial_cap, **kw)
         h = C.c_void_p()
         _check(lib().vk_index_create(C.byref(self.params), C.byref(h)))
         self._h = h
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        _check(lib().vk_index_set_option(self._h, name.replace("_", "-").encode(), int(value)))
+
+    def get_option(self, name) -> int:
+        v = C.c_uint64()
+        _check(lib().vk_index_get_option(self._h, name.replace("_", "-").encode(), C.byref(v)))
+        return v.value
+
+    def shard_stats(self, shard) -> "Stats":
+        s = Stats()
+        _check(lib().vk_index_shard_stats(self._h, int(shard), C.byref(s)))
+        return s
+
+    def submit(self, q, k, done, ef=0, allow=None, allow_nbits=None, cancel=None, partial_ok=True):
+        """vk_index_search_submit.  Returns a handle whose arrays (.d, .l, .n) hold the answer once `done(status)` has been
+        called (from a library thread); the handle keeps every buffer of the request alive."""
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
+        h = _Pending(q, k, allow, cancel)
+        ap, nb = (None, 0) if allow is None else (allow.ctypes.data, int(allow_nbits if allow_nbits is not None else allow.size * 64))
+        cflag = None if cancel is None else C.cast(C.pointer(cancel), C.c_void_p)
+
+        def _cb(_user, status, h=h, done=done):
+            h.status = status
+            done(status)
+            _PENDING.discard(h)
+
+        h.cb = SEARCH_DONE(_cb)
+        _PENDING.add(h)
+        rc = lib().vk_index_search_submit(self._h, q.ctypes.data, int(k), int(ef), ap, nb, cflag, int(partial_ok), h.d.ctypes.data,
+                                          h.l.ctypes.data, h.n.ctypes.data, h.cb, None)
+        if rc != VK_OK:
+            _PENDING.discard(h)
+            _check(rc)
+        return h
 
     @classmethod
     def _from_handle(cls, h, params, algo, dim, metric):
@@ -338,3 +416,54 @@ class Index:
 def merge_topk_device(d_dist, d_label, parts, nq, k, d_out_dist, d_out_label, d_out_n, device_id=-1, stream=None):
     _check(lib().vk_merge_topk_device(d_dist, d_label, parts, nq, k, d_out_dist, d_out_label, d_out_n, device_id,
                                       stream))
+
+
+# ---- scripts/serving_probe.cc: native drivers of the single-query serving path against an index this process holds ----
+class ProbeResult(C.Structure):
+    _fields_ = [("qps", C.c_double), ("seconds", C.c_double), ("completed", C.c_uint64), ("rejected", C.c_uint64),
+                ("mismatches", C.c_uint64), ("errors", C.c_uint64), ("device_batches", C.c_uint64),
+                ("max_batches_in_flight", C.c_uint64), ("mean_batch", C.c_double), ("p50_us", C.c_double),
+                ("p99_us", C.c_double), ("max_us", C.c_double)]
+
+    def as_dict(self):
+        return {k: (round(getattr(self, k), 1) if isinstance(getattr(self, k), float) else int(getattr(self, k))) for k, _ in self._fields_}
+
+
+_probe = None
+
+
+def probe_lib():
+    global _probe
+    if _probe is None:
+        path = PKG_DIR.parent / "scripts" / "libservingprobe.so"
+        if not path.exists():
+            raise FileNotFoundError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib()                                   # (libvkindex first: the probe links against it)
+        P = C.CDLL(str(path))
+        vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+        P.vk_probe_submit.argtypes = [vp, vp, u64, u32, u64, u64, i32, i32, u64, vp, vp, C.POINTER(ProbeResult)]
+        P.vk_probe_blocking.argtypes = [vp, vp, u64, u32, u64, u64, i32, i32, vp, vp, C.POINTER(ProbeResult)]
+        _probe = P
+    return _probe
+
+
+def probe_submit(ix, Q, k, total, producers=4, window=1024, ef=0, ref=None):
+    """`producers` native threads keep `window` vk_index_search_submit requests outstanding until `total` have completed;
+    ref = (dist [nq][k] f32, labels [nq][k] u64) to compare every answer with"""
+    Q = np.ascontiguousarray(Q, dtype=np.float32)
+    rd = rl = None
+    if ref is not None:
+        rd, rl = np.ascontiguousarray(ref[0], dtype=np.float32), np.ascontiguousarray(ref[1], dtype=np.uint64)
+    r = ProbeResult()
+    _check(probe_lib().vk_probe_submit(ix._h, _ptr(Q), Q.shape[0], Q.shape[1], k, ef, producers, window, total, _ptr(rd), _ptr(rl), C.byref(r)))
+    return r
+
+
+def probe_blocking(ix, Q, k, threads, calls, ef=0, ref=None):
+    Q = np.ascontiguousarray(Q, dtype=np.float32)
+    rd = rl = None
+    if ref is not None:
+        rd, rl = np.ascontiguousarray(ref[0], dtype=np.float32), np.ascontiguousarray(ref[1], dtype=np.uint64)
+    r = ProbeResult()
+    _check(probe_lib().vk_probe_blocking(ix._h, _ptr(Q), Q.shape[0], Q.shape[1], k, ef, threads, calls, _ptr(rd), _ptr(rl), C.byref(r)))
+    return r

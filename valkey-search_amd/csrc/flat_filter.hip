@@ -64,6 +64,17 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// experiment-only arguments (kernels.hpp): constants in the product build, so the variants they select do not exist there
+#ifdef VK_EXPERIMENTS
+__device__ __forceinline__ uint32_t exp_ablate(const FlatFilterArgs &a) { return a.ablate; }
+__device__ __forceinline__ uint32_t exp_prio(const FlatFilterArgs &a) { return a.prio; }
+__device__ __forceinline__ unsigned long long *exp_dbg(const FlatFilterArgs &a) { return a.dbg; }
+#else
+__device__ __forceinline__ uint32_t exp_ablate(const FlatFilterArgs &) { return 0u; }
+__device__ __forceinline__ uint32_t exp_prio(const FlatFilterArgs &) { return 0u; }
+__device__ __forceinline__ unsigned long long *exp_dbg(const FlatFilterArgs &) { return nullptr; }
+#endif
+
 namespace {
 constexpr int kFTileRows = 128;
 constexpr int kFStageK = 64;                 // k per pipeline stage: 4 MFMA K-steps of 16
@@ -71,7 +82,7 @@ constexpr int kFAStride = 72;                // halfs per staged row: 64 + 8 pad
 }  // namespace
 
 // ---- row statistics: the largest row norm per 128-row tile (and of the index) over rows [lo, hi) ------------------------
-// tile_r2[t] = max over the tile's rows of |x| (the norm, f32 bits, rounded up), or +inf when the tile holds a value the f16
+// tile_norm[t] = max over the tile's rows of |x| (the norm, f32 bits, rounded up), or +inf when the tile holds a value the f16
 // pipe cannot carry (non-finite, |x_i| > 32768, for L2 a half norm beyond f16): the filter lets every pair of such a
 // tile through to the exact re-rank.  stats[0] / stats[1] = the same maxima over the whole index (|x|^2, |x_i|; reported,
 // not used by the gate), stats[2] = number of tiles flagged +inf (FlatIndex keeps an index that is mostly such tiles
@@ -80,7 +91,7 @@ constexpr int kFAStride = 72;                // halfs per staged row: 64 + 8 pad
 // hn16 (optional, L2 indexes): per row half its squared norm, split into two f16 (hi | lo << 16) -- the extra K-step
 // that turns the filter's dot product into dot - |x|^2 / 2.
 __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32_t bf16, uint32_t l2, uint32_t stride_e, uint32_t chunks,
-                                                        uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *tile_r2, uint32_t *hn16) {
+                                                        uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *tile_norm, uint32_t *hn16) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 3, rq = lane >> 2;
   const uint32_t total_waves = gridDim.x * 4, n_tiles = (hi - lo + kRowsPerWave - 1) / kRowsPerWave;
   float best_n2 = 0.f, best_abs = 0.f;
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32
     const bool g_bad = !(g_abs <= 32768.f) || !(g_n2 - g_n2 == 0.f) || (l2 && !(0.5f * g_n2 <= 60000.f));
     if (lane == 0) {
       const uint32_t v = g_bad ? 0x7F800000u : __float_as_uint(sqrtf(g_n2) * 1.0001f);   // the NORM, rounded up
-      const uint32_t old = atomicMax(&tile_r2[(lo + tile * kRowsPerWave) / 128u], v);
+      const uint32_t old = atomicMax(&tile_norm[(lo + tile * kRowsPerWave) / 128u], v);
       if (g_bad && old != 0x7F800000u) atomicAdd(&stats[2], 1u);
     }
     best_n2 = fmaxf(best_n2, g_n2);
@@ -126,14 +137,14 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32
 // stats[3] = the norm cap of the sample's witnesses: the upper edge of the smallest tile-norm bin (exponent + 3 mantissa
 // bits: 9 % wide) that 97 % of the finite tiles stay below.  A robust "largest ordinary norm": one row of norm 1e6 in a
 // unit-norm index moves the global maximum by six orders of magnitude and this not at all.  One block.
-__global__ __launch_bounds__(1024) void tile_cap_kernel(const uint32_t *tile_r2, uint32_t n_tiles, uint32_t *stats) {
+__global__ __launch_bounds__(1024) void tile_cap_kernel(const uint32_t *tile_norm, uint32_t n_tiles, uint32_t *stats) {
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t part[1024];
   const uint32_t tid = threadIdx.x;
   hist[tid] = hist[tid + 1024] = 0;
   __syncthreads();
   for (uint32_t i = tid; i < n_tiles; i += 1024) {
-    const uint32_t v = tile_r2[i];
+    const uint32_t v = tile_norm[i];
     if (v < 0x7F800000u) atomicAdd(&hist[v >> 20], 1u);
   }
   __syncthreads();
@@ -153,15 +164,15 @@ __global__ __launch_bounds__(1024) void tile_cap_kernel(const uint32_t *tile_r2,
 }
 
 hipError_t launch_row_stats(const void *rows, bool bf16, bool l2, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t n_tiles,
-                            uint32_t *stats, uint32_t *tile_r2, uint32_t *hn16, hipStream_t s) {
+                            uint32_t *stats, uint32_t *tile_norm, uint32_t *hn16, hipStream_t s) {
   lo &= ~127u;                                            // whole tiles: a step of 16 rows never straddles two of them
   if (hi > lo) {
     const uint32_t tiles = (hi - lo + kRowsPerWave - 1) / kRowsPerWave;
     const uint32_t blocks = std::min<uint32_t>((tiles + 3) / 4, 2048);
     hipLaunchKernelGGL(row_stats_kernel, dim3(blocks), dim3(256), 0, s, rows, bf16 ? 1u : 0u, l2 ? 1u : 0u, stride_e, stride_e / 16, lo, hi,
-                       stats, tile_r2, hn16);
+                       stats, tile_norm, hn16);
   }
-  hipLaunchKernelGGL(tile_cap_kernel, dim3(1), dim3(1024), 0, s, tile_r2, n_tiles, stats);
+  hipLaunchKernelGGL(tile_cap_kernel, dim3(1), dim3(1024), 0, s, tile_norm, n_tiles, stats);
   return hipGetLastError();
 }
 
@@ -244,8 +255,8 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
     a.ovf_q[j] = live ? 0u : 1u;
   }
   a.qcoef[j] = co;
-  // the column's margin for the witnesses of the sample: rows of norm up to the cap (see FlatFilterArgs::r2_cap)
-  const float Rc = __uint_as_float(*a.r2_cap);
+  // the column's margin for the witnesses of the sample: rows of norm up to the cap (see FlatFilterArgs::norm_cap)
+  const float Rc = __uint_as_float(*a.norm_cap);
   a.qwit[j] = fmaf(fmaf(co.x, Rc, co.y), Rc, co.z);
 }
 
@@ -351,7 +362,8 @@ __device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing
   }
 }
 
-// The column's gate for a tile whose largest row norm is R (r2 = R^2 as f32 bits, +inf = a tile that cannot go through
+// The column's gate for a tile whose largest row norm is R (norm_bits = R itself as f32 bits, rounded up by row_stats_kernel -- NOT
+// its square; +inf = a tile that cannot go through
 // f16: everything passes).  A pair stays unless approx < thr.
 // (bound = +inf closes the column: a padding column, or a query handed to the exact pass)
 template <bool kL2> struct GateCol { float c1, c0, bound; };
@@ -361,8 +373,8 @@ template <bool kL2> __device__ __forceinline__ float tile_margin(const GateCol<k
   else return fmaf(c.c1, R, c.c0);
 }
 __device__ __forceinline__ float tile_norm(uint32_t r_bits) { return __uint_as_float(r_bits); }   // (row_stats rounded it up)
-template <bool kL2> __device__ __forceinline__ float gate_thr(const GateCol<kL2> &c, uint32_t r2_bits) {
-  const float R = tile_norm(r2_bits);
+template <bool kL2> __device__ __forceinline__ float gate_thr(const GateCol<kL2> &c, uint32_t norm_bits) {
+  const float R = tile_norm(norm_bits);
   // (2^-21 max(1, |bound|): the rounding of the subtractions that make the threshold out of bound and margin)
   float thr = (c.bound - tile_margin<kL2>(c, R)) - 0x1p-21f * fmaxf(1.f, fabsf(c.bound));
   if (!(thr == thr)) thr = -__builtin_inff();                       // (a tile beyond f16: R = +inf)
@@ -546,12 +558,12 @@ __device__ __forceinline__ void ws_rows_load_sample(WsRows<kBf16> &s, const Flat
   // (the tile look-ups are requested BEFORE the rows: loads return in order, so waiting for them leaves the rows in flight)
   uint32_t pz = 0;
   if (st == 0) {
-    uint32_t r2[kPieces];
+    uint32_t tn[kPieces];
 #pragma unroll
     for (int u = 0; u < kPieces; ++u)
-      r2[u] = a.tile_r2[((size_t)((uint32_t)u * a.n_tiles + tile) * kR + i0) * a.sample_gap >> 7];
+      tn[u] = a.tile_norm[((size_t)((uint32_t)u * a.n_tiles + tile) * kR + i0) * a.sample_gap >> 7];
 #pragma unroll
-    for (int u = 0; u < kPieces; ++u) pz |= (r2[u] > cap_bits ? 1u : 0u) << u;
+    for (int u = 0; u < kPieces; ++u) pz |= (tn[u] > cap_bits ? 1u : 0u) << u;
   }
   s.pz = pz;
 #pragma unroll
@@ -656,7 +668,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   // (experiment kernels only, kAbl != 0: a.ablate switches pieces of the pipeline OFF -- results invalid, times tell what bounds a stage:
   //  1 B producers do not store, 2 nor load; 4 row producers do not store, 8 nor load; kAbl 16 / 32: the consumers keep
   //  the B / A fragments they read first)
-  const uint32_t abl = kAbl != 0 ? a.ablate : 0u;
+  const uint32_t abl = kAbl != 0 ? exp_ablate(a) : 0u;
   extern __shared__ _Float16 lds_a[];
   constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;                    // one A stage
   uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + (kDma ? kDmaRing * kDmaStageBytes / 2 : 2 * kBufHalfs));   // [2][kWsBStage]
@@ -726,7 +738,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   // wave priorities (VK_FILTER_PRIO = row producers | query producers << 2 | consumers << 4): the two waves of a SIMD share
   // its issue slots by priority, then age -- and the producers are the younger half of the block
   {
-    const uint32_t pr = (a.prio >> (wave >= 6 ? 2 : wave >= 4 ? 0 : 4)) & 3u;
+    const uint32_t pr = (exp_prio(a) >> (wave >= 6 ? 2 : wave >= 4 ? 0 : 4)) & 3u;
     if (pr == 1) __builtin_amdgcn_s_setprio(1);
     else if (pr == 2) __builtin_amdgcn_s_setprio(2);
     else if (pr == 3) __builtin_amdgcn_s_setprio(3);
@@ -813,9 +825,9 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     }
 #undef VK_WS_BPROD
     if constexpr (timing) {
-      if (lane == 0 && a.dbg) {
-        atomicAdd(&a.dbg[4], ph[0]);
-        atomicAdd(&a.dbg[8], ph[1]);
+      if (lane == 0 && exp_dbg(a)) {
+        atomicAdd(&exp_dbg(a)[4], ph[0]);
+        atomicAdd(&exp_dbg(a)[8], ph[1]);
       }
     }
     return;
@@ -927,7 +939,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     x0.hn = x1.hn = x2.hn = x3.hn = x4.hn = x5.hn = 0;
     x0.pz = x1.pz = x2.pz = x3.pz = x4.pz = x5.pz = 0;
     uint32_t cap_bits = 0;
-    if constexpr (kSample) cap_bits = *a.r2_cap;
+    if constexpr (kSample) cap_bits = *a.norm_cap;
 #define VK_WS_ROWS_LOAD(X)                                                                                          \
     {                                                                                                               \
       if constexpr (kSample) ws_rows_load_sample<kBf16, kL2>(X, a, ld.row0, ld.st, t, cap_bits);                    \
@@ -993,8 +1005,8 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
 #undef VK_WS_PROD
 #undef VK_WS_ROWS_LOAD
     if constexpr (timing) {
-      if (lane == 0 && a.dbg)
-        for (int i = 0; i < 4; ++i) atomicAdd(&a.dbg[i], ph[i]);
+      if (lane == 0 && exp_dbg(a))
+        for (int i = 0; i < 4; ++i) atomicAdd(&exp_dbg(a)[i], ph[i]);
     }
     return;
   }
@@ -1037,12 +1049,12 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     for (int rt = 0; rt < 4; ++rt) acc[t2][rt] = zero;
   uint32_t tile_row0 = first_tile * row_step;
   uint32_t par = 0;
-  // The tile's |row|^2 bound: ONE vector-memory word per tile and wave, requested when the tile starts and looked at in
+  // The tile's norm bound (largest |row|, not squared): ONE vector-memory word per tile and wave, requested when the tile starts and looked at in
   // its gate twelve stages later (a buffer load on purpose: a scalar load shares the LDS reads' counter, and every
   // wait for a fragment behind it would become a wait for everything).
-  const __amdgpu_buffer_rsrc_t tile_rsrc = ws_rsrc(a.tile_r2);
-  uint32_t r2_bits = 0;
-  if constexpr (!kSample) r2_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
+  const __amdgpu_buffer_rsrc_t tile_rsrc = ws_rsrc(a.tile_norm);
+  uint32_t norm_bits = 0;
+  if constexpr (!kSample) norm_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
   __syncthreads();                                            // (the prologue's barrier)
 
   // iteration S: 32 MFMAs of stage S, operands from LDS (A: buffer S & 1, row li of each row tile; B: slot S & 1,
@@ -1132,13 +1144,13 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) asm volatile("" ::"v"(acc[0][rt]), "v"(acc[1][rt]));
         } else {
-          filter_gate<4, false>(a, acc[0], gate_thr<kL2>(col[0], r2_bits), tile_row0, wave * 2, li, g, ring, lane);
-          filter_gate<4, false>(a, acc[1], gate_thr<kL2>(col[1], r2_bits), tile_row0, wave * 2 + 1, li, g, ring, lane);
+          filter_gate<4, false>(a, acc[0], gate_thr<kL2>(col[0], norm_bits), tile_row0, wave * 2, li, g, ring, lane);
+          filter_gate<4, false>(a, acc[1], gate_thr<kL2>(col[1], norm_bits), tile_row0, wave * 2 + 1, li, g, ring, lane);
         }
       }
       tile_row0 += row_step;
       // (past the block's last tile this reads a word behind it: the table is padded, the value is not used)
-      if constexpr (!kSample) r2_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
+      if constexpr (!kSample) norm_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
       VK_WS_TICK(1)
       VK_WS_TILE_END(__syncthreads())
     } else {
@@ -1152,12 +1164,13 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
 #undef VK_WS_TILE_END
 #undef VK_WS_TICK
   if constexpr (timing) {
-    if (lane == 0 && a.dbg)
-      for (int i = 0; i < 3; ++i) atomicAdd(&a.dbg[5 + i], ph[i]);
+    if (lane == 0 && exp_dbg(a))
+      for (int i = 0; i < 3; ++i) atomicAdd(&exp_dbg(a)[5 + i], ph[i]);
   }
   ring_flush(a, ring, lane);
 }
 
+#ifdef VK_EXPERIMENTS
 // ---- the filter, four fat waves (r03) ---------------------------------------------------------------------------------
 // The wave-specialised kernel above moves, per 128-row tile, as many B-operand bytes from L2 as row bytes from HBM (the
 // batch's 384 KB of f16 queries per tile), and its four multiplying waves read 96 KB of LDS per 64-k stage for 128 MFMAs:
@@ -1300,8 +1313,8 @@ __global__ __launch_bounds__(kFatThreads, 1) void flat_filter_fat_kernel(FlatFil
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   uint32_t tile_row0 = first_tile * kFatRows, st_c = 0, tile_c = 0, par = 0;
   bool stop = false;
-  const __amdgpu_buffer_rsrc_t tile_rsrc = ws_rsrc(a.tile_r2);
-  uint32_t r2_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / 128u + wr) * 4u), 0);
+  const __amdgpu_buffer_rsrc_t tile_rsrc = ws_rsrc(a.tile_norm);
+  uint32_t norm_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / 128u + wr) * 4u), 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -1392,10 +1405,10 @@ __global__ __launch_bounds__(kFatThreads, 1) void flat_filter_fat_kernel(FlatFil
     if constexpr (kDbg) dbg_t0 = __builtin_readcyclecounter();
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt)
-      filter_gate<4, false>(a, acc[qt], gate_thr<false>(col[qt], r2_bits), tile_row0 + wr * 128, wc * 4 + qt, li, g, ring, lane);
+      filter_gate<4, false>(a, acc[qt], gate_thr<false>(col[qt], norm_bits), tile_row0 + wr * 128, wc * 4 + qt, li, g, ring, lane);
     if constexpr (kDbg) dbg_gate += __builtin_readcyclecounter() - dbg_t0;
     tile_row0 += kFatRows;
-    r2_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / 128u + wr) * 4u), 0);
+    norm_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / 128u + wr) * 4u), 0);
     uint32_t sv_;   // (cancellation seen during this tile; written before the tile's last barrier, see the kernel above)
     asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(sv_) : "v"((uint32_t)(uintptr_t)(lds_stop + (tile_c & 1))) : "memory");
     stop = sv_ != 0;
@@ -1416,6 +1429,8 @@ __global__ __launch_bounds__(kFatThreads, 1) void flat_filter_fat_kernel(FlatFil
   }
 }
 
+#endif  // VK_EXPERIMENTS (the four-fat-waves kernel)
+
 template <bool kBf16, bool kL2, bool kTiming, int kAbl = 0>
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_kernel(FlatFilterArgs a) {
   flat_filter_body<kBf16, kL2, kTiming, false, kAbl>(a);
@@ -1432,10 +1447,12 @@ template <bool kBf16, bool kL2, bool kBfMma>
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bdma_kernel(FlatFilterArgs a) {
   flat_filter_body<kBf16, kL2, false, false, 0, kBfMma, false, true>(a);
 }
+#ifdef VK_EXPERIMENTS
 template <int kAbl>   // (experiments, VK_FILTER_ABLATE)
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_dma_abl_kernel(FlatFilterArgs a) {
   flat_filter_body<true, false, false, false, kAbl, true, true>(a);
 }
+#endif
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_sample_kernel(FlatFilterArgs a) {
   flat_filter_body<true, false, false, true, 0, true>(a);
 }
@@ -1469,20 +1486,21 @@ hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+#ifdef VK_EXPERIMENTS
 size_t flat_filter_fat_lds_bytes() {
   return (size_t)2 * kFatABuf * sizeof(_Float16) + (size_t)2 * kFatBStage * 16 + (size_t)4 * 2 * kWave * 4 + 16;
 }
-// the four-fat-waves kernel serves the final pass in the inner-product space (VK_FILTER_FAT=0: the kernel above)
+// the four-fat-waves kernel serves the final pass in the inner-product space (experiments build, VK_FILTER_FAT=1)
 bool flat_filter_fat_enabled(const FlatFilterArgs &a) {
-  // (opt-in: measured slower than the wave-specialised kernel -- 10M x 768, B = 256, same lease: f32 6.1-7.1 ms against
+  // (measured slower than the wave-specialised kernel -- 10M x 768, B = 256, same lease: f32 6.1-7.1 ms against
   // 5.3, bf16 4.50 against 4.55 per step; its cycle counters, VK_FAT_DBG=1: a stage takes 2.1-2.7x its MFMA time)
-  const char *env = getenv("VK_FILTER_FAT");      // (read per launch: tests switch it inside one process)
-  const bool on = env && atoi(env) != 0;
-  return on && a.mode == 0 && !a.l2 && !a.timing && !a.qbf16 && (a.row_stride_f / kFStageK) % 2 == 0;
+  return a.fat && a.mode == 0 && !a.l2 && !a.timing && !a.qbf16 && (a.row_stride_f / kFStageK) % 2 == 0;
 }
+#endif
 
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.nqt == 0 || a.nqt > 8 || blocks == 0 || a.n_tiles == 0 || (a.mode == 1 && a.sample_gap == 0)) return hipErrorInvalidValue;
+#ifdef VK_EXPERIMENTS
   if (flat_filter_fat_enabled(a)) {
     const size_t lds = flat_filter_fat_lds_bytes();
     const void *fn = a.bf16 ? reinterpret_cast<const void *>(&flat_filter_fat_kernel<true>) : reinterpret_cast<const void *>(&flat_filter_fat_kernel<false>);
@@ -1495,6 +1513,7 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
     const uint32_t nb = blocks < args.n_tiles ? blocks : args.n_tiles;
     return hipLaunchKernel(fn, dim3(nb), dim3(kFatThreads), params, lds, s);
   }
+#endif
   size_t lds = flat_filter_lds_bytes();
   const void *fn = a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, true, false>)
                                   : reinterpret_cast<const void *>(&flat_filter_kernel<true, false, false>))
@@ -1510,12 +1529,19 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
     fn = a.mode == 1 ? reinterpret_cast<const void *>(&flat_filter_bfmma_sample_kernel) : reinterpret_cast<const void *>(&flat_filter_bfmma_kernel);
     if (a.mode == 0 && a.dma) {
       fn = reinterpret_cast<const void *>(&flat_filter_bfmma_dma_kernel);
+#ifdef VK_EXPERIMENTS
       if (a.ablate_on) fn = (a.ablate & 112u) == 112u ? reinterpret_cast<const void *>(&flat_filter_bfmma_dma_abl_kernel<113>)
                                                         : reinterpret_cast<const void *>(&flat_filter_bfmma_dma_abl_kernel<1>);
+#endif
       lds = flat_filter_dma_lds_bytes();
     }
   }
-  if (a.bdma && a.mode == 0 && !a.timing && !a.ablate_on && !(a.qbf16 && a.dma)) {
+#ifdef VK_EXPERIMENTS
+  const bool exp_variant = a.timing || a.ablate_on;
+#else
+  constexpr bool exp_variant = false;
+#endif
+  if (a.bdma && a.mode == 0 && !exp_variant && !(a.qbf16 && a.dma)) {
     fn = a.qbf16 ? reinterpret_cast<const void *>(&flat_filter_bdma_kernel<true, false, true>)
          : a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_bdma_kernel<true, true, false>)
                           : reinterpret_cast<const void *>(&flat_filter_bdma_kernel<true, false, false>))
@@ -1523,6 +1549,7 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
                           : reinterpret_cast<const void *>(&flat_filter_bdma_kernel<false, false, false>));
     lds = flat_filter_bdma_lds_bytes();
   }
+#ifdef VK_EXPERIMENTS
   if (a.timing) {
     if (a.l2 || a.mode == 1 || a.qbf16) return hipErrorInvalidValue;
     fn = a.bf16 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, false, true>)
@@ -1542,6 +1569,7 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
     }
 #undef VK_ABL
   }
+#endif
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (above the 64 KB default)
   if (e != hipSuccess) return e;
   FlatFilterArgs args = a;

@@ -535,27 +535,35 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
   if (a.nrp == 0 || (a.nrp & 7u) || a.tile_q == 0 || a.nqt != (a.nq + a.tile_q - 1) / a.tile_q) return hipErrorInvalidValue;
   const size_t lds = flat_gemm_lds_bytes(a.row_stride_f, a.tile_q);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+#ifdef VK_EXPERIMENTS
+  // the experiments build only (scripts/k4_ablate.sh): the timing ladder -- results INVALID -- and the A/B variants with
+  // the compiler's own placement of a stage's memory operations / without the register lists
   static const int ablate = getenv("VK_GEMM_ABLATE") ? atoi(getenv("VK_GEMM_ABLATE")) : 0;
-  // VK_GEMM_MODE=0: the compiler's own placement of the stage's memory operations (A/B switch)
   static const int mode_env = getenv("VK_GEMM_MODE") ? atoi(getenv("VK_GEMM_MODE")) : 7;
   const int mode = mode_env == 7 ? 7 : 0;
   static const int reg_env = getenv("VK_GEMM_REGLIST") ? atoi(getenv("VK_GEMM_REGLIST")) : 1;
+#else
+  constexpr int ablate = 0, mode = 7, reg_env = 1;
+#endif
   const bool reg = reg_env && a.k <= (uint32_t)kRegCap;
   const void *fn = a.prepass && !ablate ? (a.bf16 ? (reg ? reinterpret_cast<const void *>(&flat_gemm_prepass_kernel<true, true>)
                                                           : reinterpret_cast<const void *>(&flat_gemm_prepass_kernel<false, true>))
                                                   : (reg ? reinterpret_cast<const void *>(&flat_gemm_prepass_kernel<true, false>)
                                                           : reinterpret_cast<const void *>(&flat_gemm_prepass_kernel<false, false>)))
+#ifdef VK_EXPERIMENTS
                  : ablate == 1 ? reinterpret_cast<const void *>(&flat_gemm_kernel<1, 7, false, false>)
                  : ablate == 2 ? reinterpret_cast<const void *>(&flat_gemm_kernel<2, 7, false, false>)
                  : ablate == 3 ? reinterpret_cast<const void *>(&flat_gemm_kernel<3, 7, false, false>)
                  : ablate == 4 ? reinterpret_cast<const void *>(&flat_gemm_kernel<4, 7, false, false>)
                  : ablate == 5 ? reinterpret_cast<const void *>(&flat_gemm_kernel<5, 7, false, false>)
+                 : mode != 7 && !a.bf16 ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, true, false>)
+                                               : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, false, false>))
+#endif
                  : a.bf16      ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true, true>)
                                       : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false, true>))
-                 : mode == 7   ? (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true, false>)
-                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false, false>))
-                               : (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, true, false>)
-                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 0, false, false>));
+                               : (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true, false>)
+                                      : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false, false>));
+  (void)mode;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   FlatGemmArgs args = a;

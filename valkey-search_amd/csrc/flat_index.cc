@@ -158,13 +158,23 @@ void CtxPool::release(SearchCtx *c) {
   cv_.notify_one();
 }
 
-Status upload_queries(SearchCtx *ctx, const float *queries, uint64_t nq, uint32_t dim, uint32_t stride_f) {
+Status upload_queries(SearchCtx *ctx, const float *queries, uint64_t nq, uint32_t dim, uint32_t stride_f, bool parallel,
+                      const float *const *query_tab) {
   size_t bytes = (size_t)nq * stride_f * 4;
   VK_TRY(ctx->h_q.ensure(bytes));
   VK_TRY(ctx->d_q.ensure(bytes));
   float *h = ctx->h_q.as<float>();
-  static const bool par_upload = !(getenv("VK_UPLOAD_PARALLEL") && atoi(getenv("VK_UPLOAD_PARALLEL")) == 0);
-  if (par_upload && stride_f == dim && bytes >= ((size_t)8 << 20)) {
+  if (query_tab) {
+    // one pointer per query (the dispatcher's batches: every query still lies in its caller's buffer) -- gathered straight
+    // into the pinned staging block, no intermediate copy
+    for (uint64_t q = 0; q < nq; ++q) {
+      memcpy(h + q * stride_f, query_tab[q], (size_t)dim * 4);
+      if (stride_f != dim) memset(h + q * stride_f + dim, 0, (size_t)(stride_f - dim) * 4);
+    }
+    VK_HIP_TRY(hipMemcpyAsync(ctx->d_q.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return Status::Ok();
+  }
+  if (parallel && stride_f == dim && bytes >= ((size_t)8 << 20)) {
     // a large batch (8192 x 768 queries = 25 MB): the copy into pinned memory, not the DMA, is what takes the time (3 ms on
     // one thread) -- four threads copy a quarter each and hand their pieces to the copy engine as they finish them
     const size_t piece = (size_t)2 << 20;
@@ -228,9 +238,10 @@ Status search_grouped_by_filter(Index *ix, const SearchRequest &rq, float *out_d
     D.resize(m * rq.k);
     L.resize(m * rq.k);
     N.resize(m);
-    for (uint64_t i = 0; i < m; ++i) memcpy(Q.data() + i * dim, rq.queries + idx[i] * dim, (size_t)dim * 4);
+    for (uint64_t i = 0; i < m; ++i) memcpy(Q.data() + i * dim, rq.query_tab ? rq.query_tab[idx[i]] : rq.queries + idx[i] * dim, (size_t)dim * 4);
     SearchRequest g = rq;
     g.queries = Q.data();
+    g.query_tab = nullptr;
     g.nq = m;
     g.allow_tab = nullptr;
     g.allow_nbits_tab = nullptr;
@@ -374,7 +385,7 @@ class FlatIndex final : public Index {
     CtxLease lease(pool_);
     SearchCtx *ctx = lease.ctx;
     filter_used_ = false;
-    VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f()));
+    VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f(), opt_.get(kOptUploadParallel) != 0, rq.query_tab));
     const uint64_t *d_allow = nullptr;
     VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
     if (k > kMaxPassK) return search_in_passes(ctx, rq, k, count, d_allow, out_dist, out_label, out_n);
@@ -527,6 +538,7 @@ class FlatIndex final : public Index {
     out->last_filter_fallback = last_filter_fallback_;
     (void)hipSetDevice(store_.device());
     pool_.for_each_free([&](SearchCtx *c) { for (auto &tp : c->timed) drain_timed(tp); });
+    // (with kernel-timing on the time covers exactly the batches counted; off: batches are still counted, the time stands still)
     out->filter_batches = filter_batches_;
     out->filter_kernel_ns = filter_ns_total_;
     return Status::Ok();
@@ -840,7 +852,7 @@ class FlatIndex final : public Index {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, tp.t0, tp.t1) == hipSuccess) {
       filter_ns_total_ += (uint64_t)((double)ms * 1e6);
-      filter_batches_ += 1;
+      filter_timed_ += 1;
     }
     tp.pending = false;
   }
@@ -866,9 +878,9 @@ class FlatIndex final : public Index {
       all = true;
     }
     const size_t tile_bytes = (size_t)((store_.alloc_rows() + RowStore::kRowSlack + 127) / 128) * 4;
-    if (d_tile_r2_.cap < tile_bytes) {   // (the per-tile table follows the row table's size)
-      VK_TRY(d_tile_r2_.ensure(tile_bytes));
-      VK_HIP_TRY(hipMemsetAsync(d_tile_r2_.p, 0, d_tile_r2_.cap, store_.stream()));
+    if (d_tile_norm_.cap < tile_bytes) {   // (the per-tile table follows the row table's size)
+      VK_TRY(d_tile_norm_.ensure(tile_bytes));
+      VK_HIP_TRY(hipMemsetAsync(d_tile_norm_.p, 0, d_tile_norm_.cap, store_.stream()));
       VK_HIP_TRY(hipMemsetAsync(d_rowstats_.p, 0, 64, store_.stream()));
       all = true;
     }
@@ -877,15 +889,31 @@ class FlatIndex final : public Index {
       all = true;
     }
     if (store_.take_written(&lo, &hi) || all) {
-      if (all) { lo = 0; hi = count_; }
+      // The tile norms and the bad-tile count only ever grow (atomicMax): rows that were overwritten or removed leave their
+      // old maxima behind -- valid bounds, but an index that once held long or non-finite rows would keep wide gates (or stay
+      // off this path) for ever.  Once the rows rewritten since the last full pass add up to a quarter of the index, start over.
+      rewritten_ += all ? 0 : hi - lo;
+      if (!all && rewritten_ * 4 > std::max<uint64_t>(count_, 1024)) {
+        VK_HIP_TRY(hipMemsetAsync(d_tile_norm_.p, 0, d_tile_norm_.cap, store_.stream()));
+        VK_HIP_TRY(hipMemsetAsync(d_rowstats_.p, 0, 64, store_.stream()));
+        all = true;
+      }
+      if (all) { lo = 0; hi = count_; rewritten_ = 0; }
       hi = std::min<uint64_t>(hi, store_.alloc_rows());
-      VK_HIP_TRY(launch_row_stats(store_.d_rows(), store_.bf16(), l2(), store_.stride_f(), (uint32_t)lo, (uint32_t)hi,
-                                  (uint32_t)((count_ + 127) / 128), d_rowstats_.as<uint32_t>(), d_tile_r2_.as<uint32_t>(),
-                                  l2() ? d_hn16_.as<uint32_t>() : nullptr, store_.stream()));
-      uint32_t h[3] = {0, 0, 0};
-      VK_HIP_TRY(hipMemcpyAsync(h, d_rowstats_.p, sizeof h, hipMemcpyDeviceToHost, store_.stream()));
-      VK_HIP_TRY(hipStreamSynchronize(store_.stream()));
-      filter_bad_tiles_.store(h[2], std::memory_order_relaxed);
+      Status st = [&]() -> Status {
+        VK_HIP_TRY(launch_row_stats(store_.d_rows(), store_.bf16(), l2(), store_.stride_f(), (uint32_t)lo, (uint32_t)hi,
+                                    (uint32_t)((count_ + 127) / 128), d_rowstats_.as<uint32_t>(), d_tile_norm_.as<uint32_t>(),
+                                    l2() ? d_hn16_.as<uint32_t>() : nullptr, store_.stream()));
+        uint32_t h[3] = {0, 0, 0};
+        VK_HIP_TRY(hipMemcpyAsync(h, d_rowstats_.p, sizeof h, hipMemcpyDeviceToHost, store_.stream()));
+        VK_HIP_TRY(hipStreamSynchronize(store_.stream()));
+        filter_bad_tiles_.store(h[2], std::memory_order_relaxed);
+        return Status::Ok();
+      }();
+      if (!st.ok()) {   // the range was consumed above: put it back, or the next search would gate with stale tile norms
+        store_.note_written(lo, hi);
+        return st;
+      }
     }
     return Status::Ok();
   }
@@ -936,19 +964,24 @@ class FlatIndex final : public Index {
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, store_.device());
       filter_blocks_ = cus > 0 ? (uint32_t)cus : 256;
     }
-    static const bool timing = getenv("VK_FILTER_TIMING") && atoi(getenv("VK_FILTER_TIMING")) != 0;
+#ifdef VK_EXPERIMENTS
+    // (the experiments build of the library only -- scripts/filter_ablate.py, scripts/build_experiments.sh: kernels whose
+    //  ANSWERS ARE INVALID, selected through the environment per launch; none of this exists in libvkindex.so)
+    const bool timing = getenv("VK_FILTER_TIMING") && atoi(getenv("VK_FILTER_TIMING")) != 0;
+    const bool filter_experiment = getenv("VK_FILTER_TIMING") || (getenv("VK_FILTER_ABLATE") && !getenv("VK_FILTER_ABLATE_DMA")) || getenv("VK_FAT_DBG") ||
+                                   (getenv("VK_FILTER_FAT") && atoi(getenv("VK_FILTER_FAT")) != 0);
+#else
+    constexpr bool filter_experiment = false;
+#endif
 
     FlatFilterArgs f{};
     f.rows = store_.d_rows();
     f.bf16 = store_.bf16() ? 1 : 0;
     f.l2 = l2() ? 1 : 0;
-    const bool bfmma_off = getenv("VK_FILTER_BF16_MFMA") && atoi(getenv("VK_FILTER_BF16_MFMA")) == 0;   // (A/B: the f16 kernels)
-    // (the experiment kernels -- phase timing, ablations, the four-fat-waves kernel -- are f16 kernels; read per call)
-    const bool filter_experiment = getenv("VK_FILTER_TIMING") || (getenv("VK_FILTER_ABLATE") && !getenv("VK_FILTER_ABLATE_DMA")) || getenv("VK_FAT_DBG") ||
-                                   (getenv("VK_FILTER_FAT") && atoi(getenv("VK_FILTER_FAT")) != 0);
-    f.qbf16 = (store_.bf16() && !l2() && !bfmma_off && !filter_experiment) ? 1 : 0;
-    f.dma = (f.qbf16 && !(getenv("VK_FILTER_DMA") && atoi(getenv("VK_FILTER_DMA")) == 0)) ? 1 : 0;   // (read per call: A/B)
-    f.bdma = (getenv("VK_FILTER_BDMA") && atoi(getenv("VK_FILTER_BDMA")) == 0) ? 0u : 1u;                // (read per call: A/B)
+    // final-pass variants behind the same gate (options, A/B): bf16 rows on the bf16 matrix cores, rows / B operands by DMA
+    f.qbf16 = (store_.bf16() && !l2() && opt_.get(kOptFilterBf16Mfma) != 0 && !filter_experiment) ? 1 : 0;
+    f.dma = (f.qbf16 && opt_.get(kOptFilterRowDma) != 0) ? 1 : 0;
+    f.bdma = opt_.get(kOptFilterBDma) != 0 ? 1u : 0u;
     f.hn16 = l2() ? d_hn16_.as<uint32_t>() : nullptr;
     f.labels = store_.d_labels();
     f.allow_bits = d_allow;
@@ -959,9 +992,9 @@ class FlatIndex final : public Index {
     f.qcoef = ctx->d_fthr.as<float4>();
     f.qbound = reinterpret_cast<float *>(ctx->d_fthr.as<char>() + (size_t)nqt * 32 * 16);
     f.qwit = f.qbound + (size_t)nqt * 32;
-    f.r2_cap = d_rowstats_.as<uint32_t>() + 3;
+    f.norm_cap = d_rowstats_.as<uint32_t>() + 3;
     f.sample_gap = gap;
-    f.tile_r2 = d_tile_r2_.as<uint32_t>();
+    f.tile_norm = d_tile_norm_.as<uint32_t>();
     f.cand_cnt = words + w_cnt;
     f.cand_row = ctx->d_fcand.as<uint32_t>();
     f.cap = cap;
@@ -1021,33 +1054,39 @@ class FlatIndex final : public Index {
       FlatFilterArgs fm = f;
       fm.mode = 0;
       fm.n_tiles = (uint32_t)((count + 127) / 128);
-      static const bool fat_dbg = getenv("VK_FAT_DBG") != nullptr;   // cycle counters of the four-fat-waves kernel
+#ifdef VK_EXPERIMENTS
+      const bool fat_dbg = getenv("VK_FAT_DBG") != nullptr;   // cycle counters of the four-fat-waves kernel
       fm.timing = timing && !l2() && !fat_dbg;
-      fm.prio = getenv("VK_FILTER_PRIO") ? (uint32_t)atoi(getenv("VK_FILTER_PRIO")) : 0u;   // (read per launch)
-      if (!l2() && getenv("VK_FILTER_ABLATE") && (!fm.qbf16 || fm.dma)) {   // (experiments, read per launch)
+      fm.fat = (getenv("VK_FILTER_FAT") && atoi(getenv("VK_FILTER_FAT")) != 0) ? 1u : 0u;
+      fm.prio = getenv("VK_FILTER_PRIO") ? (uint32_t)atoi(getenv("VK_FILTER_PRIO")) : 0u;
+      if (!l2() && getenv("VK_FILTER_ABLATE") && (!fm.qbf16 || fm.dma)) {
         fm.ablate_on = 1;
         fm.ablate = (uint32_t)atoi(getenv("VK_FILTER_ABLATE"));
       }
-      if (fat_dbg) {
+      if (fat_dbg || fm.timing) {   // phase timing experiments: up to nine counters
         VK_TRY(ctx->d_idx.ensure(128));
         VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
         fm.dbg = ctx->d_idx.as<unsigned long long>();
       }
-      if (fm.timing) {   // phase timing experiment: nine counters
-        VK_TRY(ctx->d_idx.ensure(128));
-        VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
-        fm.dbg = ctx->d_idx.as<unsigned long long>();
+#endif
+      filter_batches_.fetch_add(1, std::memory_order_relaxed);
+      // kernel-level timing of the final pass (option kernel-timing, off by default: bench.py's roofline figure)
+      SearchCtx::TimedPair *tp = nullptr;
+      if (opt_.get(kOptKernelTiming) != 0) {
+        tp = &ctx->timed[ctx->timed_next++ % 32];
+        drain_timed(*tp);
+        if (!tp->t0) {
+          VK_HIP_TRY(hipEventCreate(&tp->t0));
+          VK_HIP_TRY(hipEventCreate(&tp->t1));
+        }
+        VK_HIP_TRY(hipEventRecord(tp->t0, s));
       }
-      SearchCtx::TimedPair *tp = &ctx->timed[ctx->timed_next++ % 32];
-      drain_timed(*tp);
-      if (!tp->t0) {
-        VK_HIP_TRY(hipEventCreate(&tp->t0));
-        VK_HIP_TRY(hipEventCreate(&tp->t1));
-      }
-      VK_HIP_TRY(hipEventRecord(tp->t0, s));
       VK_TRY(filter_launches(fm, (uint32_t)std::min<uint64_t>(filter_blocks_, fm.n_tiles)));
-      VK_HIP_TRY(hipEventRecord(tp->t1, s));
-      tp->pending = true;
+      if (tp) {
+        VK_HIP_TRY(hipEventRecord(tp->t1, s));
+        tp->pending = true;
+      }
+#ifdef VK_EXPERIMENTS
       if (fat_dbg) {
         unsigned long long h[3];
         VK_HIP_TRY(hipStreamSynchronize(s));
@@ -1065,6 +1104,7 @@ class FlatIndex final : public Index {
                         "query producers issue+wait+store %.0f  barrier %.0f | consumers mfma %.0f  gate %.0f  barrier %.0f\n",
                 h[0] / w2, h[2] / w2, h[3] / w2, h[4] / w2, h[8] / w2, h[5] / w4, h[6] / w4, h[7] / w4);
       }
+#endif
     }
     // 3. exact re-rank of the survivors + selection
     {
@@ -1122,19 +1162,20 @@ class FlatIndex final : public Index {
     return Status::Ok();
   }
 
-  // candidate filter (K4h): switches and sizes
-  bool filter_enabled_ = !(getenv("VK_FLAT_FILTER") && atoi(getenv("VK_FLAT_FILTER")) == 0);
-  uint64_t filter_min_queries_ = getenv("VK_FILTER_MIN_QUERIES") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_QUERIES")) : 5;
-  uint64_t filter_min_rows_ = getenv("VK_FILTER_MIN_ROWS") ? (uint64_t)atoll(getenv("VK_FILTER_MIN_ROWS")) : 262144;
-  uint64_t filter_prepass_rows_ = getenv("VK_FILTER_PREPASS") ? (uint64_t)atoll(getenv("VK_FILTER_PREPASS")) : 262144;
-  uint64_t filter_cap_ = getenv("VK_FILTER_CAP") ? (uint64_t)atoll(getenv("VK_FILTER_CAP")) : 8192;
+  // candidate filter (K4h): switches and sizes -- run-time options (options.hpp), read with relaxed loads on the search path
+  OptRef filter_enabled_{&opt_, kOptFlatFilter};
+  OptRef filter_min_queries_{&opt_, kOptFilterMinQueries};
+  OptRef filter_min_rows_{&opt_, kOptFilterMinRows};
+  OptRef filter_prepass_rows_{&opt_, kOptFilterPrepassRows};
+  OptRef filter_cap_{&opt_, kOptFilterCap};
   // spill chunks (of kSpillChunk survivors) a batch's queries share beyond their private lists: 16 MB per context
-  uint32_t filter_spill_chunks_ = getenv("VK_FILTER_SPILL_CHUNKS") ? (uint32_t)atoi(getenv("VK_FILTER_SPILL_CHUNKS")) : 1024;
+  OptRef filter_spill_chunks_{&opt_, kOptFilterSpillChunks};
   uint32_t filter_blocks_ = 0;
-  DevBuf d_rowstats_, d_hn16_, d_tile_r2_;
+  DevBuf d_rowstats_, d_hn16_, d_tile_norm_;
   std::atomic<uint32_t> filter_bad_tiles_{0};   // tiles the f16 pipe cannot carry (row_stats_kernel)
   std::mutex stats_mu_;
-  std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0}, filter_ns_total_{0}, filter_batches_{0};
+  uint64_t rewritten_ = 0;                      // rows brought up to date since the last full pass (under stats_mu_)
+  std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0}, filter_ns_total_{0}, filter_batches_{0}, filter_timed_{0};
   static thread_local bool filter_used_;
   static constexpr uint64_t kGemmMinQueries = 5;    // measured at 10Mx768: K3 4 queries 5.3 ms, 8 queries 11.7 ms; K4 up to 32 queries 6.1 ms
   static constexpr uint64_t kMaxPassK = 1024;
@@ -1144,14 +1185,14 @@ class FlatIndex final : public Index {
   RowStore store_;
   CtxPool pool_;
   std::shared_mutex rw_;
-  // K4 lockstep window in row tiles (see FlatGemmArgs::lockstep); VK_GEMM_LOCKSTEP=0 turns it off
-  uint32_t gemm_lockstep_ = getenv("VK_GEMM_LOCKSTEP") ? (uint32_t)atoi(getenv("VK_GEMM_LOCKSTEP")) : 1;
+  // K4 lockstep window in row tiles (see FlatGemmArgs::lockstep); 0 turns it off
+  OptRef gemm_lockstep_{&opt_, kOptGemmLockstep};
   // floor of the row partitions of a K3 launch (blocks = partitions x query groups)
-  uint32_t scan_min_nrp_ = getenv("VK_SCAN_MIN_NRP") ? (uint32_t)atoi(getenv("VK_SCAN_MIN_NRP")) : 8;
-  uint64_t gemm_prepass_rows_ = getenv("VK_GEMM_PREPASS") ? (uint64_t)atoll(getenv("VK_GEMM_PREPASS")) : 16384;
+  OptRef scan_min_nrp_{&opt_, kOptScanMinNrp};
+  OptRef gemm_prepass_rows_{&opt_, kOptGemmPrepassRows};
   static thread_local bool in_prepass_;
-  uint32_t gemm_contig_ = getenv("VK_GEMM_CONTIG") ? (uint32_t)atoi(getenv("VK_GEMM_CONTIG")) : 1;
-  bool force_scan_ = getenv("VK_FLAT_FORCE_SCAN") != nullptr;   // A/B switch for benchmarks: VALU scan for every batch size
+  OptRef gemm_contig_{&opt_, kOptGemmContig};
+  OptRef force_scan_{&opt_, kOptFlatForceScan};   // A/B switch for benchmarks: VALU scan for every batch size
   std::unordered_map<uint64_t, uint32_t> slot_of_;  // dict_external_to_internal
   uint64_t count_ = 0;                               // cur_element_count_
   uint64_t capacity_;                                // data_->getCapacity()

@@ -660,12 +660,12 @@ int flat_scan_slots_per_lane(uint64_t k) {
 int flat_scan_pick_qb(uint64_t nq, uint32_t chunks, int e, bool l2) {
   // query block must fit LDS (<= 64 KiB so that two blocks share a CU) and, with wide
   // per-lane top-k state, registers
-  static const int qb_cap = getenv("VK_SCAN_QB") ? atoi(getenv("VK_SCAN_QB")) : 8;
+  static const int qb_cap = (int)VK_TUNE("VK_SCAN_QB", 8);
   int qb = nq >= 8 ? 8 : nq >= 4 ? 4 : nq >= 2 ? 2 : 1;
   if (qb > qb_cap) qb = qb_cap;
   // (occupancy decides here: with 8 row pieces in flight per lane, 8 queries per pass needed all 256 VGPRs for L2
   // -- one wave per SIMD, 798 QPS at 10Mx768 B=256; with 4 in flight it is 158 VGPRs, three waves, 2359 QPS)
-  static const int qb_l2 = getenv("VK_SCAN_QB_L2") ? atoi(getenv("VK_SCAN_QB_L2")) : 8;
+  static const int qb_l2 = (int)VK_TUNE("VK_SCAN_QB_L2", 8);
   if (l2 && qb > qb_l2) qb = qb_l2;
   if (e > 1) qb = qb > 2 ? 2 : qb;
   if (e > 4) qb = 1;
@@ -700,7 +700,7 @@ hipError_t launch_merge_topk(const MergeArgs &a_in, int e, uint64_t nq, hipStrea
   MergeArgs a = a_in;
   if (a.out_ld < a.k) a.out_ld = a.k;
   dim3 grid((uint32_t)nq);
-  static const bool select = !(getenv("VK_MERGE_SELECT") && atoi(getenv("VK_MERGE_SELECT")) == 0);
+  static const bool select = VK_TUNE("VK_MERGE_SELECT", 1) != 0;
   if (select && e == 1 && (uint64_t)a.parts * a.per_part <= kMergeSelectMax) {
     hipLaunchKernelGGL(merge_select_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();

@@ -145,7 +145,7 @@ class HnswIndex final : public Index {
       return Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
     CtxLease lease(pool_);
     SearchCtx *ctx = lease.ctx;
-    VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f()));
+    VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f(), opt_.get(kOptUploadParallel) != 0, rq.query_tab));
     const uint64_t *d_allow = nullptr;
     VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
     // one filter per query: every distinct bitmap goes to the device once, the kernel gets [nq] pointers and lengths
@@ -217,6 +217,8 @@ class HnswIndex final : public Index {
       const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out_n.as<char>() + st_off);
       last_n_eval_ = st[0];
       last_n_hops_ = st[1];
+      total_n_eval_.fetch_add(st[0], std::memory_order_relaxed);
+      total_n_hops_.fetch_add(st[1], std::memory_order_relaxed);
       last_overflow_ = st[2];
       last_redo_ = st[4];
       // (cannot happen: the LDS frontier holds at most 2*ef live entries, the graph-sized one every node)
@@ -336,6 +338,11 @@ class HnswIndex final : public Index {
     out->last_n_hops = last_n_hops_;
     out->last_frontier_redo = last_redo_;
     out->last_frontier_dropped = last_overflow_;
+    out->total_n_eval = total_n_eval_.load(std::memory_order_relaxed);
+    out->total_n_hops = total_n_hops_.load(std::memory_order_relaxed);
+    // what a tombstone keeps alive until the slot is reused: its row and its level-0 list, on the device and on the host
+    // (the reference adds the vector's bytes to reclaimable_memory at markDelete, hnswalg.h:1199)
+    out->tombstoned_bytes = out->deleted * ((uint64_t)store_.row_bytes() + (uint64_t)(2 * params_.m + 1) * 4);
     return Status::Ok();
   }
 
@@ -531,7 +538,7 @@ class HnswIndex final : public Index {
     const bool gpool = d_allow != nullptr || a.allow_tab != nullptr || pub_.deleted > 0 || ef > 2048;
     a.gpool_level = gpool ? 1 : 0;
     if (gpool)   // (a multiple of 128: the kernel keeps one minimum per 64 entries in the LDS words of the pool)
-      a.cand_cap = (uint32_t)std::min<uint64_t>(gpool_cap_, (std::max<uint64_t>(a.cand_cap, count) + 127) & ~(uint64_t)127);
+      a.cand_cap = (uint32_t)std::min<uint64_t>(gpool_cap(), (std::max<uint64_t>(a.cand_cap, count) + 127) & ~(uint64_t)127);
     bool redo = gpool && a.cand_cap < count;
     a.pool_g = gpool ? reinterpret_cast<float *>(8) : nullptr;   // (placeholder until the buffer is sized below)
     a.nbr_cap = (uint32_t)((graph_->maxM0() + 63) & ~(size_t)63);
@@ -697,7 +704,7 @@ class HnswIndex final : public Index {
       P = nP;
       first = nfirst;
     }
-    if (getenv("VK_HNSW_BUILD_VERBOSE"))
+    if (opt_.get(kOptHnswBuildVerbose))
       fprintf(stderr,
               "[vk] device build: %llu batches; register+flush %.2fs, beam search %.2fs, select+group+relink+gather %.2fs, "
               "host table update %.2fs, waiting for the host's upper-level linking %.2fs; beam-search pool overflows %llu, "
@@ -767,7 +774,7 @@ class HnswIndex final : public Index {
     }
     VK_TRY(launch(ctx, d_new, P, efc, efc, nullptr, 0, ctx->d_out_d.as<float>(), ctx->d_out_l.as<uint64_t>(),
                   ctx->d_out_n.as<uint32_t>(), s, true, true));
-    if (getenv("VK_HNSW_BUILD_VERBOSE")) {
+    if (opt_.get(kOptHnswBuildVerbose)) {
       unsigned long long st[4];
       VK_HIP_TRY(hipMemcpyAsync(st, ctx->d_stats.p, 32, hipMemcpyDeviceToHost, s));
       VK_HIP_TRY(hipStreamSynchronize(s));
@@ -901,29 +908,29 @@ class HnswIndex final : public Index {
   // batch size of the device build: min(count / build_frac_, build_max_batch_) -- the points of one batch
   // do not see one another, so a batch stays small relative to the graph it extends.  Measured
   // (100k x 128, recall@10 at ef=64): 1/8 of the graph per batch 0.9016, 1/32 0.9090, host build 0.9086.
-  uint64_t build_max_batch_ = getenv("VK_HNSW_BUILD_BATCH") ? (uint64_t)atoll(getenv("VK_HNSW_BUILD_BATCH")) : kDeviceBuildMaxBatch;
-  uint64_t build_min_graph_ = getenv("VK_HNSW_BUILD_MIN_GRAPH") ? (uint64_t)atoll(getenv("VK_HNSW_BUILD_MIN_GRAPH")) : kDeviceBuildMinGraph;
-  uint64_t build_min_batch_ = getenv("VK_HNSW_BUILD_MIN_BATCH") ? (uint64_t)atoll(getenv("VK_HNSW_BUILD_MIN_BATCH")) : 64;
-  uint64_t build_frac_ = getenv("VK_HNSW_BUILD_FRAC") ? (uint64_t)std::max(1, atoi(getenv("VK_HNSW_BUILD_FRAC"))) : 32;
-  uint64_t cand_floor_ = getenv("VK_HNSW_POOL_FLOOR") ? (uint64_t)atoll(getenv("VK_HNSW_POOL_FLOOR")) : 512;
+  OptRef build_max_batch_{&opt_, kOptHnswBuildBatch};
+  OptRef build_min_graph_{&opt_, kOptHnswBuildMinGraph};
+  OptRef build_min_batch_{&opt_, kOptHnswBuildMinBatch};
+  OptRef build_frac_{&opt_, kOptHnswBuildFrac};
+  OptRef cand_floor_{&opt_, kOptHnswPoolFloor};
   // cap of the first launch's HBM frontier (entries per wave, a multiple of 128) and the memory the second launch's
-  // graph-sized frontiers may take per context; VK_HNSW_GPOOL_CAP=128 forces the second launch on small test graphs
-  uint64_t gpool_cap_ = std::max<uint64_t>(128, (getenv("VK_HNSW_GPOOL_CAP") ? (uint64_t)atoll(getenv("VK_HNSW_GPOOL_CAP")) : 65536) & ~(uint64_t)127);
+  // graph-sized frontiers may take per context; hnsw-gpool-cap = 128 forces the second launch on small test graphs
+  uint64_t gpool_cap() const { return std::max<uint64_t>(128, opt_.get(kOptHnswGpoolCap) & ~(uint64_t)127); }
   // visited sets as hash tables: 0 never, 1 when it pays (default), 2 always (tests); table words per unit of ef; fixed size
-  uint32_t visited_hash_ = getenv("VK_HNSW_VISITED_HASH") ? (uint32_t)atoi(getenv("VK_HNSW_VISITED_HASH")) : 1;
-  uint64_t hash_per_ef_ = getenv("VK_HNSW_HASH_PER_EF") ? (uint64_t)atoll(getenv("VK_HNSW_HASH_PER_EF")) : 64;
-  uint32_t hash_log2_forced_ = getenv("VK_HNSW_HASH_LOG2") ? (uint32_t)atoi(getenv("VK_HNSW_HASH_LOG2")) : 0;
-  uint64_t pool_bytes_ = getenv("VK_HNSW_POOL_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_POOL_BYTES")) : ((uint64_t)4 << 30);
-  uint64_t visited_bytes_ = getenv("VK_HNSW_VISITED_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_VISITED_BYTES")) : ((uint64_t)4 << 30);
-  uint64_t redo_bytes_ = getenv("VK_HNSW_REDO_BYTES") ? (uint64_t)atoll(getenv("VK_HNSW_REDO_BYTES")) : ((uint64_t)2 << 30);
-  bool device_build_ = !(getenv("VK_HNSW_DEVICE_BUILD") && atoi(getenv("VK_HNSW_DEVICE_BUILD")) == 0);
+  OptRef visited_hash_{&opt_, kOptHnswVisitedHash};
+  OptRef hash_per_ef_{&opt_, kOptHnswHashPerEf};
+  OptRef hash_log2_forced_{&opt_, kOptHnswHashLog2};
+  OptRef pool_bytes_{&opt_, kOptHnswPoolBytes};
+  OptRef visited_bytes_{&opt_, kOptHnswVisitedBytes};
+  OptRef redo_bytes_{&opt_, kOptHnswRedoBytes};
+  OptRef device_build_{&opt_, kOptHnswDeviceBuild};
   RowStore store_;
   CtxPool pool_;
   std::unique_ptr<HnswGraph> graph_;
   std::shared_mutex rw_;
   std::mutex store_mu_;
   DevBuf d_links0_, d_upper_slot_, d_upper_pool_;
-  std::atomic<uint64_t> last_n_eval_{0}, last_n_hops_{0}, last_overflow_{0}, last_redo_{0};
+  std::atomic<uint64_t> last_n_eval_{0}, last_n_hops_{0}, last_overflow_{0}, last_redo_{0}, total_n_eval_{0}, total_n_hops_{0};
   static thread_local const uint64_t *const *tab_;
   static thread_local const uint64_t *tab_nbits_;
 };

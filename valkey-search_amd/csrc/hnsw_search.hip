@@ -796,7 +796,7 @@ static const void *hnsw_pick_e(bool l2, bool bf16, bool latency, int gpool, bool
 
 // a batch this small leaves most SIMDs without a wave: latency, not occupancy, is what counts
 static bool hnsw_latency_variant(const HnswSearchArgs &a) {
-  static const uint32_t max_nq = getenv("VK_HNSW_LATENCY_NQ") ? (uint32_t)atoll(getenv("VK_HNSW_LATENCY_NQ")) : 1024;   // (1M x 768, ef = 128, 1024 queries: 3.07 ms on the throughput kernel, 2.12 ms here)
+  static const uint32_t max_nq = (uint32_t)VK_TUNE("VK_HNSW_LATENCY_NQ", 1024);   // (1M x 768, ef = 128, 1024 queries: 3.07 ms on the throughput kernel, 2.12 ms here)
   return a.nq <= max_nq;
 }
 

@@ -15,6 +15,7 @@
 
 #include "../../include/vk_index.h"
 #include "kernels.hpp"
+#include "options.hpp"
 #include "row_store.hpp"
 
 namespace vk {
@@ -108,6 +109,9 @@ inline bool cancel_raised(const volatile int *flag) {
 
 struct SearchRequest {
   const float *queries = nullptr;   // host or device, [nq][dim] (host) / [nq][stride_f] padded (device)
+  // host entry points only: one pointer per query instead of `queries` (the dispatcher's batches are made of single-query
+  // calls whose vectors still lie in their callers' buffers; they are gathered straight into the pinned staging block)
+  const float *const *query_tab = nullptr;
   uint64_t nq = 0, k = 0, ef = 0;
   const uint64_t *allow_bits = nullptr;
   uint64_t allow_nbits = 0;
@@ -150,6 +154,7 @@ class Index {
   virtual uint32_t shard_count() const { return 0; }
   virtual Status shard_device_rows(uint32_t, uint64_t, void **, uint64_t *) { return Status::Err(VK_ERR_INVALID, "not a sharded index"); }
   virtual Status shard_commit_device_rows(uint32_t, uint64_t, const uint64_t *) { return Status::Err(VK_ERR_INVALID, "not a sharded index"); }
+  virtual Status shard_stats(uint32_t, vk_index_stats *) { return Status::Err(VK_ERR_INVALID, "not a sharded index"); }
   virtual Status distance(uint64_t label, const float *query, float *out) = 0;
   virtual Status get_row(uint64_t label, float *out) = 0;
   virtual Status contains(uint64_t label, bool *found) = 0;
@@ -157,10 +162,17 @@ class Index {
   virtual Status device_rows(uint64_t n, void **d_rows, uint64_t *stride_bytes) = 0;
   virtual Status commit_device_rows(uint64_t n, const uint64_t *labels) = 0;
   virtual Status save(vk_write_chunk_fn fn, void *user) = 0;
+  // run-time options (options.hpp): vk_index_set_option / vk_index_get_option; a sharded index forwards to its shards
+  virtual Status set_option(const char *name, uint64_t value) { return opt_.set(name, value); }
+  Status get_option(const char *name, uint64_t *out) const { return opt_.get(name, out); }
+  const Options &options() const { return opt_; }
 
  protected:
-  explicit Index(const vk_index_params &p) : params_(p) {}
+  explicit Index(const vk_index_params &p) : params_(p) {
+    if (p.shard_ef_pct) opt_.set(kOptShardEfPct, p.shard_ef_pct);
+  }
   vk_index_params params_;
+  Options opt_;
 };
 
 Status create_sharded(const vk_index_params &p, std::unique_ptr<Index> *out);
@@ -172,7 +184,9 @@ Status load_hnsw(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std:
 
 // shared helpers --------------------------------------------------------------------
 // pad nq host queries of `dim` floats into ctx->h_q ([nq][stride_f]) and copy to ctx->d_q
-Status upload_queries(SearchCtx *ctx, const float *queries, uint64_t nq, uint32_t dim, uint32_t stride_f);
+// (query_tab != nullptr: one host pointer per query instead of the contiguous block; parallel: large blocks copied by four threads)
+Status upload_queries(SearchCtx *ctx, const float *queries, uint64_t nq, uint32_t dim, uint32_t stride_f, bool parallel = true,
+                      const float *const *query_tab = nullptr);
 Status upload_allow(SearchCtx *ctx, const uint64_t *allow_bits, uint64_t allow_nbits, const uint64_t **d_allow);
 // an index without per-query filters in its kernels: the batch split into runs of queries that share a bitmap
 Status search_grouped_by_filter(Index *ix, const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n);

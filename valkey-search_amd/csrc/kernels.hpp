@@ -3,6 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// A/B constants of the launchers: fixed in the product library; the -DVK_EXPERIMENTS build (csrc/Makefile `experiments`)
+// reads them from the environment once so that scripts/ can sweep them.
+#ifdef VK_EXPERIMENTS
+#include <stdlib.h>
+#define VK_TUNE(env, dflt) (getenv(env) ? atoll(getenv(env)) : (long long)(dflt))
+#else
+#define VK_TUNE(env, dflt) ((long long)(dflt))
+#endif
+
 namespace vk {
 
 // K3: FLAT scan over rows [row_begin,row_end) for nq queries.
@@ -107,7 +116,7 @@ struct FlatFilterArgs {
   // per 128-row tile (row_stats_kernel): the largest row NORM of the tile as f32 bits, rounded up; +inf for a tile with
   // a value the f16 pipe cannot carry (non-finite, beyond 32768, half norm beyond f16 for L2): every pair of such a
   // tile survives and is settled by the exact re-rank
-  const uint32_t *tile_r2;
+  const uint32_t *tile_norm;
   uint32_t *cand_cnt;         // [nq] survivors per query (zeroed by qprep; may exceed what was stored)
   uint32_t *cand_row;         // [nq][cap] their row slots ...
   uint32_t cap;
@@ -127,20 +136,24 @@ struct FlatFilterArgs {
   // The sample is made of n_tiles "sample tiles" of 128 rows spread over the WHOLE index: a sample tile is 16 (bf16
   // rows: 8) runs of 8 (16) rows sample_gap apart, the runs n_tiles * 8 * sample_gap rows apart (sample_row() in
   // flat_filter.hip), so index neighbours beyond a run land in different sample tiles, hence in different groups -- a
-  // narrow stretch of similar rows (an index loaded cluster by cluster) still puts k of its rows into k distinct groups.  Witness rows carry the margin of the norm cap *r2_cap (row_stats: a robust upper norm
+  // narrow stretch of similar rows (an index loaded cluster by cluster) still puts k of its rows into k distinct groups.  Witness rows carry the margin of the norm cap *norm_cap (row_stats: a robust upper norm
   // of the index's tiles); a row from a tile beyond the cap is no witness (the producers poison it with a NaN, which
   // the group maximum ignores).  qwit[j] = the column's margin at the cap (qprep).
   uint32_t sample_gap;
-  const uint32_t *r2_cap;
+  const uint32_t *norm_cap;
   float *qwit;
   uint32_t n_tiles;           // tiles this launch walks (mode 0: ceil(n_rows / 128); mode 1: sample tiles)
   uint32_t row_stride_f, n_rows, nq;
   uint32_t nqt;               // query tiles of 32 (<= 8 per launch)
   const uint32_t *cancel;
+#ifdef VK_EXPERIMENTS
+  // the -DVK_EXPERIMENTS build only (csrc/Makefile `experiments`): kernels whose answers are INVALID, for timing
   uint32_t timing;            // VK_FILTER_TIMING=1: the kernel variant with cycle counters per phase (f32 rows, IP only)
   unsigned long long *dbg;    // timing: [9] cycles per phase, summed over the waves (see the kernel)
   uint32_t prio;              // wave priorities of the three roles, 2 bits each (rows | queries << 2 | consumers << 4)
-  uint32_t ablate_on, ablate; // VK_FILTER_ABLATE (experiments): pieces of the pipeline switched off, see flat_filter_body
+  uint32_t ablate_on, ablate; // VK_FILTER_ABLATE: pieces of the pipeline switched off, see flat_filter_body
+  uint32_t fat;               // VK_FILTER_FAT=1: the four-fat-waves kernel (256-row tiles)
+#endif
 };
 // bound selection: qbound[q] = the k-th largest of smax[q][0 .. groups) (-inf when fewer than k are finite)
 struct FlatBoundArgs {
@@ -150,10 +163,11 @@ struct FlatBoundArgs {
 };
 size_t flat_filter_lds_bytes();
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2);
-// stats: [0] largest |row|^2, [1] largest |element| of the index (f32 bits), [2] tiles flagged +inf so far, [3] the norm
-// cap of the sample's witnesses: |row|^2 bits that 97 % of the finite tiles stay below (recomputed over n_tiles tiles)
+// stats: [0] largest |row|^2 (SQUARED, reported only), [1] largest |element| of the index (f32 bits), [2] tiles flagged +inf
+// so far, [3] the norm cap of the sample's witnesses: the NORM |row| (f32 bits, same unit as tile_norm) that 97 % of the finite
+// tiles stay below (recomputed over n_tiles tiles)
 hipError_t launch_row_stats(const void *rows, bool bf16, bool l2, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t n_tiles,
-                            uint32_t *stats, uint32_t *tile_r2, uint32_t *hn16, hipStream_t s);
+                            uint32_t *stats, uint32_t *tile_norm, uint32_t *hn16, hipStream_t s);
 hipError_t launch_flat_bound_select(const FlatBoundArgs &a, hipStream_t s);
 constexpr uint32_t kFilterMaxGroups = 16384;   // group bounds per query the selection holds in registers (8192 sample tiles)
 hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s);

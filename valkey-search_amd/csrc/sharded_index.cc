@@ -137,6 +137,13 @@ class ShardedIndex final : public Index {
   ShardedIndex(const vk_index_params &p, std::vector<int> devices)
       : Index(p), devices_(std::move(devices)), counts_(devices_.size(), 0), capacity_(p.initial_cap) {}
 
+  // an option applies to the sharded index and to every shard (kernel selection and scratch budgets live in the shards)
+  Status set_option(const char *name, uint64_t value) override {
+    VK_TRY(opt_.set(name, value));
+    for (auto &s : shards_) VK_TRY(s->set_option(name, value));
+    return Status::Ok();
+  }
+
   Status init() {
     const size_t S = devices_.size();
     for (size_t s = 0; s < S; ++s) {
@@ -155,7 +162,7 @@ class ShardedIndex final : public Index {
     // share it only queue up behind each other (8 logical shards on one GPU: 330 us enqueued one after the other from one
     // thread, 230-620 us from eight threads); across devices the enqueueing does run side by side.  The caller's thread
     // takes the serving device's shards.
-    static const bool threads_on = !(getenv("VK_SHARD_THREADS") && atoi(getenv("VK_SHARD_THREADS")) == 0);
+    const bool threads_on = opt_.get(kOptShardThreads) != 0;
     for (size_t s = 0; s < S; ++s) {
       size_t gi = 0;
       for (; gi < dev_groups_.size(); ++gi)
@@ -323,6 +330,14 @@ class ShardedIndex final : public Index {
   // ---- queries --------------------------------------------------------------------------------------
   Status search(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) override {
     if (rq.nq == 0) return Status::Ok();
+    if (rq.query_tab) {   // (the dispatcher's batches: one pointer per query) -> one block, as the fan-out uploads it
+      std::vector<float> Q((size_t)rq.nq * params_.dim);
+      for (uint64_t q = 0; q < rq.nq; ++q) memcpy(Q.data() + q * params_.dim, rq.query_tab[q], (size_t)params_.dim * 4);
+      SearchRequest g = rq;
+      g.queries = Q.data();
+      g.query_tab = nullptr;
+      return search(g, out_dist, out_label, out_n);
+    }
     if (rq.allow_tab) return search_grouped_by_filter(this, rq, out_dist, out_label, out_n);
     if (rq.k == 0) {
       for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
@@ -476,6 +491,9 @@ class ShardedIndex final : public Index {
       out->filter_kernel_ns = std::max(out->filter_kernel_ns, t.filter_kernel_ns);
       out->last_n_eval += t.last_n_eval;
       out->last_n_hops += t.last_n_hops;
+      out->total_n_eval += t.total_n_eval;
+      out->total_n_hops += t.total_n_hops;
+      out->tombstoned_bytes += t.tombstoned_bytes;
     }
     out->fanout_calls = fanout_calls_.load(std::memory_order_relaxed);
     out->fanout_enqueue_ns = fanout_ns_.load(std::memory_order_relaxed);
@@ -483,6 +501,13 @@ class ShardedIndex final : public Index {
     out->capacity = capacity_;
     out->host_bytes += route_.size() * 24;
     return Status::Ok();
+  }
+
+  // one shard's own statistics (bench.py: the slowest shard's kernel time per launch is max over shards of a shard's
+  // delta of filter_kernel_ns over its delta of filter_batches -- not a difference of maxima)
+  Status shard_stats(uint32_t s, vk_index_stats *out) override {
+    if (s >= shards_.size()) return Status::Err(VK_ERR_INVALID, "shard out of range");
+    return shards_[s]->stats(out);
   }
 
   Status device_rows(uint64_t, void **, uint64_t *) override {
@@ -637,10 +662,12 @@ class ShardedIndex final : public Index {
     VK_HIP_TRY(hipStreamWaitEvent(l.stream, mc->ready, 0));
     SearchRequest srq = rq;
     srq.cancel_flag = nullptr;
-    if (params_.algo == VK_ALGO_HNSW && params_.shard_ef_pct != 0 && params_.shard_ef_pct != 100) {
-      // per-shard ef policy (vk_index_params.shard_ef_pct): a fraction of the ef one graph over all rows would be given
+    const uint64_t ef_pct = opt_.get(kOptShardEfPct);
+    if (params_.algo == VK_ALGO_HNSW && ef_pct != 100) {
+      // per-shard ef policy (option shard-ef-pct, initialised from vk_index_params.shard_ef_pct): a fraction of the ef one
+      // graph over all rows would be given
       uint64_t ef = rq.ef ? rq.ef : (params_.ef_runtime ? params_.ef_runtime : 10);
-      ef = (ef * params_.shard_ef_pct + 99) / 100;
+      ef = (ef * ef_pct + 99) / 100;
       srq.ef = std::max<uint64_t>(std::max<uint64_t>(ef, rq.k), 1);
     }
     float *od = mc->d_all_d.as<float>() + s * nk;

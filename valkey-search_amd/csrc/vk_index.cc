@@ -8,12 +8,42 @@
 #include <memory>
 #include <string>
 
-#include "coalescer.hpp"
+#include <atomic>
+#include <chrono>
+
+#include "dispatcher.hpp"
 #include "index.hpp"
+
+// cumulative counters behind vk_index_stats (INFO fields and metrics of the adaptor: vector_base.cc:385-409,
+// metrics.h:40-50,75-80, latency samples search.cc:149,160)
+struct VkCounters {
+  std::atomic<uint64_t> searches{0}, calls{0}, lat_sum_ns{0};
+  std::atomic<uint64_t> errors[VK_STATUS_COUNT];
+  std::atomic<uint64_t> hist[16];
+  VkCounters() {
+    for (auto &e : errors) e.store(0);
+    for (auto &h : hist) h.store(0);
+  }
+  // one search call answering nq queries after ns nanoseconds with status code
+  void record(uint64_t nq, int code, uint64_t ns) {
+    calls.fetch_add(1, std::memory_order_relaxed);
+    if (code != VK_OK) {
+      errors[code < VK_STATUS_COUNT ? code : VK_ERR_INTERNAL].fetch_add(1, std::memory_order_relaxed);
+      return;
+    }
+    searches.fetch_add(nq, std::memory_order_relaxed);
+    lat_sum_ns.fetch_add(ns * nq, std::memory_order_relaxed);
+    const uint64_t us = ns / 1000;
+    int b = 0;
+    while (b < 15 && us >= ((uint64_t)64 << b)) ++b;
+    hist[b].fetch_add(nq, std::memory_order_relaxed);
+  }
+};
 
 struct vk_index {
   std::unique_ptr<vk::Index> impl;
-  vk::Coalescer coalescer;
+  VkCounters counters;
+  std::unique_ptr<vk::Dispatcher> dispatcher;   // (declared after impl: destroyed first, while the index is still there)
 };
 
 namespace {
@@ -40,6 +70,24 @@ int guarded(F &&f) {
   }
 }
 
+// a search entry point: status + the cumulative counters
+template <class F>
+int counted(vk_index *ix, uint64_t nq, F &&f) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = guarded(f);
+  const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  ix->counters.record(nq, rc, ns);
+  return rc;
+}
+
+// the serving options live in the dispatcher
+void sync_dispatcher(vk_index *ix) {
+  const vk::Options &o = ix->impl->options();
+  ix->dispatcher->configure((uint32_t)o.get(vk::kOptCoalesceMaxBatch), (uint32_t)o.get(vk::kOptCoalesceMaxWaitUs));
+  ix->dispatcher->set_in_flight((uint32_t)o.get(vk::kOptBatchesInFlight));
+  ix->dispatcher->set_queue_depth(o.get(vk::kOptMaxQueryQueueDepth));
+}
+
 vk::Status check_params(const vk_index_params *p) {
   if (!p) return vk::Status::Err(VK_ERR_INVALID, "params is NULL");
   if (p->struct_size != sizeof(vk_index_params)) return vk::Status::Err(VK_ERR_INVALID, "vk_index_params.struct_size mismatch");
@@ -50,6 +98,8 @@ vk::Status check_params(const vk_index_params *p) {
   if (p->initial_cap >= (1ull << 32)) return vk::Status::Err(VK_ERR_INVALID, "initial_cap out of range");
   if (p->algo == VK_ALGO_HNSW && (p->m < 2 || p->m > 10000)) return vk::Status::Err(VK_ERR_INVALID, "M out of range");
   if (p->n_shards > VK_MAX_SHARDS) return vk::Status::Err(VK_ERR_INVALID, "n_shards out of range");
+  if (p->shard_ef_pct > 1000) return vk::Status::Err(VK_ERR_INVALID, "shard_ef_pct out of range (0 = 100, at most 1000)");
+  if (p->load_skip_validation > 1) return vk::Status::Err(VK_ERR_INVALID, "load_skip_validation must be 0 or 1");
   return vk::Status::Ok();
 }
 }  // namespace
@@ -75,6 +125,8 @@ int vk_index_create(const vk_index_params *params, vk_index **out) {
     else VK_TRY(vk::create_hnsw(*params, &impl));
     *out = new vk_index;
     (*out)->impl = std::move(impl);
+    (*out)->dispatcher = std::make_unique<vk::Dispatcher>((*out)->impl.get());
+    sync_dispatcher(*out);
     return vk::Status::Ok();
   });
 }
@@ -128,7 +180,7 @@ int vk_index_search_batch(vk_index *ix, const void *queries, uint64_t nq, uint64
   VK_NEED(ix);
   if (nq && (!queries || !out_n)) return fail(VK_ERR_INVALID, "queries/out_n is NULL");
   if (nq && k && (!out_dist || !out_label)) return fail(VK_ERR_INVALID, "output buffers are NULL");
-  return guarded([&] {
+  return counted(ix, nq, [&] {
     vk::SearchRequest rq;
     rq.queries = static_cast<const float *>(queries);
     rq.nq = nq;
@@ -150,7 +202,7 @@ int vk_index_search_batch_filters(vk_index *ix, const void *queries, uint64_t nq
   if (nq && (!queries || !out_n)) return fail(VK_ERR_INVALID, "queries/out_n is NULL");
   if (nq && k && (!out_dist || !out_label)) return fail(VK_ERR_INVALID, "output buffers are NULL");
   if (nq && allow_bits_tab && !allow_nbits_tab) return fail(VK_ERR_INVALID, "allow_nbits_tab is NULL");
-  return guarded([&] {
+  return counted(ix, nq, [&] {
     vk::SearchRequest rq;
     rq.queries = static_cast<const float *>(queries);
     rq.nq = nq;
@@ -164,22 +216,60 @@ int vk_index_search_batch_filters(vk_index *ix, const void *queries, uint64_t nq
   });
 }
 
+// A FLAT index serves one scan per distinct allow-bitmap (search_grouped_by_filter): N filtered callers in one batch
+// would each wait for N serial scans run by one runner, where N separate calls run concurrently on the index's search
+// contexts.  Batching of filtered calls is therefore HNSW-only (one launch, a bitmap per query).
+static bool flat_filtered(vk_index *ix, const uint64_t *allow_bits) {
+  return allow_bits && ix->impl->params().algo == VK_ALGO_FLAT;
+}
+
 int vk_index_search(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, const uint64_t *allow_bits,
                     uint64_t allow_nbits, const volatile int *cancel_flag, int partial_ok, float *out_dist,
                     uint64_t *out_label, uint64_t *out_n) {
-  // A FLAT index serves one scan per distinct allow-bitmap (FlatIndex::search_grouped_by_filter): N filtered callers in
-  // one batch would each wait for N serial scans run by the leader, where N separate calls run concurrently on the
-  // index's search contexts.  Coalescing of filtered calls is therefore HNSW-only (one launch, a bitmap per query).
-  const bool flat_filtered = ix && ix->impl && allow_bits && ix->impl->params().algo == VK_ALGO_FLAT;
-  if (ix && ix->impl && ix->coalescer.enabled() && k && !flat_filtered && !vk::cancel_raised(cancel_flag)) {
+  if (ix && ix->impl && ix->dispatcher->enabled() && k && !flat_filtered(ix, allow_bits) && !vk::cancel_raised(cancel_flag)) {
     if (!query || !out_n || !out_dist || !out_label) return fail(VK_ERR_INVALID, "NULL argument");
-    return guarded([&] {
-      return ix->coalescer.search(ix->impl.get(), static_cast<const float *>(query), k, ef_runtime, allow_bits, allow_nbits,
-                                  cancel_flag, partial_ok != 0, out_dist, out_label, out_n);
+    return counted(ix, 1, [&] {
+      return ix->dispatcher->search(static_cast<const float *>(query), k, ef_runtime, allow_bits, allow_nbits, cancel_flag,
+                                    partial_ok != 0, out_dist, out_label, out_n);
     });
   }
   return vk_index_search_batch(ix, query, 1, k, ef_runtime, allow_bits, allow_nbits, cancel_flag, partial_ok,
                                out_dist, out_label, out_n);
+}
+
+namespace {
+// completion of a submitted request: the caller's callback behind the counters
+struct SubmitCtx {
+  vk_index *ix;
+  vk_search_done_fn done;
+  void *user;
+  std::chrono::steady_clock::time_point t0;
+};
+void submit_done(void *p, int status) {
+  SubmitCtx *c = static_cast<SubmitCtx *>(p);
+  const uint64_t ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c->t0).count();
+  c->ix->counters.record(1, status, ns);
+  vk_search_done_fn done = c->done;
+  void *user = c->user;
+  delete c;
+  done(user, status);
+}
+}  // namespace
+
+int vk_index_search_submit(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, const uint64_t *allow_bits,
+                           uint64_t allow_nbits, const volatile int *cancel_flag, int partial_ok, float *out_dist,
+                           uint64_t *out_label, uint64_t *out_n, vk_search_done_fn done, void *user) {
+  VK_NEED(ix);
+  if (!query || !out_n || !out_dist || !out_label || !done) return fail(VK_ERR_INVALID, "NULL argument");
+  if (k == 0) return fail(VK_ERR_INVALID, "k must be positive");
+  if (!ix->dispatcher->enabled()) return fail(VK_ERR_INVALID, "vk_index_search_submit needs coalescing (vk_index_set_coalescing with max_batch > 1)");
+  return guarded([&]() -> vk::Status {
+    SubmitCtx *c = new SubmitCtx{ix, done, user, std::chrono::steady_clock::now()};
+    vk::Status st = ix->dispatcher->submit(static_cast<const float *>(query), k, ef_runtime, allow_bits, allow_nbits, cancel_flag,
+                                           partial_ok != 0, out_dist, out_label, out_n, submit_done, c);
+    if (!st.ok()) delete c;   // (not queued: the callback will not fire)
+    return st;
+  });
 }
 
 int vk_index_search_batch_device(vk_index *ix, const void *d_queries, uint64_t nq, uint64_t k, uint64_t ef_runtime,
@@ -187,7 +277,9 @@ int vk_index_search_batch_device(vk_index *ix, const void *d_queries, uint64_t n
                                  uint64_t *d_out_label, uint32_t *d_out_n, void *hip_stream) {
   VK_NEED(ix);
   if (nq && (!d_queries || !d_out_dist || !d_out_label || !d_out_n)) return fail(VK_ERR_INVALID, "device buffers are NULL");
-  return guarded([&] {
+  return guarded([&] {   // (device-buffer calls return with the work in flight: no latency to record; counted as calls)
+    ix->counters.calls.fetch_add(1, std::memory_order_relaxed);
+    ix->counters.searches.fetch_add(nq, std::memory_order_relaxed);
     vk::SearchRequest rq;
     rq.queries = static_cast<const float *>(d_queries);
     rq.nq = nq;
@@ -236,17 +328,54 @@ int vk_index_get_stats(vk_index *ix, vk_index_stats *out) {
   if (!out) return fail(VK_ERR_INVALID, "out is NULL");
   return guarded([&] {
     vk::Status s = ix->impl->stats(out);
-    out->coalesced_batches = ix->coalescer.batches();
-    out->coalesced_queries = ix->coalescer.queries();
+    const vk::Dispatcher &d = *ix->dispatcher;
+    out->coalesced_batches = d.batches();
+    out->coalesced_queries = d.queries();
+    out->submitted = d.submitted();
+    out->rejected = d.rejected();
+    out->queued_now = d.queued();
+    out->max_batches_in_flight = d.max_in_flight_seen();
+    const VkCounters &c = ix->counters;
+    out->searches = c.searches.load(std::memory_order_relaxed);
+    out->search_calls = c.calls.load(std::memory_order_relaxed);
+    for (int i = 0; i < VK_STATUS_COUNT; ++i) out->search_errors[i] = c.errors[i].load(std::memory_order_relaxed);
+    for (int i = 0; i < 16; ++i) out->latency_hist[i] = c.hist[i].load(std::memory_order_relaxed);
+    out->latency_sum_ns = c.lat_sum_ns.load(std::memory_order_relaxed);
     return s;
   });
 }
 
+int vk_index_shard_stats(vk_index *ix, uint32_t shard, vk_index_stats *out) {
+  VK_NEED(ix);
+  if (!out) return fail(VK_ERR_INVALID, "out is NULL");
+  return guarded([&] { return ix->impl->shard_stats(shard, out); });
+}
+
 int vk_index_set_coalescing(vk_index *ix, uint32_t max_batch, uint32_t max_wait_us) {
   VK_NEED(ix);
-  if (max_batch > 4096) return fail(VK_ERR_INVALID, "max_batch out of range");
-  ix->coalescer.configure(max_batch, max_wait_us);
-  return VK_OK;
+  if (max_batch > 16384) return fail(VK_ERR_INVALID, "max_batch out of range");
+  return guarded([&]() -> vk::Status {
+    VK_TRY(ix->impl->set_option("coalesce-max-batch", max_batch));
+    VK_TRY(ix->impl->set_option("coalesce-max-wait-us", max_wait_us));
+    sync_dispatcher(ix);
+    return vk::Status::Ok();
+  });
+}
+
+int vk_index_set_option(vk_index *ix, const char *name, uint64_t value) {
+  VK_NEED(ix);
+  if (!name) return fail(VK_ERR_INVALID, "name is NULL");
+  return guarded([&]() -> vk::Status {
+    VK_TRY(ix->impl->set_option(name, value));
+    sync_dispatcher(ix);
+    return vk::Status::Ok();
+  });
+}
+
+int vk_index_get_option(vk_index *ix, const char *name, uint64_t *out_value) {
+  VK_NEED(ix);
+  if (!name || !out_value) return fail(VK_ERR_INVALID, "NULL argument");
+  return guarded([&] { return ix->impl->get_option(name, out_value); });
 }
 
 int vk_index_device_rows(vk_index *ix, uint64_t n_rows, void **d_rows, uint64_t *row_stride_bytes) {
@@ -319,6 +448,8 @@ int vk_index_load(const vk_index_params *params, vk_read_chunk_fn read_chunk, vo
     else VK_TRY(vk::load_hnsw(*params, read_chunk, user, &impl));
     *out = new vk_index;
     (*out)->impl = std::move(impl);
+    (*out)->dispatcher = std::make_unique<vk::Dispatcher>((*out)->impl.get());
+    sync_dispatcher(*out);
     return vk::Status::Ok();
   });
 }
