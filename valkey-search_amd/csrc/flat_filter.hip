@@ -49,7 +49,7 @@
 //            of three stages, no registers and no LDS store instructions in between (kBDma)
 // so HBM traffic is the row bytes and L2 traffic twice that (PMC: TCC misses 30.8 GB, hits 30.8 GB per launch).
 // bf16 rows in the inner-product space (kBfMma, kDma): rows and queries stay bf16, the bf16 matrix-core instruction
-// multiplies (query rounding 2^-9 in the margin), and the ROWS go HBM -> LDS by DMA (swizzled 128-B rows, ring of five).
+// multiplies (query rounding 2^-8 in the margin), and the ROWS go HBM -> LDS by DMA (swizzled 128-B rows, ring of five).
 // Roofline: HBM (30.72 GB per launch at 10M x 768 f32).  The matrix cores: 3.9 PFLOP of f16 per launch; their stream alone
 // (no operands fetched, no gate) takes 2.3-2.4 ms of a 5.1-5.2 ms launch at the clock the chip sustains under it --
 // scripts/filter_ablate.py and DESIGN.md section 5 have the whole ablation matrix (VK_FILTER_ABLATE below).
@@ -235,8 +235,10 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
     // see the header: relative part, absolute (subnormal) part, the reference's own rounding, 1 - dot (2^-23 (1 + R |q|)
     // covers both sides' 2^-24 max(1, |dist|)); everything rounded up by 1.001
     // (bf16 rows convert to f16 exactly; on the bf16 matrix-core path the rows are not converted at all and the query is
-    //  rounded to bf16: 2^-9 relative per element)
-    const float rel = (a.qbf16 ? 0x1p-9f : a.bf16 ? 0x1p-11f : 0x1p-10f) + 0x1p-22f + D * 0x1p-22f + (D / 16.f + 5.f) * 0x1p-24f;
+    //  rounded to bf16 -- 8 significant bits, unit roundoff 2^-8 per element.  r03 had 2^-9 here: half the true bound,
+    //  found by the margin audit on queries at bf16 rounding midpoints, tests/helpers/exp_margin_check.py: |approx - exact|
+    //  reached 1.31 E)
+    const float rel = (a.qbf16 ? 0x1p-8f : a.bf16 ? 0x1p-11f : 0x1p-10f) + 0x1p-22f + D * 0x1p-22f + (D / 16.f + 5.f) * 0x1p-24f;
     const float sub = 0x1.01p-25f * sqrtf(D);
     float c2 = 0.f, c1 = (qn * rel + sub + 0x1p-23f * qn) * 1.001f, c0 = (sub * qn + 0x1p-23f) * 1.001f;
     if (a.l2) {
@@ -388,6 +390,21 @@ template <int kRt, bool kZero>
 __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&acc)[kRt], float thr, uint32_t tile_row0,
                                             uint32_t wave, uint32_t li, uint32_t g, SurvivorRing &ring, uint32_t lane) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef VK_EXPERIMENTS
+  if (a.dump_scores != nullptr && tile_row0 < a.dump_rows) {   // margin audit: what this gate sees, for the test to judge
+    const uint32_t q = wave * 32 + li;
+    if (q < a.nq && q < a.dump_ld) {
+#pragma unroll
+      for (int rt = 0; rt < kRt; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t row = tile_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (row < a.dump_rows) a.dump_scores[(size_t)row * a.dump_ld + q] = acc[rt][r];
+        }
+      if (g == 0) a.dump_thr[(size_t)(tile_row0 / 128u) * a.dump_ld + q] = thr;
+    }
+  }
+#endif
 #pragma unroll
   for (int rt = 0; rt < kRt; ++rt) {
     // (fmaxf drops NaNs; they only occur in a tile outside f16, whose thr is -inf: "not below" then holds for any m)
@@ -647,7 +664,7 @@ template <bool kBfMma> __device__ __forceinline__ f32x16 ws_mfma(f16x8 x, f16x8 
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
 }
 // kBfMma (bf16 rows, inner-product space): rows and queries stay bf16 -- no conversion on the way into LDS, the bf16
-// matrix-core instruction, a query rounding of 2^-9 in the margin (flat_qprep_kernel)
+// matrix-core instruction, a query rounding of 2^-8 in the margin (flat_qprep_kernel)
 // kDma (with kBfMma, final pass): the rows go HBM -> LDS directly (buffer_load ... lds), no registers and no LDS store
 // instructions in between.  A stage is 128 rows x 128 B without padding; the 16-byte piece c of row r sits at piece
 // c ^ ((r >> 1) & 7) of the row (the DMA writes a wave's 64 x 16 B to consecutive LDS bytes, so the swizzle is applied to

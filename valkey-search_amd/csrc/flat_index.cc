@@ -295,6 +295,22 @@ Status Index::search_labels(const float *query, uint64_t k, const uint64_t *labe
   return Status::Ok();
 }
 
+#ifdef VK_EXPERIMENTS
+// margin audit of the candidate filter (experiments build only; tests/helpers/exp_margin_check.py): device buffers the
+// final pass of every FLAT index of the process dumps its gate's view into.  Process-wide on purpose -- one test, one index.
+struct ExpFilterDump { float *scores = nullptr, *thr = nullptr, *qstate = nullptr; uint32_t rows = 0, ld = 0; };   // qstate: [6][ld] = c2, c1, c0, closed | L_q | margin at the norm cap
+static ExpFilterDump g_exp_dump;
+}  // namespace vk
+extern "C" __attribute__((visibility("default"))) void vk_exp_filter_dump(float *d_scores, float *d_thr, float *d_qstate, uint32_t rows, uint32_t ld) {
+  vk::g_exp_dump.scores = d_scores;
+  vk::g_exp_dump.thr = d_thr;
+  vk::g_exp_dump.qstate = d_qstate;
+  vk::g_exp_dump.rows = rows;
+  vk::g_exp_dump.ld = ld;
+}
+namespace vk {
+#endif
+
 // ---- FlatIndex ---------------------------------------------------------------------------
 class FlatIndex final : public Index {
  public:
@@ -1063,6 +1079,10 @@ class FlatIndex final : public Index {
         fm.ablate_on = 1;
         fm.ablate = (uint32_t)atoi(getenv("VK_FILTER_ABLATE"));
       }
+      fm.dump_scores = g_exp_dump.scores;   // margin audit (vk_exp_filter_dump)
+      fm.dump_thr = g_exp_dump.thr;
+      fm.dump_rows = g_exp_dump.rows;
+      fm.dump_ld = g_exp_dump.ld;
       if (fat_dbg || fm.timing) {   // phase timing experiments: up to nine counters
         VK_TRY(ctx->d_idx.ensure(128));
         VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
@@ -1087,6 +1107,13 @@ class FlatIndex final : public Index {
         tp->pending = true;
       }
 #ifdef VK_EXPERIMENTS
+      if (g_exp_dump.qstate != nullptr && nq <= g_exp_dump.ld) {   // margin audit: the per-query gate state next to the scores
+        for (int c = 0; c < 4; ++c)
+          VK_HIP_TRY(hipMemcpy2DAsync(g_exp_dump.qstate + (size_t)c * g_exp_dump.ld, 4, reinterpret_cast<const float *>(f.qcoef) + c, 16, 4, nq,
+                                      hipMemcpyDeviceToDevice, s));
+        VK_HIP_TRY(hipMemcpyAsync(g_exp_dump.qstate + (size_t)4 * g_exp_dump.ld, f.qbound, nq * 4, hipMemcpyDeviceToDevice, s));
+        VK_HIP_TRY(hipMemcpyAsync(g_exp_dump.qstate + (size_t)5 * g_exp_dump.ld, f.qwit, nq * 4, hipMemcpyDeviceToDevice, s));
+      }
       if (fat_dbg) {
         unsigned long long h[3];
         VK_HIP_TRY(hipStreamSynchronize(s));

@@ -153,6 +153,12 @@ struct FlatFilterArgs {
   uint32_t prio;              // wave priorities of the three roles, 2 bits each (rows | queries << 2 | consumers << 4)
   uint32_t ablate_on, ablate; // VK_FILTER_ABLATE: pieces of the pipeline switched off, see flat_filter_body
   uint32_t fat;               // VK_FILTER_FAT=1: the four-fat-waves kernel (256-row tiles)
+  // margin audit (tests/helpers/exp_margin_check.py through vk_exp_filter_dump): the final pass writes what its gate saw for the
+  // first dump_rows rows -- the approximate score of every (row, query) pair and the threshold of every (tile, query) --
+  // so that a test can hold them against exact arithmetic.  Answers stay valid.
+  float *dump_scores;         // [dump_rows][dump_ld]
+  float *dump_thr;            // [dump_rows / 128][dump_ld]
+  uint32_t dump_rows, dump_ld;
 #endif
 };
 // bound selection: qbound[q] = the k-th largest of smax[q][0 .. groups) (-inf when fewer than k are finite)
