@@ -552,6 +552,31 @@ def lib_multi_gpu(args, world, rank, dist, device):
                 import traceback
                 return {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().strip().splitlines()[-3:]}
 
+        # ---- the gather, A/B: one-shot peer copies (the default, timed above) against the in-library RCCL all-gather of the
+        #      per-shard top-k (option shard-gather = 1; north_star's collective) -- same steps, same answer required
+        def gather_ab():
+            g0 = ix.stats().rccl_gathers
+            ix.set_option("shard-gather", 1)
+            try:
+                for _ in range(max(2, args.warmup)):
+                    state["step"]()
+                torch.cuda.synchronize()
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+                for _ in range(args.steps):
+                    state["step"]()
+                a1.record()
+                torch.cuda.synchronize()
+                same = bool((ol.cpu().numpy().view(np.uint64) == res_l).all() and (od.cpu().numpy().view(np.uint32) == res_d.view(np.uint32)).all())
+                return {"peer_copies_ms_per_step": round(dev_ms, 4), "rccl_all_gather_ms_per_step": round(a0.elapsed_time(a1) / args.steps, 4),
+                        "rccl_ranks": len(set(devs)), "lists_per_rank": max(devs.count(d) for d in set(devs)),
+                        "rccl_gathers": int(ix.stats().rccl_gathers - g0), "answers_identical": same,
+                        "note": "one communicator per distinct device inside the one process (ncclCommInitAll); two ncclAllGather "
+                                "(distances f32, labels u64) of [lists_per_rank][batch][k] per step in one group call"}
+            finally:
+                ix.set_option("shard-gather", 0)
+        gather = leg(gather_ab)
+
         # ---- CPU baseline (same oracle leg as N = 1) + parity of the merged answer on the queries it scanned ----
         cpu = parity = None
         host_rows = None
@@ -626,7 +651,7 @@ def lib_multi_gpu(args, world, rank, dist, device):
                                          + ": queries broadcast by peer copy, one enqueue thread per shard, per-shard top-k "
                                            "gathered on device 0, (distance,label) merge",
                           "devices": devs, "verify_merge": verify},
-               "roofline": roofline, "cpu_baseline": cpu, "hnsw": hnsw, "config4_sharded_hybrid": hybrid,
+               "roofline": roofline, "cpu_baseline": cpu, "gather": gather, "hnsw": hnsw, "config4_sharded_hybrid": hybrid,
                "config3_sharded_bf16_ip": cfg3, "build_s": round(state["build_s"], 2)}
         print(json.dumps(out))
         if verify is not None:

@@ -161,6 +161,9 @@ typedef struct vk_index_stats {
   uint64_t rejected;
   uint64_t queued_now;
   uint64_t max_batches_in_flight;
+  /* sharded index: fan-outs whose per-shard lists were gathered by the RCCL all-gather (option shard-gather = 1) instead of
+   * peer copies */
+  uint64_t rccl_gathers;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------

@@ -45,7 +45,7 @@ def test_struct_layouts_match_header(vsa, tmp_path):
     offset of every field (gcc compiles a probe that prints them)."""
     import subprocess
     assert C.sizeof(vsa.Params) == 144
-    assert C.sizeof(vsa.Stats) == 424
+    assert C.sizeof(vsa.Stats) == 432
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vk_index.h"', 'int main(void){']
     for cname, mirror in (("vk_index_params", vsa.Params), ("vk_index_stats", vsa.Stats)):
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -92,4 +92,17 @@ def test_hnswlib_shaped_facade_compiles_against_the_abi(vsa, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", str(ROOT / "include"),
                            str(ROOT / "tests" / "helpers" / "vk_algo_check.cc"), "-o", str(exe),
                            "-L", str(vsa.LIB_PATH.parent), "-lvkindex", f"-Wl,-rpath,{vsa.LIB_PATH.parent}"])
+    assert exe.exists()
+
+
+def test_vectorbase_adaptor_compiles_against_the_mocked_interface(vsa, tmp_path):
+    """include/vk_vector_adaptor.h: VectorGpuFlat<T> / VectorGpuHNSW<T> DERIVE from VectorBase and override the virtuals
+    VectorFlat<T> / VectorHNSW<T> override (vector_base.h:129-282, vector_flat.h:37-63, vector_hnsw.h:36-73).  Compiled
+    with -Wall -Wextra -Werror against tests/helpers/mock_valkey_search.h (a mock of the interface, not the module's
+    headers): an override that does not match its virtual, or a pure virtual left unimplemented, fails here."""
+    import subprocess
+    exe = tmp_path / "adaptor_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-Wsuggest-override", "-I", str(ROOT / "include"),
+                           "-I", str(ROOT / "tests" / "helpers"), str(ROOT / "tests" / "helpers" / "adaptor_check.cc"), "-o", str(exe),
+                           "-L", str(vsa.LIB_PATH.parent), "-lvkindex", "-lpthread", f"-Wl,-rpath,{vsa.LIB_PATH.parent}"])
     assert exe.exists()

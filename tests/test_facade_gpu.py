@@ -62,3 +62,47 @@ def test_facade_program_matches_oracle(oracle, tmp_path):
         od, ol = (o.search(q[0], k) if name == "FLAT" else o.search(q[0], k, ef=64))
         got = parse(lines[f"{name} knn0-reloaded"].split(" ", 1)[1].replace("knn0-reloaded", "x"))
         assert [g[0] for g in got] == ol.tolist() and [g[1] for g in got] == od.view(np.uint32).tolist()
+
+
+def test_vectorbase_adaptor_program_matches_oracle(oracle, tmp_path):
+    """include/vk_vector_adaptor.h -- the VectorBase-derived binding (submit + completion, token polled by the caller,
+    filter functor materialised, INFO counters, SaveIndex) -- driven through the mocked base class's entry points."""
+    import _pkg
+    vsa = _pkg.vsa
+    n, dim, k = 3000, 24, 5
+    rng = np.random.default_rng(92)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    x.tofile(tmp_path / "rows.f32")
+    q.tofile(tmp_path / "queries.f32")
+    exe = tmp_path / "adaptor_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", str(ROOT / "include"), "-I", str(ROOT / "tests" / "helpers"),
+                           str(ROOT / "tests" / "helpers" / "adaptor_check.cc"), "-o", str(exe),
+                           "-L", str(vsa.LIB_PATH.parent), "-lvkindex", "-lpthread", f"-Wl,-rpath,{vsa.LIB_PATH.parent}"])
+    out = subprocess.run([str(exe), str(tmp_path / "rows.f32"), str(tmp_path / "queries.f32")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "adaptor ok" in out.stdout, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+
+    def find(prefix):
+        return next(l for l in lines if l.startswith(prefix))
+    of = oracle.Flat(dim, "L2", max_elements=n)
+    of.add_many(x)
+    oh = oracle.HNSW(dim, "L2", max_elements=n, M=16, ef_construction=100)
+    oh.add_many(x)
+    for name, o in (("flat", of), ("hnsw", oh)):
+        assert find(f"{name} capacity").split()[2:] == ["1000", "->", "3048", "count", "3000", "max_label", "2999"]
+        for i in range(3):
+            od, ol = (o.search(q[i], k) if name == "flat" else o.search(q[i], k, ef=64))
+            got = parse("x " + find(f"{name} q{i} ").split(" ", 2)[2])
+            assert [g[0] for g in got] == ol.tolist() and [g[1] for g in got] == od.view(np.uint32).tolist()
+            even = parse("x " + find(f"{name} q{i} even").split(" ", 3)[3])
+            assert len(even) == k and all(l % 2 == 0 for l, _ in even)
+        # a raised token: HNSW answers CancelledError without partial results (vector_hnsw.cc:327-329), an answer with them;
+        # FLAT returns what its scan had (VectorFlat::Search has no such branch)
+        assert find(f"{name} cancelled") == f"{name} cancelled: {'ok' if name == 'flat' else 'CancelledError'} / partial ok"
+        assert find(f"{name} distance").split()[-3:] == ["00000000", "label", "0"]
+        assert "stored row" in find(f"{name} GetValue") and "GetValue(2) null" in find(f"{name} GetValue") and find(f"{name} GetValue").endswith("IsVectorMatch 1")
+        info = find(f"{name} info")
+        assert "data_type=FLOAT32" in info and f"algorithm={name.upper()}" in info and "gpu_searches=" in info
+        assert int(info.split("gpu_searches=")[1].split()[0]) >= 7
+        assert find(f"{name} save/load").split()[-3:] == (["2999", "->", "2999"] if name == "flat" else ["3000", "->", "3000"])

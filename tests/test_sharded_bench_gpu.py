@@ -37,6 +37,9 @@ def test_single_process_two_shards():
     assert rf["bound"] == "hbm" and 0.0 < rf["frac"] <= 1.0 and rf["algorithmic_bytes"] == 300000 * 768 * 4
     assert "flat_filter_bdma_kernel" in rf["kernel"] and rf["launches_timed"] == 3
     assert rf["host_fanout_enqueue_us_per_step"] is not None
+    ga = b["gather"]      # peer copies against the in-library RCCL all-gather, same steps, same answer
+    assert ga["answers_identical"] is True and ga["rccl_ranks"] == 1 and ga["lists_per_rank"] == 2 and ga["rccl_gathers"] >= 3
+    assert ga["rccl_all_gather_ms_per_step"] > 0 and ga["peer_copies_ms_per_step"] > 0
     assert b["cpu_baseline"] and b["cpu_baseline"]["value"] > 0 and b["cpu_baseline"]["kind"] == "port"
     assert b["config"]["parity_vs_oracle"] == "bit-exact"
     c3 = b["config3_sharded_bf16_ip"]

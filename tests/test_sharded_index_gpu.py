@@ -197,3 +197,60 @@ def test_sharded_device_buffer_entry_point(vsa, oracle):
     D, L, N = one.search_batch(Q, k)
     assert (ol.cpu().numpy().view(np.uint64) == L).all() and (od.cpu().numpy().view(np.uint32) == D.view(np.uint32)).all()
     assert (on.cpu().numpy() == k).all()
+
+
+@pytest.mark.parametrize("algo,shards", [("FLAT", 3), ("FLAT", 8), ("HNSW", 2)])
+def test_rccl_all_gather_of_the_per_shard_lists_equals_the_peer_copies(vsa, oracle, algo, shards):
+    """Option shard-gather = 1: the per-shard top-k lists travel by an in-library RCCL all-gather (ncclCommInitAll in this
+    one process, one communicator per DISTINCT device, two ncclAllGather per fan-out) instead of one-shot peer copies.  On a
+    one-GPU box the communicator has one rank and every device group holds all the shards -- the code path (library loaded
+    at run time, communicators, send slots per shard, group call, stream ordering, merge over [ranks][lists]) is the one
+    eight GPUs run; what a single device cannot show is the xGMI traffic.  Answers must not change, and a request for the
+    collective is never served by the copies (vk_index_stats.rccl_gathers counts)."""
+    rng = np.random.default_rng(77 + shards)
+    n, dim = (30_000, 64) if algo == "FLAT" else (6_000, 32)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x = x / np.linalg.norm(x, axis=1, keepdims=True)
+    kw = dict(m=16, ef_construction=100, ef_runtime=64, build_threads=1) if algo == "HNSW" else {}
+    sh = vsa.Index(algo, dim, "COSINE", initial_cap=n, shard_devices=[0] * shards, **kw)
+    sh.add_batch(x)
+    Q = rng.standard_normal((70, dim)).astype(np.float32)
+    Q = Q / np.linalg.norm(Q, axis=1, keepdims=True)
+    bits = oracle.allow_bitmap(np.arange(0, n, 3, dtype=np.uint64), n)
+    ref = {(nq, k): sh.search_batch(Q[:nq], k) for nq in (1, 7, 70) for k in (1, 10, 100)}
+    ref_f = sh.search_batch(Q, 10, allow=bits, allow_nbits=n)
+    assert sh.stats().rccl_gathers == 0
+    sh.set_option("shard-gather", 1)
+    assert sh.get_option("shard-gather") == 1
+    for (nq, k), want in ref.items():
+        _same(sh.search_batch(Q[:nq], k), want)
+    _same(sh.search_batch(Q, 10, allow=bits, allow_nbits=n), ref_f)
+    st = sh.stats()
+    assert st.rccl_gathers == len(ref) + 1 and st.fanout_calls >= 2 * (len(ref) + 1)
+    # the device-buffer entry point (what bench.py times) and a single query
+    d1, l1 = sh.search(Q[0], 10)
+    assert l1.tolist() == ref[(1, 10)][1][0].tolist()
+    sh.set_option("shard-gather", 0)
+    _same(sh.search_batch(Q[:7], 10), ref[(7, 10)])
+    assert sh.stats().rccl_gathers == st.rccl_gathers + 1
+    if algo == "FLAT":
+        o = oracle.Flat(dim, "COSINE", max_elements=n)
+        o.add_many(x)
+        D, L, N = ref[(7, 10)]
+        for i in range(7):
+            od, ol = o.search(Q[i], 10)
+            assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+
+
+def test_a_second_device_without_peer_access_is_refused_loudly(vsa):
+    """Two-device readiness: an index over devices that cannot reach each other directly would stage every broadcast and
+    gather through host memory.  vk_index_create refuses it (VK_ERR_NO_DEVICE with the reason) unless shard-allow-staged
+    is set; on this box there is one device, so what can be checked is that naming a device that does not exist fails
+    loudly too, and that the single-device sharded index does not need the switch."""
+    import pytest as _pt
+    nd = vsa.lib().vk_device_count()
+    with _pt.raises(vsa.VkError) as e:
+        vsa.Index("FLAT", 16, "L2", initial_cap=1024, shard_devices=[0, nd])
+    assert e.value.code in (vsa.VK_ERR_NO_DEVICE, vsa.VK_ERR_INVALID, vsa.VK_ERR_INTERNAL) and e.value.msg
+    ok = vsa.Index("FLAT", 16, "L2", initial_cap=1024, shard_devices=[0, 0])
+    assert ok.get_option("shard-allow-staged") == 0 and ok.shard_count() == 2

@@ -748,6 +748,7 @@ __global__ void fill_empty_kernel(float *out_dist, uint64_t *out_label, uint32_t
     out_dist[i] = __builtin_inff();
     out_label[i] = kNoLabel;
   }
+  if (out_n == nullptr) return;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) out_n[q] = 0;
 }
 hipError_t launch_fill_empty(float *out_dist, uint64_t *out_label, uint32_t *out_n, uint32_t nq, uint32_t k, hipStream_t s) {

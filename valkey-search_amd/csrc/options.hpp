@@ -40,7 +40,7 @@ enum OptId : uint32_t {
   kOptHnswBuildVerbose, kOptHnswPoolFloor, kOptHnswGpoolCap, kOptHnswVisitedHash, kOptHnswHashPerEf, kOptHnswHashLog2,
   kOptHnswPoolBytes, kOptHnswVisitedBytes, kOptHnswRedoBytes, kOptHnswVisitedDedup,
   // ---- sharded index ---------------------------------------------------------------------------------------------------
-  kOptShardThreads,
+  kOptShardThreads, kOptShardAllowStaged,
   kOptCount
 };
 
@@ -93,6 +93,7 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"hnsw-redo-bytes", "VK_HNSW_REDO_BYTES", (uint64_t)2 << 30, 1u << 20, kMax},
       {"hnsw-visited-dedup", "VK_HNSW_VISITED_DEDUP", 1, 0, 1},
       {"shard-threads", "VK_SHARD_THREADS", 1, 0, 1},
+      {"shard-allow-staged", "VK_SHARD_ALLOW_STAGED", 0, 0, 1},
   };
   return t[id];
 }

@@ -24,6 +24,9 @@
 #include <functional>
 #include <thread>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include "index.hpp"
 
 namespace vk {
@@ -41,8 +44,17 @@ struct ShardLane {
   hipEvent_t done = nullptr;
   DevBuf d_q, d_allow, d_out_d, d_out_l, d_out_n;
 };
+// shard-gather = 1: per DISTINCT device the lists of its shards, contiguous ([P][nq][k], P = the most shards any device
+// holds; unused slots stay (+inf, no label)), and the all-gathered lists of every device ([G][P][nq][k])
+struct GatherGroup {
+  int device = 0;
+  DevBuf send_d, send_l, recv_d, recv_l;
+  size_t filled_nk = 0;       // the pad slots were filled for this nq * k
+  hipEvent_t gathered = nullptr;
+};
 struct MultiCtx {
   std::vector<ShardLane> lane;
+  std::vector<GatherGroup> group;
   int dev0 = 0;
   hipStream_t s0 = nullptr;
   hipEvent_t ready = nullptr, busy = nullptr;
@@ -58,6 +70,11 @@ struct MultiCtx {
       for (DevBuf *b : {&l.d_q, &l.d_allow, &l.d_out_d, &l.d_out_l, &l.d_out_n}) b->release();
       if (l.done) (void)hipEventDestroy(l.done);
       if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    for (GatherGroup &g : group) {
+      (void)hipSetDevice(g.device);
+      for (DevBuf *b : {&g.send_d, &g.send_l, &g.recv_d, &g.recv_l}) b->release();
+      if (g.gathered) (void)hipEventDestroy(g.gathered);
     }
     (void)hipSetDevice(dev0);
     for (DevBuf *b : {&d_q, &d_allow, &d_all_d, &d_all_l, &d_all_n, &d_fin_d, &d_fin_l, &d_fin_n}) b->release();
@@ -130,6 +147,52 @@ class ShardWorkers {
   std::deque<Worker> w_;   // (deque: Worker is neither movable nor copyable)
 };
 
+// ---- RCCL (option shard-gather = 1) -----------------------------------------------------------------------------------
+// north_star names "RCCL all-gather of per-shard top-k over xGMI".  The per-shard lists are 30 KiB per shard at B = 256,
+// k = 10 -- latency-bound -- so the default gather is one-shot peer copies into the serving device (above); the collective
+// is selectable beside it so that a hardware run can A/B the two (bench.py --gpus N prints both).  The library does not
+// link librccl: it is loaded on first use -- /opt/rocm's copy first, the one built against the HIP runtime this library
+// links (a process that also holds torch has a second RCCL, tied to torch's own HIP runtime) -- and a failure to load or
+// initialise it FAILS the search that asked for it; there is no silent return to the peer copies.
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::vector<ncclComm_t> comms;   // one per DISTINCT device of the index, rank = position in dev_groups_
+
+  Status load() {
+    if (lib) return Status::Ok();
+    for (const char *name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) return Status::Err(VK_ERR_INTERNAL, std::string("shard-gather = 1 needs RCCL: ") + dlerror());
+    auto sym = [&](const char *n) { return dlsym(lib, n); };
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd || !GetErrorString)
+      return Status::Err(VK_ERR_INTERNAL, "shard-gather = 1: librccl lacks a symbol the gather needs");
+    return Status::Ok();
+  }
+  Status check(ncclResult_t r, const char *what) const {
+    if (r == ncclSuccess) return Status::Ok();
+    return Status::Err(VK_ERR_INTERNAL, std::string("RCCL ") + what + ": " + GetErrorString(r));
+  }
+  ~Rccl() {
+    for (ncclComm_t c : comms)
+      if (c) (void)CommDestroy(c);
+    // (the library stays loaded: other indexes of the process may hold communicators of it)
+  }
+};
+
 }  // namespace
 
 class ShardedIndex final : public Index {
@@ -171,15 +234,32 @@ class ShardedIndex final : public Index {
       dev_groups_[gi].push_back(s);
     }
     if (dev_groups_.size() > 1 && threads_on) workers_ = std::make_unique<ShardWorkers>(dev_groups_.size() - 1);
-    // peer access between the devices involved (a failure only means the copies are staged by the runtime)
+    shard_group_.assign(S, 0);
+    shard_pos_.assign(S, 0);
+    for (size_t gi = 0; gi < dev_groups_.size(); ++gi) {
+      group_max_ = std::max(group_max_, dev_groups_[gi].size());
+      for (size_t i = 0; i < dev_groups_[gi].size(); ++i) { shard_group_[dev_groups_[gi][i]] = (uint32_t)gi; shard_pos_[dev_groups_[gi][i]] = (uint32_t)i; }
+    }
+    // Peer access between the devices involved.  The fan-out's broadcast and gather are peer copies over xGMI; without peer
+    // access the runtime would stage every one of them through host memory -- an index that LOOKS multi-GPU and runs at PCIe
+    // latency.  That is refused here, loudly, rather than discovered in production (the option shard-allow-staged lifts it
+    // for boxes whose devices really have no direct path).
     for (size_t a = 0; a < S; ++a)
       for (size_t b = 0; b < S; ++b)
         if (devices_[a] != devices_[b]) {
           int can = 0;
-          if (hipDeviceCanAccessPeer(&can, devices_[a], devices_[b]) == hipSuccess && can) {
+          const hipError_t ce = hipDeviceCanAccessPeer(&can, devices_[a], devices_[b]);
+          if (ce == hipSuccess && can) {
             (void)hipSetDevice(devices_[a]);
             hipError_t e = hipDeviceEnablePeerAccess(devices_[b], 0);
-            if (e != hipSuccess) (void)hipGetLastError();   // (already enabled)
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+              return Status::Err(VK_ERR_INTERNAL, "hipDeviceEnablePeerAccess(" + std::to_string(devices_[a]) + " -> " + std::to_string(devices_[b]) +
+                                                      "): " + hipGetErrorString(e));
+            (void)hipGetLastError();
+          } else if (opt_.get(kOptShardAllowStaged) == 0) {
+            return Status::Err(VK_ERR_NO_DEVICE, "device " + std::to_string(devices_[a]) + " has no peer access to device " + std::to_string(devices_[b]) +
+                                                     ": the sharded index would stage every broadcast and gather through host memory "
+                                                     "(set VK_SHARD_ALLOW_STAGED=1 / option shard-allow-staged to accept that)");
           }
         }
     return Status::Ok();
@@ -497,6 +577,7 @@ class ShardedIndex final : public Index {
     }
     out->fanout_calls = fanout_calls_.load(std::memory_order_relaxed);
     out->fanout_enqueue_ns = fanout_ns_.load(std::memory_order_relaxed);
+    out->rccl_gathers = rccl_gathers_.load(std::memory_order_relaxed);
     std::shared_lock<std::shared_mutex> lk(rw_);
     out->capacity = capacity_;
     out->host_bytes += route_.size() * 24;
@@ -623,6 +704,12 @@ class ShardedIndex final : public Index {
             (void)hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
             (void)hipEventCreateWithFlags(&l.done, hipEventDisableTiming);
           }
+          n->group.resize(dev_groups_.size());
+          for (size_t gi = 0; gi < dev_groups_.size(); ++gi) {
+            n->group[gi].device = devices_[dev_groups_[gi][0]];
+            (void)hipSetDevice(n->group[gi].device);
+            (void)hipEventCreateWithFlags(&n->group[gi].gathered, hipEventDisableTiming);
+          }
           all_.push_back(std::move(n));
           mc = all_.back().get();
           break;
@@ -653,7 +740,7 @@ class ShardedIndex final : public Index {
 
   // One shard's part of a fan-out, enqueued on the shard's lane stream (any thread): wait for the queries, broadcast by
   // peer copy unless the shard lives on the serving device, search, send the lists to their slice of the gathered array.
-  Status enqueue_shard(MultiCtx *mc, size_t s, const SearchRequest &rq) {
+  Status enqueue_shard(MultiCtx *mc, size_t s, const SearchRequest &rq, bool rccl) {
     const uint32_t dim = params_.dim;
     const size_t qbytes = (size_t)rq.nq * dim * 4, nk = (size_t)rq.nq * rq.k;
     const size_t abytes = rq.allow_bits ? (size_t)((rq.allow_nbits + 63) / 64) * 8 : 0;
@@ -690,9 +777,14 @@ class ShardedIndex final : public Index {
       ol = l.d_out_l.as<uint64_t>();
       on = l.d_out_n.as<uint32_t>();
     }
+    if (rccl) {   // the lists go to this shard's slot of its DEVICE's send buffer; the all-gather moves them (fan_out)
+      GatherGroup &g = mc->group[shard_group_[s]];
+      od = g.send_d.as<float>() + shard_pos_[s] * nk;
+      ol = g.send_l.as<uint64_t>() + shard_pos_[s] * nk;
+    }
     VK_TRY(shards_[s]->search_device(srq, od, ol, on, l.stream));
     VK_HIP_TRY(hipSetDevice(l.device));
-    if (!local) {   // the shard's lists -> their slice of the gathered array on the serving device
+    if (!local && !rccl) {   // the shard's lists -> their slice of the gathered array on the serving device
       VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_d.as<float>() + s * nk, mc->dev0, od, l.device, nk * 4, l.stream));
       VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_l.as<uint64_t>() + s * nk, mc->dev0, ol, l.device, nk * 8, l.stream));
     }
@@ -712,6 +804,72 @@ class ShardedIndex final : public Index {
     (void)hipStreamSynchronize(s0);
   }
 
+  // shard-gather = 1, before the shards are enqueued: the communicators (first use), every device's send / receive buffers,
+  // and (+inf, no label) in the send slots no shard of that device writes
+  Status rccl_prepare(MultiCtx *mc, const SearchRequest &rq, size_t nk, hipStream_t s0) {
+    const size_t G = dev_groups_.size(), P = group_max_;
+    {
+      std::lock_guard<std::mutex> lk(rccl_mu_);
+      VK_TRY(rccl_.load());
+      if (rccl_.comms.empty()) {
+        std::vector<int> devs(G);
+        for (size_t gi = 0; gi < G; ++gi) devs[gi] = devices_[dev_groups_[gi][0]];
+        std::vector<ncclComm_t> comms(G, nullptr);
+        VK_TRY(rccl_.check(rccl_.CommInitAll(comms.data(), (int)G, devs.data()), "ncclCommInitAll"));
+        rccl_.comms = std::move(comms);
+      }
+    }
+    for (size_t gi = 0; gi < G; ++gi) {
+      GatherGroup &g = mc->group[gi];
+      VK_HIP_TRY(hipSetDevice(g.device));
+      VK_TRY(g.send_d.ensure(P * nk * 4));
+      VK_TRY(g.send_l.ensure(P * nk * 8));
+      VK_TRY(g.recv_d.ensure(G * P * nk * 4));
+      VK_TRY(g.recv_l.ensure(G * P * nk * 8));
+      if (dev_groups_[gi].size() < P && g.filled_nk != nk) {   // the pad slots, once per batch shape (on the stream that gathers)
+        hipStream_t cs = mc->lane[dev_groups_[gi].back()].stream;
+        for (size_t p = dev_groups_[gi].size(); p < P; ++p)
+          VK_HIP_TRY(launch_fill_empty(g.send_d.as<float>() + p * nk, g.send_l.as<uint64_t>() + p * nk, nullptr, (uint32_t)rq.nq, (uint32_t)rq.k, cs));
+        g.filled_nk = nk;
+      }
+    }
+    (void)s0;
+    return Status::Ok();
+  }
+  // ... and after them: on every device the stream of its last shard waits for the device's other shards, then ONE group
+  // call issues the all-gathers of all devices (distances, labels) from this thread
+  Status rccl_all_gather(MultiCtx *mc, size_t nk) {
+    const size_t G = dev_groups_.size(), P = group_max_;
+    for (size_t gi = 0; gi < G; ++gi) {
+      VK_HIP_TRY(hipSetDevice(mc->group[gi].device));
+      hipStream_t cs = mc->lane[dev_groups_[gi].back()].stream;
+      for (size_t i = 0; i + 1 < dev_groups_[gi].size(); ++i) VK_HIP_TRY(hipStreamWaitEvent(cs, mc->lane[dev_groups_[gi][i]].done, 0));
+    }
+    {
+      std::lock_guard<std::mutex> lk(rccl_mu_);
+      VK_TRY(rccl_.check(rccl_.GroupStart(), "ncclGroupStart"));
+      Status st = Status::Ok();
+      for (size_t gi = 0; gi < G && st.ok(); ++gi) {
+        GatherGroup &g = mc->group[gi];
+        hipStream_t cs = mc->lane[dev_groups_[gi].back()].stream;
+        st = rccl_.check(rccl_.AllGather(g.send_d.p, g.recv_d.p, P * nk, ncclFloat32, rccl_.comms[gi], cs), "ncclAllGather(distances)");
+        if (st.ok()) st = rccl_.check(rccl_.AllGather(g.send_l.p, g.recv_l.p, P * nk, ncclUint64, rccl_.comms[gi], cs), "ncclAllGather(labels)");
+      }
+      Status en = rccl_.check(rccl_.GroupEnd(), "ncclGroupEnd");
+      VK_TRY(st);
+      VK_TRY(en);
+    }
+    for (size_t gi = 0; gi < G; ++gi) {
+      VK_HIP_TRY(hipSetDevice(mc->group[gi].device));
+      hipStream_t cs = mc->lane[dev_groups_[gi].back()].stream;
+      VK_HIP_TRY(hipEventRecord(mc->group[gi].gathered, cs));
+      // (the lane's `done` event is what quiesce / the next user of the context wait for: move it behind the collective)
+      VK_HIP_TRY(hipEventRecord(mc->lane[dev_groups_[gi].back()].done, cs));
+    }
+    rccl_gathers_.fetch_add(1, std::memory_order_relaxed);
+    return Status::Ok();
+  }
+
   // the fan-out itself: rq holds DEVICE pointers on the serving device, valid on stream s0; the merged answer is written
   // to d_out_* (serving device) by work enqueued on s0
   Status fan_out(MultiCtx *mc, const SearchRequest &rq, float *d_out_dist, uint64_t *d_out_label, uint32_t *d_out_n,
@@ -723,15 +881,22 @@ class ShardedIndex final : public Index {
     VK_TRY(mc->d_all_d.ensure(S * nk * 4));
     VK_TRY(mc->d_all_l.ensure(S * nk * 8));
     VK_TRY(mc->d_all_n.ensure(S * rq.nq * 4));
+    const bool rccl = opt_.get(kOptShardGather) != 0;
+    const size_t G = dev_groups_.size(), P = group_max_;
+    if (rccl) {
+      Status st = rccl_prepare(mc, rq, nk, s0);
+      if (!st.ok()) { quiesce(mc, s0); return st; }
+      (void)hipSetDevice(mc->dev0);
+    }
     VK_HIP_TRY(hipEventRecord(mc->ready, s0));   // queries (and filter) are in place on the serving device
     std::vector<Status> res(S);
     if (workers_) {
       ShardWorkers::Latch latch;
       latch.left = (uint32_t)(dev_groups_.size() - 1);
-      auto run_group = [this, mc, &rq, &res](size_t gi) {
+      auto run_group = [this, mc, &rq, &res, rccl](size_t gi) {
         for (size_t s : dev_groups_[gi]) {
           try {
-            res[s] = enqueue_shard(mc, s, rq);
+            res[s] = enqueue_shard(mc, s, rq, rccl);
           } catch (const std::exception &e) {
             res[s] = Status::Err(VK_ERR_INTERNAL, e.what());
           }
@@ -747,7 +912,7 @@ class ShardedIndex final : public Index {
       latch.wait();
     } else {
       for (size_t s = 0; s < S; ++s) {
-        res[s] = enqueue_shard(mc, s, rq);
+        res[s] = enqueue_shard(mc, s, rq, rccl);
         if (!res[s].ok()) break;
       }
     }
@@ -758,13 +923,22 @@ class ShardedIndex final : public Index {
       }
     (void)hipSetDevice(mc->dev0);
     Status st = [&]() -> Status {
-      for (size_t s = 0; s < S; ++s) VK_HIP_TRY(hipStreamWaitEvent(s0, mc->lane[s].done, 0));
       MergeArgs m{};
-      m.in_dist = mc->d_all_d.as<float>();
-      m.in_label = mc->d_all_l.as<uint64_t>();
+      if (rccl) {
+        VK_TRY(rccl_all_gather(mc, nk));
+        (void)hipSetDevice(mc->dev0);
+        VK_HIP_TRY(hipStreamWaitEvent(s0, mc->group[0].gathered, 0));
+        m.in_dist = mc->group[0].recv_d.as<float>();
+        m.in_label = mc->group[0].recv_l.as<uint64_t>();
+        m.parts = (uint32_t)(G * P);
+      } else {
+        for (size_t s = 0; s < S; ++s) VK_HIP_TRY(hipStreamWaitEvent(s0, mc->lane[s].done, 0));
+        m.in_dist = mc->d_all_d.as<float>();
+        m.in_label = mc->d_all_l.as<uint64_t>();
+        m.parts = (uint32_t)S;
+      }
       m.part_stride = nk;
       m.q_stride = rq.k;
-      m.parts = (uint32_t)S;
       m.per_part = (uint32_t)rq.k;
       m.k = (uint32_t)rq.k;
       m.out_ld = (uint32_t)rq.k;
@@ -809,6 +983,11 @@ class ShardedIndex final : public Index {
   std::vector<int> devices_;
   std::unique_ptr<ShardWorkers> workers_;
   std::vector<std::vector<size_t>> dev_groups_;           // shards by device, the serving device's group first
+  std::vector<uint32_t> shard_group_, shard_pos_;         // shard -> its device group and its place in it
+  size_t group_max_ = 0;                                   // the most shards any device holds
+  Rccl rccl_;                                              // shard-gather = 1 (loaded and initialised on first use, under rccl_mu_)
+  std::mutex rccl_mu_;                                     // collectives of one communicator set are issued by one thread at a time
+  std::atomic<uint64_t> rccl_gathers_{0};
   std::atomic<uint64_t> fanout_calls_{0}, fanout_ns_{0};   // host time of fan_out (enqueue only), for vk_index_stats
   std::vector<std::unique_ptr<Index>> shards_;
   std::vector<uint64_t> shard_cap_;
