@@ -918,6 +918,7 @@ def main():
                     help="CPU baseline: queries per host thread (16 x 16 threads = all 256 queries of the timed batch, each a full "
                          "10M-row scan: about 30 s of CPU work, and every row of the timed step's answer is compared)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serving", action="store_true", help="skip the single-query serving legs (profiling runs)")
     ap.add_argument("--single-query-steps", type=int, default=5, help="extra: B=1 scan timing (HBM roofline)")
     ap.add_argument("--hnsw-rows", type=int, default=-1,
                     help="HNSW leg (BASELINE.json configs[2]) over the first rows: -1 = all of --rows (10M), 0 = skip")
@@ -1212,7 +1213,7 @@ def main():
 
     # ---- single-query traffic against THIS index (10M x 768 in the default run): submit with 1024 outstanding, 256 blocking callers ----
     coalescer = None
-    if rank == 0 and world == 1 and B >= 5:
+    if rank == 0 and world == 1 and B >= 5 and not args.no_serving:
         coalescer = leg(serving_leg, ix, Q.cpu().numpy(), K, B * args.steps / dt, B, 500, 4, 4 * B, 40 * B, 256, 24)
 
     if rank == 0:

@@ -106,3 +106,15 @@ def test_vectorbase_adaptor_compiles_against_the_mocked_interface(vsa, tmp_path)
                            "-I", str(ROOT / "tests" / "helpers"), str(ROOT / "tests" / "helpers" / "adaptor_check.cc"), "-o", str(exe),
                            "-L", str(vsa.LIB_PATH.parent), "-lvkindex", "-lpthread", f"-Wl,-rpath,{vsa.LIB_PATH.parent}"])
     assert exe.exists()
+
+
+def test_binaries_that_embed_the_abi_structs_are_not_older_than_the_header():
+    """vk_index_get_stats fills the caller's vk_index_stats: a helper binary compiled against an older, smaller struct gets
+    its stack overwritten (seen once: a field added to the header, scripts/libservingprobe.so not rebuilt, `stack smashing
+    detected` in the middle of a profiling run).  build() rebuilds them all; this fails loudly when it was not run."""
+    hdr = (ROOT / "include" / "vk_index.h").stat().st_mtime
+    stale = [str(p.relative_to(ROOT)) for p in (ROOT / "scripts" / "libservingprobe.so", ROOT / "scripts" / "coalescer_native",
+                                                 ROOT / "valkey-search_amd" / "libvkhost.so", ROOT / "valkey-search_amd" / "libvkindex.so",
+                                                 ROOT / "valkey-search_amd" / "libvkindex_exp.so")
+             if p.exists() and p.stat().st_mtime < hdr]
+    assert not stale, f"rebuild (python -c 'import __graft_entry__ as g; g.build()'): older than include/vk_index.h: {stale}"

@@ -510,3 +510,49 @@ def test_experiment_switches_do_nothing_in_the_product_library(vsa):
         _same(f2.search_batch(Q, 10), want)
         _same(e2.search_batch(Q, 10), want)
         assert f.stats().last_filter_candidates >= 64 * 10
+
+
+@pytest.mark.parametrize("metric,dtype", [("COSINE", "f32"), ("L2", "f32"), ("IP", "bf16")])
+def test_fused_rerank_equals_the_two_launch_rerank(vsa, oracle, metric, dtype):
+    """r04: the survivors' exact re-rank and the (distance, label) selection are ONE launch for k <= 64 (flat_rerank_kernel:
+    eight blocks per query, the block that finishes last merges the partial lists and writes the answer); option
+    flat-fused-rerank = 0 is the r03 pair of launches.  Same answers -- with ties (duplicated rows under different labels), a
+    query on 20 000 duplicates (spill chunks), an allow-bitmap, k = 1 / 10 / 64, and a batch that is not a multiple of 32."""
+    rng = np.random.default_rng(321)
+    n, dim = 90_000, 96
+    centres = rng.standard_normal((40, dim)).astype(np.float32)
+    x = (centres[rng.integers(0, 40, n)] + 0.3 * rng.standard_normal((n, dim)).astype(np.float32)).astype(np.float32)
+    x[5000:5300] = x[4999]                               # ties at the k-th distance
+    x[30_000:50_000] = x[7]                              # one query's survivors by the ten thousand
+    if metric == "COSINE":
+        x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    Q = (centres[rng.integers(0, 40, 77)] + 0.3 * rng.standard_normal((77, dim)).astype(np.float32)).astype(np.float32)
+    Q[3], Q[11] = x[7], x[4999]
+    if metric == "COSINE":
+        Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    labels = rng.permutation(2 * n)[:n].astype(np.uint64)
+    ix = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype, options={"filter-prepass-rows": 1024, "filter-min-rows": 32768})
+    ix.add_batch(x, labels)
+    nb = int(labels.max()) + 1
+    bits = oracle.allow_bitmap(labels[rng.random(n) < 0.3], nb)
+    for k in (1, 10, 64):
+        for kw in ({}, {"allow": bits, "allow_nbits": nb}):
+            ix.set_option("flat-fused-rerank", 1)
+            a = ix.search_batch(Q, k, **kw)
+            st = ix.stats()
+            assert st.last_filter_candidates > 0 and st.last_filter_fallback == 0
+            ix.set_option("flat-fused-rerank", 0)
+            b = ix.search_batch(Q, k, **kw)
+            assert ix.stats().last_filter_candidates == st.last_filter_candidates
+            assert a[2].tolist() == b[2].tolist() and (a[1] == b[1]).all() and (a[0].view(np.uint32) == b[0].view(np.uint32)).all(), (k, bool(kw))
+    ix.set_option("flat-fused-rerank", 1)
+    D, L, N = ix.search_batch(Q, 10)
+    xs = x
+    if dtype == "bf16":
+        u = x.view(np.uint32).astype(np.uint64)
+        xs = ((((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32)).view(np.float32)
+    o = oracle.Flat(dim, metric, max_elements=n)
+    o.add_many(xs, labels)
+    for i in (0, 3, 11, 40, 76):
+        od, ol = o.search(Q[i], 10)
+        assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist(), i

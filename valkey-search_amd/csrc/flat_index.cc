@@ -964,8 +964,9 @@ class FlatIndex final : public Index {
     const uint32_t smax_ld = (groups + 63) & ~63u;
     const uint32_t n_chunks = filter_spill_chunks_;
     // per-batch words: [nq] survivor counts | [nq] hand-over flags | [4] spill_next, redo_cnt | [nq] redo list | [nq][32] chunk slots
-    const size_t w_cnt = 0, w_ovf = nq, w_misc = 2 * nq, w_redo = 2 * nq + 4, w_chunk = 3 * nq + 4;
-    VK_TRY(ctx->d_fcnt.ensure((w_chunk + nq * kSpillPerQuery) * 4));
+    // ... | [nq] arrival counters of the fused re-rank
+    const size_t w_cnt = 0, w_ovf = nq, w_misc = 2 * nq, w_redo = 2 * nq + 4, w_chunk = 3 * nq + 4, w_done = w_chunk + nq * kSpillPerQuery;
+    VK_TRY(ctx->d_fcnt.ensure((w_done + nq) * 4));
     VK_TRY(ctx->d_fq16.ensure((size_t)nqt * 32 * dp * 2));
     VK_TRY(ctx->d_fthr.ensure((size_t)nqt * 32 * (16 + 4 + 4)));      // error polynomials, then bounds, then witness margins
     VK_TRY(ctx->d_fcand.ensure(nq * (size_t)cap * 4));
@@ -1019,6 +1020,7 @@ class FlatIndex final : public Index {
     f.spill_next = words + w_misc;
     f.n_chunks = n_chunks;
     f.ovf_q = words + w_ovf;
+    f.done_cnt = words + w_done;
     f.smax = ctx->d_fsmax.as<float>();
     f.smax_ld = smax_ld;
     f.smax_fine = fine ? 1 : 0;
@@ -1044,6 +1046,7 @@ class FlatIndex final : public Index {
         fg.cand_row = base.cand_row + c0 * cap;
         fg.qchunk = base.qchunk + c0 * kSpillPerQuery;
         fg.ovf_q = base.ovf_q + c0;
+        fg.done_cnt = base.done_cnt + c0;
         fg.smax = base.smax + c0 * smax_ld;
         VK_HIP_TRY(launch_flat_filter(fg, blocks, s));
       }
@@ -1157,7 +1160,8 @@ class FlatIndex final : public Index {
       r.cand_qchunk = f.qchunk;
       r.cand_spill = f.spill;
       r.cand_ovf = f.ovf_q;
-      VK_HIP_TRY(launch_flat_scan(r, l2(), store_.bf16(), 1, e, s));
+      const bool fused = e == 1 && opt_.get(kOptFlatFusedRerank) != 0;   // k <= 64: one launch writes the answers
+      if (!fused) VK_HIP_TRY(launch_flat_scan(r, l2(), store_.bf16(), 1, e, s));
       MergeArgs m{};
       m.in_dist = r.part_dist;
       m.in_label = r.part_label;
@@ -1173,7 +1177,13 @@ class FlatIndex final : public Index {
       m.ovf_q = f.ovf_q;
       m.redo_cnt = redo_cnt;
       m.redo_list = words + w_redo;
-      VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
+      if (fused) {
+        r.cancel = d_cancel;
+        r.done_cnt = f.done_cnt;
+        VK_HIP_TRY(launch_flat_rerank(r, m, l2(), store_.bf16(), s));
+      } else {
+        VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
+      }
     }
     // 4. the hand-over (decided on the device; these launches return at once when the redo list is empty): the exact
     //    scan over the listed queries alone, or -- more than kFilterRedoMax of them -- the exact kernels over the batch

@@ -222,6 +222,189 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
   }
 }
 
+// ---- fused re-rank + selection of the candidate filter's survivors (k <= 64) ------------------------------------------------
+// kRerankParts blocks of four waves per query.  The query's survivor list (private list, then spill chunks) is dealt to the
+// 32 waves sixteen rows at a time -- the quad kernel's exact arithmetic --, every wave keeps its k best in registers, a
+// block's four lists are merged by its wave 0 through LDS and written as the block's partial list; the block that
+// finishes LAST for its query (a counter per query) merges the partial lists, rank-sorts by (distance, label) and writes
+// the query's ANSWER.  r03 ran this as two launches (flat_scan_kernel in list mode, then merge_select_kernel over the
+// partial lists) and looked a row's label up inside the serial insert loop: a dependent 8-byte read from HBM per kept row,
+// one after the other -- that, not the row gathers, was most of the kernel's 125 us at 10M x 768.  Here the label of every
+// row of a round is requested together with the row (profiles/r04_step_trace_*.log).
+// A query with tens of thousands of survivors (duplicates of one vector) still spreads over 32 waves.
+constexpr int kRerankParts = 8;
+template <bool kL2, bool kBf16>
+__global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeArgs m) {
+  extern __shared__ float4 qs[];  // the query ([chunks][4] float4), later the waves' lists
+  const uint32_t q = blockIdx.x / kRerankParts, part = blockIdx.x % kRerankParts;
+  // a query the filter handed over (it lost survivors, or cannot go through f16): listed for the exact redo pass, which
+  // owns its output
+  if (m.ovf_q && m.ovf_q[q]) {
+    if (part == 0 && threadIdx.x == 0) m.redo_list[atomicAdd(m.redo_cnt, 1u)] = q;
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 3;
+  const int rq = lane >> 2;
+  const uint32_t chunks = a.chunks;
+  for (uint32_t i = threadIdx.x; i < chunks * 4; i += blockDim.x)
+    qs[i] = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f)[i];
+  const uint32_t c_raw = a.cand_cnt[q];
+  const uint32_t most = a.cand_cap + (a.cand_qchunk ? kSpillPerQuery * kSpillChunk : 0u);
+  const uint32_t n_rows = c_raw < most ? c_raw : most;
+  const uint32_t *cand = a.cand_row + (size_t)q * a.cand_cap;
+  const uint32_t *cand_chunks = a.cand_qchunk ? a.cand_qchunk + (size_t)q * kSpillPerQuery : nullptr;
+  auto cand_at = [&](uint32_t i) -> uint32_t {
+    if (i < a.cand_cap) return cand[i];
+    const uint32_t jj = i - a.cand_cap;
+    return a.cand_spill[(size_t)(cand_chunks[jj / kSpillChunk] - 2u) * kSpillChunk + jj % kSpillChunk];   // (slot = chunk + 2)
+  };
+  const uint32_t n_tiles = (n_rows + kRowsPerWave - 1) / kRowsPerWave;
+  constexpr uint32_t kStep = kRerankParts * 4;
+  const uint32_t first = part * 4u + (uint32_t)wave;
+  // the first round's row, requested before the block meets (its address does not depend on the query in LDS)
+  uint32_t next_row = 0;
+  if (first < n_tiles) {
+    const uint32_t i = first * kRowsPerWave + rq;
+    next_row = cand_at(i < n_rows ? i : n_rows - 1);
+  }
+  __syncthreads();
+
+  WaveTopK<1> top;
+  top.init(a.k);
+  uint32_t polled = 0;
+  for (uint32_t tile = first; tile < n_tiles; tile += kStep) {
+    if (a.cancel && (polled++ % kCancelPollTiles) == 0 && poll_cancel(a.cancel)) break;   // bruteforce.h:129
+    const uint32_t i = tile * kRowsPerWave + rq;
+    const bool valid = i < n_rows;
+    const uint32_t row = next_row;
+    const char *__restrict__ base = row_base<kBf16>(a.rows, row, a.row_stride_f);
+    const uint64_t row_label = a.labels[row];        // (with the row, not behind its distance)
+    if (tile + kStep < n_tiles) {                     // ... and the next round's list entry
+      const uint32_t i2 = (tile + kStep) * kRowsPerWave + rq;
+      next_row = cand_at(i2 < n_rows ? i2 : n_rows - 1);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t c = 0;
+    constexpr int kXL = 24;     // row pieces in flight per lane: a 768-element row is two round trips
+    for (; c + kXL <= chunks; c += kXL) {
+      float4 x[kXL];
+#pragma unroll
+      for (int u = 0; u < kXL; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
+#pragma unroll
+      for (int u = 0; u < kXL; ++u) chunk_fma<kL2>(acc, x[u], qs[(c + u) * 4 + j]);
+    }
+    for (; c + 8 <= chunks; c += 8) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = row_piece<kBf16>(base, (c + u) * 4 + j);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) chunk_fma<kL2>(acc, x[u], qs[(c + u) * 4 + j]);
+    }
+    for (; c < chunks; ++c) chunk_fma<kL2>(acc, row_piece<kBf16>(base, c * 4 + j), qs[c * 4 + j]);
+    const float dist = finish_distance<kL2>(quad_reduce16(acc));
+    // distance gate first, filter second -- the order of bruteforce.h:131-135
+    const bool allowed = allow_bit(a.allow_bits, a.allow_nbits, row_label);
+    uint64_t mask = __ballot(valid && j == 0 && dist <= top.thr_d && allowed);
+    while (mask) {
+      const int b = __ffsll((unsigned long long)mask) - 1;
+      mask &= mask - 1;
+      const float cd = readlane_f32(dist, b);
+      if (!(cd <= top.thr_d)) continue;
+      top.insert(cd, readlane_u64(row_label, b), lane);
+    }
+  }
+
+  // waves 1..3 -> LDS -> wave 0 (the query block is done with)
+  __syncthreads();
+  float *md = reinterpret_cast<float *>(qs);                               // [3][k] distances, then labels
+  uint64_t *ml = reinterpret_cast<uint64_t *>(md + ((3 * a.k + 1) & ~1u));
+  if (wave > 0 && (uint32_t)lane < a.k) {
+    md[(wave - 1) * a.k + lane] = top.d[0];
+    ml[(wave - 1) * a.k + lane] = top.lab[0];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  auto absorb = [&](float dist, uint64_t lab) {
+    uint64_t mask = __ballot(lab != kNoLabel && dist <= top.thr_d);
+    while (mask) {
+      const int b = __ffsll((unsigned long long)mask) - 1;
+      mask &= mask - 1;
+      const float cd = readlane_f32(dist, b);
+      if (!(cd <= top.thr_d)) continue;
+      top.insert(cd, readlane_u64(lab, b), lane);
+    }
+  };
+  for (int w = 0; w < 3; ++w) {
+    float dist = __builtin_inff();
+    uint64_t lab = kNoLabel;
+    if ((uint32_t)lane < a.k) { dist = md[w * a.k + lane]; lab = ml[w * a.k + lane]; }
+    absorb(dist, lab);
+  }
+  // the block's partial list; the block that arrives last at the query's counter merges all of them
+  float *pd = a.part_dist + ((size_t)q * kRerankParts + part) * a.k;
+  uint64_t *pl = a.part_label + ((size_t)q * kRerankParts + part) * a.k;
+  if ((uint32_t)lane < a.k) {
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(pd) + lane, __float_as_uint(top.d[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(pl + lane, top.lab[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // No fences: an agent-scope release / acquire on this multi-die part writes back / invalidates a whole L2 (measured: the
+  // kernel went from 134 to 329 us with them).  The partial list is written with device-coherent stores (sc1: they pass
+  // the die's L2), the wave waits until they are acknowledged, THEN lane 0 bumps the counter at the same coherence point;
+  // the last block reads the lists with device-coherent loads.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint32_t arrived = 0;
+  if (lane == 0) arrived = __hip_atomic_fetch_add(a.done_cnt + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+  if (arrived != kRerankParts - 1) return;
+  for (uint32_t p2 = 0; p2 < kRerankParts; ++p2) {
+    if (p2 == part) continue;
+    float dist = __builtin_inff();
+    uint64_t lab = kNoLabel;
+    if ((uint32_t)lane < a.k) {
+      const size_t at = ((size_t)q * kRerankParts + p2) * a.k + lane;
+      dist = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(a.part_dist) + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      lab = __hip_atomic_load(a.part_label + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    absorb(dist, lab);
+  }
+  // rank sort of the kept entries by (distance, label) (labels are unique, so are the keys), padding, count
+  const uint32_t cnt = top.cnt;
+  float *od = m.out_dist + (size_t)q * m.out_ld;
+  uint64_t *ol = m.out_label + (size_t)q * m.out_ld;
+  for (uint32_t s2 = a.k + lane; s2 < m.out_ld; s2 += kWave) { od[s2] = __builtin_inff(); ol[s2] = kNoLabel; }
+  uint32_t rank = 0;
+  for (uint32_t t = 0; t < cnt; ++t) {
+    const float td = readlane_f32(top.d[0], (int)t);
+    const uint64_t tl = readlane_u64(top.lab[0], (int)t);
+    rank += dl_less(td, tl, top.d[0], top.lab[0]) ? 1u : 0u;
+  }
+  if ((uint32_t)lane < cnt) { od[rank] = top.d[0]; ol[rank] = top.lab[0]; }
+  if ((uint32_t)lane >= cnt && (uint32_t)lane < a.k) { od[lane] = __builtin_inff(); ol[lane] = kNoLabel; }
+  if (lane == 0) m.out_n[q] = cnt;
+}
+
+hipError_t launch_flat_rerank(const FlatScanArgs &a, const MergeArgs &m_in, bool l2, bool bf16, hipStream_t s) {
+  if (a.nq == 0) return hipSuccess;
+  if (a.k == 0 || a.k > 64 || a.cand_row == nullptr || a.done_cnt == nullptr || a.nrp != (uint32_t)kRerankParts || m_in.q_index || m_in.run_flag ||
+      a.run_flag)
+    return hipErrorInvalidValue;
+  MergeArgs m = m_in;
+  if (m.out_ld < a.k) m.out_ld = a.k;
+  const size_t lds = std::max<size_t>((size_t)a.chunks * 64, ((size_t)3 * a.k + 2) * 12);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const void *f = l2 ? (bf16 ? reinterpret_cast<const void *>(&flat_rerank_kernel<true, true>) : reinterpret_cast<const void *>(&flat_rerank_kernel<true, false>))
+                     : (bf16 ? reinterpret_cast<const void *>(&flat_rerank_kernel<false, true>) : reinterpret_cast<const void *>(&flat_rerank_kernel<false, false>));
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  FlatScanArgs args = a;
+  void *params[] = {&args, &m};
+  return hipLaunchKernel(f, dim3(a.nq * kRerankParts), dim3(256), params, lds, s);
+}
+
 // Which query a merge block serves, and whether it has anything to do.  Plain launch: block b = query b.  Redo mode
 // (MergeArgs::q_index): block b = compact query b < *nq_dev, lists at index b, output of query q_index[b].  A query the
 // candidate filter handed over (ovf_q) is appended to the redo list and left to the exact pass.

@@ -55,6 +55,9 @@ struct FlatScanArgs {
   // *run_flag == run_if, or -- with run_hi != 0 -- unless run_if <= *run_flag <= run_hi
   const uint32_t *run_flag;
   uint32_t run_if, run_hi;
+  // fused re-rank (flat_rerank_kernel): per query the number of its blocks that have written their partial list (zeroed by
+  // flat_qprep_kernel); the block that arrives last merges them and writes the answer
+  uint32_t *done_cnt;
 };
 constexpr uint32_t kSpillChunk = 4096;      // entries per spill chunk of the candidate filter's survivor lists
 constexpr uint32_t kSpillPerQuery = 32;     // chunks one query may take (131072 survivors beyond its private list)
@@ -126,6 +129,7 @@ struct FlatFilterArgs {
   uint32_t n_chunks;
   uint32_t *redo_cnt;         // [1] length of the redo list the final merge builds (zeroed by qprep)
   uint32_t *ovf_q;            // [nq] raised for a query that lost survivors (or cannot go through f16): the exact pass answers it
+  uint32_t *done_cnt;         // [nq] the fused re-rank's arrival counters (zeroed by qprep; nullptr = not used)
   // sample pass (mode 1): instead of gating, every (group of 64 rows, query) writes a LOWER BOUND of the group's best
   // exact score -- its best approximate score minus the margin -- to smax[q * smax_ld + group]; the k-th largest
   // of a query's group bounds bounds its k-th best exact score from below (k distinct rows reach it)
@@ -335,6 +339,8 @@ hipError_t launch_flat_scan(const FlatScanArgs &a, bool l2, bool bf16, int qb, i
 hipError_t launch_merge_topk(const MergeArgs &a, int e, uint64_t nq, hipStream_t s);
 hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipStream_t s);
 // the answer of an empty index / shard: out_n = 0, every entry (+inf, kNoLabel)
+// fused re-rank + selection of the candidate filter's survivors (k <= 64): one block per query writes the query's answer
+hipError_t launch_flat_rerank(const FlatScanArgs &a, const MergeArgs &m, bool l2, bool bf16, hipStream_t s);
 hipError_t launch_fill_empty(float *out_dist, uint64_t *out_label, uint32_t *out_n, uint32_t nq, uint32_t k, hipStream_t s);
 // bound[q] = out_dist[q][k-1] if the query found k entries, +inf otherwise; bound[nq + q] = the same as an
 // order-preserving u32 key (the buffer holds 2*nq words)

@@ -33,12 +33,12 @@ enum OptId : uint32_t {
   kOptKernelTiming,         // 1 = HIP event pairs around the dominant kernel's launches (vk_index_stats.filter_kernel_ns)
   // ---- FLAT: kernel selection and the candidate filter (K4h) ------------------------------------------------------------
   kOptFlatFilter, kOptFilterMinQueries, kOptFilterMinRows, kOptFilterPrepassRows, kOptFilterCap, kOptFilterSpillChunks,
-  kOptFilterBDma, kOptFilterRowDma, kOptFilterBf16Mfma, kOptFilterTilePrune, kOptFlatForceScan, kOptFlatGraph,
+  kOptFilterBDma, kOptFilterRowDma, kOptFilterBf16Mfma, kOptFlatForceScan, kOptFlatFusedRerank,
   kOptGemmLockstep, kOptGemmPrepassRows, kOptGemmContig, kOptScanMinNrp, kOptUploadParallel,
   // ---- HNSW ----------------------------------------------------------------------------------------------------------------
   kOptHnswDeviceBuild, kOptHnswBuildBatch, kOptHnswBuildMinGraph, kOptHnswBuildMinBatch, kOptHnswBuildFrac,
   kOptHnswBuildVerbose, kOptHnswPoolFloor, kOptHnswGpoolCap, kOptHnswVisitedHash, kOptHnswHashPerEf, kOptHnswHashLog2,
-  kOptHnswPoolBytes, kOptHnswVisitedBytes, kOptHnswRedoBytes, kOptHnswVisitedDedup,
+  kOptHnswPoolBytes, kOptHnswVisitedBytes, kOptHnswRedoBytes,
   // ---- sharded index ---------------------------------------------------------------------------------------------------
   kOptShardThreads, kOptShardAllowStaged,
   kOptCount
@@ -69,9 +69,8 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"filter-bdma", "VK_FILTER_BDMA", 1, 0, 1},
       {"filter-row-dma", "VK_FILTER_DMA", 1, 0, 1},
       {"filter-bf16-mfma", "VK_FILTER_BF16_MFMA", 1, 0, 1},
-      {"filter-tile-prune", "VK_FILTER_TILE_PRUNE", 1, 0, 1},
       {"flat-force-scan", "VK_FLAT_FORCE_SCAN", 0, 0, 1},
-      {"flat-graph", "VK_FLAT_GRAPH", 1, 0, 1},
+      {"flat-fused-rerank", "VK_FLAT_FUSED_RERANK", 1, 0, 1},
       {"gemm-lockstep", "VK_GEMM_LOCKSTEP", 1, 0, 64},
       {"gemm-prepass-rows", "VK_GEMM_PREPASS", 16384, 0, kMax},
       {"gemm-contig", "VK_GEMM_CONTIG", 1, 0, 1},
@@ -91,7 +90,6 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"hnsw-pool-bytes", "VK_HNSW_POOL_BYTES", (uint64_t)4 << 30, 1u << 20, kMax},
       {"hnsw-visited-bytes", "VK_HNSW_VISITED_BYTES", (uint64_t)4 << 30, 1u << 20, kMax},
       {"hnsw-redo-bytes", "VK_HNSW_REDO_BYTES", (uint64_t)2 << 30, 1u << 20, kMax},
-      {"hnsw-visited-dedup", "VK_HNSW_VISITED_DEDUP", 1, 0, 1},
       {"shard-threads", "VK_SHARD_THREADS", 1, 0, 1},
       {"shard-allow-staged", "VK_SHARD_ALLOW_STAGED", 0, 0, 1},
   };
