@@ -1100,7 +1100,8 @@ def main():
     if filt_n and world == 1:
         ix.search_batch(Q.cpu().numpy(), K)
         st_f = ix.stats()
-        filt_stats = {"survivors_per_query": round(st_f.last_filter_candidates / B, 1), "queries_handed_over": int(st_f.last_filter_fallback)}
+        filt_stats = {"survivors_per_query": round(st_f.last_filter_candidates / B, 1), "reranked_per_query": round(st_f.last_filter_reranked / B, 1),
+                      "queries_handed_over": int(st_f.last_filter_fallback)}
     result_d = (fin_d if world > 1 else out_d).cpu().numpy()
     result_l = (fin_l if world > 1 else out_l).cpu().numpy().view(np.uint64)
 

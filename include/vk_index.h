@@ -164,6 +164,9 @@ typedef struct vk_index_stats {
   /* sharded index: fan-outs whose per-shard lists were gathered by the RCCL all-gather (option shard-gather = 1) instead of
    * peer copies */
   uint64_t rccl_gathers;
+  /* batched FLAT through the candidate filter, most recent batch (host entry points): survivors that passed the re-rank's
+   * second bound -- the rows that actually got an exact distance -- summed over the queries */
+  uint64_t last_filter_reranked;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------

@@ -556,3 +556,60 @@ def test_fused_rerank_equals_the_two_launch_rerank(vsa, oracle, metric, dtype):
     for i in (0, 3, 11, 40, 76):
         od, ol = o.search(Q[i], 10)
         assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist(), i
+
+
+@pytest.mark.parametrize("metric,dtype", [("COSINE", "f32"), ("L2", "f32"), ("IP", "bf16")])
+def test_second_bound_of_the_rerank_changes_nothing_but_the_work(vsa, oracle, metric, dtype):
+    """r04: the filter hands every survivor's approximate score to the re-rank; the k-th largest (score - margin) of a
+    query's survivors bounds its k-th best exact score from below -- from the whole index, not from the sample -- and only
+    survivors whose (score + margin) reaches it get an exact distance (option filter-second-bound, vk_index_stats.
+    last_filter_reranked).  Same answers with the option off, far fewer rows evaluated with it on: short lists (one block
+    per query, the list in registers), a list of 20 000 duplicates (spill chunks, eight blocks, the walk), ties at the
+    k-th distance, an allow-bitmap, a private list cut to 64 entries (option filter-cap), k = 1 / 10 / 64."""
+    rng = np.random.default_rng(77)
+    n, dim = 90_000, 96
+    centres = rng.standard_normal((40, dim)).astype(np.float32)
+    x = (centres[rng.integers(0, 40, n)] + 0.3 * rng.standard_normal((n, dim)).astype(np.float32)).astype(np.float32)
+    x[5000:5300] = x[4999]                               # ties at the k-th distance
+    x[30_000:50_000] = x[7]                              # one query's survivors by the ten thousand
+    if metric == "COSINE":
+        x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    Q = (centres[rng.integers(0, 40, 77)] + 0.3 * rng.standard_normal((77, dim)).astype(np.float32)).astype(np.float32)
+    Q[3], Q[11] = x[7], x[4999]
+    if metric == "COSINE":
+        Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    labels = rng.permutation(2 * n)[:n].astype(np.uint64)
+    nb = int(labels.max()) + 1
+    bits = oracle.allow_bitmap(labels[rng.random(n) < 0.3], nb)
+    for cap in (8192, 64):
+        ix = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype,
+                       options={"filter-prepass-rows": 1024, "filter-min-rows": 32768, "filter-cap": cap})
+        ix.add_batch(x, labels)
+        for k in (1, 10, 64):
+            for kw in ({}, {"allow": bits, "allow_nbits": nb}):
+                ix.set_option("filter-second-bound", 1)
+                a = ix.search_batch(Q, k, **kw)
+                st = ix.stats()
+                assert st.last_filter_candidates > 0 and st.last_filter_fallback == 0
+                ix.set_option("filter-second-bound", 0)
+                b = ix.search_batch(Q, k, **kw)
+                s0 = ix.stats()
+                assert s0.last_filter_candidates == st.last_filter_candidates
+                assert a[2].tolist() == b[2].tolist() and (a[1] == b[1]).all() and (a[0].view(np.uint32) == b[0].view(np.uint32)).all(), (cap, k, bool(kw))
+                # without the bound every stored survivor is evaluated; with it a fraction (the duplicates all stay: ties)
+                assert st.last_filter_reranked <= s0.last_filter_reranked
+                if cap == 8192 and not kw and k == 10:
+                    assert s0.last_filter_reranked == s0.last_filter_candidates
+                    dup = 20_000 + 300                   # the two queries sitting on duplicated rows keep all of them
+                    assert st.last_filter_reranked - dup < (s0.last_filter_reranked - dup) // 2, (st.last_filter_reranked, s0.last_filter_reranked)
+        ix.set_option("filter-second-bound", 1)
+        D, L, N = ix.search_batch(Q, 10)
+        xs = x
+        if dtype == "bf16":
+            u = x.view(np.uint32).astype(np.uint64)
+            xs = ((((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32)).view(np.float32)
+        o = oracle.Flat(dim, metric, max_elements=n)
+        o.add_many(xs, labels)
+        for i in (0, 3, 11, 40, 76):
+            od, ol = o.search(Q[i], 10)
+            assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist(), (cap, i)

@@ -116,3 +116,35 @@ def test_default_choice_small_graph_keeps_the_bitmap_and_filters_never_hash(vsa,
         od, ol = o2.search(Q[i], 10, ef=64, allow=bits, allow_nbits=n)
         assert L[i, :N[i]].tolist() == ol.tolist()
         assert D[i, :N[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("ef,k,log2", [(32, 10, None), (128, 10, None), (300, 40, None), (700, 20, None), (64, 10, 7), (128, 10, 9)])
+def test_other_ways_of_keeping_the_hash_set_match_the_oracle(vsa, oracle, mode, ef, k, log2):
+    """r04, option hnsw-visited-mode: 1 = the compare-and-swap at WAVEFRONT scope (the set is private to its wave), 2 = the
+    table in buckets of eight ids whose fill counts live in LDS -- a look-up is a 32-byte read (none at all when the
+    bucket is empty), an insert a store nobody waits for, no atomic ever touches memory.  Measured on the 10M graph
+    (profiles/r04_hnsw_visited_modes.log) all three run within 3 % of each other: what the visited set costs is its
+    accesses' place in the memory system's mix, not how they are made.  Same ids, distance bits and work counters as
+    the oracle on the same graph, including the queries a small table sends to the second launch."""
+    rng = np.random.default_rng(1000 + ef + mode)
+    n, dim, M = 5000, 48, 8
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    env = {"VK_HNSW_VISITED_HASH": 2, "VK_HNSW_VISITED_MODE": mode}
+    if log2:
+        env["VK_HNSW_HASH_LOG2"] = log2
+    with _Env(**env):
+        g = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=M, ef_construction=40, build_threads=4)
+    assert g.get_option("hnsw-visited-mode") == mode
+    g.add_batch(x)
+    g.flush()
+    o = oracle.HNSW.from_product_index(g.save_raw, dim, "L2", M, ef_construction=40)
+    Q = rng.standard_normal((70, dim)).astype(np.float32)
+    st = _check(g, o, Q, k, ef)
+    if log2 == 7:
+        assert st.last_frontier_redo > 0
+    if log2 is None:
+        assert st.last_frontier_redo == 0
+    # the mode is a run-time option: back to the default on the same index, same answers
+    g.set_option("hnsw-visited-mode", 0)
+    _check(g, o, Q[:20], k, ef)

@@ -52,7 +52,8 @@ class Stats(C.Structure):
                 ("total_n_eval", C.c_uint64), ("total_n_hops", C.c_uint64), ("tombstoned_bytes", C.c_uint64),
                 ("latency_hist", C.c_uint64 * 16), ("latency_sum_ns", C.c_uint64),
                 ("submitted", C.c_uint64), ("rejected", C.c_uint64), ("queued_now", C.c_uint64),
-                ("max_batches_in_flight", C.c_uint64), ("rccl_gathers", C.c_uint64)]
+                ("max_batches_in_flight", C.c_uint64), ("rccl_gathers", C.c_uint64),
+                ("last_filter_reranked", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)

@@ -294,4 +294,20 @@ __device__ __forceinline__ bool allow_bit(const uint64_t *__restrict__ bits, uin
   return (bits[label >> 6] >> (label & 63)) & 1ull;
 }
 
+// ---- candidate filter: what both the gate (flat_filter.hip) and the re-rank's second bound (flat_scan.hip) compute ----
+// The bound on |approximate score - the reference's exact score| for a row of norm <= R against a query whose error
+// polynomial is co = (c2, c1, c0, state) (flat_qprep_kernel): c2 R^2 + c1 R + c0 (c2 = 0 in the inner-product space).
+template <bool kL2> __device__ __forceinline__ float filter_margin(float c2, float c1, float c0, float R) {
+  if constexpr (kL2) return fmaf(fmaf(c2, R, c1), R, c0);
+  else return fmaf(c1, R, c0);
+}
+// order-preserving key of a float: larger float <-> larger key (NaN must not get here)
+__device__ __forceinline__ uint32_t desc_key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float desc_key_float(uint32_t key) {
+  return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+}
+
 }  // namespace vk

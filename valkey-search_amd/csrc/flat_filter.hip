@@ -231,6 +231,7 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
   if (j < a.nq) {
     a.cand_cnt[j] = 0u;
     if (a.done_cnt) a.done_cnt[j] = 0u;
+    if (a.rerank_cnt) a.rerank_cnt[j] = 0u;
     const float qn = sqrtf(n2) * 1.0001f;
     const float D = (float)a.row_stride_f;
     // see the header: relative part, absolute (subnormal) part, the reference's own rounding, 1 - dot (2^-23 (1 + R |q|)
@@ -266,10 +267,6 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
 // ---- bound selection --------------------------------------------------------------------------------------------------
 // qbound[q] = the k-th largest of the query's group bounds (sample pass), found by a binary descent over the
 // order-preserving keys: one block per query, up to 64 values per thread in registers, one barrier per bit.
-__device__ __forceinline__ uint32_t desc_key(float f) {   // larger float <-> larger key (NaN never reaches here)
-  const uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
 template <int kPer>
 __global__ __launch_bounds__(256) void flat_bound_select_kernel(FlatBoundArgs a) {
   __shared__ uint32_t s_cnt[2][4];
@@ -290,8 +287,9 @@ __global__ __launch_bounds__(256) void flat_bound_select_kernel(FlatBoundArgs a)
     return t;
   };
   // T = the largest key with count(key >= T) >= k, i.e. the k-th largest key (0 if there are fewer than k values)
+  // (the top 20 bits: a bound 2^-11 short of the k-th largest group bound is as valid and costs twelve barriers less)
   uint32_t T = 0;
-  for (int bit = 31; bit >= 0; --bit) {
+  for (int bit = 31; bit >= 12; --bit) {
     const uint32_t cand = T | (1u << bit);
     uint32_t c = 0;
 #pragma unroll
@@ -319,10 +317,12 @@ hipError_t launch_flat_bound_select(const FlatBoundArgs &a, hipStream_t s) {
 // append is an atomicAdd that RETURNS the slot, a round trip of a microsecond or two -- paid per survivor it sat on the
 // critical path of every row tile (some wave of the block nearly always had one, and the block's barrier waits for it).
 struct SurvivorRing {
-  uint32_t *q;     // [64] LDS
-  uint32_t *row;   // [64] LDS
+  // [64][3] LDS: (query, row slot, the pair's approximate score -- the re-rank's second bound works on these) side by side,
+  // so that an entry is ONE LDS store of the consumer wave that found it (three dwords, stride 3: no bank conflicts)
+  uint32_t *ent;
   uint32_t cnt;    // wave-uniform
 };
+constexpr int kRingWords = 3 * kWave;   // LDS words of one wave's ring
 // A query's private list is full: the survivor goes to the query's spill chunks, handed out from a pool shared by the
 // batch.  A chunk slot goes 0 (none) -> 1 (claimed: its chunk is being taken from the pool) -> id + 2, or kNoChunk when
 // the pool is empty.  Exactly one thread claims a slot, so no chunk is ever lost; the others wait for the id.  Inside
@@ -333,11 +333,13 @@ constexpr uint32_t kChunkClaimed = 1u, kNoChunk = 0xFFFFFFFFu;
 __device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing &r, uint32_t lane) {
   bool spill = false;
   uint32_t q = 0, row = 0, j = 0;
+  float val = 0.f;
   if (lane < r.cnt) {
-    q = r.q[lane];
-    row = r.row[lane];
+    q = r.ent[lane * 3];
+    row = r.ent[lane * 3 + 1];
+    val = __uint_as_float(r.ent[lane * 3 + 2]);
     const uint32_t at = atomicAdd(&a.cand_cnt[q], 1u);
-    if (at < a.cap) a.cand_row[(size_t)q * a.cap + at] = row;
+    if (at < a.cap) { a.cand_row[(size_t)q * a.cap + at] = row; a.cand_val[(size_t)q * a.cap + at] = val; }
     else { spill = true; j = at - a.cap; }
   }
   r.cnt = 0;
@@ -360,8 +362,10 @@ __device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing
     while ((id = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == kChunkClaimed) __builtin_amdgcn_s_sleep(1);
   }
   if (spill) {
-    if (id != kNoChunk) a.spill[(size_t)(id - 2u) * kSpillChunk + j % kSpillChunk] = row;
-    else __hip_atomic_store(a.ovf_q + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (id != kNoChunk) {
+      a.spill[(size_t)(id - 2u) * kSpillChunk + j % kSpillChunk] = row;
+      a.spill_val[(size_t)(id - 2u) * kSpillChunk + j % kSpillChunk] = val;
+    } else __hip_atomic_store(a.ovf_q + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -372,8 +376,8 @@ __device__ __forceinline__ void ring_flush(const FlatFilterArgs &a, SurvivorRing
 template <bool kL2> struct GateCol { float c1, c0, bound; };
 template <> struct GateCol<true> { float c2, c1, c0, bound; };
 template <bool kL2> __device__ __forceinline__ float tile_margin(const GateCol<kL2> &c, float R) {
-  if constexpr (kL2) return fmaf(fmaf(c.c2, R, c.c1), R, c.c0);
-  else return fmaf(c.c1, R, c.c0);
+  if constexpr (kL2) return filter_margin<true>(c.c2, c.c1, c.c0, R);
+  else return filter_margin<false>(0.f, c.c1, c.c0, R);
 }
 __device__ __forceinline__ float tile_norm(uint32_t r_bits) { return __uint_as_float(r_bits); }   // (row_stats rounded it up)
 template <bool kL2> __device__ __forceinline__ float gate_thr(const GateCol<kL2> &c, uint32_t norm_bits) {
@@ -419,11 +423,21 @@ __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&ac
 #pragma unroll
       for (int r = 0; r < 16; ++r) mk |= !(acc[rt][r] < thr) ? 1u << r : 0u;
       if (q >= a.nq) mk = 0;
+      // (... or whose one passing register is not its maximum: a NaN, which fmaxf dropped)
+      const bool multi = __builtin_amdgcn_ballot_w64(__builtin_popcount(mk) > 1 || (mk != 0 && m < thr)) != 0;
       while (__builtin_amdgcn_ballot_w64(mk != 0) != 0) {
         const uint32_t r = (uint32_t)__builtin_ctz(mk | 0x10000u);
         const uint32_t row = tile_row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         bool pass = mk != 0 && row < a.n_rows;
         if (pass && a.allow_bits != nullptr) pass = allow_bit(a.allow_bits, a.allow_nbits, a.labels[row]);
+        // the pair's approximate score, for the re-rank's second bound: a lane with ONE passing register holds it already
+        // -- the maximum it just took -- and only a block in which some lane has several picks register r out of the
+        // sixteen (a chain of selects: 25 us of the launch when every survivor paid for it)
+        float score = m;
+        if (multi) {
+#pragma unroll
+          for (int r2 = 0; r2 < 16; ++r2) score = r == (uint32_t)r2 ? acc[rt][r2] : score;
+        }
         mk &= mk - 1;
         const uint64_t pm = __builtin_amdgcn_ballot_w64(pass);
         if (pm != 0) {
@@ -431,8 +445,9 @@ __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&ac
           if (ring.cnt + n > kWave) ring_flush(a, ring, lane);
           if (pass) {
             const uint32_t at = ring.cnt + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-            ring.q[at] = q;
-            ring.row[at] = row;
+            ring.ent[at * 3] = q;
+            ring.ent[at * 3 + 1] = row;
+            ring.ent[at * 3 + 2] = __float_as_uint(score);
           }
           ring.cnt += n;
         }
@@ -690,8 +705,8 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   extern __shared__ _Float16 lds_a[];
   constexpr uint32_t kBufHalfs = kFTileRows * kFAStride;                    // one A stage
   uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + (kDma ? kDmaRing * kDmaStageBytes / 2 : 2 * kBufHalfs));   // [2][kWsBStage]
-  uint32_t *lds_ring = reinterpret_cast<uint32_t *>(lds_b + (kBDma ? kBRing : 2) * kWsBStage); // [4 consumer waves][2][64]
-  uint32_t *hn_lds = lds_ring + 4 * 2 * kWave;                              // [2][128] (kL2)
+  uint32_t *lds_ring = reinterpret_cast<uint32_t *>(lds_b + (kBDma ? kBRing : 2) * kWsBStage); // [4 consumer waves][3][64]
+  uint32_t *hn_lds = lds_ring + 4 * kRingWords;                              // [2][128] (kL2)
   // [2]: cancellation seen during tile T -> word T & 1.  (An LDS-qualified pointer: through a generic one the accesses
   // become FLAT instructions, whose out-of-order return forces every later wait for a load to be vmcnt(0).)
   volatile __attribute__((address_space(3))) uint32_t *lds_stop =
@@ -1033,8 +1048,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   // ================================== consumer ===========================================================
   const uint32_t li = lane & 31, g = lane >> 5;
   SurvivorRing ring;
-  ring.q = lds_ring + wave * 2 * kWave;
-  ring.row = ring.q + kWave;
+  ring.ent = lds_ring + wave * kRingWords;
   ring.cnt = 0;
   const bool has_q = wave * 2 < a.nqt;
   // per query tile of the wave: the column's gate (bound + error polynomial), or in sample mode its margin at the norm cap
@@ -1278,9 +1292,9 @@ __global__ __launch_bounds__(kFatThreads, 1) void flat_filter_fat_kernel(FlatFil
   if constexpr (kDbg) dbg_start = __builtin_readcyclecounter();
   extern __shared__ _Float16 lds_a[];                                         // [2][256 rows][72 halfs]
   uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + 2 * kFatABuf);             // [2][kFatBStage]
-  uint32_t *lds_ring = reinterpret_cast<uint32_t *>(lds_b + 2 * kFatBStage);  // [4 waves][2][64]
+  uint32_t *lds_ring = reinterpret_cast<uint32_t *>(lds_b + 2 * kFatBStage);  // [4 waves][3][64]
   volatile __attribute__((address_space(3))) uint32_t *lds_stop =
-      (volatile __attribute__((address_space(3))) uint32_t *)(lds_ring + 4 * 2 * kWave);   // [2], as in the kernel above
+      (volatile __attribute__((address_space(3))) uint32_t *)(lds_ring + 4 * kRingWords);   // [2], as in the kernel above
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t wr = wave >> 1, wc = wave & 1, li = lane & 31, g = lane >> 5;
@@ -1305,8 +1319,7 @@ __global__ __launch_bounds__(kFatThreads, 1) void flat_filter_fat_kernel(FlatFil
     col[qt].bound = (!have || co.w != 0.f) ? __builtin_inff() : a.qbound[jc];
   }
   SurvivorRing ring;
-  ring.q = lds_ring + wave * 2 * kWave;
-  ring.row = ring.q + kWave;
+  ring.ent = lds_ring + wave * kRingWords;
   ring.cnt = 0;
 
   // producer side: stream positions of the next row load (three stages ahead of the multiply) and the next B load (two)
@@ -1483,14 +1496,14 @@ __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_sample_kernel(FlatF
 }
 
 size_t flat_filter_dma_lds_bytes() {
-  return (size_t)kDmaRing * kDmaStageBytes + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 + (size_t)2 * kFTileRows * 4 + 16;
+  return (size_t)kDmaRing * kDmaStageBytes + (size_t)2 * kWsBStage * 16 + (size_t)4 * kRingWords * 4 + (size_t)2 * kFTileRows * 4 + 16;
 }
 size_t flat_filter_bdma_lds_bytes() {
-  return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)kBRing * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 +
+  return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)kBRing * kWsBStage * 16 + (size_t)4 * kRingWords * 4 +
          (size_t)2 * kFTileRows * 4 + 16;
 }
 size_t flat_filter_lds_bytes() {
-  return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)2 * kWsBStage * 16 + (size_t)4 * 2 * kWave * 4 +
+  return (size_t)2 * kFTileRows * kFAStride * sizeof(_Float16) + (size_t)2 * kWsBStage * 16 + (size_t)4 * kRingWords * 4 +
          (size_t)2 * kFTileRows * 4 + 16;   // (+ the stop words)
 }
 
@@ -1507,7 +1520,7 @@ hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
 
 #ifdef VK_EXPERIMENTS
 size_t flat_filter_fat_lds_bytes() {
-  return (size_t)2 * kFatABuf * sizeof(_Float16) + (size_t)2 * kFatBStage * 16 + (size_t)4 * 2 * kWave * 4 + 16;
+  return (size_t)2 * kFatABuf * sizeof(_Float16) + (size_t)2 * kFatBStage * 16 + (size_t)4 * kRingWords * 4 + 16;
 }
 // the four-fat-waves kernel serves the final pass in the inner-product space (experiments build, VK_FILTER_FAT=1)
 bool flat_filter_fat_enabled(const FlatFilterArgs &a) {

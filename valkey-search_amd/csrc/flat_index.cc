@@ -300,7 +300,9 @@ Status Index::search_labels(const float *query, uint64_t k, const uint64_t *labe
 // final pass of every FLAT index of the process dumps its gate's view into.  Process-wide on purpose -- one test, one index.
 struct ExpFilterDump { float *scores = nullptr, *thr = nullptr, *qstate = nullptr; uint32_t rows = 0, ld = 0; };   // qstate: [6][ld] = c2, c1, c0, closed | L_q | margin at the norm cap
 static ExpFilterDump g_exp_dump;
+static unsigned long long *g_exp_rerank_stamps = nullptr;   // [nq][16], device memory (vk_exp_rerank_stamps)
 }  // namespace vk
+extern "C" __attribute__((visibility("default"))) void vk_exp_rerank_stamps(unsigned long long *d_stamps) { vk::g_exp_rerank_stamps = d_stamps; }
 extern "C" __attribute__((visibility("default"))) void vk_exp_filter_dump(float *d_scores, float *d_thr, float *d_qstate, uint32_t rows, uint32_t ld) {
   vk::g_exp_dump.scores = d_scores;
   vk::g_exp_dump.thr = d_thr;
@@ -423,8 +425,11 @@ class FlatIndex final : public Index {
     }
     if (filter_used_) {   // survivor counts + the number of handed-over queries of the candidate filter, for vk_index_stats
       // (layout of the batch's words: scan_filter -- [nq] counts | [nq] flags | spill_next, redo_cnt, ...)
-      VK_TRY(ctx->h_tmp.ensure(rq.nq * 8 + 8));
+      // ... | [nq] redo list | [nq][kSpillPerQuery] chunk slots | [nq] arrival counters | [nq] rows the re-rank evaluated
+      VK_TRY(ctx->h_tmp.ensure(rq.nq * 12 + 8));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_fcnt.p, rq.nq * 8 + 8, hipMemcpyDeviceToHost, ctx->stream));
+      VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.as<char>() + rq.nq * 8 + 8, ctx->d_fcnt.as<uint32_t>() + (4 + 4 * rq.nq + rq.nq * kSpillPerQuery),
+                                rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     VK_TRY(ctx->wait(rq.cancel_flag));   // (a raised flag stops the kernels: the answer is what they had, bruteforce.h:129)
     if (filter_used_) {
@@ -433,9 +438,13 @@ class FlatIndex final : public Index {
       for (uint64_t q = 0; q < rq.nq; ++q) sum += c[q];
       last_filter_cands_ = sum;
       last_filter_fallback_ = c[2 * rq.nq + 1];   // queries the exact redo pass answered
+      uint64_t rr = 0;
+      for (uint64_t q = 0; q < rq.nq; ++q) rr += c[2 * rq.nq + 2 + q];
+      last_filter_reranked_ = rr;                 // rows that got an exact distance
     } else {
       last_filter_cands_ = 0;
       last_filter_fallback_ = 0;
+      last_filter_reranked_ = 0;
     }
     // caller's buffers are [nq][rq.k]
     for (uint64_t q = 0; q < rq.nq; ++q) {
@@ -552,6 +561,7 @@ class FlatIndex final : public Index {
     out->max_level = -1;
     out->last_filter_candidates = last_filter_cands_;
     out->last_filter_fallback = last_filter_fallback_;
+    out->last_filter_reranked = last_filter_reranked_;
     (void)hipSetDevice(store_.device());
     pool_.for_each_free([&](SearchCtx *c) { for (auto &tp : c->timed) drain_timed(tp); });
     // (with kernel-timing on the time covers exactly the batches counted; off: batches are still counted, the time stands still)
@@ -966,11 +976,11 @@ class FlatIndex final : public Index {
     // per-batch words: [nq] survivor counts | [nq] hand-over flags | [4] spill_next, redo_cnt | [nq] redo list | [nq][32] chunk slots
     // ... | [nq] arrival counters of the fused re-rank
     const size_t w_cnt = 0, w_ovf = nq, w_misc = 2 * nq, w_redo = 2 * nq + 4, w_chunk = 3 * nq + 4, w_done = w_chunk + nq * kSpillPerQuery;
-    VK_TRY(ctx->d_fcnt.ensure((w_done + nq) * 4));
+    VK_TRY(ctx->d_fcnt.ensure((w_done + 2 * nq) * 4));          // (... | [nq] rows the re-rank evaluated)
     VK_TRY(ctx->d_fq16.ensure((size_t)nqt * 32 * dp * 2));
     VK_TRY(ctx->d_fthr.ensure((size_t)nqt * 32 * (16 + 4 + 4)));      // error polynomials, then bounds, then witness margins
-    VK_TRY(ctx->d_fcand.ensure(nq * (size_t)cap * 4));
-    VK_TRY(ctx->d_fspill.ensure((size_t)n_chunks * kSpillChunk * 4));
+    VK_TRY(ctx->d_fcand.ensure(nq * (size_t)cap * 8));                 // row slots, then the scores
+    VK_TRY(ctx->d_fspill.ensure((size_t)n_chunks * kSpillChunk * 8));
     VK_TRY(ctx->d_fsmax.ensure(nq * (size_t)smax_ld * 4));
     VK_TRY(ctx->d_fpart_d.ensure(nq * per_q * 4));
     VK_TRY(ctx->d_fpart_l.ensure(nq * per_q * 8));
@@ -1014,13 +1024,16 @@ class FlatIndex final : public Index {
     f.tile_norm = d_tile_norm_.as<uint32_t>();
     f.cand_cnt = words + w_cnt;
     f.cand_row = ctx->d_fcand.as<uint32_t>();
+    f.cand_val = reinterpret_cast<float *>(f.cand_row + nq * (size_t)cap);
     f.cap = cap;
     f.qchunk = words + w_chunk;
     f.spill = ctx->d_fspill.as<uint32_t>();
+    f.spill_val = reinterpret_cast<float *>(f.spill + (size_t)n_chunks * kSpillChunk);
     f.spill_next = words + w_misc;
     f.n_chunks = n_chunks;
     f.ovf_q = words + w_ovf;
     f.done_cnt = words + w_done;
+    f.rerank_cnt = words + w_done + nq;
     f.smax = ctx->d_fsmax.as<float>();
     f.smax_ld = smax_ld;
     f.smax_fine = fine ? 1 : 0;
@@ -1044,9 +1057,11 @@ class FlatIndex final : public Index {
         fg.qwit = base.qwit + c0;
         fg.cand_cnt = base.cand_cnt + c0;
         fg.cand_row = base.cand_row + c0 * cap;
+        fg.cand_val = base.cand_val + c0 * cap;
         fg.qchunk = base.qchunk + c0 * kSpillPerQuery;
         fg.ovf_q = base.ovf_q + c0;
         fg.done_cnt = base.done_cnt + c0;
+        fg.rerank_cnt = base.rerank_cnt + c0;
         fg.smax = base.smax + c0 * smax_ld;
         VK_HIP_TRY(launch_flat_filter(fg, blocks, s));
       }
@@ -1180,6 +1195,16 @@ class FlatIndex final : public Index {
       if (fused) {
         r.cancel = d_cancel;
         r.done_cnt = f.done_cnt;
+        r.reranked = f.rerank_cnt;
+#ifdef VK_EXPERIMENTS
+        r.stamps = g_exp_rerank_stamps;
+#endif
+        if (opt_.get(kOptFilterSecondBound) != 0) {   // the second bound: from the survivors' own approximate scores
+          r.cand_val = f.cand_val;
+          r.cand_spill_val = f.spill_val;
+          r.qcoef = f.qcoef;
+          r.tile_norm = f.tile_norm;
+        }
         VK_HIP_TRY(launch_flat_rerank(r, m, l2(), store_.bf16(), s));
       } else {
         VK_HIP_TRY(launch_merge_topk(m, e, nq, s));
@@ -1212,7 +1237,7 @@ class FlatIndex final : public Index {
   std::atomic<uint32_t> filter_bad_tiles_{0};   // tiles the f16 pipe cannot carry (row_stats_kernel)
   std::mutex stats_mu_;
   uint64_t rewritten_ = 0;                      // rows brought up to date since the last full pass (under stats_mu_)
-  std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0}, filter_ns_total_{0}, filter_batches_{0}, filter_timed_{0};
+  std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0}, last_filter_reranked_{0}, filter_ns_total_{0}, filter_batches_{0}, filter_timed_{0};
   static thread_local bool filter_used_;
   static constexpr uint64_t kGemmMinQueries = 5;    // measured at 10Mx768: K3 4 queries 5.3 ms, 8 queries 11.7 ms; K4 up to 32 queries 6.1 ms
   static constexpr uint64_t kMaxPassK = 1024;

@@ -17,6 +17,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 
@@ -233,10 +235,23 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
 // row of a round is requested together with the row (profiles/r04_step_trace_*.log).
 // A query with tens of thousands of survivors (duplicates of one vector) still spreads over 32 waves.
 constexpr int kRerankParts = 8;
+constexpr uint32_t kRerankSlots = 576;       // LDS row slots per wave: eight steps of 64 entries (a short list's share) + one more
+constexpr uint32_t kRerankSoloMax = 2048;    // survivors one block re-ranks alone
 template <bool kL2, bool kBf16>
 __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeArgs m) {
   extern __shared__ float4 qs[];  // the query ([chunks][4] float4), later the waves' lists
-  const uint32_t q = blockIdx.x / kRerankParts, part = blockIdx.x % kRerankParts;
+#ifdef VK_EXPERIMENTS
+#define VK_STAMP(i) do { if (a.stamps && blockIdx.x < a.nq && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define VK_STAMP(i) do { } while (0)
+#endif
+  VK_STAMP(0);
+  // Grid: the FIRST nq blocks are part 0 of the queries, the other 7 nq are parts 1..7 (query-major).  A short list is
+  // served by its part 0 alone, so the blocks that do the work are dispatched first, all at once, and -- workgroups being
+  // dealt to the eight XCDs round robin by their number -- evenly over the dies; the rest leave as they come.  (With
+  // part = number % 8 every working block sat on XCD 0: the blocks of a batch started over 100 us, each running 28.)
+  const uint32_t q = blockIdx.x < a.nq ? blockIdx.x : (blockIdx.x - a.nq) / (kRerankParts - 1);
+  const uint32_t part = blockIdx.x < a.nq ? 0u : 1u + (blockIdx.x - a.nq) % (kRerankParts - 1);
   // a query the filter handed over (it lost survivors, or cannot go through f16): listed for the exact redo pass, which
   // owns its output
   if (m.ovf_q && m.ovf_q[q]) {
@@ -248,46 +263,121 @@ __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeA
   const int j = lane & 3;
   const int rq = lane >> 2;
   const uint32_t chunks = a.chunks;
-  for (uint32_t i = threadIdx.x; i < chunks * 4; i += blockDim.x)
-    qs[i] = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f)[i];
   const uint32_t c_raw = a.cand_cnt[q];
   const uint32_t most = a.cand_cap + (a.cand_qchunk ? kSpillPerQuery * kSpillChunk : 0u);
   const uint32_t n_rows = c_raw < most ? c_raw : most;
+  VK_STAMP(1);
   const uint32_t *cand = a.cand_row + (size_t)q * a.cand_cap;
   const uint32_t *cand_chunks = a.cand_qchunk ? a.cand_qchunk + (size_t)q * kSpillPerQuery : nullptr;
-  auto cand_at = [&](uint32_t i) -> uint32_t {
+  auto cand_at = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
     if (i < a.cand_cap) return cand[i];
     const uint32_t jj = i - a.cand_cap;
     return a.cand_spill[(size_t)(cand_chunks[jj / kSpillChunk] - 2u) * kSpillChunk + jj % kSpillChunk];   // (slot = chunk + 2)
   };
-  const uint32_t n_tiles = (n_rows + kRowsPerWave - 1) / kRowsPerWave;
+  auto val_at = [&](uint32_t i) __attribute__((always_inline)) -> float {
+    if (i < a.cand_cap) return a.cand_val[(size_t)q * a.cand_cap + i];
+    const uint32_t jj = i - a.cand_cap;
+    return a.cand_spill_val[(size_t)(cand_chunks[jj / kSpillChunk] - 2u) * kSpillChunk + jj % kSpillChunk];
+  };
   constexpr uint32_t kStep = kRerankParts * 4;
   const uint32_t first = part * 4u + (uint32_t)wave;
-  // the first round's row, requested before the block meets (its address does not depend on the query in LDS)
-  uint32_t next_row = 0;
-  if (first < n_tiles) {
-    const uint32_t i = first * kRowsPerWave + rq;
-    next_row = cand_at(i < n_rows ? i : n_rows - 1);
+  uint32_t *my_rows = reinterpret_cast<uint32_t *>(qs + chunks * 4) + wave * kRerankSlots;   // [4 waves][kRerankSlots] behind the query
+  const bool solo = n_rows <= kRerankSoloMax;   // a short list: the query's first block serves it alone
+  if (solo && part != 0) return;
+  for (uint32_t i = threadIdx.x; i < chunks * 4; i += blockDim.x)
+    qs[i] = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f)[i];
+
+  // ---- the second bound (every wave on its own: no barrier, no other wave's result) ----------------------------------
+  // lo_i = score_i - margin_i is a lower bound of survivor i's exact score, hi_i = score_i + margin_i an upper bound
+  // (margin = the query's error polynomial at the row's tile norm: what the gate of flat_filter.hip charges).  k distinct
+  // rows reach the k-th largest lo, so it bounds the k-th best exact score from below; a survivor whose hi stays under it
+  // cannot be among the k best (ties at the k-th score have hi >= score = bound: kept, and settled by the exact
+  // (distance, label) order).  The bound comes from the first kSel survivors (any k distinct rows will do).
+  const bool prune = a.cand_val != nullptr;
+  float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+  float thr2 = -__builtin_inff();
+  // the first kPer * 64 survivors of the list, held in registers: entry u * 64 + lane = (row slot, score, margin).  All of
+  // a step's loads are requested before any is waited for (eight entries per lane at a time: list and scores in one round
+  // trip, the tile norms in a second) -- taken one entry at a time this part alone was 90 us of the kernel.
+  constexpr int kPer = 32;
+  uint32_t rowv[kPer];
+  float valv[kPer], marv[kPer];
+  uint32_t n_sel = n_rows < (uint32_t)(kPer * kWave) ? n_rows : (uint32_t)(kPer * kWave);
+  if (n_sel > a.cand_cap) n_sel = a.cand_cap;                // (the private list: no spill chunks in this part)
+  const uint32_t nu = (n_sel + kWave - 1) / kWave;
+  if (prune) co = a.qcoef[q];
+  // (clamped indices instead of predicates or branches: entries past the list re-read its last one -- one address for the
+  //  whole wave -- and every load of the step goes out back to back)
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const uint32_t i = (uint32_t)u * kWave + lane;
+    const uint32_t ic = i < n_sel ? i : (n_sel ? n_sel - 1 : 0u);
+    rowv[u] = cand[ic];
+    valv[u] = prune ? a.cand_val[(size_t)q * a.cand_cap + ic] : 0.f;
   }
-  __syncthreads();
+#ifdef VK_EXPERIMENTS
+  if (a.stamps && rowv[0] + rowv[kPer - 1] + __float_as_uint(valv[0]) == 0xFFFFFFF1u) return;   // (nothing: keeps the stamp behind the loads)
+#endif
+  VK_STAMP(2);
+#pragma unroll
+  for (int u = 0; u < kPer; ++u)
+    marv[u] = prune ? filter_margin<kL2>(co.x, co.y, co.z, __uint_as_float(a.tile_norm[rowv[u] >> 7])) : 0.f;
+#ifdef VK_EXPERIMENTS
+  if (a.stamps && marv[0] + marv[kPer - 1] == 123.25f) return;
+#endif
+  VK_STAMP(3);
+  if (prune && n_sel >= a.k) {
+    uint32_t key[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const float lo = valv[u] - marv[u];
+      // (0 = below every float: never counted.  NaN, +-inf: a tile outside f16 -- no information)
+      key[u] = ((uint32_t)u * kWave + lane < n_sel && fabsf(lo) < __builtin_inff()) ? desc_key(lo) : 0u;
+    }
+    // T = the largest threshold with kBoundBits significant bits that k keys reach: a lower bound of the k-th largest key,
+    // short of it by less than 2^-(kBoundBits - 9) relative -- a bound need not be tight to the last bit, and every bit is a
+    // dependent step.  The eight compares of a group write eight scalar masks before any is counted (as `c += popc(ballot)`
+    // each compare went through VCC and waited for the count before it: 530 cycles a bit).
+    constexpr int kBoundBits = 20;
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 32 - kBoundBits; --bit) {
+      const uint32_t cnd = T | (1u << bit);
+      uint32_t c = 0;
+      auto count8 = [&](auto G) __attribute__((always_inline)) {
+        constexpr int g = decltype(G)::value;
+        unsigned long long mk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(mk[u]) : "s"(cnd), "v"(key[g + u]));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c += (uint32_t)__builtin_popcountll(mk[u]);
+      };
+      count8(std::integral_constant<int, 0>{});
+      if (nu > 8) count8(std::integral_constant<int, 8>{});
+      if (nu > 16) count8(std::integral_constant<int, 16>{});
+      if (nu > 24) count8(std::integral_constant<int, 24>{});
+      if (c >= a.k) T = cnd;
+    }
+    if (T != 0) {
+      const float b = desc_key_float(T);
+      // (2^-21 max(1, |b|): the rounding of the additions and subtractions on both sides, as in gate_thr)
+      if (b == b) thr2 = b - 0x1p-21f * fmaxf(1.f, fabsf(b));
+    }
+  }
+  VK_STAMP(4);
+  __syncthreads();   // (the query is in LDS)
+  VK_STAMP(5);
 
   WaveTopK<1> top;
   top.init(a.k);
-  uint32_t polled = 0;
-  for (uint32_t tile = first; tile < n_tiles; tile += kStep) {
-    if (a.cancel && (polled++ % kCancelPollTiles) == 0 && poll_cancel(a.cancel)) break;   // bruteforce.h:129
-    const uint32_t i = tile * kRowsPerWave + rq;
-    const bool valid = i < n_rows;
-    const uint32_t row = next_row;
+  // one round: exact distances of the wave's (up to 16) rows in my_rows, one per quad
+  auto round16 = [&](uint32_t off, uint32_t cnt) __attribute__((always_inline)) {
+    const uint32_t row = my_rows[off + ((uint32_t)rq < cnt ? rq : 0)];
+    const bool valid = (uint32_t)rq < cnt;
     const char *__restrict__ base = row_base<kBf16>(a.rows, row, a.row_stride_f);
     const uint64_t row_label = a.labels[row];        // (with the row, not behind its distance)
-    if (tile + kStep < n_tiles) {                     // ... and the next round's list entry
-      const uint32_t i2 = (tile + kStep) * kRowsPerWave + rq;
-      next_row = cand_at(i2 < n_rows ? i2 : n_rows - 1);
-    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t c = 0;
-    constexpr int kXL = 24;     // row pieces in flight per lane: a 768-element row is two round trips
+    constexpr int kXL = 48;     // row pieces in flight per lane: a 768-element row is ONE round trip (the block is alone on its CU's registers)
     for (; c + kXL <= chunks; c += kXL) {
       float4 x[kXL];
 #pragma unroll
@@ -314,7 +404,69 @@ __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeA
       if (!(cd <= top.thr_d)) continue;
       top.insert(cd, readlane_u64(row_label, b), lane);
     }
+  };
+  // The entries that pass the second bound wait in the wave's LDS slots for an exact distance, sixteen at a time.  A short
+  // list (the usual case: a few hundred survivors, a dozen of them kept) is served by the query's FIRST block alone -- the
+  // other seven leave at once and nothing crosses a block.
+  uint32_t kept = 0, pend = 0, polled = 0;
+  // a step's kept entries join the waiting ones in the wave's LDS slots ...
+  auto take = [&](bool keep, uint32_t row) __attribute__((always_inline)) {
+    const uint64_t km = __ballot(keep);
+    if (keep) my_rows[pend + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = row;
+    pend += (uint32_t)__popcll(km);
+    kept += (uint32_t)__popcll(km);
+  };
+  // ... and every full sixteen of them gets its exact distances; what is left (< 16 entries) moves to the front
+  auto flush = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_wave_barrier();
+    uint32_t o = 0;
+    for (; o + kRowsPerWave <= pend; o += kRowsPerWave) round16(o, kRowsPerWave);
+    if (o != 0) {
+      const uint32_t left = pend - o;
+      uint32_t v = 0;
+      if ((uint32_t)lane < left) v = my_rows[o + lane];
+      __builtin_amdgcn_wave_barrier();
+      if ((uint32_t)lane < left) my_rows[lane] = v;
+      __builtin_amdgcn_wave_barrier();
+      pend = left;
+    }
+  };
+  if (solo && n_rows <= n_sel) {
+    // the whole list is in registers: wave w of the block takes the steps u = w, w + 4, ... (at most eight: 512 slots)
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      // (every wave looks at every step and keeps its own: a compile-time register index, a run-time mask)
+      const bool own = (uint32_t)(u & 3) == (uint32_t)wave && (uint32_t)u * kWave + lane < n_rows;
+      if ((uint32_t)u < nu) take(own && !(valv[u] + marv[u] < thr2), rowv[u]);   // ("not below": a NaN stays)
+    }
+  } else {
+    // a long list (spill chunks, or a private list cut short by the option filter-cap): every wave of the query's blocks
+    // walks its own contiguous slice of it, 64 entries per step
+    const uint32_t n_waves = solo ? 4u : kStep, wid = solo ? (uint32_t)wave : first;
+    const uint32_t per = (n_rows + n_waves - 1) / n_waves;
+    const uint32_t s_lo = wid * per < n_rows ? wid * per : n_rows, s_hi = s_lo + per < n_rows ? s_lo + per : n_rows;
+    for (uint32_t base = s_lo; base < s_hi; base += kWave) {
+      if (a.cancel && (polled++ % kCancelPollTiles) == 0 && poll_cancel(a.cancel)) break;   // bruteforce.h:129
+      const uint32_t i = base + lane;
+      bool keep = i < s_hi;
+      uint32_t row = 0;
+      if (keep) {
+        row = cand_at(i);
+        if (prune) {
+          const float R = __uint_as_float(a.tile_norm[row >> 7]);
+          const float hi = val_at(i) + filter_margin<kL2>(co.x, co.y, co.z, R);
+          keep = !(hi < thr2);
+        }
+      }
+      take(keep, row);
+      if (pend + kWave > kRerankSlots) flush();
+    }
   }
+  VK_STAMP(6);
+  flush();
+  VK_STAMP(7);
+  if (pend != 0) round16(0, pend);
+  if (a.reranked && lane == 0 && kept != 0) atomicAdd(a.reranked + q, kept);   // (per query: at most 32 waves meet here)
 
   // waves 1..3 -> LDS -> wave 0 (the query block is done with)
   __syncthreads();
@@ -326,7 +478,8 @@ __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeA
   }
   __syncthreads();
   if (wave > 0) return;
-  auto absorb = [&](float dist, uint64_t lab) {
+  VK_STAMP(8);
+  auto absorb = [&](float dist, uint64_t lab) __attribute__((always_inline)) {
     uint64_t mask = __ballot(lab != kNoLabel && dist <= top.thr_d);
     while (mask) {
       const int b = __ffsll((unsigned long long)mask) - 1;
@@ -342,6 +495,7 @@ __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeA
     if ((uint32_t)lane < a.k) { dist = md[w * a.k + lane]; lab = ml[w * a.k + lane]; }
     absorb(dist, lab);
   }
+  if (!solo) {
   // the block's partial list; the block that arrives last at the query's counter merges all of them
   float *pd = a.part_dist + ((size_t)q * kRerankParts + part) * a.k;
   uint64_t *pl = a.part_label + ((size_t)q * kRerankParts + part) * a.k;
@@ -369,6 +523,7 @@ __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeA
     }
     absorb(dist, lab);
   }
+  }
   // rank sort of the kept entries by (distance, label) (labels are unique, so are the keys), padding, count
   const uint32_t cnt = top.cnt;
   float *od = m.out_dist + (size_t)q * m.out_ld;
@@ -383,6 +538,8 @@ __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeA
   if ((uint32_t)lane < cnt) { od[rank] = top.d[0]; ol[rank] = top.lab[0]; }
   if ((uint32_t)lane >= cnt && (uint32_t)lane < a.k) { od[lane] = __builtin_inff(); ol[lane] = kNoLabel; }
   if (lane == 0) m.out_n[q] = cnt;
+  VK_STAMP(9);
+#undef VK_STAMP
 }
 
 hipError_t launch_flat_rerank(const FlatScanArgs &a, const MergeArgs &m_in, bool l2, bool bf16, hipStream_t s) {
@@ -392,8 +549,9 @@ hipError_t launch_flat_rerank(const FlatScanArgs &a, const MergeArgs &m_in, bool
     return hipErrorInvalidValue;
   MergeArgs m = m_in;
   if (m.out_ld < a.k) m.out_ld = a.k;
-  const size_t lds = std::max<size_t>((size_t)a.chunks * 64, ((size_t)3 * a.k + 2) * 12);
+  const size_t lds = std::max<size_t>((size_t)a.chunks * 64 + 4 * kRerankSlots * 4, ((size_t)3 * a.k + 2) * 12);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (a.cand_val != nullptr && (a.qcoef == nullptr || a.tile_norm == nullptr)) return hipErrorInvalidValue;
   const void *f = l2 ? (bf16 ? reinterpret_cast<const void *>(&flat_rerank_kernel<true, true>) : reinterpret_cast<const void *>(&flat_rerank_kernel<true, false>))
                      : (bf16 ? reinterpret_cast<const void *>(&flat_rerank_kernel<false, true>) : reinterpret_cast<const void *>(&flat_rerank_kernel<false, false>));
   if (lds > 48 * 1024) {

@@ -569,6 +569,7 @@ class HnswIndex final : public Index {
     if (hash_log2) {
       h = a;
       h.vis_hash_log2 = hash_log2;
+      h.vis_mode = (uint32_t)visited_mode_;
       h.bitmap_words = 1u << hash_log2;
       // (its LDS frontier need not hold 2 x ef entries for the worst run of equal distances: a query that fills it is
       // re-run like one that fills its table, and the LDS saved is resident waves at large ef)
@@ -919,6 +920,7 @@ class HnswIndex final : public Index {
   // visited sets as hash tables: 0 never, 1 when it pays (default), 2 always (tests); table words per unit of ef; fixed size
   OptRef visited_hash_{&opt_, kOptHnswVisitedHash};
   OptRef hash_per_ef_{&opt_, kOptHnswHashPerEf};
+  OptRef visited_mode_{&opt_, kOptHnswVisitedMode};
   OptRef hash_log2_forced_{&opt_, kOptHnswHashLog2};
   OptRef pool_bytes_{&opt_, kOptHnswPoolBytes};
   OptRef visited_bytes_{&opt_, kOptHnswVisitedBytes};

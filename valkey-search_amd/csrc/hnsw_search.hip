@@ -44,6 +44,8 @@ namespace {
 constexpr uint32_t kDeleteFlag = 0x00010000u;
 constexpr uint32_t kNoneId = 0xFFFFFFFFu;
 constexpr float kFltMax = 3.402823466e+38F;
+constexpr int kVisBucketLog2 = 3, kVisBucket = 1 << kVisBucketLog2;   // ids per bucket of the visited table (vis_mode 2)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // result list: rank r lives in slot r/64 of lane r%64, ascending by distance
 template <int kE>
@@ -191,7 +193,7 @@ __device__ __forceinline__ void pool_prune(Pool<kG> &c, float bound, int lane) {
 // entries, one exact minimum per segment of 64 entries in LDS; a query whose frontier does not fit is ABANDONED and
 // queued in a.redo_out.  2 = HBM, sized by the graph (a node enters the frontier at most once, so it cannot overflow),
 // segment minima in HBM too and one minimum per 64 segments in LDS: the kernel that re-runs the abandoned queries.
-template <bool kL2, int kE, bool kBf16, int kBatch, bool kSplitRows, int kGPool = 0, bool kHash = false>
+template <bool kL2, int kE, bool kBf16, int kBatch, bool kSplitRows, int kGPool = 0, int kHash = 0>
 __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   extern __shared__ float4 lds4[];
   const int lane = threadIdx.x & 63;
@@ -206,13 +208,16 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   // (HBM frontier: the LDS keeps one minimum per segment of 64 entries in the pool's place, cand_cap / 64 floats;
   // two-level: one per 64 segments, cand_cap / 4096 floats)
   const uint32_t lds_pool = kGPool == 2 ? a.cand_cap / 8192 : kGPool == 1 ? a.cand_cap / 128 : a.cand_cap;
-  const size_t per_wave_f4 = (size_t)chunks * 4 + (list_words + lds_pool * 2 + a.nbr_cap * 2 + 3) / 4;
+  // (kHash == 2: one count byte per bucket of the visited table, behind the neighbour arrays)
+  const uint32_t vis_cnt_words = kHash == 2 ? (1u << a.vis_hash_log2) / (kVisBucket * 4u) : 0u;
+  const size_t per_wave_f4 = (size_t)chunks * 4 + (list_words + lds_pool * 2 + a.nbr_cap * 2 + vis_cnt_words + 3) / 4;
   float4 *qs = lds4 + wave * per_wave_f4;
   float *list_d = reinterpret_cast<float *>(qs + chunks * 4);
   float *pool_d = list_d + list_words;
   uint32_t *pool_id = reinterpret_cast<uint32_t *>(pool_d + lds_pool);
   uint32_t *nbr_id = pool_id + lds_pool;
   float *nbr_d = reinterpret_cast<float *>(nbr_id + a.nbr_cap);
+  uint32_t *vis_cnt = reinterpret_cast<uint32_t *>(nbr_d + a.nbr_cap);
 
   const uint32_t wpb = blockDim.x >> 6;                  // 4 waves per block, 1 with the LDS result list
   const uint32_t wslot = blockIdx.x * wpb + wave;
@@ -247,9 +252,13 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     {
       const float4 *src = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f);
       for (uint32_t i = lane; i < chunks * 4; i += kWave) qs[i] = src[i];
-      uint4 *bm4 = reinterpret_cast<uint4 *>(bitmap);
-      const uint4 z = kHash ? make_uint4(kNoneId, kNoneId, kNoneId, kNoneId) : make_uint4(0, 0, 0, 0);
-      for (uint32_t i = lane; i < a.bitmap_words / 4; i += kWave) bm4[i] = z;
+      if constexpr (kHash == 2) {   // the counts say which table words mean anything: the table itself is never cleared
+        for (uint32_t i = lane; i < vis_cnt_words; i += kWave) vis_cnt[i] = 0;
+      } else {
+        uint4 *bm4 = reinterpret_cast<uint4 *>(bitmap);
+        const uint4 z = kHash ? make_uint4(kNoneId, kNoneId, kNoneId, kNoneId) : make_uint4(0, 0, 0, 0);
+        for (uint32_t i = lane; i < a.bitmap_words / 4; i += kWave) bm4[i] = z;
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
@@ -258,15 +267,67 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     auto row_dist = [&](uint32_t id) -> float {
       return quad_row_distance<kL2, kBf16, kBatch>(row_base<kBf16>(a.rows, id, a.row_stride_f), qs, chunks, j);
     };
+    // kHash == 2 -- the visited set without atomics on memory.  The table is `buckets` buckets of kVisBucket ids (32 B)
+    // in HBM; how many ids a bucket holds is a byte in LDS.  An id lives in the first bucket from its home bucket on that
+    // had room when it came (buckets only fill up, so every bucket in front of it is full for good).  Look-up: the
+    // count from LDS -- zero: the id is new and nothing is read -- else ONE 32-B read of the bucket, on to the next
+    // bucket only behind a full one.  Insert: a slot number from an LDS atomic (the lanes of the wave insert the distinct
+    // ids of one list at the same time) and a 4-B store nobody waits for.  Exact like the table of mode 0/1: ids, not
+    // fingerprints.  A count can pass kVisBucket only by the lanes that raced for the last slots (< 64): it fits its byte.
+    const uint32_t vis_bmask = ((1u << a.vis_hash_log2) / kVisBucket) - 1u;
+    const __amdgpu_buffer_rsrc_t vis_rsrc = __builtin_amdgcn_make_buffer_rsrc(bitmap, 0, (int)(a.bitmap_words * 4u), 0x00020000);
+    auto vis_count = [&](uint32_t b) -> uint32_t { return (vis_cnt[b >> 2] >> ((b & 3u) * 8u)) & 0xFFu; };
+    auto vis_insert = [&](uint32_t id, uint32_t b) {   // b: a bucket the id's probe sequence has reached
+      for (;;) {
+        if (vis_count(b) < (uint32_t)kVisBucket) {
+          const uint32_t sh = (b & 3u) * 8u;
+          const uint32_t slot = (atomicAdd(&vis_cnt[b >> 2], 1u << sh) >> sh) & 0xFFu;
+          if (slot < (uint32_t)kVisBucket) {
+            __builtin_amdgcn_raw_buffer_store_b32(id, vis_rsrc, (int)((b * kVisBucket + slot) * 4u), 0, 16);
+            return;
+          }
+        }
+        b = (b + 1) & vis_bmask;
+      }
+    };
+    auto vis_lookup = [&](uint32_t id, uint32_t &b) -> bool {   // true: visited before; false: new, b = where to insert from
+      b = (id * 2654435761u) >> (32u - a.vis_hash_log2 + kVisBucketLog2);
+      for (;;) {
+        const uint32_t c = vis_count(b);
+        if (c) {
+          // (sc1: past this CU's vector L1 -- the stores above are not looked for there)
+          const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(vis_rsrc, (int)(b * kVisBucket * 4u), 0, 16);
+          bool hit = (c > 0 && v0[0] == id) || (c > 1 && v0[1] == id) || (c > 2 && v0[2] == id) || (c > 3 && v0[3] == id);
+          if (c > 4) {
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(vis_rsrc, (int)(b * kVisBucket * 4u + 16u), 0, 16);
+            hit = hit || v1[0] == id || (c > 5 && v1[1] == id) || (c > 6 && v1[2] == id) || (c > 7 && v1[3] == id);
+          }
+          if (hit) return true;
+        }
+        if (c < (uint32_t)kVisBucket) return false;
+        b = (b + 1) & vis_bmask;
+      }
+    };
     auto visit = [&](uint32_t id) -> bool {  // true if it was NOT visited before
-      if constexpr (kHash) {
+      if constexpr (kHash == 2) {
+        uint32_t b;
+        if (vis_lookup(id, b)) return false;
+        vis_insert(id, b);
+        return true;
+      } else if constexpr (kHash == 1) {
         // exact set of ids, linear probing from a multiplicative hash; never more than 3/4 full (checked per hop), so
         // the probe ends.  The lanes of the wave insert the (distinct) ids of one list at the same time: two that meet in
         // a slot are told apart by the compare-and-swap
         const uint32_t mask = (1u << a.vis_hash_log2) - 1u;
         uint32_t h = (id * 2654435761u) >> (32u - a.vis_hash_log2);
         for (;;) {
-          const uint32_t old = atomicCAS(&bitmap[h], kNoneId, id);
+          uint32_t old;
+          if (a.vis_mode == 1) {
+            old = kNoneId;
+            (void)__hip_atomic_compare_exchange_strong(&bitmap[h], &old, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          } else {
+            old = atomicCAS(&bitmap[h], kNoneId, id);
+          }
           if (old == kNoneId) return true;
           if (old == id) return false;
           h = (h + 1) & mask;
@@ -691,7 +752,12 @@ __global__ __launch_bounds__(256, kE == 16 ? 3 : 4) void hnsw_search_kernel(Hnsw
 // kind of access this kernel has no bandwidth to spare for.
 template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 3) void hnsw_search_hash_kernel(HnswSearchArgs a) {
-  hnsw_search_body<kL2, kE, kBf16, (kE <= 4 ? 12 : 8), false, 0, true>(a);   // (8 and 16 slots per lane leave room for 8 pieces only)
+  hnsw_search_body<kL2, kE, kBf16, (kE <= 4 ? 12 : 8), false, 0, 1>(a);   // (8 and 16 slots per lane leave room for 8 pieces only)
+}
+// ... with the table in buckets whose fill counts live in LDS: no atomics on memory (HnswSearchArgs::vis_mode == 2)
+template <bool kL2, int kE, bool kBf16>
+__global__ __launch_bounds__(256, 3) void hnsw_search_bucket_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, (kE <= 4 ? 12 : 8), false, 0, 2>(a);
 }
 // searches with a filter or tombstones: the frontier lives in HBM (HnswSearchArgs::pool_g)
 template <bool kL2, int kE, bool kBf16>
@@ -751,7 +817,8 @@ static size_t hnsw_lds_per_wave(const HnswSearchArgs &a) {
   // HBM frontier: segment minima only (gpool_level 2: one per 64 segments)
   const size_t pool = a.gpool_level == 2 ? (size_t)(a.cand_cap / 8192) * 2
                       : a.gpool_level == 1 ? (size_t)(a.cand_cap / 128) * 2 : (size_t)a.cand_cap * 2;
-  const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + pool + a.nbr_cap * 2 + 3) / 4;
+  const size_t vis_cnt_words = a.vis_hash_log2 && a.vis_mode == 2 ? ((size_t)1 << a.vis_hash_log2) / (kVisBucket * 4) : 0;
+  const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + pool + a.nbr_cap * 2 + vis_cnt_words + 3) / 4;
   return per_wave_f4 * 16;
 }
 
@@ -771,7 +838,8 @@ int hnsw_waves_per_block(const HnswSearchArgs &a) {
 size_t hnsw_lds_bytes(const HnswSearchArgs &a) { return hnsw_lds_per_wave(a) * (size_t)hnsw_waves_per_block(a); }
 
 template <bool kL2, int kE, bool kBf16>
-static const void *hnsw_fn(bool latency, int gpool, bool hash) {
+static const void *hnsw_fn(bool latency, int gpool, int hash) {
+  if (hash == 2) return reinterpret_cast<const void *>(&hnsw_search_bucket_kernel<kL2, kE, kBf16>);
   if (hash) return reinterpret_cast<const void *>(&hnsw_search_hash_kernel<kL2, kE, kBf16>);
   if constexpr (kE == 16) {   // (LDS-frontier kernels only)
     return gpool ? nullptr : reinterpret_cast<const void *>(&hnsw_search_kernel<kL2, kE, kBf16>);
@@ -789,7 +857,7 @@ static const void *hnsw_fn(bool latency, int gpool, bool hash) {
 }
 
 template <int kE>
-static const void *hnsw_pick_e(bool l2, bool bf16, bool latency, int gpool, bool hash) {
+static const void *hnsw_pick_e(bool l2, bool bf16, bool latency, int gpool, int hash) {
   return l2 ? (bf16 ? hnsw_fn<true, kE, true>(latency, gpool, hash) : hnsw_fn<true, kE, false>(latency, gpool, hash))
             : (bf16 ? hnsw_fn<false, kE, true>(latency, gpool, hash) : hnsw_fn<false, kE, false>(latency, gpool, hash));
 }
@@ -801,7 +869,7 @@ static bool hnsw_latency_variant(const HnswSearchArgs &a) {
 }
 
 static const void *hnsw_pick(const HnswSearchArgs &a, bool l2, bool bf16, int e) {
-  const bool hash = a.vis_hash_log2 != 0;
+  const int hash = a.vis_hash_log2 == 0 ? 0 : a.vis_mode == 2 ? 2 : 1;
   if (hash && (a.gpool_level != 0 || a.redo_in != nullptr)) return nullptr;   // (LDS-frontier first launches only)
   const bool latency = !hash && hnsw_latency_variant(a);
   const int gpool = (int)a.gpool_level;

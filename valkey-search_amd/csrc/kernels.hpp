@@ -58,6 +58,21 @@ struct FlatScanArgs {
   // fused re-rank (flat_rerank_kernel): per query the number of its blocks that have written their partial list (zeroed by
   // flat_qprep_kernel); the block that arrives last merges them and writes the answer
   uint32_t *done_cnt;
+  // second bound of the fused re-rank (cand_val != nullptr): the filter's approximate score of every survivor, next to its
+  // row slot (cand_val[q][i] / cand_spill_val[...] parallel to cand_row / cand_spill), the query's error polynomial
+  // (FlatFilterArgs::qcoef) and the per-tile row norms.  The k-th largest of (score - margin) over a query's survivors
+  // bounds its k-th best exact score from below -- from the WHOLE index this time, not from the sample -- and only the
+  // survivors whose (score + margin) reaches it get an exact distance: a few dozen of the few hundred.
+  const float *cand_val;
+  const float *cand_spill_val;
+  const float4 *qcoef;
+  const uint32_t *tile_norm;
+  uint32_t *reranked;         // optional [nq]: rows per query that got an exact distance (statistics; zeroed by flat_qprep_kernel)
+#ifdef VK_EXPERIMENTS
+  // the experiments build only: [nq][16] timestamps (wall_clock64, 100 MHz) of the fused re-rank's stages, written by wave 0
+  // of each query's first block (scripts/rerank_stamps.py through vk_exp_rerank_stamps)
+  unsigned long long *stamps;
+#endif
 };
 constexpr uint32_t kSpillChunk = 4096;      // entries per spill chunk of the candidate filter's survivor lists
 constexpr uint32_t kSpillPerQuery = 32;     // chunks one query may take (131072 survivors beyond its private list)
@@ -122,14 +137,17 @@ struct FlatFilterArgs {
   const uint32_t *tile_norm;
   uint32_t *cand_cnt;         // [nq] survivors per query (zeroed by qprep; may exceed what was stored)
   uint32_t *cand_row;         // [nq][cap] their row slots ...
+  float *cand_val;            // [nq][cap] ... and their approximate scores (accumulator space), for the re-rank's second bound
   uint32_t cap;
   uint32_t *qchunk;           // [nq][kSpillPerQuery] ... continued in spill chunks (2 + chunk index, 0 = none, 1 = being claimed; zeroed by qprep)
   uint32_t *spill;            // [n_chunks][kSpillChunk]
+  float *spill_val;           // [n_chunks][kSpillChunk] scores of the spilled survivors
   uint32_t *spill_next;       // [1] chunks handed out (zeroed by qprep)
   uint32_t n_chunks;
   uint32_t *redo_cnt;         // [1] length of the redo list the final merge builds (zeroed by qprep)
   uint32_t *ovf_q;            // [nq] raised for a query that lost survivors (or cannot go through f16): the exact pass answers it
   uint32_t *done_cnt;         // [nq] the fused re-rank's arrival counters (zeroed by qprep; nullptr = not used)
+  uint32_t *rerank_cnt;       // [nq] rows per query the re-rank evaluated (zeroed by qprep; statistics)
   // sample pass (mode 1): instead of gating, every (group of 64 rows, query) writes a LOWER BOUND of the group's best
   // exact score -- its best approximate score minus the margin -- to smax[q * smax_ld + group]; the k-th largest
   // of a query's group bounds bounds its k-th best exact score from below (k distinct rows reach it)
@@ -266,6 +284,9 @@ struct HnswSearchArgs {
   // cache and is cleared in no time where the bitmap takes 1.25 MB per resident wave.  LDS-frontier launches only; a
   // query that would fill the table beyond 3/4 is abandoned into redo_out and re-run with the bitmap.
   uint32_t vis_hash_log2;
+  // how the hash set is kept (option hnsw-visited-mode): 0 = compare-and-swap at agent scope (r02), 1 = the same at
+  // WAVEFRONT scope -- the set is private to its wave, nothing outside it ever looks
+  uint32_t vis_mode;
 };
 constexpr int kHnswLdsList = 255;     // hnsw_slots_per_lane(): 1024 < ef <= kHnswMaxEf, result list in LDS (also 512 < ef <= 1024
                                       // when the frontier lives in HBM: those kernels have no 16-slot variant)

@@ -33,11 +33,11 @@ enum OptId : uint32_t {
   kOptKernelTiming,         // 1 = HIP event pairs around the dominant kernel's launches (vk_index_stats.filter_kernel_ns)
   // ---- FLAT: kernel selection and the candidate filter (K4h) ------------------------------------------------------------
   kOptFlatFilter, kOptFilterMinQueries, kOptFilterMinRows, kOptFilterPrepassRows, kOptFilterCap, kOptFilterSpillChunks,
-  kOptFilterBDma, kOptFilterRowDma, kOptFilterBf16Mfma, kOptFlatForceScan, kOptFlatFusedRerank,
+  kOptFilterBDma, kOptFilterRowDma, kOptFilterBf16Mfma, kOptFlatForceScan, kOptFlatFusedRerank, kOptFilterSecondBound,
   kOptGemmLockstep, kOptGemmPrepassRows, kOptGemmContig, kOptScanMinNrp, kOptUploadParallel,
   // ---- HNSW ----------------------------------------------------------------------------------------------------------------
   kOptHnswDeviceBuild, kOptHnswBuildBatch, kOptHnswBuildMinGraph, kOptHnswBuildMinBatch, kOptHnswBuildFrac,
-  kOptHnswBuildVerbose, kOptHnswPoolFloor, kOptHnswGpoolCap, kOptHnswVisitedHash, kOptHnswHashPerEf, kOptHnswHashLog2,
+  kOptHnswBuildVerbose, kOptHnswPoolFloor, kOptHnswGpoolCap, kOptHnswVisitedHash, kOptHnswHashPerEf, kOptHnswHashLog2, kOptHnswVisitedMode,
   kOptHnswPoolBytes, kOptHnswVisitedBytes, kOptHnswRedoBytes,
   // ---- sharded index ---------------------------------------------------------------------------------------------------
   kOptShardThreads, kOptShardAllowStaged,
@@ -71,6 +71,7 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"filter-bf16-mfma", "VK_FILTER_BF16_MFMA", 1, 0, 1},
       {"flat-force-scan", "VK_FLAT_FORCE_SCAN", 0, 0, 1},
       {"flat-fused-rerank", "VK_FLAT_FUSED_RERANK", 1, 0, 1},
+      {"filter-second-bound", "VK_FILTER_SECOND_BOUND", 1, 0, 1},
       {"gemm-lockstep", "VK_GEMM_LOCKSTEP", 1, 0, 64},
       {"gemm-prepass-rows", "VK_GEMM_PREPASS", 16384, 0, kMax},
       {"gemm-contig", "VK_GEMM_CONTIG", 1, 0, 1},
@@ -87,6 +88,7 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"hnsw-visited-hash", "VK_HNSW_VISITED_HASH", 1, 0, 2},
       {"hnsw-hash-per-ef", "VK_HNSW_HASH_PER_EF", 64, 1, 1u << 16},
       {"hnsw-hash-log2", "VK_HNSW_HASH_LOG2", 0, 0, 26},
+      {"hnsw-visited-mode", "VK_HNSW_VISITED_MODE", 0, 0, 2},
       {"hnsw-pool-bytes", "VK_HNSW_POOL_BYTES", (uint64_t)4 << 30, 1u << 20, kMax},
       {"hnsw-visited-bytes", "VK_HNSW_VISITED_BYTES", (uint64_t)4 << 30, 1u << 20, kMax},
       {"hnsw-redo-bytes", "VK_HNSW_REDO_BYTES", (uint64_t)2 << 30, 1u << 20, kMax},
