@@ -410,12 +410,28 @@ __device__ __forceinline__ void filter_gate(const FlatFilterArgs &a, f32x16 (&ac
     }
   }
 #endif
+  // One vote for the wave's kRt blocks together: a vote is a trip from the vector to the scalar side (~60 cycles), and 96 %
+  // of the blocks have no survivor.
+  // (fmaxf drops NaNs; they only occur in a tile outside f16, whose thr is -inf: "not below" then holds for any m)
+  float mx[kRt];
+  bool any = false;
 #pragma unroll
   for (int rt = 0; rt < kRt; ++rt) {
-    // (fmaxf drops NaNs; they only occur in a tile outside f16, whose thr is -inf: "not below" then holds for any m)
-    float m = acc[rt][0];
+    mx[rt] = acc[rt][0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][r]);
+    for (int r = 1; r < 16; ++r) mx[rt] = fmaxf(mx[rt], acc[rt][r]);
+    any = any || !(mx[rt] < thr);
+  }
+  if (__builtin_amdgcn_ballot_w64(any) == 0) {
+    if constexpr (kZero) {
+#pragma unroll
+      for (int rt = 0; rt < kRt; ++rt) acc[rt] = zero;
+    }
+    return;
+  }
+#pragma unroll
+  for (int rt = 0; rt < kRt; ++rt) {
+    const float m = mx[rt];
     if (__builtin_amdgcn_ballot_w64(!(m < thr)) != 0) {   // (rare: a survivor somewhere in this 32 x 32 block)
       const uint32_t q = wave * 32 + li;
       // the lane's passing registers as a bit mask, then one round per remaining bit of the busiest lane (usually one)

@@ -565,7 +565,7 @@ class HnswIndex final : public Index {
       if (visited_hash_ == 2 || ((uint64_t)8 << lg) <= bm_bytes) hash_log2 = lg;   // (at most half the bitmap's size)
     }
     HnswSearchArgs h{};
-    uint64_t blocks_h = 0;
+    uint64_t blocks_h = 0, wpb_h = wpb;
     if (hash_log2) {
       h = a;
       h.vis_hash_log2 = hash_log2;
@@ -574,10 +574,24 @@ class HnswIndex final : public Index {
       // (its LDS frontier need not hold 2 x ef entries for the worst run of equal distances: a query that fills it is
       // re-run like one that fills its table, and the LDS saved is resident waves at large ef)
       h.cand_cap = (uint32_t)((std::max<uint64_t>(cand_floor_, ef + std::max<uint64_t>(64, ef / 4)) + 3) & ~(uint64_t)3);
+      if (h.vis_mode >= 3) {
+        // the set in LDS (12 KB per wave hold 4800 ids): ids below 2^24, result lists in registers (ef <= 256), two blocks of
+        // four waves must still fit a CU (rows of up to ~880 dimensions), and -- mode 3, the default -- a search that stays
+        // well below 4800 evaluations: measured 0.82 x ef x maxM0 on the graphs of the bench (ef = 128, M = 16: 3 373; at
+        // ef = 160: 4 101 and 54 of 8 192 queries re-run by the second launch, slower than the table in HBM).  Mode 4 takes
+        // the LDS set whenever it FITS (tests: queries that outgrow it are re-run).  Else the table in HBM, mode 0.
+        const bool fits = count < (1u << 24) && e <= 4 && 2 * hnsw_lds_bytes(h) <= 160 * 1024;
+        if (!fits || (h.vis_mode == 3 && ef * (uint64_t)graph_->maxM0() > kHnswLdsVisMaxWork)) h.vis_mode = 0;
+        else { h.vis_mode = 3; h.bitmap_words = 4; }   // (no table in memory)
+      }
       int mbh = 0;
       VK_HIP_TRY(hnsw_max_blocks(h, l2(), store_.bf16(), e, &mbh));
-      blocks_h = std::min<uint64_t>((nq + wpb - 1) / wpb, (uint64_t)mbh);
-      blocks_h = std::max<uint64_t>(1, std::min<uint64_t>(blocks_h, visited_bytes_ / ((uint64_t)h.bitmap_words * 4 * wpb)));
+      // (the hash kernels' own waves per block: with the option hnsw-visited-hash = 2 a batch of up to 1024 queries comes
+      //  here too, and `wpb` above is then the latency kernel's ONE wave per block -- sized with it, a batch of 769 .. 1024
+      //  queries got 768 tables for up to 1024 waves: a memory fault in the device build of a small graph, found in r04)
+      wpb_h = (uint64_t)hnsw_waves_per_block(h);
+      blocks_h = std::min<uint64_t>((nq + wpb_h - 1) / wpb_h, (uint64_t)mbh);
+      blocks_h = std::max<uint64_t>(1, std::min<uint64_t>(blocks_h, visited_bytes_ / ((uint64_t)h.bitmap_words * 4 * wpb_h)));
       VK_TRY(ctx->d_redo.ensure((nq + 1) * 4));
     }
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, visited_bytes_ / (bm_bytes * wpb)));
@@ -609,7 +623,7 @@ class HnswIndex final : public Index {
     // visited-set scratch of the launches that actually run: hash tables (h) + the re-run's bitmaps (b) on the hash
     // path -- the bitmap launch `a` is skipped there, and its blocks * wpb bitmaps are up to 4 GiB per context on
     // exactly the large-graph, large-batch case the hash sets exist for -- else a (+ b)
-    const uint64_t vis_first = hash_log2 ? blocks_h * wpb * (uint64_t)h.bitmap_words * 4 : blocks * wpb * bm_bytes;
+    const uint64_t vis_first = hash_log2 ? blocks_h * wpb_h * (uint64_t)h.bitmap_words * 4 : blocks * wpb * bm_bytes;
     VK_TRY(ctx->d_tmp.ensure(std::max(vis_first, blocks2 * wpb2 * bm_bytes)));
     a.visited = ctx->d_tmp.as<uint32_t>();
     VK_TRY(ctx->d_stats.ensure(64));

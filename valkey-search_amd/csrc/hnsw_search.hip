@@ -46,6 +46,13 @@ constexpr uint32_t kNoneId = 0xFFFFFFFFu;
 constexpr float kFltMax = 3.402823466e+38F;
 constexpr int kVisBucketLog2 = 3, kVisBucket = 1 << kVisBucketLog2;   // ids per bucket of the visited table (vis_mode 2)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// vis_mode 3: the visited set entirely in LDS -- kLvBuckets buckets of six 16-bit entries (12 B), 12 KB per wave.  An id
+// below 2^24 has TWO home buckets, from two bijections of [0, 2^24) (odd multipliers): the top ten bits of the scrambled
+// id name the bucket, the low fourteen are what is stored, next to one bit that says which bijection and one that says
+// whether the entry sits in the home bucket or the one behind it (it goes there only when the home is full) -- so an
+// entry names ONE id wherever it lies: the set is exact.  An id goes to the emptier of its homes (two choices keep the
+// fullest bucket within a slot or two of the average); 0xFFFF = an empty slot.
+constexpr uint32_t kLvBuckets = 1024, kLvSlots = 6, kLvWords = kLvBuckets * 3, kLvMaxIds = 4800;   // (6144 slots: 78 % full at most)
 
 // result list: rank r lives in slot r/64 of lane r%64, ascending by distance
 template <int kE>
@@ -209,7 +216,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   // two-level: one per 64 segments, cand_cap / 4096 floats)
   const uint32_t lds_pool = kGPool == 2 ? a.cand_cap / 8192 : kGPool == 1 ? a.cand_cap / 128 : a.cand_cap;
   // (kHash == 2: one count byte per bucket of the visited table, behind the neighbour arrays)
-  const uint32_t vis_cnt_words = kHash == 2 ? (1u << a.vis_hash_log2) / (kVisBucket * 4u) : 0u;
+  const uint32_t vis_cnt_words = kHash == 3 ? kLvWords : kHash == 2 ? (1u << a.vis_hash_log2) / (kVisBucket * 4u) : 0u;
   const size_t per_wave_f4 = (size_t)chunks * 4 + (list_words + lds_pool * 2 + a.nbr_cap * 2 + vis_cnt_words + 3) / 4;
   float4 *qs = lds4 + wave * per_wave_f4;
   float *list_d = reinterpret_cast<float *>(qs + chunks * 4);
@@ -252,7 +259,9 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     {
       const float4 *src = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f);
       for (uint32_t i = lane; i < chunks * 4; i += kWave) qs[i] = src[i];
-      if constexpr (kHash == 2) {   // the counts say which table words mean anything: the table itself is never cleared
+      if constexpr (kHash == 3) {   // every slot empty
+        for (uint32_t i = lane; i < vis_cnt_words; i += kWave) vis_cnt[i] = 0xFFFFFFFFu;
+      } else if constexpr (kHash == 2) {   // the counts say which table words mean anything: the table itself is never cleared
         for (uint32_t i = lane; i < vis_cnt_words; i += kWave) vis_cnt[i] = 0;
       } else {
         uint4 *bm4 = reinterpret_cast<uint4 *>(bitmap);
@@ -308,8 +317,49 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         b = (b + 1) & vis_bmask;
       }
     };
+    // kHash == 3 -- the set in LDS (see kLvBuckets).  Look-up and insert are one walk over at most three buckets: the id's
+    // entry found -> visited; a free slot -> taken with a compare-and-swap of its 32-bit word (the lanes of the wave insert
+    // the ids of one list at the same time; one that loses the word reads the bucket again -- and finds its own id there if
+    // the list named it twice); three full buckets -> the query is given up (vis_full) and re-run by the second launch.
+    bool vis_full = false;
+    auto visit_lds = [&](uint32_t id) -> bool {
+      // two bijections of [0, 2^24): two home buckets (top ten bits) with their remainders (low fourteen)
+      const uint32_t H0 = (id * 0x9E3779B1u) & 0xFFFFFFu, H1 = (id * 0x85EBCA6Bu + 0x5BD1E9u) & 0xFFFFFFu;
+      for (;;) {
+        uint32_t best_free = 0, best_at = 0, best_old = 0, best_new = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 2; ++c) {
+          const uint32_t Hc = c ? H1 : H0;
+          for (uint32_t d = 0; d < 2; ++d) {
+            const uint32_t at = (((Hc >> 14) + d) & (kLvBuckets - 1u)) * 3u;
+            const uint32_t key = (c << 15) | (d << 14) | (Hc & 0x3FFFu);
+            const uint32_t w0 = vis_cnt[at], w1 = vis_cnt[at + 1], w2 = vis_cnt[at + 2];
+            if ((w0 & 0xFFFFu) == key || (w0 >> 16) == key || (w1 & 0xFFFFu) == key || (w1 >> 16) == key || (w2 & 0xFFFFu) == key ||
+                (w2 >> 16) == key)
+              return false;
+            // free slots of the bucket (entries fill it front to back) and the word + value that would take the first
+            const uint32_t nfree = ((w0 & 0xFFFFu) == 0xFFFFu) + ((w0 >> 16) == 0xFFFFu) + ((w1 & 0xFFFFu) == 0xFFFFu) + ((w1 >> 16) == 0xFFFFu) +
+                                   ((w2 & 0xFFFFu) == 0xFFFFu) + ((w2 >> 16) == 0xFFFFu);
+            if (nfree == 0) continue;                         // full: the id may sit one bucket further
+            if (key != 0xFFFFu && nfree > best_free) {       // (the one key that reads as "empty" is never stored)
+              const uint32_t used = kLvSlots - nfree, wi = used >> 1;
+              const uint32_t old = wi == 0 ? w0 : wi == 1 ? w1 : w2;
+              best_free = nfree;
+              best_at = at + wi;
+              best_old = old;
+              best_new = (used & 1u) ? (old & 0xFFFFu) | (key << 16) : (old & 0xFFFF0000u) | key;
+            }
+            break;                                             // a bucket with room never sent anything further
+          }
+        }
+        if (best_free == 0) { vis_full = true; return false; }
+        if (atomicCAS(&vis_cnt[best_at], best_old, best_new) == best_old) return true;
+      }
+    };
     auto visit = [&](uint32_t id) -> bool {  // true if it was NOT visited before
-      if constexpr (kHash == 2) {
+      if constexpr (kHash == 3) {
+        return visit_lds(id);
+      } else if constexpr (kHash == 2) {
         uint32_t b;
         if (vis_lookup(id, b)) return false;
         vis_insert(id, b);
@@ -553,7 +603,9 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       // slots past the count hold whatever the list held before -- never used)
       const uint32_t nid_first = (uint32_t)lane + 1 < a.l0_stride ? ll[1 + lane] : 0u;
       const uint32_t size = ll[0] & 0xFFFFu;
-      if constexpr (kHash) {   // the table must not fill up: this query goes to the launch with the bitmap
+      if constexpr (kHash == 3) {
+        if (q_vis + size > kLvMaxIds) { abandoned = true; break; }
+      } else if constexpr (kHash != 0) {   // the table must not fill up: this query goes to the launch with the bitmap
         if (q_vis + size > (3u << a.vis_hash_log2) / 4u) { abandoned = true; break; }
       }
       uint32_t nn = 0;
@@ -565,6 +617,9 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         const uint64_t m = __ballot(unv);
         if (unv) nbr_id[nn + __popcll(m & ((1ull << lane) - 1ull))] = nid;
         nn += __popcll(m);
+      }
+      if constexpr (kHash == 3) {   // three full buckets in a row somewhere: the second launch answers this query
+        if (__ballot(vis_full) != 0) { abandoned = true; break; }
       }
       // phase 3a: distances, 16 rows per round; a round of <= 8 (<= 4) rows gives every row two (four) quads, which
       // fetch alternate batches of its pieces (same arithmetic, half / a quarter of the memory round trips)
@@ -759,6 +814,12 @@ template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 3) void hnsw_search_bucket_kernel(HnswSearchArgs a) {
   hnsw_search_body<kL2, kE, kBf16, (kE <= 4 ? 12 : 8), false, 0, 2>(a);
 }
+// ... with the set in LDS (vis_mode 3; result lists up to 256 entries): two waves per SIMD, each with twice the row pieces
+// in flight -- what the 12 KB of the set cost in resident waves comes back as bytes per wave
+template <bool kL2, int kE, bool kBf16>
+__global__ __launch_bounds__(256, 2) void hnsw_search_ldsvis_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, 24, false, 0, 3>(a);
+}
 // searches with a filter or tombstones: the frontier lives in HBM (HnswSearchArgs::pool_g)
 template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 4) void hnsw_search_gpool_kernel(HnswSearchArgs a) {
@@ -817,7 +878,7 @@ static size_t hnsw_lds_per_wave(const HnswSearchArgs &a) {
   // HBM frontier: segment minima only (gpool_level 2: one per 64 segments)
   const size_t pool = a.gpool_level == 2 ? (size_t)(a.cand_cap / 8192) * 2
                       : a.gpool_level == 1 ? (size_t)(a.cand_cap / 128) * 2 : (size_t)a.cand_cap * 2;
-  const size_t vis_cnt_words = a.vis_hash_log2 && a.vis_mode == 2 ? ((size_t)1 << a.vis_hash_log2) / (kVisBucket * 4) : 0;
+  const size_t vis_cnt_words = a.vis_hash_log2 && a.vis_mode == 3 ? kLvWords : a.vis_hash_log2 && a.vis_mode == 2 ? ((size_t)1 << a.vis_hash_log2) / (kVisBucket * 4) : 0;
   const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + pool + a.nbr_cap * 2 + vis_cnt_words + 3) / 4;
   return per_wave_f4 * 16;
 }
@@ -839,6 +900,10 @@ size_t hnsw_lds_bytes(const HnswSearchArgs &a) { return hnsw_lds_per_wave(a) * (
 
 template <bool kL2, int kE, bool kBf16>
 static const void *hnsw_fn(bool latency, int gpool, int hash) {
+  if constexpr (kE >= 1 && kE <= 4) {
+    if (hash == 3) return reinterpret_cast<const void *>(&hnsw_search_ldsvis_kernel<kL2, kE, kBf16>);
+  }
+  if (hash == 3) return nullptr;
   if (hash == 2) return reinterpret_cast<const void *>(&hnsw_search_bucket_kernel<kL2, kE, kBf16>);
   if (hash) return reinterpret_cast<const void *>(&hnsw_search_hash_kernel<kL2, kE, kBf16>);
   if constexpr (kE == 16) {   // (LDS-frontier kernels only)
@@ -869,7 +934,7 @@ static bool hnsw_latency_variant(const HnswSearchArgs &a) {
 }
 
 static const void *hnsw_pick(const HnswSearchArgs &a, bool l2, bool bf16, int e) {
-  const int hash = a.vis_hash_log2 == 0 ? 0 : a.vis_mode == 2 ? 2 : 1;
+  const int hash = a.vis_hash_log2 == 0 ? 0 : a.vis_mode == 3 ? 3 : a.vis_mode == 2 ? 2 : 1;
   if (hash && (a.gpool_level != 0 || a.redo_in != nullptr)) return nullptr;   // (LDS-frontier first launches only)
   const bool latency = !hash && hnsw_latency_variant(a);
   const int gpool = (int)a.gpool_level;

@@ -285,9 +285,13 @@ struct HnswSearchArgs {
   // query that would fill the table beyond 3/4 is abandoned into redo_out and re-run with the bitmap.
   uint32_t vis_hash_log2;
   // how the hash set is kept (option hnsw-visited-mode): 0 = compare-and-swap at agent scope (r02), 1 = the same at
-  // WAVEFRONT scope -- the set is private to its wave, nothing outside it ever looks
+  // WAVEFRONT scope -- the set is private to its wave, nothing outside it ever looks --, 2 = buckets in HBM with their
+  // fill counts in LDS (no atomics on memory), 3 = the whole set in LDS (graphs below 2^24 nodes, ef x maxM0 <= kHnswLdsVisMaxWork:
+  // 12 KB per wave hold 4800 ids; vis_hash_log2 only says "a hash set", no memory is used); the option's 4 = 3 whenever
+  // the set fits the LDS at all (tests)
   uint32_t vis_mode;
 };
+constexpr uint64_t kHnswLdsVisMaxWork = 4224;   // vis_mode 3: ef x maxM0 up to here (ef = 132 at M = 16) keeps the visited set in LDS
 constexpr int kHnswLdsList = 255;     // hnsw_slots_per_lane(): 1024 < ef <= kHnswMaxEf, result list in LDS (also 512 < ef <= 1024
                                       // when the frontier lives in HBM: those kernels have no 16-slot variant)
 constexpr uint64_t kHnswMaxEf = 16384;   // (2 * ef words of LDS: the default max-vector-knn of 10000 fits, ft_search_parser.cc:34-45)

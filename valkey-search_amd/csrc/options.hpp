@@ -88,7 +88,7 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"hnsw-visited-hash", "VK_HNSW_VISITED_HASH", 1, 0, 2},
       {"hnsw-hash-per-ef", "VK_HNSW_HASH_PER_EF", 64, 1, 1u << 16},
       {"hnsw-hash-log2", "VK_HNSW_HASH_LOG2", 0, 0, 26},
-      {"hnsw-visited-mode", "VK_HNSW_VISITED_MODE", 0, 0, 2},
+      {"hnsw-visited-mode", "VK_HNSW_VISITED_MODE", 3, 0, 4},
       {"hnsw-pool-bytes", "VK_HNSW_POOL_BYTES", (uint64_t)4 << 30, 1u << 20, kMax},
       {"hnsw-visited-bytes", "VK_HNSW_VISITED_BYTES", (uint64_t)4 << 30, 1u << 20, kMax},
       {"hnsw-redo-bytes", "VK_HNSW_REDO_BYTES", (uint64_t)2 << 30, 1u << 20, kMax},
