@@ -886,20 +886,20 @@ def source_sha256():
 
 def pmc_traffic(N, D, B, world, kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc is a separate run by
-    rule, so bench.py cannot collect it live): profiles/r03_pmc_fetch_size.json, written by scripts/pmc_traffic.sh and
+    rule, so bench.py cannot collect it live): profiles/r04_pmc_fetch_size.json, written by scripts/pmc_traffic.sh and
     stamped with the hash of the sources it measured.  Printed only for the default single-GPU workload AND only while
     that hash equals the current sources' -- a stale file yields null, never an old number."""
-    path = ROOT / "profiles" / "r03_pmc_fetch_size.json"
+    path = ROOT / "profiles" / "r04_pmc_fetch_size.json"
     if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not path.exists() or "bf16" in sys.argv:
         return None, None
     if any(os.environ.get(v) for v in ("VK_FLAT_FORCE_SCAN", "VK_GEMM_MODE", "VK_GEMM_ABLATE", "VK_GEMM_LOCKSTEP", "VK_FILTER_TIMING", "VK_FLAT_FILTER")):
         return None, None
     j = json.load(open(path))
     if j.get("src_sha256") != source_sha256():
-        return None, "profiles/r03_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
+        return None, "profiles/r04_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
     for name, v in j.get("kernels", {}).items():
         if kernel_prefix in name and "prepass" not in name and "[small]" not in name:
-            return round(v["hbm_bytes_per_launch"]), "profiles/r03_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
+            return round(v["hbm_bytes_per_launch"]), "profiles/r04_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
     return None, None
 
 

@@ -150,3 +150,26 @@ def test_other_ways_of_keeping_the_hash_set_match_the_oracle(vsa, oracle, mode, 
     # the mode is a run-time option: to the default (3: the LDS set where a search is sure to fit it) on the same index
     g.set_option("hnsw-visited-mode", 3)
     _check(g, o, Q[:20], k, ef)
+
+
+def test_a_search_that_outgrows_the_lds_set_spills_into_memory(vsa, oracle):
+    """hnsw-visited-mode 4 takes the LDS set (6144 slots in 12 KB) wherever it fits the LDS; on a graph with 64 links per node
+    a search at ef = 256 evaluates about 5000 nodes, at ef = 400 (the 32 KB set: 16384 slots) about 7500.  An id whose four
+    candidate buckets are full goes to the wave's table in memory instead and is found there next time -- nothing is
+    re-run, and ids, distance bits and work counters are the oracle's all the same.  (The default, mode 3, takes an LDS set
+    only where ef x maxM0 keeps a search well inside it.)"""
+    rng = np.random.default_rng(41)
+    n, dim, M = 12000, 48, 32
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    with _Env(VK_HNSW_VISITED_HASH=2, VK_HNSW_VISITED_MODE=4):
+        g = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=M, ef_construction=60, build_threads=8)
+    g.add_batch(x)
+    g.flush()
+    o = oracle.HNSW.from_product_index(g.save_raw, dim, "L2", M, ef_construction=60)
+    Q = rng.standard_normal((60, dim)).astype(np.float32)
+    for ef in (256, 400, 48):                # the 12 KB set overfull, the 32 KB set, a search either holds with room to spare
+        st = _check(g, o, Q, 10, ef)
+        assert st.last_frontier_redo == 0
+    g.set_option("hnsw-visited-mode", 3)     # the default rule: 256 x 64 is beyond both LDS sets' budgets -> the table in memory
+    st = _check(g, o, Q, 10, 256)
+    assert st.last_frontier_redo == 0

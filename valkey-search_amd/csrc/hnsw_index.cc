@@ -580,9 +580,16 @@ class HnswIndex final : public Index {
         // well below 4800 evaluations: measured 0.82 x ef x maxM0 on the graphs of the bench (ef = 128, M = 16: 3 373; at
         // ef = 160: 4 101 and 54 of 8 192 queries re-run by the second launch, slower than the table in HBM).  Mode 4 takes
         // the LDS set whenever it FITS (tests: queries that outgrow it are re-run).  Else the table in HBM, mode 0.
-        const bool fits = count < (1u << 24) && e <= 4 && 2 * hnsw_lds_bytes(h) <= 160 * 1024;
-        if (!fits || (h.vis_mode == 3 && ef * (uint64_t)graph_->maxM0() > kHnswLdsVisMaxWork)) h.vis_mode = 0;
-        else { h.vis_mode = 3; h.bitmap_words = 4; }   // (no table in memory)
+        const bool forced = h.vis_mode == 4;
+        const uint64_t work = ef * (uint64_t)graph_->maxM0();
+        h.vis_mode = 3;                                     // the 12 KB set: two blocks of four waves per CU
+        const bool fits_small = count < (1u << 24) && e <= 4 && 2 * hnsw_lds_bytes(h) <= 160 * 1024;
+        h.vis_mode = 5;                                     // the 32 KB set: one block of four waves per CU
+        const bool fits_big = count < (1u << 24) && e <= 8 && hnsw_waves_per_block(h) == 4 && hnsw_lds_bytes(h) <= 160 * 1024;
+        if (fits_small && (forced || work <= kHnswLdsVisMaxWork)) h.vis_mode = 3;
+        else if (fits_big && (forced || work <= kHnswLdsVisBigMaxWork)) h.vis_mode = 5;
+        else h.vis_mode = 0;
+        // (the table in memory stays: ids that find no room on chip spill into it)
       }
       int mbh = 0;
       VK_HIP_TRY(hnsw_max_blocks(h, l2(), store_.bf16(), e, &mbh));

@@ -52,7 +52,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // whether the entry sits in the home bucket or the one behind it (it goes there only when the home is full) -- so an
 // entry names ONE id wherever it lies: the set is exact.  An id goes to the emptier of its homes (two choices keep the
 // fullest bucket within a slot or two of the average); 0xFFFF = an empty slot.
-constexpr uint32_t kLvBuckets = 1024, kLvSlots = 6, kLvWords = kLvBuckets * 3, kLvMaxIds = 4800;   // (6144 slots: 78 % full at most)
+// Two sizes: 1024 buckets of six entries (12 KB per wave, 4800 ids: two waves per SIMD), and -- one wave per SIMD with a
+// whole row in flight per lane -- 2048 buckets of eight (32 KB, 12800 ids; thirteen stored bits, eleven bucket bits).
+template <bool kBig> struct LdsVis {
+  static constexpr uint32_t kRemBits = kBig ? 13 : 14, kBuckets = kBig ? 2048 : 1024, kSlots = kBig ? 8 : 6;
+  static constexpr uint32_t kWordsPerBucket = kSlots / 2, kWords = kBuckets * kWordsPerBucket, kMaxIds = kBig ? 12800 : 4800;
+};
 
 // result list: rank r lives in slot r/64 of lane r%64, ascending by distance
 template <int kE>
@@ -216,7 +221,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
   // two-level: one per 64 segments, cand_cap / 4096 floats)
   const uint32_t lds_pool = kGPool == 2 ? a.cand_cap / 8192 : kGPool == 1 ? a.cand_cap / 128 : a.cand_cap;
   // (kHash == 2: one count byte per bucket of the visited table, behind the neighbour arrays)
-  const uint32_t vis_cnt_words = kHash == 3 ? kLvWords : kHash == 2 ? (1u << a.vis_hash_log2) / (kVisBucket * 4u) : 0u;
+  const uint32_t vis_cnt_words = kHash == 5 ? LdsVis<true>::kWords : kHash == 3 ? LdsVis<false>::kWords : kHash == 2 ? (1u << a.vis_hash_log2) / (kVisBucket * 4u) : 0u;
   const size_t per_wave_f4 = (size_t)chunks * 4 + (list_words + lds_pool * 2 + a.nbr_cap * 2 + vis_cnt_words + 3) / 4;
   float4 *qs = lds4 + wave * per_wave_f4;
   float *list_d = reinterpret_cast<float *>(qs + chunks * 4);
@@ -259,7 +264,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     {
       const float4 *src = reinterpret_cast<const float4 *>(a.queries + (size_t)q * a.q_stride_f);
       for (uint32_t i = lane; i < chunks * 4; i += kWave) qs[i] = src[i];
-      if constexpr (kHash == 3) {   // every slot empty
+      if constexpr (kHash == 3 || kHash == 5) {   // every slot empty
         for (uint32_t i = lane; i < vis_cnt_words; i += kWave) vis_cnt[i] = 0xFFFFFFFFu;
       } else if constexpr (kHash == 2) {   // the counts say which table words mean anything: the table itself is never cleared
         for (uint32_t i = lane; i < vis_cnt_words; i += kWave) vis_cnt[i] = 0;
@@ -320,10 +325,14 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     // kHash == 3 -- the set in LDS (see kLvBuckets).  Look-up and insert are one walk over at most three buckets: the id's
     // entry found -> visited; a free slot -> taken with a compare-and-swap of its 32-bit word (the lanes of the wave insert
     // the ids of one list at the same time; one that loses the word reads the bucket again -- and finds its own id there if
-    // the list named it twice); three full buckets -> the query is given up (vis_full) and re-run by the second launch.
-    bool vis_full = false;
-    auto visit_lds = [&](uint32_t id) -> bool {
-      // two bijections of [0, 2^24): two home buckets (top ten bits) with their remainders (low fourteen)
+    // the list named it twice).  An id whose four candidate buckets are all full goes to the wave's table in HBM instead
+    // (the compare-and-swap table of mode 0, cleared when a query first needs it): full buckets stay full, so the same id
+    // finds them full again next time and is looked up THERE -- no id is ever in both places, nothing is re-run, and a
+    // search that outgrows the on-chip set merely pays memory accesses for its last few hundred ids.
+    auto visit_lds = [&](uint32_t id) -> uint32_t {   // 0 = visited before, 1 = new (now in the set), 2 = new to the set, but its four buckets are full
+      using LV = LdsVis<kHash == 5>;
+      constexpr uint32_t kW = LV::kWordsPerBucket;
+      // two bijections of [0, 2^24): two home buckets (top bits) with their remainders (low bits)
       const uint32_t H0 = (id * 0x9E3779B1u) & 0xFFFFFFu, H1 = (id * 0x85EBCA6Bu + 0x5BD1E9u) & 0xFFFFFFu;
       for (;;) {
         uint32_t best_free = 0, best_at = 0, best_old = 0, best_new = 0;
@@ -331,19 +340,29 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         for (uint32_t c = 0; c < 2; ++c) {
           const uint32_t Hc = c ? H1 : H0;
           for (uint32_t d = 0; d < 2; ++d) {
-            const uint32_t at = (((Hc >> 14) + d) & (kLvBuckets - 1u)) * 3u;
-            const uint32_t key = (c << 15) | (d << 14) | (Hc & 0x3FFFu);
-            const uint32_t w0 = vis_cnt[at], w1 = vis_cnt[at + 1], w2 = vis_cnt[at + 2];
-            if ((w0 & 0xFFFFu) == key || (w0 >> 16) == key || (w1 & 0xFFFFu) == key || (w1 >> 16) == key || (w2 & 0xFFFFu) == key ||
-                (w2 >> 16) == key)
-              return false;
-            // free slots of the bucket (entries fill it front to back) and the word + value that would take the first
-            const uint32_t nfree = ((w0 & 0xFFFFu) == 0xFFFFu) + ((w0 >> 16) == 0xFFFFu) + ((w1 & 0xFFFFu) == 0xFFFFu) + ((w1 >> 16) == 0xFFFFu) +
-                                   ((w2 & 0xFFFFu) == 0xFFFFu) + ((w2 >> 16) == 0xFFFFu);
+            const uint32_t at = (((Hc >> LV::kRemBits) + d) & (LV::kBuckets - 1u)) * kW;
+            const uint32_t key = (c << (LV::kRemBits + 1)) | (d << LV::kRemBits) | (Hc & ((1u << LV::kRemBits) - 1u));
+            // (the one 16-bit key that reads as "empty" is never stored: an id cannot live in the bucket it would need it
+            //  for -- not looked for there (an empty slot would answer "visited"), not put there)
+            if (key == 0xFFFFu) continue;
+            uint32_t w[kW];
+#pragma unroll
+            for (uint32_t t = 0; t < kW; ++t) w[t] = vis_cnt[at + t];
+            bool hit = false;
+            uint32_t nfree = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < kW; ++t) {
+              hit = hit || (w[t] & 0xFFFFu) == key || (w[t] >> 16) == key;
+              nfree += ((w[t] & 0xFFFFu) == 0xFFFFu) + ((w[t] >> 16) == 0xFFFFu);
+            }
+            if (hit) return 0u;
             if (nfree == 0) continue;                         // full: the id may sit one bucket further
-            if (key != 0xFFFFu && nfree > best_free) {       // (the one key that reads as "empty" is never stored)
-              const uint32_t used = kLvSlots - nfree, wi = used >> 1;
-              const uint32_t old = wi == 0 ? w0 : wi == 1 ? w1 : w2;
+            if (nfree > best_free) {
+              // entries fill a bucket front to back: the first free slot is number `used`
+              const uint32_t used = LV::kSlots - nfree, wi = used >> 1;
+              uint32_t old = w[0];
+#pragma unroll
+              for (uint32_t t = 1; t < kW; ++t) old = wi == t ? w[t] : old;
               best_free = nfree;
               best_at = at + wi;
               best_old = old;
@@ -352,13 +371,25 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
             break;                                             // a bucket with room never sent anything further
           }
         }
-        if (best_free == 0) { vis_full = true; return false; }
-        if (atomicCAS(&vis_cnt[best_at], best_old, best_new) == best_old) return true;
+        if (best_free == 0) return 2u;
+        if (atomicCAS(&vis_cnt[best_at], best_old, best_new) == best_old) return 1u;
       }
     };
+    auto visit_hbm = [&](uint32_t id) -> bool {   // the table in memory: exact set of ids, linear probing, compare-and-swap
+      const uint32_t mask = (1u << a.vis_hash_log2) - 1u;
+      uint32_t h = (id * 2654435761u) >> (32u - a.vis_hash_log2);
+      for (;;) {
+        const uint32_t old = atomicCAS(&bitmap[h], kNoneId, id);
+        if (old == kNoneId) return true;
+        if (old == id) return false;
+        h = (h + 1) & mask;
+      }
+    };
+    bool hbm_used = false;       // kHash 3 / 5: this query has spilled ids into the table in memory (cleared on first use)
+    uint32_t q_hbm = 0;          // ... how many
     auto visit = [&](uint32_t id) -> bool {  // true if it was NOT visited before
-      if constexpr (kHash == 3) {
-        return visit_lds(id);
+      if constexpr (kHash == 3 || kHash == 5) {
+        return visit_lds(id) == 1u;                          // (the entry point: an empty set has room)
       } else if constexpr (kHash == 2) {
         uint32_t b;
         if (vis_lookup(id, b)) return false;
@@ -603,8 +634,8 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
       // slots past the count hold whatever the list held before -- never used)
       const uint32_t nid_first = (uint32_t)lane + 1 < a.l0_stride ? ll[1 + lane] : 0u;
       const uint32_t size = ll[0] & 0xFFFFu;
-      if constexpr (kHash == 3) {
-        if (q_vis + size > kLvMaxIds) { abandoned = true; break; }
+      if constexpr (kHash == 3 || kHash == 5) {   // (only the spill table can fill up)
+        if (q_hbm + size > (3u << a.vis_hash_log2) / 4u) { abandoned = true; break; }
       } else if constexpr (kHash != 0) {   // the table must not fill up: this query goes to the launch with the bitmap
         if (q_vis + size > (3u << a.vis_hash_log2) / 4u) { abandoned = true; break; }
       }
@@ -613,13 +644,28 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         const uint32_t i = base + lane;
         bool unv = false;
         uint32_t nid = 0;
-        if (i < size) { nid = base == 0 ? nid_first : ll[1 + i]; unv = visit(nid); }
+        if constexpr (kHash == 3 || kHash == 5) {
+          uint32_t r = 0;
+          if (i < size) { nid = base == 0 ? nid_first : ll[1 + i]; r = visit_lds(nid); }
+          unv = r == 1u;
+          const uint64_t spill = __ballot(r == 2u);
+          if (spill != 0) {                                   // rare: ids without room on chip
+            if (!hbm_used) {
+              uint4 *bm4 = reinterpret_cast<uint4 *>(bitmap);
+              for (uint32_t t = lane; t < a.bitmap_words / 4; t += kWave) bm4[t] = make_uint4(kNoneId, kNoneId, kNoneId, kNoneId);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              hbm_used = true;
+            }
+            if (r == 2u) unv = visit_hbm(nid);
+            q_hbm += (uint32_t)__popcll(spill);
+          }
+        } else {
+          if (i < size) { nid = base == 0 ? nid_first : ll[1 + i]; unv = visit(nid); }
+        }
         const uint64_t m = __ballot(unv);
         if (unv) nbr_id[nn + __popcll(m & ((1ull << lane) - 1ull))] = nid;
         nn += __popcll(m);
-      }
-      if constexpr (kHash == 3) {   // three full buckets in a row somewhere: the second launch answers this query
-        if (__ballot(vis_full) != 0) { abandoned = true; break; }
       }
       // phase 3a: distances, 16 rows per round; a round of <= 8 (<= 4) rows gives every row two (four) quads, which
       // fetch alternate batches of its pieces (same arithmetic, half / a quarter of the memory round trips)
@@ -820,6 +866,11 @@ template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 2) void hnsw_search_ldsvis_kernel(HnswSearchArgs a) {
   hnsw_search_body<kL2, kE, kBf16, 24, false, 0, 3>(a);
 }
+// ... and the 32 KB set (result lists up to 512 entries): ONE wave per SIMD, a whole 768-element row in flight per lane
+template <bool kL2, int kE, bool kBf16>
+__global__ __launch_bounds__(256, 1) void hnsw_search_ldsvis_big_kernel(HnswSearchArgs a) {
+  hnsw_search_body<kL2, kE, kBf16, 48, false, 0, 5>(a);
+}
 // searches with a filter or tombstones: the frontier lives in HBM (HnswSearchArgs::pool_g)
 template <bool kL2, int kE, bool kBf16>
 __global__ __launch_bounds__(256, 4) void hnsw_search_gpool_kernel(HnswSearchArgs a) {
@@ -878,7 +929,7 @@ static size_t hnsw_lds_per_wave(const HnswSearchArgs &a) {
   // HBM frontier: segment minima only (gpool_level 2: one per 64 segments)
   const size_t pool = a.gpool_level == 2 ? (size_t)(a.cand_cap / 8192) * 2
                       : a.gpool_level == 1 ? (size_t)(a.cand_cap / 128) * 2 : (size_t)a.cand_cap * 2;
-  const size_t vis_cnt_words = a.vis_hash_log2 && a.vis_mode == 3 ? kLvWords : a.vis_hash_log2 && a.vis_mode == 2 ? ((size_t)1 << a.vis_hash_log2) / (kVisBucket * 4) : 0;
+  const size_t vis_cnt_words = a.vis_hash_log2 && a.vis_mode == 5 ? LdsVis<true>::kWords : a.vis_hash_log2 && a.vis_mode == 3 ? LdsVis<false>::kWords : a.vis_hash_log2 && a.vis_mode == 2 ? ((size_t)1 << a.vis_hash_log2) / (kVisBucket * 4) : 0;
   const size_t per_wave_f4 = (size_t)a.chunks * 4 + ((lds_list ? 2 * a.ef : 0) + pool + a.nbr_cap * 2 + vis_cnt_words + 3) / 4;
   return per_wave_f4 * 16;
 }
@@ -903,7 +954,10 @@ static const void *hnsw_fn(bool latency, int gpool, int hash) {
   if constexpr (kE >= 1 && kE <= 4) {
     if (hash == 3) return reinterpret_cast<const void *>(&hnsw_search_ldsvis_kernel<kL2, kE, kBf16>);
   }
-  if (hash == 3) return nullptr;
+  if constexpr (kE >= 1 && kE <= 8) {
+    if (hash == 5) return reinterpret_cast<const void *>(&hnsw_search_ldsvis_big_kernel<kL2, kE, kBf16>);
+  }
+  if (hash == 3 || hash == 5) return nullptr;
   if (hash == 2) return reinterpret_cast<const void *>(&hnsw_search_bucket_kernel<kL2, kE, kBf16>);
   if (hash) return reinterpret_cast<const void *>(&hnsw_search_hash_kernel<kL2, kE, kBf16>);
   if constexpr (kE == 16) {   // (LDS-frontier kernels only)
@@ -934,7 +988,7 @@ static bool hnsw_latency_variant(const HnswSearchArgs &a) {
 }
 
 static const void *hnsw_pick(const HnswSearchArgs &a, bool l2, bool bf16, int e) {
-  const int hash = a.vis_hash_log2 == 0 ? 0 : a.vis_mode == 3 ? 3 : a.vis_mode == 2 ? 2 : 1;
+  const int hash = a.vis_hash_log2 == 0 ? 0 : a.vis_mode == 5 ? 5 : a.vis_mode == 3 ? 3 : a.vis_mode == 2 ? 2 : 1;
   if (hash && (a.gpool_level != 0 || a.redo_in != nullptr)) return nullptr;   // (LDS-frontier first launches only)
   const bool latency = !hash && hnsw_latency_variant(a);
   const int gpool = (int)a.gpool_level;
