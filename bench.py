@@ -462,6 +462,16 @@ def lib_multi_gpu(args, world, rank, dist, device):
         try:
             if vsa.lib().vk_device_count() < (1 if args.same_device else world):
                 raise RuntimeError(f"this process sees {vsa.lib().vk_device_count()} HIP devices, needs {world}")
+            # The library REFUSES devices without peer access (an index that looks multi-GPU and gathers through host memory).
+            # A benchmark run on such a box should still produce its line -- loudly labelled: the option is set for every index
+            # of this process and the line says so (config.peer_access).
+            distinct = sorted(set(devs))
+            no_peer = [(a, b) for a in distinct for b in distinct if a != b and not torch.cuda.can_device_access_peer(a, b)]
+            state["peer_access"] = not no_peer
+            if no_peer:
+                os.environ["VK_SHARD_ALLOW_STAGED"] = "1"
+                print(f"[bench] WARNING: no peer access between devices {no_peer[:4]}...: the sharded index stages its broadcast "
+                      f"and gather through host memory (VK_SHARD_ALLOW_STAGED=1 set for this run)", file=sys.stderr, flush=True)
             t_build = time.time()
             ix = vsa.Index("FLAT", D, "COSINE", initial_cap=N, dtype=args.dtype, shard_devices=devs, options={"kernel-timing": 1})
             tabs = []
@@ -648,6 +658,7 @@ def lib_multi_gpu(args, world, rank, dist, device):
                "config": {"workload": f"FLAT {N}x{D} {'bf16 rows' if bf16 else 'fp32'} COSINE k={K} batch={B} (BASELINE.json configs[1]), "
                                       f"rows dealt over {world} GPUs",
                           "rows_per_gpu": n_local, "sharding": f"rows/{world}", "recall_at_10": 1.0, "parity_vs_oracle": parity,
+                          "peer_access": state.get("peer_access", True),
                           "parallelism": f"one vk_index with n_shards={world} in ONE process"
                                          + (" (rank 0 of the launcher's ranks; the others idle)" if multi_proc else "")
                                          + ": queries broadcast by peer copy, one enqueue thread per shard, per-shard top-k "
