@@ -575,19 +575,19 @@ class HnswIndex final : public Index {
       // re-run like one that fills its table, and the LDS saved is resident waves at large ef)
       h.cand_cap = (uint32_t)((std::max<uint64_t>(cand_floor_, ef + std::max<uint64_t>(64, ef / 4)) + 3) & ~(uint64_t)3);
       if (h.vis_mode >= 3) {
-        // the set in LDS (12 KB per wave hold 4800 ids): ids below 2^24, result lists in registers (ef <= 256), two blocks of
-        // four waves must still fit a CU (rows of up to ~880 dimensions), and -- mode 3, the default -- a search that stays
-        // well below 4800 evaluations: measured 0.82 x ef x maxM0 on the graphs of the bench (ef = 128, M = 16: 3 373; at
-        // ef = 160: 4 101 and 54 of 8 192 queries re-run by the second launch, slower than the table in HBM).  Mode 4 takes
-        // the LDS set whenever it FITS (tests: queries that outgrow it are re-run).  Else the table in HBM, mode 0.
+        // the set in LDS (12 KB per wave, ~5500 ids before most new ones spill into the table in memory): ids below 2^24, result
+        // lists in registers (ef <= 256), two blocks of four waves must still fit a CU (rows of up to ~880 dimensions), and --
+        // mode 3, the default -- ef x maxM0 within the option hnsw-lds-visited-work: a search evaluates about 0.82 ef maxM0
+        // nodes, and one whose ids mostly spill probes the LDS buckets for nothing (10M x 768, M = 16: +15 % at ef = 128,
+        // +13 % at ef = 256 where 13 % of the ids spill).  Mode 4 takes an LDS set whenever it FITS (tests).
         const bool forced = h.vis_mode == 4;
         const uint64_t work = ef * (uint64_t)graph_->maxM0();
         h.vis_mode = 3;                                     // the 12 KB set: two blocks of four waves per CU
         const bool fits_small = count < (1u << 24) && e <= 4 && 2 * hnsw_lds_bytes(h) <= 160 * 1024;
         h.vis_mode = 5;                                     // the 32 KB set: one block of four waves per CU
         const bool fits_big = count < (1u << 24) && e <= 8 && hnsw_waves_per_block(h) == 4 && hnsw_lds_bytes(h) <= 160 * 1024;
-        if (fits_small && (forced || work <= kHnswLdsVisMaxWork)) h.vis_mode = 3;
-        else if (fits_big && (forced || work <= kHnswLdsVisBigMaxWork)) h.vis_mode = 5;
+        if (fits_small && (forced || work <= opt_.get(kOptHnswLdsWork))) h.vis_mode = 3;
+        else if (fits_big && (forced || work <= opt_.get(kOptHnswLdsWorkBig))) h.vis_mode = 5;
         else h.vis_mode = 0;
         // (the table in memory stays: ids that find no room on chip spill into it)
       }
