@@ -46,17 +46,19 @@ constexpr uint32_t kNoneId = 0xFFFFFFFFu;
 constexpr float kFltMax = 3.402823466e+38F;
 constexpr int kVisBucketLog2 = 3, kVisBucket = 1 << kVisBucketLog2;   // ids per bucket of the visited table (vis_mode 2)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// vis_mode 3: the visited set entirely in LDS -- kLvBuckets buckets of six 16-bit entries (12 B), 12 KB per wave.  An id
+// vis_mode 3: the visited set in LDS -- LdsVis::kBuckets buckets of six 16-bit entries (12 B), 12 KB per wave.  An id
 // below 2^24 has TWO home buckets, from two bijections of [0, 2^24) (odd multipliers): the top ten bits of the scrambled
 // id name the bucket, the low fourteen are what is stored, next to one bit that says which bijection and one that says
 // whether the entry sits in the home bucket or the one behind it (it goes there only when the home is full) -- so an
 // entry names ONE id wherever it lies: the set is exact.  An id goes to the emptier of its homes (two choices keep the
-// fullest bucket within a slot or two of the average); 0xFFFF = an empty slot.
-// Two sizes: 1024 buckets of six entries (12 KB per wave, 4800 ids: two waves per SIMD), and -- one wave per SIMD with a
-// whole row in flight per lane -- 2048 buckets of eight (32 KB, 12800 ids; thirteen stored bits, eleven bucket bits).
+// fullest bucket within a slot or two of the average); 0xFFFF = an empty slot; an id whose four candidate buckets are full
+// lives in the wave's table in memory instead (hnsw_search_body).
+// Two sizes: 1024 buckets of six entries (12 KB per wave, about 5500 ids before most new ones spill: two waves per SIMD), and
+// -- one wave per SIMD with a whole row in flight per lane -- 2048 buckets of eight (32 KB; thirteen stored bits, eleven
+// bucket bits).
 template <bool kBig> struct LdsVis {
   static constexpr uint32_t kRemBits = kBig ? 13 : 14, kBuckets = kBig ? 2048 : 1024, kSlots = kBig ? 8 : 6;
-  static constexpr uint32_t kWordsPerBucket = kSlots / 2, kWords = kBuckets * kWordsPerBucket, kMaxIds = kBig ? 12800 : 4800;
+  static constexpr uint32_t kWordsPerBucket = kSlots / 2, kWords = kBuckets * kWordsPerBucket;
 };
 
 // result list: rank r lives in slot r/64 of lane r%64, ascending by distance
@@ -322,7 +324,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
         b = (b + 1) & vis_bmask;
       }
     };
-    // kHash == 3 -- the set in LDS (see kLvBuckets).  Look-up and insert are one walk over at most three buckets: the id's
+    // kHash == 3 / 5 -- the set in LDS (see LdsVis).  Look-up and insert are one walk over at most four buckets: the id's
     // entry found -> visited; a free slot -> taken with a compare-and-swap of its 32-bit word (the lanes of the wave insert
     // the ids of one list at the same time; one that loses the word reads the bucket again -- and finds its own id there if
     // the list named it twice).  An id whose four candidate buckets are all full goes to the wave's table in HBM instead
