@@ -613,3 +613,19 @@ def test_second_bound_of_the_rerank_changes_nothing_but_the_work(vsa, oracle, me
         for i in (0, 3, 11, 40, 76):
             od, ol = o.search(Q[i], 10)
             assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist(), (cap, i)
+
+
+def test_first_batch_of_a_fresh_index_with_nothing_allowed(vsa, oracle):
+    """The re-rank of an EMPTY survivor list must not take whatever the (never written) list memory holds for a row slot: the
+    very first batch of a fresh index, with a filter that allows no row at all, answers with empty lists -- and the index
+    then answers the next, unfiltered batch exactly."""
+    rng = np.random.default_rng(99)
+    n, dim = 70_000, 64
+    x = _unit(rng.standard_normal((n, dim)).astype(np.float32))
+    labels = rng.permutation(n).astype(np.uint64)
+    f, e = _pair(vsa, dim, "COSINE", x, labels)
+    Q = _unit(rng.standard_normal((64, dim)).astype(np.float32))
+    none = oracle.allow_bitmap(np.zeros(0, np.uint64), n)
+    D, L, N = f.search_batch(Q, 10, allow=none, allow_nbits=n)
+    assert (N == 0).all()
+    _same(f.search_batch(Q, 10), e.search_batch(Q, 10))

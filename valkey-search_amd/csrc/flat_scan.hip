@@ -312,7 +312,9 @@ __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeA
   for (int u = 0; u < kPer; ++u) {
     const uint32_t i = (uint32_t)u * kWave + lane;
     const uint32_t ic = i < n_sel ? i : (n_sel ? n_sel - 1 : 0u);
-    rowv[u] = cand[ic];
+    // (an EMPTY list -- every row of a query filtered out -- has nothing at entry 0 but what an earlier batch, or nobody, left
+    //  there: not to be used as a row slot for the tile-norm look-up below)
+    rowv[u] = n_sel ? cand[ic] : 0u;
     valv[u] = prune ? a.cand_val[(size_t)q * a.cand_cap + ic] : 0.f;
   }
 #ifdef VK_EXPERIMENTS
