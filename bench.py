@@ -212,8 +212,8 @@ def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
             **head, "single_query_ms": round(lat_ms, 3),
             "roofline": {"bound": "hbm", "achieved": head["useful_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": head["frac_of_hbm_peak"],
-                         "kernel": "hnsw_search_ldsvis_kernel" if ef <= 256 else "hnsw_search_hash_kernel",
-                         "visited_set": "LDS, 12 KB per wave, spill to memory (option hnsw-visited-mode 3)" if ef <= 256 else "hash table in HBM",
+                         "kernel": "hnsw_search_ldsvis_kernel" if ef <= 448 else "hnsw_search_hash_kernel",
+                         "visited_set": "LDS, 12 KB per wave, spill to memory (option hnsw-visited-mode 3)" if ef <= 448 else "hash table in HBM",
                          "bytes": "n_eval*(D*4+4) + n_hops*132 per query, counted by the kernel",
                          "gather_ceiling_gbs": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r01_gather_ceiling_10Mx768.log"},
             "matched_recall_0.95": matched, "ef_sweep": sweep, "single_query_serving": serving,

@@ -286,15 +286,15 @@ struct HnswSearchArgs {
   uint32_t vis_hash_log2;
   // how the hash set is kept (option hnsw-visited-mode): 0 = compare-and-swap at agent scope (r02), 1 = the same at
   // WAVEFRONT scope -- the set is private to its wave, nothing outside it ever looks --, 2 = buckets in HBM with their
-  // fill counts in LDS (no atomics on memory), 3 = the set in LDS (graphs below 2^24 nodes, ef <= 256, ef x maxM0 <= hnsw-lds-visited-work:
+  // fill counts in LDS (no atomics on memory), 3 = the set in LDS (graphs below 2^24 nodes, ef <= ~450, ef x maxM0 <= hnsw-lds-visited-work:
   // 12 KB per wave hold about 5500 ids; ids that find no room on chip spill into the table in memory); the option's 4 = 3 whenever
   // the set fits the LDS at all (tests)
   uint32_t vis_mode;
 };
-// vis_mode 3: result lists in registers up to 256 entries and ef x maxM0 up to the option hnsw-lds-visited-work (12288) keep the
-// visited set in 12 KB of LDS (ids beyond its ~5500 spill into the table in memory); hnsw-lds-visited-work-big (12288)
-// takes a 32 KB set with one wave per SIMD (vis_mode 5, chosen by the host) where the small one has no kernel (result lists of
-// eight slots per lane, ef 257..512): slower than the small one + spill wherever both exist, +1..11 % over the table in memory at ef = 384
+// vis_mode 3: result lists in registers at up to eight slots per lane, two blocks of four waves per CU (ef up to ~450 at 768
+// dimensions) and ef x maxM0 up to the option hnsw-lds-visited-work (14400) keep the visited set in 12 KB of LDS (ids beyond its
+// ~5500 spill into the table in memory); hnsw-lds-visited-work-big (default 0 = off) takes a 32 KB set with one wave per SIMD
+// (vis_mode 5, chosen by the host): measured slower than the small one + spill at every ef
 constexpr int kHnswLdsList = 255;     // hnsw_slots_per_lane(): 1024 < ef <= kHnswMaxEf, result list in LDS (also 512 < ef <= 1024
                                       // when the frontier lives in HBM: those kernels have no 16-slot variant)
 constexpr uint64_t kHnswMaxEf = 16384;   // (2 * ef words of LDS: the default max-vector-knn of 10000 fits, ft_search_parser.cc:34-45)
