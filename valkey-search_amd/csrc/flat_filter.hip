@@ -10,8 +10,11 @@
 //
 // L_q is a lower bound of the query's k-th best EXACT score and E_q(R) bounds |approx - exact| (plus the reference's
 // own rounding) rigorously for a row of norm <= R; R_t is the largest row norm of the 128-row tile the row lives in.
-// The survivors -- a few hundred per query out of 10M -- are re-ranked by the exact quad kernel (flat_scan.hip with a
-// row list) and selected by (distance,label), so the answer is BIT-IDENTICAL to the exact path's; only the work differs.
+// The survivors -- a few hundred per query out of 10M -- go, WITH their approximate scores, to the fused re-rank
+// (flat_rerank_kernel, flat_scan.hip): a second bound taken from those scores (the k-th largest score - E over a query's
+// survivors bounds its k-th best exact score from the whole index, not from the sample) leaves about k + 1 of them, which
+// get an exact distance from the quad kernel's arithmetic and are selected by (distance,label) -- so the answer is
+// BIT-IDENTICAL to the exact path's; only the work differs.
 //
 // Where L_q comes from (r03; r02 ran the exact kernel over the first rows, a filter pass over a larger prefix and a
 // re-rank of that -- eleven launches, and a bound that depended on the order the index was loaded in): one pass of THIS

@@ -225,15 +225,20 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatScanArgs a) {
 }
 
 // ---- fused re-rank + selection of the candidate filter's survivors (k <= 64) ------------------------------------------------
-// kRerankParts blocks of four waves per query.  The query's survivor list (private list, then spill chunks) is dealt to the
-// 32 waves sixteen rows at a time -- the quad kernel's exact arithmetic --, every wave keeps its k best in registers, a
-// block's four lists are merged by its wave 0 through LDS and written as the block's partial list; the block that
-// finishes LAST for its query (a counter per query) merges the partial lists, rank-sorts by (distance, label) and writes
-// the query's ANSWER.  r03 ran this as two launches (flat_scan_kernel in list mode, then merge_select_kernel over the
-// partial lists) and looked a row's label up inside the serial insert loop: a dependent 8-byte read from HBM per kept row,
-// one after the other -- that, not the row gathers, was most of the kernel's 125 us at 10M x 768.  Here the label of every
-// row of a round is requested together with the row (profiles/r04_step_trace_*.log).
-// A query with tens of thousands of survivors (duplicates of one vector) still spreads over 32 waves.
+// One launch turns a query's survivor list (private list, then spill chunks; row slots with their approximate scores) into
+// its ANSWER:
+//   1. the second bound: from the survivors' own scores a lower bound of the k-th best exact score, and with it the few
+//      entries of the list that can still be among the k best (about k + 1 of a few hundred);
+//   2. exact distances of those -- the quad kernel's arithmetic, sixteen rows per wave and round, labels requested with the
+//      rows (r03 looked a label up inside the serial insert loop: a dependent 8-byte read per kept row) --, every wave
+//      keeping its k best in registers;
+//   3. the block's four lists merged by its wave 0 through LDS, rank-sorted by (distance, label), written out.
+// A short list (up to kRerankSoloMax survivors: the usual case) is served by ONE block per query -- part 0 --, the whole list
+// in registers; the other kRerankParts - 1 blocks of the query leave at once.  A long list (a query on tens of thousands of
+// duplicates of one vector: spill chunks) is walked by all kRerankParts blocks, a contiguous slice per wave, each block
+// writes a partial list, and the block that finishes LAST for its query (a counter per query) merges the partial lists and
+// writes the answer.  r03 ran steps 2 and 3 as two launches (flat_scan_kernel in list mode, merge_select_kernel).
+// (profiles/r04_step_trace_*.log, profiles/r04_rerank_stamps.log: 143 us -> 32 us at 10M x 768.)
 constexpr int kRerankParts = 8;
 constexpr uint32_t kRerankSlots = 576;       // LDS row slots per wave: eight steps of 64 entries (a short list's share) + one more
 constexpr uint32_t kRerankSoloMax = 2048;    // survivors one block re-ranks alone
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeA
   // (margin = the query's error polynomial at the row's tile norm: what the gate of flat_filter.hip charges).  k distinct
   // rows reach the k-th largest lo, so it bounds the k-th best exact score from below; a survivor whose hi stays under it
   // cannot be among the k best (ties at the k-th score have hi >= score = bound: kept, and settled by the exact
-  // (distance, label) order).  The bound comes from the first kSel survivors (any k distinct rows will do).
+  // (distance, label) order).  The bound comes from the first kPer * 64 survivors (any k distinct rows will do).
   const bool prune = a.cand_val != nullptr;
   float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
   float thr2 = -__builtin_inff();
