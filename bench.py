@@ -858,6 +858,14 @@ def serving_leg(ix, hq, K, device_qps, max_batch, wait_us, producers, window, to
         vsa.probe_submit(ix, hq, K, min(total, 4 * max_batch), producers, window, ef, ref=(rd, rl))     # warm-up: runner threads, contexts
         sub = vsa.probe_submit(ix, hq, K, total, producers, window, ef, ref=(rd, rl))
         blk = vsa.probe_blocking(ix, hq, K, threads, calls, ef, ref=(rd, rl))
+        # ... and THROUGH THE ADAPTOR CLASSES (include/vk_vector_adaptor.h on the mock of VectorBase, scripts/adaptor_probe.cc):
+        # a reader pool of the box's cores; SearchAsync with `window` FT.SEARCHes outstanding (the clients' concurrency), the
+        # coalescing the adaptor sets itself; and the reference's blocking Search() from the same pool
+        readers = effective_cpus()
+        hnsw_ix = ix.algo == "HNSW"
+        vsa.adaptor_probe(ix, hq, K, min(total, 4 * max_batch), readers, window, ef, hnsw=hnsw_ix, ref=(rd, rl))
+        ada = vsa.adaptor_probe(ix, hq, K, total, readers, window, ef, hnsw=hnsw_ix, ref=(rd, rl))
+        adb = vsa.adaptor_probe(ix, hq, K, max(readers * 24, total // 8), readers, readers, ef, hnsw=hnsw_ix, blocking=True, ref=(rd, rl))
     finally:
         ix.set_coalescing(0, 0)
     st = ix.stats()
@@ -871,6 +879,9 @@ def serving_leg(ix, hq, K, device_qps, max_batch, wait_us, producers, window, to
     return {"max_batch": max_batch, "max_wait_us": wait_us, "device_batch_qps": round(device_qps, 1) if device_qps else None,
             "submit": row(sub, producers=producers, outstanding=window),
             "blocking": row(blk, callers=threads, calls_per_caller=calls),
+            "adaptor": {"async": row(ada, reader_threads=readers, outstanding=window, entry="VectorGpu::SearchAsync"),
+                        "blocking": row(adb, reader_threads=readers, entry="VectorGpu::Search"),
+                        "cancelled_early": int(st.cancelled_early)},
             "latency_hist_us_pow2_from_64": list(st.latency_hist)}
 
 

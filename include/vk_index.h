@@ -167,6 +167,21 @@ typedef struct vk_index_stats {
   /* batched FLAT through the candidate filter, most recent batch (host entry points): survivors that passed the re-rank's
    * second bound -- the rows that actually got an exact distance -- summed over the queries */
   uint64_t last_filter_reranked;
+  /* the largest label the index has ever held (0 when empty): VectorBase resumes its id counter from it after an RDB load
+   * (GetMaxInternalLabel, vector_hnsw.cc:387-394; vector_base.cc:480-481) */
+  uint64_t max_label;
+  /* dispatcher: members of device batches that were answered (or left) BEFORE their batch finished because their own token
+   * went up; device-resident filters: built, served from the cache, looked up and not found, resident right now (count, bytes) */
+  uint64_t cancelled_early;
+  uint64_t filters_built;
+  uint64_t filter_cache_hits;
+  uint64_t filter_cache_misses;
+  uint64_t filter_cache_entries;
+  uint64_t filter_cache_bytes;
+  /* HNSW: vk_index_add calls that were staged and linked later in bulk (at vk_index_flush / the next search), and how many of
+   * those went through the device build (K9) rather than the host builder */
+  uint64_t staged_adds;
+  uint64_t staged_adds_device;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------
@@ -282,6 +297,50 @@ int vk_index_search_submit(vk_index *ix, const void *query, uint64_t k, uint64_t
                            const volatile int *cancel_flag, int partial_ok,
                            float *out_dist, uint64_t *out_label, uint64_t *out_n,
                            vk_search_done_fn done, void *user);
+/* ---- device-resident filters ---------------------------------------------------------------------------------------------
+ * The reference filters an HNSW search with InlineVectorFilter (src/query/search.cc:103-134), a functor called per visited
+ * candidate.  A kernel cannot call a functor: a search carries a bitmap over the labels.  What the query layer HOLDS for a
+ * predicate is not a bitmap but the EntriesFetchers of its terms (search.cc:301-399; src/indexes/tag.cc:383-455 yields the
+ * keys of the matched tags) -- lists of keys, i.e. of internal ids.  vk_filter_create builds the bitmap ON THE DEVICE from
+ * such lists: `labels` in any order, duplicates allowed (the union of several fetchers, search.cc:208-220), and / or sorted
+ * `runs` of consecutive ids ([n_runs][2] = first, last inclusive; what a numeric range over ids assigned in ingest order
+ * yields), on top of an optional host bitmap `base_bits` of nbits bits (NULL = start empty).  Labels >= nbits are ignored
+ * (rejected by every search, like allow_nbits above).  Cost: 8 B per id over PCIe + one scatter pass, instead of a host sweep
+ * over every label of the index per query (r04: 10M functor calls per FT.SEARCH).
+ * A filter is reference counted: the creator holds one reference (vk_filter_release drops it), every search in flight holds
+ * one, so a caller may release -- or time out and leave -- while its batch is still on the device.  A filter belongs to
+ * the index it was created for (its bitmap lives on that index's device(s)) and is immutable.
+ *   vk_filter_combine: a OP b (0 = and, 1 = or, 2 = a and not b) of two filters of one index and one nbits, on the device:
+ *   composed predicates over cached terms (search.cc:326-360 intersects by re-evaluating the predicate per key). */
+typedef struct vk_filter vk_filter;
+int vk_filter_create(vk_index *ix, uint64_t nbits, const uint64_t *labels, uint64_t n_labels, const uint64_t *runs,
+                     uint64_t n_runs, const uint64_t *base_bits, vk_filter **out);
+int vk_filter_combine(vk_index *ix, const vk_filter *a, const vk_filter *b, uint32_t op, vk_filter **out);
+void vk_filter_retain(vk_filter *f);
+void vk_filter_release(vk_filter *f);
+/* nbits, and the number of allowed labels (counted on the device: what query::UsePreFiltering, planner.cc:21-45, wants as
+ * its estimate) */
+int vk_filter_info(const vk_filter *f, uint64_t *out_nbits, uint64_t *out_allowed);
+/* the bitmap back on the host: n_words words, zero filled past the filter's end (tests, debugging) */
+int vk_filter_read(const vk_filter *f, uint64_t *out_words, uint64_t n_words);
+/* Cache: filters of one index under a caller-chosen key (e.g. the predicate's canonical text, "@tag:{x}") and EPOCH -- any
+ * counter that changes whenever the answer of the predicate may have changed (the module: the count of write phases of the
+ * schema's time-sliced mutex, src/index_schema.cc:285-292; finer: a mutation counter of the attribute's own index).  get
+ * returns a retained handle in *out, or NULL when the key is unknown or was stored under another epoch (the stale entry is
+ * dropped); put stores (and retains) the handle, replacing an older entry; the cache is bounded by the options
+ * filter-cache-entries / filter-cache-bytes, least recently used first. */
+int vk_index_filter_cache_get(vk_index *ix, const void *key, uint64_t key_len, uint64_t epoch, vk_filter **out);
+int vk_index_filter_cache_put(vk_index *ix, const void *key, uint64_t key_len, uint64_t epoch, vk_filter *f);
+/* searches with a filter handle (NULL = unfiltered): as vk_index_search / vk_index_search_submit / vk_index_search_batch_filters */
+int vk_index_search_filter(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, vk_filter *filter,
+                           const volatile int *cancel_flag, int partial_ok, float *out_dist, uint64_t *out_label, uint64_t *out_n);
+int vk_index_search_submit_filter(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, vk_filter *filter,
+                                  const volatile int *cancel_flag, int partial_ok, float *out_dist, uint64_t *out_label,
+                                  uint64_t *out_n, vk_search_done_fn done, void *user);
+int vk_index_search_batch_filter_handles(vk_index *ix, const void *queries, uint64_t nq, uint64_t k, uint64_t ef_runtime,
+                                         vk_filter *const *filters, const volatile int *cancel_flag, int partial_ok,
+                                         float *out_dist, uint64_t *out_label, uint64_t *out_n);
+
 /* Run-time options: the analogue of `CONFIG SET search.<name>` (src/valkey_search_options.cc:74-81 hnsw-block-size,
  * :150-162 hnsw-allow-replace-deleted / hnsw-validation-enable, :231-234 max-query-queue-depth, :363-390
  * prefiltering-threshold-ratio).  Names (csrc/options.hpp has the table with defaults and ranges), e.g.
@@ -326,6 +385,13 @@ typedef int (*vk_write_chunk_fn)(void *user, const void *data, uint64_t len);
 typedef int (*vk_read_chunk_fn)(void *user, void *buf, uint64_t cap, uint64_t *len);
 int vk_index_save(vk_index *ix, vk_write_chunk_fn write_chunk, void *user);
 int vk_index_load(const vk_index_params *params, vk_read_chunk_fn read_chunk, void *user, vk_index **out);
+/* The same with the VectorTracker hook of LoadIndex (bruteforce.h:171-207 at :201, hnswalg.h:887-1139 at :1000: every loaded vector is
+ * handed to vector_tracker->TrackVector(label, data, len), which is how VectorBase gets its interned vectors back after a
+ * restart, vector_base.cc:333-338): on_row(row_user, label, row) is called once per element with the dim f32 values as
+ * they lie in the stream, in stream order, from the loading thread; non-zero aborts the load (VK_ERR_INTERNAL). */
+typedef int (*vk_row_fn)(void *user, uint64_t label, const void *row);
+int vk_index_load_tracked(const vk_index_params *params, vk_read_chunk_fn read_chunk, void *user, vk_row_fn on_row,
+                          void *row_user, vk_index **out);
 
 #ifdef __cplusplus
 }

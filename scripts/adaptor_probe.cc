@@ -1,0 +1,214 @@
+// adaptor_probe.cc -- single-query FT.SEARCH traffic THROUGH THE ADAPTOR CLASSES (include/vk_vector_adaptor.h: VectorGpuFlat /
+// VectorGpuHNSW derived from the mock of VectorBase, tests/helpers/mock_valkey_search.h), driven natively against an index
+// the benchmark already holds (adopted, not owned).  The shape is query::SearchAsync's (src/query/search.cc:886-910):
+//   a "main thread" keeps `window` FT.SEARCH requests outstanding (the clients' concurrency) and schedules each on a reader
+//   pool of `readers` threads (reader-threads = the box's cores); the pool task calls
+//     async    VectorGpu::SearchAsync -- returns after the submission; the library's completion re-posts a task to the pool
+//              that takes the reply (CreateReply's key lookups already done) and frees the request slot, or
+//     blocking VectorGpu::Search      -- what PerformVectorSearch does today (search.cc:135-170): the pool thread is parked
+//              until the answer is there, so at most `readers` queries are in flight.
+// Every reply is compared with a reference answer of the same query (ids and distance bits).  bench.py:
+// single_query_serving.adaptor.  Built by __graft_entry__.build() as a shared library (g++, no HIP).
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "mock_valkey_search.h"
+#include "vk_vector_adaptor.h"
+
+extern "C" int ValkeyModule_ReplyWithSimpleString(ValkeyModuleCtx *, const char *) { return 0; }
+extern "C" int ValkeyModule_ReplyWithLongLong(ValkeyModuleCtx *, long long) { return 0; }
+
+extern "C" {
+struct vk_probe_result {   // == scripts/serving_probe.cc
+  double qps, seconds;
+  uint64_t completed, rejected, mismatches, errors;
+  uint64_t device_batches, max_batches_in_flight;
+  double mean_batch, p50_us, p99_us, max_us;
+};
+}
+
+namespace {
+using namespace valkey_search;
+using namespace valkey_search::indexes;
+typedef std::chrono::steady_clock Clock;
+
+struct NeverCancelled : cancel::Base {
+  bool IsCancelled() override { return false; }
+  void Cancel() override {}
+};
+
+// vmsdk::ThreadPool in a dozen lines: FIFO, `n` workers
+class Pool {
+ public:
+  explicit Pool(int n) {
+    for (int i = 0; i < n; ++i) ts_.emplace_back([this] { Run(); });
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &t : ts_) t.join();
+  }
+  void Schedule(std::function<void()> f) {
+    { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); }
+    cv_.notify_one();
+  }
+
+ private:
+  void Run() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+        if (q_.empty()) return;
+        f = std::move(q_.front());
+        q_.pop_front();
+      }
+      f();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> q_;
+  std::vector<std::thread> ts_;
+  bool stop_ = false;
+};
+
+struct Run {
+  const float *ref_d;
+  const uint64_t *ref_l;
+  uint64_t k;
+  std::atomic<uint64_t> completed{0}, mismatches{0}, errors{0}, rejected{0};
+  std::mutex mu;
+  std::condition_variable cv;
+  int free_slots = 0;
+  std::vector<float> lat_us;
+  bool same(uint64_t qi, const std::vector<Neighbor> &r) const {
+    if (!ref_d) return true;
+    if (r.size() != k) return false;
+    for (uint64_t i = 0; i < k; ++i) {
+      if (memcmp(&r[i].distance, ref_d + qi * k + i, 4) != 0) return false;
+      if (strtoull(std::string(r[i].external_id->Str()).c_str(), nullptr, 10) != ref_l[qi * k + i]) return false;
+    }
+    return true;
+  }
+  void finish(uint64_t qi, Clock::time_point t0, const absl::StatusOr<std::vector<Neighbor>> &r) {
+    const float us = (float)std::chrono::duration<double, std::micro>(Clock::now() - t0).count();
+    if (!r.ok()) errors.fetch_add(1, std::memory_order_relaxed);
+    else if (!same(qi, r.value())) mismatches.fetch_add(1, std::memory_order_relaxed);
+    completed.fetch_add(1, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      lat_us.push_back(us);
+      free_slots += 1;
+    }
+    cv.notify_one();
+  }
+};
+
+template <class Ix>
+int drive(Ix &ix, const float *queries, uint64_t nq, uint32_t dim, uint64_t k, uint64_t ef, int readers, int window, uint64_t total, int blocking,
+          Run &run, vk_probe_result *out) {
+  vk_index_stats st0{}, st1{};
+  vk_index_get_stats(ix.handle(), &st0);
+  run.free_slots = window;
+  run.lat_us.reserve((size_t)total + 16);
+  cancel::Token token = std::make_shared<NeverCancelled>();
+  const Clock::time_point t0 = Clock::now();
+  {
+    Pool pool(readers);
+    for (uint64_t i = 0; i < total; ++i) {
+      {   // the clients' concurrency: `window` requests outstanding
+        std::unique_lock<std::mutex> lk(run.mu);
+        run.cv.wait(lk, [&] { return run.free_slots > 0; });
+        run.free_slots -= 1;
+      }
+      const uint64_t qi = i % nq;
+      const Clock::time_point ts = Clock::now();
+      pool.Schedule([&, qi, ts] {
+        absl::string_view q(reinterpret_cast<const char *>(queries + qi * dim), (size_t)dim * 4);
+        std::optional<size_t> efo;
+        if (ef) efo = (size_t)ef;
+        if (blocking) {
+          cancel::Token tk = token;
+          run.finish(qi, ts, ix.Search(q, k, tk, VkFilterRef(), efo, false));
+          return;
+        }
+        for (;;) {
+          absl::Status st = ix.SearchAsync(q, k, token, VkFilterRef(), efo, false, [&run, &pool, qi, ts](absl::StatusOr<std::vector<Neighbor>> r) {
+            // (a library thread: the reply goes back to the pool, like ResolveContent / QueryCompleteBackground)
+            auto shared = std::make_shared<absl::StatusOr<std::vector<Neighbor>>>(std::move(r));
+            pool.Schedule([&run, qi, ts, shared] { run.finish(qi, ts, *shared); });
+          });
+          if (st.ok()) break;
+          if (st.code() != absl::StatusCode::kResourceExhausted) { run.finish(qi, ts, st); break; }
+          run.rejected.fetch_add(1, std::memory_order_relaxed);
+          std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+      });
+    }
+    std::unique_lock<std::mutex> lk(run.mu);
+    run.cv.wait(lk, [&] { return run.free_slots == window; });
+  }   // (the pool drains and joins)
+  out->seconds = std::chrono::duration<double>(Clock::now() - t0).count();
+  vk_index_get_stats(ix.handle(), &st1);
+  out->completed = run.completed.load();
+  out->rejected = run.rejected.load();
+  out->mismatches = run.mismatches.load();
+  out->errors = run.errors.load();
+  out->qps = out->seconds > 0 ? (double)out->completed / out->seconds : 0;
+  out->device_batches = st1.coalesced_batches - st0.coalesced_batches;
+  out->mean_batch = out->device_batches ? (double)(st1.coalesced_queries - st0.coalesced_queries) / (double)out->device_batches : 0;
+  out->max_batches_in_flight = st1.max_batches_in_flight;
+  std::vector<float> &v = run.lat_us;
+  if (!v.empty()) {
+    std::sort(v.begin(), v.end());
+    out->p50_us = v[v.size() / 2];
+    out->p99_us = v[std::min(v.size() - 1, v.size() * 99 / 100)];
+    out->max_us = v.back();
+  }
+  return VK_OK;
+}
+}  // namespace
+
+// `ix` stays the caller's; max_batch / wait_us: the coalescing the adaptor would set from reader-threads (0 = its defaults)
+extern "C" int vk_adaptor_probe(vk_index *ix, int hnsw, uint32_t dim, uint32_t m, const float *queries, uint64_t nq, uint64_t k, uint64_t ef,
+                                int readers, int window, uint64_t total, int blocking, uint32_t max_batch, uint32_t wait_us, const float *ref_d,
+                                const uint64_t *ref_l, vk_probe_result *out) {
+  memset(out, 0, sizeof(*out));
+  if (!ix || !queries || nq == 0 || readers < 1 || window < 1) return VK_ERR_INVALID;
+  data_model::VectorIndex proto;
+  proto.dimension_count_ = dim;
+  // (rows and queries are normalised by the benchmark already: the inner-product space, no second normalisation of the query)
+  proto.distance_metric_ = data_model::DISTANCE_METRIC_IP;
+  proto.hnsw_.m_ = m ? m : 16;
+  Run run;
+  run.ref_d = ref_d;
+  run.ref_l = ref_l;
+  run.k = k;
+  int rc;
+  if (hnsw) {
+    auto a = VectorGpuHNSW<float>::FromHandle(ix, proto, "v", data_model::ATTRIBUTE_DATA_TYPE_HASH, (uint32_t)readers);
+    if (!a.ok()) return VK_ERR_INTERNAL;
+    a.value()->MockAllKeysLive();
+    if (max_batch) vk_index_set_coalescing(ix, max_batch, wait_us);
+    rc = drive(*a.value(), queries, nq, dim, k, ef, readers, window, total, blocking, run, out);
+  } else {
+    auto a = VectorGpuFlat<float>::FromHandle(ix, proto, "v", data_model::ATTRIBUTE_DATA_TYPE_HASH, (uint32_t)readers);
+    if (!a.ok()) return VK_ERR_INTERNAL;
+    a.value()->MockAllKeysLive();
+    if (max_batch) vk_index_set_coalescing(ix, max_batch, wait_us);
+    rc = drive(*a.value(), queries, nq, dim, k, ef, readers, window, total, blocking, run, out);
+  }
+  return rc;
+}

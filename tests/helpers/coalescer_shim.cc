@@ -13,7 +13,7 @@
 namespace {
 struct FakeIndex final : vk::Index {
   explicit FakeIndex(const vk_index_params &p) : Index(p) {}
-  std::atomic<uint64_t> calls{0}, queries{0}, max_batch{0}, concurrent{0}, max_concurrent{0}, cancelled_batches{0};
+  std::atomic<uint64_t> calls{0}, queries{0}, max_batch{0}, concurrent{0}, max_concurrent{0}, cancelled_batches{0}, member_words_seen{0};
   int delay_us = 200;   // a device pass takes a while: requests pile up behind it
   vk::Status search(const vk::SearchRequest &rq, float *od, uint64_t *ol, uint64_t *on) override {
     calls += 1;
@@ -26,8 +26,13 @@ struct FakeIndex final : vk::Index {
     // the "device pass": like the real kernels it polls the batch's cancellation word and stops early when it goes up
     const auto end = std::chrono::steady_clock::now() + std::chrono::microseconds(delay_us);
     bool stopped = false;
+    std::vector<uint8_t> seen(rq.nq, 0);
     while (std::chrono::steady_clock::now() < end) {
       if (vk::cancel_raised(rq.cancel_flag)) { stopped = true; break; }
+      // (like the HNSW kernel: a member's own word stops the work on that member only)
+      if (rq.member_cancel)
+        for (uint64_t q = 0; q < rq.nq; ++q)
+          if (!seen[q] && __atomic_load_n(const_cast<const uint32_t *>(&rq.member_cancel[q]), __ATOMIC_RELAXED)) { seen[q] = 1; member_words_seen += 1; }
       std::this_thread::sleep_for(std::chrono::microseconds(delay_us > 1000 ? 100 : 20));
     }
     if (stopped) cancelled_batches += 1;
@@ -38,7 +43,8 @@ struct FakeIndex final : vk::Index {
       const uint64_t n = rq.k < 3 ? rq.k : 3;            // "fewer than k found" is part of the contract
       on[q] = n;
       // a per-query filter shows in the answer: word 0 of the query's own bitmap is added to every label
-      const uint64_t tag = rq.allow_tab && rq.allow_tab[q] ? rq.allow_tab[q][0] + rq.allow_nbits_tab[q] : 0;
+      // (a FLAT lane shares one filter: it arrives as the batch's allow_bits)
+      const uint64_t tag = rq.allow_tab && rq.allow_tab[q] ? rq.allow_tab[q][0] + rq.allow_nbits_tab[q] : (rq.allow_bits ? rq.allow_bits[0] + rq.allow_nbits : 0);
       for (uint64_t i = 0; i < n; ++i) {
         od[q * rq.k + i] = v[0] * 1000.f + (float)i + (float)rq.ef * 0.001f;
         ol[q * rq.k + i] = (uint64_t)v[1] * 10 + i + tag;
@@ -62,6 +68,7 @@ struct FakeIndex final : vk::Index {
   vk::Status device_rows(uint64_t, void **, uint64_t *) override { return vk::Status::Ok(); }
   vk::Status commit_device_rows(uint64_t, const uint64_t *) override { return vk::Status::Ok(); }
   vk::Status save(vk_write_chunk_fn, void *) override { return vk::Status::Ok(); }
+  void filter_devices(std::vector<int> *out) const override { out->clear(); }
 };
 }  // namespace
 
@@ -74,6 +81,7 @@ extern "C" int coalescer_run(int threads, int per_thread, uint32_t max_batch, ui
   vk_index_params p{};
   p.struct_size = sizeof p;
   p.dim = 4;
+  p.algo = VK_ALGO_HNSW;   // (a filter per query inside one batch; a FLAT index groups filtered requests into lanes by filter: dispatcher_async_run)
   FakeIndex ix(p);
   vk::Dispatcher co(&ix);
   co.configure(max_batch, max_wait_us);
@@ -95,7 +103,7 @@ extern "C" int coalescer_run(int threads, int per_thread, uint32_t max_batch, ui
       const uint64_t nbits = 64 + (uint64_t)(id % 5);
       volatile int flag = cancelled ? 1 : 0;
       if (toggle && id == threads * per_thread / 2) co.configure(0, 0);      // coalescing switched off under load
-      vk::Status st = co.search(q, k, ef, filtered ? bits : nullptr, filtered ? nbits : 0, &flag, true, d, l, &n);
+      vk::Status st = co.search(q, k, ef, filtered ? bits : nullptr, filtered ? nbits : 0, nullptr, &flag, true, d, l, &n);
       if (cancelled) {
         if (!st.ok() || n != 0) bad += 1;
         continue;
@@ -191,7 +199,7 @@ extern "C" int dispatcher_async_run(int producers, int per_producer, int window,
         s->flag = s->cancelled ? 1 : 0;
         s->n = 99;
         s->completions = &completions;
-        vk::Status st = dp.submit(s->q, 3, 100, s->filtered ? s->bits : nullptr, s->filtered ? 64 : 0, s->id % 2 ? &s->flag : (s->cancelled ? &s->flag : nullptr),
+        vk::Status st = dp.submit(s->q, 3, 100, s->filtered ? s->bits : nullptr, s->filtered ? 64 : 0, nullptr, s->id % 2 ? &s->flag : (s->cancelled ? &s->flag : nullptr),
                                   /*partial_ok=*/false, s->d, s->l, &s->n, async_done, s.get());
         if (!st.ok()) {
           if (st.code != VK_ERR_BUSY) bad += 1;
@@ -251,7 +259,7 @@ extern "C" int dispatcher_destroy_run(int rounds, int n_req) {
         s->q[0] = (float)i; s->q[1] = (float)(i + 7); s->q[2] = s->q[3] = 0.f;
         s->flag = 0;
         s->completions = &completions;
-        if (dp.submit(s->q, 3, 100 + (uint64_t)(i % 2), nullptr, 0, nullptr, true, s->d, s->l, &s->n, async_done, s.get()).ok()) accepted += 1;
+        if (dp.submit(s->q, 3, 100 + (uint64_t)(i % 2), nullptr, 0, nullptr, nullptr, true, s->d, s->l, &s->n, async_done, s.get()).ok()) accepted += 1;
         slots.push_back(std::move(s));
       }
       if (r % 2) std::this_thread::sleep_for(std::chrono::microseconds(700));   // some batches are on the device by now
@@ -283,7 +291,7 @@ extern "C" int dispatcher_batch_cancel_run(int all_cancel, uint64_t *out) {
     ts.emplace_back([&, t] {
       float q[4] = {(float)t, (float)(t + 7), 0.f, 0.f}, d[16];
       uint64_t l[16], n = 99;
-      vk::Status st = dp.search(q, 3, 100, nullptr, 0, &flags[t], /*partial_ok=*/false, d, l, &n);
+      vk::Status st = dp.search(q, 3, 100, nullptr, 0, nullptr, &flags[t], /*partial_ok=*/false, d, l, &n);
       const bool mine_up = all_cancel || t != 0;
       if (mine_up ? st.code != VK_ERR_CANCELLED : (!st.ok() || n != 3)) bad += 1;
     });
@@ -291,7 +299,126 @@ extern "C" int dispatcher_batch_cancel_run(int all_cancel, uint64_t *out) {
   for (int t = all_cancel ? 0 : 1; t < 8; ++t) __atomic_store_n(const_cast<int *>(&flags[t]), 1, __ATOMIC_RELAXED);
   for (auto &t : ts) t.join();
   out[0] = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+  // (the callers leave on their own tokens; the batch they left behind stops when the watcher has seen all eight)
+  dp.shutdown();
+  out[3] = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
   out[1] = ix.cancelled_batches;
   out[2] = ix.calls;
+  return bad.load();
+}
+
+// ONE member of a batch on the device is cancelled while the others live on: it must come back at once (r04: with its batch).
+// Blocking callers poll their own token; submitted requests are answered by the watcher.  The batch runs to its end, the
+// member's own word goes up (the HNSW kernel's wave stops there), the other members get their full answers.
+// out[0] = microseconds between raising the member's token and its return / callback, out[1] = total milliseconds,
+// out[2] = member words the "device" saw go up, out[3] = dispatcher's count of early leavers.
+namespace {
+struct CancelSlot {
+  float q[4], d[16];
+  uint64_t l[16], n = 99;
+  volatile int flag = 0;
+  std::atomic<int> done{0};
+  int status = -1;
+  std::chrono::steady_clock::time_point t_done;
+};
+void cancel_done(void *user, int status) {
+  CancelSlot *s = static_cast<CancelSlot *>(user);
+  s->status = status;
+  s->t_done = std::chrono::steady_clock::now();
+  s->done.store(1, std::memory_order_release);
+}
+}  // namespace
+
+extern "C" int dispatcher_member_cancel_run(int hnsw, int use_submit, int victim, uint64_t *out) {
+  vk_index_params p{};
+  p.struct_size = sizeof p;
+  p.dim = 4;
+  p.algo = hnsw ? VK_ALGO_HNSW : VK_ALGO_FLAT;
+  FakeIndex ix(p);
+  ix.delay_us = 200000;   // 0.2 s on the "device"
+  std::atomic<int> bad{0};
+  std::vector<std::unique_ptr<CancelSlot>> slots;
+  for (int t = 0; t < 8; ++t) {
+    slots.push_back(std::make_unique<CancelSlot>());
+    slots[t]->q[0] = (float)t; slots[t]->q[1] = (float)(t + 7); slots[t]->q[2] = slots[t]->q[3] = 0.f;
+  }
+  std::chrono::steady_clock::time_point t_raise, t_back[8];
+  const auto t0 = std::chrono::steady_clock::now();
+  {
+    vk::Dispatcher dp(&ix);
+    dp.configure(8, 20000);
+    std::vector<std::thread> ts;
+    if (use_submit) {
+      for (int t = 0; t < 8; ++t)
+        if (!dp.submit(slots[t]->q, 3, 100, nullptr, 0, nullptr, &slots[t]->flag, /*partial_ok=*/false, slots[t]->d, slots[t]->l, &slots[t]->n,
+                       cancel_done, slots[t].get()).ok()) bad += 1;
+    } else {
+      for (int t = 0; t < 8; ++t)
+        ts.emplace_back([&, t] {
+          CancelSlot &s = *slots[t];
+          vk::Status st = dp.search(s.q, 3, 100, nullptr, 0, nullptr, &s.flag, /*partial_ok=*/false, s.d, s.l, &s.n);
+          t_back[t] = std::chrono::steady_clock::now();
+          s.status = st.code;
+        });
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(40));     // the batch of eight is on the device
+    t_raise = std::chrono::steady_clock::now();
+    __atomic_store_n(const_cast<int *>(&slots[victim]->flag), 1, __ATOMIC_RELAXED);
+    if (use_submit) {
+      for (int t = 0; t < 8; ++t) {
+        while (slots[t]->done.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        t_back[t] = slots[t]->t_done;
+      }
+    } else {
+      for (auto &t : ts) t.join();
+    }
+    out[3] = dp.left_early();
+  }
+  for (int t = 0; t < 8; ++t) {
+    const CancelSlot &s = *slots[t];
+    if (t == victim) {
+      if (hnsw ? s.status != VK_ERR_CANCELLED : (s.status != VK_OK || s.n != 0)) bad += 1;
+    } else {
+      if (s.status != VK_OK || s.n != 3 || s.l[0] != (uint64_t)(t + 7) * 10) bad += 1;
+      // (the others stayed for the whole pass)
+      if (t_back[t] - t0 < std::chrono::milliseconds(150)) bad += 1;
+    }
+  }
+  out[0] = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t_back[victim] - t_raise).count();
+  out[1] = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+  out[2] = ix.member_words_seen;
+  return bad.load();
+}
+
+// FLAT: `threads` blocking callers, back to back, max_batch = threads.  One pass costs the same for a half-empty batch, so the
+// callers must keep travelling TOGETHER (r04: two batches of half the callers each in flight).  out[0] = device passes,
+// out[1] = queries served.
+extern "C" int dispatcher_flat_fill_run(int threads, int calls, int delay_us, int hnsw, uint64_t *out) {
+  vk_index_params p{};
+  p.struct_size = sizeof p;
+  p.dim = 4;
+  p.algo = hnsw ? VK_ALGO_HNSW : VK_ALGO_FLAT;
+  FakeIndex ix(p);
+  ix.delay_us = delay_us;
+  std::atomic<int> bad{0};
+  {
+    vk::Dispatcher dp(&ix);
+    dp.configure((uint32_t)threads, getenv("VK_TEST_WAIT_US") ? (uint32_t)atoi(getenv("VK_TEST_WAIT_US")) : 200);
+    dp.set_in_flight(2);
+    std::vector<std::thread> ts;
+    for (int t = 0; t < threads; ++t)
+      ts.emplace_back([&, t] {
+        for (int r = 0; r < calls; ++r) {
+          const int id = t * calls + r;
+          float q[4] = {(float)id, (float)(id + 7), 0.f, 0.f}, d[16];
+          uint64_t l[16], n = 99;
+          vk::Status st = dp.search(q, 3, 100, nullptr, 0, nullptr, nullptr, true, d, l, &n);
+          if (!st.ok() || n != 3 || l[0] != (uint64_t)(id + 7) * 10) bad += 1;
+        }
+      });
+    for (auto &t : ts) t.join();
+  }
+  out[0] = ix.calls;
+  out[1] = ix.queries;
   return bad.load();
 }

@@ -13,10 +13,15 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <optional>
+#include <queue>
 #include <string>
 #include <string_view>
+#include <unordered_set>
 #include <utility>
 #include <variant>
 #include <vector>
@@ -135,9 +140,60 @@ class RDBChunkOutputStream {
   virtual ~RDBChunkOutputStream() = default;
   virtual absl::Status SaveChunk(const char *data, size_t len) = 0;
 };
+// rdb_serialization.h:162-205: the chunks of one supplemental-content section, move-only; the mock iterates a vector
+class SupplementalContentChunkIter {
+ public:
+  explicit SupplementalContentChunkIter(std::vector<std::string> chunks) : chunks_(std::move(chunks)) {}
+  SupplementalContentChunkIter(SupplementalContentChunkIter &&) noexcept = default;
+  SupplementalContentChunkIter &operator=(SupplementalContentChunkIter &&) noexcept = default;
+  SupplementalContentChunkIter(const SupplementalContentChunkIter &) = delete;
+  bool HasNext() const { return next_ < chunks_.size(); }
+  absl::StatusOr<std::unique_ptr<std::string>> Next() { return std::make_unique<std::string>(std::move(chunks_[next_++])); }
+
+ private:
+  std::vector<std::string> chunks_;
+  size_t next_ = 0;
+};
+// rdb_serialization.h:289-303, rdb_serialization.cc:103-109
+class RDBChunkInputStream {
+ public:
+  explicit RDBChunkInputStream(SupplementalContentChunkIter &&iter) : iter_(std::move(iter)) {}
+  RDBChunkInputStream(RDBChunkInputStream &&) noexcept = default;
+  absl::StatusOr<std::unique_ptr<std::string>> LoadChunk() {
+    if (!iter_.HasNext()) return absl::NotFoundError("No more elements remaining");
+    return iter_.Next();
+  }
+
+ private:
+  SupplementalContentChunkIter iter_;
+};
+// attribute_data_type.h:61-81 (the one member LoadFromRDB uses)
+class AttributeDataType {
+ public:
+  virtual ~AttributeDataType() = default;
+  virtual data_model::AttributeDataType ToProto() const = 0;
+};
+class HashAttributeDataType : public AttributeDataType {
+ public:
+  data_model::AttributeDataType ToProto() const override { return data_model::ATTRIBUTE_DATA_TYPE_HASH; }
+};
 
 namespace indexes {
 enum class IndexerType { kHNSW, kFlat };
+// index_base.h:103-116: what Tag::Search / Numeric::Search hand to the query layer
+class EntriesFetcherIteratorBase {
+ public:
+  virtual bool Done() const = 0;
+  virtual void Next() = 0;
+  virtual const InternedStringPtr &operator*() const = 0;
+  virtual ~EntriesFetcherIteratorBase() = default;
+};
+class EntriesFetcherBase {
+ public:
+  virtual size_t Size() const = 0;
+  virtual ~EntriesFetcherBase() = default;
+  virtual std::unique_ptr<EntriesFetcherIteratorBase> Begin() = 0;
+};
 struct Neighbor {
   InternedStringPtr external_id;
   float distance = 0.f;
@@ -156,15 +212,35 @@ class VectorBase {
   virtual size_t GetLabelCount() const { return 0; }
   bool GetNormalize() const { return normalize_; }
   int GetVectorDataSize() const { return (int)GetDataTypeSize() * dimensions_; }
+  // (the mock's key of internal id N is the string "N"; ids that were removed have no key any more)
   absl::StatusOr<InternedStringPtr> GetKeyDuringSearch(uint64_t internal_id) const {
+    if (!mock_all_live_) {
+      std::lock_guard<std::mutex> l(mock_mu_);
+      if (!mock_live_.count(internal_id)) return absl::InvalidArgumentError("Record was not found");
+    }
     return std::make_shared<InternedString>(std::to_string(internal_id));
+  }
+  void MockAllKeysLive() { mock_all_live_ = true; }   // (an adopted index: every label has its key)
+  // vector_base.cc:333-338: the VectorTracker entry LoadIndex calls -- intern, then the virtual
+  char *TrackVector(uint64_t internal_id, char *vector, size_t len) {
+    auto interned = std::make_shared<InternedString>(std::string(vector, len));
+    {
+      std::lock_guard<std::mutex> l(mock_mu_);
+      mock_live_.insert(internal_id);
+    }
+    TrackVector(internal_id, interned);
+    return const_cast<char *>(interned->Str().data());
   }
   // What the real base class's public entry points (AddRecord, RemoveRecord, ModifyRecord, SaveIndex, RespondWithInfo,
   // ToProto, GetValue, ComputeDistanceFromRecord: vector_base.cc) reach after their key <-> id bookkeeping: the Impl
   // virtuals, called here with the internal id directly.
   absl::Status MockAdd(uint64_t id, absl::string_view record, const InternedStringPtr &vector) {
     absl::Status st = AddRecordImpl(id, record);
-    if (st.ok()) TrackVector(id, vector);
+    if (st.ok()) {
+      TrackVector(id, vector);
+      std::lock_guard<std::mutex> l(mock_mu_);
+      mock_live_.insert(id);
+    }
     return st;
   }
   absl::Status MockModify(uint64_t id, absl::string_view record, const InternedStringPtr &vector) {
@@ -174,7 +250,11 @@ class VectorBase {
   }
   absl::Status MockRemove(uint64_t id) {
     absl::Status st = RemoveRecordImpl(id);
-    if (st.ok()) UnTrackVector(id);
+    if (st.ok()) {
+      UnTrackVector(id);
+      std::lock_guard<std::mutex> l(mock_mu_);
+      mock_live_.erase(id);
+    }
     return st;
   }
   bool MockIsVectorMatch(uint64_t id, const InternedStringPtr &vector) { return IsVectorMatch(id, vector); }
@@ -201,7 +281,22 @@ class VectorBase {
   virtual void TrackVector(uint64_t internal_id, const InternedStringPtr &vector) = 0;
   virtual bool IsVectorMatch(uint64_t internal_id, const InternedStringPtr &vector) = 0;
   virtual void UnTrackVector(uint64_t internal_id) = 0;
+  // vector_base.cc:203-210.  PRIVATE upstream: the one access change the adaptor needs
+  absl::StatusOr<uint64_t> GetInternalIdDuringSearch(const InternedStringPtr &key) const {
+    const std::string k(key->Str());
+    char *end = nullptr;
+    const unsigned long long id = std::strtoull(k.c_str(), &end, 10);
+    if (end == k.c_str() || *end) return absl::InvalidArgumentError("Record was not found");
+    if (!mock_all_live_) {
+      std::lock_guard<std::mutex> l(mock_mu_);
+      if (!mock_live_.count(id)) return absl::InvalidArgumentError("Record was not found");
+    }
+    return (uint64_t)id;
+  }
 
+  mutable std::mutex mock_mu_;
+  std::unordered_set<uint64_t> mock_live_;
+  bool mock_all_live_ = false;
   int dimensions_;
   std::string attribute_identifier_;
   bool normalize_{false};

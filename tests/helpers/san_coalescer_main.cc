@@ -34,12 +34,15 @@ static int cancel_mid_batch(int rounds) {
         std::thread raiser;
         const bool cancels = t % 2 == 1;
         if (cancels) raiser = std::thread([&flag] { std::this_thread::sleep_for(std::chrono::microseconds(1200)); __atomic_store_n(const_cast<int *>(&flag), 1, __ATOMIC_RELAXED); });
-        vk::Status st = co.search(q.get(), 3, 100, bits.get(), 64, &flag, /*partial_ok=*/t % 4 == 1, d, l, &n);
+        // rounds alternate: a raw host bitmap pins the caller to its batch (the runner reads it); without one the caller
+        // LEAVES when its token goes up -- its query, its token and its output buffers die while the batch is on the device
+        const bool pinned = r % 2 == 0;
+        vk::Status st = co.search(q.get(), 3, 100, pinned ? bits.get() : nullptr, pinned ? 64 : 0, nullptr, &flag, /*partial_ok=*/t % 4 == 1, d, l, &n);
         q.reset();                           // the module's buffers die with the call
         bits.reset();
         if (raiser.joinable()) raiser.join();
         if (!cancels) {
-          if (!st.ok() || n != 3 || l[0] != (uint64_t)(id + 7) * 10 + (uint64_t)id * 1000 + 64) bad += 1;
+          if (!st.ok() || n != 3 || l[0] != (uint64_t)(id + 7) * 10 + (pinned ? (uint64_t)id * 1000 + 64 : 0)) bad += 1;
         } else if (t % 4 == 1) {             // partial results wanted: an answer or nothing, never an error
           if (!st.ok()) bad += 1;
         } else {                             // HNSW without partial results: cancelled (or served before the flag)
@@ -67,6 +70,10 @@ int main(int argc, char **argv) {
   bad += dispatcher_destroy_run(6 * scale, 50);
   bad += dispatcher_batch_cancel_run(1, out);
   bad += dispatcher_batch_cancel_run(0, out);
+  // one member of a live batch cancelled: blocking and submitted, both index kinds
+  for (int hnsw = 0; hnsw < 2; ++hnsw)
+    for (int sub = 0; sub < 2; ++sub) bad += dispatcher_member_cancel_run(hnsw, sub, 3, out);
+  bad += dispatcher_flat_fill_run(32, 6, 2000, 0, out);
   printf("bad=%d\n", bad);
   return bad ? 1 : 0;
 }

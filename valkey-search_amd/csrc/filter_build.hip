@@ -1,0 +1,87 @@
+// filter_build.hip -- allow-sets built ON THE DEVICE from what the query layer already holds.
+//
+// valkey-search filters an HNSW search with InlineVectorFilter (src/query/search.cc:103-134): a functor called per visited
+// candidate, label -> key -> predicate.  A functor cannot be called from a kernel, so a search carries a bitmap over the
+// labels instead.  The module does not have that bitmap -- it has the EntriesFetchers of the predicate
+// (search.cc:301-399; tag.cc:383-455 yields the keys of the matched tags), i.e. LISTS of keys / internal ids.  These
+// kernels turn such lists (ids in any order, duplicates allowed: an OR of fetchers, search.cc:208-220) or sorted id RUNS
+// [first, last] into the bitmap: 8 B per listed id over PCIe and one scatter pass instead of a host sweep over every
+// label of the index.  HBM-bound integer work: one u64 load per id, one atomic OR per id (ids of one fetcher are random
+// in label space, so neighbouring lanes seldom share a word); runs are written a word per lane.
+#include <algorithm>
+
+#include "kernels.hpp"
+
+namespace vk {
+namespace {
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void filter_set_ids_kernel(unsigned long long *bits, uint64_t nbits, const uint64_t *ids, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) {
+    const uint64_t id = ids[i];
+    if (id < nbits) atomicOr(&bits[id >> 6], 1ull << (id & 63));   // (labels beyond the bitmap are rejected, vk_index.h allow_nbits)
+  }
+}
+
+// one wave per run: the run's words are dealt to the lanes, the two edge words are masked.  Runs may overlap or share a
+// word with their neighbours, hence the atomic.
+__global__ __launch_bounds__(kThreads) void filter_set_runs_kernel(unsigned long long *bits, uint64_t nbits, const uint64_t *runs, uint64_t n_runs) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, waves = ((uint64_t)gridDim.x * kThreads) >> 6;
+  for (uint64_t r = wave; r < n_runs; r += waves) {
+    uint64_t lo = runs[2 * r], hi = runs[2 * r + 1];
+    if (lo > hi || lo >= nbits) continue;
+    if (hi >= nbits) hi = nbits - 1;
+    const uint64_t w0 = lo >> 6, w1 = hi >> 6;
+    for (uint64_t w = w0 + lane; w <= w1; w += 64) {
+      unsigned long long m = ~0ull;
+      if (w == w0) m &= ~0ull << (lo & 63);
+      if (w == w1) m &= ~0ull >> (63 - (hi & 63));
+      atomicOr(&bits[w], m);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void filter_popcount_kernel(const unsigned long long *bits, uint64_t words, unsigned long long *out) {
+  unsigned long long c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < words; i += (uint64_t)gridDim.x * kThreads) c += (unsigned long long)__popcll(bits[i]);
+  for (int off = 32; off; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63u) == 0 && c) atomicAdd(out, c);
+}
+
+// dst = a OP b over `words` words (0 = and, 1 = or, 2 = and-not): composed predicates whose parts are cached bitmaps
+__global__ __launch_bounds__(kThreads) void filter_combine_kernel(unsigned long long *dst, const unsigned long long *a, const unsigned long long *b,
+                                                                   uint64_t words, uint32_t op) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < words; i += (uint64_t)gridDim.x * kThreads) {
+    const unsigned long long x = a[i], y = b[i];
+    dst[i] = op == 0 ? (x & y) : op == 1 ? (x | y) : (x & ~y);
+  }
+}
+
+inline uint32_t grid_for(uint64_t items) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (items + kThreads - 1) / kThreads), 256 * 8); }
+}  // namespace
+
+hipError_t launch_filter_set_ids(uint64_t *bits, uint64_t nbits, const uint64_t *d_ids, uint64_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(filter_set_ids_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, reinterpret_cast<unsigned long long *>(bits), nbits, d_ids, n);
+  return hipGetLastError();
+}
+hipError_t launch_filter_set_runs(uint64_t *bits, uint64_t nbits, const uint64_t *d_runs, uint64_t n_runs, hipStream_t s) {
+  if (n_runs == 0) return hipSuccess;
+  hipLaunchKernelGGL(filter_set_runs_kernel, dim3(grid_for(n_runs * 64)), dim3(kThreads), 0, s, reinterpret_cast<unsigned long long *>(bits), nbits, d_runs,
+                     n_runs);
+  return hipGetLastError();
+}
+hipError_t launch_filter_popcount(const uint64_t *bits, uint64_t words, unsigned long long *d_out, hipStream_t s) {
+  if (words == 0) return hipSuccess;
+  hipLaunchKernelGGL(filter_popcount_kernel, dim3(grid_for(words)), dim3(kThreads), 0, s, reinterpret_cast<const unsigned long long *>(bits), words, d_out);
+  return hipGetLastError();
+}
+hipError_t launch_filter_combine(uint64_t *dst, const uint64_t *a, const uint64_t *b, uint64_t words, uint32_t op, hipStream_t s) {
+  if (words == 0) return hipSuccess;
+  hipLaunchKernelGGL(filter_combine_kernel, dim3(grid_for(words)), dim3(kThreads), 0, s, reinterpret_cast<unsigned long long *>(dst),
+                     reinterpret_cast<const unsigned long long *>(a), reinterpret_cast<const unsigned long long *>(b), words, op);
+  return hipGetLastError();
+}
+
+}  // namespace vk

@@ -1,0 +1,189 @@
+// filter_set.cc -- see filter_set.hpp.
+#include "filter_set.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <string.h>
+
+#include "kernels.hpp"
+
+namespace vk {
+namespace {
+std::atomic<uint64_t> g_next_id{1};
+
+// one build stream + pinned staging block per device, shared by the builds on it (they are short and serialise)
+struct BuildLane {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  char *pin = nullptr;
+  size_t pin_cap = 0;
+  void *d_stage = nullptr;
+  size_t d_cap = 0;
+  unsigned long long *d_count = nullptr;
+};
+BuildLane *lane_of(int device) {
+  static std::mutex mu;
+  static std::vector<std::unique_ptr<BuildLane>> lanes;
+  std::lock_guard<std::mutex> lk(mu);
+  if ((size_t)device >= lanes.size()) lanes.resize((size_t)device + 1);
+  if (!lanes[(size_t)device]) lanes[(size_t)device] = std::make_unique<BuildLane>();
+  return lanes[(size_t)device].get();
+}
+constexpr size_t kStageBytes = (size_t)4 << 20;   // ids travel in 4 MiB pieces through pinned memory: copy k+1 is filled while k is in flight
+
+Status lane_ready(BuildLane *l) {
+  if (!l->stream) VK_HIP_TRY(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+  if (!l->pin) {
+    VK_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&l->pin), 2 * kStageBytes, hipHostMallocDefault));
+    l->pin_cap = 2 * kStageBytes;
+  }
+  if (!l->d_count) VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&l->d_count), 8));
+  return Status::Ok();
+}
+Status stage_ensure(BuildLane *l, size_t bytes) {
+  if (bytes <= l->d_cap) return Status::Ok();
+  if (l->d_stage) (void)hipFree(l->d_stage);
+  l->d_stage = nullptr;
+  l->d_cap = 0;
+  const size_t want = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
+  VK_HIP_TRY(hipMalloc(&l->d_stage, want));
+  l->d_cap = want;
+  return Status::Ok();
+}
+// host words -> device through the two halves of the pinned block
+Status upload(BuildLane *l, void *d_dst, const void *h_src, size_t bytes) {
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  VK_HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+  VK_HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  Status st = Status::Ok();
+  bool used[2] = {false, false};
+  size_t off = 0;
+  for (int h = 0; off < bytes && st.ok(); h ^= 1) {
+    const size_t n = std::min(kStageBytes, bytes - off);
+    if (used[h]) {
+      hipError_t e = hipEventSynchronize(ev[h]);
+      if (e != hipSuccess) { st = Status::Err(4, std::string("hipEventSynchronize: ") + hipGetErrorString(e)); break; }
+    }
+    memcpy(l->pin + (size_t)h * kStageBytes, static_cast<const char *>(h_src) + off, n);
+    hipError_t e = hipMemcpyAsync(static_cast<char *>(d_dst) + off, l->pin + (size_t)h * kStageBytes, n, hipMemcpyHostToDevice, l->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev[h], l->stream);
+    if (e != hipSuccess) { st = Status::Err(4, std::string("filter upload: ") + hipGetErrorString(e)); break; }
+    used[h] = true;
+    off += n;
+  }
+  (void)hipStreamSynchronize(l->stream);
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  return st;
+}
+}  // namespace
+
+FilterSet::~FilterSet() {
+  for (Copy &c : copies_) {
+    (void)hipSetDevice(c.device);
+    if (c.bits) (void)hipFree(c.bits);
+  }
+}
+
+Status FilterSet::build(const std::vector<int> &devices, uint64_t nbits, const uint64_t *ids, uint64_t n_ids, const uint64_t *runs,
+                        uint64_t n_runs, const uint64_t *host_bits, std::shared_ptr<FilterSet> *out) {
+  if (devices.empty()) return Status::Err(1, "filter: the index has no device");
+  if (nbits >= ((uint64_t)1 << 40)) return Status::Err(1, "filter: nbits out of range");
+  if ((n_ids && !ids) || (n_runs && !runs)) return Status::Err(1, "filter: NULL id list");
+  std::shared_ptr<FilterSet> f(new FilterSet());
+  f->nbits_ = nbits;
+  f->id_ = g_next_id.fetch_add(1, std::memory_order_relaxed);
+  const size_t words = (size_t)f->words();
+  const size_t alloc = (words + 1) * 8;             // (one word of slack: the kernels read whole words)
+  for (int dev : devices) {
+    bool have = false;
+    for (const Copy &c : f->copies_) have = have || c.device == dev;
+    if (have) continue;                              // (logical shards share a device)
+    VK_HIP_TRY(hipSetDevice(dev));
+    uint64_t *p = nullptr;
+    VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), alloc));
+    f->copies_.push_back(Copy{dev, p});
+  }
+  const int dev0 = f->copies_[0].device;
+  BuildLane *l = lane_of(dev0);
+  {
+    std::lock_guard<std::mutex> lk(l->mu);
+    VK_HIP_TRY(hipSetDevice(dev0));
+    VK_TRY(lane_ready(l));
+    uint64_t *bits = f->copies_[0].bits;
+    VK_HIP_TRY(hipMemsetAsync(bits, 0, alloc, l->stream));
+    if (host_bits && words) VK_TRY(upload(l, bits, host_bits, words * 8));
+    if (host_bits && words && nbits % 64) {   // (a caller's bitmap may carry stray bits past nbits in its last word: they would be counted)
+      const uint64_t last = host_bits[words - 1] & (~0ull >> (64 - nbits % 64));
+      VK_HIP_TRY(hipMemcpyAsync(bits + words - 1, &last, 8, hipMemcpyHostToDevice, l->stream));
+      VK_HIP_TRY(hipStreamSynchronize(l->stream));
+    }
+    if (n_ids) {
+      VK_TRY(stage_ensure(l, (size_t)n_ids * 8));
+      VK_TRY(upload(l, l->d_stage, ids, (size_t)n_ids * 8));
+      VK_HIP_TRY(launch_filter_set_ids(bits, nbits, static_cast<const uint64_t *>(l->d_stage), n_ids, l->stream));
+      VK_HIP_TRY(hipStreamSynchronize(l->stream));   // (the staging block is reused by the runs below / the next build)
+    }
+    if (n_runs) {
+      VK_TRY(stage_ensure(l, (size_t)n_runs * 16));
+      VK_TRY(upload(l, l->d_stage, runs, (size_t)n_runs * 16));
+      VK_HIP_TRY(launch_filter_set_runs(bits, nbits, static_cast<const uint64_t *>(l->d_stage), n_runs, l->stream));
+    }
+    VK_HIP_TRY(hipMemsetAsync(l->d_count, 0, 8, l->stream));
+    VK_HIP_TRY(launch_filter_popcount(bits, words, l->d_count, l->stream));
+    unsigned long long cnt = 0;
+    VK_HIP_TRY(hipMemcpyAsync(&cnt, l->d_count, 8, hipMemcpyDeviceToHost, l->stream));
+    for (size_t c = 1; c < f->copies_.size(); ++c)
+      VK_HIP_TRY(hipMemcpyPeerAsync(f->copies_[c].bits, f->copies_[c].device, bits, dev0, alloc, l->stream));
+    VK_HIP_TRY(hipStreamSynchronize(l->stream));
+    f->allowed_ = cnt;
+  }
+  *out = std::move(f);
+  return Status::Ok();
+}
+
+Status FilterSet::combine(const FilterSet &a, const FilterSet &b, uint32_t op, std::shared_ptr<FilterSet> *out) {
+  if (op > 2) return Status::Err(1, "filter: unknown combine op");
+  std::vector<int> devs;
+  for (const Copy &c : a.copies_)
+    if (b.bits_on(c.device)) devs.push_back(c.device);
+  if (devs.empty() || devs.size() != a.copies_.size() || devs.size() != b.copies_.size())
+    return Status::Err(1, "filter: the two filters live on different devices");
+  // the result covers the longer of the two; the shorter one reads as zeros beyond its end (its allocation is zeroed up
+  // to its own slack word only, so it is widened first when the sizes differ)
+  if (a.nbits_ != b.nbits_) return Status::Err(1, "filter: combine needs filters of one size (build both with the same nbits)");
+  std::shared_ptr<FilterSet> f;
+  VK_TRY(build(devs, a.nbits_, nullptr, 0, nullptr, 0, nullptr, &f));
+  const size_t words = (size_t)f->words();
+  for (const Copy &c : f->copies_) {
+    BuildLane *l = lane_of(c.device);
+    std::lock_guard<std::mutex> lk(l->mu);
+    VK_HIP_TRY(hipSetDevice(c.device));
+    VK_TRY(lane_ready(l));
+    VK_HIP_TRY(launch_filter_combine(c.bits, a.bits_on(c.device), b.bits_on(c.device), words, op, l->stream));
+    if (&c == &f->copies_[0]) {
+      unsigned long long cnt = 0;
+      VK_HIP_TRY(hipMemsetAsync(l->d_count, 0, 8, l->stream));
+      VK_HIP_TRY(launch_filter_popcount(c.bits, words, l->d_count, l->stream));
+      VK_HIP_TRY(hipMemcpyAsync(&cnt, l->d_count, 8, hipMemcpyDeviceToHost, l->stream));
+      VK_HIP_TRY(hipStreamSynchronize(l->stream));
+      f->allowed_ = cnt;
+    } else {
+      VK_HIP_TRY(hipStreamSynchronize(l->stream));
+    }
+  }
+  *out = std::move(f);
+  return Status::Ok();
+}
+
+Status FilterSet::read(uint64_t *out_words, uint64_t n_words) const {
+  if (copies_.empty()) return Status::Err(4, "filter: no device copy");
+  const uint64_t n = std::min<uint64_t>(n_words, words());
+  VK_HIP_TRY(hipSetDevice(copies_[0].device));
+  if (n) VK_HIP_TRY(hipMemcpy(out_words, copies_[0].bits, (size_t)n * 8, hipMemcpyDeviceToHost));
+  for (uint64_t i = n; i < n_words; ++i) out_words[i] = 0;
+  return Status::Ok();
+}
+
+}  // namespace vk

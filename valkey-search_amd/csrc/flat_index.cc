@@ -75,26 +75,43 @@ Status SearchCtx::end_async(hipStream_t s) {
   return Status::Ok();
 }
 
-Status SearchCtx::arm_cancel(const volatile int *caller_flag, const uint32_t **device_word) {
+Status SearchCtx::arm_cancel(const volatile int *caller_flag, const uint32_t **device_word, uint64_t n_members,
+                             const uint32_t **member_words) {
   *device_word = nullptr;
-  if (!caller_flag) return Status::Ok();
-  VK_TRY(h_cancel.ensure(64));
-  *h_cancel.as<volatile uint32_t>() = 0u;   // (the waiting thread raises it; a flag that was up at entry is the caller's case)
-  *device_word = h_cancel.as<uint32_t>();
+  if (member_words) *member_words = nullptr;
+  if (!caller_flag && (!n_members || !member_words)) return Status::Ok();
+  if (!member_words) n_members = 0;
+  VK_TRY(h_cancel.ensure((kMemberCancelOffset + n_members) * 4 + 64));
+  volatile uint32_t *w = h_cancel.as<volatile uint32_t>();
+  w[0] = 0u;   // (the waiting thread raises it; a flag that was up at entry is the caller's case)
+  for (uint64_t i = 0; i < n_members; ++i) w[kMemberCancelOffset + i] = 0u;
+  if (caller_flag) *device_word = h_cancel.as<uint32_t>();
+  if (n_members) *member_words = h_cancel.as<uint32_t>() + kMemberCancelOffset;
   return Status::Ok();
 }
 
-Status SearchCtx::wait(const volatile int *caller_flag) {
-  if (!caller_flag || !h_cancel.p) {
+Status SearchCtx::wait(const volatile int *caller_flag) { return wait(caller_flag, nullptr, 0); }
+
+Status SearchCtx::wait(const volatile int *caller_flag, const volatile uint32_t *member_cancel, uint64_t nq) {
+  if ((!caller_flag && !member_cancel) || !h_cancel.p) {
     VK_HIP_TRY(hipStreamSynchronize(stream));
     return Status::Ok();
   }
   volatile uint32_t *word = h_cancel.as<volatile uint32_t>();
+  auto last_members = std::chrono::steady_clock::now();
   for (unsigned spins = 0;; ++spins) {
     const hipError_t e = hipStreamQuery(stream);
     if (e == hipSuccess) return Status::Ok();
     if (e != hipErrorNotReady) return Status::Err(4, std::string("hipStreamQuery: ") + hipGetErrorString(e));
     if (cancel_raised(caller_flag)) *word = 1u;
+    if (member_cancel) {   // (a sweep over the members' words every 50 us: the batch may hold thousands)
+      const auto now = std::chrono::steady_clock::now();
+      if (now - last_members >= std::chrono::microseconds(50)) {
+        last_members = now;
+        for (uint64_t i = 0; i < nq; ++i)
+          if (member_cancel[i] && !word[kMemberCancelOffset + i]) word[kMemberCancelOffset + i] = 1u;
+      }
+    }
     if (spins < 2000) __builtin_ia32_pause();
     else std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
@@ -228,11 +245,14 @@ Status search_grouped_by_filter(Index *ix, const SearchRequest &rq, float *out_d
   std::vector<uint8_t> done(rq.nq, 0);
   std::vector<float> Q, D;
   std::vector<uint64_t> L, N, idx;
+  auto fs = [&](uint64_t q) { return rq.filter_tab ? rq.filter_tab[q] : nullptr; };
+  auto ab = [&](uint64_t q) { return rq.allow_tab && !fs(q) ? rq.allow_tab[q] : nullptr; };
+  auto nb = [&](uint64_t q) { return ab(q) ? rq.allow_nbits_tab[q] : 0; };
   for (uint64_t q0 = 0; q0 < rq.nq; ++q0) {
     if (done[q0]) continue;
     idx.clear();
     for (uint64_t q = q0; q < rq.nq; ++q)
-      if (!done[q] && rq.allow_tab[q] == rq.allow_tab[q0] && rq.allow_nbits_tab[q] == rq.allow_nbits_tab[q0]) { idx.push_back(q); done[q] = 1; }
+      if (!done[q] && fs(q) == fs(q0) && ab(q) == ab(q0) && nb(q) == nb(q0)) { idx.push_back(q); done[q] = 1; }
     const uint64_t m = idx.size();
     Q.resize(m * dim);
     D.resize(m * rq.k);
@@ -245,8 +265,11 @@ Status search_grouped_by_filter(Index *ix, const SearchRequest &rq, float *out_d
     g.nq = m;
     g.allow_tab = nullptr;
     g.allow_nbits_tab = nullptr;
-    g.allow_bits = rq.allow_tab[q0];
-    g.allow_nbits = rq.allow_nbits_tab[q0];
+    g.filter_tab = nullptr;
+    g.member_cancel = nullptr;
+    g.filter = fs(q0);
+    g.allow_bits = ab(q0);
+    g.allow_nbits = nb(q0);
     VK_TRY(ix->search(g, D.data(), L.data(), N.data()));
     for (uint64_t i = 0; i < m; ++i) {
       out_n[idx[i]] = N[i];
@@ -388,9 +411,17 @@ class FlatIndex final : public Index {
     return store_.flush();
   }
 
-  Status search(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) override {
+  Status search(const SearchRequest &rq_in, float *out_dist, uint64_t *out_label, uint64_t *out_n) override {
+    SearchRequest rq = rq_in;
+    const uint64_t *d_filter = nullptr;
+    if (rq.filter) {   // a device-resident filter (filter_set.hpp): its bitmap is used where it lies
+      d_filter = rq.filter->bits_on(store_.device());
+      if (!d_filter) return Status::Err(VK_ERR_INVALID, "the filter was not built for this index's device");
+      rq.allow_bits = nullptr;
+      rq.allow_nbits = rq.filter->nbits();
+    }
     // (FLAT + filter is the pre-filter path in valkey-search, planner.cc:23-29: per-query bitmaps are served run by run)
-    if (rq.allow_tab) return search_grouped_by_filter(this, rq, out_dist, out_label, out_n);
+    if (rq.allow_tab || rq.filter_tab) return search_grouped_by_filter(this, rq, out_dist, out_label, out_n);
     VK_TRY(flush_if_dirty());
     std::shared_lock<std::shared_mutex> lk(rw_);
     (void)hipSetDevice(store_.device());
@@ -404,8 +435,8 @@ class FlatIndex final : public Index {
     SearchCtx *ctx = lease.ctx;
     filter_used_ = false;
     VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f(), opt_.get(kOptUploadParallel) != 0, rq.query_tab));
-    const uint64_t *d_allow = nullptr;
-    VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
+    const uint64_t *d_allow = d_filter;
+    if (!d_filter) VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
     if (k > kMaxPassK) return search_in_passes(ctx, rq, k, count, d_allow, out_dist, out_label, out_n);
     VK_TRY(ctx->h_out_d.ensure(rq.nq * k * 4));
     VK_TRY(ctx->h_out_l.ensure(rq.nq * k * 8));
@@ -562,6 +593,7 @@ class FlatIndex final : public Index {
     out->last_filter_candidates = last_filter_cands_;
     out->last_filter_fallback = last_filter_fallback_;
     out->last_filter_reranked = last_filter_reranked_;
+    out->max_label = max_label_;
     (void)hipSetDevice(store_.device());
     pool_.for_each_free([&](SearchCtx *c) { for (auto &tp : c->timed) drain_timed(tp); });
     // (with kernel-timing on the time covers exactly the batches counted; off: batches are still counted, the time stands still)
@@ -569,6 +601,8 @@ class FlatIndex final : public Index {
     out->filter_kernel_ns = filter_ns_total_;
     return Status::Ok();
   }
+
+  void filter_devices(std::vector<int> *out) const override { out->assign(1, store_.device()); }
 
   Status device_rows(uint64_t n, void **d_rows, uint64_t *stride_bytes) override {
     std::unique_lock<std::shared_mutex> lk(rw_);
@@ -588,6 +622,7 @@ class FlatIndex final : public Index {
     slot_of_.reserve(n);
     for (uint64_t i = 0; i < n; ++i) {
       uint64_t lab = labels ? labels[i] : i;
+      if (lab > max_label_) max_label_ = lab;
       if (!slot_of_.emplace(lab, (uint32_t)i).second) {
         slot_of_.clear();
         return Status::Err(VK_ERR_INVALID, "duplicate label in bulk load");
@@ -613,6 +648,7 @@ class FlatIndex final : public Index {
         return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
       slot = (uint32_t)count_++;
       slot_of_.emplace(label, slot);
+      if (label > max_label_) max_label_ = label;
     }
     return store_.stage_write(slot, row, label);
   }
@@ -1237,6 +1273,7 @@ class FlatIndex final : public Index {
   std::atomic<uint32_t> filter_bad_tiles_{0};   // tiles the f16 pipe cannot carry (row_stats_kernel)
   std::mutex stats_mu_;
   uint64_t rewritten_ = 0;                      // rows brought up to date since the last full pass (under stats_mu_)
+  uint64_t max_label_ = 0;   // the largest label ever held (vk_index_stats.max_label)
   std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0}, last_filter_reranked_{0}, filter_ns_total_{0}, filter_batches_{0}, filter_timed_{0};
   static thread_local bool filter_used_;
   static constexpr uint64_t kGemmMinQueries = 5;    // measured at 10Mx768: K3 4 queries 5.3 ms, 8 queries 11.7 ms; K4 up to 32 queries 6.1 ms
@@ -1325,6 +1362,7 @@ Status FlatIndex::load_from(vk_read_chunk_fn fn, void *user) {
       return Status::Err(VK_ERR_INTERNAL, "truncated element chunk");
     uint64_t lab;
     memcpy(&lab, buf.data() + (size_t)params_.dim * 4, 8);
+    VK_TRY(observe_loaded_row(lab, buf.data()));
     VK_TRY(add_locked(lab, reinterpret_cast<const float *>(buf.data())));
     if (store_.staged_bytes() >= ((size_t)256 << 20)) VK_TRY(store_.flush());
   }

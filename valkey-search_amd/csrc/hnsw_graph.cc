@@ -71,12 +71,7 @@ uint64_t HnswGraph::host_bytes() const {
   return b;
 }
 
-uint64_t HnswGraph::max_label() const {
-  std::lock_guard<std::mutex> lk(label_lookup_lock_);
-  uint64_t m = 0;
-  for (const auto &kv : label_lookup_) m = std::max(m, kv.first);
-  return m;
-}
+uint64_t HnswGraph::max_label() const { return max_label_.load(std::memory_order_relaxed); }
 
 bool HnswGraph::lookup(uint64_t label, uint32_t *id) const {
   std::lock_guard<std::mutex> lk(label_lookup_lock_);
@@ -408,6 +403,7 @@ Status HnswGraph::add_point_level(const float *new_row, uint64_t label, int leve
     memcpy(row_mut(cur_c), new_row, dim_ * sizeof(float));
     count_.fetch_add(1, std::memory_order_release);
     label_lookup_[label] = cur_c;
+    note_label(label);
   }
   *out_id = cur_c;
 
@@ -505,6 +501,7 @@ Status HnswGraph::add(const float *new_row, uint64_t label, uint32_t *out_id) {
     std::lock_guard<std::mutex> lk(label_lookup_lock_);
     label_lookup_.erase(label_replaced);
     label_lookup_[label] = replaced;
+    note_label(label);
   }
   VK_TRY(unmark_deleted_internal(replaced));
   *out_id = replaced;
@@ -549,6 +546,7 @@ Status HnswGraph::bulk_register(const float *rows, const uint64_t *labels, size_
     }
     mark(id, 0);
     label_lookup_[labels[i]] = id;
+    note_label(labels[i]);
   }
   count_.fetch_add(n, std::memory_order_release);
   return Status::Ok();
@@ -621,6 +619,7 @@ Status HnswGraph::load_labels(size_t count) {
     auto it = label_lookup_.find(labels_[i]);
     if (it == label_lookup_.end()) {
       label_lookup_[labels_[i]] = i;
+      note_label(labels_[i]);
     } else if (!is_deleted(i)) {
       if (!is_deleted(it->second))
         return Status::Err(kErrInternal, "HNSW index load validation failed: duplicate live label in index");

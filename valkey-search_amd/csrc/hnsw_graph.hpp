@@ -70,7 +70,11 @@ class HnswGraph {
   const uint32_t *upper(uint32_t id, int level) const { return upper_[id] + (size_t)(level - 1) * (maxM_ + 1); }
   uint32_t upper_slot(uint32_t id) const { return upper_slot_[id]; }   // first device slot of id's upper lists
   uint32_t upper_slots_used() const { return upper_slots_used_.load(); }
-  uint64_t max_label() const;                                          // VectorHNSW::GetMaxInternalLabel
+  uint64_t max_label() const;                                          // VectorHNSW::GetMaxInternalLabel: the largest label ever held
+  void note_label(uint64_t label) {
+    uint64_t cur = max_label_.load(std::memory_order_relaxed);
+    while (label > cur && !max_label_.compare_exchange_weak(cur, label, std::memory_order_relaxed)) {}
+  }
   uint64_t host_bytes() const;
 
   // dirty tracking for the device mirror
@@ -188,6 +192,7 @@ class HnswGraph {
   size_t max_elements_;
   std::atomic<size_t> count_{0};
   std::atomic<size_t> num_deleted_{0};
+  std::atomic<uint64_t> max_label_{0};
   size_t M_, maxM_, maxM0_, efC_, ef_ = 10;
   double mult_;
   int maxlevel_ = -1;

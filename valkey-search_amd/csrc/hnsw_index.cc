@@ -147,17 +147,33 @@ class HnswIndex final : public Index {
     SearchCtx *ctx = lease.ctx;
     VK_TRY(upload_queries(ctx, rq.queries, rq.nq, params_.dim, store_.stride_f(), opt_.get(kOptUploadParallel) != 0, rq.query_tab));
     const uint64_t *d_allow = nullptr;
-    VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
-    // one filter per query: every distinct bitmap goes to the device once, the kernel gets [nq] pointers and lengths
+    uint64_t allow_nbits = rq.allow_nbits;
+    if (rq.filter) {   // a device-resident filter for the whole batch: nothing to upload
+      d_allow = rq.filter->bits_on(store_.device());
+      allow_nbits = rq.filter->nbits();
+      if (!d_allow) return Status::Err(VK_ERR_INVALID, "the filter was not built for this index's device");
+    } else {
+      VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
+    }
+    // one filter per query: every distinct HOST bitmap goes to the device once, device-resident filters (filter_set.hpp) are
+    // pointed at where they lie; the kernel gets [nq] pointers and lengths
     const uint64_t *const *d_tab = nullptr;
     const uint64_t *d_tab_nbits = nullptr;
-    if (rq.allow_tab) {
+    if (rq.allow_tab || rq.filter_tab) {
       std::vector<const uint64_t *> uniq;
       std::vector<uint64_t> uniq_bits, off;
       size_t words = 0;
       std::vector<uint32_t> which(rq.nq, ~0u);
+      std::vector<const uint64_t *> resident(rq.nq, nullptr);
+      bool any = false;
       for (uint64_t q = 0; q < rq.nq; ++q) {
-        if (!rq.allow_tab[q]) continue;
+        if (rq.filter_tab && rq.filter_tab[q]) {
+          resident[q] = rq.filter_tab[q]->bits_on(store_.device());
+          if (!resident[q]) return Status::Err(VK_ERR_INVALID, "the filter was not built for this index's device");
+          any = true;
+          continue;
+        }
+        if (!rq.allow_tab || !rq.allow_tab[q]) continue;
         uint32_t u = 0;
         for (; u < uniq.size(); ++u)
           if (uniq[u] == rq.allow_tab[q] && uniq_bits[u] == rq.allow_nbits_tab[q]) break;
@@ -168,6 +184,7 @@ class HnswIndex final : public Index {
           words += (size_t)((rq.allow_nbits_tab[q] + 63) / 64) + 1;
         }
         which[q] = u;
+        any = true;
       }
       const size_t tab_bytes = rq.nq * 16;
       VK_TRY(ctx->d_allow_tab.ensure(tab_bytes + words * 8 + 8));
@@ -175,8 +192,13 @@ class HnswIndex final : public Index {
       char *base = ctx->d_allow_tab.as<char>();
       uint64_t *h = ctx->h_tmp.as<uint64_t>();
       for (uint64_t q = 0; q < rq.nq; ++q) {
-        h[q] = which[q] == ~0u ? 0 : reinterpret_cast<uint64_t>(base + tab_bytes + off[which[q]] * 8);
-        h[rq.nq + q] = which[q] == ~0u ? 0 : rq.allow_nbits_tab[q];
+        if (resident[q]) {
+          h[q] = reinterpret_cast<uint64_t>(resident[q]);
+          h[rq.nq + q] = rq.filter_tab[q]->nbits();
+        } else {
+          h[q] = which[q] == ~0u ? 0 : reinterpret_cast<uint64_t>(base + tab_bytes + off[which[q]] * 8);
+          h[rq.nq + q] = which[q] == ~0u ? 0 : rq.allow_nbits_tab[q];
+        }
       }
       VK_HIP_TRY(hipMemcpyAsync(base, h, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
       for (size_t u = 0; u < uniq.size(); ++u) {
@@ -185,26 +207,27 @@ class HnswIndex final : public Index {
       }
       d_tab = reinterpret_cast<const uint64_t *const *>(base);
       d_tab_nbits = reinterpret_cast<const uint64_t *>(base + rq.nq * 8);
-      if (uniq.empty()) d_tab = nullptr;   // (every entry was "no filter")
+      if (!any) d_tab = nullptr;   // (every entry was "no filter")
     }
     tab_ = d_tab;
     tab_nbits_ = d_tab_nbits;
     // (launch() consumes and clears them; an early return before it must not leave this batch's table behind for the
     // thread's next launch, e.g. a search_device or a device build)
-    struct TabReset { ~TabReset() { tab_ = nullptr; tab_nbits_ = nullptr; } } tab_reset;
+    struct TabReset { ~TabReset() { tab_ = nullptr; tab_nbits_ = nullptr; cancel_q_ = nullptr; } } tab_reset;
     VK_TRY(ctx->h_out_d.ensure(rq.nq * rq.k * 4));
     VK_TRY(ctx->h_out_l.ensure(rq.nq * rq.k * 8));
     VK_TRY(ctx->h_out_n.ensure(rq.nq * 4 + 64));
-    const uint32_t *d_cancel = nullptr;
-    VK_TRY(ctx->arm_cancel(rq.cancel_flag, &d_cancel));
+    const uint32_t *d_cancel = nullptr, *d_cancel_q = nullptr;
+    VK_TRY(ctx->arm_cancel(rq.cancel_flag, &d_cancel, rq.member_cancel ? rq.nq : 0, &d_cancel_q));
+    cancel_q_ = d_cancel_q;   // (consumed and cleared by launch(), like tab_)
     if (rq.nq * rq.k <= kZeroCopyEntries) {   // the kernel writes the answer into the pinned host buffers
-      VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, rq.allow_nbits, ctx->h_out_d.as<float>(),
+      VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, allow_nbits, ctx->h_out_d.as<float>(),
                     ctx->h_out_l.as<uint64_t>(), ctx->h_out_n.as<uint32_t>(), ctx->stream, true, false, d_cancel));
     } else {
       VK_TRY(ctx->d_out_d.ensure(rq.nq * rq.k * 4));
       VK_TRY(ctx->d_out_l.ensure(rq.nq * rq.k * 8));
       VK_TRY(ctx->d_out_n.ensure(rq.nq * 4));
-      VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, rq.allow_nbits, ctx->d_out_d.as<float>(),
+      VK_TRY(launch(ctx, ctx->d_q.as<float>(), rq.nq, rq.k, rq.ef, d_allow, allow_nbits, ctx->d_out_d.as<float>(),
                     ctx->d_out_l.as<uint64_t>(), ctx->d_out_n.as<uint32_t>(), ctx->stream, true, false, d_cancel));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_d.p, ctx->d_out_d.p, rq.nq * rq.k * 4, hipMemcpyDeviceToHost, ctx->stream));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_l.p, ctx->d_out_l.p, rq.nq * rq.k * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -212,7 +235,7 @@ class HnswIndex final : public Index {
     }
     const size_t st_off = (rq.nq * 4 + 7) & ~(size_t)7;
     VK_HIP_TRY(hipMemcpyAsync(ctx->h_out_n.as<char>() + st_off, ctx->d_stats.p, 40, hipMemcpyDeviceToHost, ctx->stream));
-    VK_TRY(ctx->wait(rq.cancel_flag));   // (a raised flag stops the kernel between hops: hnswalg.h:400-402)
+    VK_TRY(ctx->wait(rq.cancel_flag, rq.member_cancel, rq.nq));   // (a raised flag stops the kernel between hops: hnswalg.h:400-402)
     {
       const unsigned long long *st = reinterpret_cast<const unsigned long long *>(ctx->h_out_n.as<char>() + st_off);
       last_n_eval_ = st[0];
@@ -343,8 +366,11 @@ class HnswIndex final : public Index {
     // what a tombstone keeps alive until the slot is reused: its row and its level-0 list, on the device and on the host
     // (the reference adds the vector's bytes to reclaimable_memory at markDelete, hnswalg.h:1199)
     out->tombstoned_bytes = out->deleted * ((uint64_t)store_.row_bytes() + (uint64_t)(2 * params_.m + 1) * 4);
+    out->max_label = graph_->max_label();
     return Status::Ok();
   }
+
+  void filter_devices(std::vector<int> *out) const override { out->assign(1, store_.device()); }
 
   Status device_rows(uint64_t, void **, uint64_t *) override {
     return Status::Err(VK_ERR_INVALID, "device bulk load is a FLAT-only path (the HNSW graph is built from host rows)");
@@ -545,6 +571,8 @@ class HnswIndex final : public Index {
     a.check_deleted = pub_.deleted ? 1 : 0;
     a.out_ids = out_ids ? 1 : 0;
     a.cancel = d_cancel;
+    a.cancel_q = cancel_q_;
+    cancel_q_ = nullptr;
     if (hnsw_lds_bytes(a) > 160 * 1024)
       return Status::Err(VK_ERR_INVALID, "query block + result list (dimension, ef, M) do not fit the 160 KiB of LDS");
     int max_blocks = 0;
@@ -959,10 +987,12 @@ class HnswIndex final : public Index {
   std::atomic<uint64_t> last_n_eval_{0}, last_n_hops_{0}, last_overflow_{0}, last_redo_{0}, total_n_eval_{0}, total_n_hops_{0};
   static thread_local const uint64_t *const *tab_;
   static thread_local const uint64_t *tab_nbits_;
+  static thread_local const uint32_t *cancel_q_;
 };
 
 thread_local const uint64_t *const *HnswIndex::tab_ = nullptr;
 thread_local const uint64_t *HnswIndex::tab_nbits_ = nullptr;
+thread_local const uint32_t *HnswIndex::cancel_q_ = nullptr;
 
 // ---- persistence: hnswalg.h:808-865 (SaveIndex), :887-1139 (LoadIndex + loadCheck) -----------------
 Status HnswIndex::save(vk_write_chunk_fn fn, void *user) {
@@ -1074,6 +1104,7 @@ Status HnswIndex::load_from(vk_read_chunk_fn fn, void *user) {
     }
     uint64_t lab;
     memcpy(&lab, buf.data() + sl0 + vec, 8);
+    VK_TRY(observe_loaded_row(lab, buf.data() + sl0));
     VK_TRY(graph_->load_element(i, ll, reinterpret_cast<const float *>(buf.data() + sl0), lab));
     VK_TRY(store_.stage_write(i, reinterpret_cast<const float *>(buf.data() + sl0), lab));
     if (store_.staged_bytes() >= ((size_t)256 << 20)) VK_TRY(store_.flush());

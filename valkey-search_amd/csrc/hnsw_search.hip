@@ -254,7 +254,7 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     // FT.SEARCH, search.cc:103-134), else the batch's
     const uint64_t *q_bits = a.allow_tab ? a.allow_tab[q] : a.allow_bits;
     const uint64_t q_nbits = a.allow_tab ? a.allow_nbits_tab[q] : a.allow_nbits;
-    if (poll_cancel(a.cancel)) {   // cancelled before this query started: an empty answer, and on to drain the queue
+    if (poll_cancel(a.cancel) || (a.cancel_q && poll_cancel(a.cancel_q + q))) {   // cancelled before this query started: an empty answer, and on to drain the queue
       for (uint32_t r = lane; r < a.k; r += kWave) { a.out_dist[(size_t)q * a.k + r] = __builtin_inff(); a.out_label[(size_t)q * a.k + r] = kNoLabel; }
       if (lane == 0) a.out_n[q] = 0;
       uint32_t nxt0 = 0;
@@ -520,7 +520,8 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
 
     for (;;) {
       if (c.cnt == 0 || abandoned) break;
-      if (a.cancel && (q_hops % kCancelPollHops) == kCancelPollHops - 1 && poll_cancel(a.cancel)) break;   // :400-402
+      if ((a.cancel || a.cancel_q) && (q_hops % kCancelPollHops) == kCancelPollHops - 1 &&
+          (poll_cancel(a.cancel) || (a.cancel_q && poll_cancel(a.cancel_q + q)))) break;   // :400-402
       // extract-min over the pool
       float bd = __builtin_inff();
       uint32_t bi = kNoneId;

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/vk_index.h"
+#include "filter_set.hpp"
 #include "kernels.hpp"
 #include "options.hpp"
 #include "row_store.hpp"
@@ -49,11 +50,15 @@ struct SearchCtx {
       d_fq16, d_fthr, d_fcnt, d_fcand, d_fspill, d_fsmax, d_fpart_d, d_fpart_l,   // candidate filter (flat_filter.hip)
       d_allow_tab;                                             // per-query filter table + the bitmaps behind it
   PinBuf h_q, h_out_d, h_out_l, h_out_n, h_tmp, h_idx, h_cancel;
+  // per-member cancellation (SearchRequest::member_cancel): the words the kernel polls follow the batch word in h_cancel
+  static constexpr size_t kMemberCancelOffset = 16;   // in u32 words
+  Status wait(const volatile int *caller_flag, const volatile uint32_t *member_cancel, uint64_t nq);
   // In-kernel cancellation: the caller's flag (any host memory) cannot be read by the device, so the thread that
   // waits for the stream polls it and raises the context's own word in pinned memory, which the kernels poll
   // (FlatScanArgs::cancel).  arm_cancel: allocate + clear, returns the device-visible word (nullptr when the call
   // carries no flag); wait: hipStreamSynchronize, or with a flag a poll of stream and flag.
-  Status arm_cancel(const volatile int *caller_flag, const uint32_t **device_word);
+  Status arm_cancel(const volatile int *caller_flag, const uint32_t **device_word, uint64_t n_members = 0,
+                    const uint32_t **member_words = nullptr);
   Status wait(const volatile int *caller_flag);
   // A device-buffer search (vk_index_search_batch_device) returns with its kernels still in flight on the CALLER's
   // stream and gives the context back: `busy` is recorded behind that work, and whoever leases the context next makes
@@ -120,8 +125,16 @@ struct SearchRequest {
   // queries carries as many bitmaps as queries.
   const uint64_t *const *allow_tab = nullptr;
   const uint64_t *allow_nbits_tab = nullptr;
+  // device-resident filters (filter_set.hpp; host entry points): one for the whole batch, or one per query (a nullptr
+  // entry = that query's allow_tab entry, or no filter).  They override allow_bits / allow_tab and are never uploaded.
+  const FilterSet *filter = nullptr;
+  const FilterSet *const *filter_tab = nullptr;
   const volatile int *cancel_flag = nullptr;
   bool partial_ok = true;
+  // dispatcher batches: one host word per member, raised when THAT member's token goes up.  HNSW relays it to the wave
+  // working on the member's query, which stops like the reference's loop does (hnswalg.h:400-402); FLAT ignores it (a
+  // row pass costs the same with or without the member).
+  const volatile uint32_t *member_cancel = nullptr;
   // search_device only: a device-visible cancellation word the caller maintains itself (the sharded index relays one
   // host flag to the kernels of every shard through it)
   const uint32_t *cancel_word = nullptr;
@@ -151,6 +164,8 @@ class Index {
   Status search_labels(const float *query, uint64_t k, const uint64_t *labels, uint64_t n, float *out_dist,
                        uint64_t *out_label, uint64_t *out_n);
   // sharded index: its shards (vk_index_shard_device_rows / _commit_device_rows address one of them)
+  // the devices a filter of this index must be resident on (FilterSet::build)
+  virtual void filter_devices(std::vector<int> *out) const = 0;
   virtual uint32_t shard_count() const { return 0; }
   virtual Status shard_device_rows(uint32_t, uint64_t, void **, uint64_t *) { return Status::Err(VK_ERR_INVALID, "not a sharded index"); }
   virtual Status shard_commit_device_rows(uint32_t, uint64_t, const uint64_t *) { return Status::Err(VK_ERR_INVALID, "not a sharded index"); }
@@ -174,6 +189,16 @@ class Index {
   vk_index_params params_;
   Options opt_;
 };
+
+// vk_index_load_tracked: the VectorTracker hook of LoadIndex (bruteforce.h:201, hnswalg.h:1000) -- set by the ABI entry
+// around the load on the loading thread, called by the loaders once per element as it is read from the stream
+struct LoadObserver { vk_row_fn fn; void *user; };
+extern thread_local const LoadObserver *g_load_observer;
+inline Status observe_loaded_row(uint64_t label, const void *row) {
+  if (g_load_observer && g_load_observer->fn(g_load_observer->user, label, row))
+    return Status::Err(VK_ERR_INTERNAL, "load: the row callback failed");
+  return Status::Ok();
+}
 
 Status create_sharded(const vk_index_params &p, std::unique_ptr<Index> *out);
 Status load_sharded(const vk_index_params &p, vk_read_chunk_fn fn, void *user, std::unique_ptr<Index> *out);

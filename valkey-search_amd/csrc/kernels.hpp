@@ -279,6 +279,10 @@ struct HnswSearchArgs {
   // expanded nodes (the reference polls per popped candidate, hnswalg.h:400-402); a cancelled search keeps what its
   // result list holds, queries not started yet answer with empty lists
   const uint32_t *cancel;
+  // optional, the same per QUERY ([nq] words in host-pinned memory): the members of a dispatcher batch carry their own
+  // tokens; a raised word stops the wave that works on that query (or answers it empty if it has not started), the rest of
+  // the batch runs on.  The reference stops one search within one distance evaluation (hnswalg.h:400-402)
+  const uint32_t *cancel_q;
   // Visited set as an exact hash set of node ids (open addressing, 2^vis_hash_log2 words per wave slot = bitmap_words)
   // instead of one bit per node of the graph: a search touches a few thousand of 10M nodes, a table of 64 KB stays in
   // cache and is cleared in no time where the bitmap takes 1.25 MB per resident wave.  LDS-frontier launches only; a
@@ -373,5 +377,12 @@ hipError_t launch_fill_empty(float *out_dist, uint64_t *out_label, uint32_t *out
 // bound[q] = out_dist[q][k-1] if the query found k entries, +inf otherwise; bound[nq + q] = the same as an
 // order-preserving u32 key (the buffer holds 2*nq words)
 hipError_t launch_kth_bound(const float *out_dist, const uint32_t *out_n, uint32_t k, uint32_t nq, float *bound, hipStream_t s);
+
+// filter_build.hip: allow-bitmaps built on the device from id lists / id runs (what the EntriesFetchers of a predicate
+// yield, src/query/search.cc:301-399): bits must be zeroed (or hold the set to extend); labels >= nbits are ignored
+hipError_t launch_filter_set_ids(uint64_t *bits, uint64_t nbits, const uint64_t *d_ids, uint64_t n, hipStream_t s);
+hipError_t launch_filter_set_runs(uint64_t *bits, uint64_t nbits, const uint64_t *d_runs, uint64_t n_runs, hipStream_t s);   // [n_runs][2] = first, last
+hipError_t launch_filter_popcount(const uint64_t *bits, uint64_t words, unsigned long long *d_out, hipStream_t s);             // *d_out += set bits
+hipError_t launch_filter_combine(uint64_t *dst, const uint64_t *a, const uint64_t *b, uint64_t words, uint32_t op, hipStream_t s);   // 0 and, 1 or, 2 and-not
 
 }  // namespace vk

@@ -30,6 +30,8 @@ enum OptId : uint32_t {
   kOptBatchesInFlight,      // device batches the dispatcher keeps in flight per index (collect N+1 while N runs)
   kOptShardEfPct,           // sharded HNSW: per-shard ef as a percentage of the query's ef (vk_index_params.shard_ef_pct)
   kOptShardGather,          // sharded index: 0 = per-shard top-k gathered by peer copies, 1 = by an RCCL all-gather
+  kOptFilterCacheEntries,   // vk_index_filter_cache_put: most filters kept (0 = the cache is off) ...
+  kOptFilterCacheBytes,     // ... and most device memory they may hold
   kOptKernelTiming,         // 1 = HIP event pairs around the dominant kernel's launches (vk_index_stats.filter_kernel_ns)
   // ---- FLAT: kernel selection and the candidate filter (K4h) ------------------------------------------------------------
   kOptFlatFilter, kOptFilterMinQueries, kOptFilterMinRows, kOptFilterPrepassRows, kOptFilterCap, kOptFilterSpillChunks,
@@ -59,6 +61,8 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"batches-in-flight", "VK_BATCHES_IN_FLIGHT", 2, 1, 8},
       {"shard-ef-pct", nullptr, 100, 1, 1000},
       {"shard-gather", "VK_SHARD_GATHER", 0, 0, 1},
+      {"filter-cache-entries", nullptr, 256, 0, 1u << 20},
+      {"filter-cache-bytes", nullptr, (uint64_t)1 << 30, 0, kMax},
       {"kernel-timing", "VK_KERNEL_TIMING", 0, 0, 1},
       {"flat-filter", "VK_FLAT_FILTER", 1, 0, 1},
       {"filter-min-queries", "VK_FILTER_MIN_QUERIES", 5, 1, kMax},

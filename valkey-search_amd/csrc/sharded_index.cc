@@ -266,6 +266,7 @@ class ShardedIndex final : public Index {
   }
 
   uint32_t shard_count() const override { return (uint32_t)shards_.size(); }
+  void filter_devices(std::vector<int> *out) const override { *out = devices_; }   // (a copy per distinct device)
 
   // ---- mutations ------------------------------------------------------------------------------------
   Status add(uint64_t label, const float *row) override {
@@ -418,7 +419,7 @@ class ShardedIndex final : public Index {
       g.query_tab = nullptr;
       return search(g, out_dist, out_label, out_n);
     }
-    if (rq.allow_tab) return search_grouped_by_filter(this, rq, out_dist, out_label, out_n);
+    if (rq.allow_tab || rq.filter_tab) return search_grouped_by_filter(this, rq, out_dist, out_label, out_n);
     if (rq.k == 0) {
       for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
       return Status::Ok();
@@ -443,7 +444,9 @@ class ShardedIndex final : public Index {
     memcpy(mc->h_q.p, rq.queries, qbytes);
     VK_HIP_TRY(hipMemcpyAsync(mc->d_q.p, mc->h_q.p, qbytes, hipMemcpyHostToDevice, mc->s0));
     const uint64_t *d_allow = nullptr;
-    if (rq.allow_bits) {
+    if (rq.filter) {   // device-resident on every shard's device (filter_set.hpp): nothing to upload or broadcast
+      if (!rq.filter->bits_on(mc->dev0)) return Status::Err(VK_ERR_INVALID, "the filter was not built for this index's devices");
+    } else if (rq.allow_bits) {
       const size_t words = (size_t)((rq.allow_nbits + 63) / 64);
       VK_TRY(mc->d_allow.ensure(std::max<size_t>(words * 8, 8)));
       if (words) VK_HIP_TRY(hipMemcpyAsync(mc->d_allow.p, rq.allow_bits, words * 8, hipMemcpyHostToDevice, mc->s0));
@@ -464,6 +467,7 @@ class ShardedIndex final : public Index {
     SearchRequest drq = rq;
     drq.queries = mc->d_q.as<float>();
     drq.allow_bits = d_allow;
+    if (rq.filter) drq.allow_nbits = rq.filter->nbits();
     drq.cancel_word = d_cancel;
     VK_TRY(fan_out(mc, drq, mc->d_fin_d.as<float>(), mc->d_fin_l.as<uint64_t>(), mc->d_fin_n.as<uint32_t>(), mc->s0));
     (void)hipSetDevice(mc->dev0);
@@ -574,6 +578,9 @@ class ShardedIndex final : public Index {
       out->total_n_eval += t.total_n_eval;
       out->total_n_hops += t.total_n_hops;
       out->tombstoned_bytes += t.tombstoned_bytes;
+      out->max_label = std::max(out->max_label, t.max_label);
+      out->staged_adds += t.staged_adds;
+      out->staged_adds_device += t.staged_adds_device;
     }
     out->fanout_calls = fanout_calls_.load(std::memory_order_relaxed);
     out->fanout_enqueue_ns = fanout_ns_.load(std::memory_order_relaxed);
@@ -749,6 +756,12 @@ class ShardedIndex final : public Index {
     VK_HIP_TRY(hipStreamWaitEvent(l.stream, mc->ready, 0));
     SearchRequest srq = rq;
     srq.cancel_flag = nullptr;
+    srq.filter = nullptr;
+    srq.member_cancel = nullptr;
+    if (rq.filter) {
+      srq.allow_bits = rq.filter->bits_on(l.device);
+      if (!srq.allow_bits) return Status::Err(VK_ERR_INVALID, "the filter was not built for this index's devices");
+    }
     const uint64_t ef_pct = opt_.get(kOptShardEfPct);
     if (params_.algo == VK_ALGO_HNSW && ef_pct != 100) {
       // per-shard ef policy (option shard-ef-pct, initialised from vk_index_params.shard_ef_pct): a fraction of the ef one
@@ -765,7 +778,7 @@ class ShardedIndex final : public Index {
       VK_TRY(l.d_q.ensure(qbytes));
       VK_HIP_TRY(hipMemcpyPeerAsync(l.d_q.p, l.device, rq.queries, mc->dev0, qbytes, l.stream));
       srq.queries = l.d_q.as<float>();
-      if (rq.allow_bits) {
+      if (rq.allow_bits && !rq.filter) {
         VK_TRY(l.d_allow.ensure(std::max<size_t>(abytes, 8)));
         if (abytes) VK_HIP_TRY(hipMemcpyPeerAsync(l.d_allow.p, l.device, rq.allow_bits, mc->dev0, abytes, l.stream));
         srq.allow_bits = l.d_allow.as<uint64_t>();
@@ -1117,6 +1130,7 @@ Status ShardedIndex::load_from(vk_read_chunk_fn fn, void *user) {
     uint64_t lab;
     memcpy(&lab, buf.data() + sl0 + vec, 8);
     labs.push_back(lab);
+    VK_TRY(observe_loaded_row(lab, buf.data() + sl0));
     const float *v = reinterpret_cast<const float *>(buf.data() + sl0);
     rows.insert(rows.end(), v, v + dim);
     if (labs.size() >= group) VK_TRY(flush_group());

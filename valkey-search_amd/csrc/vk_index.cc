@@ -5,8 +5,11 @@
 #include <string.h>
 
 #include <exception>
+#include <list>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include <atomic>
 #include <chrono>
@@ -40,11 +43,36 @@ struct VkCounters {
   }
 };
 
+// a device-resident filter behind the ABI: a counted reference on a vk::FilterSet (filter_set.hpp)
+struct vk_filter {
+  std::shared_ptr<vk::FilterSet> set;
+  const vk_index *owner;
+  std::atomic<uint32_t> refs{1};
+};
+
+// filters under caller keys (vk_index_filter_cache_*): least recently used first out, bounded in entries and device bytes
+struct VkFilterCache {
+  struct Entry { std::string key; uint64_t epoch; std::shared_ptr<vk::FilterSet> set; };
+  std::mutex mu;
+  std::list<Entry> lru;   // front = most recently used
+  std::unordered_map<std::string, std::list<Entry>::iterator> by_key;
+  uint64_t bytes = 0;
+  std::atomic<uint64_t> hits{0}, misses{0}, built{0};
+  void drop(std::list<Entry>::iterator it) {
+    bytes -= it->set->device_bytes();
+    by_key.erase(it->key);
+    lru.erase(it);
+  }
+};
+
 struct vk_index {
   std::unique_ptr<vk::Index> impl;
   VkCounters counters;
+  VkFilterCache filters;
   std::unique_ptr<vk::Dispatcher> dispatcher;   // (declared after impl: destroyed first, while the index is still there)
 };
+
+thread_local const vk::LoadObserver *vk::g_load_observer = nullptr;
 
 namespace {
 thread_local std::string g_last_error;
@@ -216,9 +244,9 @@ int vk_index_search_batch_filters(vk_index *ix, const void *queries, uint64_t nq
   });
 }
 
-// A FLAT index serves one scan per distinct allow-bitmap (search_grouped_by_filter): N filtered callers in one batch
-// would each wait for N serial scans run by one runner, where N separate calls run concurrently on the index's search
-// contexts.  Batching of filtered calls is therefore HNSW-only (one launch, a bitmap per query).
+// A FLAT index serves one scan per distinct allow-bitmap.  The dispatcher groups filtered FLAT requests into lanes by filter
+// (one scan per lane: dispatcher.hpp); a BLOCKING call with a raw host bitmap -- which nobody else can share -- is not
+// worth a lane of its own and runs directly on one of the index's search contexts, as before.
 static bool flat_filtered(vk_index *ix, const uint64_t *allow_bits) {
   return allow_bits && ix->impl->params().algo == VK_ALGO_FLAT;
 }
@@ -229,7 +257,7 @@ int vk_index_search(vk_index *ix, const void *query, uint64_t k, uint64_t ef_run
   if (ix && ix->impl && ix->dispatcher->enabled() && k && !flat_filtered(ix, allow_bits) && !vk::cancel_raised(cancel_flag)) {
     if (!query || !out_n || !out_dist || !out_label) return fail(VK_ERR_INVALID, "NULL argument");
     return counted(ix, 1, [&] {
-      return ix->dispatcher->search(static_cast<const float *>(query), k, ef_runtime, allow_bits, allow_nbits, cancel_flag,
+      return ix->dispatcher->search(static_cast<const float *>(query), k, ef_runtime, allow_bits, allow_nbits, nullptr, cancel_flag,
                                     partial_ok != 0, out_dist, out_label, out_n);
     });
   }
@@ -265,7 +293,7 @@ int vk_index_search_submit(vk_index *ix, const void *query, uint64_t k, uint64_t
   if (!ix->dispatcher->enabled()) return fail(VK_ERR_INVALID, "vk_index_search_submit needs coalescing (vk_index_set_coalescing with max_batch > 1)");
   return guarded([&]() -> vk::Status {
     SubmitCtx *c = new SubmitCtx{ix, done, user, std::chrono::steady_clock::now()};
-    vk::Status st = ix->dispatcher->submit(static_cast<const float *>(query), k, ef_runtime, allow_bits, allow_nbits, cancel_flag,
+    vk::Status st = ix->dispatcher->submit(static_cast<const float *>(query), k, ef_runtime, allow_bits, allow_nbits, nullptr, cancel_flag,
                                            partial_ok != 0, out_dist, out_label, out_n, submit_done, c);
     if (!st.ok()) delete c;   // (not queued: the callback will not fire)
     return st;
@@ -335,6 +363,16 @@ int vk_index_get_stats(vk_index *ix, vk_index_stats *out) {
     out->rejected = d.rejected();
     out->queued_now = d.queued();
     out->max_batches_in_flight = d.max_in_flight_seen();
+    out->cancelled_early = d.left_early();
+    {
+      VkFilterCache &fc = ix->filters;
+      out->filters_built = fc.built.load(std::memory_order_relaxed);
+      out->filter_cache_hits = fc.hits.load(std::memory_order_relaxed);
+      out->filter_cache_misses = fc.misses.load(std::memory_order_relaxed);
+      std::lock_guard<std::mutex> lk(fc.mu);
+      out->filter_cache_entries = fc.lru.size();
+      out->filter_cache_bytes = fc.bytes;
+    }
     const VkCounters &c = ix->counters;
     out->searches = c.searches.load(std::memory_order_relaxed);
     out->search_calls = c.calls.load(std::memory_order_relaxed);
@@ -437,9 +475,15 @@ int vk_index_save(vk_index *ix, vk_write_chunk_fn write_chunk, void *user) {
   return guarded([&] { return ix->impl->save(write_chunk, user); });
 }
 
-int vk_index_load(const vk_index_params *params, vk_read_chunk_fn read_chunk, void *user, vk_index **out) {
+int vk_index_load_tracked(const vk_index_params *params, vk_read_chunk_fn read_chunk, void *user, vk_row_fn on_row, void *row_user,
+                          vk_index **out) {
   if (!out || !read_chunk) return fail(VK_ERR_INVALID, "NULL argument");
   *out = nullptr;
+  const vk::LoadObserver obs{on_row, row_user};
+  struct Scope {   // (the loaders run on this thread)
+    explicit Scope(const vk::LoadObserver *o) { vk::g_load_observer = o; }
+    ~Scope() { vk::g_load_observer = nullptr; }
+  } scope(on_row ? &obs : nullptr);
   return guarded([&]() -> vk::Status {
     VK_TRY(check_params(params));
     std::unique_ptr<vk::Index> impl;
@@ -451,6 +495,181 @@ int vk_index_load(const vk_index_params *params, vk_read_chunk_fn read_chunk, vo
     (*out)->dispatcher = std::make_unique<vk::Dispatcher>((*out)->impl.get());
     sync_dispatcher(*out);
     return vk::Status::Ok();
+  });
+}
+
+int vk_index_load(const vk_index_params *params, vk_read_chunk_fn read_chunk, void *user, vk_index **out) {
+  return vk_index_load_tracked(params, read_chunk, user, nullptr, nullptr, out);
+}
+
+// ---- device-resident filters ------------------------------------------------------------------------------------------
+int vk_filter_create(vk_index *ix, uint64_t nbits, const uint64_t *labels, uint64_t n_labels, const uint64_t *runs, uint64_t n_runs,
+                     const uint64_t *base_bits, vk_filter **out) {
+  VK_NEED(ix);
+  if (!out) return fail(VK_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  return guarded([&]() -> vk::Status {
+    std::vector<int> devs;
+    ix->impl->filter_devices(&devs);
+    std::shared_ptr<vk::FilterSet> set;
+    VK_TRY(vk::FilterSet::build(devs, nbits, labels, n_labels, runs, n_runs, base_bits, &set));
+    ix->filters.built.fetch_add(1, std::memory_order_relaxed);
+    *out = new vk_filter{std::move(set), ix};
+    return vk::Status::Ok();
+  });
+}
+
+int vk_filter_combine(vk_index *ix, const vk_filter *a, const vk_filter *b, uint32_t op, vk_filter **out) {
+  VK_NEED(ix);
+  if (!a || !b || !out) return fail(VK_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (a->owner != ix || b->owner != ix) return fail(VK_ERR_INVALID, "the filter belongs to another index");
+  return guarded([&]() -> vk::Status {
+    std::shared_ptr<vk::FilterSet> set;
+    VK_TRY(vk::FilterSet::combine(*a->set, *b->set, op, &set));
+    ix->filters.built.fetch_add(1, std::memory_order_relaxed);
+    *out = new vk_filter{std::move(set), ix};
+    return vk::Status::Ok();
+  });
+}
+
+void vk_filter_retain(vk_filter *f) {
+  if (f) f->refs.fetch_add(1, std::memory_order_relaxed);
+}
+
+void vk_filter_release(vk_filter *f) {
+  if (!f) return;
+  if (f->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+    try {
+      delete f;   // (the FilterSet itself lives on while a search or the cache holds it)
+    } catch (...) {
+    }
+  }
+}
+
+int vk_filter_info(const vk_filter *f, uint64_t *out_nbits, uint64_t *out_allowed) {
+  if (!f) return fail(VK_ERR_INVALID, "filter is NULL");
+  if (out_nbits) *out_nbits = f->set->nbits();
+  if (out_allowed) *out_allowed = f->set->allowed();
+  return VK_OK;
+}
+
+int vk_filter_read(const vk_filter *f, uint64_t *out_words, uint64_t n_words) {
+  if (!f || (n_words && !out_words)) return fail(VK_ERR_INVALID, "NULL argument");
+  return guarded([&] { return f->set->read(out_words, n_words); });
+}
+
+int vk_index_filter_cache_get(vk_index *ix, const void *key, uint64_t key_len, uint64_t epoch, vk_filter **out) {
+  VK_NEED(ix);
+  if (!out || (key_len && !key)) return fail(VK_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  return guarded([&]() -> vk::Status {
+    VkFilterCache &fc = ix->filters;
+    std::string k(static_cast<const char *>(key), (size_t)key_len);
+    std::lock_guard<std::mutex> lk(fc.mu);
+    auto it = fc.by_key.find(k);
+    if (it != fc.by_key.end() && it->second->epoch != epoch) {   // stored before the predicate's answer may have changed
+      fc.drop(it->second);
+      it = fc.by_key.end();
+    }
+    if (it == fc.by_key.end()) {
+      fc.misses.fetch_add(1, std::memory_order_relaxed);
+      return vk::Status::Ok();
+    }
+    fc.lru.splice(fc.lru.begin(), fc.lru, it->second);
+    fc.hits.fetch_add(1, std::memory_order_relaxed);
+    *out = new vk_filter{it->second->set, ix};
+    return vk::Status::Ok();
+  });
+}
+
+int vk_index_filter_cache_put(vk_index *ix, const void *key, uint64_t key_len, uint64_t epoch, vk_filter *f) {
+  VK_NEED(ix);
+  if (!f || (key_len && !key)) return fail(VK_ERR_INVALID, "NULL argument");
+  if (f->owner != ix) return fail(VK_ERR_INVALID, "the filter belongs to another index");
+  return guarded([&]() -> vk::Status {
+    VkFilterCache &fc = ix->filters;
+    const uint64_t max_entries = ix->impl->options().get(vk::kOptFilterCacheEntries);
+    const uint64_t max_bytes = ix->impl->options().get(vk::kOptFilterCacheBytes);
+    std::string k(static_cast<const char *>(key), (size_t)key_len);
+    std::lock_guard<std::mutex> lk(fc.mu);
+    auto it = fc.by_key.find(k);
+    if (it != fc.by_key.end()) fc.drop(it->second);
+    if (max_entries == 0) return vk::Status::Ok();   // (the cache is switched off)
+    fc.lru.push_front(VkFilterCache::Entry{k, epoch, f->set});
+    fc.by_key[k] = fc.lru.begin();
+    fc.bytes += f->set->device_bytes();
+    while (fc.lru.size() > 1 && (fc.lru.size() > max_entries || fc.bytes > max_bytes)) fc.drop(std::prev(fc.lru.end()));
+    return vk::Status::Ok();
+  });
+}
+
+int vk_index_search_filter(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, vk_filter *filter,
+                           const volatile int *cancel_flag, int partial_ok, float *out_dist, uint64_t *out_label, uint64_t *out_n) {
+  VK_NEED(ix);
+  if (!filter) return vk_index_search(ix, query, k, ef_runtime, nullptr, 0, cancel_flag, partial_ok, out_dist, out_label, out_n);
+  if (filter->owner != ix) return fail(VK_ERR_INVALID, "the filter belongs to another index");
+  if (!query || !out_n || (k && (!out_dist || !out_label))) return fail(VK_ERR_INVALID, "NULL argument");
+  if (ix->dispatcher->enabled() && k && !vk::cancel_raised(cancel_flag)) {
+    return counted(ix, 1, [&] {
+      return ix->dispatcher->search(static_cast<const float *>(query), k, ef_runtime, nullptr, 0, filter->set, cancel_flag, partial_ok != 0,
+                                    out_dist, out_label, out_n);
+    });
+  }
+  return counted(ix, 1, [&] {
+    vk::SearchRequest rq;
+    rq.queries = static_cast<const float *>(query);
+    rq.nq = 1;
+    rq.k = k;
+    rq.ef = ef_runtime;
+    rq.filter = filter->set.get();
+    rq.cancel_flag = cancel_flag;
+    rq.partial_ok = partial_ok != 0;
+    return ix->impl->search(rq, out_dist, out_label, out_n);
+  });
+}
+
+int vk_index_search_submit_filter(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, vk_filter *filter,
+                                  const volatile int *cancel_flag, int partial_ok, float *out_dist, uint64_t *out_label, uint64_t *out_n,
+                                  vk_search_done_fn done, void *user) {
+  VK_NEED(ix);
+  if (!query || !out_n || !out_dist || !out_label || !done) return fail(VK_ERR_INVALID, "NULL argument");
+  if (k == 0) return fail(VK_ERR_INVALID, "k must be positive");
+  if (filter && filter->owner != ix) return fail(VK_ERR_INVALID, "the filter belongs to another index");
+  if (!ix->dispatcher->enabled()) return fail(VK_ERR_INVALID, "vk_index_search_submit needs coalescing (vk_index_set_coalescing with max_batch > 1)");
+  return guarded([&]() -> vk::Status {
+    SubmitCtx *c = new SubmitCtx{ix, done, user, std::chrono::steady_clock::now()};
+    vk::Status st = ix->dispatcher->submit(static_cast<const float *>(query), k, ef_runtime, nullptr, 0, filter ? filter->set : nullptr,
+                                           cancel_flag, partial_ok != 0, out_dist, out_label, out_n, submit_done, c);
+    if (!st.ok()) delete c;   // (not queued: the callback will not fire)
+    return st;
+  });
+}
+
+int vk_index_search_batch_filter_handles(vk_index *ix, const void *queries, uint64_t nq, uint64_t k, uint64_t ef_runtime,
+                                         vk_filter *const *filters, const volatile int *cancel_flag, int partial_ok, float *out_dist,
+                                         uint64_t *out_label, uint64_t *out_n) {
+  VK_NEED(ix);
+  if (nq && (!queries || !out_n)) return fail(VK_ERR_INVALID, "queries/out_n is NULL");
+  if (nq && k && (!out_dist || !out_label)) return fail(VK_ERR_INVALID, "output buffers are NULL");
+  std::vector<const vk::FilterSet *> tab;
+  if (filters) {
+    tab.resize(nq);
+    for (uint64_t q = 0; q < nq; ++q) {
+      if (filters[q] && filters[q]->owner != ix) return fail(VK_ERR_INVALID, "the filter belongs to another index");
+      tab[q] = filters[q] ? filters[q]->set.get() : nullptr;
+    }
+  }
+  return counted(ix, nq, [&] {
+    vk::SearchRequest rq;
+    rq.queries = static_cast<const float *>(queries);
+    rq.nq = nq;
+    rq.k = k;
+    rq.ef = ef_runtime;
+    rq.filter_tab = filters ? tab.data() : nullptr;
+    rq.cancel_flag = cancel_flag;
+    rq.partial_ok = partial_ok != 0;
+    return ix->impl->search(rq, out_dist, out_label, out_n);
   });
 }
 
