@@ -136,6 +136,26 @@ def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
     from oracle import oracle as O
     Nh, D, K, ef = host_rows.shape[0], args.dim, args.k, args.hnsw_ef
     t_leg = time.perf_counter()
+    # the two ingest routes over the same 1M rows: one vk_index_add_batch, and what IndexSchema does -- one vk_index_add per
+    # key from the writer pool (src/index_schema.cc:755-791; here 16 native threads), linked in bulk on the device at flush
+    routes = None
+    if Nh >= 1_000_000 and not args.no_serving:
+        sub = host_rows[:1_000_000]
+        t0 = time.perf_counter()
+        hb = vsa.Index("HNSW", D, "COSINE", initial_cap=len(sub), m=16, ef_construction=200, ef_runtime=ef)
+        hb.add_batch(sub)
+        hb.flush()
+        t_b = time.perf_counter() - t0
+        del hb
+        t0 = time.perf_counter()
+        hs = vsa.Index("HNSW", D, "COSINE", initial_cap=len(sub), m=16, ef_construction=200, ef_runtime=ef)
+        failed, t_adds = vsa.probe_add_single(hs, sub, threads=16)
+        hs.flush()
+        t_s = time.perf_counter() - t0
+        sst = hs.stats()
+        routes = {"rows": len(sub), "add_batch_s": round(t_b, 2), "single_adds_16_threads_s": round(t_s, 2), "of_which_staging_s": round(t_adds, 2),
+                  "single_over_batch": round(t_s / t_b, 3), "failed": failed, "staged": int(sst.staged_adds), "linked_on_device": int(sst.staged_adds_device)}
+        del hs
     t0 = time.perf_counter()
     h = vsa.Index("HNSW", D, "COSINE", initial_cap=Nh, m=16, ef_construction=200, ef_runtime=ef)
     h.add_batch(host_rows)
@@ -149,16 +169,22 @@ def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
     ol = torch.empty(nq, K, device=device, dtype=torch.int64)
     on = torch.empty(nq, device=device, dtype=torch.int32)
 
+    vis_modes = {}
+    VIS = {0: ("hnsw_search_kernel", "one bit per node in memory"), 1: ("hnsw_search_hash_kernel", "hash table in HBM"),
+           2: ("hnsw_search_hash_kernel", "buckets in HBM, counts in LDS"), 3: ("hnsw_search_ldsvis_kernel", "LDS, 12 KB per wave, spill to memory"),
+           5: ("hnsw_search_ldsvis_kernel", "LDS, 32 KB per wave, spill to memory")}
+
     def point(ef_s, reps=5):
         ms = timed(lambda: h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef_s,
                                                  stream=stream_ptr()), reps)
         gl = ol.cpu().numpy().view(np.uint64).copy()
         _D, _L, _N = h.search_batch(hq[:1024], K, ef=ef_s)        # host path once: fills the work counters
         st = h.stats()
+        vis_modes[ef_s] = int(st.last_visited_mode)
         useful = (st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132) / 1024.0 * nq
         gbs = useful / (ms * 1e-3) / 1e9
         return gl, {"ef": ef_s, "gpu_qps": round(nq / (ms * 1e-3), 1), "ms_per_batch": round(ms, 3),
-                    "recall_at_10": round(recall_of(gl, gt, K), 4),
+                    "recall_at_10": round(recall_of(gl, gt, K), 4), "visited_mode": vis_modes[ef_s],
                     "n_eval_per_query": round(st.last_n_eval / 1024.0, 1), "n_hops_per_query": round(st.last_n_hops / 1024.0, 1),
                     "useful_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                     "frac_of_gather_ceiling": round(gbs / GATHER_CEILING_GBS, 4)}
@@ -208,12 +234,11 @@ def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
     del views
     return {"workload": f"HNSW {Nh}x{D} fp32 COSINE M=16 efC=200 efSearch={ef} k={K} (BASELINE.json configs[2])",
             "rows": Nh, "M": 16, "ef_construction": 200, "k": K, "queries_per_batch": nq,
-            "build_s": round(build_s, 2), "build_inserts_per_s": round(Nh / build_s, 1), "build": "device-assisted (K9)",
+            "build_s": round(build_s, 2), "build_inserts_per_s": round(Nh / build_s, 1), "build": "device-assisted (K9)", "build_routes_1M": routes,
             **head, "single_query_ms": round(lat_ms, 3),
             "roofline": {"bound": "hbm", "achieved": head["useful_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": head["frac_of_hbm_peak"],
-                         "kernel": "hnsw_search_ldsvis_kernel" if ef <= 448 else "hnsw_search_hash_kernel",
-                         "visited_set": "LDS, 12 KB per wave, spill to memory (option hnsw-visited-mode 3)" if ef <= 448 else "hash table in HBM",
+                         "kernel": VIS[vis_modes[ef]][0], "visited_set": VIS[vis_modes[ef]][1] + " (vk_index_stats.last_visited_mode)",
                          "bytes": "n_eval*(D*4+4) + n_hops*132 per query, counted by the kernel",
                          "gather_ceiling_gbs": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r01_gather_ceiling_10Mx768.log"},
             "matched_recall_0.95": matched, "ef_sweep": sweep, "single_query_serving": serving,
@@ -735,9 +760,19 @@ def _exact_gt(flat_ix, hq, K, bits, nbits):
 
 
 def sharded_hybrid_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows):
-    """BASELINE.json configs[4]: one HNSW graph (M=16, efC=200) of --hybrid-rows rows per GPU inside ONE sharded index +
-    a TAG-like filter as an allow-bitmap (10 % selectivity: the inline-filter branch of planner.cc:21-45), efSearch=256,
-    k=10.  QPS of the sharded search and recall@10 against the exact filtered answer of the sharded FLAT index."""
+    """BASELINE.json configs[4]: one HNSW graph (M=16, efC=200) of --hybrid-rows rows per GPU inside ONE sharded index + TAG
+    filters of 10 % selectivity (the inline-filter branch of planner.cc:21-45), efSearch=256, k=10 -- the way FT.SEARCH traffic
+    brings them: EVERY QUERY CARRIES ITS OWN PREDICATE, and the filter is built INSIDE the timed step from what the query
+    layer holds for it, the posting list of the tag (tag.cc:383-455 -> search.cc:301-399), through vk_filter_create (device
+    scatter of the id list) and the (predicate, epoch) cache.  Three steps are timed:
+      shared_tags_cold   16 tags over 4096 queries, a write phase before every step (epoch bump): all 16 filters are rebuilt
+                         from their 10 %-of-N id lists inside the step; each query looks its predicate up
+      shared_tags_warm   the same without the write phase: 4096 cache hits
+      distinct_per_query 1024 queries, each with a predicate nobody shares (tag_a OR tag_b, 1024 distinct pairs): one
+                         vk_filter_combine of two cached terms per query inside the step
+    Reported per step: QPS, recall@10 against the exact filtered FLAT answer per query, the layer-0 work counters, the useful
+    bytes they imply and their fraction of the HBM peak (through the host entry point: query upload and result copy-out are
+    inside), and -- a sample -- the CPU oracle searching the SAME graphs with the SAME bitmaps (ids compared, timed)."""
     from oracle import oracle as O
     Nh, D, K, ef_h, S = host_rows.shape[0], args.dim, args.k, 256, len(devs)
     t_leg = time.perf_counter()
@@ -748,20 +783,142 @@ def sharded_hybrid_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows
     nq = min(args.hybrid_queries, 4096)
     Qh = make_queries(A, nq, D, device, 7070)
     hq = Qh.cpu().numpy()
-    tag = np.arange(3, Nh, 10, dtype=np.uint64)                                # "tag t3": 10 % of the rows
-    tag_bits = O.allow_bitmap(tag, Nh)
-    d_bits = torch.from_numpy(tag_bits.view(np.int64)).to(device)
-    gt = _exact_gt(flat_ix, hq, K, tag_bits, Nh)
-    od = torch.empty(nq, K, device=device, dtype=torch.float32)
-    ol = torch.empty(nq, K, device=device, dtype=torch.int64)
-    on = torch.empty(nq, device=device, dtype=torch.int32)
-    ms, wall_ms = _timed_steps(lambda: h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef_h,
-                                                             d_allow=d_bits.data_ptr(), allow_nbits=Nh, stream=ws.cuda_stream), 3, 1)
-    rec = recall_of(ol.cpu().numpy().view(np.uint64), gt, K)
+    T = 16
+    tag_ids = [np.flatnonzero(np.random.default_rng(4000 + t).random(Nh) < 0.1).astype(np.uint64) for t in range(T)]   # posting lists
+    tag_bits = [O.allow_bitmap(ids, Nh) for ids in tag_ids]
+    which = np.arange(nq) % T
+    gt = np.empty((nq, K), np.uint64)
+    for t in range(T):                                                      # exact filtered answers, one scan group per tag
+        sel = np.flatnonzero(which == t)
+        gt[sel] = _exact_gt(flat_ix, hq[sel], K, tag_bits[t], Nh)
+    epoch = [1]
+    t_filters = [0.0]
+    n_built = [0]
+
+    def filters_of_step():
+        """what the adaptor's BuildFilter does per FT.SEARCH (include/vk_vector_adaptor.h): cache lookup under the predicate's
+        text and the write-phase epoch; on a miss the posting list goes to the device"""
+        t0 = time.perf_counter()
+        out = []
+        for i in range(nq):
+            key = b"@tag:{t%d}" % which[i]
+            f = h.filter_cache_get(key, epoch[0])
+            if f is None:
+                f = h.make_filter(Nh, labels=tag_ids[which[i]])
+                h.filter_cache_put(key, epoch[0], f)
+                n_built[0] += 1
+            out.append(f)
+        t_filters[0] += time.perf_counter() - t0
+        return out
+
+    last = {}
+
+    def step(cold):
+        if cold:
+            epoch[0] += 1                                                   # a write phase happened: cached filters are stale
+        fl = filters_of_step()
+        last["out"] = h.search_batch_filter_handles(hq, K, fl, ef=ef_h)
+
+    def timed_leg(fn, steps):
+        fn()                                                                # warm-up (contexts, first-use allocations)
+        t_filters[0], n_built[0] = 0.0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        dt = (time.perf_counter() - t0) / steps
+        return dt, t_filters[0] / steps, n_built[0] / steps
+
+    def work(n_queries, dt_search):
+        st = h.stats()
+        useful = st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132
+        gbs = useful / dt_search / 1e9
+        return {"n_eval_per_query": round(st.last_n_eval / n_queries, 1), "n_hops_per_query": round(st.last_n_hops / n_queries, 1),
+                "useful_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / (HBM_PEAK_GBS * len(set(devs))), 4)}
+
+    legs = {}
+    for name, cold in (("shared_tags_cold", True), ("shared_tags_warm", False)):
+        dt, dt_f, built = timed_leg(lambda: step(cold), 2)
+        _D, L, _N = last["out"]
+        legs[name] = {"queries": nq, "distinct_predicates": T, "gpu_qps": round(nq / dt, 1), "ms_per_step": round(dt * 1e3, 2),
+                      "of_which_filters_ms": round(dt_f * 1e3, 2), "filters_built_per_step": built,
+                      "ids_per_filter": int(np.mean([len(x) for x in tag_ids])), "recall_at_10": round(recall_of(L, gt, K), 4),
+                      **work(nq, dt - dt_f)}
+    glw = last["out"][1].copy()
+    # every query its own predicate: tag_a OR tag_b over cached terms, combined on the device inside the step
+    nd = min(1024, nq)
+    pairs = [(i % T, (i // T + 1 + i) % T) for i in range(nd)]
+    pairs = [(a, b if b != a else (b + 1) % T) for a, b in pairs]
+    terms = [h.filter_cache_get(b"@tag:{t%d}" % t, epoch[0]) for t in range(T)]
+
+    def step_distinct():
+        t0 = time.perf_counter()
+        fl = [h.combine_filters(terms[a], terms[b], "or") for a, b in pairs]
+        t_filters[0] += time.perf_counter() - t0
+        n_built[0] += nd
+        last["out"] = h.search_batch_filter_handles(hq[:nd], K, fl, ef=ef_h)
+
+    dt, dt_f, built = timed_leg(step_distinct, 2)
+    _D, Ld, _N = last["out"]
+    gtd = np.empty((nd, K), np.uint64)
+    uniq = sorted(set(pairs))
+    if len(uniq) <= 256:                                                    # (one exact scan per distinct pair)
+        for a, b in uniq:
+            sel = np.array([i for i, p in enumerate(pairs) if p == (a, b)])
+            gtd[sel] = _exact_gt(flat_ix, hq[sel], K, tag_bits[a] | tag_bits[b], Nh)
+        rec_d = round(recall_of(Ld, gtd, K), 4)
+    else:
+        rec_d = None
+    legs["distinct_per_query"] = {"queries": nd, "distinct_predicates": len(uniq), "predicate": "tag_a OR tag_b, combined on the device from cached terms",
+                                  "gpu_qps": round(nd / dt, 1), "ms_per_step": round(dt * 1e3, 2), "of_which_filters_ms": round(dt_f * 1e3, 2),
+                                  "filters_built_per_step": built, "recall_at_10": rec_d, **work(nd, dt - dt_f)}
+    # the CPU oracle on the very same graphs with the very same bitmaps (a sample): ids, and its rate on the box's cores
+    cpu = None
+    try:
+        t1 = time.perf_counter()
+        graphs = O.HNSW.shards_from_product_index(h.save_raw, D, "COSINE", 16, ef_construction=200, ef=ef_h)
+        export_s = time.perf_counter() - t1
+        threads = effective_cpus()
+        ncq = min(nq, threads * 4)
+        views = [[g if t == 0 else g.view() for g in graphs] for t in range(threads)]
+
+        def cpu_chunk(t):
+            out = []
+            for i in range(t, ncq, threads):
+                parts = [g.search(hq[i], K, ef=ef_h, allow=tag_bits[which[i]], allow_nbits=Nh) for g in views[t]]
+                dd = np.full((len(parts), K), np.inf, np.float32)
+                ll = np.full((len(parts), K), np.iinfo(np.uint64).max, np.uint64)
+                cc = np.zeros(len(parts), np.uint64)
+                for s_, (pd, pl) in enumerate(parts):
+                    dd[s_, :len(pd)], ll[s_, :len(pl)], cc[s_] = pd, pl, len(pd)
+                out.append((i, O.merge_topk(dd, ll, cc, K)))
+            return out
+
+        cpu_chunk(0)
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(cpu_chunk, range(threads)))
+        cdt = time.perf_counter() - t1
+        res = dict(kv for p_ in parts for kv in p_)
+        same = sum(int(res[i][1].tolist() == glw[i][:len(res[i][1])].tolist()) for i in range(ncq))
+        cpu = {"kind": "port", "threads": threads, "queries": ncq, "qps": round(ncq / cdt, 1), "same_graphs_same_bitmaps": True,
+               "ids_identical_to_gpu": f"{same}/{ncq}", "graph_export_s": round(export_s, 2),
+               "recall_at_10": round(recall_of([res[i][1] for i in range(ncq)], gt[:ncq], K), 4)}
+        del views, graphs
+    except Exception as e:   # noqa: BLE001
+        cpu = {"error": f"{type(e).__name__}: {e}"}
+    head = legs["shared_tags_warm"]
+    st = h.stats()
     return {"workload": f"BASELINE.json configs[4]: HNSW M=16 efC=200, {Nh}x{D} fp32 COSINE over {S} GPUs ({Nh // S} rows per graph) "
-                        f"+ TAG filter (10 %), efSearch={ef_h}, k={K}",
+                        f"+ TAG filters (10 %, one predicate per query, built inside the step), efSearch={ef_h}, k={K}",
             "shards": S, "rows": Nh, "rows_per_shard": Nh // S, "queries_per_batch": nq, "build_s": round(build_s, 2),
-            "gpu_qps": round(nq / (wall_ms * 1e-3), 1), "ms_per_batch": round(wall_ms, 3), "recall_at_10": round(rec, 4),
+            "gpu_qps": head["gpu_qps"], "ms_per_batch": head["ms_per_step"], "recall_at_10": head["recall_at_10"],
+            "roofline": {"bound": "hbm", "achieved": head["useful_gbs"], "peak": HBM_PEAK_GBS * len(set(devs)), "unit": "GB/s",
+                         "frac": head["frac_of_hbm_peak"], "kernel": "hnsw_search_kernel (HBM frontier, one bitmap per query)",
+                         "bytes": "n_eval*(D*4+4) + n_hops*132 per query, counted by the kernels of every shard",
+                         "note": "every shard is searched with the full ef: S times the hops of one graph" + ("; the shards share one GPU here" if len(set(devs)) == 1 else "")},
+            "steps": legs, "filter_cache": {"hits": int(st.filter_cache_hits), "misses": int(st.filter_cache_misses), "built": int(st.filters_built),
+                                            "entries": int(st.filter_cache_entries), "device_bytes": int(st.filter_cache_bytes)},
+            "cpu": cpu,
             "merge": "one graph per shard inside one vk_index; per-shard top-k gathered on device 0, (distance,label) merge",
             "leg_s": round(time.perf_counter() - t_leg, 1)}
 

@@ -182,6 +182,10 @@ typedef struct vk_index_stats {
    * those went through the device build (K9) rather than the host builder */
   uint64_t staged_adds;
   uint64_t staged_adds_device;
+  /* HNSW: how the most recent search launch kept its visited set: 0 = one bit per node in memory, 1 = hash table in memory,
+   * 2 = buckets in memory with counts in LDS, 3 = the 12 KB set in LDS (spill to memory), 5 = the 32 KB set in LDS
+   * (option hnsw-visited-mode picks among what fits; bench.py names the kernel it timed from this, not from ef) */
+  uint64_t last_visited_mode;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------

@@ -208,3 +208,33 @@ extern "C" int vk_probe_blocking(vk_index *ix, const float *queries, uint64_t nq
   percentiles(all, out);
   return VK_OK;
 }
+
+// `threads` writer threads feed n rows ONE AT A TIME through vk_index_add, the way IndexSchema's writer pool feeds AddRecord
+// (src/index_schema.cc:755-791; the adaptor's resize-and-retry loop around VK_ERR_CAPACITY included), then the caller flushes.
+// Returns the number of failed adds; *seconds = the time of the adds alone.
+extern "C" uint64_t vk_probe_add_single(vk_index *ix, const uint64_t *labels, const float *rows, uint64_t n, uint32_t dim, int threads,
+                                        uint64_t grow_by, double *seconds) {
+  std::atomic<uint64_t> next{0}, failed{0};
+  std::mutex resize_mu;
+  const Clock::time_point t0 = Clock::now();
+  std::vector<std::thread> ts;
+  for (int t = 0; t < threads; ++t)
+    ts.emplace_back([&] {
+      for (;;) {
+        const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= n) return;
+        for (;;) {
+          const int rc = vk_index_add(ix, labels ? labels[i] : i, rows + i * dim);
+          if (rc == VK_OK) break;
+          if (rc != VK_ERR_CAPACITY) { failed.fetch_add(1, std::memory_order_relaxed); break; }
+          std::lock_guard<std::mutex> lk(resize_mu);   // (vector_hnsw.cc:238-271 ResizeIfFull)
+          vk_index_stats st{};
+          vk_index_get_stats(ix, &st);
+          if (st.count >= st.capacity && vk_index_resize(ix, st.capacity + (grow_by ? grow_by : 10240)) != VK_OK) { failed.fetch_add(1, std::memory_order_relaxed); break; }
+        }
+      }
+    });
+  for (auto &t : ts) t.join();
+  if (seconds) *seconds = std::chrono::duration<double>(Clock::now() - t0).count();
+  return failed.load();
+}

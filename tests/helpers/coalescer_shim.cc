@@ -422,3 +422,42 @@ extern "C" int dispatcher_flat_fill_run(int threads, int calls, int delay_us, in
   out[1] = ix.queries;
   return bad.load();
 }
+
+// A SUBMITTED request whose token goes up while it is still QUEUED behind the batches in flight (one runner, 0.1 s passes, the
+// victim three batches back): the watcher answers it within its tick, not when a runner reaches its lane.
+// out[0] = microseconds from the token to the callback, out[1] = queries the "device" served (the victim is not among them).
+extern "C" int dispatcher_queued_cancel_run(int hnsw, uint64_t *out) {
+  vk_index_params p{};
+  p.struct_size = sizeof p;
+  p.dim = 4;
+  p.algo = hnsw ? VK_ALGO_HNSW : VK_ALGO_FLAT;
+  FakeIndex ix(p);
+  ix.delay_us = 100000;
+  std::atomic<int> bad{0};
+  const int n = 32, victim = 29;
+  std::vector<std::unique_ptr<CancelSlot>> slots;
+  for (int t = 0; t < n; ++t) {
+    slots.push_back(std::make_unique<CancelSlot>());
+    slots[t]->q[0] = (float)t; slots[t]->q[1] = (float)(t + 7); slots[t]->q[2] = slots[t]->q[3] = 0.f;
+  }
+  std::chrono::steady_clock::time_point t_raise;
+  {
+    vk::Dispatcher dp(&ix);
+    dp.configure(8, 500);
+    dp.set_in_flight(1);
+    for (int t = 0; t < n; ++t)
+      if (!dp.submit(slots[t]->q, 3, 100, nullptr, 0, nullptr, &slots[t]->flag, /*partial_ok=*/false, slots[t]->d, slots[t]->l, &slots[t]->n, cancel_done,
+                     slots[t].get()).ok()) bad += 1;
+    std::this_thread::sleep_for(std::chrono::milliseconds(30));     // batch 0..7 is on the device, 8..31 wait
+    t_raise = std::chrono::steady_clock::now();
+    __atomic_store_n(const_cast<int *>(&slots[victim]->flag), 1, __ATOMIC_RELAXED);
+    while (slots[victim]->done.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    out[0] = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(slots[victim]->t_done - t_raise).count();
+  }   // (the destructor serves the rest)
+  for (int t = 0; t < n; ++t) {
+    const CancelSlot &s = *slots[t];
+    if (t == victim ? (hnsw ? s.status != VK_ERR_CANCELLED : (s.status != VK_OK || s.n != 0)) : (s.status != VK_OK || s.n != 3 || s.l[0] != (uint64_t)(t + 7) * 10)) bad += 1;
+  }
+  out[1] = ix.queries;
+  return bad.load();
+}

@@ -74,6 +74,8 @@ int main(int argc, char **argv) {
   for (int hnsw = 0; hnsw < 2; ++hnsw)
     for (int sub = 0; sub < 2; ++sub) bad += dispatcher_member_cancel_run(hnsw, sub, 3, out);
   bad += dispatcher_flat_fill_run(32, 6, 2000, 0, out);
+  bad += dispatcher_queued_cancel_run(1, out);
+  bad += dispatcher_queued_cancel_run(0, out);
   printf("bad=%d\n", bad);
   return bad ? 1 : 0;
 }

@@ -28,6 +28,7 @@ def shim(tmp_path_factory):
     lib.dispatcher_batch_cancel_run.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.dispatcher_member_cancel_run.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     lib.dispatcher_flat_fill_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    lib.dispatcher_queued_cancel_run.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     return lib
 
 
@@ -165,3 +166,13 @@ def test_flat_callers_keep_travelling_together(shim):
     out = (C.c_uint64 * 8)()
     assert shim.dispatcher_flat_fill_run(64, 12, 3000, 0, out) == 0
     assert out[1] == 64 * 12 and out[1] / out[0] >= 48, (out[0], out[1])
+
+
+@pytest.mark.parametrize("hnsw", [1, 0])
+def test_a_queued_submitted_request_is_answered_when_its_token_goes_up(shim, hnsw):
+    """One runner, 0.1 s device passes, 32 submissions in lanes of 8: the request three batches back is cancelled while it
+    waits.  r05's first GPU run showed such a request waiting for a runner to reach its lane (0.48 s); the watcher now
+    sweeps the queue every tick."""
+    out = (C.c_uint64 * 8)()
+    assert shim.dispatcher_queued_cancel_run(hnsw, out) == 0, list(out)[:2]
+    assert out[0] < 1000 and out[1] == 31, list(out)[:2]

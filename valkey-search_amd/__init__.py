@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("last_filter_reranked", C.c_uint64), ("max_label", C.c_uint64), ("cancelled_early", C.c_uint64),
                 ("filters_built", C.c_uint64), ("filter_cache_hits", C.c_uint64), ("filter_cache_misses", C.c_uint64),
                 ("filter_cache_entries", C.c_uint64), ("filter_cache_bytes", C.c_uint64),
-                ("staged_adds", C.c_uint64), ("staged_adds_device", C.c_uint64)]
+                ("staged_adds", C.c_uint64), ("staged_adds_device", C.c_uint64), ("last_visited_mode", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -561,6 +561,8 @@ def probe_lib():
         vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
         P.vk_probe_submit.argtypes = [vp, vp, u64, u32, u64, u64, i32, i32, u64, vp, vp, C.POINTER(ProbeResult)]
         P.vk_probe_blocking.argtypes = [vp, vp, u64, u32, u64, u64, i32, i32, vp, vp, C.POINTER(ProbeResult)]
+        P.vk_probe_add_single.argtypes = [vp, vp, vp, u64, u32, i32, u64, C.POINTER(C.c_double)]
+        P.vk_probe_add_single.restype = u64
         _probe = P
     return _probe
 
@@ -575,6 +577,16 @@ def probe_submit(ix, Q, k, total, producers=4, window=1024, ef=0, ref=None):
     r = ProbeResult()
     _check(probe_lib().vk_probe_submit(ix._h, _ptr(Q), Q.shape[0], Q.shape[1], k, ef, producers, window, total, _ptr(rd), _ptr(rl), C.byref(r)))
     return r
+
+
+def probe_add_single(ix, rows, labels=None, threads=16, grow_by=0):
+    """n rows through vk_index_add, one call each, from `threads` native writer threads (IndexSchema's AddRecord traffic);
+    returns (failed adds, seconds)"""
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint64)
+    sec = C.c_double()
+    failed = probe_lib().vk_probe_add_single(ix._h, _ptr(lab), _ptr(rows), rows.shape[0], rows.shape[1], threads, grow_by, C.byref(sec))
+    return int(failed), sec.value
 
 
 def probe_blocking(ix, Q, k, threads, calls, ef=0, ref=None):

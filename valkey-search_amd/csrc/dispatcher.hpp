@@ -537,7 +537,38 @@ class Dispatcher {
         }
         if (all) __atomic_store_n(&w->word, 1, __ATOMIC_RELAXED);
       }
+      // ... and the submitted requests that are still QUEUED behind the batches in flight: a token that goes up there is
+      // answered now, not when a runner gets to its lane (blocking callers poll their own).  Outside wmu_: the queue has its
+      // own lock, and the callbacks run without either.
+      lk.unlock();
+      sweep_queued();
+      lk.lock();
     }
+  }
+  void sweep_queued() {
+    std::vector<std::shared_ptr<Req>> gone;
+    {
+      std::lock_guard<std::mutex> ql(mu_);
+      size_t budget = 8192;   // requests looked at per tick, oldest first
+      for (auto it = lanes_.begin(); it != lanes_.end() && budget;) {
+        auto &q = it->second.q;
+        for (auto qi = q.begin(); qi != q.end() && budget; --budget) {
+          Req &r = **qi;
+          if (r.cb && cancel_raised(r.cancel)) {
+            r.state.store(kInBatch, std::memory_order_relaxed);   // (claimed below like a member of a batch)
+            gone.push_back(std::move(*qi));
+            qi = q.erase(qi);
+            queued_.fetch_sub(1, std::memory_order_relaxed);
+          } else {
+            ++qi;
+          }
+        }
+        if (q.empty() && !it->second.collector) it = lanes_.erase(it);   // (a collector holds a pointer to its lane)
+        else ++it;
+      }
+    }
+    for (auto &r : gone)
+      if (finish(*r, cancelled_status(r->partial_ok), nullptr, nullptr, 0)) left_early_.fetch_add(1, std::memory_order_relaxed);
   }
   bool stop_flag() const { return stop_watch_.load(std::memory_order_relaxed); }
 

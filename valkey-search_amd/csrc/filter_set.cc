@@ -186,4 +186,18 @@ Status FilterSet::read(uint64_t *out_words, uint64_t n_words) const {
   return Status::Ok();
 }
 
+// kernels.hpp: see the declaration
+hipError_t ensure_max_lds(const void *fn) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void *, int>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  for (const auto &d : done)
+    if (d.first == fn && d.second == dev) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) done.emplace_back(fn, dev);
+  return e;
+}
+
 }  // namespace vk

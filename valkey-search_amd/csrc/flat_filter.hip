@@ -1556,7 +1556,7 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
     const size_t lds = flat_filter_fat_lds_bytes();
     const void *fn = a.bf16 ? reinterpret_cast<const void *>(&flat_filter_fat_kernel<true>) : reinterpret_cast<const void *>(&flat_filter_fat_kernel<false>);
     if (a.dbg) fn = a.bf16 ? reinterpret_cast<const void *>(&flat_filter_fat_kernel<true, true>) : reinterpret_cast<const void *>(&flat_filter_fat_kernel<false, true>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_max_lds(fn);
     if (e != hipSuccess) return e;
     FlatFilterArgs args = a;
     args.n_tiles = (a.n_rows + kFatRows - 1) / kFatRows;
@@ -1621,7 +1621,7 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
 #undef VK_ABL
   }
 #endif
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   // (above the 64 KB default)
+  hipError_t e = ensure_max_lds(fn);   // (above the 64 KB default)
   if (e != hipSuccess) return e;
   FlatFilterArgs args = a;
   void *params[] = {&args};

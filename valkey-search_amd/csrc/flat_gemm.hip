@@ -564,7 +564,7 @@ hipError_t launch_flat_gemm(const FlatGemmArgs &a, hipStream_t s) {
                                : (reg ? reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, true, false>)
                                       : reinterpret_cast<const void *>(&flat_gemm_kernel<0, 7, false, false>));
   (void)mode;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = ensure_max_lds(fn);
   if (e != hipSuccess) return e;
   FlatGemmArgs args = a;
   void *params[] = {&args};

@@ -510,15 +510,16 @@ __global__ __launch_bounds__(256) void flat_rerank_kernel(FlatScanArgs a, MergeA
     __hip_atomic_store(reinterpret_cast<uint32_t *>(pd) + lane, __float_as_uint(top.d[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(pl + lane, top.lab[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // No fences: an agent-scope release / acquire on this multi-die part writes back / invalidates a whole L2 (measured: the
-  // kernel went from 134 to 329 us with them).  The partial list is written with device-coherent stores (sc1: they pass
-  // the die's L2), the wave waits until they are acknowledged, THEN lane 0 bumps the counter at the same coherence point;
-  // the last block reads the lists with device-coherent loads.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Publication of the partial list: device-coherent stores, then a RELEASE bump of the query's counter at agent scope; the
+  // block that arrives last ACQUIRES before it reads the other blocks' lists.  (r04 had no fences here -- it relied on the
+  // sc1 stores passing the die's L2 and on the wave's s_waitcnt, formally a data race -- because an agent-scope release /
+  // acquire writes back / invalidates a whole L2 and cost 134 -> 329 us when EVERY query merged across blocks.  Since the
+  // second bound only lists over 2048 survivors come here; the fences are paid by those alone.)
   uint32_t arrived = 0;
-  if (lane == 0) arrived = __hip_atomic_fetch_add(a.done_cnt + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) arrived = __hip_atomic_fetch_add(a.done_cnt + q, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
   if (arrived != kRerankParts - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   for (uint32_t p2 = 0; p2 < kRerankParts; ++p2) {
     if (p2 == part) continue;
     float dist = __builtin_inff();
@@ -562,7 +563,7 @@ hipError_t launch_flat_rerank(const FlatScanArgs &a, const MergeArgs &m_in, bool
   const void *f = l2 ? (bf16 ? reinterpret_cast<const void *>(&flat_rerank_kernel<true, true>) : reinterpret_cast<const void *>(&flat_rerank_kernel<true, false>))
                      : (bf16 ? reinterpret_cast<const void *>(&flat_rerank_kernel<false, true>) : reinterpret_cast<const void *>(&flat_rerank_kernel<false, false>));
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_max_lds(f);
     if (e != hipSuccess) return e;
   }
   FlatScanArgs args = a;
@@ -947,8 +948,7 @@ __global__ __launch_bounds__(256) void merge_select_kernel(MergeArgs a) {
 template <bool kL2, bool kBf16>
 static hipError_t launch_scan_lb(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<1, kL2, 16, kBf16, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_max_lds(reinterpret_cast<const void *>(&flat_scan_kernel<1, kL2, 16, kBf16, true>));
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((flat_scan_kernel<1, kL2, 16, kBf16, true>), grid, dim3(256), lds, s, a);
@@ -958,8 +958,7 @@ static hipError_t launch_scan_lb(const FlatScanArgs &a, dim3 grid, size_t lds, h
 template <int kQB, bool kL2, int kE, bool kBf16>
 static hipError_t launch_scan_t(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<kQB, kL2, kE, kBf16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_max_lds(reinterpret_cast<const void *>(&flat_scan_kernel<kQB, kL2, kE, kBf16>));
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((flat_scan_kernel<kQB, kL2, kE, kBf16>), grid, dim3(256), lds, s, a);
@@ -985,8 +984,7 @@ static hipError_t launch_scan_l2(bool l2, int qb, const FlatScanArgs &a, dim3 gr
 template <bool kL2, bool kBf16, int kE>
 static hipError_t launch_rerank_t(const FlatScanArgs &a, dim3 grid, size_t lds, hipStream_t s) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&flat_scan_kernel<1, kL2, kE, kBf16, false, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_max_lds(reinterpret_cast<const void *>(&flat_scan_kernel<1, kL2, kE, kBf16, false, true>));
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((flat_scan_kernel<1, kL2, kE, kBf16, false, true>), grid, dim3(256), lds, s, a);
@@ -1073,7 +1071,7 @@ hipError_t launch_gather_distance(const GatherArgs &a, bool l2, bool bf16, hipSt
                      : (bf16 ? reinterpret_cast<const void *>(&gather_distance_kernel<false, true>)
                              : reinterpret_cast<const void *>(&gather_distance_kernel<false, false>));
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_max_lds(f);
     if (e != hipSuccess) return e;
   }
   GatherArgs args = a;

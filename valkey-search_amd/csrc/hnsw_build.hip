@@ -393,7 +393,7 @@ hipError_t launch_hnsw_select(const HnswBuildArgs &a, bool l2, bool bf16, hipStr
                               : reinterpret_cast<const void *>(&hnsw_select_kernel<true, false>))
                       : (bf16 ? reinterpret_cast<const void *>(&hnsw_select_kernel<false, true>)
                               : reinterpret_cast<const void *>(&hnsw_select_kernel<false, false>));
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = ensure_max_lds(fn);
   if (e != hipSuccess) return e;
   HnswBuildArgs args = a;
   void *params[] = {&args};
@@ -407,7 +407,7 @@ hipError_t launch_hnsw_relink(const HnswBuildArgs &a, bool l2, bool bf16, hipStr
                               : reinterpret_cast<const void *>(&hnsw_relink_kernel<true, false>))
                       : (bf16 ? reinterpret_cast<const void *>(&hnsw_relink_kernel<false, true>)
                               : reinterpret_cast<const void *>(&hnsw_relink_kernel<false, false>));
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = ensure_max_lds(fn);
   if (e != hipSuccess) return e;
   HnswBuildArgs args = a;
   void *params[] = {&args};

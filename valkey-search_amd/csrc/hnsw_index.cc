@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <unordered_map>
 
 #include "hnsw_graph.hpp"
 #include "index.hpp"
@@ -62,18 +63,88 @@ class HnswIndex final : public Index {
     d_upper_pool_.release();
   }
 
+  // addPoint, one element (hnswalg.h:1278-1340).  IndexSchema feeds AddRecord one key at a time from the writer pool
+  // (src/index_schema.cc:755-791), so this -- not add_batch -- is what a backfill or an ingest burst arrives through.  A NEW
+  // label is therefore STAGED (its row copied, nothing linked) once the graph is large enough for the device build; what a
+  // writer phase staged is linked in bulk by drain_pending() at vk_index_flush / before the next search -- on the device
+  // (K9, hnsw_build.hip) when there are thousands, by the host threads otherwise.  The points of one bulk do not see one
+  // another while they are linked: the relaxation concurrent addPoint calls already have (hnswalg.h:1523-1650 take no lock
+  // across points).  Updates of an existing label, replace-deleted inserts and small graphs take the host builder at once.
   Status add(uint64_t label, const float *row) override {
-    std::shared_lock<std::shared_mutex> lk(rw_);
-    return add_one(label, row);
+    bool full = false;
+    {
+      std::shared_lock<std::shared_mutex> lk(rw_);
+      if (!stage_candidate()) return add_one(label, row);
+      std::lock_guard<std::mutex> pl(pend_.mu);
+      auto it = pend_.pos.find(label);
+      if (it != pend_.pos.end()) {   // the same label again before it was linked: the later row wins (an in-place update)
+        memcpy(pend_.rows.data() + it->second * params_.dim, row, (size_t)params_.dim * 4);
+        return Status::Ok();
+      }
+      uint32_t id;
+      if (graph_->lookup(label, &id)) return add_one(label, row);   // an update of a linked element
+      if (graph_->count() + pend_.live + draining_.load(std::memory_order_relaxed) >= graph_->max_elements())
+        return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+      pend_.pos.emplace(label, pend_.labels.size());
+      pend_.labels.push_back(label);
+      pend_.rows.insert(pend_.rows.end(), row, row + params_.dim);
+      pend_.live += 1;
+      graph_->note_label(label);
+      staged_adds_.fetch_add(1, std::memory_order_relaxed);
+      full = pend_.labels.size() >= opt_.get(kOptHnswStageMax);
+    }
+    // (the staging area is bounded: the writer that fills it links what is there -- the others wait on the index lock like
+    //  callers of one long add_batch)
+    return full ? drain_pending() : Status::Ok();
   }
 
   Status add_batch(const uint64_t *labels, const float *rows, uint64_t n) override {
+    VK_TRY(drain_pending());   // (order of effects = order of calls)
+    return add_batch_now(labels, rows, n, nullptr);
+  }
+
+  Status add_batch_now(const uint64_t *labels, const float *rows, uint64_t n, bool *on_device) {
+    if (on_device) *on_device = false;
     if (device_build_ && n >= kDeviceBuildMinBatch) {
       bool handled = false;
       Status s = add_batch_device(labels, rows, n, &handled);
+      if (on_device) *on_device = handled;
       if (handled || !s.ok()) return s;
     }
     return add_batch_host(labels, rows, n);
+  }
+
+  // link what the single adds staged (see add()); called without the index lock
+  Status drain_pending() {
+    std::vector<float> rows;
+    std::vector<uint64_t> labels;
+    {
+      std::lock_guard<std::mutex> pl(pend_.mu);
+      if (pend_.labels.empty()) return Status::Ok();
+      if (pend_.live == pend_.labels.size()) {
+        rows.swap(pend_.rows);
+        labels.swap(pend_.labels);
+      } else {   // some were removed again before they were linked
+        const uint32_t dim = params_.dim;
+        for (size_t i = 0; i < pend_.labels.size(); ++i) {
+          auto it = pend_.pos.find(pend_.labels[i]);
+          if (it == pend_.pos.end() || it->second != i) continue;
+          labels.push_back(pend_.labels[i]);
+          rows.insert(rows.end(), pend_.rows.begin() + i * dim, pend_.rows.begin() + (i + 1) * dim);
+        }
+        pend_.rows.clear();
+        pend_.labels.clear();
+      }
+      pend_.pos.clear();
+      pend_.live = 0;
+      draining_.store(labels.size(), std::memory_order_relaxed);
+    }
+    struct Done { std::atomic<uint64_t> &d; ~Done() { d.store(0, std::memory_order_relaxed); } } done{draining_};
+    if (labels.empty()) return Status::Ok();
+    bool on_device = false;
+    Status st = add_batch_now(labels.data(), rows.data(), labels.size(), &on_device);
+    if (st.ok() && on_device) staged_adds_device_.fetch_add(labels.size(), std::memory_order_relaxed);
+    return st;
   }
 
   Status add_batch_host(const uint64_t *labels, const float *rows, uint64_t n) {
@@ -114,6 +185,15 @@ class HnswIndex final : public Index {
 
   Status remove(uint64_t label) override {
     std::shared_lock<std::shared_mutex> lk(rw_);
+    {
+      std::lock_guard<std::mutex> pl(pend_.mu);
+      auto it = pend_.pos.find(label);
+      if (it != pend_.pos.end()) {   // staged and not linked yet: it never enters the graph
+        pend_.pos.erase(it);
+        pend_.live -= 1;
+        return Status::Ok();
+      }
+    }
     return graph_->mark_delete(label);
   }
 
@@ -128,6 +208,7 @@ class HnswIndex final : public Index {
   }
 
   Status flush() override {
+    VK_TRY(drain_pending());
     std::unique_lock<std::shared_mutex> lk(rw_);
     return flush_locked();
   }
@@ -155,60 +236,9 @@ class HnswIndex final : public Index {
     } else {
       VK_TRY(upload_allow(ctx, rq.allow_bits, rq.allow_nbits, &d_allow));
     }
-    // one filter per query: every distinct HOST bitmap goes to the device once, device-resident filters (filter_set.hpp) are
-    // pointed at where they lie; the kernel gets [nq] pointers and lengths
     const uint64_t *const *d_tab = nullptr;
     const uint64_t *d_tab_nbits = nullptr;
-    if (rq.allow_tab || rq.filter_tab) {
-      std::vector<const uint64_t *> uniq;
-      std::vector<uint64_t> uniq_bits, off;
-      size_t words = 0;
-      std::vector<uint32_t> which(rq.nq, ~0u);
-      std::vector<const uint64_t *> resident(rq.nq, nullptr);
-      bool any = false;
-      for (uint64_t q = 0; q < rq.nq; ++q) {
-        if (rq.filter_tab && rq.filter_tab[q]) {
-          resident[q] = rq.filter_tab[q]->bits_on(store_.device());
-          if (!resident[q]) return Status::Err(VK_ERR_INVALID, "the filter was not built for this index's device");
-          any = true;
-          continue;
-        }
-        if (!rq.allow_tab || !rq.allow_tab[q]) continue;
-        uint32_t u = 0;
-        for (; u < uniq.size(); ++u)
-          if (uniq[u] == rq.allow_tab[q] && uniq_bits[u] == rq.allow_nbits_tab[q]) break;
-        if (u == uniq.size()) {
-          uniq.push_back(rq.allow_tab[q]);
-          uniq_bits.push_back(rq.allow_nbits_tab[q]);
-          off.push_back(words);
-          words += (size_t)((rq.allow_nbits_tab[q] + 63) / 64) + 1;
-        }
-        which[q] = u;
-        any = true;
-      }
-      const size_t tab_bytes = rq.nq * 16;
-      VK_TRY(ctx->d_allow_tab.ensure(tab_bytes + words * 8 + 8));
-      VK_TRY(ctx->h_tmp.ensure(tab_bytes));
-      char *base = ctx->d_allow_tab.as<char>();
-      uint64_t *h = ctx->h_tmp.as<uint64_t>();
-      for (uint64_t q = 0; q < rq.nq; ++q) {
-        if (resident[q]) {
-          h[q] = reinterpret_cast<uint64_t>(resident[q]);
-          h[rq.nq + q] = rq.filter_tab[q]->nbits();
-        } else {
-          h[q] = which[q] == ~0u ? 0 : reinterpret_cast<uint64_t>(base + tab_bytes + off[which[q]] * 8);
-          h[rq.nq + q] = which[q] == ~0u ? 0 : rq.allow_nbits_tab[q];
-        }
-      }
-      VK_HIP_TRY(hipMemcpyAsync(base, h, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
-      for (size_t u = 0; u < uniq.size(); ++u) {
-        const size_t w = (size_t)((uniq_bits[u] + 63) / 64);
-        if (w) VK_HIP_TRY(hipMemcpyAsync(base + tab_bytes + off[u] * 8, uniq[u], w * 8, hipMemcpyHostToDevice, ctx->stream));
-      }
-      d_tab = reinterpret_cast<const uint64_t *const *>(base);
-      d_tab_nbits = reinterpret_cast<const uint64_t *>(base + rq.nq * 8);
-      if (!any) d_tab = nullptr;   // (every entry was "no filter")
-    }
+    VK_TRY(build_filter_table(ctx, rq, ctx->stream, &d_tab, &d_tab_nbits));
     tab_ = d_tab;
     tab_nbits_ = d_tab_nbits;
     // (launch() consumes and clears them; an early return before it must not leave this batch's table behind for the
@@ -283,8 +313,17 @@ class HnswIndex final : public Index {
                                   (size_t)params_.dim * 4, rq.nq, hipMemcpyDeviceToDevice, s));
       dq = ctx->d_q.as<float>();
     }
+    // (a sharded index hands its members' device-resident filters down: one per query, pointed at where they lie on THIS device)
+    if (rq.filter_tab) {
+      SearchRequest only = rq;
+      only.allow_tab = nullptr;   // (host bitmaps cannot come through a device-buffer call)
+      Status ft = build_filter_table(ctx, only, s, &tab_, &tab_nbits_);
+      if (!ft.ok()) { tab_ = nullptr; tab_nbits_ = nullptr; (void)ctx->end_async(s); return ft; }
+    }
     Status st = launch(ctx, dq, rq.nq, rq.k, rq.ef, rq.allow_bits, rq.allow_nbits, d_out_dist, d_out_label,
                        d_out_n, s, true, false, rq.cancel_word);
+    tab_ = nullptr;
+    tab_nbits_ = nullptr;
     Status en = ctx->end_async(s);
     return st.ok() ? en : st;
   }
@@ -333,6 +372,14 @@ class HnswIndex final : public Index {
 
   Status get_row(uint64_t label, float *out) override {
     std::shared_lock<std::shared_mutex> lk(rw_);
+    {
+      std::lock_guard<std::mutex> pl(pend_.mu);
+      auto it = pend_.pos.find(label);
+      if (it != pend_.pos.end()) {
+        memcpy(out, pend_.rows.data() + it->second * params_.dim, (size_t)params_.dim * 4);
+        return Status::Ok();
+      }
+    }
     uint32_t id;
     if (!graph_->lookup(label, &id)) return Status::Err(VK_ERR_NOT_FOUND, "label not found");
     memcpy(out, graph_->row(id), (size_t)params_.dim * 4);
@@ -342,6 +389,10 @@ class HnswIndex final : public Index {
   Status contains(uint64_t label, bool *found) override {
     std::shared_lock<std::shared_mutex> lk(rw_);   // (resize reallocates the tables under the unique lock)
     uint32_t id;
+    {
+      std::lock_guard<std::mutex> pl(pend_.mu);
+      if (pend_.pos.count(label)) { *found = true; return Status::Ok(); }
+    }
     *found = graph_->lookup(label, &id) && !graph_->is_deleted(id);
     return Status::Ok();
   }
@@ -349,12 +400,19 @@ class HnswIndex final : public Index {
   Status stats(vk_index_stats *out) override {
     std::shared_lock<std::shared_mutex> lk(rw_);
     memset(out, 0, sizeof(*out));
-    out->count = graph_->count();
+    size_t staged;
+    {
+      std::lock_guard<std::mutex> pl(pend_.mu);
+      staged = pend_.live;
+    }
+    out->count = graph_->count() + staged + draining_.load(std::memory_order_relaxed);
     out->deleted = graph_->deleted_count();
+    out->staged_adds = staged_adds_.load(std::memory_order_relaxed);
+    out->staged_adds_device = staged_adds_device_.load(std::memory_order_relaxed);
     out->capacity = graph_->max_elements();
     out->device_bytes = store_.device_bytes() + d_links0_.cap + d_upper_slot_.cap + d_upper_pool_.cap;
     out->host_bytes = store_.host_bytes() + graph_->host_bytes();
-    out->staged_ops = store_.staged_ops();
+    out->staged_ops = store_.staged_ops() + staged;
     out->max_level = graph_->max_level();
     out->entry_point = graph_->entry_point();
     out->last_n_eval = last_n_eval_;
@@ -367,6 +425,7 @@ class HnswIndex final : public Index {
     // (the reference adds the vector's bytes to reclaimable_memory at markDelete, hnswalg.h:1199)
     out->tombstoned_bytes = out->deleted * ((uint64_t)store_.row_bytes() + (uint64_t)(2 * params_.m + 1) * 4);
     out->max_label = graph_->max_label();
+    out->last_visited_mode = last_visited_mode_.load(std::memory_order_relaxed);
     return Status::Ok();
   }
 
@@ -403,6 +462,7 @@ class HnswIndex final : public Index {
   }
 
   Status flush_if_dirty() {
+    VK_TRY(drain_pending());
     {
       std::shared_lock<std::shared_mutex> lk(rw_);
       if (!store_.dirty() && !graph_->any_dirty()) return Status::Ok();
@@ -516,6 +576,65 @@ class HnswIndex final : public Index {
     d_idx.release();
     VK_HIP_TRY(hipStreamSynchronize(s));
     return st;
+  }
+
+  // One filter per query: every distinct HOST bitmap goes to the device once, device-resident filters (filter_set.hpp) are
+  // pointed at where they lie; the kernel gets [nq] pointers and lengths.  (The table is staged in a vector: a copy from
+  // pageable memory has consumed its source when the call returns, so this also serves search_device, which returns with
+  // its work in flight.)
+  Status build_filter_table(SearchCtx *ctx, const SearchRequest &rq, hipStream_t s, const uint64_t *const **d_tab_out,
+                            const uint64_t **d_nbits_out) {
+    *d_tab_out = nullptr;
+    *d_nbits_out = nullptr;
+    if (!rq.allow_tab && !rq.filter_tab) return Status::Ok();
+    std::vector<const uint64_t *> uniq;
+    std::vector<uint64_t> uniq_bits, off;
+    size_t words = 0;
+    std::vector<uint32_t> which(rq.nq, ~0u);
+    std::vector<const uint64_t *> resident(rq.nq, nullptr);
+    bool any = false;
+    for (uint64_t q = 0; q < rq.nq; ++q) {
+      if (rq.filter_tab && rq.filter_tab[q]) {
+        resident[q] = rq.filter_tab[q]->bits_on(store_.device());
+        if (!resident[q]) return Status::Err(VK_ERR_INVALID, "the filter was not built for this index's device");
+        any = true;
+        continue;
+      }
+      if (!rq.allow_tab || !rq.allow_tab[q]) continue;
+      uint32_t u = 0;
+      for (; u < uniq.size(); ++u)
+        if (uniq[u] == rq.allow_tab[q] && uniq_bits[u] == rq.allow_nbits_tab[q]) break;
+      if (u == uniq.size()) {
+        uniq.push_back(rq.allow_tab[q]);
+        uniq_bits.push_back(rq.allow_nbits_tab[q]);
+        off.push_back(words);
+        words += (size_t)((rq.allow_nbits_tab[q] + 63) / 64) + 1;
+      }
+      which[q] = u;
+      any = true;
+    }
+    if (!any) return Status::Ok();   // (every entry was "no filter")
+    const size_t tab_bytes = rq.nq * 16;
+    VK_TRY(ctx->d_allow_tab.ensure(tab_bytes + words * 8 + 8));
+    char *base = ctx->d_allow_tab.as<char>();
+    std::vector<uint64_t> h(2 * rq.nq);
+    for (uint64_t q = 0; q < rq.nq; ++q) {
+      if (resident[q]) {
+        h[q] = reinterpret_cast<uint64_t>(resident[q]);
+        h[rq.nq + q] = rq.filter_tab[q]->nbits();
+      } else {
+        h[q] = which[q] == ~0u ? 0 : reinterpret_cast<uint64_t>(base + tab_bytes + off[which[q]] * 8);
+        h[rq.nq + q] = which[q] == ~0u ? 0 : rq.allow_nbits_tab[q];
+      }
+    }
+    VK_HIP_TRY(hipMemcpyAsync(base, h.data(), tab_bytes, hipMemcpyHostToDevice, s));
+    for (size_t u = 0; u < uniq.size(); ++u) {
+      const size_t w = (size_t)((uniq_bits[u] + 63) / 64);
+      if (w) VK_HIP_TRY(hipMemcpyAsync(base + tab_bytes + off[u] * 8, uniq[u], w * 8, hipMemcpyHostToDevice, s));
+    }
+    *d_tab_out = reinterpret_cast<const uint64_t *const *>(base);
+    *d_nbits_out = reinterpret_cast<const uint64_t *>(base + rq.nq * 8);
+    return Status::Ok();
   }
 
   Status launch(SearchCtx *ctx, const float *d_q, uint64_t nq, uint64_t k, uint64_t ef_runtime, const uint64_t *d_allow,
@@ -681,6 +800,7 @@ class HnswIndex final : public Index {
       h.queue = a.queue;
       h.redo_out = ctx->d_redo.as<uint32_t>();
       VK_HIP_TRY(hipMemsetAsync(h.redo_out, 0, 4, s));
+      last_visited_mode_.store(h.vis_mode >= 3 ? h.vis_mode : (h.vis_mode == 2 ? 2 : 1), std::memory_order_relaxed);
       VK_HIP_TRY(launch_hnsw_search(h, l2(), store_.bf16(), e, (uint32_t)blocks_h, s));
       b.visited = a.visited;
       b.stats = a.stats;
@@ -690,6 +810,7 @@ class HnswIndex final : public Index {
       VK_HIP_TRY(launch_hnsw_search(b, l2(), store_.bf16(), e, (uint32_t)blocks2, s));
       return Status::Ok();
     }
+    last_visited_mode_.store(0, std::memory_order_relaxed);
     VK_HIP_TRY(launch_hnsw_search(a, l2(), store_.bf16(), e, (uint32_t)blocks, s));
     if (redo) {   // a few microseconds when the list is empty
       b.visited = a.visited;
@@ -978,6 +1099,19 @@ class HnswIndex final : public Index {
   OptRef visited_bytes_{&opt_, kOptHnswVisitedBytes};
   OptRef redo_bytes_{&opt_, kOptHnswRedoBytes};
   OptRef device_build_{&opt_, kOptHnswDeviceBuild};
+  // new labels staged by single add() calls, linked in bulk by drain_pending()
+  struct Pending {
+    std::mutex mu;
+    std::vector<float> rows;                       // [labels.size()][dim]
+    std::vector<uint64_t> labels;
+    std::unordered_map<uint64_t, size_t> pos;      // live staged labels -> their place
+    size_t live = 0;
+  } pend_;
+  std::atomic<uint64_t> draining_{0}, staged_adds_{0}, staged_adds_device_{0}, last_visited_mode_{0};
+  bool stage_candidate() const {
+    return opt_.get(kOptHnswStageAdds) != 0 && device_build_ != 0 && graph_->count() >= build_min_graph_ &&
+           !(params_.allow_replace_deleted && graph_->deleted_count() > 0) && graph_->ef_construction() <= 512 && graph_->maxM0() <= 192;
+  }
   RowStore store_;
   CtxPool pool_;
   std::unique_ptr<HnswGraph> graph_;
@@ -996,6 +1130,7 @@ thread_local const uint32_t *HnswIndex::cancel_q_ = nullptr;
 
 // ---- persistence: hnswalg.h:808-865 (SaveIndex), :887-1139 (LoadIndex + loadCheck) -----------------
 Status HnswIndex::save(vk_write_chunk_fn fn, void *user) {
+  VK_TRY(drain_pending());   // (staged rows are part of the index)
   std::shared_lock<std::shared_mutex> lk(rw_);
   const HnswGraph &g = *graph_;
   const size_t vec = (size_t)params_.dim * 4;

@@ -1013,7 +1013,7 @@ hipError_t hnsw_max_blocks(const HnswSearchArgs &a, bool l2, bool bf16, int e, i
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 48 * 1024) {
-    hipError_t er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t er = ensure_max_lds(f);
     if (er != hipSuccess) return er;
   }
   int per_cu = 0;
@@ -1032,7 +1032,7 @@ hipError_t launch_hnsw_search(const HnswSearchArgs &a, bool l2, bool bf16, int e
   if (!f || blocks == 0) return hipErrorInvalidValue;
   const size_t lds = hnsw_lds_bytes(a);
   if (lds > 48 * 1024) {
-    hipError_t er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t er = ensure_max_lds(f);
     if (er != hipSuccess) return er;
   }
   HnswSearchArgs args = a;

@@ -14,6 +14,12 @@
 
 namespace vk {
 
+// Dynamic LDS above the 64 KB default needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel function -- a property
+// of the FUNCTION (per device), not of a launch.  r04 set it per launch to that launch's size: two dispatcher runners serving
+// different (k, ef) lanes could interleave "set 80 KB / set 50 KB / launch 80 KB" and fail the launch.  It is
+// now raised ONCE per (function, device) to the whole 160 KB of a CU; what a launch may use is still what it asks for.
+hipError_t ensure_max_lds(const void *fn);
+
 // K3: FLAT scan over rows [row_begin,row_end) for nq queries.
 struct FlatScanArgs {
   const void *rows;           // [cap][row_stride_f] f32 or bf16 elements, zero padded to a multiple of 64 elements

@@ -25,7 +25,16 @@
 #include <thread>
 
 #include <dlfcn.h>
+// RCCL is loaded with dlopen on first use (option shard-gather = 1), so the library builds on a box without the RCCL headers
+// too: the handful of types and constants the gather needs are then declared here as the NCCL ABI fixes them (nccl.h:
+// ncclResult_t 0 = ncclSuccess; ncclDataType_t: ncclFloat32 = 7, ncclUint64 = 5; ncclComm_t an opaque pointer).
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint64 = 5, ncclFloat32 = 7 } ncclDataType_t;
+#endif
 
 #include "index.hpp"
 
@@ -419,7 +428,10 @@ class ShardedIndex final : public Index {
       g.query_tab = nullptr;
       return search(g, out_dist, out_label, out_n);
     }
-    if (rq.allow_tab || rq.filter_tab) return search_grouped_by_filter(this, rq, out_dist, out_label, out_n);
+    // one filter per query: host bitmaps (and FLAT, whose kernels take one bitmap per pass) are served in runs of queries
+    // that share a filter; device-resident filters of an HNSW index travel to the shards as they are, one launch per shard
+    const bool tab_to_shards = rq.filter_tab && !rq.allow_tab && params_.algo == VK_ALGO_HNSW && flat_scan_slots_per_lane(rq.k) != 0;
+    if ((rq.allow_tab || rq.filter_tab) && !tab_to_shards) return search_grouped_by_filter(this, rq, out_dist, out_label, out_n);
     if (rq.k == 0) {
       for (uint64_t q = 0; q < rq.nq; ++q) out_n[q] = 0;
       return Status::Ok();
@@ -756,7 +768,7 @@ class ShardedIndex final : public Index {
     VK_HIP_TRY(hipStreamWaitEvent(l.stream, mc->ready, 0));
     SearchRequest srq = rq;
     srq.cancel_flag = nullptr;
-    srq.filter = nullptr;
+    srq.filter = nullptr;          // (filter_tab stays: the shard points its table at the copies on its own device)
     srq.member_cancel = nullptr;
     if (rq.filter) {
       srq.allow_bits = rq.filter->bits_on(l.device);
