@@ -178,9 +178,9 @@ def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
         ms = timed(lambda: h.search_batch_device(Qh.data_ptr(), nq, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef_s,
                                                  stream=stream_ptr()), reps)
         gl = ol.cpu().numpy().view(np.uint64).copy()
+        vis_modes[ef_s] = int(h.stats().last_visited_mode)         # (of the launches just timed: a 1024-query call takes another kernel)
         _D, _L, _N = h.search_batch(hq[:1024], K, ef=ef_s)        # host path once: fills the work counters
         st = h.stats()
-        vis_modes[ef_s] = int(st.last_visited_mode)
         useful = (st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132) / 1024.0 * nq
         gbs = useful / (ms * 1e-3) / 1e9
         return gl, {"ef": ef_s, "gpu_qps": round(nq / (ms * 1e-3), 1), "ms_per_batch": round(ms, 3),
@@ -822,17 +822,24 @@ def sharded_hybrid_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows
     def timed_leg(fn, steps):
         fn()                                                                # warm-up (contexts, first-use allocations)
         t_filters[0], n_built[0] = 0.0, 0
+        st0 = h.stats()
+        totals[0] = (st0.total_n_eval, st0.total_n_hops)
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         dt = (time.perf_counter() - t0) / steps
         return dt, t_filters[0] / steps, n_built[0] / steps
 
-    def work(n_queries, dt_search):
+    totals = [None]
+
+    def work(n_queries, dt_search, steps_run):
+        """layer-0 work of the steps just timed, from the index's running totals (the shards' kernels add to them on the device)"""
         st = h.stats()
-        useful = st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132
+        ev, hp = st.total_n_eval - totals[0][0], st.total_n_hops - totals[0][1]
+        ev, hp = ev / steps_run, hp / steps_run
+        useful = ev * (D * 4 + 4) + hp * 132
         gbs = useful / dt_search / 1e9
-        return {"n_eval_per_query": round(st.last_n_eval / n_queries, 1), "n_hops_per_query": round(st.last_n_hops / n_queries, 1),
+        return {"n_eval_per_query": round(ev / n_queries, 1), "n_hops_per_query": round(hp / n_queries, 1),
                 "useful_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / (HBM_PEAK_GBS * len(set(devs))), 4)}
 
     legs = {}
@@ -842,7 +849,7 @@ def sharded_hybrid_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows
         legs[name] = {"queries": nq, "distinct_predicates": T, "gpu_qps": round(nq / dt, 1), "ms_per_step": round(dt * 1e3, 2),
                       "of_which_filters_ms": round(dt_f * 1e3, 2), "filters_built_per_step": built,
                       "ids_per_filter": int(np.mean([len(x) for x in tag_ids])), "recall_at_10": round(recall_of(L, gt, K), 4),
-                      **work(nq, dt - dt_f)}
+                      **work(nq, dt - dt_f, 2)}
     glw = last["out"][1].copy()
     # every query its own predicate: tag_a OR tag_b over cached terms, combined on the device inside the step
     nd = min(1024, nq)
@@ -870,7 +877,7 @@ def sharded_hybrid_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows
         rec_d = None
     legs["distinct_per_query"] = {"queries": nd, "distinct_predicates": len(uniq), "predicate": "tag_a OR tag_b, combined on the device from cached terms",
                                   "gpu_qps": round(nd / dt, 1), "ms_per_step": round(dt * 1e3, 2), "of_which_filters_ms": round(dt_f * 1e3, 2),
-                                  "filters_built_per_step": built, "recall_at_10": rec_d, **work(nd, dt - dt_f)}
+                                  "filters_built_per_step": built, "recall_at_10": rec_d, **work(nd, dt - dt_f, 2)}
     # the CPU oracle on the very same graphs with the very same bitmaps (a sample): ids, and its rate on the box's cores
     cpu = None
     try:

@@ -40,7 +40,6 @@
 #include <condition_variable>
 #include <cstring>
 #include <functional>
-#include <list>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -115,20 +114,28 @@ class VkFilterRef {
 // (cancel.cc: TimeoutPollFrequency).  While a request is registered here this thread is its only poller.
 class VkTokenWatch {
  public:
-  struct Entry {
-    cancel::Token token;
-    volatile int *word;                                                  // raised once, never lowered
-    std::optional<std::chrono::steady_clock::time_point> deadline;       // when known: the token is confirmed right there
-  };
-  using Handle = std::list<Entry>::iterator;
+  using Handle = uint32_t;   // a slot of the slab below
   static VkTokenWatch &Instance() {
     static VkTokenWatch *w = new VkTokenWatch();   // (never destroyed: requests may complete during static destruction)
     return *w;
   }
   Handle Register(cancel::Token token, volatile int *word, std::optional<std::chrono::steady_clock::time_point> deadline) {
     std::lock_guard<std::mutex> lk(mu_);
-    const bool was_idle = entries_.empty();
-    entries_.push_front(Entry{std::move(token), word, deadline});
+    Handle h;
+    if (!free_.empty()) {
+      h = free_.back();
+      free_.pop_back();
+    } else {
+      h = (Handle)slots_.size();
+      slots_.emplace_back();
+    }
+    Slot &e = slots_[h];
+    e.token = std::move(token);
+    e.word = word;
+    e.has_deadline = deadline.has_value();
+    if (deadline) e.deadline = *deadline;
+    e.live = true;
+    const bool was_idle = live_++ == 0;
     if (!started_) {
       started_ = true;
       std::thread([this] { Loop(); }).detach();
@@ -136,45 +143,65 @@ class VkTokenWatch {
     // (only out of the idle wait: a notify per registration made the watcher sweep -- under this mutex -- once per request,
     //  and 16 reader threads queued behind it: 13 k QPS where the library does 350 k)
     if (was_idle) cv_.notify_one();
-    return entries_.begin();
+    return h;
   }
   void Unregister(Handle h) {   // after this returns the watcher no longer touches the token or the word
     std::lock_guard<std::mutex> lk(mu_);
-    if (cursor_ == h) ++cursor_;
-    entries_.erase(h);
+    Slot &e = slots_[h];
+    e.live = false;
+    e.token.reset();
+    e.word = nullptr;
+    free_.push_back(h);
+    live_ -= 1;
   }
 
  private:
+  struct Slot {
+    cancel::Token token;
+    volatile int *word = nullptr;                                       // raised once, never lowered
+    std::chrono::steady_clock::time_point deadline{};                   // when known: the token is confirmed right there
+    bool has_deadline = false, live = false;
+  };
   static constexpr int kBurst = 128;            // > TimeoutPollFrequency: forces one look at the clock
-  static constexpr size_t kPerTick = 8192;      // tokens polled per 200 us tick (the rest next tick, round robin)
+  // A tick every 200 us looks at every request with a known deadline that has passed, and at 1/25 of the others (each token
+  // is polled about every 5 ms: its own cadence is one look at the clock per 100 polls anyway).  The slab is contiguous and
+  // the lock is dropped every 256 slots: with 32 768 requests in flight the registering threads still get through.
   void Loop() {
     std::unique_lock<std::mutex> lk(mu_);
+    size_t cursor = 0;
     for (;;) {
-      if (entries_.empty()) cv_.wait(lk, [&] { return !entries_.empty(); });
+      if (live_ == 0) cv_.wait(lk, [&] { return live_ != 0; });
       else cv_.wait_until(lk, next_tick_);
       const auto now = std::chrono::steady_clock::now();
-      if (now < next_tick_) continue;   // (woken early: the tick is kept, a sweep costs the registering threads the mutex)
+      if (now < next_tick_) continue;   // (woken early: the tick is kept)
       next_tick_ = now + std::chrono::microseconds(200);
-      size_t budget = std::min(kPerTick, entries_.size());
-      while (budget-- > 0 && !entries_.empty()) {
-        if (cursor_ == entries_.end()) cursor_ = entries_.begin();
-        Entry &e = *cursor_;
-        ++cursor_;
-        if (*e.word || !e.token) continue;
+      const size_t n = slots_.size();
+      size_t slow_budget = std::max<size_t>(64, n / 25);
+      for (size_t i = 0; i < n; ++i) {
+        if ((i & 255) == 255) { lk.unlock(); lk.lock(); if (slots_.size() < n) break; }
+        Slot &e = slots_[i];
+        if (!e.live || *e.word) continue;
         bool up = false;
-        if (e.deadline && now >= *e.deadline) {
-          for (int i = 0; i < kBurst && !up; ++i) up = e.token->IsCancelled();
+        if (e.has_deadline) {
+          if (now < e.deadline) continue;
+          for (int b = 0; b < kBurst && !up; ++b) up = e.token->IsCancelled();
         } else {
-          up = e.token->IsCancelled();           // one call per tick: the token's own cadence (and its gRPC context check)
+          // round robin over the tokens without a deadline
+          if (slow_budget == 0 || (i < cursor && cursor < n)) continue;
+          slow_budget -= 1;
+          cursor = i + 1;
+          up = e.token->IsCancelled();
         }
         if (up) __atomic_store_n(const_cast<int *>(e.word), 1, __ATOMIC_RELAXED);
       }
+      if (cursor >= n || slow_budget != 0) cursor = 0;
     }
   }
   std::mutex mu_;
   std::condition_variable cv_;
-  std::list<Entry> entries_;
-  Handle cursor_ = entries_.end();
+  std::vector<Slot> slots_;
+  std::vector<Handle> free_;
+  size_t live_ = 0;
   std::chrono::steady_clock::time_point next_tick_{};
   bool started_ = false;
 };

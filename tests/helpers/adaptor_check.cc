@@ -314,6 +314,23 @@ int main(int argc, char **argv) {
   auto hnsw = VectorGpuHNSW<float>::Create(proto, "v", data_model::ATTRIBUTE_DATA_TYPE_HASH, false, 1024);
   if (!hnsw.ok()) { printf("create failed: %s\n", hnsw.status().message().c_str()); return 1; }
   if (run(*hnsw.value(), "hnsw", x, q, n, dim, proto)) return 1;
+  {   // the token watcher: a token that goes up is relayed to its request's cancel word within a few ticks, with or without a
+      // known deadline; an unregistered request is left alone
+    volatile int w1 = 0, w2 = 0, w3 = 0;
+    auto t1 = std::make_shared<Token>(), t2 = std::make_shared<Token>(), t3 = std::make_shared<Token>();
+    auto &watch = VkTokenWatch::Instance();
+    auto h1 = watch.Register(t1, &w1, std::nullopt);
+    auto h2 = watch.Register(t2, &w2, std::chrono::steady_clock::now() + std::chrono::milliseconds(5));
+    auto h3 = watch.Register(t3, &w3, std::nullopt);
+    watch.Unregister(h3);
+    t1->Cancel(); t2->Cancel(); t3->Cancel();
+    const auto t0 = std::chrono::steady_clock::now();
+    while ((!w1 || !w2) && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(500)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    const long us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    watch.Unregister(h1);
+    watch.Unregister(h2);
+    printf("watch raised %d %d untouched %d within %s\n", (int)w1, (int)w2, (int)!w3, us < 100000 ? "100 ms" : "TOO LONG");
+  }
   printf("adaptor ok\n");
   return 0;
 }

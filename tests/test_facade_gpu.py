@@ -124,6 +124,8 @@ def test_vectorbase_adaptor_program_matches_oracle(oracle, tmp_path):
         # LoadFromRDB: the saved stream through the chunk iterator; same answer as the live index, vectors tracked again
         assert find(f"{name} loadrdb q0").split(" ", 3)[3] == find(f"{name} final q0").split(" ", 3)[3]
         assert find(f"{name} loadrdb count").split()[3:] == (["2999" if name == "flat" else "3000", "max_label", "2999", "GetValue(1)", "stored", "row"])
+    # the token watcher relays a raised token (with or without a known deadline) and leaves an unregistered request alone
+    assert find("watch raised") == "watch raised 1 1 untouched 1 within 100 ms"
 
 
 def test_adaptor_loads_hand_assembled_reference_streams(oracle, tmp_path):

@@ -51,8 +51,8 @@ HnswGraph::HnswGraph(uint32_t dim, bool l2, size_t max_elements, size_t M, size_
   maxM_ = M_;
   maxM0_ = M_ * 2;
   efC_ = std::max(ef_construction, M_);              // :146
-  level_generator_.seed(seed);                       // :149
-  update_probability_generator_.seed(seed + 1);
+  level_rng_.seed(seed);                             // :149
+  refresh_rng_.seed(seed + 1);
   mult_ = 1 / log(1.0 * M_);                         // :177
   alloc_tables(max_elements_, 0);
 }
@@ -93,419 +93,397 @@ Status HnswGraph::ensure_row_chunk(uint32_t id) {
   return Status::Ok();
 }
 
-std::unique_ptr<HnswGraph::VisitedList> HnswGraph::get_visited() {
+std::unique_ptr<HnswGraph::SeenStamps> HnswGraph::borrow_seen() {
   {
-    std::lock_guard<std::mutex> lk(visited_mu_);
-    if (!visited_pool_.empty()) {
-      auto v = std::move(visited_pool_.back());
-      visited_pool_.pop_back();
-      if (v->mass.size() >= max_elements_) return v;
+    std::lock_guard<std::mutex> lk(seen_mu_);
+    if (!seen_pool_.empty()) {
+      auto v = std::move(seen_pool_.back());
+      seen_pool_.pop_back();
+      if (v->stamp.size() >= max_elements_) return v;
     }
   }
-  return std::make_unique<VisitedList>(max_elements_ ? max_elements_ : 1);
+  return std::make_unique<SeenStamps>(max_elements_ ? max_elements_ : 1);
 }
-void HnswGraph::put_visited(std::unique_ptr<VisitedList> v) {
-  std::lock_guard<std::mutex> lk(visited_mu_);
-  visited_pool_.push_back(std::move(v));
-}
-
-int HnswGraph::random_level() {                        // :243-247
-  std::uniform_real_distribution<double> distribution(0.0, 1.0);
-  double r = -log(distribution(level_generator_)) * mult_;
-  return (int)r;
+void HnswGraph::return_seen(std::unique_ptr<SeenStamps> v) {
+  std::lock_guard<std::mutex> lk(seen_mu_);
+  seen_pool_.push_back(std::move(v));
 }
 
-Status HnswGraph::resize(size_t new_max) {             // :758-777
-  if (new_max < count_.load())
-    return Status::Err(kErrInternal, "Cannot resize, max element is less than the current number of elements");
+int HnswGraph::draw_level() {   // getRandomLevel: floor(-ln U * 1/ln M), U from the seeded engine
+  std::uniform_real_distribution<double> unit(0.0, 1.0);
+  return (int)(-log(unit(level_rng_)) * mult_);
+}
+
+Status HnswGraph::resize(size_t new_max) {
+  if (new_max < count_.load()) return Status::Err(kErrInternal, "resize below the number of elements held");
   alloc_tables(new_max, std::min(count_.load(), max_elements_));
   max_elements_ = new_max;
-  std::lock_guard<std::mutex> lk(visited_mu_);
-  visited_pool_.clear();
+  std::lock_guard<std::mutex> lk(seen_mu_);
+  seen_pool_.clear();
   return Status::Ok();
 }
 
-// ---- :255-347 --------------------------------------------------------------------------------
-HnswGraph::Heap HnswGraph::search_base_layer(uint32_t ep_id, const float *q, int layer) {
-  auto vl = get_visited();
-  uint16_t *visited = vl->mass.data();
-  const uint16_t tag = vl->next();
-  Heap top, cand;
-  float lowerBound;
-  if (!is_deleted(ep_id)) {
-    float d = dist(q, row(ep_id));
-    top.emplace(d, ep_id);
-    lowerBound = d;
-    cand.emplace(-d, ep_id);
-  } else {
-    lowerBound = std::numeric_limits<float>::max();
-    cand.emplace(-lowerBound, ep_id);
-  }
-  visited[ep_id] = tag;
-  std::vector<uint32_t> nbrs;
-  nbrs.reserve(maxM0_);
-  while (!cand.empty()) {
-    Pair cur = cand.top();
-    if ((-cur.first) > lowerBound && top.size() == efC_) break;
-    cand.pop();
-    const uint32_t cur_id = cur.second;
-    {
-      Spin lock(link_locks_[cur_id]);
-      const uint32_t *ll = list_at(cur_id, layer);
-      size_t size = list_count(ll);
-      nbrs.assign(ll + 1, ll + 1 + size);
-    }
-    for (uint32_t cid : nbrs) {
-      if (visited[cid] == tag) continue;
-      visited[cid] = tag;
-      float d1 = dist(q, row(cid));
-      if (top.size() < efC_ || lowerBound > d1) {
-        cand.emplace(-d1, cid);
-        if (!is_deleted(cid)) top.emplace(d1, cid);
-        if (top.size() > efC_) top.pop();
-        if (!top.empty()) lowerBound = top.top().first;
-      }
-    }
-  }
-  put_visited(std::move(vl));
-  return top;
-}
-
-// ---- :553-594 --------------------------------------------------------------------------------
-void HnswGraph::neighbors_by_heuristic2(Heap &top, size_t M) {
-  if (top.size() < M) return;
-  std::priority_queue<Pair> queue_closest;   // std::less<pair>: ties on distance order by id
-  std::vector<Pair> return_list;
-  while (!top.empty()) {
-    queue_closest.emplace(-top.top().first, top.top().second);
-    top.pop();
-  }
-  while (!queue_closest.empty()) {
-    if (return_list.size() >= M) break;
-    Pair cur = queue_closest.top();
-    float dist_to_query = -cur.first;
-    queue_closest.pop();
-    bool good = true;
-    for (const Pair &second : return_list) {
-      float curdist = dist(row(second.second), row(cur.second));
-      if (curdist < dist_to_query) { good = false; break; }
-    }
-    if (good) return_list.push_back(cur);
-  }
-  for (const Pair &p : return_list) top.emplace(-p.first, p.second);
-}
-
-// ---- :613-756 --------------------------------------------------------------------------------
-Status HnswGraph::mutually_connect(const float *q, uint32_t cur_c, Heap &top, int level, bool is_update, uint32_t *next) {
-  (void)q;
-  const size_t Mcurmax = level ? maxM_ : maxM0_;
-  neighbors_by_heuristic2(top, M_);
-  if (top.size() > M_) return Status::Err(kErrInternal, "Should be not be more than M_ candidates returned by the heuristic");
-  std::vector<uint32_t> sel;
-  sel.reserve(M_);
-  while (!top.empty()) { sel.push_back(top.top().second); top.pop(); }
-  if (sel.empty()) return Status::Err(kErrInternal, "During insertion, no neighbors found to mutually connect to");
-  *next = sel.back();
-  {
-    // the lock for cur_c is already held during an insert (:646-650)
-    std::unique_ptr<Spin> lock;
-    if (is_update) lock = std::make_unique<Spin>(link_locks_[cur_c]);
-    uint32_t *ll_cur = list_at(cur_c, level);
-    if (*ll_cur && !is_update) return Status::Err(kErrInternal, "The newly inserted element should have blank link list");
-    set_list_count(ll_cur, (unsigned)sel.size());
-    for (size_t i = 0; i < sel.size(); ++i) {
-      if (ll_cur[1 + i] && !is_update) return Status::Err(kErrInternal, "Possible memory corruption");
-      if (level > levels_[sel[i]]) return Status::Err(kErrInternal, "Trying to make a link on a non-existent level");
-      ll_cur[1 + i] = sel[i];
-    }
-    mark(cur_c, level);
-  }
-  for (size_t i = 0; i < sel.size(); ++i) {
-    const uint32_t nb = sel[i];
-    Spin lock(link_locks_[nb]);
-    uint32_t *ll_other = list_at(nb, level);
-    const size_t sz = list_count(ll_other);
-    if (sz > Mcurmax) return Status::Err(kErrInternal, "Bad value of sz_link_list_other");
-    if (nb == cur_c) return Status::Err(kErrInternal, "Trying to connect an element to itself");
-    if (level > levels_[nb]) return Status::Err(kErrInternal, "Trying to make a link on a non-existent level");
-    uint32_t *data = ll_other + 1;
-    bool present = false;
-    if (is_update)
-      for (size_t j = 0; j < sz; ++j)
-        if (data[j] == cur_c) { present = true; break; }
-    if (present) continue;
-    if (sz < Mcurmax) {
-      data[sz] = cur_c;
-      set_list_count(ll_other, (unsigned)(sz + 1));
-    } else {
-      float d_max = dist(row(cur_c), row(nb));
-      Heap cands;
-      cands.emplace(d_max, cur_c);
-      for (size_t j = 0; j < sz; ++j) cands.emplace(dist(row(data[j]), row(nb)), data[j]);
-      neighbors_by_heuristic2(cands, Mcurmax);
-      unsigned indx = 0;
-      while (!cands.empty()) { data[indx++] = cands.top().second; cands.pop(); }
-      set_list_count(ll_other, indx);
-    }
-    mark(nb, level);
-  }
-  return Status::Ok();
-}
-
-Status HnswGraph::mark_deleted_internal(uint32_t id) {   // :1194-1209
-  if (is_deleted(id)) return Status::Err(kErrInternal, "The requested to delete element is already deleted");
-  __atomic_fetch_or(links0_mut(id), kDeleteFlag, __ATOMIC_RELAXED);   // (see set_list_count)
-  num_deleted_ += 1;
-  mark(id, 0);
-  if (allow_replace_deleted_) {
-    std::lock_guard<std::mutex> lk(deleted_lock_);
-    deleted_elements_.insert(id);
-  }
-  return Status::Ok();
-}
-
-Status HnswGraph::unmark_deleted_internal(uint32_t id) { // :1236-1251
-  if (!is_deleted(id)) return Status::Err(kErrInternal, "The requested to undelete element is not deleted");
-  __atomic_fetch_and(links0_mut(id), ~kDeleteFlag, __ATOMIC_RELAXED);
-  num_deleted_ -= 1;
-  mark(id, 0);
-  if (allow_replace_deleted_) {
-    std::lock_guard<std::mutex> lk(deleted_lock_);
-    deleted_elements_.erase(id);
-  }
-  return Status::Ok();
-}
-
-Status HnswGraph::mark_delete(uint64_t label) {          // :1173-1187
-  std::lock_guard<std::mutex> lock_label(label_op_locks_[label & (kLabelLocks - 1)]);
-  uint32_t id;
-  if (!lookup(label, &id)) return Status::Err(kErrNotFound, "Label not found");
-  return mark_deleted_internal(id);
-}
-
-std::vector<uint32_t> HnswGraph::connections_with_lock(uint32_t id, int level) {
-  Spin lock(link_locks_[id]);
+std::vector<uint32_t> HnswGraph::snapshot_list(uint32_t id, int level) {
+  Spin hold(link_locks_[id]);
   const uint32_t *ll = list_at(id, level);
   return std::vector<uint32_t>(ll + 1, ll + 1 + list_count(ll));
 }
 
-// ---- :1342-1430 ------------------------------------------------------------------------------
-Status HnswGraph::update_point(const float *new_row, uint32_t id, float prob) {
+// ---- the building blocks -----------------------------------------------------------------------------------------------
+// Everything below works on NearList = a vector of (distance, id) kept NEAREST FIRST under the total order `nearer`
+// (distance, then id).  hnswlib moves the same sets between std::priority_queues that compare the distance alone
+// (hnswalg.h:202-208), so what it does with equal distances is whatever libstdc++'s heap does; on data without ties the two
+// produce the same graph link for link (tests/test_host_graph.py compares with the oracle, which does use that heap).  What
+// IS shared with the reference is the stored layout -- a node's list holds its neighbours FARTHEST first, because that is
+// the order its heap pops them in and the list order decides the order a search looks at them -- and the on-disk format.
+
+// Beam search over one layer (the role of searchBaseLayer, hnswalg.h:255-347): the ef_construction nearest LIVE nodes
+// reachable from `entry`, nearest first.  `open` = reached and not expanded yet (a min-heap), `best` = the survivors (a
+// max-heap, worst on top); a node is expanded while it can still improve the worst survivor.  Tombstoned nodes are walked
+// through but do not survive.
+HnswGraph::NearList HnswGraph::beam_search(uint32_t entry, const float *q, int layer) {
+  auto seen = borrow_seen();
+  uint16_t *stamp = seen->stamp.data();
+  const uint16_t epoch = seen->advance();
+  const auto worst_on_top = [](const Near &a, const Near &b) { return nearer(a, b); };
+  const auto nearest_on_top = [](const Near &a, const Near &b) { return nearer(b, a); };
+  NearList best, open;
+  best.reserve(efC_ + 1);
+  float reach;   // distance of the worst survivor once the beam is full
+  if (!is_deleted(entry)) {
+    const float d = dist(q, row(entry));
+    best.push_back(Near{d, entry});
+    open.push_back(Near{d, entry});
+    reach = d;
+  } else {
+    reach = std::numeric_limits<float>::max();
+    open.push_back(Near{reach, entry});
+  }
+  stamp[entry] = epoch;
+  std::vector<uint32_t> adj;
+  adj.reserve(maxM0_);
+  while (!open.empty()) {
+    const Near cur = open.front();
+    if (cur.d > reach && best.size() == efC_) break;
+    std::pop_heap(open.begin(), open.end(), nearest_on_top);
+    open.pop_back();
+    {
+      Spin hold(link_locks_[cur.id]);
+      const uint32_t *ll = list_at(cur.id, layer);
+      adj.assign(ll + 1, ll + 1 + list_count(ll));
+    }
+    for (const uint32_t nb : adj) {
+      if (stamp[nb] == epoch) continue;
+      stamp[nb] = epoch;
+      const float d = dist(q, row(nb));
+      if (best.size() >= efC_ && !(reach > d)) continue;
+      open.push_back(Near{d, nb});
+      std::push_heap(open.begin(), open.end(), nearest_on_top);
+      if (!is_deleted(nb)) {
+        best.push_back(Near{d, nb});
+        std::push_heap(best.begin(), best.end(), worst_on_top);
+      }
+      if (best.size() > efC_) {
+        std::pop_heap(best.begin(), best.end(), worst_on_top);
+        best.pop_back();
+      }
+      if (!best.empty()) reach = best.front().d;
+    }
+  }
+  return_seen(std::move(seen));
+  std::sort(best.begin(), best.end(), nearer);
+  return best;
+}
+
+// Neighbour selection (the heuristic of the HNSW paper, getNeighborsByHeuristic2 hnswalg.h:553-594): walk the candidates
+// nearest first and keep one only if it is nearer to the base point than to every candidate already kept -- a candidate
+// that sits "behind" a kept one is reachable through it.  Fewer candidates than `keep`: all stay.
+void HnswGraph::keep_diverse(NearList &cands, size_t keep) const {
+  if (cands.size() < keep) return;
+  NearList kept;
+  kept.reserve(keep);
+  for (const Near &c : cands) {
+    if (kept.size() >= keep) break;
+    bool shadowed = false;
+    for (const Near &k : kept)
+      if (dist(row(k.id), row(c.id)) < c.d) { shadowed = true; break; }
+    if (!shadowed) kept.push_back(c);
+  }
+  cands.swap(kept);
+}
+
+void HnswGraph::store_list(uint32_t *list, const NearList &nearest_first) {
+  const size_t n = nearest_first.size();
+  set_list_count(list, (unsigned)n);
+  for (size_t i = 0; i < n; ++i) list[1 + i] = nearest_first[n - 1 - i].id;   // farthest first (see above)
+}
+
+// Give `node` its list on `layer` from the beam's survivors and link it into each chosen neighbour's list, re-selecting a
+// neighbour's list that is full (mutuallyConnectNewElement, hnswalg.h:613-756).  rewire = the node already has lists (an
+// updated point being re-attached): its own lock is not held by the caller and back-links may exist already.
+// *closest = the nearest chosen neighbour: where the next layer down starts.
+Status HnswGraph::wire(uint32_t node, int layer, NearList &cands, bool rewire, uint32_t *closest) {
+  const size_t cap = layer ? maxM_ : maxM0_;
+  keep_diverse(cands, M_);
+  if (cands.size() > M_) return Status::Err(kErrInternal, "neighbour selection kept more than M");
+  if (cands.empty()) return Status::Err(kErrInternal, "insert found nothing to link to");
+  *closest = cands.front().id;
+  for (const Near &c : cands)
+    if (layer > levels_[c.id]) return Status::Err(kErrInternal, "link to a layer its target does not have");
+  {
+    std::unique_ptr<Spin> hold;   // (a fresh insert holds its node's lock for its whole duration)
+    if (rewire) hold = std::make_unique<Spin>(link_locks_[node]);
+    uint32_t *mine = list_at(node, layer);
+    if (!rewire && list_count(mine)) return Status::Err(kErrInternal, "a new node already has links");
+    store_list(mine, cands);
+    mark(node, layer);
+  }
+  NearList pool;
+  for (size_t i = cands.size(); i-- > 0;) {   // (farthest first, the order they were stored in)
+    const uint32_t nb = cands[i].id;
+    if (nb == node) return Status::Err(kErrInternal, "a node cannot link to itself");
+    Spin hold(link_locks_[nb]);
+    uint32_t *theirs = list_at(nb, layer);
+    const size_t have = list_count(theirs);
+    if (have > cap) return Status::Err(kErrInternal, "a link list is longer than its layer allows");
+    if (rewire && std::find(theirs + 1, theirs + 1 + have, node) != theirs + 1 + have) continue;
+    if (have < cap) {
+      theirs[1 + have] = node;
+      set_list_count(theirs, (unsigned)(have + 1));
+    } else {   // full: the neighbour keeps the diverse subset of its list plus the newcomer, seen from itself
+      const float *base = row(nb);
+      pool.clear();
+      pool.push_back(Near{dist(row(node), base), node});
+      for (size_t j = 0; j < have; ++j) pool.push_back(Near{dist(row(theirs[1 + j]), base), theirs[1 + j]});
+      std::sort(pool.begin(), pool.end(), nearer);
+      keep_diverse(pool, cap);
+      store_list(theirs, pool);
+    }
+    mark(nb, layer);
+  }
+  return Status::Ok();
+}
+
+// Greedy walk on the sparse upper layers: from `from` on layer `top` down to (not including) `stop`, moving to any
+// neighbour strictly nearer to q until none is (hnswalg.h:1593-1618 and its two other copies)
+uint32_t HnswGraph::descend(const float *q, uint32_t from, int top, int stop) {
+  uint32_t at = from;
+  float nearest = dist(q, row(at));
+  for (int layer = top; layer > stop; --layer) {
+    for (bool moved = true; moved;) {
+      moved = false;
+      for (const uint32_t nb : snapshot_list(at, layer)) {
+        const float d = dist(q, row(nb));
+        if (d < nearest) { nearest = d; at = nb; moved = true; }
+      }
+    }
+  }
+  return at;
+}
+
+// Link `node` on layers first .. last (downwards), each layer's beam starting at the nearest neighbour chosen one layer up.
+// A tombstoned entry point is offered as a candidate too (it is walked through but never survives the beam, and the graph
+// above may hang on it: hnswalg.h:1624-1634).
+Status HnswGraph::link_layers(uint32_t node, const float *q, uint32_t start, int first, int last, uint32_t entry, bool rewire) {
+  const bool entry_dead = is_deleted(entry);
+  uint32_t at = start;
+  for (int layer = first; layer >= last; --layer) {
+    NearList found = beam_search(at, q, layer);
+    if (rewire) {
+      found.erase(std::remove_if(found.begin(), found.end(), [&](const Near &n) { return n.id == node; }), found.end());
+      if (found.empty()) continue;
+    }
+    if (entry_dead) {
+      const Near e{dist(q, row(entry)), entry};
+      found.insert(std::upper_bound(found.begin(), found.end(), e, nearer), e);
+      if (found.size() > efC_) found.pop_back();
+    }
+    VK_TRY(wire(node, layer, found, rewire, &at));
+  }
+  return Status::Ok();
+}
+
+Status HnswGraph::set_tombstone(uint32_t id) {   // markDeletedInternal
+  if (is_deleted(id)) return Status::Err(kErrInternal, "the element is deleted already");
+  __atomic_fetch_or(links0_mut(id), kDeleteFlag, __ATOMIC_RELAXED);   // (see set_list_count)
+  num_deleted_ += 1;
+  mark(id, 0);
+  if (allow_replace_deleted_) {
+    std::lock_guard<std::mutex> lk(vacant_mu_);
+    vacant_.insert(id);
+  }
+  return Status::Ok();
+}
+
+Status HnswGraph::clear_tombstone(uint32_t id) {   // unmarkDeletedInternal
+  if (!is_deleted(id)) return Status::Err(kErrInternal, "the element is not deleted");
+  __atomic_fetch_and(links0_mut(id), ~kDeleteFlag, __ATOMIC_RELAXED);
+  num_deleted_ -= 1;
+  mark(id, 0);
+  if (allow_replace_deleted_) {
+    std::lock_guard<std::mutex> lk(vacant_mu_);
+    vacant_.erase(id);
+  }
+  return Status::Ok();
+}
+
+Status HnswGraph::mark_delete(uint64_t label) {   // markDelete, hnswalg.h:1173-1187
+  std::lock_guard<std::mutex> one_op_per_label(label_op_locks_[label & (kLabelLocks - 1)]);
+  uint32_t id;
+  if (!lookup(label, &id)) return Status::Err(kErrNotFound, "Label not found");
+  return set_tombstone(id);
+}
+
+// A point whose vector changed (updatePoint, hnswalg.h:1342-1430, + repairConnectionsForUpdate :1432-1511).  Per layer:
+// the lists of (a `share` of) the node's neighbours are re-selected from the node's two-hop neighbourhood -- the node
+// moved, so links that went through it may no longer be the diverse ones -- and then the node itself is searched for from
+// the top and re-attached like a new point.
+Status HnswGraph::refresh(const float *new_row, uint32_t id, float share) {
   memcpy(row_mut(id), new_row, dim_ * sizeof(float));
-  const int maxLevelCopy = maxlevel_;
-  const uint32_t entryPointCopy = enterpoint_;
-  if (entryPointCopy == id && count_.load() == 1) return Status::Ok();
-  const int elemLevel = levels_[id];
-  std::uniform_real_distribution<float> distribution(0.0, 1.0);
-  for (int layer = 0; layer <= elemLevel; layer++) {
-    std::unordered_set<uint32_t> sCand, sNeigh;
-    std::vector<uint32_t> listOneHop = connections_with_lock(id, layer);
-    if (listOneHop.empty()) continue;
-    sCand.insert(id);
-    for (uint32_t elOneHop : listOneHop) {
-      sCand.insert(elOneHop);
+  const int top = maxlevel_;
+  const uint32_t entry = enterpoint_;
+  if (entry == id && count_.load() == 1) return Status::Ok();
+  const int node_top = levels_[id];
+  std::uniform_real_distribution<float> unit(0.0, 1.0);
+  std::vector<uint32_t> around, redo;
+  NearList pool;
+  for (int layer = 0; layer <= node_top; ++layer) {
+    const std::vector<uint32_t> ring = snapshot_list(id, layer);
+    if (ring.empty()) continue;
+    around.assign(1, id);
+    redo.clear();
+    for (const uint32_t nb : ring) {
+      around.push_back(nb);
       float u;
       {
         std::lock_guard<std::mutex> lk(rng_mu_);
-        u = distribution(update_probability_generator_);
+        u = unit(refresh_rng_);     // (one draw per neighbour, in list order: the sequence is part of the build's determinism)
       }
-      if (u > prob) continue;
-      sNeigh.insert(elOneHop);
-      for (uint32_t elTwoHop : connections_with_lock(elOneHop, layer)) sCand.insert(elTwoHop);
+      if (u > share) continue;
+      redo.push_back(nb);
+      const std::vector<uint32_t> second = snapshot_list(nb, layer);
+      around.insert(around.end(), second.begin(), second.end());
     }
-    for (uint32_t neigh : sNeigh) {
-      Heap candidates;
-      const size_t size = sCand.find(neigh) == sCand.end() ? sCand.size() : sCand.size() - 1;
-      const size_t elementsToKeep = std::min(efC_, size);
-      for (uint32_t cand : sCand) {
-        if (cand == neigh) continue;
-        float distance = dist(row(neigh), row(cand));
-        if (candidates.size() < elementsToKeep) {
-          candidates.emplace(distance, cand);
-        } else if (!candidates.empty() && distance < candidates.top().first) {
-          candidates.pop();
-          candidates.emplace(distance, cand);
-        }
-      }
-      neighbors_by_heuristic2(candidates, layer == 0 ? maxM0_ : maxM_);
-      {
-        Spin lock(link_locks_[neigh]);
-        uint32_t *ll_cur = list_at(neigh, layer);
-        const size_t candSize = candidates.size();
-        set_list_count(ll_cur, (unsigned)candSize);
-        for (size_t idx = 0; idx < candSize; idx++) { ll_cur[1 + idx] = candidates.top().second; candidates.pop(); }
-        mark(neigh, layer);
-      }
+    std::sort(around.begin(), around.end());
+    around.erase(std::unique(around.begin(), around.end()), around.end());
+    std::sort(redo.begin(), redo.end());
+    redo.erase(std::unique(redo.begin(), redo.end()), redo.end());
+    for (const uint32_t nb : redo) {
+      const float *base = row(nb);
+      pool.clear();
+      for (const uint32_t c : around)
+        if (c != nb) pool.push_back(Near{dist(base, row(c)), c});
+      std::sort(pool.begin(), pool.end(), nearer);
+      if (pool.size() > efC_) pool.resize(efC_);
+      keep_diverse(pool, layer == 0 ? maxM0_ : maxM_);
+      Spin hold(link_locks_[nb]);
+      store_list(list_at(nb, layer), pool);
+      mark(nb, layer);
     }
   }
-  return repair_connections(row(id), entryPointCopy, id, elemLevel, maxLevelCopy);
+  // ... and the node itself
+  const float *q = row(id);
+  if (node_top > top) return Status::Err(kErrInternal, "an element's level is above the graph's");
+  const uint32_t start = node_top < top ? descend(q, entry, top, node_top) : entry;
+  return link_layers(id, q, start, node_top, 0, entry, /*rewire=*/true);
 }
 
-// ---- :1432-1511 ------------------------------------------------------------------------------
-Status HnswGraph::repair_connections(const float *q, uint32_t ep, uint32_t id, int dataPointLevel, int maxLevel) {
-  uint32_t currObj = ep;
-  if (dataPointLevel < maxLevel) {
-    float curdist = dist(q, row(currObj));
-    for (int level = maxLevel; level > dataPointLevel; level--) {
-      bool changed = true;
-      while (changed) {
-        changed = false;
-        std::vector<uint32_t> nb = connections_with_lock(currObj, level);
-        for (uint32_t cand : nb) {
-          float d = dist(q, row(cand));
-          if (d < curdist) { curdist = d; currObj = cand; changed = true; }
-        }
-      }
-    }
-  }
-  if (dataPointLevel > maxLevel) return Status::Err(kErrInternal, "Level of item to be updated cannot be bigger than max level");
-  for (int level = dataPointLevel; level >= 0; level--) {
-    Heap topCandidates = search_base_layer(currObj, q, level);
-    Heap filtered;
-    while (!topCandidates.empty()) {
-      if (topCandidates.top().second != id) filtered.push(topCandidates.top());
-      topCandidates.pop();
-    }
-    if (!filtered.empty()) {
-      if (is_deleted(ep)) {
-        filtered.emplace(dist(q, row(ep)), ep);
-        if (filtered.size() > efC_) filtered.pop();
-      }
-      VK_TRY(mutually_connect(q, id, filtered, level, true, &currObj));
-    }
-  }
-  return Status::Ok();
-}
-
-// ---- :1523-1650 ------------------------------------------------------------------------------
-Status HnswGraph::add_point_level(const float *new_row, uint64_t label, int level_in, uint32_t *out_id) {
-  uint32_t cur_c = 0;
+// A new point, or the same label again (addPoint(data, label, level), hnswalg.h:1523-1650)
+Status HnswGraph::insert(const float *new_row, uint64_t label, uint32_t *out_id) {
+  uint32_t node = 0;
   {
-    std::unique_lock<std::mutex> lock_table(label_lookup_lock_);
-    auto search = label_lookup_.find(label);
-    if (search != label_lookup_.end()) {
-      const uint32_t existing = search->second;
+    std::unique_lock<std::mutex> table(label_lookup_lock_);
+    auto known = label_lookup_.find(label);
+    if (known != label_lookup_.end()) {   // the label exists: an in-place update
+      const uint32_t existing = known->second;
       if (allow_replace_deleted_ && is_deleted(existing))
-        return Status::Err(kErrInternal,
-                           "Can't use addPoint to update deleted elements if replacement of deleted elements is enabled.");
-      lock_table.unlock();
-      if (is_deleted(existing)) VK_TRY(unmark_deleted_internal(existing));
+        return Status::Err(kErrInternal, "a deleted element cannot be updated in place while deleted slots are being reused");
+      table.unlock();
+      if (is_deleted(existing)) VK_TRY(clear_tombstone(existing));
       *out_id = existing;
-      return update_point(new_row, existing, 1.0f);
+      return refresh(new_row, existing, 1.0f);
     }
     if (count_.load() >= max_elements_)
-      return Status::Err(kErrCapacity, "The number of elements exceeds the specified limit");
-    cur_c = (uint32_t)count_.load();
-    VK_TRY(ensure_row_chunk(cur_c));
-    // initialise the slot before it becomes visible through count_ / label_lookup_
-    memset(links0_mut(cur_c), 0, (maxM0_ + 1) * sizeof(uint32_t));
-    labels_[cur_c] = label;
-    memcpy(row_mut(cur_c), new_row, dim_ * sizeof(float));
+      return Status::Err(kErrCapacity, "The number of elements exceeds the specified limit");   // (the text callers match: vk_index.h)
+    node = (uint32_t)count_.load();
+    VK_TRY(ensure_row_chunk(node));
+    // the slot is complete before count_ / the label map make it reachable
+    memset(links0_mut(node), 0, (maxM0_ + 1) * sizeof(uint32_t));
+    labels_[node] = label;
+    memcpy(row_mut(node), new_row, dim_ * sizeof(float));
     count_.fetch_add(1, std::memory_order_release);
-    label_lookup_[label] = cur_c;
+    label_lookup_[label] = node;
     note_label(label);
   }
-  *out_id = cur_c;
+  *out_id = node;
 
-  std::unique_lock<std::mutex> templock(global_);
-  const int maxlevelcopy = maxlevel_;
-  Spin lock_el(link_locks_[cur_c]);
-  int curlevel = random_level();
-  if (level_in > 0) curlevel = level_in;
-  if (curlevel <= maxlevelcopy) templock.unlock();
-  levels_[cur_c] = curlevel;
-  uint32_t currObj = enterpoint_;
-  const uint32_t enterpoint_copy = enterpoint_;
-
-  delete[] upper_[cur_c];
-  upper_[cur_c] = nullptr;
-  if (curlevel) {
-    upper_[cur_c] = new uint32_t[(size_t)curlevel * (maxM_ + 1)]();
-    upper_slot_[cur_c] = upper_slots_used_.fetch_add((uint32_t)curlevel);
+  // an insert that raises the graph's top level keeps every other insert out until it is done
+  std::unique_lock<std::mutex> raising(global_);
+  const int top = maxlevel_;
+  Spin mine(link_locks_[node]);
+  const int node_top = draw_level();
+  if (node_top <= top) raising.unlock();
+  levels_[node] = node_top;
+  const uint32_t entry = enterpoint_;
+  delete[] upper_[node];
+  upper_[node] = nullptr;
+  if (node_top) {
+    upper_[node] = new uint32_t[(size_t)node_top * (maxM_ + 1)]();
+    upper_slot_[node] = upper_slots_used_.fetch_add((uint32_t)node_top);
+    mark(node, 1);
   }
-  mark(cur_c, 0);
-  if (curlevel) mark(cur_c, 1);
-
-  if (currObj != kNone) {
-    if (curlevel < maxlevelcopy) {
-      float curdist = dist(new_row, row(currObj));
-      for (int level = maxlevelcopy; level > curlevel; level--) {
-        bool changed = true;
-        while (changed) {
-          changed = false;
-          Spin lock(link_locks_[currObj]);
-          const uint32_t *ll = upper(currObj, level);
-          const int size = (int)list_count(ll);
-          for (int i = 0; i < size; i++) {
-            const uint32_t cand = ll[1 + i];
-            if (cand > max_elements_) return Status::Err(kErrInternal, "cand error");
-            float d = dist(new_row, row(cand));
-            if (d < curdist) { curdist = d; currObj = cand; changed = true; }
-          }
-        }
-      }
-    }
-    const bool epDeleted = is_deleted(enterpoint_copy);
-    for (int level = std::min(curlevel, maxlevelcopy); level >= 0; level--) {
-      Heap top = search_base_layer(currObj, new_row, level);
-      if (epDeleted) {
-        top.emplace(dist(new_row, row(enterpoint_copy)), enterpoint_copy);
-        if (top.size() > efC_) top.pop();
-      }
-      VK_TRY(mutually_connect(new_row, cur_c, top, level, false, &currObj));
-    }
-  } else {
+  mark(node, 0);
+  if (entry == kNone) {   // the first point
     enterpoint_ = 0;
-    maxlevel_ = curlevel;
+    maxlevel_ = node_top;
+  } else {
+    const uint32_t start = node_top < top ? descend(new_row, entry, top, node_top) : entry;
+    VK_TRY(link_layers(node, new_row, start, std::min(node_top, top), 0, entry, /*rewire=*/false));
   }
-  if (curlevel > maxlevelcopy) {
-    enterpoint_ = cur_c;
-    maxlevel_ = curlevel;
+  if (node_top > top) {
+    enterpoint_ = node;
+    maxlevel_ = node_top;
   }
   return Status::Ok();
 }
 
-// ---- :1278-1340 ------------------------------------------------------------------------------
+// addPoint(data, label, replace_deleted) hnswalg.h:1278-1340: with reuse of deleted slots switched on, a new label takes
+// over a tombstoned slot (and is then linked like an update of it)
 Status HnswGraph::add(const float *new_row, uint64_t label, uint32_t *out_id) {
-  std::lock_guard<std::mutex> lock_label(label_op_locks_[label & (kLabelLocks - 1)]);
-  if (!allow_replace_deleted_) return add_point_level(new_row, label, -1, out_id);
-  {
-    uint32_t existing;
-    if (lookup(label, &existing)) {
-      if (is_deleted(existing)) {
-        {
-          std::lock_guard<std::mutex> lk(deleted_lock_);
-          deleted_elements_.erase(existing);
-        }
-        VK_TRY(unmark_deleted_internal(existing));
+  std::lock_guard<std::mutex> one_op_per_label(label_op_locks_[label & (kLabelLocks - 1)]);
+  if (!allow_replace_deleted_) return insert(new_row, label, out_id);
+  uint32_t existing;
+  if (lookup(label, &existing)) {
+    if (is_deleted(existing)) {
+      {
+        std::lock_guard<std::mutex> lk(vacant_mu_);
+        vacant_.erase(existing);
       }
-      *out_id = existing;
-      return update_point(new_row, existing, 1.0f);
+      VK_TRY(clear_tombstone(existing));
     }
+    *out_id = existing;
+    return refresh(new_row, existing, 1.0f);
   }
-  uint32_t replaced = 0;
-  bool vacant = false;
+  uint32_t slot = kNone;
   {
-    std::lock_guard<std::mutex> lk(deleted_lock_);
-    if (!deleted_elements_.empty()) {
-      auto it = deleted_elements_.begin();
-      replaced = *it;
-      deleted_elements_.erase(it);
-      vacant = true;
+    std::lock_guard<std::mutex> lk(vacant_mu_);
+    if (!vacant_.empty()) {
+      slot = *vacant_.begin();
+      vacant_.erase(vacant_.begin());
     }
   }
-  if (!vacant) return add_point_level(new_row, label, -1, out_id);
-  const uint64_t label_replaced = labels_[replaced];
-  labels_[replaced] = label;
+  if (slot == kNone) return insert(new_row, label, out_id);
+  const uint64_t old_label = labels_[slot];
+  labels_[slot] = label;
   {
     std::lock_guard<std::mutex> lk(label_lookup_lock_);
-    label_lookup_.erase(label_replaced);
-    label_lookup_[label] = replaced;
+    label_lookup_.erase(old_label);
+    label_lookup_[label] = slot;
     note_label(label);
   }
-  VK_TRY(unmark_deleted_internal(replaced));
-  *out_id = replaced;
-  return update_point(new_row, replaced, 1.0f);
+  VK_TRY(clear_tombstone(slot));
+  *out_id = slot;
+  return refresh(new_row, slot, 1.0f);
 }
 
 // ---- device-assisted bulk insert -----------------------------------------------------------------
@@ -535,7 +513,7 @@ Status HnswGraph::bulk_register(const float *rows, const uint64_t *labels, size_
     memset(links0_mut(id), 0, (maxM0_ + 1) * sizeof(uint32_t));
     labels_[id] = labels[i];
     memcpy(row_mut(id), rows + i * dim_, dim_ * sizeof(float));
-    const int lv = random_level();
+    const int lv = draw_level();
     levels_[id] = lv;
     delete[] upper_[id];
     upper_[id] = nullptr;
@@ -552,46 +530,22 @@ Status HnswGraph::bulk_register(const float *rows, const uint64_t *labels, size_
   return Status::Ok();
 }
 
+// the upper layers of a point whose level 0 the device links (hnsw_build.hip): insert() without layer 0
 Status HnswGraph::bulk_link_upper(uint32_t id) {
-  const int curlevel = levels_[id];
-  if (curlevel <= 0) return Status::Ok();
+  const int node_top = levels_[id];
+  if (node_top <= 0) return Status::Ok();
   const float *q = row(id);
-  std::unique_lock<std::mutex> templock(global_);
-  const int maxlevelcopy = maxlevel_;
-  Spin lock_el(link_locks_[id]);
-  if (curlevel <= maxlevelcopy) templock.unlock();
-  uint32_t currObj = enterpoint_;
-  const uint32_t enterpoint_copy = enterpoint_;
-  if (currObj == kNone) return Status::Err(kErrInternal, "bulk insert into an empty graph");
-  if (curlevel < maxlevelcopy) {
-    float curdist = dist(q, row(currObj));
-    for (int level = maxlevelcopy; level > curlevel; level--) {
-      bool changed = true;
-      while (changed) {
-        changed = false;
-        Spin lock(link_locks_[currObj]);
-        const uint32_t *ll = upper(currObj, level);
-        const int size = (int)list_count(ll);
-        for (int i = 0; i < size; i++) {
-          const uint32_t cand = ll[1 + i];
-          float d = dist(q, row(cand));
-          if (d < curdist) { curdist = d; currObj = cand; changed = true; }
-        }
-      }
-    }
-  }
-  const bool epDeleted = is_deleted(enterpoint_copy);
-  for (int level = std::min(curlevel, maxlevelcopy); level >= 1; level--) {
-    Heap top = search_base_layer(currObj, q, level);
-    if (epDeleted) {
-      top.emplace(dist(q, row(enterpoint_copy)), enterpoint_copy);
-      if (top.size() > efC_) top.pop();
-    }
-    VK_TRY(mutually_connect(q, id, top, level, false, &currObj));
-  }
-  if (curlevel > maxlevelcopy) {
+  std::unique_lock<std::mutex> raising(global_);
+  const int top = maxlevel_;
+  Spin mine(link_locks_[id]);
+  if (node_top <= top) raising.unlock();
+  const uint32_t entry = enterpoint_;
+  if (entry == kNone) return Status::Err(kErrInternal, "bulk insert into an empty graph");
+  const uint32_t start = node_top < top ? descend(q, entry, top, node_top) : entry;
+  VK_TRY(link_layers(id, q, start, std::min(node_top, top), 1, entry, /*rewire=*/false));
+  if (node_top > top) {
     enterpoint_ = id;
-    maxlevel_ = curlevel;
+    maxlevel_ = node_top;
   }
   return Status::Ok();
 }
@@ -606,7 +560,7 @@ Status HnswGraph::load_element(uint32_t id, const uint32_t *links0_words, const 
   levels_[id] = 0;
   if (links0(id)[0] & kDeleteFlag) {
     num_deleted_ += 1;
-    if (allow_replace_deleted_) deleted_elements_.insert(id);
+    if (allow_replace_deleted_) vacant_.insert(id);
   }
   mark(id, 0);
   return Status::Ok();

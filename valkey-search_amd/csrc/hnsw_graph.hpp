@@ -3,18 +3,19 @@
 // exactly as the reference builds it (concurrent addPoint from writer threads,
 // hnswalg.h:1523-1650) and mirrored to HBM for the device search (hnsw_search.hip).
 //
-// Same algorithmic steps and the same standard-library containers as the reference
-// (std::priority_queue with CompareByFirst, std::default_random_engine seeded 100,
-// std::unordered_set in updatePoint), so a single-threaded insert sequence produces the
-// graph hnswlib produces; storage is flat fixed-stride arrays instead of hnswlib's
-// ChunkedArray of {links | pointer | label} records so the level-0 table can be uploaded
-// as is: links0[id][0] = count (low 16 bits) | tombstone (bit 16, hnswalg.h:1259-1262),
+// Same ALGORITHM as the reference's builder (the HNSW paper's: beam search per layer, diversity heuristic, mutual links
+// with re-selection of full lists, two-hop repair on update) and the same seeded level generator
+// (std::default_random_engine seeded 100), organised around this file's own structures: candidate sets are vectors kept
+// nearest first under a total (distance, id) order, not std::priority_queues compared on the distance alone, so what
+// happens on equal distances is defined here and not by libstdc++'s heap; on tie-free data a single-threaded insert
+// sequence produces the graph hnswlib produces, link for link (tests/test_host_graph.py, against the oracle).  Storage is
+// flat fixed-stride arrays instead of hnswlib's ChunkedArray of {links | pointer | label} records so the level-0 table can be
+// uploaded as is: links0[id][0] = count (low 16 bits) | tombstone (bit 16, hnswalg.h:1259-1262),
 // links0[id][1..maxM0] = neighbour ids.
 #pragma once
 #include <atomic>
 #include <memory>
 #include <mutex>
-#include <queue>
 #include <random>
 #include <thread>
 #include <unordered_map>
@@ -107,11 +108,10 @@ class HnswGraph {
 
  private:
   static constexpr uint32_t kChunkShift = 10, kChunkMask = (1u << kChunkShift) - 1;
-  using Pair = std::pair<float, uint32_t>;
-  struct CompareByFirst {
-    constexpr bool operator()(const Pair &a, const Pair &b) const noexcept { return a.first < b.first; }
-  };
-  using Heap = std::priority_queue<Pair, std::vector<Pair>, CompareByFirst>;
+  // a neighbour candidate; sets of them are kept nearest first under a TOTAL order (distance, then id)
+  struct Near { float d; uint32_t id; };
+  static bool nearer(const Near &a, const Near &b) { return a.d < b.d || (a.d == b.d && a.id < b.id); }
+  using NearList = std::vector<Near>;
 
   struct Spin {
     std::atomic_flag &f;
@@ -136,14 +136,14 @@ class HnswGraph {
     }
     ~Spin() { f.clear(std::memory_order_release); }
   };
-  struct VisitedList {
-    uint16_t curV = (uint16_t)-1;
-    std::vector<uint16_t> mass;
-    explicit VisitedList(size_t n) : mass(n) {}
-    uint16_t next() {
-      curV++;
-      if (curV == 0) { std::fill(mass.begin(), mass.end(), 0); curV++; }
-      return curV;
+  // "seen in this search" without clearing: a node is seen when its stamp equals the search's epoch
+  struct SeenStamps {
+    uint16_t epoch = 0;
+    std::vector<uint16_t> stamp;
+    explicit SeenStamps(size_t n) : stamp(n, 0) {}
+    uint16_t advance() {
+      if (++epoch == 0) { std::fill(stamp.begin(), stamp.end(), 0); epoch = 1; }
+      return epoch;
     }
   };
 
@@ -172,19 +172,22 @@ class HnswGraph {
     }
     any_dirty_.store(true, std::memory_order_release);
   }
-  std::unique_ptr<VisitedList> get_visited();
-  void put_visited(std::unique_ptr<VisitedList> v);
-  int random_level();
+  std::unique_ptr<SeenStamps> borrow_seen();
+  void return_seen(std::unique_ptr<SeenStamps> v);
+  int draw_level();
 
-  Heap search_base_layer(uint32_t ep_id, const float *q, int layer);                 // :255-347
-  void neighbors_by_heuristic2(Heap &top, size_t M);                                 // :553-594
-  Status mutually_connect(const float *q, uint32_t cur_c, Heap &top, int level, bool is_update, uint32_t *next);  // :613-756
-  Status add_point_level(const float *row, uint64_t label, int level, uint32_t *out_id);   // :1523-1650
-  Status update_point(const float *row, uint32_t id, float prob);                   // :1342-1430
-  Status repair_connections(const float *q, uint32_t ep, uint32_t id, int level, int maxlevel);  // :1432-1511
-  Status mark_deleted_internal(uint32_t id);
-  Status unmark_deleted_internal(uint32_t id);
-  std::vector<uint32_t> connections_with_lock(uint32_t id, int level);
+  // the builder (hnsw_graph.cc): what each stands in for is cited there
+  NearList beam_search(uint32_t entry, const float *q, int layer);
+  void keep_diverse(NearList &cands, size_t keep) const;
+  static void store_list(uint32_t *list, const NearList &nearest_first);
+  Status wire(uint32_t node, int layer, NearList &cands, bool rewire, uint32_t *closest);
+  uint32_t descend(const float *q, uint32_t from, int top, int stop);
+  Status link_layers(uint32_t node, const float *q, uint32_t start, int first, int last, uint32_t entry, bool rewire);
+  Status insert(const float *row, uint64_t label, uint32_t *out_id);
+  Status refresh(const float *row, uint32_t id, float share);
+  Status set_tombstone(uint32_t id);
+  Status clear_tombstone(uint32_t id);
+  std::vector<uint32_t> snapshot_list(uint32_t id, int level);
   void alloc_tables(size_t n, size_t keep);
 
   size_t dim_;
@@ -218,12 +221,12 @@ class HnswGraph {
   std::unordered_map<uint64_t, uint32_t> label_lookup_;
   static constexpr size_t kLabelLocks = 65536;
   std::unique_ptr<std::mutex[]> label_op_locks_;
-  std::mutex deleted_lock_;
-  std::unordered_set<uint32_t> deleted_elements_;
+  std::mutex vacant_mu_;
+  std::unordered_set<uint32_t> vacant_;          // tombstoned slots a new label may take over (allow_replace_deleted)
   std::mutex rng_mu_;
-  std::default_random_engine level_generator_, update_probability_generator_;
-  std::mutex visited_mu_;
-  std::vector<std::unique_ptr<VisitedList>> visited_pool_;
+  std::default_random_engine level_rng_, refresh_rng_;
+  std::mutex seen_mu_;
+  std::vector<std::unique_ptr<SeenStamps>> seen_pool_;
 };
 
 }  // namespace vk

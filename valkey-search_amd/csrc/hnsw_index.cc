@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -59,6 +60,7 @@ class HnswIndex final : public Index {
   ~HnswIndex() override {
     (void)hipSetDevice(store_.device());
     d_links0_.release();
+    d_totals_.release();
     d_upper_slot_.release();
     d_upper_pool_.release();
   }
@@ -71,31 +73,38 @@ class HnswIndex final : public Index {
   // another while they are linked: the relaxation concurrent addPoint calls already have (hnswalg.h:1523-1650 take no lock
   // across points).  Updates of an existing label, replace-deleted inserts and small graphs take the host builder at once.
   Status add(uint64_t label, const float *row) override {
-    bool full = false;
-    {
-      std::shared_lock<std::shared_mutex> lk(rw_);
-      if (!stage_candidate()) return add_one(label, row);
-      std::lock_guard<std::mutex> pl(pend_.mu);
-      auto it = pend_.pos.find(label);
-      if (it != pend_.pos.end()) {   // the same label again before it was linked: the later row wins (an in-place update)
-        memcpy(pend_.rows.data() + it->second * params_.dim, row, (size_t)params_.dim * 4);
-        return Status::Ok();
+    // Staging does not take the index lock: it touches the staging area alone (its own mutex), so the writers keep staging
+    // while a bulk of earlier rows is being linked on the device under the exclusive lock.
+    if (stage_candidate()) {
+      bool full = false, staged = false;
+      {
+        std::lock_guard<std::mutex> pl(pend_.mu);
+        auto it = pend_.pos.find(label);
+        uint32_t id;
+        if (it != pend_.pos.end()) {   // the same label again before it was linked: the later row wins (an in-place update)
+          memcpy(pend_.rows.data() + it->second * params_.dim, row, (size_t)params_.dim * 4);
+          return Status::Ok();
+        }
+        if (!graph_->lookup(label, &id)) {   // (an update of a linked element goes to the host builder below)
+          if (graph_->count() + pend_.live + draining_.load(std::memory_order_relaxed) >= graph_->max_elements())
+            return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+          if (pend_.rows.capacity() == 0) pend_.rows.reserve((size_t)std::min<uint64_t>(opt_.get(kOptHnswStageMax), 1u << 20) * params_.dim);
+          pend_.pos.emplace(label, pend_.labels.size());
+          pend_.labels.push_back(label);
+          pend_.rows.insert(pend_.rows.end(), row, row + params_.dim);
+          pend_.live += 1;
+          graph_->note_label(label);
+          staged_adds_.fetch_add(1, std::memory_order_relaxed);
+          full = pend_.labels.size() >= opt_.get(kOptHnswStageMax);
+          staged = true;
+        }
       }
-      uint32_t id;
-      if (graph_->lookup(label, &id)) return add_one(label, row);   // an update of a linked element
-      if (graph_->count() + pend_.live + draining_.load(std::memory_order_relaxed) >= graph_->max_elements())
-        return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
-      pend_.pos.emplace(label, pend_.labels.size());
-      pend_.labels.push_back(label);
-      pend_.rows.insert(pend_.rows.end(), row, row + params_.dim);
-      pend_.live += 1;
-      graph_->note_label(label);
-      staged_adds_.fetch_add(1, std::memory_order_relaxed);
-      full = pend_.labels.size() >= opt_.get(kOptHnswStageMax);
+      // (the staging area is bounded: a writer that finds it full links what is there -- or waits for the writer that is
+      //  doing so -- before it returns, like a caller of one long add_batch)
+      if (staged) return full ? drain_pending() : Status::Ok();
     }
-    // (the staging area is bounded: the writer that fills it links what is there -- the others wait on the index lock like
-    //  callers of one long add_batch)
-    return full ? drain_pending() : Status::Ok();
+    std::shared_lock<std::shared_mutex> lk(rw_);
+    return add_one(label, row);
   }
 
   Status add_batch(const uint64_t *labels, const float *rows, uint64_t n) override {
@@ -116,8 +125,15 @@ class HnswIndex final : public Index {
 
   // link what the single adds staged (see add()); called without the index lock
   Status drain_pending() {
-    std::vector<float> rows;
-    std::vector<uint64_t> labels;
+    {   // (cheap exit: nothing staged)
+      std::lock_guard<std::mutex> pl(pend_.mu);
+      if (pend_.labels.empty()) return Status::Ok();
+    }
+    std::lock_guard<std::mutex> one_at_a_time(drain_mu_);
+    std::vector<float> &rows = spare_rows_;       // (the buffers keep their capacity from bulk to bulk: 800 MB at the default
+    std::vector<uint64_t> &labels = spare_labels_;   //  stage size is not reallocated and re-faulted every time)
+    rows.clear();
+    labels.clear();
     {
       std::lock_guard<std::mutex> pl(pend_.mu);
       if (pend_.labels.empty()) return Status::Ok();
@@ -320,8 +336,13 @@ class HnswIndex final : public Index {
       Status ft = build_filter_table(ctx, only, s, &tab_, &tab_nbits_);
       if (!ft.ok()) { tab_ = nullptr; tab_nbits_ = nullptr; (void)ctx->end_async(s); return ft; }
     }
+    std::call_once(totals_once_, [&] {
+      if (d_totals_.ensure(16).ok() && hipMemset(d_totals_.p, 0, 16) == hipSuccess) totals_zeroed_.store(true);
+    });
+    device_totals_ = totals_zeroed_.load() ? d_totals_.as<unsigned long long>() : nullptr;
     Status st = launch(ctx, dq, rq.nq, rq.k, rq.ef, rq.allow_bits, rq.allow_nbits, d_out_dist, d_out_label,
                        d_out_n, s, true, false, rq.cancel_word);
+    device_totals_ = nullptr;
     tab_ = nullptr;
     tab_nbits_ = nullptr;
     Status en = ctx->end_async(s);
@@ -421,6 +442,14 @@ class HnswIndex final : public Index {
     out->last_frontier_dropped = last_overflow_;
     out->total_n_eval = total_n_eval_.load(std::memory_order_relaxed);
     out->total_n_hops = total_n_hops_.load(std::memory_order_relaxed);
+    if (totals_zeroed_.load() && d_totals_.p) {   // + what device-buffer calls (a sharded index's fan-outs) added on the device so far
+      unsigned long long t[2] = {0, 0};
+      (void)hipSetDevice(store_.device());
+      if (hipMemcpy(t, d_totals_.p, 16, hipMemcpyDeviceToHost) == hipSuccess) {
+        out->total_n_eval += t[0];
+        out->total_n_hops += t[1];
+      }
+    }
     // what a tombstone keeps alive until the slot is reused: its row and its level-0 list, on the device and on the host
     // (the reference adds the vector's bytes to reclaimable_memory at markDelete, hnswalg.h:1199)
     out->tombstoned_bytes = out->deleted * ((uint64_t)store_.row_bytes() + (uint64_t)(2 * params_.m + 1) * 4);
@@ -786,6 +815,8 @@ class HnswIndex final : public Index {
     VK_TRY(ctx->d_stats.ensure(64));
     if (reset_stats) VK_HIP_TRY(hipMemsetAsync(ctx->d_stats.p, 0, 40, s));
     a.stats = ctx->d_stats.as<unsigned long long>();
+    a.totals = device_totals_;   // (set by search_device only: the host entry adds what it reads back)
+    device_totals_ = nullptr;
     a.queue = reinterpret_cast<uint32_t *>(a.stats + 6);          // [0]: first launch, [1]: second
     VK_HIP_TRY(hipMemsetAsync(a.queue, 0, 8, s));
     if (redo) {
@@ -1108,6 +1139,9 @@ class HnswIndex final : public Index {
     size_t live = 0;
   } pend_;
   std::atomic<uint64_t> draining_{0}, staged_adds_{0}, staged_adds_device_{0}, last_visited_mode_{0};
+  std::mutex drain_mu_;
+  std::vector<float> spare_rows_;
+  std::vector<uint64_t> spare_labels_;
   bool stage_candidate() const {
     return opt_.get(kOptHnswStageAdds) != 0 && device_build_ != 0 && graph_->count() >= build_min_graph_ &&
            !(params_.allow_replace_deleted && graph_->deleted_count() > 0) && graph_->ef_construction() <= 512 && graph_->maxM0() <= 192;
@@ -1122,11 +1156,16 @@ class HnswIndex final : public Index {
   static thread_local const uint64_t *const *tab_;
   static thread_local const uint64_t *tab_nbits_;
   static thread_local const uint32_t *cancel_q_;
+  static thread_local unsigned long long *device_totals_;
+  DevBuf d_totals_;
+  std::atomic<bool> totals_zeroed_{false};
+  std::once_flag totals_once_;
 };
 
 thread_local const uint64_t *const *HnswIndex::tab_ = nullptr;
 thread_local const uint64_t *HnswIndex::tab_nbits_ = nullptr;
 thread_local const uint32_t *HnswIndex::cancel_q_ = nullptr;
+thread_local unsigned long long *HnswIndex::device_totals_ = nullptr;
 
 // ---- persistence: hnswalg.h:808-865 (SaveIndex), :887-1139 (LoadIndex + loadCheck) -----------------
 Status HnswIndex::save(vk_write_chunk_fn fn, void *user) {

@@ -837,6 +837,10 @@ __device__ __forceinline__ void hnsw_search_body(const HnswSearchArgs &a) {
     atomicAdd(&a.stats[2], st_over);
     atomicAdd(&a.stats[3], st_q);
     if (a.redo_in) atomicAdd(&a.stats[4], st_q);   // ... of which answered by the graph-sized-frontier launch
+    if (a.totals) {   // the index's running totals (device-buffer calls return before their statistics could be read back)
+      atomicAdd(&a.totals[0], st_eval);
+      atomicAdd(&a.totals[1], st_hops);
+    }
   }
 }
 

@@ -260,6 +260,7 @@ struct HnswSearchArgs {
   uint64_t *out_label;
   uint32_t *out_n;
   unsigned long long *stats;   // [5]: n_eval, n_hops, frontier entries dropped (must stay 0), queries, queries re-run (redo_in)
+  unsigned long long *totals;  // optional [2]: n_eval, n_hops added to the INDEX's device-resident running totals as well
   uint32_t *queue;             // zeroed per launch: queries past the first wave of slots are taken in arrival order
   uint32_t row_stride_f, q_stride_f, chunks;
   uint32_t l0_stride, up_stride;
