@@ -34,6 +34,7 @@ settings = [("default", {}), ("hash-per-ef 32", {"hnsw-hash-per-ef": 32}), ("has
             ("mode 2", {"hnsw-visited-mode": 2}), ("mode 2, per-ef 32", {"hnsw-visited-mode": 2, "hnsw-hash-per-ef": 32}),
             ("mode 1", {"hnsw-visited-mode": 1}), ("default again", {})]
 defaults = {"hnsw-hash-per-ef": 64, "hnsw-visited-mode": 3}
+ws = torch.cuda.Stream(device=dev)    # (a stream of its own: the library takes the null stream for "the index's own")
 for ef in efs:
     ref = None
     for name, opts in settings:
@@ -45,16 +46,16 @@ for ef in efs:
         cur = (Dh.view(np.uint32).copy(), Lh.copy(), st.last_n_eval, st.last_n_hops)
         same = "-" if ref is None else str(bool((cur[0] == ref[0]).all() and (cur[1] == ref[1]).all() and cur[2:] == ref[2:]))
         if ref is None: ref = cur
-        s = torch.cuda.current_stream().cuda_stream
+        s = ws.cuda_stream
         for _ in range(2):
             h.search_batch_device(Qd.data_ptr(), nq, 10, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef, stream=s)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 4
-        e0.record()
+        e0.record(ws)
         for _ in range(reps):
             h.search_batch_device(Qd.data_ptr(), nq, 10, od.data_ptr(), ol.data_ptr(), on.data_ptr(), ef=ef, stream=s)
-        e1.record()
+        e1.record(ws)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         print(f"ef={ef} {name:22s}: {nq/ms*1e3:9.0f} QPS {ms:8.2f} ms, useful {useful/ms/1e9:.3f} TB/s = {useful/ms/1e9/8:.3f} of peak, "

@@ -175,4 +175,4 @@ def test_a_queued_submitted_request_is_answered_when_its_token_goes_up(shim, hns
     sweeps the queue every tick."""
     out = (C.c_uint64 * 8)()
     assert shim.dispatcher_queued_cancel_run(hnsw, out) == 0, list(out)[:2]
-    assert out[0] < 1000 and out[1] == 31, list(out)[:2]
+    assert out[0] < 3000 and out[1] == 31, list(out)[:2]      # (the queue is looked at every millisecond, a lane at a time)

@@ -223,11 +223,8 @@ class HnswIndex final : public Index {
     return Status::Ok();
   }
 
-  Status flush() override {
-    VK_TRY(drain_pending());
-    std::unique_lock<std::shared_mutex> lk(rw_);
-    return flush_locked();
-  }
+  // (nothing staged or dirty: no exclusive lock, so a flush at every write -> read switch does not wait for the batches in flight)
+  Status flush() override { return flush_if_dirty(); }
 
   Status search(const SearchRequest &rq, float *out_dist, uint64_t *out_label, uint64_t *out_n) override {
     VK_TRY(flush_if_dirty());
