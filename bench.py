@@ -1289,10 +1289,7 @@ def main():
         ix.search_batch(Q.cpu().numpy(), K)
         st_f = ix.stats()
         filt_stats = {"survivors_per_query": round(st_f.last_filter_candidates / B, 1), "reranked_per_query": round(st_f.last_filter_reranked / B, 1),
-                      "queries_handed_over": int(st_f.last_filter_fallback),
-                      # K-step early exit: (consumer wave, tile) pairs of the final pass that stopped multiplying after 5/12 of the tile
-                      "kskip": int(ix.get_option("filter-kskip")),
-                      "tiles_cut_frac": round(st_f.last_filter_tiles_cut / st_f.last_filter_tiles, 4) if st_f.last_filter_tiles else 0.0}
+                      "queries_handed_over": int(st_f.last_filter_fallback)}
     result_d = (fin_d if world > 1 else out_d).cpu().numpy()
     result_l = (fin_l if world > 1 else out_l).cpu().numpy().view(np.uint64)
 

@@ -186,11 +186,6 @@ typedef struct vk_index_stats {
    * 2 = buckets in memory with counts in LDS, 3 = the 12 KB set in LDS (spill to memory), 5 = the 32 KB set in LDS
    * (option hnsw-visited-mode picks among what fits; bench.py names the kernel it timed from this, not from ef) */
   uint64_t last_visited_mode;
-  /* batched FLAT, most recent batch through the candidate filter (host entry points): (consumer wave, 128-row tile) pairs of
-   * the final pass, and how many of them stopped multiplying after 5/12 of the tile's K-steps because no pair of theirs could
-   * reach its gate any more (option filter-kskip; the survivors are the same either way) */
-  uint64_t last_filter_tiles;
-  uint64_t last_filter_tiles_cut;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------

@@ -67,6 +67,7 @@ int main(int argc, char **argv) {
   // the non-blocking entry: submit / completion callbacks / VK_ERR_BUSY / destroy with work in flight / the batch's own token
   bad += dispatcher_async_run(6 * scale, 300, 64, 32, 500, 2, 100000, 300, 0, out);
   bad += dispatcher_async_run(4 * scale, 200, 200, 16, 500, 3, 40, 300, 1, out);   // a shallow queue: rejections
+  bad += dispatcher_async_run(8, 1200 * scale, 1200, 4096, 3000, 2, 100000, 2000, 1, out);   // batches beyond 1024: answered by the completer threads
   bad += dispatcher_destroy_run(6 * scale, 50);
   bad += dispatcher_batch_cancel_run(1, out);
   bad += dispatcher_batch_cancel_run(0, out);

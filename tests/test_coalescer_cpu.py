@@ -176,3 +176,11 @@ def test_a_queued_submitted_request_is_answered_when_its_token_goes_up(shim, hns
     out = (C.c_uint64 * 8)()
     assert shim.dispatcher_queued_cancel_run(hnsw, out) == 0, list(out)[:2]
     assert out[0] < 3000 and out[1] == 31, list(out)[:2]      # (the queue is looked at every millisecond, a lane at a time)
+
+
+def test_large_batches_are_answered_by_the_completer_threads(shim):
+    """Batches of 1024 members or more hand their answers out on a completer thread (8192 callbacks take as long as the device
+    pass; the runner forms the next batch meanwhile): every request still completes exactly once with its own answer, the
+    destructor waits for what the completers still hold."""
+    bad, st = arun(shim, 8, 1500, 1500, 4096, 3000, 2, 100000, delay_us=2000, hnsw=1)
+    assert bad == 0 and st["completions"] == 12000 and st["rejected"] == 0 and st["max_batch"] >= 1024, st

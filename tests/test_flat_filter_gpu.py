@@ -630,52 +630,3 @@ def test_first_batch_of_a_fresh_index_with_nothing_allowed(vsa, oracle):
     assert (N == 0).all()
     _same(f.search_batch(Q, 10), e.search_batch(Q, 10))
 
-
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_kstep_early_exit_changes_nothing_but_the_matrix_core_work(vsa, oracle, dtype):
-    """r05: after 5/12 of a tile's K-steps a consumer wave of the final pass stops multiplying when no pair of its 128 rows x
-    64 queries can reach its gate any more: partial dot product + |x_tail| |q_tail| (Cauchy-Schwarz, from the tile's largest
-    tail norm and the query's) under the gate's threshold.  Such pairs would be dropped by the gate anyway, so the SURVIVORS
-    -- hence the answers, the counts, the re-rank's work -- are identical with the option filter-kskip on or off; only
-    vk_index_stats.last_filter_tiles_cut differs.  Clustered rows of dimension 768 (twelve stages), IP and COSINE, rows of
-    very different norms in one index (the bound uses the TILE's tail norm), a NaN row (its tile goes on), an allow-bitmap;
-    against the oracle as well."""
-    rng = np.random.default_rng(2025)
-    n, dim, k = 70_000, 768, 10
-    A = rng.standard_normal((dim, 24)).astype(np.float32)
-    x = (rng.standard_normal((n, 24)).astype(np.float32) @ A.T + 0.05 * rng.standard_normal((n, dim)).astype(np.float32)).astype(np.float32)
-    x /= np.linalg.norm(x, axis=1, keepdims=True)
-    x[20_000:20_256] *= 37.0                                   # two tiles of long rows
-    x[41_000:41_128, 500:] = 0.0                               # a tile whose tail is empty
-    x[41_200:41_328, :300] = 0.0                               # ... and one that is all tail
-    x[55_555, 700] = np.nan
-    Q = (rng.standard_normal((96, 24)).astype(np.float32) @ A.T).astype(np.float32)
-    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
-    Q[5] = x[20_100] / 37.0
-    Q[6, 600:] = 0.0
-    Q[7, :600] = 0.0
-    Q[7] /= np.linalg.norm(Q[7])
-    bits = oracle.allow_bitmap(np.flatnonzero(rng.random(n) < 0.4).astype(np.uint64), n)
-    for metric in ("IP", "COSINE"):
-        xs = x if metric == "IP" else np.nan_to_num(x / np.linalg.norm(np.nan_to_num(x), axis=1, keepdims=True)).astype(np.float32)
-        ix = vsa.Index("FLAT", dim, metric, initial_cap=n, dtype=dtype, options={"filter-min-rows": 32768, "filter-prepass-rows": 8192})
-        ix.add_batch(xs)
-        for kw in ({}, {"allow": bits, "allow_nbits": n}):
-            ix.set_option("filter-kskip", 1)
-            a = ix.search_batch(Q, k, **kw)
-            s1 = ix.stats()
-            ix.set_option("filter-kskip", 0)
-            b = ix.search_batch(Q, k, **kw)
-            s0 = ix.stats()
-            assert s1.last_filter_candidates > 0 and s1.last_filter_candidates == s0.last_filter_candidates
-            assert s1.last_filter_reranked == s0.last_filter_reranked and s1.last_filter_fallback == s0.last_filter_fallback
-            assert a[2].tolist() == b[2].tolist() and (a[1] == b[1]).all() and (a[0].view(np.uint32) == b[0].view(np.uint32)).all(), (metric, bool(kw))
-            assert s0.last_filter_tiles_cut == 0 and s0.last_filter_tiles == 0
-            assert s1.last_filter_tiles > 0 and s1.last_filter_tiles_cut > s1.last_filter_tiles // 4, (s1.last_filter_tiles_cut, s1.last_filter_tiles)
-        if dtype == "f32" and metric == "COSINE":
-            o = oracle.Flat(dim, "COSINE", max_elements=n)
-            keep = np.flatnonzero(np.isfinite(xs).all(axis=1))
-            o.add_many(xs[keep], keep.astype(np.uint64))
-            for i in range(0, 96, 7):
-                od, ol = o.search(Q[i], k)
-                assert a[1][i, :a[2][i]].tolist() == ol.tolist() and a[0][i, :a[2][i]].view(np.uint32).tolist() == od.view(np.uint32).tolist()

@@ -56,8 +56,7 @@ class Stats(C.Structure):
                 ("last_filter_reranked", C.c_uint64), ("max_label", C.c_uint64), ("cancelled_early", C.c_uint64),
                 ("filters_built", C.c_uint64), ("filter_cache_hits", C.c_uint64), ("filter_cache_misses", C.c_uint64),
                 ("filter_cache_entries", C.c_uint64), ("filter_cache_bytes", C.c_uint64),
-                ("staged_adds", C.c_uint64), ("staged_adds_device", C.c_uint64), ("last_visited_mode", C.c_uint64),
-                ("last_filter_tiles", C.c_uint64), ("last_filter_tiles_cut", C.c_uint64)]
+                ("staged_adds", C.c_uint64), ("staged_adds_device", C.c_uint64), ("last_visited_mode", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)

@@ -175,6 +175,13 @@ class Dispatcher {
     for (auto &t : runners_) t.join();
     runners_.clear();
     {
+      std::lock_guard<std::mutex> lk(cmu_);
+      cstop_ = true;
+    }
+    ccv_.notify_all();
+    for (auto &t : completers_) t.join();   // (they hand out what the runners left them first)
+    completers_.clear();
+    {
       std::lock_guard<std::mutex> lk(wmu_);
       stop_watch_.store(true, std::memory_order_relaxed);
     }
@@ -402,6 +409,16 @@ class Dispatcher {
     std::vector<const FilterSet *> ftab;
   };
 
+  static constexpr uint64_t kOffloadMin = 1024;
+  struct Done {
+    std::vector<std::shared_ptr<Req>> batch;
+    Scratch sc;
+    Status st;
+    std::vector<Status> each;
+    uint64_t k = 0;
+    bool hnsw = false;
+  };
+
   Status search_members(uint64_t k, uint64_t ef, const std::vector<std::shared_ptr<Req>> &batch, size_t first, size_t nq, Scratch &sc,
                         const volatile int *batch_word, const volatile uint32_t *member_words) {
     sc.qtab.resize(nq);
@@ -490,6 +507,29 @@ class Dispatcher {
     if (w) unwatch(w);
     batches_.fetch_add(1, std::memory_order_relaxed);
     queries_.fetch_add(nq, std::memory_order_relaxed);
+    // Handing the answers out -- per member a copy and a callback into the caller's code -- takes as long as the device pass
+    // for a batch of thousands (8192 callbacks: 8-16 ms next to a 14 ms HNSW launch).  Such a batch is passed to a completer
+    // thread and the runner goes back to forming the next one; small batches (a FLAT batch, blocking callers waiting for a
+    // wake-up) are answered right here.
+    if (nq >= kOffloadMin) {
+      auto d = std::make_unique<Done>();
+      d->batch.swap(batch);
+      std::swap(d->sc, sc);
+      d->st = st;
+      d->each.swap(each);
+      d->k = k;
+      d->hnsw = hnsw;
+      std::lock_guard<std::mutex> lk(cmu_);
+      while (completers_.size() < 2) completers_.emplace_back([this] { complete_loop(); });
+      done_q_.push_back(std::move(d));
+      ccv_.notify_one();
+      return;
+    }
+    hand_out(batch, sc, st, each, k, hnsw);
+  }
+
+  void hand_out(std::vector<std::shared_ptr<Req>> &batch, Scratch &sc, const Status &st, const std::vector<Status> &each, uint64_t k, bool hnsw) {
+    const uint64_t nq = batch.size();
     for (uint64_t i = 0; i < nq; ++i) {
       Req &r = *batch[i];
       if (!claim(r)) continue;   // (it left, or was answered when its token went up; its token may be gone: not read)
@@ -504,6 +544,19 @@ class Dispatcher {
       deliver(r, mine, sc.D.data() + i * k, sc.L.data() + i * k, n);
     }
     wake_blocked();
+  }
+  void complete_loop() {
+    std::unique_lock<std::mutex> lk(cmu_);
+    for (;;) {
+      ccv_.wait(lk, [&] { return cstop_ || !done_q_.empty(); });
+      if (done_q_.empty()) return;
+      std::unique_ptr<Done> d = std::move(done_q_.front());
+      done_q_.pop_front();
+      lk.unlock();
+      hand_out(d->batch, d->sc, d->st, d->each, d->k, d->hnsw);
+      d.reset();
+      lk.lock();
+    }
   }
 
   // ---- the watcher: batches on the device that carry tokens ---------------------------------------------------------
@@ -607,6 +660,11 @@ class Dispatcher {
   std::atomic<uint32_t> wake_seq_{0}, sleepers_{0};
   std::atomic<uint64_t> queue_depth_{100000};
   std::atomic<uint64_t> queued_{0}, batches_{0}, queries_{0}, submitted_{0}, rejected_{0}, max_active_seen_{0}, left_early_{0};
+  std::mutex cmu_;
+  std::condition_variable ccv_;
+  std::deque<std::unique_ptr<Done>> done_q_;
+  std::vector<std::thread> completers_;
+  bool cstop_ = false;
   std::mutex wmu_;
   std::condition_variable wcv_;
   std::vector<std::shared_ptr<Watched>> watched_;

@@ -94,29 +94,24 @@ constexpr int kFAStride = 72;                // halfs per staged row: 64 + 8 pad
 // hn16 (optional, L2 indexes): per row half its squared norm, split into two f16 (hi | lo << 16) -- the extra K-step
 // that turns the filter's dot product into dot - |x|^2 / 2.
 __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32_t bf16, uint32_t l2, uint32_t stride_e, uint32_t chunks,
-                                                        uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *tile_norm, uint32_t *hn16,
-                                                        uint32_t tail_from, uint32_t *tile_tail) {
+                                                        uint32_t lo, uint32_t hi, uint32_t *stats, uint32_t *tile_norm, uint32_t *hn16) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 3, rq = lane >> 2;
   const uint32_t total_waves = gridDim.x * 4, n_tiles = (hi - lo + kRowsPerWave - 1) / kRowsPerWave;
   float best_n2 = 0.f, best_abs = 0.f;
   for (uint32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += total_waves) {   // (lo is a multiple of 128)
     const uint32_t row = lo + tile * kRowsPerWave + rq;
     const uint32_t lrow = row < hi ? row : hi - 1;
-    float n2 = 0.f, mx = 0.f, t2 = 0.f;   // t2: the squared norm of the row's elements from tail_from on (the K-step early exit)
+    float n2 = 0.f, mx = 0.f;
     bool bad = false;
     for (uint32_t c = 0; c < chunks; ++c) {
       const float4 x = bf16 ? row_piece<true>(row_base<true>(rows, lrow, stride_e), c * 4 + j)
                             : row_piece<false>(row_base<false>(rows, lrow, stride_e), c * 4 + j);
-      const float p2 = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, x.w * x.w)));
-      if (c * 16 >= tail_from) t2 += p2;
       n2 = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, n2))));
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
       bad = bad || !(x.x - x.x == 0.f) || !(x.y - x.y == 0.f) || !(x.z - x.z == 0.f) || !(x.w - x.w == 0.f);
     }
     n2 += dpp_quad_xor1(n2);
     n2 += dpp_quad_xor2(n2);
-    t2 += dpp_quad_xor1(t2);
-    t2 += dpp_quad_xor2(t2);
     if (bad || !(n2 - n2 == 0.f)) mx = __builtin_inff();
     if (hn16 != nullptr && row < hi && j == 0) {
       const float hn = 0.5f * n2;
@@ -127,14 +122,11 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const void *rows, uint32
     // the 16 rows of this step lie in one 128-row tile
     const float g_n2 = wave_max_f32(n2) * 1.0001f;   // (rounding of the sum itself: far below 1e-4)
     const float g_abs = wave_max_f32(mx);
-    const float g_t2 = tile_tail != nullptr ? wave_max_f32(t2) * 1.0001f : 0.f;
     const bool g_bad = !(g_abs <= 32768.f) || !(g_n2 - g_n2 == 0.f) || (l2 && !(0.5f * g_n2 <= 60000.f));
     if (lane == 0) {
       const uint32_t v = g_bad ? 0x7F800000u : __float_as_uint(sqrtf(g_n2) * 1.0001f);   // the NORM, rounded up
       const uint32_t old = atomicMax(&tile_norm[(lo + tile * kRowsPerWave) / 128u], v);
       if (g_bad && old != 0x7F800000u) atomicAdd(&stats[2], 1u);
-      if (tile_tail != nullptr)
-        atomicMax(&tile_tail[(lo + tile * kRowsPerWave) / 128u], g_bad || !(g_t2 - g_t2 == 0.f) ? 0x7F800000u : __float_as_uint(sqrtf(g_t2) * 1.0001f));
     }
     best_n2 = fmaxf(best_n2, g_n2);
     best_abs = fmaxf(best_abs, g_abs);
@@ -175,13 +167,13 @@ __global__ __launch_bounds__(1024) void tile_cap_kernel(const uint32_t *tile_nor
 }
 
 hipError_t launch_row_stats(const void *rows, bool bf16, bool l2, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t n_tiles,
-                            uint32_t *stats, uint32_t *tile_norm, uint32_t *hn16, hipStream_t s, uint32_t tail_from, uint32_t *tile_tail) {
+                            uint32_t *stats, uint32_t *tile_norm, uint32_t *hn16, hipStream_t s) {
   lo &= ~127u;                                            // whole tiles: a step of 16 rows never straddles two of them
   if (hi > lo) {
     const uint32_t tiles = (hi - lo + kRowsPerWave - 1) / kRowsPerWave;
     const uint32_t blocks = std::min<uint32_t>((tiles + 3) / 4, 2048);
     hipLaunchKernelGGL(row_stats_kernel, dim3(blocks), dim3(256), 0, s, rows, bf16 ? 1u : 0u, l2 ? 1u : 0u, stride_e, stride_e / 16, lo, hi,
-                       stats, tile_norm, hn16, tail_from, tile_tail);
+                       stats, tile_norm, hn16);
   }
   hipLaunchKernelGGL(tile_cap_kernel, dim3(1), dim3(1024), 0, s, tile_norm, n_tiles, stats);
   return hipGetLastError();
@@ -197,15 +189,13 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
   const uint32_t q = j < a.nq ? j : a.nq - 1;          // padding columns replicate the last query (their gate never opens)
   const float *src = a.queries + (size_t)q * a.q_stride_f;
   const uint32_t ks_n = a.row_stride_f / 16, jt = j >> 5, jj = j & 31;
-  float n2 = 0.f, mx = 0.f, t2 = 0.f;
+  float n2 = 0.f, mx = 0.f;
   bool bad = false;
-  const uint32_t tail_k8 = a.kskip_stage * (kFStageK / 8);   // (first 8-element group of the K-steps an early exit leaves out)
   for (uint32_t k8 = lane; k8 < a.row_stride_f / 8; k8 += kWave) {
     const float4 u = reinterpret_cast<const float4 *>(src)[k8 * 2], v = reinterpret_cast<const float4 *>(src)[k8 * 2 + 1];
     const float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      if (k8 >= tail_k8) t2 = fmaf(e[t], e[t], t2);
       n2 = fmaf(e[t], e[t], n2);
       mx = fmaxf(mx, fabsf(e[t]));
       bad = bad || !(e[t] - e[t] == 0.f);
@@ -214,7 +204,6 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
 #pragma unroll
   for (int m = 1; m < kWave; m <<= 1) {
     n2 += __shfl_xor(n2, m);
-    t2 += __shfl_xor(t2, m);
     mx = fmaxf(mx, __shfl_xor(mx, m));
     bad = bad || __shfl_xor((int)bad, m);
   }
@@ -240,12 +229,7 @@ __global__ __launch_bounds__(64) void flat_qprep_kernel(FlatFilterArgs a) {
   }
   if (j < a.nq && lane < kSpillPerQuery) a.qchunk[(size_t)j * kSpillPerQuery + lane] = 0u;
   if (lane != 0) return;
-  if (j == 0) {
-    *a.spill_next = 0u;
-    *a.redo_cnt = 0u;
-    if (a.kskip_cnt) a.kskip_cnt[0] = a.kskip_cnt[1] = 0ull;
-  }
-  if (a.qtail) a.qtail[j] = sqrtf(t2) * 1.0001f;
+  if (j == 0) { *a.spill_next = 0u; *a.redo_cnt = 0u; }
   float4 co = make_float4(0.f, 0.f, 0.f, 1.f);          // padding column: closed
   if (j < a.nq) {
     a.cand_cnt[j] = 0u;
@@ -1108,15 +1092,6 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       col[t2].bound = (closed[t2] || abl != 0) ? __builtin_inff() : a.qbound[jc];   // (experiments: nothing survives)
     }
   }
-  // K-step early exit (FlatFilterArgs::kskip_stage): the columns' tail norms, the tile's tail norm beside its norm
-  const uint32_t kskip = (!kSample && !kL2 && kAbl == 0) ? a.kskip_stage : 0u;
-  float qtl[2] = {0.f, 0.f};
-  if (kskip) {
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) qtl[t2] = a.qtail[wave * 2 + t2 < a.nqt ? (wave * 2 + t2) * 32 + li : 0u];
-  }
-  bool dead = false;                                          // this wave multiplies no further for the current tile
-  uint32_t n_cut = 0, n_seen = 0;                             // (wave-uniform: scalar registers)
   f32x16 acc[2][4];
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1129,10 +1104,8 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   // its gate twelve stages later (a buffer load on purpose: a scalar load shares the LDS reads' counter, and every
   // wait for a fragment behind it would become a wait for everything).
   const __amdgpu_buffer_rsrc_t tile_rsrc = ws_rsrc(a.tile_norm);
-  uint32_t norm_bits = 0, tail_bits = 0;
+  uint32_t norm_bits = 0;
   if constexpr (!kSample) norm_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
-  const __amdgpu_buffer_rsrc_t tail_rsrc = ws_rsrc(kskip ? a.tile_tail : a.tile_norm);
-  if (kskip) tail_bits = __builtin_amdgcn_raw_buffer_load_b32(tail_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
   __syncthreads();                                            // (the prologue's barrier)
 
   // iteration S: 32 MFMAs of stage S, operands from LDS (A: buffer S & 1, row li of each row tile; B: slot S & 1,
@@ -1191,7 +1164,7 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     const _Float16 *ab = lds_a + par * kBufHalfs + li * kFAStride + g * 8;
     const char *dma_ab = reinterpret_cast<const char *>(lds_a) + dma_slot;
     const f16x8 *bb = reinterpret_cast<const f16x8 *>(lds_b + (kBDma ? b_slot : par * kWsBStage) + (wave * 2) * 4 * kWave) + lane;
-    if (has_q && !dead) {
+    if (has_q) {
       if (st_c == 0) VK_WS_STAGE(VK_WS_MMZ) else VK_WS_STAGE(VK_WS_MM)
       if constexpr ((kAbl & 128) != 0) VK_WS_STAGE(VK_WS_MM)   // (experiment: a stage's MFMAs twice per barrier)
       if constexpr (kL2) {
@@ -1213,30 +1186,8 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
     par ^= 1;
     if constexpr (kDma) dma_slot = dma_slot + kDmaStageBytes == kDmaRing * kDmaStageBytes ? 0u : dma_slot + kDmaStageBytes;
     if constexpr (kBDma) b_slot = b_slot + kWsBStage == kBRing * kWsBStage ? 0u : b_slot + kWsBStage;
-    if (kskip != 0 && st_c == kskip && has_q) {
-      // Can any of this wave's 128 x 64 pairs still reach its gate?  The remaining K-steps add at most |x_tail| |q_tail| to
-      // a pair's score (Cauchy-Schwarz over the f16 / bf16 operands: 1 % covers their rounding, the small absolute term the
-      // f16 subnormals, the tile's margin once more the accumulation's rounding), so a pair whose partial score stays under
-      // thr - that would be dropped by the gate at the end of the tile anyway.  (A NaN compares false: the wave goes on.)
-      const float R = tile_norm(norm_bits), T = __uint_as_float(tail_bits);
-      bool none = true;
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        float m = acc[t2][0][0];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[t2][rt][r]);
-        const float more = fmaf(qtl[t2] * T, 1.01f, fmaf(0x1p-19f, qtl[t2] + T, 0x1p-36f));
-        const float thr_mid = (gate_thr<kL2>(col[t2], norm_bits) - tile_margin<kL2>(col[t2], R)) - more;
-        none = none && (closed[t2] || m < thr_mid);
-      }
-      dead = __ballot(none) == ~0ull;
-    }
     if (st_c == stages) {
-      n_seen += has_q ? 1u : 0u;
-      n_cut += dead ? 1u : 0u;
-      if (has_q && !dead) {
+      if (has_q) {
         if constexpr (kSample) {
           sample_max<4, kBf16>(a, acc[0], wit[0], closed[0], tile_row0, (wave * 2) * 32 + li, g);
           sample_max<4, kBf16>(a, acc[1], wit[1], closed[1], tile_row0, (wave * 2 + 1) * 32 + li, g);
@@ -1248,11 +1199,9 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
           filter_gate<4, false>(a, acc[1], gate_thr<kL2>(col[1], norm_bits), tile_row0, wave * 2 + 1, li, g, ring, lane);
         }
       }
-      dead = false;
       tile_row0 += row_step;
       // (past the block's last tile this reads a word behind it: the table is padded, the value is not used)
       if constexpr (!kSample) norm_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
-      if (kskip) tail_bits = __builtin_amdgcn_raw_buffer_load_b32(tail_rsrc, 0, (int)((tile_row0 / (uint32_t)kFTileRows) * 4u), 0);
       VK_WS_TICK(1)
       VK_WS_TILE_END(__syncthreads())
     } else {
@@ -1270,10 +1219,6 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
       for (int i = 0; i < 3; ++i) atomicAdd(&exp_dbg(a)[5 + i], ph[i]);
   }
   ring_flush(a, ring, lane);
-  if (kskip != 0 && a.kskip_cnt != nullptr && lane == 0 && n_seen != 0) {
-    atomicAdd(&a.kskip_cnt[0], (unsigned long long)n_cut);
-    atomicAdd(&a.kskip_cnt[1], (unsigned long long)n_seen);
-  }
 }
 
 #ifdef VK_EXPERIMENTS

@@ -348,7 +348,6 @@ class FlatIndex final : public Index {
     d_rowstats_.release();
     d_hn16_.release();
     d_tile_norm_.release();
-    d_tile_tail_.release();
   }
 
   Status add(uint64_t label, const float *row) override {
@@ -459,8 +458,7 @@ class FlatIndex final : public Index {
     if (filter_used_) {   // survivor counts + the number of handed-over queries of the candidate filter, for vk_index_stats
       // (layout of the batch's words: scan_filter -- [nq] counts | [nq] flags | spill_next, redo_cnt, ...)
       // ... | [nq] redo list | [nq][kSpillPerQuery] chunk slots | [nq] arrival counters | [nq] rows the re-rank evaluated
-      VK_TRY(ctx->h_tmp.ensure(rq.nq * 12 + 8 + 16));
-      VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.as<char>() + rq.nq * 12 + 8, ctx->d_fcnt.as<uint32_t>() + kskip_off_, 16, hipMemcpyDeviceToHost, ctx->stream));
+      VK_TRY(ctx->h_tmp.ensure(rq.nq * 12 + 8));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.p, ctx->d_fcnt.p, rq.nq * 8 + 8, hipMemcpyDeviceToHost, ctx->stream));
       VK_HIP_TRY(hipMemcpyAsync(ctx->h_tmp.as<char>() + rq.nq * 8 + 8, ctx->d_fcnt.as<uint32_t>() + (4 + 4 * rq.nq + rq.nq * kSpillPerQuery),
                                 rq.nq * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -475,13 +473,7 @@ class FlatIndex final : public Index {
       uint64_t rr = 0;
       for (uint64_t q = 0; q < rq.nq; ++q) rr += c[2 * rq.nq + 2 + q];
       last_filter_reranked_ = rr;                 // rows that got an exact distance
-      unsigned long long ks[2];
-      memcpy(ks, ctx->h_tmp.as<char>() + rq.nq * 12 + 8, 16);
-      last_filter_tiles_cut_ = ks[0];             // (wave, tile) pairs of the final pass that stopped multiplying early, of ...
-      last_filter_tiles_ = ks[1];
     } else {
-      last_filter_tiles_cut_ = 0;
-      last_filter_tiles_ = 0;
       last_filter_cands_ = 0;
       last_filter_fallback_ = 0;
       last_filter_reranked_ = 0;
@@ -602,8 +594,6 @@ class FlatIndex final : public Index {
     out->last_filter_candidates = last_filter_cands_;
     out->last_filter_fallback = last_filter_fallback_;
     out->last_filter_reranked = last_filter_reranked_;
-    out->last_filter_tiles = last_filter_tiles_;
-    out->last_filter_tiles_cut = last_filter_tiles_cut_;
     out->max_label = max_label_;
     (void)hipSetDevice(store_.device());
     pool_.for_each_free([&](SearchCtx *c) { for (auto &tp : c->timed) drain_timed(tp); });
@@ -953,9 +943,7 @@ class FlatIndex final : public Index {
     const size_t tile_bytes = (size_t)((store_.alloc_rows() + RowStore::kRowSlack + 127) / 128) * 4;
     if (d_tile_norm_.cap < tile_bytes) {   // (the per-tile tables follow the row table's size)
       VK_TRY(d_tile_norm_.ensure(tile_bytes));
-      VK_TRY(d_tile_tail_.ensure(tile_bytes));
       VK_HIP_TRY(hipMemsetAsync(d_tile_norm_.p, 0, d_tile_norm_.cap, store_.stream()));
-      VK_HIP_TRY(hipMemsetAsync(d_tile_tail_.p, 0, d_tile_tail_.cap, store_.stream()));
       VK_HIP_TRY(hipMemsetAsync(d_rowstats_.p, 0, 64, store_.stream()));
       all = true;
     }
@@ -970,7 +958,6 @@ class FlatIndex final : public Index {
       rewritten_ += all ? 0 : hi - lo;
       if (!all && rewritten_ * 4 > std::max<uint64_t>(count_, 1024)) {
         VK_HIP_TRY(hipMemsetAsync(d_tile_norm_.p, 0, d_tile_norm_.cap, store_.stream()));
-        VK_HIP_TRY(hipMemsetAsync(d_tile_tail_.p, 0, d_tile_tail_.cap, store_.stream()));
         VK_HIP_TRY(hipMemsetAsync(d_rowstats_.p, 0, 64, store_.stream()));
         all = true;
       }
@@ -979,8 +966,7 @@ class FlatIndex final : public Index {
       Status st = [&]() -> Status {
         VK_HIP_TRY(launch_row_stats(store_.d_rows(), store_.bf16(), l2(), store_.stride_f(), (uint32_t)lo, (uint32_t)hi,
                                     (uint32_t)((count_ + 127) / 128), d_rowstats_.as<uint32_t>(), d_tile_norm_.as<uint32_t>(),
-                                    l2() ? d_hn16_.as<uint32_t>() : nullptr, store_.stream(), kskip_default_stage() * 64,
-                                    d_tile_tail_.as<uint32_t>()));
+                                    l2() ? d_hn16_.as<uint32_t>() : nullptr, store_.stream()));
         uint32_t h[3] = {0, 0, 0};
         VK_HIP_TRY(hipMemcpyAsync(h, d_rowstats_.p, sizeof h, hipMemcpyDeviceToHost, store_.stream()));
         VK_HIP_TRY(hipStreamSynchronize(store_.stream()));
@@ -993,13 +979,6 @@ class FlatIndex final : public Index {
       }
     }
     return Status::Ok();
-  }
-
-  // The K-step early exit's split point is a property of the INDEX (the per-tile tail norms are kept for it): after 5/12 of
-  // a tile's stages of 64 elements, for rows of at least six stages; the option filter-kskip picks whether a launch uses it.
-  uint32_t kskip_default_stage() const {
-    const uint32_t stages = store_.stride_f() / 64;
-    return stages >= 6 && !l2() ? std::max<uint32_t>(2, stages * 5 / 12) : 0u;
   }
 
   // K4h pipeline (flat_filter.hip), six launches for a batch that needs no hand-over:
@@ -1034,10 +1013,9 @@ class FlatIndex final : public Index {
     // per-batch words: [nq] survivor counts | [nq] hand-over flags | [4] spill_next, redo_cnt | [nq] redo list | [nq][32] chunk slots
     // ... | [nq] arrival counters of the fused re-rank
     const size_t w_cnt = 0, w_ovf = nq, w_misc = 2 * nq, w_redo = 2 * nq + 4, w_chunk = 3 * nq + 4, w_done = w_chunk + nq * kSpillPerQuery;
-    const size_t w_kskip = (w_done + 2 * nq + 1) & ~(size_t)1;   // (... | [nq] rows the re-rank evaluated | two 64-bit early-exit counters)
-    VK_TRY(ctx->d_fcnt.ensure((w_kskip + 4) * 4));
+    VK_TRY(ctx->d_fcnt.ensure((w_done + 2 * nq) * 4));          // (... | [nq] rows the re-rank evaluated)
     VK_TRY(ctx->d_fq16.ensure((size_t)nqt * 32 * dp * 2));
-    VK_TRY(ctx->d_fthr.ensure((size_t)nqt * 32 * (16 + 4 + 4 + 4)));  // error polynomials, then bounds, witness margins, tail norms
+    VK_TRY(ctx->d_fthr.ensure((size_t)nqt * 32 * (16 + 4 + 4)));      // error polynomials, then bounds, then witness margins
     VK_TRY(ctx->d_fcand.ensure(nq * (size_t)cap * 8));                 // row slots, then the scores
     VK_TRY(ctx->d_fspill.ensure((size_t)n_chunks * kSpillChunk * 8));
     VK_TRY(ctx->d_fsmax.ensure(nq * (size_t)smax_ld * 4));
@@ -1081,11 +1059,6 @@ class FlatIndex final : public Index {
     f.norm_cap = d_rowstats_.as<uint32_t>() + 3;
     f.sample_gap = gap;
     f.tile_norm = d_tile_norm_.as<uint32_t>();
-    f.tile_tail = d_tile_tail_.as<uint32_t>();
-    f.qtail = f.qwit + (size_t)nqt * 32;
-    f.kskip_stage = (opt_.get(kOptFilterKSkip) != 0 && !filter_experiment) ? kskip_default_stage() : 0u;   // (the tail norms exist for this split only)
-    f.kskip_cnt = reinterpret_cast<unsigned long long *>(words + w_kskip);
-    kskip_off_ = w_kskip;
     f.cand_cnt = words + w_cnt;
     f.cand_row = ctx->d_fcand.as<uint32_t>();
     f.cand_val = reinterpret_cast<float *>(f.cand_row + nq * (size_t)cap);
@@ -1297,13 +1270,11 @@ class FlatIndex final : public Index {
   // spill chunks (of kSpillChunk survivors) a batch's queries share beyond their private lists: 16 MB per context
   OptRef filter_spill_chunks_{&opt_, kOptFilterSpillChunks};
   uint32_t filter_blocks_ = 0;
-  DevBuf d_rowstats_, d_hn16_, d_tile_norm_, d_tile_tail_;
-  static thread_local size_t kskip_off_;   // (words: where the batch's early-exit counters lie in its context's d_fcnt)
+  DevBuf d_rowstats_, d_hn16_, d_tile_norm_;
   std::atomic<uint32_t> filter_bad_tiles_{0};   // tiles the f16 pipe cannot carry (row_stats_kernel)
   std::mutex stats_mu_;
   uint64_t rewritten_ = 0;                      // rows brought up to date since the last full pass (under stats_mu_)
   uint64_t max_label_ = 0;   // the largest label ever held (vk_index_stats.max_label)
-  std::atomic<uint64_t> last_filter_tiles_{0}, last_filter_tiles_cut_{0};
   std::atomic<uint64_t> last_filter_cands_{0}, last_filter_fallback_{0}, last_filter_reranked_{0}, filter_ns_total_{0}, filter_batches_{0}, filter_timed_{0};
   static thread_local bool filter_used_;
   static constexpr uint64_t kGemmMinQueries = 5;    // measured at 10Mx768: K3 4 queries 5.3 ms, 8 queries 11.7 ms; K4 up to 32 queries 6.1 ms
@@ -1368,8 +1339,6 @@ Status FlatIndex::save(vk_write_chunk_fn fn, void *user) {
   }
   return Status::Ok();
 }
-
-thread_local size_t FlatIndex::kskip_off_ = 0;
 
 Status FlatIndex::load_from(vk_read_chunk_fn fn, void *user) {
   std::vector<char> buf((size_t)params_.dim * 4 + 64);

@@ -174,16 +174,6 @@ struct FlatFilterArgs {
   uint32_t row_stride_f, n_rows, nq;
   uint32_t nqt;               // query tiles of 32 (<= 8 per launch)
   const uint32_t *cancel;
-  // K-step early exit (r05; final pass, inner-product space).  After kskip_stage of a tile's stages (0 = off) a consumer wave
-  // looks at its 8192 partial scores: a pair whose partial dot product plus the Cauchy-Schwarz bound of what the remaining
-  // K-steps can add -- |x[k0..]| |q[k0..]|, k0 = 64 kskip_stage, from the tile's largest TAIL norm (tile_tail, row_stats_kernel)
-  // and the query's (qtail, qprep) -- stays under the gate's threshold WOULD BE DROPPED BY THE GATE ANYWAY; when that holds for
-  // all of the wave's pairs it multiplies no further for this tile (and skips the gate).  The survivors are the same pairs
-  // either way; what changes is the matrix-core work, hence the power the row stream has to share.
-  uint32_t kskip_stage;
-  const uint32_t *tile_tail;      // [tiles] f32 bits, rounded up; +inf for a tile the f16 pipe cannot carry
-  float *qtail;                   // [nqt * 32] per query column (written by qprep)
-  unsigned long long *kskip_cnt;  // optional [2]: (wave, tile) pairs that stopped early, and all of them (zeroed by qprep)
 #ifdef VK_EXPERIMENTS
   // the -DVK_EXPERIMENTS build only (csrc/Makefile `experiments`): kernels whose answers are INVALID, for timing
   uint32_t timing;            // VK_FILTER_TIMING=1: the kernel variant with cycle counters per phase (f32 rows, IP only)
@@ -210,10 +200,8 @@ bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2
 // stats: [0] largest |row|^2 (SQUARED, reported only), [1] largest |element| of the index (f32 bits), [2] tiles flagged +inf
 // so far, [3] the norm cap of the sample's witnesses: the NORM |row| (f32 bits, same unit as tile_norm) that 97 % of the finite
 // tiles stay below (recomputed over n_tiles tiles)
-// (tail_from: element index, a multiple of 64, from which tile_tail takes the rows' norms; tile_tail == nullptr: not kept)
 hipError_t launch_row_stats(const void *rows, bool bf16, bool l2, uint32_t stride_e, uint32_t lo, uint32_t hi, uint32_t n_tiles,
-                            uint32_t *stats, uint32_t *tile_norm, uint32_t *hn16, hipStream_t s, uint32_t tail_from = 0,
-                            uint32_t *tile_tail = nullptr);
+                            uint32_t *stats, uint32_t *tile_norm, uint32_t *hn16, hipStream_t s);
 hipError_t launch_flat_bound_select(const FlatBoundArgs &a, hipStream_t s);
 constexpr uint32_t kFilterMaxGroups = 16384;   // group bounds per query the selection holds in registers (8192 sample tiles)
 hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s);

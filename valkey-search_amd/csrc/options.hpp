@@ -35,7 +35,7 @@ enum OptId : uint32_t {
   kOptKernelTiming,         // 1 = HIP event pairs around the dominant kernel's launches (vk_index_stats.filter_kernel_ns)
   // ---- FLAT: kernel selection and the candidate filter (K4h) ------------------------------------------------------------
   kOptFlatFilter, kOptFilterMinQueries, kOptFilterMinRows, kOptFilterPrepassRows, kOptFilterCap, kOptFilterSpillChunks,
-  kOptFilterBDma, kOptFilterRowDma, kOptFilterBf16Mfma, kOptFlatForceScan, kOptFlatFusedRerank, kOptFilterSecondBound, kOptFilterKSkip,
+  kOptFilterBDma, kOptFilterRowDma, kOptFilterBf16Mfma, kOptFlatForceScan, kOptFlatFusedRerank, kOptFilterSecondBound,
   kOptGemmLockstep, kOptGemmPrepassRows, kOptGemmContig, kOptScanMinNrp, kOptUploadParallel,
   // ---- HNSW ----------------------------------------------------------------------------------------------------------------
   kOptHnswStageAdds, kOptHnswStageMax,
@@ -77,7 +77,6 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"flat-force-scan", "VK_FLAT_FORCE_SCAN", 0, 0, 1},
       {"flat-fused-rerank", "VK_FLAT_FUSED_RERANK", 1, 0, 1},
       {"filter-second-bound", "VK_FILTER_SECOND_BOUND", 1, 0, 1},
-      {"filter-kskip", "VK_FILTER_KSKIP", 1, 0, 64},                              // K-step early exit of the final pass: 0 off, 1 after 5/12 of a tile's stages, n >= 2: after n stages
       {"gemm-lockstep", "VK_GEMM_LOCKSTEP", 1, 0, 64},
       {"gemm-prepass-rows", "VK_GEMM_PREPASS", 16384, 0, kMax},
       {"gemm-contig", "VK_GEMM_CONTIG", 1, 0, 1},
