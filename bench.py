@@ -1018,18 +1018,30 @@ def serving_leg(ix, hq, K, device_qps, max_batch, wait_us, producers, window, to
     rd, rl, rn = ix.search_batch(hq, K, ef=ef)
     assert (rn == K).all()
     ix.set_coalescing(max_batch, wait_us)
+
+    def accounted(fn):
+        """the probe's result + the dispatcher's account of its threads' time during it (vk_index_stats.dispatch_*_us)"""
+        s0 = ix.stats()
+        r = fn()
+        s1 = ix.stats()
+        r.threads_ms = {k: round((getattr(s1, f"dispatch_{k}_us") - getattr(s0, f"dispatch_{k}_us")) / 1e3, 1)
+                        for k in ("idle", "window", "search", "handout", "completer")}
+        r.wall_ms = round(r.seconds * 1e3, 1)
+        return r
+
     try:
         vsa.probe_submit(ix, hq, K, min(total, 4 * max_batch), producers, window, ef, ref=(rd, rl))     # warm-up: runner threads, contexts
-        sub = vsa.probe_submit(ix, hq, K, total, producers, window, ef, ref=(rd, rl))
-        blk = vsa.probe_blocking(ix, hq, K, threads, calls, ef, ref=(rd, rl))
+        sub = accounted(lambda: vsa.probe_submit(ix, hq, K, total, producers, window, ef, ref=(rd, rl)))
+        blk = accounted(lambda: vsa.probe_blocking(ix, hq, K, threads, calls, ef, ref=(rd, rl)))
         # ... and THROUGH THE ADAPTOR CLASSES (include/vk_vector_adaptor.h on the mock of VectorBase, scripts/adaptor_probe.cc):
-        # a reader pool of the box's cores; SearchAsync with `window` FT.SEARCHes outstanding (the clients' concurrency), the
-        # coalescing the adaptor sets itself; and the reference's blocking Search() from the same pool
+        # one front thread (the main thread) keeps `window` FT.SEARCHes outstanding (the clients' concurrency) and posts each to a
+        # reader pool of the box's cores, which calls SearchAsync (the coalescing is the adaptor's own); and the reference's
+        # blocking Search() from the same pool
         readers = effective_cpus()
         hnsw_ix = ix.algo == "HNSW"
         vsa.adaptor_probe(ix, hq, K, min(total, 4 * max_batch), readers, window, ef, hnsw=hnsw_ix, ref=(rd, rl))
-        ada = vsa.adaptor_probe(ix, hq, K, total, readers, window, ef, hnsw=hnsw_ix, ref=(rd, rl))
-        adb = vsa.adaptor_probe(ix, hq, K, max(readers * 24, total // 8), readers, readers, ef, hnsw=hnsw_ix, blocking=True, ref=(rd, rl))
+        ada = accounted(lambda: vsa.adaptor_probe(ix, hq, K, total, readers, window, ef, hnsw=hnsw_ix, ref=(rd, rl)))
+        adb = accounted(lambda: vsa.adaptor_probe(ix, hq, K, max(readers * 24, total // 8), readers, readers, ef, hnsw=hnsw_ix, blocking=True, ref=(rd, rl)))
     finally:
         ix.set_coalescing(0, 0)
     st = ix.stats()
@@ -1038,12 +1050,13 @@ def serving_leg(ix, hq, K, device_qps, max_batch, wait_us, producers, window, to
         return {**kw, "qps": round(r.qps, 1), "of_device_batch_rate": round(r.qps / device_qps, 3) if device_qps else None,
                 "requests": int(r.completed), "answers_identical": bool(r.mismatches == 0 and r.errors == 0), "rejected_busy": int(r.rejected),
                 "device_batches": int(r.device_batches), "mean_batch": round(r.mean_batch, 1), "batches_in_flight": int(r.max_batches_in_flight),
-                "latency_us": {"p50": round(r.p50_us, 1), "p99": round(r.p99_us, 1), "max": round(r.max_us, 1)}}
+                "latency_us": {"p50": round(r.p50_us, 1), "p99": round(r.p99_us, 1), "max": round(r.max_us, 1)},
+                "wall_ms": r.wall_ms, "dispatcher_threads_ms": r.threads_ms}
 
     return {"max_batch": max_batch, "max_wait_us": wait_us, "device_batch_qps": round(device_qps, 1) if device_qps else None,
             "submit": row(sub, producers=producers, outstanding=window),
             "blocking": row(blk, callers=threads, calls_per_caller=calls),
-            "adaptor": {"async": row(ada, reader_threads=readers, outstanding=window, entry="VectorGpu::SearchAsync"),
+            "adaptor": {"async": row(ada, reader_threads=readers, front_threads=1, outstanding=window, entry="VectorGpu::SearchAsync"),
                         "blocking": row(adb, reader_threads=readers, entry="VectorGpu::Search"),
                         "cancelled_early": int(st.cancelled_early)},
             "latency_hist_us_pow2_from_64": list(st.latency_hist)}
@@ -1072,20 +1085,20 @@ def source_sha256():
 
 def pmc_traffic(N, D, B, world, kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc is a separate run by
-    rule, so bench.py cannot collect it live): profiles/r04_pmc_fetch_size.json, written by scripts/pmc_traffic.sh and
+    rule, so bench.py cannot collect it live): profiles/r05_pmc_fetch_size.json, written by scripts/pmc_traffic.sh and
     stamped with the hash of the sources it measured.  Printed only for the default single-GPU workload AND only while
     that hash equals the current sources' -- a stale file yields null, never an old number."""
-    path = ROOT / "profiles" / "r04_pmc_fetch_size.json"
+    path = ROOT / "profiles" / "r05_pmc_fetch_size.json"
     if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not path.exists() or "bf16" in sys.argv:
         return None, None
     if any(os.environ.get(v) for v in ("VK_FLAT_FORCE_SCAN", "VK_GEMM_MODE", "VK_GEMM_ABLATE", "VK_GEMM_LOCKSTEP", "VK_FILTER_TIMING", "VK_FLAT_FILTER")):
         return None, None
     j = json.load(open(path))
     if j.get("src_sha256") != source_sha256():
-        return None, "profiles/r04_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
+        return None, "profiles/r05_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
     for name, v in j.get("kernels", {}).items():
         if kernel_prefix in name and "prepass" not in name and "[small]" not in name:
-            return round(v["hbm_bytes_per_launch"]), "profiles/r04_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
+            return round(v["hbm_bytes_per_launch"]), "profiles/r05_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
     return None, None
 
 

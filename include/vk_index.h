@@ -186,6 +186,15 @@ typedef struct vk_index_stats {
    * 2 = buckets in memory with counts in LDS, 3 = the 12 KB set in LDS (spill to memory), 5 = the 32 KB set in LDS
    * (option hnsw-visited-mode picks among what fits; bench.py names the kernel it timed from this, not from ef) */
   uint64_t last_visited_mode;
+  /* the dispatcher's runner threads, summed over the runners, in microseconds since the index was created: waiting for
+   * requests, inside the batching window, inside the batch's search (upload + kernels + download: two batches in flight
+   * overlap on the device, so this can exceed wall time), handing answers out themselves; and the completer threads' time
+   * inside the callers' completion callbacks (option completer-threads) */
+  uint64_t dispatch_idle_us;
+  uint64_t dispatch_window_us;
+  uint64_t dispatch_search_us;
+  uint64_t dispatch_handout_us;
+  uint64_t dispatch_completer_us;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------

@@ -114,95 +114,115 @@ class VkFilterRef {
 // (cancel.cc: TimeoutPollFrequency).  While a request is registered here this thread is its only poller.
 class VkTokenWatch {
  public:
-  using Handle = uint32_t;   // a slot of the slab below
+  using Handle = uint32_t;   // slot << 3 | shard
   static VkTokenWatch &Instance() {
     static VkTokenWatch *w = new VkTokenWatch();   // (never destroyed: requests may complete during static destruction)
     return *w;
   }
+  // (the slab is cut into kShards pieces with a lock each: one lock was taken twice per request by every reader thread and
+  //  every completion thread, and by the watcher while it swept)
   Handle Register(cancel::Token token, volatile int *word, std::optional<std::chrono::steady_clock::time_point> deadline) {
-    std::lock_guard<std::mutex> lk(mu_);
-    Handle h;
-    if (!free_.empty()) {
-      h = free_.back();
-      free_.pop_back();
-    } else {
-      h = (Handle)slots_.size();
-      slots_.emplace_back();
+    const uint32_t si = next_shard_.fetch_add(1, std::memory_order_relaxed) & (kShards - 1);
+    Shard &sh = shards_[si];
+    uint32_t slot;
+    {
+      std::lock_guard<std::mutex> lk(sh.mu);
+      if (!sh.free.empty()) {
+        slot = sh.free.back();
+        sh.free.pop_back();
+      } else {
+        slot = (uint32_t)sh.slots.size();
+        sh.slots.emplace_back();
+      }
+      Slot &e = sh.slots[slot];
+      e.token = std::move(token);
+      e.word = word;
+      e.has_deadline = deadline.has_value();
+      if (deadline) e.deadline = *deadline;
+      e.live = true;
     }
-    Slot &e = slots_[h];
-    e.token = std::move(token);
-    e.word = word;
-    e.has_deadline = deadline.has_value();
-    if (deadline) e.deadline = *deadline;
-    e.live = true;
-    const bool was_idle = live_++ == 0;
-    if (!started_) {
-      started_ = true;
-      std::thread([this] { Loop(); }).detach();
+    // (the watcher is woken only out of its idle wait: a notify per registration made it sweep once per request)
+    if (live_.fetch_add(1, std::memory_order_acq_rel) == 0) {
+      std::lock_guard<std::mutex> lk(idle_mu_);
+      if (!started_) {
+        started_ = true;
+        std::thread([this] { Loop(); }).detach();
+      }
+      idle_cv_.notify_one();
     }
-    // (only out of the idle wait: a notify per registration made the watcher sweep -- under this mutex -- once per request,
-    //  and 16 reader threads queued behind it: 13 k QPS where the library does 350 k)
-    if (was_idle) cv_.notify_one();
-    return h;
+    return (slot << 3) | si;
   }
   void Unregister(Handle h) {   // after this returns the watcher no longer touches the token or the word
-    std::lock_guard<std::mutex> lk(mu_);
-    Slot &e = slots_[h];
-    e.live = false;
-    e.token.reset();
-    e.word = nullptr;
-    free_.push_back(h);
-    live_ -= 1;
+    Shard &sh = shards_[h & (kShards - 1)];
+    cancel::Token dropped;      // (released outside the lock)
+    {
+      std::lock_guard<std::mutex> lk(sh.mu);
+      Slot &e = sh.slots[h >> 3];
+      e.live = false;
+      dropped = std::move(e.token);
+      e.word = nullptr;
+      sh.free.push_back(h >> 3);
+    }
+    live_.fetch_sub(1, std::memory_order_acq_rel);
   }
 
  private:
+  static constexpr uint32_t kShards = 8;
   struct Slot {
     cancel::Token token;
     volatile int *word = nullptr;                                       // raised once, never lowered
     std::chrono::steady_clock::time_point deadline{};                   // when known: the token is confirmed right there
     bool has_deadline = false, live = false;
   };
+  struct Shard {
+    std::mutex mu;
+    std::vector<Slot> slots;
+    std::vector<uint32_t> free;
+    size_t cursor = 0;
+  };
   static constexpr int kBurst = 128;            // > TimeoutPollFrequency: forces one look at the clock
   // A tick every 200 us looks at every request with a known deadline that has passed, and at 1/25 of the others (each token
-  // is polled about every 5 ms: its own cadence is one look at the clock per 100 polls anyway).  The slab is contiguous and
-  // the lock is dropped every 256 slots: with 32 768 requests in flight the registering threads still get through.
+  // is polled about every 5 ms: its own cadence is one look at the clock per 100 polls anyway).  A shard's slab is contiguous
+  // and its lock is dropped every 256 slots: with 32 768 requests in flight the registering threads still get through.
   void Loop() {
-    std::unique_lock<std::mutex> lk(mu_);
-    size_t cursor = 0;
     for (;;) {
-      if (live_ == 0) cv_.wait(lk, [&] { return live_ != 0; });
-      else cv_.wait_until(lk, next_tick_);
-      const auto now = std::chrono::steady_clock::now();
-      if (now < next_tick_) continue;   // (woken early: the tick is kept)
-      next_tick_ = now + std::chrono::microseconds(200);
-      const size_t n = slots_.size();
-      size_t slow_budget = std::max<size_t>(64, n / 25);
-      for (size_t i = 0; i < n; ++i) {
-        if ((i & 255) == 255) { lk.unlock(); lk.lock(); if (slots_.size() < n) break; }
-        Slot &e = slots_[i];
-        if (!e.live || *e.word) continue;
-        bool up = false;
-        if (e.has_deadline) {
-          if (now < e.deadline) continue;
-          for (int b = 0; b < kBurst && !up; ++b) up = e.token->IsCancelled();
-        } else {
-          // round robin over the tokens without a deadline
-          if (slow_budget == 0 || (i < cursor && cursor < n)) continue;
-          slow_budget -= 1;
-          cursor = i + 1;
-          up = e.token->IsCancelled();
-        }
-        if (up) __atomic_store_n(const_cast<int *>(e.word), 1, __ATOMIC_RELAXED);
+      if (live_.load(std::memory_order_acquire) == 0) {
+        std::unique_lock<std::mutex> lk(idle_mu_);
+        idle_cv_.wait(lk, [&] { return live_.load(std::memory_order_acquire) != 0; });
+      } else {
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
       }
-      if (cursor >= n || slow_budget != 0) cursor = 0;
+      const auto now = std::chrono::steady_clock::now();
+      for (Shard &sh : shards_) {
+        std::unique_lock<std::mutex> lk(sh.mu);
+        const size_t n = sh.slots.size();
+        size_t slow_budget = std::max<size_t>(16, n / 25);
+        for (size_t i = 0; i < n; ++i) {
+          if ((i & 255) == 255) { lk.unlock(); lk.lock(); if (sh.slots.size() < n) break; }
+          Slot &e = sh.slots[i];
+          if (!e.live || *e.word) continue;
+          bool up = false;
+          if (e.has_deadline) {
+            if (now < e.deadline) continue;
+            for (int b = 0; b < kBurst && !up; ++b) up = e.token->IsCancelled();
+          } else {
+            // round robin over the tokens without a deadline
+            if (slow_budget == 0 || (i < sh.cursor && sh.cursor < n)) continue;
+            slow_budget -= 1;
+            sh.cursor = i + 1;
+            up = e.token->IsCancelled();
+          }
+          if (up) __atomic_store_n(const_cast<int *>(e.word), 1, __ATOMIC_RELAXED);
+        }
+        if (sh.cursor >= n || slow_budget != 0) sh.cursor = 0;
+      }
     }
   }
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::vector<Slot> slots_;
-  std::vector<Handle> free_;
-  size_t live_ = 0;
-  std::chrono::steady_clock::time_point next_tick_{};
+  Shard shards_[kShards];
+  std::atomic<uint32_t> next_shard_{0};
+  std::atomic<size_t> live_{0};
+  std::mutex idle_mu_;
+  std::condition_variable idle_cv_;
   bool started_ = false;
 };
 
@@ -298,8 +318,8 @@ class VectorGpu : public VectorBase {
     auto *rq = new AsyncSearch();
     rq->self = this;
     rq->done = std::move(done);
-    rq->dist.resize(count);
-    rq->label.resize(count);
+    rq->out.reset(new uint64_t[count + (count + 1) / 2]);   // labels, then distances: one allocation
+    rq->dist = reinterpret_cast<float *>(rq->out.get() + count);
     rq->filter = std::move(filter);
     rq->cancel_word = cancellation_token && cancellation_token->IsCancelled() ? 1 : 0;
     rq->watched = static_cast<bool>(cancellation_token) && !rq->cancel_word;
@@ -307,7 +327,7 @@ class VectorGpu : public VectorBase {
     std::vector<T> normalised;
     const void *q = NormalisedQuery(query, &normalised);   // (the library copies the query at submission)
     const int rc = vk_index_search_submit_filter(ix_, q, count, ef_runtime.value_or(0), rq->filter.get(), &rq->cancel_word,
-                                                 enable_partial_results ? 1 : 0, rq->dist.data(), rq->label.data(), &rq->n,
+                                                 enable_partial_results ? 1 : 0, rq->dist, rq->out.get(), &rq->n,
                                                  &AsyncSearch::Completed, rq);
     if (rc != VK_OK) {
       if (rq->watched) VkTokenWatch::Instance().Unregister(rq->watch);
@@ -377,7 +397,7 @@ class VectorGpu : public VectorBase {
     // costs the same for 1 query or 256 (and its window waits for the callers of the batch that has just finished), an HNSW
     // launch wants thousands of waves.  A lone query is held for a quarter of the window at most.
     const uint32_t device_batch = algo_ == VK_ALGO_FLAT ? 256u : 8192u;
-    return VkToStatus(vk_index_set_coalescing(ix_, std::max(reader_threads, device_batch), algo_ == VK_ALGO_FLAT ? 400 : 800));
+    return VkToStatus(vk_index_set_coalescing(ix_, std::max(reader_threads, device_batch), algo_ == VK_ALGO_FLAT ? 400 : 2000));
   }
   // an index that exists already (built by a bulk loader, or -- scripts/adaptor_probe.cc -- by the benchmark): served through
   // this object, destroyed by whoever made it.  The caller keeps it alive until every search through this object is done.
@@ -549,8 +569,8 @@ class VectorGpu : public VectorBase {
   struct AsyncSearch {
     VectorGpu *self = nullptr;
     SearchDone done;
-    std::vector<float> dist;
-    std::vector<uint64_t> label;
+    std::unique_ptr<uint64_t[]> out;   // the library's answer: labels [count], distances [count]
+    float *dist = nullptr;
     uint64_t n = 0;
     VkFilterRef filter;
     volatile int cancel_word = 0;
@@ -560,7 +580,7 @@ class VectorGpu : public VectorBase {
       std::unique_ptr<AsyncSearch> rq(static_cast<AsyncSearch *>(user));
       if (rq->watched) VkTokenWatch::Instance().Unregister(rq->watch);
       if (status != VK_OK) rq->done(VkCompletionStatus(status));
-      else rq->done(rq->self->Reply(rq->dist.data(), rq->label.data(), rq->n));
+      else rq->done(rq->self->Reply(rq->dist, rq->out.get(), rq->n));
     }
   };
 

@@ -1,10 +1,12 @@
 // adaptor_probe.cc -- single-query FT.SEARCH traffic THROUGH THE ADAPTOR CLASSES (include/vk_vector_adaptor.h: VectorGpuFlat /
 // VectorGpuHNSW derived from the mock of VectorBase, tests/helpers/mock_valkey_search.h), driven natively against an index
 // the benchmark already holds (adopted, not owned).  The shape is query::SearchAsync's (src/query/search.cc:886-910):
-//   a "main thread" keeps `window` FT.SEARCH requests outstanding (the clients' concurrency) and schedules each on a reader
-//   pool of `readers` threads (reader-threads = the box's cores); the pool task calls
-//     async    VectorGpu::SearchAsync -- returns after the submission; the library's completion re-posts a task to the pool
-//              that takes the reply (CreateReply's key lookups already done) and frees the request slot, or
+//   `fronts` front threads (the main thread and the io threads that parse commands next to it) keep `window` FT.SEARCH
+//   requests outstanding between them (the clients' concurrency) and schedule each on a reader pool of `readers` threads
+//   (reader-threads = the box's cores); the pool task calls
+//     async    VectorGpu::SearchAsync -- returns after the submission; the library's completion thread takes the reply
+//              (CreateReply's key lookups already done), compares it and hands the request slot back to its front thread
+//              (the RunByMain step of the reference's callback), or
 //     blocking VectorGpu::Search      -- what PerformVectorSearch does today (search.cc:135-170): the pool thread is parked
 //              until the answer is there, so at most `readers` queries are in flight.
 // Every reply is compared with a reference answer of the same query (ids and distance bits).  bench.py:
@@ -47,41 +49,53 @@ struct NeverCancelled : cancel::Base {
   void Cancel() override {}
 };
 
-// vmsdk::ThreadPool in a dozen lines: FIFO, `n` workers
+// vmsdk::ThreadPool's role -- `n` workers taking tasks in order -- with a queue PER WORKER (tasks are dealt round robin): with
+// one queue, one mutex, the 4 lock operations per request of 16 workers, the front threads and the library's completer
+// threads were what bounded the request rate (r05_pipeline1.log: 15-60 us inside each completion callback)
 class Pool {
  public:
-  explicit Pool(int n) {
-    for (int i = 0; i < n; ++i) ts_.emplace_back([this] { Run(); });
+  explicit Pool(int n) : ws_((size_t)n) {
+    for (int i = 0; i < n; ++i) ws_[(size_t)i].t = std::thread([this, i] { Run(ws_[(size_t)i]); });
   }
   ~Pool() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-    cv_.notify_all();
-    for (auto &t : ts_) t.join();
+    for (auto &w : ws_) {
+      { std::lock_guard<std::mutex> lk(w.mu); w.stop = true; }
+      w.cv.notify_all();
+    }
+    for (auto &w : ws_) w.t.join();
   }
   void Schedule(std::function<void()> f) {
-    { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); }
-    cv_.notify_one();
+    Worker &w = ws_[next_.fetch_add(1, std::memory_order_relaxed) % ws_.size()];
+    bool wake;
+    { std::lock_guard<std::mutex> lk(w.mu); w.q.push_back(std::move(f)); wake = w.idle; }
+    if (wake) w.cv.notify_one();
   }
 
  private:
-  void Run() {
+  struct Worker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::thread t;
+    bool idle = false, stop = false;
+  };
+  void Run(Worker &w) {
+    std::deque<std::function<void()>> mine;
     for (;;) {
-      std::function<void()> f;
       {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
-        if (q_.empty()) return;
-        f = std::move(q_.front());
-        q_.pop_front();
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.idle = true;
+        w.cv.wait(lk, [&] { return w.stop || !w.q.empty(); });
+        w.idle = false;
+        if (w.q.empty()) return;
+        mine.swap(w.q);   // (everything that is there: one lock operation for the lot)
       }
-      f();
+      for (auto &f : mine) f();
+      mine.clear();
     }
   }
-  std::mutex mu_;
-  std::condition_variable cv_;
-  std::deque<std::function<void()>> q_;
-  std::vector<std::thread> ts_;
-  bool stop_ = false;
+  std::vector<Worker> ws_;
+  std::atomic<uint64_t> next_{0};
 };
 
 struct Run {
@@ -89,10 +103,6 @@ struct Run {
   const uint64_t *ref_l;
   uint64_t k;
   std::atomic<uint64_t> completed{0}, mismatches{0}, errors{0}, rejected{0};
-  std::mutex mu;
-  std::condition_variable cv;
-  int free_slots = 0;
-  std::vector<float> lat_us;
   bool same(uint64_t qi, const std::vector<Neighbor> &r) const {
     if (!ref_d) return true;
     if (r.size() != k) return false;
@@ -102,63 +112,97 @@ struct Run {
     }
     return true;
   }
+};
+
+// one front thread (the main thread, or one of the io threads that parse commands next to it): its share of the clients'
+// concurrency and of the requests
+struct Front {
+  Run *run = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  int free_slots = 0, window = 0;
+  bool waiting = false;
+  std::vector<float> lat_us;
   void finish(uint64_t qi, Clock::time_point t0, const absl::StatusOr<std::vector<Neighbor>> &r) {
     const float us = (float)std::chrono::duration<double, std::micro>(Clock::now() - t0).count();
-    if (!r.ok()) errors.fetch_add(1, std::memory_order_relaxed);
-    else if (!same(qi, r.value())) mismatches.fetch_add(1, std::memory_order_relaxed);
-    completed.fetch_add(1, std::memory_order_relaxed);
+    if (!r.ok()) run->errors.fetch_add(1, std::memory_order_relaxed);
+    else if (!run->same(qi, r.value())) run->mismatches.fetch_add(1, std::memory_order_relaxed);
+    run->completed.fetch_add(1, std::memory_order_relaxed);
+    bool wake;
     {
       std::lock_guard<std::mutex> lk(mu);
       lat_us.push_back(us);
       free_slots += 1;
+      wake = waiting;
     }
-    cv.notify_one();
+    if (wake) cv.notify_one();
   }
 };
 
 template <class Ix>
-int drive(Ix &ix, const float *queries, uint64_t nq, uint32_t dim, uint64_t k, uint64_t ef, int readers, int window, uint64_t total, int blocking,
-          Run &run, vk_probe_result *out) {
+int drive(Ix &ix, const float *queries, uint64_t nq, uint32_t dim, uint64_t k, uint64_t ef, int readers, int fronts, int window, uint64_t total,
+          int blocking, Run &run, vk_probe_result *out) {
   vk_index_stats st0{}, st1{};
   vk_index_get_stats(ix.handle(), &st0);
-  run.free_slots = window;
-  run.lat_us.reserve((size_t)total + 16);
+  fronts = std::max(1, std::min(fronts, window));
+  std::vector<std::unique_ptr<Front>> fs;
+  for (int f = 0; f < fronts; ++f) {
+    fs.emplace_back(new Front());
+    fs.back()->run = &run;
+    fs.back()->window = fs.back()->free_slots = window / fronts + (f < window % fronts ? 1 : 0);
+    fs.back()->lat_us.reserve((size_t)(total / fronts) + 16);
+  }
   cancel::Token token = std::make_shared<NeverCancelled>();
   const Clock::time_point t0 = Clock::now();
   {
     Pool pool(readers);
-    for (uint64_t i = 0; i < total; ++i) {
-      {   // the clients' concurrency: `window` requests outstanding
-        std::unique_lock<std::mutex> lk(run.mu);
-        run.cv.wait(lk, [&] { return run.free_slots > 0; });
-        run.free_slots -= 1;
+    auto front_loop = [&](int f) {
+      Front &me = *fs[f];
+      const uint64_t share = total / fronts + ((uint64_t)f < total % fronts ? 1 : 0);
+      int slots = 0;
+      for (uint64_t i = 0; i < share; ++i) {
+        if (slots == 0) {   // the clients' concurrency: `window` requests outstanding (every free slot is taken at once)
+          std::unique_lock<std::mutex> lk(me.mu);
+          me.waiting = true;
+          me.cv.wait(lk, [&] { return me.free_slots > 0; });
+          me.waiting = false;
+          slots = me.free_slots;
+          me.free_slots = 0;
+        }
+        slots -= 1;
+        const uint64_t qi = (i * fronts + f) % nq;
+        const Clock::time_point ts = Clock::now();
+        pool.Schedule([&, qi, ts] {
+          absl::string_view q(reinterpret_cast<const char *>(queries + qi * dim), (size_t)dim * 4);
+          std::optional<size_t> efo;
+          if (ef) efo = (size_t)ef;
+          if (blocking) {
+            cancel::Token tk = token;
+            me.finish(qi, ts, ix.Search(q, k, tk, VkFilterRef(), efo, false));
+            return;
+          }
+          for (;;) {
+            absl::Status st = ix.SearchAsync(q, k, token, VkFilterRef(), efo, false, [&me, qi, ts](absl::StatusOr<std::vector<Neighbor>> r) {
+              // (a library thread in the role of the pool thread that runs the callback of query::SearchAsync today,
+              //  search.cc:905-908: the neighbours are checked here and the slot goes back to the front thread -- RunByMain)
+              me.finish(qi, ts, r);
+            });
+            if (st.ok()) break;
+            if (st.code() != absl::StatusCode::kResourceExhausted) { me.finish(qi, ts, st); break; }
+            run.rejected.fetch_add(1, std::memory_order_relaxed);
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+          }
+        });
       }
-      const uint64_t qi = i % nq;
-      const Clock::time_point ts = Clock::now();
-      pool.Schedule([&, qi, ts] {
-        absl::string_view q(reinterpret_cast<const char *>(queries + qi * dim), (size_t)dim * 4);
-        std::optional<size_t> efo;
-        if (ef) efo = (size_t)ef;
-        if (blocking) {
-          cancel::Token tk = token;
-          run.finish(qi, ts, ix.Search(q, k, tk, VkFilterRef(), efo, false));
-          return;
-        }
-        for (;;) {
-          absl::Status st = ix.SearchAsync(q, k, token, VkFilterRef(), efo, false, [&run, &pool, qi, ts](absl::StatusOr<std::vector<Neighbor>> r) {
-            // (a library thread: the reply goes back to the pool, like ResolveContent / QueryCompleteBackground)
-            auto shared = std::make_shared<absl::StatusOr<std::vector<Neighbor>>>(std::move(r));
-            pool.Schedule([&run, qi, ts, shared] { run.finish(qi, ts, *shared); });
-          });
-          if (st.ok()) break;
-          if (st.code() != absl::StatusCode::kResourceExhausted) { run.finish(qi, ts, st); break; }
-          run.rejected.fetch_add(1, std::memory_order_relaxed);
-          std::this_thread::sleep_for(std::chrono::microseconds(50));
-        }
-      });
-    }
-    std::unique_lock<std::mutex> lk(run.mu);
-    run.cv.wait(lk, [&] { return run.free_slots == window; });
+      std::unique_lock<std::mutex> lk(me.mu);
+      me.free_slots += slots;
+      me.waiting = true;
+      me.cv.wait(lk, [&] { return me.free_slots == me.window; });
+    };
+    std::vector<std::thread> ts;
+    for (int f = 1; f < fronts; ++f) ts.emplace_back(front_loop, f);
+    front_loop(0);
+    for (auto &t : ts) t.join();
   }   // (the pool drains and joins)
   out->seconds = std::chrono::duration<double>(Clock::now() - t0).count();
   vk_index_get_stats(ix.handle(), &st1);
@@ -170,7 +214,8 @@ int drive(Ix &ix, const float *queries, uint64_t nq, uint32_t dim, uint64_t k, u
   out->device_batches = st1.coalesced_batches - st0.coalesced_batches;
   out->mean_batch = out->device_batches ? (double)(st1.coalesced_queries - st0.coalesced_queries) / (double)out->device_batches : 0;
   out->max_batches_in_flight = st1.max_batches_in_flight;
-  std::vector<float> &v = run.lat_us;
+  std::vector<float> v;
+  for (auto &f : fs) v.insert(v.end(), f->lat_us.begin(), f->lat_us.end());
   if (!v.empty()) {
     std::sort(v.begin(), v.end());
     out->p50_us = v[v.size() / 2];
@@ -183,7 +228,7 @@ int drive(Ix &ix, const float *queries, uint64_t nq, uint32_t dim, uint64_t k, u
 
 // `ix` stays the caller's; max_batch / wait_us: the coalescing the adaptor would set from reader-threads (0 = its defaults)
 extern "C" int vk_adaptor_probe(vk_index *ix, int hnsw, uint32_t dim, uint32_t m, const float *queries, uint64_t nq, uint64_t k, uint64_t ef,
-                                int readers, int window, uint64_t total, int blocking, uint32_t max_batch, uint32_t wait_us, const float *ref_d,
+                                int readers, int fronts, int window, uint64_t total, int blocking, uint32_t max_batch, uint32_t wait_us, const float *ref_d,
                                 const uint64_t *ref_l, vk_probe_result *out) {
   memset(out, 0, sizeof(*out));
   if (!ix || !queries || nq == 0 || readers < 1 || window < 1) return VK_ERR_INVALID;
@@ -202,13 +247,13 @@ extern "C" int vk_adaptor_probe(vk_index *ix, int hnsw, uint32_t dim, uint32_t m
     if (!a.ok()) return VK_ERR_INTERNAL;
     a.value()->MockAllKeysLive();
     if (max_batch) vk_index_set_coalescing(ix, max_batch, wait_us);
-    rc = drive(*a.value(), queries, nq, dim, k, ef, readers, window, total, blocking, run, out);
+    rc = drive(*a.value(), queries, nq, dim, k, ef, readers, fronts, window, total, blocking, run, out);
   } else {
     auto a = VectorGpuFlat<float>::FromHandle(ix, proto, "v", data_model::ATTRIBUTE_DATA_TYPE_HASH, (uint32_t)readers);
     if (!a.ok()) return VK_ERR_INTERNAL;
     a.value()->MockAllKeysLive();
     if (max_batch) vk_index_set_coalescing(ix, max_batch, wait_us);
-    rc = drive(*a.value(), queries, nq, dim, k, ef, readers, window, total, blocking, run, out);
+    rc = drive(*a.value(), queries, nq, dim, k, ef, readers, fronts, window, total, blocking, run, out);
   }
   return rc;
 }

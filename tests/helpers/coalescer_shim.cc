@@ -226,6 +226,9 @@ extern "C" int dispatcher_async_run(int producers, int per_producer, int window,
     if (dp.rejected() != rejected.load()) bad += 1;
     if (dp.submitted() != completions.load()) bad += 1;
     out[2] = dp.max_in_flight_seen();
+    // (bits 0-31: the completer threads' time inside callbacks, bits 32-63: what the runners handed out themselves; us)
+    const vk::Dispatcher::Times tm = dp.times();
+    out[7] = (std::min<uint64_t>(tm.handout_us, 0xFFFFFFFFull) << 32) | std::min<uint64_t>(tm.completer_us, 0xFFFFFFFFull);
   }   // (the dispatcher is destroyed with nothing queued)
   out[0] = ix.calls;
   out[1] = ix.max_batch;

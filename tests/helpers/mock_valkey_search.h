@@ -21,6 +21,7 @@
 #include <queue>
 #include <string>
 #include <string_view>
+#include <unordered_map>
 #include <unordered_set>
 #include <utility>
 #include <variant>
@@ -218,7 +219,13 @@ class VectorBase {
       std::lock_guard<std::mutex> l(mock_mu_);
       if (!mock_live_.count(internal_id)) return absl::InvalidArgumentError("Record was not found");
     }
-    return std::make_shared<InternedString>(std::to_string(internal_id));
+    // The real class FINDS the interned key (key_by_internal_id_.find, vector_base.cc:212-219: a hash lookup and a reference
+    // count, no allocation): the mock's keys are made on first use and kept
+    KeyShard &sh = mock_keys_[internal_id & (kKeyShards - 1)];
+    std::lock_guard<std::mutex> l(sh.mu);
+    auto it = sh.map.find(internal_id);
+    if (it == sh.map.end()) it = sh.map.emplace(internal_id, std::make_shared<InternedString>(std::to_string(internal_id))).first;
+    return it->second;
   }
   void MockAllKeysLive() { mock_all_live_ = true; }   // (an adopted index: every label has its key)
   // vector_base.cc:333-338: the VectorTracker entry LoadIndex calls -- intern, then the virtual
@@ -294,6 +301,12 @@ class VectorBase {
     return (uint64_t)id;
   }
 
+  static constexpr uint64_t kKeyShards = 64;
+  struct KeyShard {
+    std::mutex mu;
+    std::unordered_map<uint64_t, InternedStringPtr> map;
+  };
+  mutable KeyShard mock_keys_[kKeyShards];
   mutable std::mutex mock_mu_;
   std::unordered_set<uint64_t> mock_live_;
   bool mock_all_live_ = false;

@@ -94,7 +94,7 @@ def arun(lib, producers, per, window, max_batch, wait_us, in_flight, depth, dela
     out = (C.c_uint64 * 8)()
     bad = lib.dispatcher_async_run(producers, per, window, max_batch, wait_us, in_flight, depth, delay_us, hnsw, out)
     return bad, {"calls": out[0], "max_batch": out[1], "in_flight": out[2], "rejected": out[3], "completions": out[4],
-                 "cancelled": out[5], "concurrent_passes": out[6]}
+                 "cancelled": out[5], "concurrent_passes": out[6], "completer_us": out[7] & 0xFFFFFFFF, "runner_handout_us": out[7] >> 32}
 
 
 def test_submit_completes_every_request_once_with_two_batches_in_flight(shim):
@@ -178,9 +178,14 @@ def test_a_queued_submitted_request_is_answered_when_its_token_goes_up(shim, hns
     assert out[0] < 3000 and out[1] == 31, list(out)[:2]      # (the queue is looked at every millisecond, a lane at a time)
 
 
-def test_large_batches_are_answered_by_the_completer_threads(shim):
-    """Batches of 1024 members or more hand their answers out on a completer thread (8192 callbacks take as long as the device
-    pass; the runner forms the next batch meanwhile): every request still completes exactly once with its own answer, the
-    destructor waits for what the completers still hold."""
+def test_batches_with_callbacks_are_answered_by_the_completer_threads(shim):
+    """A batch whose members carry callbacks is cut into pieces that the completer threads hand out side by side (8192 callbacks
+    take as long as the device pass, 256 of the adaptor's delayed the next FLAT pass by a quarter of its length; the runner
+    forms the next batch meanwhile): every request still completes exactly once with its own answer, the destructor waits for
+    what the completers still hold, and the dispatcher's own account shows who spent the time."""
     bad, st = arun(shim, 8, 1500, 1500, 4096, 3000, 2, 100000, delay_us=2000, hnsw=1)
     assert bad == 0 and st["completions"] == 12000 and st["rejected"] == 0 and st["max_batch"] >= 1024, st
+    assert st["completer_us"] > 0, st
+    # ... FLAT batches of 64 too (the old rule left everything under 1024 members to the runner)
+    bad, st = arun(shim, 4, 600, 256, 64, 500, 2, 100000, delay_us=500, hnsw=0)
+    assert bad == 0 and st["completions"] == 2400 and st["completer_us"] > 0, st

@@ -56,7 +56,9 @@ class Stats(C.Structure):
                 ("last_filter_reranked", C.c_uint64), ("max_label", C.c_uint64), ("cancelled_early", C.c_uint64),
                 ("filters_built", C.c_uint64), ("filter_cache_hits", C.c_uint64), ("filter_cache_misses", C.c_uint64),
                 ("filter_cache_entries", C.c_uint64), ("filter_cache_bytes", C.c_uint64),
-                ("staged_adds", C.c_uint64), ("staged_adds_device", C.c_uint64), ("last_visited_mode", C.c_uint64)]
+                ("staged_adds", C.c_uint64), ("staged_adds_device", C.c_uint64), ("last_visited_mode", C.c_uint64),
+                ("dispatch_idle_us", C.c_uint64), ("dispatch_window_us", C.c_uint64), ("dispatch_search_us", C.c_uint64),
+                ("dispatch_handout_us", C.c_uint64), ("dispatch_completer_us", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -602,10 +604,10 @@ def probe_blocking(ix, Q, k, threads, calls, ef=0, ref=None):
 _aprobe = None
 
 
-def adaptor_probe(ix, Q, k, total, readers, window, ef=0, hnsw=False, m=16, blocking=False, max_batch=0, wait_us=0, ref=None):
+def adaptor_probe(ix, Q, k, total, readers, window, ef=0, hnsw=False, m=16, blocking=False, max_batch=0, wait_us=0, ref=None, fronts=1):
     """scripts/adaptor_probe.cc: single-query traffic through VectorGpuFlat / VectorGpuHNSW (include/vk_vector_adaptor.h over the
     mock of VectorBase) adopted onto `ix`: `window` FT.SEARCHes outstanding, a reader pool of `readers` threads, SearchAsync
-    (or, blocking=True, Search).  max_batch = 0: the coalescing the adaptor sets itself."""
+    (or, blocking=True, Search), `fronts` threads feeding the pool.  max_batch = 0: the coalescing the adaptor sets itself."""
     global _aprobe
     if _aprobe is None:
         path = PKG_DIR.parent / "scripts" / "libadaptorprobe.so"
@@ -614,13 +616,13 @@ def adaptor_probe(ix, Q, k, total, readers, window, ef=0, hnsw=False, m=16, bloc
         lib()
         P = C.CDLL(str(path))
         vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
-        P.vk_adaptor_probe.argtypes = [vp, i32, u32, u32, vp, u64, u64, u64, i32, i32, u64, i32, u32, u32, vp, vp, C.POINTER(ProbeResult)]
+        P.vk_adaptor_probe.argtypes = [vp, i32, u32, u32, vp, u64, u64, u64, i32, i32, i32, u64, i32, u32, u32, vp, vp, C.POINTER(ProbeResult)]
         _aprobe = P
     Q = np.ascontiguousarray(Q, dtype=np.float32)
     rd = rl = None
     if ref is not None:
         rd, rl = np.ascontiguousarray(ref[0], dtype=np.float32), np.ascontiguousarray(ref[1], dtype=np.uint64)
     r = ProbeResult()
-    _check(_aprobe.vk_adaptor_probe(ix._h, int(hnsw), Q.shape[1], int(m), _ptr(Q), Q.shape[0], k, ef, readers, window, total, int(blocking),
+    _check(_aprobe.vk_adaptor_probe(ix._h, int(hnsw), Q.shape[1], int(m), _ptr(Q), Q.shape[0], k, ef, readers, int(fronts), window, total, int(blocking),
                                     int(max_batch), int(wait_us), _ptr(rd), _ptr(rl), C.byref(r)))
     return r

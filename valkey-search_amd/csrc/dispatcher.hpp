@@ -19,6 +19,12 @@
 // batch waits until the batch is full, the oldest request has waited max_wait_us, or nobody has arrived for a quarter
 // of that (20-200 us): callers of the batch that just finished come back within microseconds of each other.
 //
+// COMPLETER threads (option completer-threads, default 4) hand the answers of a finished batch to the callers' callbacks,
+// a piece of the batch each: a callback runs the caller's code (the adaptor builds the neighbour list and posts it on; 7-18 us
+// each measured), and with the runner doing that a FLAT pass started 1.5 ms late (0.77 of the device rate through the
+// adaptor, 0.98 with completers) and an HNSW runner spent more time answering than searching (0.35 -> 0.86).
+// vk_index_stats.dispatch_*_us is the dispatcher's own account of where its threads' time goes.
+//
 // Ownership.  A request OWNS its query (copied at submission: 4 * dim bytes) and holds a reference on its filter when that
 // is a device-resident FilterSet (filter_set.hpp); results are written to the caller's buffers only by whoever wins the
 // request's state word (kInBatch -> kCompleting).  A caller therefore need not outlive its batch: it may LEAVE.  (A raw
@@ -84,6 +90,11 @@ class Dispatcher {
     cv_.notify_all();
   }
   void set_queue_depth(uint64_t d) { queue_depth_.store(d, std::memory_order_relaxed); }
+  // completer threads (0 = answers are handed out by the runner that ran the batch) and members per piece of hand-out work
+  void set_completers(uint32_t threads, uint32_t chunk) {
+    completer_threads_.store(std::min<uint32_t>(threads, 16), std::memory_order_relaxed);
+    handout_chunk_.store(std::max<uint32_t>(chunk, 16), std::memory_order_relaxed);
+  }
   bool enabled() const { return max_batch_.load(std::memory_order_relaxed) > 1; }
   uint64_t batches() const { return batches_.load(std::memory_order_relaxed); }
   uint64_t queries() const { return queries_.load(std::memory_order_relaxed); }
@@ -92,6 +103,15 @@ class Dispatcher {
   uint64_t queued() const { return queued_.load(std::memory_order_relaxed); }
   uint64_t max_in_flight_seen() const { return max_active_seen_.load(std::memory_order_relaxed); }
   uint64_t left_early() const { return left_early_.load(std::memory_order_relaxed); }
+  // where the runner threads' time went, summed over the runners (microseconds): waiting for a lane, inside the batching
+  // window, inside Index::search (upload + kernels + download; two runners overlap on the device), handing answers out
+  // on the runner itself -- and the completer threads' time inside the callers' callbacks
+  struct Times { uint64_t idle_us, window_us, search_us, handout_us, completer_us; };
+  Times times() const {
+    return Times{t_idle_.load(std::memory_order_relaxed) / 1000, t_window_.load(std::memory_order_relaxed) / 1000,
+                 t_search_.load(std::memory_order_relaxed) / 1000, t_handout_.load(std::memory_order_relaxed) / 1000,
+                 t_completer_.load(std::memory_order_relaxed) / 1000};
+  }
 
   // vk_index_search_submit: queue one single-query request and return.  `done(user, status)` is called exactly once, from
   // a dispatcher thread, after the outputs have been written (status = the vk_status of the batch the request travelled
@@ -310,12 +330,15 @@ class Dispatcher {
     for (;;) {
       auto it = lanes_.end();
       idle_runners_ += 1;
+      const auto t_a = std::chrono::steady_clock::now();
       cv_.wait(lk, [&] {
         if (active_ < in_flight_) it = pick_lane();
         return it != lanes_.end() || (stop_ && queued_.load(std::memory_order_relaxed) == 0);
       });
       idle_runners_ -= 1;
       if (it == lanes_.end()) return;   // stopping and drained
+      const auto t_b = std::chrono::steady_clock::now();
+      t_idle_.fetch_add(ns_between(t_a, t_b), std::memory_order_relaxed);
       const Key key = it->first;
       Lane *lane = &it->second;
       lane->collector = true;
@@ -352,6 +375,7 @@ class Dispatcher {
       lane->collector = false;
       if (lane->q.empty()) lanes_.erase(key);   // the map does not grow by one entry per (k, ef) pair ever seen
       else cv_.notify_all();                    // more than a batch was queued: another runner may start on the rest
+      t_window_.fetch_add(ns_between(t_b, std::chrono::steady_clock::now()), std::memory_order_relaxed);
       if (batch.empty()) continue;              // (every queued request of the lane left, cancelled)
       active_ += 1;
       if (active_ > max_active_seen_.load(std::memory_order_relaxed)) max_active_seen_.store(active_, std::memory_order_relaxed);
@@ -409,8 +433,8 @@ class Dispatcher {
     std::vector<const FilterSet *> ftab;
   };
 
-  static constexpr uint64_t kOffloadMin = 1024;
-  struct Done {
+  static constexpr uint64_t kOffloadMin = 32;   // (a couple of callbacks are not worth a thread hand-over)
+  struct Done {   // a finished batch whose answers the completer threads hand out, piece by piece
     std::vector<std::shared_ptr<Req>> batch;
     Scratch sc;
     Status st;
@@ -418,6 +442,13 @@ class Dispatcher {
     uint64_t k = 0;
     bool hnsw = false;
   };
+  struct Piece {
+    std::shared_ptr<Done> d;
+    uint64_t first, count;
+  };
+  static uint64_t ns_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return b > a ? (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() : 0;
+  }
 
   Status search_members(uint64_t k, uint64_t ef, const std::vector<std::shared_ptr<Req>> &batch, size_t first, size_t nq, Scratch &sc,
                         const volatile int *batch_word, const volatile uint32_t *member_words) {
@@ -479,6 +510,7 @@ class Dispatcher {
     Status st = Status::Ok();
     std::shared_ptr<Watched> w;
     std::vector<Status> each;   // per-member status when the batch had to be re-run member by member
+    const auto t_s = std::chrono::steady_clock::now();
     try {
       sc.D.resize(nq * k);
       sc.L.resize(nq * k);
@@ -507,30 +539,38 @@ class Dispatcher {
     if (w) unwatch(w);
     batches_.fetch_add(1, std::memory_order_relaxed);
     queries_.fetch_add(nq, std::memory_order_relaxed);
-    // Handing the answers out -- per member a copy and a callback into the caller's code -- takes as long as the device pass
-    // for a batch of thousands (8192 callbacks: 8-16 ms next to a 14 ms HNSW launch).  Such a batch is passed to a completer
-    // thread and the runner goes back to forming the next one; small batches (a FLAT batch, blocking callers waiting for a
-    // wake-up) are answered right here.
-    if (nq >= kOffloadMin) {
-      auto d = std::make_unique<Done>();
+    const auto t_h = std::chrono::steady_clock::now();
+    t_search_.fetch_add(ns_between(t_s, t_h), std::memory_order_relaxed);
+    // Handing the answers out -- per member a copy and a callback into the caller's code (which builds its reply and posts it
+    // to a pool of its own: microseconds each, more when that pool's lock is contended) -- is not the runner's work: 8192
+    // callbacks take as long as the HNSW launch that produced them, and 256 of them delayed the next FLAT pass by a quarter
+    // of its length.  A batch with callbacks is cut into pieces that the completer threads hand out side by side while the
+    // runner forms the next batch; a batch of blocking callers only (a copy each and ONE wake-up) is answered right here.
+    const uint32_t n_completers = completer_threads_.load(std::memory_order_relaxed);
+    bool any_cb = false;
+    for (uint64_t i = 0; i < nq && !any_cb; ++i) any_cb = batch[i]->cb != nullptr;
+    if (any_cb && n_completers != 0 && nq >= kOffloadMin) {
+      auto d = std::make_shared<Done>();
       d->batch.swap(batch);
       std::swap(d->sc, sc);
       d->st = st;
       d->each.swap(each);
       d->k = k;
       d->hnsw = hnsw;
+      const uint64_t chunk = std::max<uint64_t>(handout_chunk_.load(std::memory_order_relaxed), (nq + 4 * n_completers - 1) / (4 * n_completers));
       std::lock_guard<std::mutex> lk(cmu_);
-      while (completers_.size() < 2) completers_.emplace_back([this] { complete_loop(); });
-      done_q_.push_back(std::move(d));
-      ccv_.notify_one();
+      while (completers_.size() < n_completers) completers_.emplace_back([this] { complete_loop(); });
+      for (uint64_t first = 0; first < nq; first += chunk) done_q_.push_back(Piece{d, first, std::min<uint64_t>(chunk, nq - first)});
+      ccv_.notify_all();
       return;
     }
-    hand_out(batch, sc, st, each, k, hnsw);
+    hand_out(batch, sc, st, each, k, hnsw, 0, nq);
+    t_handout_.fetch_add(ns_between(t_h, std::chrono::steady_clock::now()), std::memory_order_relaxed);
   }
 
-  void hand_out(std::vector<std::shared_ptr<Req>> &batch, Scratch &sc, const Status &st, const std::vector<Status> &each, uint64_t k, bool hnsw) {
-    const uint64_t nq = batch.size();
-    for (uint64_t i = 0; i < nq; ++i) {
+  void hand_out(std::vector<std::shared_ptr<Req>> &batch, Scratch &sc, const Status &st, const std::vector<Status> &each, uint64_t k, bool hnsw,
+                uint64_t first, uint64_t count) {
+    for (uint64_t i = first; i < first + count; ++i) {
       Req &r = *batch[i];
       if (!claim(r)) continue;   // (it left, or was answered when its token went up; its token may be gone: not read)
       Status mine = each.empty() ? st : each[i];
@@ -550,11 +590,13 @@ class Dispatcher {
     for (;;) {
       ccv_.wait(lk, [&] { return cstop_ || !done_q_.empty(); });
       if (done_q_.empty()) return;
-      std::unique_ptr<Done> d = std::move(done_q_.front());
+      Piece p = std::move(done_q_.front());
       done_q_.pop_front();
       lk.unlock();
-      hand_out(d->batch, d->sc, d->st, d->each, d->k, d->hnsw);
-      d.reset();
+      const auto t0 = std::chrono::steady_clock::now();
+      hand_out(p.d->batch, p.d->sc, p.d->st, p.d->each, p.d->k, p.d->hnsw, p.first, p.count);
+      p.d.reset();   // (the last piece frees the batch)
+      t_completer_.fetch_add(ns_between(t0, std::chrono::steady_clock::now()), std::memory_order_relaxed);
       lk.lock();
     }
   }
@@ -659,10 +701,12 @@ class Dispatcher {
   uint32_t max_wait_us_ = 0;
   std::atomic<uint32_t> wake_seq_{0}, sleepers_{0};
   std::atomic<uint64_t> queue_depth_{100000};
+  std::atomic<uint32_t> completer_threads_{4}, handout_chunk_{64};
+  std::atomic<uint64_t> t_idle_{0}, t_window_{0}, t_search_{0}, t_handout_{0}, t_completer_{0};   // nanoseconds
   std::atomic<uint64_t> queued_{0}, batches_{0}, queries_{0}, submitted_{0}, rejected_{0}, max_active_seen_{0}, left_early_{0};
   std::mutex cmu_;
   std::condition_variable ccv_;
-  std::deque<std::unique_ptr<Done>> done_q_;
+  std::deque<Piece> done_q_;
   std::vector<std::thread> completers_;
   bool cstop_ = false;
   std::mutex wmu_;

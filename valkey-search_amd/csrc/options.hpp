@@ -28,6 +28,8 @@ enum OptId : uint32_t {
   kOptCoalesceMaxWaitUs,    // longest time a queued query waits for company
   kOptMaxQueryQueueDepth,   // max-query-queue-depth (valkey_search_options.cc:231-234): submissions beyond it are rejected
   kOptBatchesInFlight,      // device batches the dispatcher keeps in flight per index (collect N+1 while N runs)
+  kOptCompleterThreads,     // threads that hand the answers of a finished batch to the callers' callbacks (0 = the runner does)
+  kOptHandoutChunk,         // ... members per piece of that work
   kOptShardEfPct,           // sharded HNSW: per-shard ef as a percentage of the query's ef (vk_index_params.shard_ef_pct)
   kOptShardGather,          // sharded index: 0 = per-shard top-k gathered by peer copies, 1 = by an RCCL all-gather
   kOptFilterCacheEntries,   // vk_index_filter_cache_put: most filters kept (0 = the cache is off) ...
@@ -60,6 +62,8 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"coalesce-max-wait-us", nullptr, 200, 0, 10000000},
       {"max-query-queue-depth", nullptr, 100000, 0, 0x7FFFFFFF},
       {"batches-in-flight", "VK_BATCHES_IN_FLIGHT", 2, 1, 8},
+      {"completer-threads", "VK_COMPLETER_THREADS", 4, 0, 16},
+      {"handout-chunk", "VK_HANDOUT_CHUNK", 64, 16, 16384},
       {"shard-ef-pct", nullptr, 100, 1, 1000},
       {"shard-gather", "VK_SHARD_GATHER", 0, 0, 1},
       {"filter-cache-entries", nullptr, 256, 0, 1u << 20},

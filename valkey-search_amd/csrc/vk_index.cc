@@ -114,6 +114,7 @@ void sync_dispatcher(vk_index *ix) {
   ix->dispatcher->configure((uint32_t)o.get(vk::kOptCoalesceMaxBatch), (uint32_t)o.get(vk::kOptCoalesceMaxWaitUs));
   ix->dispatcher->set_in_flight((uint32_t)o.get(vk::kOptBatchesInFlight));
   ix->dispatcher->set_queue_depth(o.get(vk::kOptMaxQueryQueueDepth));
+  ix->dispatcher->set_completers((uint32_t)o.get(vk::kOptCompleterThreads), (uint32_t)o.get(vk::kOptHandoutChunk));
 }
 
 vk::Status check_params(const vk_index_params *p) {
@@ -364,6 +365,14 @@ int vk_index_get_stats(vk_index *ix, vk_index_stats *out) {
     out->queued_now = d.queued();
     out->max_batches_in_flight = d.max_in_flight_seen();
     out->cancelled_early = d.left_early();
+    {
+      const vk::Dispatcher::Times t = d.times();
+      out->dispatch_idle_us = t.idle_us;
+      out->dispatch_window_us = t.window_us;
+      out->dispatch_search_us = t.search_us;
+      out->dispatch_handout_us = t.handout_us;
+      out->dispatch_completer_us = t.completer_us;
+    }
     {
       VkFilterCache &fc = ix->filters;
       out->filters_built = fc.built.load(std::memory_order_relaxed);
