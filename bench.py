@@ -434,6 +434,18 @@ def _fill_shard(ix, shard, r0, n, D, sdev, bf16):
     return tab
 
 
+def _final_rows(ix, rows):
+    """rows the candidate filter's MAIN pass walked in the most recent batch -- the launch the library's kernel timing brackets
+    (vk_index_stats.last_filter_final_rows: all rows, or, with option filter-two-pass, the rows behind the early pass's share);
+    of shard 0 for a sharded index (equal shards)"""
+    try:
+        st = ix.shard_stats(0) if ix.shard_count() > 1 else ix.stats()
+    except Exception:   # noqa: BLE001
+        st = ix.stats()
+    v = int(st.last_filter_final_rows)
+    return v if 0 < v <= rows else rows
+
+
 def _shard_filter_ms(ix, before, after=None):
     """the SLOWEST shard's final-pass time per launch: max over shards of a shard's own delta(ns) / delta(batches)
     (vk_index_shard_stats; a difference of maxima over shards would not be any shard's time).  With after=None returns the
@@ -573,9 +585,10 @@ def lib_multi_gpu(args, world, rank, dist, device):
         fan_calls = st1.fanout_calls - st0.fanout_calls
         fan_us = (st1.fanout_enqueue_ns - st0.fanout_enqueue_ns) / 1e3 / fan_calls if fan_calls else None
         kern_ms = filt_ms if filt_ms else dev_ms
-        roofline = {"bound": "hbm", "achieved": round(scan_bytes / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(scan_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                    "per_gpu": True, "algorithmic_bytes": scan_bytes,
+        kern_bytes = (_final_rows(ix, n_local) if filt_ms else n_local) * stride     # the main pass's rows (bench.py, N = 1)
+        roofline = {"bound": "hbm", "achieved": round(kern_bytes / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(kern_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                    "per_gpu": True, "algorithmic_bytes": kern_bytes, "step_algorithmic_bytes": scan_bytes,
                     "kernel": "flat_filter_bdma_kernel (slowest shard)" if filt_ms else "whole step (small shard: the exact kernels)",
                     "per_launch_ms": round(kern_ms, 4), "launches_timed": int(filt_n), "step_ms_on_stream": round(dev_ms, 4),
                     "hbm_frac_of_whole_step": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -740,11 +753,13 @@ def sharded_bf16_ip_leg(args, A, device, ws, devs):
         okp = okp and bl[i, :bn[i]].tolist() == e_l.tolist() and bd[i, :bn[i]].view(np.uint32).tolist() == e_d.view(np.uint32).tolist()
     stride = ((D + 63) // 64) * 64 * 2
     kern = fms if fms else ms
+    kb = (_final_rows(ix, n) if fms else n) * stride          # the main pass's rows of a shard
     return {"workload": f"BASELINE.json configs[3]: FLAT {n * S}x{D} bf16 rows over {S} GPUs ({n} per GPU), IP, k={K}, batch={B}",
             "scaling": "weak", "rows": n * S, "rows_per_gpu": n, "gpu_qps": round(B / (wall_ms * 1e-3), 1), "ms_per_step": round(wall_ms, 3),
             "step_ms_on_stream": round(ms, 3),
-            "roofline": {"bound": "hbm", "per_gpu": True, "algorithmic_bytes": n * stride, "achieved": round(n * stride / (kern * 1e-3) / 1e9, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(n * stride / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "per_gpu": True, "algorithmic_bytes": kb, "step_algorithmic_bytes": n * stride,
+                         "achieved": round(kb / (kern * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb / (kern * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "kernel": "flat_filter_bfmma_dma_kernel (slowest shard)" if fms else "whole step", "per_launch_ms": round(kern, 4)},
             "aggregate_scan_gbs": round(S * n * stride / (ms * 1e-3) / 1e9, 1),
             "parity_vs_oracle": "bit-exact" if okp else "MISMATCH", "build_s": round(build_s, 2),
@@ -1425,7 +1440,11 @@ def main():
         traffic, traffic_src = pmc_traffic(N, D, B, world, dominant)
         qps = B * args.steps / dt
         scan_bytes = n_local * stride                       # algorithmic bytes of one pass over the shard
-        flops = 2.0 * n_local * D * B                       # per step per GPU
+        # ... and of the launch the roofline prices: the candidate filter's main pass (two-pass batches: the early pass's
+        # share of the rows went through flat_filter_early_kernel before it)
+        main_rows = _final_rows(ix, n_local) if filt_n else n_local
+        kern_bytes = main_rows * stride
+        flops = 2.0 * main_rows * D * B                     # of that launch
         out = {
             # BASELINE.json's metric, verbatim; `value` is its FLAT leg on configs[1] (k=10, batch=256, exact: recall@10
             # = 1.0, ids bit-identical to the CPU path), the HNSW leg with its recall is under "hnsw"
@@ -1443,11 +1462,17 @@ def main():
             # B >= 5: f16 matrix-core candidate filter (flat_filter_kernel, one pass over the rows:
             # HBM-bound, algorithmic bytes = rows * row bytes) + exact re-rank of the survivors; 5 <= B <= 32: the exact f32
             # matrix-core kernel (MFMA-bound); else the scan (HBM-bound)
-            "roofline": ({"bound": "hbm", "achieved": round(scan_bytes / (filt_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(scan_bytes / (filt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
-                          "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src, "algorithmic_bytes": scan_bytes,
+            "roofline": ({"bound": "hbm", "achieved": round(kern_bytes / (filt_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(kern_bytes / (filt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                          "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src, "algorithmic_bytes": kern_bytes,
                           "kernel": filter_name, "per_launch_ms": round(filt_ms, 4), "launches_timed": int(filt_n),
-                          "step_ms_on_stream": round(dev_ms, 4),
+                          "rows_in_launch": main_rows, "rows_in_step": n_local,
+                          "early_pass": ({"kernel": filter_name.replace("flat_filter_bdma_kernel", "flat_filter_early_kernel")
+                                                               .replace("flat_filter_bfmma_dma_kernel", "flat_filter_early_bfmma_dma_kernel"),
+                                          "rows": n_local - main_rows,
+                                          "role": "the head of every block's tile range; its survivors give the main pass's bound"}
+                                         if main_rows != n_local else None),
+                          "step_ms_on_stream": round(dev_ms, 4), "step_algorithmic_bytes": scan_bytes,
                           "hbm_frac_of_whole_step": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                           "filter": filt_stats,
                           "f16_mfma_tflops": round(flops / (filt_ms * 1e-3) / 1e12, 1),

@@ -195,6 +195,9 @@ typedef struct vk_index_stats {
   uint64_t dispatch_search_us;
   uint64_t dispatch_handout_us;
   uint64_t dispatch_completer_us;
+  /* FLAT, batched path: rows the MAIN pass of the most recent batch walked (the launch option kernel-timing brackets): all of
+   * them, or -- option filter-two-pass -- the rows behind the early pass's share */
+  uint64_t last_filter_final_rows;
 } vk_index_stats;
 
 /* ---- life cycle ------------------------------------------------------------------

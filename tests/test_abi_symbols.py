@@ -45,7 +45,7 @@ def test_struct_layouts_match_header(vsa, tmp_path):
     offset of every field (gcc compiles a probe that prints them)."""
     import subprocess
     assert C.sizeof(vsa.Params) == 144
-    assert C.sizeof(vsa.Stats) == 440 + 15 * 8
+    assert C.sizeof(vsa.Stats) == 440 + 16 * 8
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vk_index.h"', 'int main(void){']
     for cname, mirror in (("vk_index_params", vsa.Params), ("vk_index_stats", vsa.Stats)):
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -58,7 +58,8 @@ class Stats(C.Structure):
                 ("filter_cache_entries", C.c_uint64), ("filter_cache_bytes", C.c_uint64),
                 ("staged_adds", C.c_uint64), ("staged_adds_device", C.c_uint64), ("last_visited_mode", C.c_uint64),
                 ("dispatch_idle_us", C.c_uint64), ("dispatch_window_us", C.c_uint64), ("dispatch_search_us", C.c_uint64),
-                ("dispatch_handout_us", C.c_uint64), ("dispatch_completer_us", C.c_uint64)]
+                ("dispatch_handout_us", C.c_uint64), ("dispatch_completer_us", C.c_uint64),
+                ("last_filter_final_rows", C.c_uint64)]
 
 
 WRITE_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)

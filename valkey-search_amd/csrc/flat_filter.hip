@@ -315,6 +315,60 @@ hipError_t launch_flat_bound_select(const FlatBoundArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- the early pass's harvest ------------------------------------------------------------------------------------------
+// One wave per query: the first 64 kPer survivors of its list (any k distinct rows are witnesses; an early pass leaves a query
+// a few hundred: kPer = 8 for k <= 64, 32 beyond), lo = score - margin at the row's tile norm, the k-th largest lo to 20 bits
+// from below -- and the query's bound is raised to it.  The gate
+// (gate_thr) charges the rounding of its own subtractions, so none is charged here.
+template <bool kL2, int kPer>
+__global__ __launch_bounds__(64) void flat_bound_tighten_kernel(FlatTightenArgs a) {
+  const uint32_t q = blockIdx.x, lane = threadIdx.x;
+  const uint32_t c_raw = a.cand_cnt[q];
+  uint32_t n = c_raw < a.cap ? c_raw : a.cap;
+  if (n > (uint32_t)kPer * kWave) n = (uint32_t)kPer * kWave;
+  if (n < a.k) return;
+  const float4 co = a.qcoef[q];
+  if (co.w != 0.f) return;   // (a closed column: handed to the exact pass)
+  uint32_t rowv[kPer];
+  float valv[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const uint32_t i = (uint32_t)u * kWave + lane, ic = i < n ? i : n - 1;
+    rowv[u] = a.cand_row[(size_t)q * a.cap + ic];
+    valv[u] = a.cand_val[(size_t)q * a.cap + ic];
+  }
+  uint32_t key[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const float lo = valv[u] - filter_margin<kL2>(co.x, co.y, co.z, __uint_as_float(a.tile_norm[rowv[u] >> 7]));
+    // (0 = below every float: never counted.  NaN, +-inf: a tile outside f16 -- no information)
+    key[u] = ((uint32_t)u * kWave + lane < n && fabsf(lo) < __builtin_inff()) ? desc_key(lo) : 0u;
+  }
+  uint32_t T = 0;
+  for (int bit = 31; bit >= 12; --bit) {
+    const uint32_t cnd = T | (1u << bit);
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) c += (uint32_t)__popcll(__ballot(key[u] >= cnd));
+    if (c >= a.k) T = cnd;
+  }
+  if (T == 0 || lane != 0) return;
+  const float b = desc_key_float(T);
+  if (b == b && b > a.qbound[q]) a.qbound[q] = b;
+}
+
+hipError_t launch_flat_bound_tighten(const FlatTightenArgs &a, hipStream_t s) {
+  if (a.nq == 0) return hipSuccess;
+  if (a.k <= 64) {
+    if (a.l2) hipLaunchKernelGGL((flat_bound_tighten_kernel<true, 8>), dim3(a.nq), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((flat_bound_tighten_kernel<false, 8>), dim3(a.nq), dim3(64), 0, s, a);
+  } else {
+    if (a.l2) hipLaunchKernelGGL((flat_bound_tighten_kernel<true, 32>), dim3(a.nq), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((flat_bound_tighten_kernel<false, 32>), dim3(a.nq), dim3(64), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
 // ---- survivors, gate, stream position --------------------------------------------------------------------------------
 // Survivors are collected per wave in LDS (a ring of 64 (query, row) entries) and written out 64 at a time: the global
 // append is an atomicAdd that RETURNS the slot, a round trip of a microsecond or two -- paid per survivor it sat on the
@@ -738,8 +792,16 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   // stream positions below call a row is then the sample tile's number)
   const uint32_t n_tiles = a.n_tiles;
   const uint32_t t_base = n_tiles / gridDim.x, t_rem = n_tiles % gridDim.x;
-  const uint32_t first_tile = blockIdx.x * t_base + (blockIdx.x < t_rem ? blockIdx.x : t_rem);
-  const uint32_t my_tiles = t_base + (blockIdx.x < t_rem ? 1u : 0u);
+  uint32_t first_tile = blockIdx.x * t_base + (blockIdx.x < t_rem ? blockIdx.x : t_rem);
+  uint32_t my_tiles = t_base + (blockIdx.x < t_rem ? 1u : 0u);
+  if constexpr (!kSample) {
+    if (a.part_tiles != 0) {   // the early pass: the head of the range; the main pass: what is behind it
+      const uint32_t lo = a.part_first < my_tiles ? a.part_first : my_tiles;
+      const uint32_t n = a.part_tiles < my_tiles - lo ? a.part_tiles : my_tiles - lo;
+      first_tile += lo;
+      my_tiles = n;
+    }
+  }
   if (my_tiles == 0) return;
   const uint32_t row_step = kSample ? 1u : (uint32_t)kFTileRows;
   const uint32_t total = my_tiles * stages;
@@ -1497,6 +1559,15 @@ template <bool kBf16, bool kL2, bool kBfMma>
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bdma_kernel(FlatFilterArgs a) {
   flat_filter_body<kBf16, kL2, false, false, 0, kBfMma, false, true>(a);
 }
+// the early pass of a batch that walks the index in two launches (FlatFilterArgs::part_tiles): the final pass's code under its
+// own names
+template <bool kBf16, bool kL2, bool kBfMma>
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_early_kernel(FlatFilterArgs a) {
+  flat_filter_body<kBf16, kL2, false, false, 0, kBfMma, false, true>(a);
+}
+__global__ __launch_bounds__(kWsThreads, 1) void flat_filter_early_bfmma_dma_kernel(FlatFilterArgs a) {
+  flat_filter_body<true, false, false, false, 0, true, true>(a);
+}
 #ifdef VK_EXPERIMENTS
 template <int kAbl>   // (experiments, VK_FILTER_ABLATE)
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_bfmma_dma_abl_kernel(FlatFilterArgs a) {
@@ -1579,7 +1650,7 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
     if (!a.bf16 || a.l2) return hipErrorInvalidValue;
     fn = a.mode == 1 ? reinterpret_cast<const void *>(&flat_filter_bfmma_sample_kernel) : reinterpret_cast<const void *>(&flat_filter_bfmma_kernel);
     if (a.mode == 0 && a.dma) {
-      fn = reinterpret_cast<const void *>(&flat_filter_bfmma_dma_kernel);
+      fn = a.early ? reinterpret_cast<const void *>(&flat_filter_early_bfmma_dma_kernel) : reinterpret_cast<const void *>(&flat_filter_bfmma_dma_kernel);
 #ifdef VK_EXPERIMENTS
       if (a.ablate_on) fn = (a.ablate & 112u) == 112u ? reinterpret_cast<const void *>(&flat_filter_bfmma_dma_abl_kernel<113>)
                                                         : reinterpret_cast<const void *>(&flat_filter_bfmma_dma_abl_kernel<1>);
@@ -1598,6 +1669,12 @@ hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStrea
                           : reinterpret_cast<const void *>(&flat_filter_bdma_kernel<true, false, false>))
                   : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_bdma_kernel<false, true, false>)
                           : reinterpret_cast<const void *>(&flat_filter_bdma_kernel<false, false, false>));
+    if (a.early)
+      fn = a.qbf16 ? reinterpret_cast<const void *>(&flat_filter_early_kernel<true, false, true>)
+           : a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_early_kernel<true, true, false>)
+                            : reinterpret_cast<const void *>(&flat_filter_early_kernel<true, false, false>))
+                    : (a.l2 ? reinterpret_cast<const void *>(&flat_filter_early_kernel<false, true, false>)
+                            : reinterpret_cast<const void *>(&flat_filter_early_kernel<false, false, false>));
     lds = flat_filter_bdma_lds_bytes();
   }
 #ifdef VK_EXPERIMENTS

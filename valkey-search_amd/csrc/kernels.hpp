@@ -171,6 +171,12 @@ struct FlatFilterArgs {
   const uint32_t *norm_cap;
   float *qwit;
   uint32_t n_tiles;           // tiles this launch walks (mode 0: ceil(n_rows / 128); mode 1: sample tiles)
+  // A batch may walk the index in TWO launches of mode 0 (FlatIndex::scan_filter: the early pass and the main pass).  A block
+  // owns the same contiguous range of the tile sequence in both; the early pass takes the first part_tiles tiles of every
+  // range -- one stretch per block, spread evenly over the whole index -- and the main pass starts behind them
+  // (part_first).  part_tiles = 0: the whole range in one launch.  early = 1 selects the early pass's kernel symbol (the
+  // same code under another name, so that a profile tells the two apart).
+  uint32_t part_first, part_tiles, early;
   uint32_t row_stride_f, n_rows, nq;
   uint32_t nqt;               // query tiles of 32 (<= 8 per launch)
   const uint32_t *cancel;
@@ -195,6 +201,19 @@ struct FlatBoundArgs {
   uint32_t smax_ld, groups, k, nq;
   float *qbound;
 };
+// the early pass's harvest: qbound[q] = max(qbound[q], the k-th largest of (score - margin) over the query's survivors so far)
+// -- k distinct rows reach it, so it bounds the k-th best exact score from below like the sample's bound does
+// (flat_rerank_kernel takes its second bound the same way)
+struct FlatTightenArgs {
+  const uint32_t *cand_cnt;   // [nq]
+  const uint32_t *cand_row;   // [nq][cap]
+  const float *cand_val;      // [nq][cap]
+  uint32_t cap, k, nq, l2;
+  const float4 *qcoef;
+  const uint32_t *tile_norm;
+  float *qbound;
+};
+hipError_t launch_flat_bound_tighten(const FlatTightenArgs &a, hipStream_t s);
 size_t flat_filter_lds_bytes();
 bool flat_filter_supported(uint32_t row_stride_f, uint64_t k, bool bf16, bool l2);
 // stats: [0] largest |row|^2 (SQUARED, reported only), [1] largest |element| of the index (f32 bits), [2] tiles flagged +inf

@@ -593,6 +593,7 @@ class ShardedIndex final : public Index {
       out->max_label = std::max(out->max_label, t.max_label);
       out->staged_adds += t.staged_adds;
       out->staged_adds_device += t.staged_adds_device;
+      out->last_filter_final_rows += t.last_filter_final_rows;
     }
     out->fanout_calls = fanout_calls_.load(std::memory_order_relaxed);
     out->fanout_enqueue_ns = fanout_ns_.load(std::memory_order_relaxed);
