@@ -1023,7 +1023,8 @@ class FlatIndex final : public Index {
     if (filter_two_pass_ != 0 && tiles_per_block >= filter_two_pass_min_tiles_ && !filter_dump_active()) {
       const uint64_t kk = (k + 9) / 10;
       sample_rows = std::min<uint64_t>(sample_rows, std::max<uint64_t>(8192 * kk, std::min<uint64_t>(32768 * kk, count / 256)));
-      const double f = std::sqrt((double)sample_rows / (double)count);
+      const uint64_t pm = opt_.get(kOptFilterEarlyPermille);
+      const double f = pm != 0 ? (double)pm / 1000.0 : std::sqrt((double)sample_rows / (double)count);
       early_tiles = (uint32_t)std::max<double>(1.0, std::floor((double)tiles_per_block * f + 0.5));
       early_tiles = (uint32_t)std::min<uint64_t>(early_tiles, std::max<uint64_t>(1, tiles_per_block / 4));
     }

@@ -37,7 +37,7 @@ enum OptId : uint32_t {
   kOptKernelTiming,         // 1 = HIP event pairs around the dominant kernel's launches (vk_index_stats.filter_kernel_ns)
   // ---- FLAT: kernel selection and the candidate filter (K4h) ------------------------------------------------------------
   kOptFlatFilter, kOptFilterMinQueries, kOptFilterMinRows, kOptFilterPrepassRows, kOptFilterCap, kOptFilterSpillChunks,
-  kOptFilterBDma, kOptFilterRowDma, kOptFilterBf16Mfma, kOptFlatForceScan, kOptFlatFusedRerank, kOptFilterSecondBound, kOptFilterTwoPass, kOptFilterTwoPassMinTiles,
+  kOptFilterBDma, kOptFilterRowDma, kOptFilterBf16Mfma, kOptFlatForceScan, kOptFlatFusedRerank, kOptFilterSecondBound, kOptFilterTwoPass, kOptFilterTwoPassMinTiles, kOptFilterEarlyPermille,
   kOptGemmLockstep, kOptGemmPrepassRows, kOptGemmContig, kOptScanMinNrp, kOptUploadParallel,
   // ---- HNSW ----------------------------------------------------------------------------------------------------------------
   kOptHnswStageAdds, kOptHnswStageMax,
@@ -83,6 +83,7 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"filter-second-bound", "VK_FILTER_SECOND_BOUND", 1, 0, 1},
       {"filter-two-pass", "VK_FILTER_TWO_PASS", 1, 0, 1},                         // the rows in an early and a main launch, the main pass's bound from the early one's survivors
       {"filter-two-pass-min-tiles", "VK_FILTER_TWO_PASS_MIN_TILES", 16, 2, 1u << 20},   // ... for indexes of at least this many 128-row tiles per block (CU)
+      {"filter-early-permille", "VK_FILTER_EARLY_PERMILLE", 0, 0, 250},          // ... the early pass's share of the rows (0 = sqrt(sample / rows))
       {"gemm-lockstep", "VK_GEMM_LOCKSTEP", 1, 0, 64},
       {"gemm-prepass-rows", "VK_GEMM_PREPASS", 16384, 0, kMax},
       {"gemm-contig", "VK_GEMM_CONTIG", 1, 0, 1},
