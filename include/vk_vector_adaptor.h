@@ -520,7 +520,11 @@ class VectorGpu : public VectorBase {
         {"gpu_queue_depth", s.queued_now},          {"gpu_rejected_busy", s.rejected},
         {"gpu_cancelled_early", s.cancelled_early}, {"gpu_filters_built", s.filters_built},
         {"gpu_filter_cache_hits", s.filter_cache_hits}, {"gpu_staged_adds", s.staged_adds},
-        {"gpu_staged_adds_device", s.staged_adds_device}};
+        {"gpu_staged_adds_device", s.staged_adds_device},
+        // the library's serving threads: device batches formed from single queries, and where the runners' / completers' time went
+        {"gpu_batches", s.coalesced_batches},          {"gpu_batched_queries", s.coalesced_queries},
+        {"gpu_runner_idle_us", s.dispatch_idle_us},    {"gpu_runner_search_us", s.dispatch_search_us},
+        {"gpu_completer_us", s.dispatch_completer_us}};
     for (const auto &r : rows) {
       ValkeyModule_ReplyWithSimpleString(ctx, r.first);
       ValkeyModule_ReplyWithLongLong(ctx, (long long)r.second);

@@ -686,6 +686,12 @@ def test_two_passes_over_the_rows_change_nothing_but_the_work(vsa, oracle, metri
                 assert st.last_filter_candidates <= s1.last_filter_candidates, (st.last_filter_candidates, s1.last_filter_candidates)
     ix.set_option("filter-two-pass", 1)
     D, L, N = ix.search_batch(Q, 10)
+    # (the early pass's share set by hand -- option filter-early-permille; 0 = sqrt(sample / rows) -- changes the work only)
+    for pm in (1, 250):
+        ix.set_option("filter-early-permille", pm)
+        Dp, Lp, Np = ix.search_batch(Q, 10)
+        assert Np.tolist() == N.tolist() and (Lp == L).all() and (Dp.view(np.uint32) == D.view(np.uint32)).all(), pm
+    ix.set_option("filter-early-permille", 0)
     for i in (0, 3, 11, 40, 76, 199):
         od, ol = o.search(Q[i], 10)
         assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist(), i

@@ -1177,8 +1177,9 @@ class FlatIndex final : public Index {
           VK_HIP_TRY(hipEventCreate(&tp->t0));
           VK_HIP_TRY(hipEventCreate(&tp->t1));
         }
-        VK_HIP_TRY(hipEventRecord(tp->t0, s));
       }
+      // (an event record is a marker the stream executes: 6 us of idle device each, seen as gaps in profiles/r05_step_trace_*.log
+      //  -- ONE in front of the timed launch and one behind it, only with the option on)
       const bool two_pass = early_tiles != 0 && !filter_experiment;
       if (two_pass) {
         // the early pass (before the timed pair: kernel-timing brackets the main pass, the launch bench.py prices) ...
@@ -1186,7 +1187,6 @@ class FlatIndex final : public Index {
         fe.part_first = 0;
         fe.part_tiles = early_tiles;
         fe.early = 1;
-        if (tp) VK_HIP_TRY(hipEventRecord(tp->t0, s));   // (re-recorded below: an event holds its LAST record)
         VK_TRY(filter_launches(fe, filter_grid));
         // ... its survivors raise the bounds ...
         FlatTightenArgs t{};
@@ -1204,8 +1204,8 @@ class FlatIndex final : public Index {
         // ... and the main pass walks the rest of every block's range
         fm.part_first = early_tiles;
         fm.part_tiles = 0xFFFFFFFFu;
-        if (tp) VK_HIP_TRY(hipEventRecord(tp->t0, s));
       }
+      if (tp) VK_HIP_TRY(hipEventRecord(tp->t0, s));
       last_filter_final_rows_.store(count - (two_pass ? (uint64_t)early_tiles * filter_grid * 128 : 0), std::memory_order_relaxed);
       VK_TRY(filter_launches(fm, filter_grid));
       if (tp) {
