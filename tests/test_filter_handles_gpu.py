@@ -159,3 +159,40 @@ def test_a_filter_of_another_index_fails_alone(vsa, graphs):
     with pytest.raises(vsa.VkError) as e:
         h.search_filter(q, 5, foreign)
     assert e.value.code == vsa.VK_ERR_INVALID and "another index" in e.value.msg
+
+
+def test_released_bitmaps_are_recycled_and_a_recycled_block_starts_clean(vsa, oracle, graphs):
+    """r05: a released filter's device memory goes to a per-device pool (hipFree would wait for every search in flight on the
+    device) and the next filter of that size takes it over -- with whatever the previous owner left in it.  A block that held
+    ALL ONES must come back as exactly the new id list / the new combination (bits, slack word, count); device memory does
+    not grow over a thousand create / combine / release rounds."""
+    g, n, rng = graphs["h"], graphs["n"], graphs["rng"]
+    ones = np.full((n + 63) // 64, ~np.uint64(0), dtype=np.uint64)
+    few = np.array([3, 64, n - 1], dtype=np.uint64)
+    a_ids = np.flatnonzero(rng.random(n) < 0.2).astype(np.uint64)
+    b_ids = np.flatnonzero(rng.random(n) < 0.2).astype(np.uint64)
+    fa, fb = g.make_filter(n, labels=a_ids), g.make_filter(n, labels=b_ids)
+    want_few = oracle.allow_bitmap(few, n).tolist()
+    want_and = oracle.allow_bitmap(np.intersect1d(a_ids, b_ids), n).tolist()
+    import torch
+    free0 = None
+    for r in range(1000):
+        full = g.make_filter(n, base_bits=ones)
+        assert full.info() == (n, n)                 # (stray bits past nbits in the caller's last word are not counted)
+        full.release()
+        f1 = g.make_filter(n, labels=few)            # takes the block that held all ones
+        if r % 100 == 0:
+            assert f1.read().tolist() == want_few and f1.info() == (n, 3)
+        f1.release()
+        fc = g.combine_filters(fa, fb, "and")
+        if r % 100 == 0:
+            assert fc.read().tolist() == want_and and fc.info()[1] == np.intersect1d(a_ids, b_ids).size
+            # a search through the recycled bitmap equals the search through the host bitmap
+            q = graphs["x"][r % n]
+            d1, l1 = g.search_filter(q, 5, fc, ef=64)
+            d2, l2 = g.search(q, 5, ef=64, allow=np.array(want_and, dtype=np.uint64), allow_nbits=n)
+            assert l1.tolist() == l2.tolist() and d1.view(np.uint32).tolist() == d2.view(np.uint32).tolist()
+        fc.release()
+        if r == 10:
+            free0 = torch.cuda.mem_get_info()[0]
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20), (free0, torch.cuda.mem_get_info()[0])

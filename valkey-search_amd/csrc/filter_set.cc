@@ -21,7 +21,9 @@ struct BuildLane {
   void *d_stage = nullptr;
   size_t d_cap = 0;
   unsigned long long *d_count = nullptr;
+  unsigned long long *d_partial = nullptr;   // [kPartials]: a combine's per-block bit counts
 };
+constexpr size_t kPartials = 2048;
 BuildLane *lane_of(int device) {
   static std::mutex mu;
   static std::vector<std::unique_ptr<BuildLane>> lanes;
@@ -29,6 +31,52 @@ BuildLane *lane_of(int device) {
   if ((size_t)device >= lanes.size()) lanes.resize((size_t)device + 1);
   if (!lanes[(size_t)device]) lanes[(size_t)device] = std::make_unique<BuildLane>();
   return lanes[(size_t)device].get();
+}
+// Bitmap blocks are recycled per device and size: a filter per FT.SEARCH (a predicate combined from cached terms) otherwise pays
+// a hipMalloc per copy, and -- worse -- its release a hipFree, which waits for EVERYTHING in flight on the device: the searches
+// of every other request.  Up to kPoolBytes per device wait for the next filter of their size (an index's filters are all
+// of one size); beyond that a block is freed as before.
+struct BitsPool {
+  std::mutex mu;
+  std::vector<std::pair<size_t, uint64_t *>> free;
+  size_t held = 0;
+};
+constexpr size_t kPoolBytes = (size_t)512 << 20;
+BitsPool *pool_of(int device) {
+  static std::mutex mu;
+  static std::vector<std::unique_ptr<BitsPool>> pools;
+  std::lock_guard<std::mutex> lk(mu);
+  if ((size_t)device >= pools.size()) pools.resize((size_t)device + 1);
+  if (!pools[(size_t)device]) pools[(size_t)device] = std::make_unique<BitsPool>();
+  return pools[(size_t)device].get();
+}
+// (the caller has made `device` current)
+hipError_t pool_take(int device, size_t bytes, uint64_t **out) {
+  BitsPool *p = pool_of(device);
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (size_t i = p->free.size(); i-- > 0;)
+      if (p->free[i].first == bytes) {
+        *out = p->free[i].second;
+        p->free.erase(p->free.begin() + (std::ptrdiff_t)i);
+        p->held -= bytes;
+        return hipSuccess;
+      }
+  }
+  return hipMalloc(reinterpret_cast<void **>(out), bytes);
+}
+void pool_give(int device, size_t bytes, uint64_t *bits) {
+  BitsPool *p = pool_of(device);
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (p->held + bytes <= kPoolBytes) {
+      p->free.emplace_back(bytes, bits);
+      p->held += bytes;
+      return;
+    }
+  }
+  (void)hipSetDevice(device);
+  (void)hipFree(bits);
 }
 constexpr size_t kStageBytes = (size_t)4 << 20;   // ids travel in 4 MiB pieces through pinned memory: copy k+1 is filled while k is in flight
 
@@ -39,6 +87,7 @@ Status lane_ready(BuildLane *l) {
     l->pin_cap = 2 * kStageBytes;
   }
   if (!l->d_count) VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&l->d_count), 8));
+  if (!l->d_partial) VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&l->d_partial), kPartials * 8));
   return Status::Ok();
 }
 Status stage_ensure(BuildLane *l, size_t bytes) {
@@ -80,10 +129,28 @@ Status upload(BuildLane *l, void *d_dst, const void *h_src, size_t bytes) {
 }  // namespace
 
 FilterSet::~FilterSet() {
-  for (Copy &c : copies_) {
-    (void)hipSetDevice(c.device);
-    if (c.bits) (void)hipFree(c.bits);
+  // (nobody reads the bitmap any more: every search that carried it held a reference until its answer was delivered)
+  for (Copy &c : copies_)
+    if (c.bits) pool_give(c.device, (size_t)(words() + 1) * 8, c.bits);
+}
+
+// the copies of an (uninitialised) filter of nbits bits on `devices`
+Status FilterSet::allocate(const std::vector<int> &devices, uint64_t nbits, std::shared_ptr<FilterSet> *out) {
+  std::shared_ptr<FilterSet> f(new FilterSet());
+  f->nbits_ = nbits;
+  f->id_ = g_next_id.fetch_add(1, std::memory_order_relaxed);
+  const size_t alloc = ((size_t)f->words() + 1) * 8;             // (one word of slack: the kernels read whole words)
+  for (int dev : devices) {
+    bool have = false;
+    for (const Copy &c : f->copies_) have = have || c.device == dev;
+    if (have) continue;                              // (logical shards share a device)
+    VK_HIP_TRY(hipSetDevice(dev));
+    uint64_t *p = nullptr;
+    VK_HIP_TRY(pool_take(dev, alloc, &p));
+    f->copies_.push_back(Copy{dev, p});
   }
+  *out = std::move(f);
+  return Status::Ok();
 }
 
 Status FilterSet::build(const std::vector<int> &devices, uint64_t nbits, const uint64_t *ids, uint64_t n_ids, const uint64_t *runs,
@@ -91,20 +158,10 @@ Status FilterSet::build(const std::vector<int> &devices, uint64_t nbits, const u
   if (devices.empty()) return Status::Err(1, "filter: the index has no device");
   if (nbits >= ((uint64_t)1 << 40)) return Status::Err(1, "filter: nbits out of range");
   if ((n_ids && !ids) || (n_runs && !runs)) return Status::Err(1, "filter: NULL id list");
-  std::shared_ptr<FilterSet> f(new FilterSet());
-  f->nbits_ = nbits;
-  f->id_ = g_next_id.fetch_add(1, std::memory_order_relaxed);
+  std::shared_ptr<FilterSet> f;
+  VK_TRY(allocate(devices, nbits, &f));
   const size_t words = (size_t)f->words();
-  const size_t alloc = (words + 1) * 8;             // (one word of slack: the kernels read whole words)
-  for (int dev : devices) {
-    bool have = false;
-    for (const Copy &c : f->copies_) have = have || c.device == dev;
-    if (have) continue;                              // (logical shards share a device)
-    VK_HIP_TRY(hipSetDevice(dev));
-    uint64_t *p = nullptr;
-    VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), alloc));
-    f->copies_.push_back(Copy{dev, p});
-  }
+  const size_t alloc = (words + 1) * 8;
   const int dev0 = f->copies_[0].device;
   BuildLane *l = lane_of(dev0);
   {
@@ -154,25 +211,33 @@ Status FilterSet::combine(const FilterSet &a, const FilterSet &b, uint32_t op, s
   // to its own slack word only, so it is widened first when the sizes differ)
   if (a.nbits_ != b.nbits_) return Status::Err(1, "filter: combine needs filters of one size (build both with the same nbits)");
   std::shared_ptr<FilterSet> f;
-  VK_TRY(build(devs, a.nbits_, nullptr, 0, nullptr, 0, nullptr, &f));
+  VK_TRY(allocate(devs, a.nbits_, &f));
   const size_t words = (size_t)f->words();
+  // every copy's kernels are enqueued before any is waited for; the count comes back with the first copy
+  unsigned long long cnt = 0;
+  std::vector<BuildLane *> lanes;
   for (const Copy &c : f->copies_) {
     BuildLane *l = lane_of(c.device);
     std::lock_guard<std::mutex> lk(l->mu);
     VK_HIP_TRY(hipSetDevice(c.device));
     VK_TRY(lane_ready(l));
-    VK_HIP_TRY(launch_filter_combine(c.bits, a.bits_on(c.device), b.bits_on(c.device), words, op, l->stream));
+    const uint32_t nb = filter_combine_blocks(words);
+    if (nb > kPartials) return Status::Err(4, "filter: combine grid larger than its partial sums");
+    VK_HIP_TRY(launch_filter_combine(c.bits, a.bits_on(c.device), b.bits_on(c.device), words, op, l->d_partial, l->stream));
     if (&c == &f->copies_[0]) {
-      unsigned long long cnt = 0;
-      VK_HIP_TRY(hipMemsetAsync(l->d_count, 0, 8, l->stream));
-      VK_HIP_TRY(launch_filter_popcount(c.bits, words, l->d_count, l->stream));
-      VK_HIP_TRY(hipMemcpyAsync(&cnt, l->d_count, 8, hipMemcpyDeviceToHost, l->stream));
+      // (the lane's pinned block: free while the lane's lock is held)
+      VK_HIP_TRY(hipMemcpyAsync(l->pin, l->d_partial, (size_t)nb * 8, hipMemcpyDeviceToHost, l->stream));
       VK_HIP_TRY(hipStreamSynchronize(l->stream));
-      f->allowed_ = cnt;
-    } else {
-      VK_HIP_TRY(hipStreamSynchronize(l->stream));
+      const unsigned long long *part = reinterpret_cast<const unsigned long long *>(l->pin);
+      for (uint32_t i = 0; i < nb; ++i) cnt += part[i];
     }
+    lanes.push_back(l);
   }
+  for (size_t i = 1; i < lanes.size(); ++i) {
+    VK_HIP_TRY(hipSetDevice(f->copies_[i].device));
+    VK_HIP_TRY(hipStreamSynchronize(lanes[i]->stream));
+  }
+  f->allowed_ = cnt;
   *out = std::move(f);
   return Status::Ok();
 }

@@ -41,6 +41,7 @@ class FilterSet {
 
  private:
   FilterSet() = default;
+  static Status allocate(const std::vector<int> &devices, uint64_t nbits, std::shared_ptr<FilterSet> *out);
   struct Copy { int device; uint64_t *bits; };
   std::vector<Copy> copies_;
   uint64_t nbits_ = 0, id_ = 0, allowed_ = 0;

@@ -409,6 +409,9 @@ hipError_t launch_kth_bound(const float *out_dist, const uint32_t *out_n, uint32
 hipError_t launch_filter_set_ids(uint64_t *bits, uint64_t nbits, const uint64_t *d_ids, uint64_t n, hipStream_t s);
 hipError_t launch_filter_set_runs(uint64_t *bits, uint64_t nbits, const uint64_t *d_runs, uint64_t n_runs, hipStream_t s);   // [n_runs][2] = first, last
 hipError_t launch_filter_popcount(const uint64_t *bits, uint64_t words, unsigned long long *d_out, hipStream_t s);             // *d_out += set bits
-hipError_t launch_filter_combine(uint64_t *dst, const uint64_t *a, const uint64_t *b, uint64_t words, uint32_t op, hipStream_t s);   // 0 and, 1 or, 2 and-not
+// dst = a OP b, dst[words] = 0, d_partial[block] = set bits of the block's words (filter_combine_blocks(words) of them)
+uint32_t filter_combine_blocks(uint64_t words);
+hipError_t launch_filter_combine(uint64_t *dst, const uint64_t *a, const uint64_t *b, uint64_t words, uint32_t op, unsigned long long *d_partial,
+                                 hipStream_t s);   // 0 and, 1 or, 2 and-not
 
 }  // namespace vk
