@@ -16,18 +16,41 @@ namespace vk {
 namespace {
 constexpr int kThreads = 256;
 
-__global__ __launch_bounds__(kThreads) void filter_set_ids_kernel(unsigned long long *bits, uint64_t nbits, const uint64_t *ids, uint64_t n) {
+// (both kernels also COUNT the bits they turn on -- the atomic OR returns the word as it was, so a bit is counted by exactly
+//  one of the lanes that set it, duplicates and overlaps included -- as one partial sum per block; the host that waits for the
+//  build adds them up: no counter to clear, no popcount pass over the bitmap)
+__device__ __forceinline__ void block_partial(unsigned long long c, unsigned long long *partial) {
+  __shared__ unsigned long long s_c[kThreads / 64];
+  for (int off = 32; off; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63u) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kThreads / 64; ++w) t += s_c[w];
+    partial[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void filter_set_ids_kernel(unsigned long long *bits, uint64_t nbits, const uint64_t *ids, uint64_t n,
+                                                                   unsigned long long *partial) {
+  unsigned long long c = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) {
     const uint64_t id = ids[i];
-    if (id < nbits) atomicOr(&bits[id >> 6], 1ull << (id & 63));   // (labels beyond the bitmap are rejected, vk_index.h allow_nbits)
+    if (id < nbits) {   // (labels beyond the bitmap are rejected, vk_index.h allow_nbits)
+      const unsigned long long m = 1ull << (id & 63);
+      c += (atomicOr(&bits[id >> 6], m) & m) == 0 ? 1u : 0u;
+    }
   }
+  block_partial(c, partial);
 }
 
 // one wave per run: the run's words are dealt to the lanes, the two edge words are masked.  Runs may overlap or share a
 // word with their neighbours, hence the atomic.
-__global__ __launch_bounds__(kThreads) void filter_set_runs_kernel(unsigned long long *bits, uint64_t nbits, const uint64_t *runs, uint64_t n_runs) {
+__global__ __launch_bounds__(kThreads) void filter_set_runs_kernel(unsigned long long *bits, uint64_t nbits, const uint64_t *runs, uint64_t n_runs,
+                                                                    unsigned long long *partial) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, waves = ((uint64_t)gridDim.x * kThreads) >> 6;
+  unsigned long long c = 0;
   for (uint64_t r = wave; r < n_runs; r += waves) {
     uint64_t lo = runs[2 * r], hi = runs[2 * r + 1];
     if (lo > hi || lo >= nbits) continue;
@@ -37,9 +60,10 @@ __global__ __launch_bounds__(kThreads) void filter_set_runs_kernel(unsigned long
       unsigned long long m = ~0ull;
       if (w == w0) m &= ~0ull << (lo & 63);
       if (w == w1) m &= ~0ull >> (63 - (hi & 63));
-      atomicOr(&bits[w], m);
+      c += (unsigned long long)__popcll(m & ~atomicOr(&bits[w], m));
     }
   }
+  block_partial(c, partial);
 }
 
 __global__ __launch_bounds__(kThreads) void filter_popcount_kernel(const unsigned long long *bits, uint64_t words, unsigned long long *out) {
@@ -77,15 +101,17 @@ __global__ __launch_bounds__(kThreads) void filter_combine_kernel(unsigned long 
 inline uint32_t grid_for(uint64_t items) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (items + kThreads - 1) / kThreads), 256 * 8); }
 }  // namespace
 
-hipError_t launch_filter_set_ids(uint64_t *bits, uint64_t nbits, const uint64_t *d_ids, uint64_t n, hipStream_t s) {
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(filter_set_ids_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, reinterpret_cast<unsigned long long *>(bits), nbits, d_ids, n);
+uint32_t filter_set_ids_blocks(uint64_t n) { return grid_for(n); }
+uint32_t filter_set_runs_blocks(uint64_t n_runs) { return grid_for(n_runs * 64); }
+hipError_t launch_filter_set_ids(uint64_t *bits, uint64_t nbits, const uint64_t *d_ids, uint64_t n, unsigned long long *d_partial, hipStream_t s) {
+  hipLaunchKernelGGL(filter_set_ids_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, reinterpret_cast<unsigned long long *>(bits), nbits, d_ids, n,
+                     d_partial);
   return hipGetLastError();
 }
-hipError_t launch_filter_set_runs(uint64_t *bits, uint64_t nbits, const uint64_t *d_runs, uint64_t n_runs, hipStream_t s) {
-  if (n_runs == 0) return hipSuccess;
-  hipLaunchKernelGGL(filter_set_runs_kernel, dim3(grid_for(n_runs * 64)), dim3(kThreads), 0, s, reinterpret_cast<unsigned long long *>(bits), nbits, d_runs,
-                     n_runs);
+hipError_t launch_filter_set_runs(uint64_t *bits, uint64_t nbits, const uint64_t *d_runs, uint64_t n_runs, unsigned long long *d_partial,
+                                  hipStream_t s) {
+  hipLaunchKernelGGL(filter_set_runs_kernel, dim3(grid_for(n_runs * 64)), dim3(kThreads), 0, s, reinterpret_cast<unsigned long long *>(bits), nbits,
+                     d_runs, n_runs, d_partial);
   return hipGetLastError();
 }
 hipError_t launch_filter_popcount(const uint64_t *bits, uint64_t words, unsigned long long *d_out, hipStream_t s) {

@@ -87,7 +87,7 @@ Status lane_ready(BuildLane *l) {
     l->pin_cap = 2 * kStageBytes;
   }
   if (!l->d_count) VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&l->d_count), 8));
-  if (!l->d_partial) VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&l->d_partial), kPartials * 8));
+  if (!l->d_partial) VK_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&l->d_partial), 2 * kPartials * 8));   // (ids | runs)
   return Status::Ok();
 }
 Status stage_ensure(BuildLane *l, size_t bytes) {
@@ -176,24 +176,40 @@ Status FilterSet::build(const std::vector<int> &devices, uint64_t nbits, const u
       VK_HIP_TRY(hipMemcpyAsync(bits + words - 1, &last, 8, hipMemcpyHostToDevice, l->stream));
       VK_HIP_TRY(hipStreamSynchronize(l->stream));
     }
+    // ids and runs side by side in the staging block; both kernels count what they turn on (a partial sum per block), a
+    // base bitmap is counted by the popcount pass; one wait behind the kernels (upload() waits for its own copies)
+    const size_t ids_bytes = (size_t)n_ids * 8, runs_bytes = (size_t)n_runs * 16;
+    if (n_ids || n_runs) VK_TRY(stage_ensure(l, ids_bytes + runs_bytes));
+    char *stage = static_cast<char *>(l->d_stage);
+    uint32_t nb_ids = 0, nb_runs = 0;
     if (n_ids) {
-      VK_TRY(stage_ensure(l, (size_t)n_ids * 8));
-      VK_TRY(upload(l, l->d_stage, ids, (size_t)n_ids * 8));
-      VK_HIP_TRY(launch_filter_set_ids(bits, nbits, static_cast<const uint64_t *>(l->d_stage), n_ids, l->stream));
-      VK_HIP_TRY(hipStreamSynchronize(l->stream));   // (the staging block is reused by the runs below / the next build)
+      VK_TRY(upload(l, stage, ids, ids_bytes));
+      nb_ids = filter_set_ids_blocks(n_ids);
+      VK_HIP_TRY(launch_filter_set_ids(bits, nbits, reinterpret_cast<const uint64_t *>(stage), n_ids, l->d_partial, l->stream));
     }
     if (n_runs) {
-      VK_TRY(stage_ensure(l, (size_t)n_runs * 16));
-      VK_TRY(upload(l, l->d_stage, runs, (size_t)n_runs * 16));
-      VK_HIP_TRY(launch_filter_set_runs(bits, nbits, static_cast<const uint64_t *>(l->d_stage), n_runs, l->stream));
+      VK_TRY(upload(l, stage + ids_bytes, runs, runs_bytes));
+      nb_runs = filter_set_runs_blocks(n_runs);
+      VK_HIP_TRY(launch_filter_set_runs(bits, nbits, reinterpret_cast<const uint64_t *>(stage + ids_bytes), n_runs, l->d_partial + kPartials, l->stream));
     }
-    VK_HIP_TRY(hipMemsetAsync(l->d_count, 0, 8, l->stream));
-    VK_HIP_TRY(launch_filter_popcount(bits, words, l->d_count, l->stream));
+    if (nb_ids > kPartials || nb_runs > kPartials) return Status::Err(4, "filter: build grid larger than its partial sums");
     unsigned long long cnt = 0;
-    VK_HIP_TRY(hipMemcpyAsync(&cnt, l->d_count, 8, hipMemcpyDeviceToHost, l->stream));
+    // (the pinned block is free: upload() has waited for its copies)
+    unsigned long long *h_part = reinterpret_cast<unsigned long long *>(l->pin);
+    if (nb_ids) VK_HIP_TRY(hipMemcpyAsync(h_part, l->d_partial, (size_t)nb_ids * 8, hipMemcpyDeviceToHost, l->stream));
+    if (nb_runs) VK_HIP_TRY(hipMemcpyAsync(h_part + kPartials, l->d_partial + kPartials, (size_t)nb_runs * 8, hipMemcpyDeviceToHost, l->stream));
+    if (host_bits && words) {   // (before the id kernels in stream order would be as good: they only add bits, counted separately)
+      VK_HIP_TRY(hipMemsetAsync(l->d_count, 0, 8, l->stream));
+      VK_HIP_TRY(launch_filter_popcount(bits, words, l->d_count, l->stream));
+      VK_HIP_TRY(hipMemcpyAsync(&cnt, l->d_count, 8, hipMemcpyDeviceToHost, l->stream));
+    }
     for (size_t c = 1; c < f->copies_.size(); ++c)
       VK_HIP_TRY(hipMemcpyPeerAsync(f->copies_[c].bits, f->copies_[c].device, bits, dev0, alloc, l->stream));
     VK_HIP_TRY(hipStreamSynchronize(l->stream));
+    if (!(host_bits && words)) {
+      for (uint32_t i = 0; i < nb_ids; ++i) cnt += h_part[i];
+      for (uint32_t i = 0; i < nb_runs; ++i) cnt += h_part[kPartials + i];
+    }
     f->allowed_ = cnt;
   }
   *out = std::move(f);

@@ -406,8 +406,12 @@ hipError_t launch_kth_bound(const float *out_dist, const uint32_t *out_n, uint32
 
 // filter_build.hip: allow-bitmaps built on the device from id lists / id runs (what the EntriesFetchers of a predicate
 // yield, src/query/search.cc:301-399): bits must be zeroed (or hold the set to extend); labels >= nbits are ignored
-hipError_t launch_filter_set_ids(uint64_t *bits, uint64_t nbits, const uint64_t *d_ids, uint64_t n, hipStream_t s);
-hipError_t launch_filter_set_runs(uint64_t *bits, uint64_t nbits, const uint64_t *d_runs, uint64_t n_runs, hipStream_t s);   // [n_runs][2] = first, last
+// (d_partial[block] = bits the block turned on, filter_set_*_blocks() of them: the host adds them up)
+uint32_t filter_set_ids_blocks(uint64_t n);
+uint32_t filter_set_runs_blocks(uint64_t n_runs);
+hipError_t launch_filter_set_ids(uint64_t *bits, uint64_t nbits, const uint64_t *d_ids, uint64_t n, unsigned long long *d_partial, hipStream_t s);
+hipError_t launch_filter_set_runs(uint64_t *bits, uint64_t nbits, const uint64_t *d_runs, uint64_t n_runs, unsigned long long *d_partial,
+                                  hipStream_t s);   // [n_runs][2] = first, last
 hipError_t launch_filter_popcount(const uint64_t *bits, uint64_t words, unsigned long long *d_out, hipStream_t s);             // *d_out += set bits
 // dst = a OP b, dst[words] = 0, d_partial[block] = set bits of the block's words (filter_combine_blocks(words) of them)
 uint32_t filter_combine_blocks(uint64_t words);
