@@ -33,6 +33,10 @@ on = torch.empty(nq, device=dev, dtype=torch.int32)
 settings = [("default", {}), ("hash-per-ef 32", {"hnsw-hash-per-ef": 32}), ("hash-per-ef 24", {"hnsw-hash-per-ef": 24}), ("hash-per-ef 16", {"hnsw-hash-per-ef": 16}),
             ("mode 2", {"hnsw-visited-mode": 2}), ("mode 2, per-ef 32", {"hnsw-visited-mode": 2, "hnsw-hash-per-ef": 32}),
             ("mode 1", {"hnsw-visited-mode": 1}), ("default again", {})]
+settings += [("mode 4 (LDS set forced)", {"hnsw-visited-mode": 4})]
+if os.environ.get("SETTINGS"):
+    keep = [x.strip() for x in os.environ["SETTINGS"].split(",")]
+    settings = [s_ for s_ in settings if s_[0] in keep]
 defaults = {"hnsw-hash-per-ef": 64, "hnsw-visited-mode": 3}
 ws = torch.cuda.Stream(device=dev)    # (a stream of its own: the library takes the null stream for "the index's own")
 for ef in efs:
