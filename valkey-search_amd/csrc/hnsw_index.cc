@@ -749,22 +749,32 @@ class HnswIndex final : public Index {
       h.cand_cap = (uint32_t)((std::max<uint64_t>(cand_floor_, ef + std::max<uint64_t>(64, ef / 4)) + 3) & ~(uint64_t)3);
       if (h.vis_mode >= 3) {
         // the set in LDS (12 KB per wave, ~5500 ids before most new ones spill into the table in memory): ids below 2^24, result
-        // lists in registers at up to eight slots per lane, two blocks of four waves must fit a CU (ef up to ~450 at 768
-        // dimensions), and -- mode 3, the default -- ef x maxM0 within the option hnsw-lds-visited-work: a search evaluates about
-        // 0.82 ef maxM0 nodes (10M x 768, M = 16: +15..27 % at ef = 128, +12..17 % at ef = 320 .. 448 where half of the ids
-        // spill; nothing at 512, -7 % at 640 .. 768).  Mode 4 takes an LDS set whenever it FITS (tests).
+        // lists in registers at up to eight slots per lane (ef <= 512), two blocks of four waves must fit a CU (at 768 dimensions
+        // ef = 512 fits with the frontier trimmed, below), and -- mode 3, the default -- ef x maxM0 within the option
+        // hnsw-lds-visited-work: a search evaluates about 0.82 ef maxM0 nodes (10M x 768, M = 16: +15..27 % at ef = 128,
+        // +12..17 % at ef = 320 .. 448 where half of the ids spill, +10 % at 480 and 512: profiles/r05_hnsw_large_ef_lds512.log).
+        // Beyond 512 the lists take sixteen slots per lane and eight waves no longer fit (six were -7 % at 640 .. 768).
+        // Mode 4 takes an LDS set whenever it FITS (tests).
         const bool forced = h.vis_mode == 4;
         const uint64_t work = ef * (uint64_t)graph_->maxM0();
         h.vis_mode = 3;                                     // the 12 KB set: two blocks of four waves per CU
-        // (two blocks of four waves per CU: result lists of up to eight slots per lane, ef up to ~450 -- the frontier grows with
-        //  ef.  Six waves per CU in blocks of two were measured for ef = 512 .. 1024 with sixteen slots: +2 % at 512, -7 % at
-        //  640 and 768, where two thirds of a search's ids spill anyway)
-        const bool fits_small = count < (1u << 24) && e <= 8 && 2 * hnsw_lds_bytes(h) <= 160 * 1024;
+        bool fits_small = count < (1u << 24) && e <= 8 && 2 * hnsw_lds_bytes(h) <= 160 * 1024;
+        if (!fits_small && count < (1u << 24) && e <= 8) {
+          // (ef = 512 misses the budget by 270 B per wave: a frontier of ef + 64 entries instead of ef + ef / 4 -- it holds
+          //  candidates nearer than the ef-th result, rarely more than ef of them; a query that fills it is re-run)
+          const uint32_t was = h.cand_cap;
+          h.cand_cap = (uint32_t)((std::max<uint64_t>(cand_floor_, ef + 64) + 3) & ~(uint64_t)3);
+          fits_small = 2 * hnsw_lds_bytes(h) <= 160 * 1024;
+          if (!fits_small) h.cand_cap = was;
+        }
+        const uint32_t cap_small = h.cand_cap;
         h.vis_mode = 5;                                     // the 32 KB set: one block of four waves per CU
         const bool fits_big = count < (1u << 24) && e <= 8 && hnsw_waves_per_block(h) == 4 && hnsw_lds_bytes(h) <= 160 * 1024;
         if (fits_small && (forced || work <= opt_.get(kOptHnswLdsWork))) h.vis_mode = 3;
         else if (fits_big && (forced || work <= opt_.get(kOptHnswLdsWorkBig))) h.vis_mode = 5;
         else h.vis_mode = 0;
+        if (h.vis_mode != 3 && cap_small != 0)   // (the trimmed frontier is the LDS set's concession only)
+          h.cand_cap = (uint32_t)((std::max<uint64_t>(cand_floor_, ef + std::max<uint64_t>(64, ef / 4)) + 3) & ~(uint64_t)3);
         // (the table in memory stays: ids that find no room on chip spill into it)
       }
       int mbh = 0;
