@@ -19,8 +19,8 @@
 // batch waits until the batch is full, the oldest request has waited max_wait_us, or nobody has arrived for a quarter
 // of that (20-200 us): callers of the batch that just finished come back within microseconds of each other.
 //
-// COMPLETER threads (option completer-threads, default 4) hand the answers of a finished batch to the callers' callbacks,
-// a piece of the batch each: a callback runs the caller's code (the adaptor builds the neighbour list and posts it on; 7-18 us
+// COMPLETER threads (option completer-threads, default 4; the PROCESS's, shared by all its indexes: CompleterPool) hand the
+// answers of a finished batch to the callers' callbacks, a piece of the batch each: a callback runs the caller's code (the adaptor builds the neighbour list and posts it on; 7-18 us
 // each measured), and with the runner doing that a FLAT pass started 1.5 ms late (0.77 of the device rate through the
 // adaptor, 0.98 with completers) and an HNSW runner spent more time answering than searching (0.35 -> 0.86).
 // vk_index_stats.dispatch_*_us is the dispatcher's own account of where its threads' time goes.
@@ -59,6 +59,7 @@
 #include <climits>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -70,6 +71,46 @@
 namespace vk {
 
 typedef void (*SearchDoneFn)(void *user, int status);   // == vk_search_done_fn (include/vk_index.h)
+
+// The completer threads are the PROCESS's, not an index's: a deployment holds dozens of indexes (one per vector field) and
+// the reference has one reader pool for all of them.  A piece of work is a closure; the pool grows to the largest number of
+// threads any index asked for (option completer-threads) and never shrinks; its threads are never joined (an index waits
+// for its own pieces, see Dispatcher::shutdown).
+class CompleterPool {
+ public:
+  static CompleterPool &instance() {
+    static CompleterPool *p = new CompleterPool();   // (never destroyed: indexes may be destroyed during static destruction)
+    return *p;
+  }
+  template <class It>
+  void post(It first, It last, uint32_t want_threads) {
+    std::lock_guard<std::mutex> lk(mu_);
+    while (threads_ < want_threads && threads_ < 16) {
+      std::thread([this] { loop(); }).detach();
+      threads_ += 1;
+    }
+    for (; first != last; ++first) q_.push_back(std::move(*first));
+    cv_.notify_all();
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&] { return !q_.empty(); });
+      std::function<void()> f = std::move(q_.front());
+      q_.pop_front();
+      lk.unlock();
+      f();
+      f = nullptr;
+      lk.lock();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> q_;
+  uint32_t threads_ = 0;
+};
 
 class Dispatcher {
  public:
@@ -194,13 +235,10 @@ class Dispatcher {
     cv_.notify_all();
     for (auto &t : runners_) t.join();
     runners_.clear();
-    {
-      std::lock_guard<std::mutex> lk(cmu_);
-      cstop_ = true;
+    {   // (the completer threads are the process's: what they still hold of THIS index is waited for)
+      std::unique_lock<std::mutex> lk(cmu_);
+      ccv_.wait(lk, [&] { return pieces_out_ == 0; });
     }
-    ccv_.notify_all();
-    for (auto &t : completers_) t.join();   // (they hand out what the runners left them first)
-    completers_.clear();
     {
       std::lock_guard<std::mutex> lk(wmu_);
       stop_watch_.store(true, std::memory_order_relaxed);
@@ -442,10 +480,6 @@ class Dispatcher {
     uint64_t k = 0;
     bool hnsw = false;
   };
-  struct Piece {
-    std::shared_ptr<Done> d;
-    uint64_t first, count;
-  };
   static uint64_t ns_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return b > a ? (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() : 0;
   }
@@ -558,10 +592,22 @@ class Dispatcher {
       d->k = k;
       d->hnsw = hnsw;
       const uint64_t chunk = std::max<uint64_t>(handout_chunk_.load(std::memory_order_relaxed), (nq + 4 * n_completers - 1) / (4 * n_completers));
-      std::lock_guard<std::mutex> lk(cmu_);
-      while (completers_.size() < n_completers) completers_.emplace_back([this] { complete_loop(); });
-      for (uint64_t first = 0; first < nq; first += chunk) done_q_.push_back(Piece{d, first, std::min<uint64_t>(chunk, nq - first)});
-      ccv_.notify_all();
+      std::vector<std::function<void()>> work;
+      for (uint64_t first = 0; first < nq; first += chunk) {
+        const uint64_t count = std::min<uint64_t>(chunk, nq - first);
+        work.emplace_back([this, d, first, count] {
+          const auto t0 = std::chrono::steady_clock::now();
+          hand_out(d->batch, d->sc, d->st, d->each, d->k, d->hnsw, first, count);
+          t_completer_.fetch_add(ns_between(t0, std::chrono::steady_clock::now()), std::memory_order_relaxed);
+          piece_done();
+        });
+      }
+      d.reset();   // (the pieces hold the batch; the last one to finish frees it)
+      {
+        std::lock_guard<std::mutex> lk(cmu_);
+        pieces_out_ += work.size();
+      }
+      CompleterPool::instance().post(work.begin(), work.end(), n_completers);
       return;
     }
     hand_out(batch, sc, st, each, k, hnsw, 0, nq);
@@ -585,20 +631,11 @@ class Dispatcher {
     }
     wake_blocked();
   }
-  void complete_loop() {
-    std::unique_lock<std::mutex> lk(cmu_);
-    for (;;) {
-      ccv_.wait(lk, [&] { return cstop_ || !done_q_.empty(); });
-      if (done_q_.empty()) return;
-      Piece p = std::move(done_q_.front());
-      done_q_.pop_front();
-      lk.unlock();
-      const auto t0 = std::chrono::steady_clock::now();
-      hand_out(p.d->batch, p.d->sc, p.d->st, p.d->each, p.d->k, p.d->hnsw, p.first, p.count);
-      p.d.reset();   // (the last piece frees the batch)
-      t_completer_.fetch_add(ns_between(t0, std::chrono::steady_clock::now()), std::memory_order_relaxed);
-      lk.lock();
-    }
+  void piece_done() {
+    // (the closure -- and with it the piece's reference on the batch -- is destroyed by the pool thread AFTER this returns: the
+    //  batch's requests and buffers are the batch's own, nothing of the dispatcher is touched by that)
+    std::lock_guard<std::mutex> lk(cmu_);
+    if (--pieces_out_ == 0) ccv_.notify_all();
   }
 
   // ---- the watcher: batches on the device that carry tokens ---------------------------------------------------------
@@ -706,9 +743,7 @@ class Dispatcher {
   std::atomic<uint64_t> queued_{0}, batches_{0}, queries_{0}, submitted_{0}, rejected_{0}, max_active_seen_{0}, left_early_{0};
   std::mutex cmu_;
   std::condition_variable ccv_;
-  std::deque<Piece> done_q_;
-  std::vector<std::thread> completers_;
-  bool cstop_ = false;
+  uint64_t pieces_out_ = 0;   // pieces of finished batches the process's completer threads still hold (under cmu_)
   std::mutex wmu_;
   std::condition_variable wcv_;
   std::vector<std::shared_ptr<Watched>> watched_;
