@@ -82,7 +82,7 @@ if NH:
         h.search_batch(hq, K, ef=128)
     dq = nq * 5 / (time.perf_counter() - t0)
     print(f"HNSW host-entry batch rate {dq:.0f} QPS (8192 queries a call, ef=128)", flush=True)
-    for comp in (4, 2, 0):
+    for comp in [int(c) for c in __import__("os").environ.get("COMPLETERS", "4,2,0").split(",")]:
         h.set_option("completer-threads", comp)
         h.set_coalescing(nq, 2000)
         vsa.probe_submit(h, hq, K, 4 * nq, 8, 4 * nq, 128, ref=(rd, rl))
