@@ -303,7 +303,8 @@ int vk_index_set_coalescing(vk_index *ix, uint32_t max_batch, uint32_t max_wait_
  * of reader threads.  Coalescing must be on (vk_index_set_coalescing with max_batch > 1), else VK_ERR_INVALID.
  *   done(user, status) is called exactly once, from a library thread, after out_dist / out_label / *out_n have been
  *   written; status is the vk_status of the batch the request travelled in (VK_ERR_CANCELLED as for vk_index_search).
- *   The callbacks of a batch run on the library's completer threads (option completer-threads, default 4), several
+ *   The callbacks of a batch run on the library's completer threads (option completer-threads, default 4; one pool for all
+ *   indexes of the process), several
  *   side by side and in no particular order; one must not block for long (it holds up the completions queued behind
  *   it) and must not destroy the index.
  *   The query is copied at submission; allow_bits, cancel_flag and the output buffers must stay valid until then.
