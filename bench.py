@@ -192,7 +192,7 @@ def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
     gl, head = point(ef)
     # matched recall: the smallest ef of the sweep whose recall@10 reaches 0.95 (SURVEY.md 8e asks for both points)
     sweep, matched = [head], None
-    for ef_s in (192, 256, 384, 512, 576, 640, 768, 1024, 1536, 2048, 3072, 4096):
+    for ef_s in (192, 256, 384, 512, 544, 576, 640, 768, 1024, 1536, 2048, 3072, 4096):
         if ef_s <= ef:
             continue
         _, pt = point(ef_s, reps=2)

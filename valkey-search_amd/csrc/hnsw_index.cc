@@ -749,22 +749,25 @@ class HnswIndex final : public Index {
       h.cand_cap = (uint32_t)((std::max<uint64_t>(cand_floor_, ef + std::max<uint64_t>(64, ef / 4)) + 3) & ~(uint64_t)3);
       if (h.vis_mode >= 3) {
         // the set in LDS (12 KB per wave, ~5500 ids before most new ones spill into the table in memory): ids below 2^24, result
-        // lists in registers at up to eight slots per lane (ef <= 512), two blocks of four waves must fit a CU (at 768 dimensions
-        // ef = 512 fits with the frontier trimmed, below), and -- mode 3, the default -- ef x maxM0 within the option
+        // lists in registers (up to sixteen slots per lane), two blocks of four waves must fit a CU (at 768 dimensions up to
+        // ef = 544, with the frontier trimmed, below), and -- mode 3, the default -- ef x maxM0 within the option
         // hnsw-lds-visited-work: a search evaluates about 0.82 ef maxM0 nodes (10M x 768, M = 16: +15..27 % at ef = 128,
-        // +12..17 % at ef = 320 .. 448 where half of the ids spill, +10 % at 480 and 512: profiles/r05_hnsw_large_ef_lds512.log).
-        // Beyond 512 the lists take sixteen slots per lane and eight waves no longer fit (six were -7 % at 640 .. 768).
-        // Mode 4 takes an LDS set whenever it FITS (tests).
+        // +12..17 % at ef = 320 .. 448 where half of the ids spill, +10 % at 480 .. 544: profiles/r05_hnsw_large_ef_lds5*.log).
+        // Beyond that eight waves no longer fit (six were -7 % at 640 .. 768).  Mode 4 takes an LDS set whenever it FITS (tests).
         const bool forced = h.vis_mode == 4;
         const uint64_t work = ef * (uint64_t)graph_->maxM0();
         h.vis_mode = 3;                                     // the 12 KB set: two blocks of four waves per CU
-        bool fits_small = count < (1u << 24) && e <= 8 && 2 * hnsw_lds_bytes(h) <= 160 * 1024;
-        if (!fits_small && count < (1u << 24) && e <= 8) {
+        bool fits_small = count < (1u << 24) && e <= 16 && 2 * hnsw_lds_bytes(h) <= 160 * 1024;
+        if (!fits_small && count < (1u << 24) && e <= 16) {
           // (ef = 512 misses the budget by 270 B per wave: a frontier of ef + 64 entries instead of ef + ef / 4 -- it holds
-          //  candidates nearer than the ef-th result, rarely more than ef of them; a query that fills it is re-run)
+          //  candidates nearer than the ef-th result, rarely more than ef of them; a query that fills it is re-run -- and
+          //  with ef + 32 entries ef = 544 fits to the byte)
           const uint32_t was = h.cand_cap;
-          h.cand_cap = (uint32_t)((std::max<uint64_t>(cand_floor_, ef + 64) + 3) & ~(uint64_t)3);
-          fits_small = 2 * hnsw_lds_bytes(h) <= 160 * 1024;
+          for (uint64_t room : {(uint64_t)64, (uint64_t)32}) {
+            h.cand_cap = (uint32_t)((std::max<uint64_t>(cand_floor_, ef + room) + 3) & ~(uint64_t)3);
+            fits_small = 2 * hnsw_lds_bytes(h) <= 160 * 1024;
+            if (fits_small) break;
+          }
           if (!fits_small) h.cand_cap = was;
         }
         const uint32_t cap_small = h.cand_cap;

@@ -958,7 +958,7 @@ size_t hnsw_lds_bytes(const HnswSearchArgs &a) { return hnsw_lds_per_wave(a) * (
 
 template <bool kL2, int kE, bool kBf16>
 static const void *hnsw_fn(bool latency, int gpool, int hash) {
-  if constexpr (kE >= 1 && kE <= 8) {
+  if constexpr (kE >= 1 && kE <= 16) {   // (sixteen slots per lane: ef 513 .. 576, as far as eight waves fit a CU at 768 dimensions)
     if (hash == 3) return reinterpret_cast<const void *>(&hnsw_search_ldsvis_kernel<kL2, kE, kBf16>);
   }
   if constexpr (kE >= 1 && kE <= 8) {

@@ -103,7 +103,7 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"hnsw-hash-per-ef", "VK_HNSW_HASH_PER_EF", 64, 1, 1u << 16},
       {"hnsw-hash-log2", "VK_HNSW_HASH_LOG2", 0, 0, 26},
       {"hnsw-visited-mode", "VK_HNSW_VISITED_MODE", 3, 0, 4},
-      {"hnsw-lds-visited-work", "VK_HNSW_LDS_WORK", 16384, 0, 1u << 24},         // mode 3: ef x maxM0 up to here (ef = 512 at M = 16) takes the 12 KB LDS set ...
+      {"hnsw-lds-visited-work", "VK_HNSW_LDS_WORK", 17408, 0, 1u << 24},         // mode 3: ef x maxM0 up to here (ef = 544 at M = 16) takes the 12 KB LDS set ...
       {"hnsw-lds-visited-work-big", "VK_HNSW_LDS_WORK_BIG", 0, 0, 1u << 24},      // ... the 32 KB one (off: the small set with spill beats it at every ef measured)
       {"hnsw-pool-bytes", "VK_HNSW_POOL_BYTES", (uint64_t)4 << 30, 1u << 20, kMax},
       {"hnsw-visited-bytes", "VK_HNSW_VISITED_BYTES", (uint64_t)4 << 30, 1u << 20, kMax},
