@@ -138,8 +138,8 @@ def test_other_ways_of_keeping_the_hash_set_match_the_oracle(vsa, oracle, mode, 
         env["VK_HNSW_HASH_LOG2"] = log2
     # (one builder thread: the same graph every run.  With several the graph differs from build to build, and about one
     #  (graph, query) in tens of thousands has two frontier candidates at EXACTLY the same f32 distance whose expansion order
-    #  decides whether the second is still expanded -- hnswlib pops the larger id first, the kernels the smaller pool index:
-    #  same answer, one hop more or less.  DESIGN.md section 2 states the contract for tie-free data; scripts/
+    #  decides whether the second is still expanded -- hnswlib's heaps compare distances only, so its order is libstdc++'s sift
+    #  order; the kernels take the smaller pool index: same answer, one hop more or less.  DESIGN.md section 2 states the contract for tie-free data; scripts/
     #  hnsw_hop_mismatch_hunt.py finds such a case, profiles/r05_hnsw_tie_hop.log.)
     with _Env(**env):
         g = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=M, ef_construction=40, build_threads=1)
