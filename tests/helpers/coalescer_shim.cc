@@ -274,6 +274,58 @@ extern "C" int dispatcher_destroy_run(int rounds, int n_req) {
   return bad.load();
 }
 
+// Two indexes share the process's completer threads (CompleterPool): both serve submissions whose batches are handed out
+// in pieces by the pool; index A is destroyed while B's pieces are still queued and running -- A's destructor waits for A's
+// own pieces only, B goes on, and nothing of A is touched afterwards (ASAN / TSAN).
+extern "C" int dispatcher_two_indexes_run(int rounds, int n_req) {
+  std::atomic<int> bad{0};
+  for (int r = 0; r < rounds; ++r) {
+    vk_index_params p{};
+    p.struct_size = sizeof p;
+    p.dim = 4;
+    p.algo = VK_ALGO_HNSW;
+    FakeIndex ia(p), ib(p);
+    ia.delay_us = 300;
+    ib.delay_us = 900;
+    std::atomic<uint64_t> ca{0}, cb{0};
+    std::vector<std::unique_ptr<AsyncSlot>> sa, sb;
+    uint64_t acc_a = 0, acc_b = 0;
+    auto feed = [&](vk::Dispatcher &dp, std::vector<std::unique_ptr<AsyncSlot>> &slots, std::atomic<uint64_t> &cnt, uint64_t &acc) {
+      for (int i = 0; i < n_req; ++i) {
+        auto s = std::make_unique<AsyncSlot>();
+        s->id = i;
+        s->q[0] = (float)i; s->q[1] = (float)(i + 7); s->q[2] = s->q[3] = 0.f;
+        s->flag = 0;
+        s->completions = &cnt;
+        if (dp.submit(s->q, 3, 100, nullptr, 0, nullptr, nullptr, true, s->d, s->l, &s->n, async_done, s.get()).ok()) acc += 1;
+        slots.push_back(std::move(s));
+      }
+    };
+    {
+      vk::Dispatcher db(&ib);
+      db.configure(64, 2000);
+      db.set_in_flight(2);
+      db.set_completers(3, 16);
+      {
+        vk::Dispatcher da(&ia);
+        da.configure(64, 2000);
+        da.set_in_flight(2);
+        da.set_completers(2, 16);
+        std::thread tb([&] { feed(db, sb, cb, acc_b); });
+        feed(da, sa, ca, acc_a);
+        tb.join();
+      }   // ~Dispatcher A: B still has batches on its "device" and pieces in the pool
+      if (ca.load() != acc_a) bad += 1;
+      for (auto &s : sa)
+        if (s->done.load() != 1 || s->status != VK_OK || s->n != 3 || s->l[0] != (uint64_t)(s->id + 7) * 10) bad += 1;
+    }
+    if (cb.load() != acc_b) bad += 1;
+    for (auto &s : sb)
+      if (s->done.load() != 1 || s->status != VK_OK || s->n != 3 || s->l[0] != (uint64_t)(s->id + 7) * 10) bad += 1;
+  }
+  return bad.load();
+}
+
 // Every member of a batch carries a token and all of them go up while the batch is on the device: the batch's own
 // cancellation word must go up (the fake device pass polls it like the kernels do) and the callers come back long before
 // the pass would have ended; with one live member among them the batch must run to its end.

@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
   bad += dispatcher_async_run(4 * scale, 200, 200, 16, 500, 3, 40, 300, 1, out);   // a shallow queue: rejections
   bad += dispatcher_async_run(8, 1200 * scale, 1200, 4096, 3000, 2, 100000, 2000, 1, out);   // batches beyond 1024: answered by the completer threads
   bad += dispatcher_destroy_run(6 * scale, 50);
+  bad += dispatcher_two_indexes_run(4 * scale, 600);
   bad += dispatcher_batch_cancel_run(1, out);
   bad += dispatcher_batch_cancel_run(0, out);
   // one member of a live batch cancelled: blocking and submitted, both index kinds

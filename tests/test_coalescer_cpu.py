@@ -25,6 +25,7 @@ def shim(tmp_path_factory):
     lib.dispatcher_async_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int,
                                          C.POINTER(C.c_uint64)]
     lib.dispatcher_destroy_run.argtypes = [C.c_int, C.c_int]
+    lib.dispatcher_two_indexes_run.argtypes = [C.c_int, C.c_int]
     lib.dispatcher_batch_cancel_run.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.dispatcher_member_cancel_run.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     lib.dispatcher_flat_fill_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
@@ -132,6 +133,12 @@ def test_a_full_queue_rejects_with_busy_and_its_callback_never_fires(shim):
 
 def test_destroy_answers_what_is_queued(shim):
     assert shim.dispatcher_destroy_run(8, 60) == 0
+
+
+def test_two_indexes_share_the_completer_threads_and_one_is_destroyed_while_the_other_serves(shim):
+    """The completer threads are the process's (CompleterPool): an index's destructor waits for ITS pieces of finished batches
+    only, the other index's pieces -- queued in the same pool -- go on; every callback fires exactly once with its own answer."""
+    assert shim.dispatcher_two_indexes_run(6, 600) == 0
 
 
 def test_a_batch_whose_members_are_all_cancelled_stops_on_the_device(shim):
