@@ -33,6 +33,11 @@ def test_random_shape_through_the_filter(vsa, oracle, seed):
     rng = np.random.default_rng(9000 + seed + SWEEP_OFFSET)
     dim = int(rng.choice(DIMS))
     n = int(rng.integers(34_000, 70_000 if dim <= 512 else 40_000))
+    # every fourth seed (small dimensions): three times the rows and the two-pass pipeline switched on for indexes of two tiles
+    # per CU -- an early pass over up to half of every block's range, the main pass's bound from its survivors (r05)
+    two_pass = seed % 4 == 3 and dim <= 256
+    if two_pass:
+        n *= 3
     nq = int(rng.choice(BATCHES))
     metric = str(rng.choice(["L2", "IP", "COSINE"]))
     dtype = "bf16" if rng.random() < 0.3 else "f32"
@@ -72,6 +77,8 @@ def test_random_shape_through_the_filter(vsa, oracle, seed):
                 os.environ.pop(v, None)
             else:
                 os.environ[v] = o
+    if two_pass:
+        g.set_option("filter-two-pass-min-tiles", 2)
     g.add_batch(x, labels)
     xs = _bf16_round(x) if dtype == "bf16" else x
     o = oracle.Flat(dim, metric, max_elements=n)
@@ -90,6 +97,8 @@ def test_random_shape_through_the_filter(vsa, oracle, seed):
         allow = oracle.allow_bitmap(labels[rng.random(n) < rng.choice([0.5, 0.1, 0.01])], nbits)
     D, L, N = g.search_batch(Q, k, allow=allow, allow_nbits=nbits)
     st = g.stats()
+    if two_pass and st.last_filter_candidates > 0 and st.count >= 256 * 2 * 128:
+        assert 0 < st.last_filter_final_rows < st.count, (st.last_filter_final_rows, st.count)   # the batch did take two passes
     # (the path needs an index at least eight times the bound's sample: 1024 rows per 10 of k with this test's settings)
     # ... and rows the f16 pipe can carry: an index that is mostly tiles with a value beyond 32768 (or, for L2, a half
     # norm beyond f16) is kept off the path altogether
