@@ -104,6 +104,9 @@ typedef struct vk_index_params {
   uint32_t load_skip_validation;
 } vk_index_params;
 
+/* vk_index_get_stats fills sizeof(vk_index_stats) bytes of THIS header's layout: the struct grows at its end from round to round
+ * (vk_index_params carries struct_size and is checked; this one is output only), so a binding is rebuilt against the header of
+ * the library it loads -- tests/test_abi_symbols.py holds the Python binding and the in-tree binaries to that. */
 typedef struct vk_index_stats {
   uint64_t count;             /* cur_element_count_ (live + tombstoned) */
   uint64_t deleted;           /* num_deleted_ (HNSW tombstones) */
