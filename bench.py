@@ -866,6 +866,19 @@ def sharded_hybrid_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows
                       "ids_per_filter": int(np.mean([len(x) for x in tag_ids])), "recall_at_10": round(recall_of(L, gt, K), 4),
                       **work(nq, dt - dt_f, 2)}
     glw = last["out"][1].copy()
+    # What S graphs need to give back the ONE graph's recall: every shard searched with a fraction of the query's ef (option
+    # shard-ef-pct; the reference's cluster mode sends the full ef to every shard, which is what the two steps above time)
+    if S > 1:
+        for pct in (50, 25):
+            try:
+                h.set_option("shard-ef-pct", pct)
+                dt, dt_f, built = timed_leg(lambda: step(False), 2)
+                _D, L, _N = last["out"]
+                legs[f"shared_tags_warm_shard_ef_{pct}pct"] = {"queries": nq, "per_shard_ef": max(K, ef_h * pct // 100), "gpu_qps": round(nq / dt, 1),
+                                                               "ms_per_step": round(dt * 1e3, 2), "recall_at_10": round(recall_of(L, gt, K), 4),
+                                                               **work(nq, dt - dt_f, 2)}
+            finally:
+                h.set_option("shard-ef-pct", 100)
     # every query its own predicate: tag_a OR tag_b over cached terms, combined on the device inside the step
     nd = min(1024, nq)
     pairs = [(i % T, (i // T + 1 + i) % T) for i in range(nd)]
