@@ -212,6 +212,9 @@ int vk_index_create(const vk_index_params *params, vk_index **out);
 void vk_index_destroy(vk_index *ix);
 int vk_device_count(void);
 const char *vk_last_error(void);
+/* What the LOADED library thinks the two structs of this header measure (which = 0: vk_index_params, 1: vk_index_stats, else
+ * 0): a binding compares it with its own sizeof before the first call -- vk_index_get_stats writes that many bytes. */
+uint64_t vk_abi_struct_size(int which);
 
 /* ---- mutations (writer phase) -------------------------------------------------------
  * addPoint: bruteforce.h:66-83 / hnswalg.h:1278-1340 (same label again = in-place update,

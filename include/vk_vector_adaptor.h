@@ -401,7 +401,14 @@ class VectorGpu : public VectorBase {
   }
   // an index that exists already (built by a bulk loader, or -- scripts/adaptor_probe.cc -- by the benchmark): served through
   // this object, destroyed by whoever made it.  The caller keeps it alive until every search through this object is done.
+  // (a libvkindex.so of another round behind this header: vk_index_get_stats would write past -- or short of -- the struct)
+  static absl::Status CheckAbi() {
+    if (vk_abi_struct_size(0) != sizeof(vk_index_params) || vk_abi_struct_size(1) != sizeof(vk_index_stats))
+      return absl::FailedPreconditionError("libvkindex.so was built from another vk_index.h than this adaptor");
+    return absl::OkStatus();
+  }
   absl::Status Adopt(vk_index *ix, vk_index_params p, uint32_t reader_threads) {
+    if (auto st = CheckAbi(); !st.ok()) return st;
     params_ = MakeParams(p);
     ix_ = ix;
     owns_ = false;
@@ -409,6 +416,7 @@ class VectorGpu : public VectorBase {
     return Serve(reader_threads);
   }
   absl::Status Open(vk_index_params p, uint32_t reader_threads) {
+    if (auto st = CheckAbi(); !st.ok()) return st;
     params_ = MakeParams(p);
     if (int rc = vk_index_create(&params_, &ix_); rc != VK_OK) return VkToStatus(rc);
     return Serve(reader_threads);
@@ -417,6 +425,7 @@ class VectorGpu : public VectorBase {
   // stream through vk_index_load_tracked; every loaded vector goes back to VectorBase::TrackVector like LoadIndex's
   // VectorTracker calls (bruteforce.h:201, hnswalg.h:1000); the id counter resumes behind the largest loaded label
   absl::Status OpenFromRDB(vk_index_params p, uint32_t reader_threads, SupplementalContentChunkIter &&iter) {
+    if (auto st = CheckAbi(); !st.ok()) return st;
     params_ = MakeParams(p);
     struct Source {
       RDBChunkInputStream input;

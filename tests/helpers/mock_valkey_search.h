@@ -29,7 +29,7 @@
 
 namespace absl {
 using string_view = std::string_view;
-enum class StatusCode { kOk = 0, kCancelled = 1, kInvalidArgument = 3, kNotFound = 5, kResourceExhausted = 8, kInternal = 13, kUnavailable = 14 };
+enum class StatusCode { kOk = 0, kCancelled = 1, kInvalidArgument = 3, kNotFound = 5, kResourceExhausted = 8, kFailedPrecondition = 9, kInternal = 13, kUnavailable = 14 };
 class Status {
  public:
   Status() = default;
@@ -49,6 +49,7 @@ inline Status NotFoundError(std::string_view m) { return Status(StatusCode::kNot
 inline Status CancelledError(std::string_view m) { return Status(StatusCode::kCancelled, std::string(m)); }
 inline Status ResourceExhaustedError(std::string_view m) { return Status(StatusCode::kResourceExhausted, std::string(m)); }
 inline Status UnavailableError(std::string_view m) { return Status(StatusCode::kUnavailable, std::string(m)); }
+inline Status FailedPreconditionError(std::string_view m) { return Status(StatusCode::kFailedPrecondition, std::string(m)); }
 template <typename T>
 class StatusOr {
  public:

@@ -40,6 +40,15 @@ def test_library_exports_every_declared_symbol(vsa):
     assert not missing, missing
 
 
+def test_library_reports_the_struct_sizes_of_the_header_it_was_built_from(vsa):
+    """vk_abi_struct_size: what a binding checks before its first call (the Python binding and the adaptor classes do)"""
+    lib = C.CDLL(str(vsa.LIB_PATH))
+    lib.vk_abi_struct_size.argtypes = [C.c_int]
+    lib.vk_abi_struct_size.restype = C.c_uint64
+    assert lib.vk_abi_struct_size(0) == C.sizeof(vsa.Params) and lib.vk_abi_struct_size(1) == C.sizeof(vsa.Stats)
+    assert lib.vk_abi_struct_size(2) == 0
+
+
 def test_struct_layouts_match_header(vsa, tmp_path):
     """The ctypes mirrors against what a C compiler makes of include/vk_index.h: size and the
     offset of every field (gcc compiles a probe that prints them)."""

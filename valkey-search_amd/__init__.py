@@ -101,6 +101,11 @@ def lib() -> C.CDLL:
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     u64p, f32p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     L.vk_last_error.restype = C.c_char_p
+    L.vk_abi_struct_size.argtypes = [i32]
+    L.vk_abi_struct_size.restype = u64
+    if L.vk_abi_struct_size(0) != C.sizeof(Params) or L.vk_abi_struct_size(1) != C.sizeof(Stats):
+        raise RuntimeError(f"{LIB_PATH}: built from another vk_index.h than this binding (params {L.vk_abi_struct_size(0)} / {C.sizeof(Params)}, "
+                           f"stats {L.vk_abi_struct_size(1)} / {C.sizeof(Stats)} bytes): run `python -c 'import __graft_entry__ as g; g.build()'`")
     L.vk_device_count.restype = i32
     L.vk_index_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     L.vk_index_destroy.argtypes = [vp]

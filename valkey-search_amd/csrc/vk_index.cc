@@ -137,6 +137,8 @@ extern "C" {
 
 const char *vk_last_error(void) { return g_last_error.c_str(); }
 
+uint64_t vk_abi_struct_size(int which) { return which == 0 ? sizeof(vk_index_params) : which == 1 ? sizeof(vk_index_stats) : 0; }
+
 int vk_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
