@@ -504,6 +504,18 @@ static int add_point_level(vko_hnsw *h, const float *row, uint64_t label, int le
     return 0;
 }
 
+/* hnswalg.h:1306-1338: the new label takes over tombstoned slot `replaced` */
+static int replace_vacant(vko_hnsw *h, const float *row, uint64_t label, uint32_t replaced) {
+    vacant_erase(h, replaced);
+    uint64_t label_replaced = h->labels[replaced];
+    h->labels[replaced] = label;
+    vko_map_del(&h->label_lookup, label_replaced);
+    vko_map_put(&h->label_lookup, label, replaced);
+    int err = 0;
+    unmark_deleted_internal(h, replaced, &err);
+    return update_point(h, row, replaced, 1.0f);
+}
+
 /* hnswalg.h:1278-1340 with replace_deleted = allow_replace_deleted_
  * (vector_hnsw.cc:182-183) */
 int vko_hnsw_add(vko_hnsw *h, const float *row, uint64_t label) {
@@ -515,14 +527,27 @@ int vko_hnsw_add(vko_hnsw *h, const float *row, uint64_t label) {
         return update_point(h, row, existing, 1.0f);
     }
     if (h->n_vacant == 0) return add_point_level(h, row, label, -1);
-    uint32_t replaced = h->vacant[--h->n_vacant];
-    uint64_t label_replaced = h->labels[replaced];
-    h->labels[replaced] = label;
-    vko_map_del(&h->label_lookup, label_replaced);
-    vko_map_put(&h->label_lookup, label, replaced);
-    int err = 0;
-    unmark_deleted_internal(h, replaced, &err);
-    return update_point(h, row, replaced, 1.0f);
+    return replace_vacant(h, row, label, h->vacant[h->n_vacant - 1]);
+}
+
+/* The same, with the tombstoned slot to take over NAMED by the caller.  hnswalg.h:1306-1309
+ * takes `*deleted_elements.begin()` of a std::unordered_set<tableint>: which vacant slot that
+ * is depends on the container's bucket history and is not part of the algorithm.  A
+ * differential test lets the implementation under test choose and replays the choice here;
+ * the slot must be vacant (else 2).  With no vacant slot or a known label: vko_hnsw_add. */
+int vko_hnsw_add_into(vko_hnsw *h, const float *row, uint64_t label, uint32_t slot) {
+    uint32_t existing;
+    if (!h->allow_replace_deleted || vko_map_get(&h->label_lookup, label, &existing) || h->n_vacant == 0)
+        return vko_hnsw_add(h, row, label);
+    for (size_t i = 0; i < h->n_vacant; ++i)
+        if (h->vacant[i] == slot) return replace_vacant(h, row, label, slot);
+    vko_set_error("the named slot is not vacant");
+    return 2;
+}
+
+size_t vko_hnsw_vacant(const vko_hnsw *h, uint32_t *out, size_t cap) {
+    for (size_t i = 0; i < h->n_vacant && i < cap; ++i) out[i] = h->vacant[i];
+    return h->n_vacant;
 }
 
 /* ---- query: searchBaseLayerST<false,false>, hnswalg.h:351-551 ------------------ */

@@ -75,6 +75,10 @@ def _load():
     lib.vko_hnsw_set_ef.argtypes = [C.c_void_p, C.c_size_t]
     lib.vko_hnsw_add.restype = C.c_int
     lib.vko_hnsw_add.argtypes = [C.c_void_p, _f32p, C.c_uint64]
+    lib.vko_hnsw_add_into.restype = C.c_int
+    lib.vko_hnsw_add_into.argtypes = [C.c_void_p, _f32p, C.c_uint64, C.c_uint32]
+    lib.vko_hnsw_vacant.restype = C.c_size_t
+    lib.vko_hnsw_vacant.argtypes = [C.c_void_p, _u32p, C.c_size_t]
     lib.vko_hnsw_mark_delete.restype = C.c_int
     lib.vko_hnsw_mark_delete.argtypes = [C.c_void_p, C.c_uint64]
     lib.vko_hnsw_resize.argtypes = [C.c_void_p, C.c_size_t]
@@ -267,6 +271,21 @@ class HNSW:
         row = f32(row)
         assert row.size == self.dim
         return LIB.vko_hnsw_add(self._h, _fp(row), int(label))
+
+    def add_into(self, row, label, slot) -> int:
+        """addPoint(replace_deleted) with the tombstoned slot to reuse named by the caller (hnswalg.h:1306-1309 takes
+        `*deleted_elements.begin()` of an unordered_set: the choice is the container's, not the algorithm's).
+        2 if `slot` is not vacant; a known label or no vacancy: plain add."""
+        row = f32(row)
+        assert row.size == self.dim
+        return LIB.vko_hnsw_add_into(self._h, _fp(row), int(label), int(slot))
+
+    def vacant(self):
+        """The tombstoned slots a new label may take over (deleted_elements)."""
+        n = LIB.vko_hnsw_vacant(self._h, None, 0)
+        out = np.empty(max(n, 1), np.uint32)
+        LIB.vko_hnsw_vacant(self._h, out.ctypes.data_as(_u32p), n)
+        return out[:n].tolist()
 
     def add_many(self, rows, labels=None):
         rows = f32(rows)

@@ -89,6 +89,10 @@ void vko_hnsw_set_ef(vko_hnsw *h, size_t ef);
 /* addPoint(data,label,replace_deleted=allow_replace_deleted) (hnswalg.h:1278-1340).
  * 0 ok; 1 = exceeds limit; 2 = other runtime_error (message via vko_last_error) */
 int vko_hnsw_add(vko_hnsw *h, const float *row, uint64_t label);
+/* the same with the tombstoned slot to take over named by the caller (the reference takes
+ * *deleted_elements.begin() of an unordered_set, hnswalg.h:1306-1309); 2 if not vacant */
+int vko_hnsw_add_into(vko_hnsw *h, const float *row, uint64_t label, uint32_t slot);
+size_t vko_hnsw_vacant(const vko_hnsw *h, uint32_t *out, size_t cap);
 int vko_hnsw_mark_delete(vko_hnsw *h, uint64_t label); /* 0 ok, 2 error */
 void vko_hnsw_resize(vko_hnsw *h, size_t new_max);
 size_t vko_hnsw_count(const vko_hnsw *h);

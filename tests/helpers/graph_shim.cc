@@ -14,6 +14,11 @@ int gs_add(void *g, const float *row, uint64_t label) {
   uint32_t id;
   return static_cast<HnswGraph *>(g)->add(row, label, &id).code;
 }
+// the slot the label landed in (a new slot, its own on an update, or a tombstoned one taken over); -1 on error
+long gs_add_at(void *g, const float *row, uint64_t label) {
+  uint32_t id;
+  return static_cast<HnswGraph *>(g)->add(row, label, &id).code ? -1L : (long)id;
+}
 int gs_mark_delete(void *g, uint64_t label) { return static_cast<HnswGraph *>(g)->mark_delete(label).code; }
 int gs_resize(void *g, size_t n) { return static_cast<HnswGraph *>(g)->resize(n).code; }
 size_t gs_count(void *g) { return static_cast<HnswGraph *>(g)->count(); }

@@ -27,6 +27,8 @@ def gs(tmp_path_factory):
     lib.gs_new.argtypes = [C.c_uint32, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
     lib.gs_free.argtypes = [C.c_void_p]
     lib.gs_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.gs_add_at.restype = C.c_long
+    lib.gs_add_at.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.gs_mark_delete.argtypes = [C.c_void_p, C.c_uint64]
     lib.gs_resize.argtypes = [C.c_void_p, C.c_size_t]
     lib.gs_count.restype = C.c_size_t
@@ -120,6 +122,84 @@ def test_tombstones_updates_and_capacity(gs, oracle):
         assert len(lst) <= (2 * M if l == 0 else M)
     # updatePoint iterates std::unordered_set (order unpinned in the oracle): compare as sets
     same = sum(set(a["links"][k]) == set(b["links"][k]) for k in a["links"])
+    assert same >= 0.97 * len(a["links"])
+    gs.gs_free(g)
+
+
+def test_replace_deleted_slots_follow_hnswalg(gs, oracle):
+    """addPoint(data, label, replace_deleted = true) (hnswalg.h:1278-1340; switched on by hnsw-allow-replace-deleted,
+    valkey_search_options.cc:149-152, vector_hnsw.cc:99-100,182-183): a new label takes over a tombstoned slot and is linked
+    like an update of it; a known deleted label is un-deleted in place; with no vacancy the graph grows.  Which vacant slot
+    `*deleted_elements.begin()` names is the unordered_set's business: the product chooses, the oracle replays the choice
+    (and refuses a slot that is not vacant), everything else must agree."""
+    rng = np.random.default_rng(18)
+    dim, n, M, efc = 24, 500, 8, 60
+    x = rng.standard_normal((n + 400, dim)).astype(np.float32)
+    g = gs.gs_new(dim, 1, n + 40, M, efc, 100, 1)
+    o = oracle.HNSW(dim, "L2", max_elements=n + 40, M=M, ef_construction=efc, seed=100, allow_replace_deleted=True)
+    nxt = [n]
+
+    def fresh():
+        nxt[0] += 1
+        return nxt[0] - 1
+
+    def add_new(label):
+        row = np.ascontiguousarray(x[label % x.shape[0]])
+        vac = set(o.vacant())
+        slot = gs.gs_add_at(g, row.ctypes.data, label)
+        assert slot >= 0
+        if vac:
+            assert slot in vac, "a new label must take a tombstoned slot while one is vacant"
+        else:
+            assert slot == o.count, "no vacancy: a new slot at the end"
+        assert o.add_into(row, label, slot) == 0, oracle.last_error()
+        return slot
+
+    for i in range(n):
+        assert gs.gs_add(g, x[i].ctypes.data, i) == 0 and o.add(x[i], i) == 0
+    # one vacancy at a time: nothing for a container to choose
+    for lab in (3, 77, 250, 499, 0):
+        assert gs.gs_mark_delete(g, lab) == 0 and o.mark_delete(lab) == 0
+        slot = add_new(fresh())
+        assert slot == lab                                  # labels were slot numbers so far
+        assert gs.gs_label_of(g, slot) == nxt[0] - 1
+        assert gs.gs_mark_delete(g, lab) == 3 and o.mark_delete(lab) == 2      # the old label is gone ("Label not found")
+    count0 = gs.gs_count(g)
+    assert count0 == n == o.count
+    # many vacancies
+    dead = [int(v) for v in rng.permutation(np.arange(5, n))[:30] if v not in (77, 250, 499)]
+    for lab in dead:
+        assert gs.gs_mark_delete(g, lab) == 0 and o.mark_delete(lab) == 0
+    taken = [add_new(fresh()) for _ in range(len(dead) - 12)]
+    assert len(set(taken)) == len(taken) and set(taken) <= set(dead)
+    assert gs.gs_count(g) == n
+    left = sorted(set(dead) - set(taken))
+    # a deleted label comes back: un-deleted in its own slot, which stops being vacant (:1297-1305)
+    back = left[0]
+    row = rng.standard_normal(dim).astype(np.float32)
+    assert gs.gs_add_at(g, row.ctypes.data, back) == back and o.add(row, back) == 0
+    assert back not in o.vacant() and not gs.gs_is_deleted(g, back)
+    # a live label updated while vacancies exist keeps its slot
+    row = rng.standard_normal(dim).astype(np.float32)
+    assert gs.gs_add_at(g, row.ctypes.data, 1) == 1 and o.add(row, 1) == 0
+    # fill the remaining vacancies, then grow, up to the limit
+    more = [add_new(fresh()) for _ in range(len(left) - 1)]
+    assert sorted(more) == left[1:] and o.vacant() == []
+    grown = [add_new(fresh()) for _ in range(40)]
+    assert grown == list(range(n, n + 40))
+    assert gs.gs_add(g, x[0].ctypes.data, 10 ** 6) == 2 and o.add(x[0], 10 ** 6) == 1   # exceeds the specified limit...
+    assert gs.gs_mark_delete(g, 2) == 0 and o.mark_delete(2) == 0
+    assert add_new(10 ** 6) == 2                                                        # ...unless a slot is vacant (ResizeIfFull, vector_hnsw.cc:231-236)
+    a, b = graph_of(gs, g, M), oracle_graph(o)
+    assert a["levels"] == b["levels"] and a["labels"] == b["labels"] and a["deleted"] == b["deleted"]
+    assert (a["ep"], a["maxlevel"]) == (b["ep"], b["maxlevel"]) and not any(a["deleted"])
+    nn = gs.gs_count(g)
+    for (i, l), lst in a["links"].items():
+        assert len(set(lst)) == len(lst) and i not in lst and all(v < nn for v in lst)
+        assert len(lst) <= (2 * M if l == 0 else M)
+    # updatePoint iterates std::unordered_set (order unpinned in the oracle): compare as sets
+    same = sum(set(a["links"][k]) == set(b["links"][k]) for k in a["links"])
+    print("replace-deleted: %d / %d link lists equal as sets" % (same, len(a["links"])))
     assert same >= 0.97 * len(a["links"])
     gs.gs_free(g)
 

@@ -527,18 +527,32 @@ class Dispatcher {
   void run_batch(uint64_t k, uint64_t ef, std::vector<std::shared_ptr<Req>> &batch, Scratch &sc) {
     const bool hnsw = ix_->params().algo == VK_ALGO_HNSW;
     // requests whose token is already up are answered without a search
+    // (A token is read only while its request is still kInBatch and under wmu_: a blocking caller whose token went up
+    //  leaves by changing the state under that lock, and its token -- a word on its stack -- dies with the call.  Members
+    //  that left already are dropped here.  The answers go out after the lock is released; a member that leaves in
+    //  between loses nothing, finish() fails to claim it.)
     size_t live = 0;
-    for (size_t i = 0; i < batch.size(); ++i) {
-      Req &r = *batch[i];
-      if (cancel_raised(r.cancel)) {
-        finish(r, cancelled_status(r.partial_ok), nullptr, nullptr, 0);
-      } else {
-        if (live != i) batch[live] = std::move(batch[i]);
-        ++live;
+    bool any_token = false;
+    for (size_t i = 0; i < batch.size() && !any_token; ++i) any_token = batch[i]->cancel != nullptr;
+    if (any_token) {
+      std::vector<std::shared_ptr<Req>> up;
+      {
+        std::lock_guard<std::mutex> wl(wmu_);
+        for (size_t i = 0; i < batch.size(); ++i) {
+          Req &r = *batch[i];
+          if (r.state.load(std::memory_order_acquire) != kInBatch) continue;   // left while it was queued for a runner
+          if (cancel_raised(r.cancel)) {
+            up.push_back(std::move(batch[i]));
+          } else {
+            if (live != i) batch[live] = std::move(batch[i]);
+            ++live;
+          }
+        }
       }
+      for (auto &r : up) finish(*r, cancelled_status(r->partial_ok), nullptr, nullptr, 0);
+      if (!up.empty()) wake_blocked();
+      batch.resize(live);
     }
-    if (live != batch.size()) wake_blocked();
-    batch.resize(live);
     const uint64_t nq = batch.size();
     if (nq == 0) return;
     Status st = Status::Ok();
@@ -549,8 +563,6 @@ class Dispatcher {
       sc.D.resize(nq * k);
       sc.L.resize(nq * k);
       sc.N.assign(nq, 0);
-      bool any_token = false;
-      for (uint64_t i = 0; i < nq; ++i) any_token = any_token || batch[i]->cancel != nullptr;
       if (any_token) {
         w = std::make_shared<Watched>();
         w->members = batch;
@@ -662,6 +674,7 @@ class Dispatcher {
       else wcv_.wait_for(lk, std::chrono::microseconds(200));
       if (stop_flag() && watched_.empty()) return;
       size_t budget = kMemberBudget;
+      std::vector<std::shared_ptr<Req>> mine;   // claimed under the lock, answered after it is dropped
       for (auto &w : watched_) {
         if (budget == 0) break;
         if (__atomic_load_n(&w->word, __ATOMIC_RELAXED)) continue;
@@ -678,9 +691,18 @@ class Dispatcher {
           __atomic_store_n(&w->words[i], 1u, __ATOMIC_RELAXED);             // the wave working on this member stops
           w->n_up += 1;
           // ... and the member is answered now: the rest of its batch runs on without it
-          if (!gone && !r.pinned && r.cb && finish(r, cancelled_status(r.partial_ok), nullptr, nullptr, 0)) left_early_.fetch_add(1, std::memory_order_relaxed);
+          if (!gone && !r.pinned && r.cb && claim(r)) mine.push_back(w->members[i]);
         }
         if (w->n_up == n) __atomic_store_n(&w->word, 1, __ATOMIC_RELAXED);   // every member is cancelled: the kernels stop
+      }
+      // A completion callback is the caller's code (the adaptor builds a reply and posts it on; it may search again): it runs
+      // without wmu_, which every runner needs for watch / unwatch and every blocking caller to leave on its token.
+      if (!mine.empty()) {
+        lk.unlock();
+        for (auto &r : mine) deliver(*r, cancelled_status(r->partial_ok), nullptr, nullptr, 0);
+        left_early_.fetch_add(mine.size(), std::memory_order_relaxed);
+        mine.clear();
+        lk.lock();
       }
       // ... and the submitted requests that are still QUEUED behind the batches in flight: a token that goes up there is
       // answered now, not when a runner gets to its lane (blocking callers poll their own).  Outside wmu_: the queue has its

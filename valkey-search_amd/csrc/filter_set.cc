@@ -100,11 +100,18 @@ Status stage_ensure(BuildLane *l, size_t bytes) {
   l->d_cap = want;
   return Status::Ok();
 }
+struct LaneDrain {   // see FilterSet::build
+  hipStream_t s;
+  ~LaneDrain() { (void)hipStreamSynchronize(s); }
+};
 // host words -> device through the two halves of the pinned block
 Status upload(BuildLane *l, void *d_dst, const void *h_src, size_t bytes) {
   hipEvent_t ev[2] = {nullptr, nullptr};
   VK_HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-  VK_HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  if (hipError_t e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming); e != hipSuccess) {
+    (void)hipEventDestroy(ev[0]);
+    return Status::Err(4, std::string("hipEventCreate: ") + hipGetErrorString(e));
+  }
   Status st = Status::Ok();
   bool used[2] = {false, false};
   size_t off = 0;
@@ -168,6 +175,9 @@ Status FilterSet::build(const std::vector<int> &devices, uint64_t nbits, const u
     std::lock_guard<std::mutex> lk(l->mu);
     VK_HIP_TRY(hipSetDevice(dev0));
     VK_TRY(lane_ready(l));
+    // An error return below lets `f` go, and its blocks back into the pool, while copies and kernels that write them may
+    // still be queued on the lane's stream: whatever way this scope is left, the stream is drained first.
+    LaneDrain drained_on_exit{l->stream};
     uint64_t *bits = f->copies_[0].bits;
     VK_HIP_TRY(hipMemsetAsync(bits, 0, alloc, l->stream));
     if (host_bits && words) VK_TRY(upload(l, bits, host_bits, words * 8));
@@ -223,8 +233,8 @@ Status FilterSet::combine(const FilterSet &a, const FilterSet &b, uint32_t op, s
     if (b.bits_on(c.device)) devs.push_back(c.device);
   if (devs.empty() || devs.size() != a.copies_.size() || devs.size() != b.copies_.size())
     return Status::Err(1, "filter: the two filters live on different devices");
-  // the result covers the longer of the two; the shorter one reads as zeros beyond its end (its allocation is zeroed up
-  // to its own slack word only, so it is widened first when the sizes differ)
+  // both operands must cover the same label range (an allocation is zeroed up to its own slack word only, so a shorter
+  // operand cannot be read beyond its end): callers build every filter of an index with one nbits
   if (a.nbits_ != b.nbits_) return Status::Err(1, "filter: combine needs filters of one size (build both with the same nbits)");
   std::shared_ptr<FilterSet> f;
   VK_TRY(allocate(devs, a.nbits_, &f));
@@ -232,11 +242,20 @@ Status FilterSet::combine(const FilterSet &a, const FilterSet &b, uint32_t op, s
   // every copy's kernels are enqueued before any is waited for; the count comes back with the first copy
   unsigned long long cnt = 0;
   std::vector<BuildLane *> lanes;
+  // (an error return lets `f` go while earlier copies' kernels may still be running: every lane used so far is drained)
+  struct DrainAll {
+    std::vector<BuildLane *> &ls; const std::vector<Copy> &cs; bool armed = true;
+    ~DrainAll() {
+      if (!armed) return;
+      for (size_t i = 0; i < ls.size(); ++i) { (void)hipSetDevice(cs[i].device); (void)hipStreamSynchronize(ls[i]->stream); }
+    }
+  } drain_on_error{lanes, f->copies_};
   for (const Copy &c : f->copies_) {
     BuildLane *l = lane_of(c.device);
     std::lock_guard<std::mutex> lk(l->mu);
     VK_HIP_TRY(hipSetDevice(c.device));
     VK_TRY(lane_ready(l));
+    lanes.push_back(l);
     const uint32_t nb = filter_combine_blocks(words);
     if (nb > kPartials) return Status::Err(4, "filter: combine grid larger than its partial sums");
     VK_HIP_TRY(launch_filter_combine(c.bits, a.bits_on(c.device), b.bits_on(c.device), words, op, l->d_partial, l->stream));
@@ -247,12 +266,12 @@ Status FilterSet::combine(const FilterSet &a, const FilterSet &b, uint32_t op, s
       const unsigned long long *part = reinterpret_cast<const unsigned long long *>(l->pin);
       for (uint32_t i = 0; i < nb; ++i) cnt += part[i];
     }
-    lanes.push_back(l);
   }
   for (size_t i = 1; i < lanes.size(); ++i) {
     VK_HIP_TRY(hipSetDevice(f->copies_[i].device));
     VK_HIP_TRY(hipStreamSynchronize(lanes[i]->stream));
   }
+  drain_on_error.armed = false;
   f->allowed_ = cnt;
   *out = std::move(f);
   return Status::Ok();

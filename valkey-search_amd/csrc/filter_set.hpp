@@ -36,7 +36,7 @@ class FilterSet {
   // nbits bits to start from (nullptr = empty).  Labels >= nbits are ignored.  Blocks until every copy is complete.
   static Status build(const std::vector<int> &devices, uint64_t nbits, const uint64_t *ids, uint64_t n_ids, const uint64_t *runs,
                       uint64_t n_runs, const uint64_t *host_bits, std::shared_ptr<FilterSet> *out);
-  // dst = a OP b (0 and, 1 or, 2 and-not) on every device both live on; nbits = max of the two (missing words read as 0)
+  // dst = a OP b (0 and, 1 or, 2 and-not) on every device both live on; the two must have the same nbits (else an error)
   static Status combine(const FilterSet &a, const FilterSet &b, uint32_t op, std::shared_ptr<FilterSet> *out);
 
  private:

@@ -75,34 +75,38 @@ class HnswIndex final : public Index {
   Status add(uint64_t label, const float *row) override {
     // Staging does not take the index lock: it touches the staging area alone (its own mutex), so the writers keep staging
     // while a bulk of earlier rows is being linked on the device under the exclusive lock.
-    if (stage_candidate()) {
-      bool full = false, staged = false;
-      {
-        std::lock_guard<std::mutex> pl(pend_.mu);
-        auto it = pend_.pos.find(label);
-        uint32_t id;
-        if (it != pend_.pos.end()) {   // the same label again before it was linked: the later row wins (an in-place update)
-          memcpy(pend_.rows.data() + it->second * params_.dim, row, (size_t)params_.dim * 4);
-          return Status::Ok();
-        }
-        if (!graph_->lookup(label, &id)) {   // (an update of a linked element goes to the host builder below)
-          if (graph_->count() + pend_.live + draining_.load(std::memory_order_relaxed) >= graph_->max_elements())
-            return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
-          if (pend_.rows.capacity() == 0) pend_.rows.reserve((size_t)std::min<uint64_t>(opt_.get(kOptHnswStageMax), 1u << 20) * params_.dim);
-          pend_.pos.emplace(label, pend_.labels.size());
-          pend_.labels.push_back(label);
-          pend_.rows.insert(pend_.rows.end(), row, row + params_.dim);
-          pend_.live += 1;
-          graph_->note_label(label);
-          staged_adds_.fetch_add(1, std::memory_order_relaxed);
-          full = pend_.labels.size() >= opt_.get(kOptHnswStageMax);
-          staged = true;
-        }
+    // A label that is staged, or in the bulk being linked right now, is looked for there whatever stage_candidate() says
+    // by now (a remove of a linked element switches staging off under hnsw-allow-replace-deleted while rows still wait).
+    const bool can_stage = stage_candidate();
+    bool full = false, staged = false, in_bulk = false;
+    {
+      std::lock_guard<std::mutex> pl(pend_.mu);
+      auto it = pend_.pos.find(label);
+      uint32_t id;
+      if (it != pend_.pos.end()) {   // the same label again before it was linked: the later row wins (an in-place update)
+        memcpy(pend_.rows.data() + it->second * params_.dim, row, (size_t)params_.dim * 4);
+        return Status::Ok();
       }
-      // (the staging area is bounded: a writer that finds it full links what is there -- or waits for the writer that is
-      //  doing so -- before it returns, like a caller of one long add_batch)
-      if (staged) return full ? drain_pending() : Status::Ok();
+      if (pend_.linking.count(label)) {
+        in_bulk = true;   // its first row is being linked right now: this one is an update behind that bulk
+      } else if (can_stage && !graph_->lookup(label, &id)) {   // (an update of a linked element goes to the host builder below)
+        if (graph_->count() + pend_.live + draining_.load(std::memory_order_relaxed) >= graph_->max_elements())
+          return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+        if (pend_.rows.capacity() == 0) pend_.rows.reserve((size_t)std::min<uint64_t>(opt_.get(kOptHnswStageMax), 1u << 20) * params_.dim);
+        pend_.pos.emplace(label, pend_.labels.size());
+        pend_.labels.push_back(label);
+        pend_.rows.insert(pend_.rows.end(), row, row + params_.dim);
+        pend_.live += 1;
+        graph_->note_label(label);
+        staged_adds_.fetch_add(1, std::memory_order_relaxed);
+        full = pend_.labels.size() >= opt_.get(kOptHnswStageMax);
+        staged = true;
+      }
     }
+    // (the staging area is bounded: a writer that finds it full links what is there -- or waits for the writer that is
+    //  doing so -- before it returns, like a caller of one long add_batch)
+    if (staged) return full ? drain_pending() : Status::Ok();
+    if (in_bulk) wait_for_bulk();
     std::shared_lock<std::shared_mutex> lk(rw_);
     return add_one(label, row);
   }
@@ -125,9 +129,10 @@ class HnswIndex final : public Index {
 
   // link what the single adds staged (see add()); called without the index lock
   Status drain_pending() {
-    {   // (cheap exit: nothing staged)
+    {   // (cheap exit: nothing staged and nobody linking -- a flush, a save or a search that arrives while ANOTHER thread
+        //  links what it swapped out waits for it below: every add that was acknowledged is in the graph when this returns)
       std::lock_guard<std::mutex> pl(pend_.mu);
-      if (pend_.labels.empty()) return Status::Ok();
+      if (pend_.labels.empty() && draining_.load(std::memory_order_relaxed) == 0) return Status::Ok();
     }
     std::lock_guard<std::mutex> one_at_a_time(drain_mu_);
     std::vector<float> &rows = spare_rows_;       // (the buffers keep their capacity from bulk to bulk: 800 MB at the default
@@ -151,11 +156,18 @@ class HnswIndex final : public Index {
         pend_.rows.clear();
         pend_.labels.clear();
       }
-      pend_.pos.clear();
+      // The labels of the bulk stay findable until they are in the graph: between this swap and the moment the builder has
+      // registered them a remove / contains / get_row / add of one of them would otherwise find it nowhere (a delete lost, a
+      // ghost vector linked behind it).  The map itself moves over -- no per-label work.
+      pend_.linking.clear();
+      pend_.linking.swap(pend_.pos);
       pend_.live = 0;
       draining_.store(labels.size(), std::memory_order_relaxed);
     }
-    struct Done { std::atomic<uint64_t> &d; ~Done() { d.store(0, std::memory_order_relaxed); } } done{draining_};
+    struct Done {
+      Pending &p; std::atomic<uint64_t> &d;
+      ~Done() { std::lock_guard<std::mutex> pl(p.mu); p.linking.clear(); d.store(0, std::memory_order_relaxed); }
+    } done{pend_, draining_};
     if (labels.empty()) return Status::Ok();
     bool on_device = false;
     Status st = add_batch_now(labels.data(), rows.data(), labels.size(), &on_device);
@@ -200,7 +212,7 @@ class HnswIndex final : public Index {
   }
 
   Status remove(uint64_t label) override {
-    std::shared_lock<std::shared_mutex> lk(rw_);
+    bool in_bulk = false;
     {
       std::lock_guard<std::mutex> pl(pend_.mu);
       auto it = pend_.pos.find(label);
@@ -209,9 +221,16 @@ class HnswIndex final : public Index {
         pend_.live -= 1;
         return Status::Ok();
       }
+      in_bulk = pend_.linking.count(label) != 0;
     }
+    if (in_bulk) wait_for_bulk();   // (being linked right now: the tombstone goes on the linked element)
+    std::shared_lock<std::shared_mutex> lk(rw_);
     return graph_->mark_delete(label);
   }
+
+  // The bulk that drain_pending() swapped out is in the graph when this returns.  Called WITHOUT the index lock (the device
+  // build takes it exclusively).
+  void wait_for_bulk() { std::lock_guard<std::mutex> behind_the_bulk(drain_mu_); }
 
   Status resize(uint64_t new_max) override {
     std::unique_lock<std::shared_mutex> lk(rw_);
@@ -389,7 +408,7 @@ class HnswIndex final : public Index {
   }
 
   Status get_row(uint64_t label, float *out) override {
-    std::shared_lock<std::shared_mutex> lk(rw_);
+    bool in_bulk = false;
     {
       std::lock_guard<std::mutex> pl(pend_.mu);
       auto it = pend_.pos.find(label);
@@ -397,7 +416,10 @@ class HnswIndex final : public Index {
         memcpy(out, pend_.rows.data() + it->second * params_.dim, (size_t)params_.dim * 4);
         return Status::Ok();
       }
+      in_bulk = pend_.linking.count(label) != 0;
     }
+    if (in_bulk) wait_for_bulk();
+    std::shared_lock<std::shared_mutex> lk(rw_);
     uint32_t id;
     if (!graph_->lookup(label, &id)) return Status::Err(VK_ERR_NOT_FOUND, "label not found");
     memcpy(out, graph_->row(id), (size_t)params_.dim * 4);
@@ -409,7 +431,7 @@ class HnswIndex final : public Index {
     uint32_t id;
     {
       std::lock_guard<std::mutex> pl(pend_.mu);
-      if (pend_.pos.count(label)) { *found = true; return Status::Ok(); }
+      if (pend_.pos.count(label) || pend_.linking.count(label)) { *found = true; return Status::Ok(); }
     }
     *found = graph_->lookup(label, &id) && !graph_->is_deleted(id);
     return Status::Ok();
@@ -1146,6 +1168,7 @@ class HnswIndex final : public Index {
     std::vector<float> rows;                       // [labels.size()][dim]
     std::vector<uint64_t> labels;
     std::unordered_map<uint64_t, size_t> pos;      // live staged labels -> their place
+    std::unordered_map<uint64_t, size_t> linking;  // the labels of the bulk drain_pending() is linking right now
     size_t live = 0;
   } pend_;
   std::atomic<uint64_t> draining_{0}, staged_adds_{0}, staged_adds_device_{0}, last_visited_mode_{0};
