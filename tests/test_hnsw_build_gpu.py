@@ -39,24 +39,43 @@ def build(vsa, x, device, metric="IP", M=16, efc=100, cap=None):
 
 
 def recall(g, flat, Q, k=10, ef=64):
-    D, L, N = g.search_batch(Q, k, ef=ef)
-    Dt, Lt, Nt = flat.search_batch(Q, k)
-    return float(np.mean([len(set(L[i, :N[i]].tolist()) & set(Lt[i].tolist())) / k for i in range(len(Q))]))
+    hit = 0
+    for lo in range(0, len(Q), 512):
+        D, L, N = g.search_batch(Q[lo:lo + 512], k, ef=ef)
+        Dt, Lt, Nt = flat.search_batch(Q[lo:lo + 512], k)
+        hit += sum(len(set(L[i, :N[i]].tolist()) & set(Lt[i].tolist())) for i in range(L.shape[0]))
+    return hit / float(k * len(Q))
+
+
+def zero_degree_nodes(chunks, n):
+    """level-0 out-degree per element, from the SaveIndex stream (first word of an element chunk, hnswalg.h:1259-1270)"""
+    return np.array([int(np.frombuffer(c[:4], np.uint32)[0] & 0xFFFF) for c in chunks[1:1 + n]])
 
 
 @pytest.mark.parametrize("metric", ["IP", "L2"])
 def test_device_build_recall_and_invariants(vsa, oracle, metric):
-    n, dim = 30000, 64
-    x = latent(n, dim, 1)
-    Q = latent(400, dim, 2)
-    flat = vsa.Index("FLAT", dim, metric, initial_cap=n)
-    flat.add_batch(x)
-    gd = build(vsa, x, True, metric)
-    gh = build(vsa, x, False, metric)
-    assert gd.stats().count == n and gd.stats().max_level >= 2
-    rd, rh = recall(gd, flat, Q), recall(gh, flat, Q)
-    assert rd >= rh - 0.02, (rd, rh)           # no worse than the host (hnswlib-order) build
-    assert rd >= 0.9, rd
+    """north_star: recall >= reference at identical ef.  The reference-order graph is the host builder's (link for link the
+    oracle's, tests/test_host_graph.py); K9's is compared with it over 3 data seeds x 2048 queries: the MEAN recall must not
+    be lower by more than half a percent (the spread of two hnswlib builds of the same rows with different thread
+    interleavings), and no node may be left without out-links."""
+    n, dim, nq = 30000, 64, 2048
+    rd, rh = [], []
+    for seed in range(3):
+        x = latent(n, dim, 10 + seed)
+        Q = latent(nq, dim, 20 + seed)
+        flat = vsa.Index("FLAT", dim, metric, initial_cap=n)
+        flat.add_batch(x)
+        gd = build(vsa, x, True, metric)
+        gh = build(vsa, x, False, metric)
+        assert gd.stats().count == n and gd.stats().max_level >= 2
+        rd.append(recall(gd, flat, Q))
+        rh.append(recall(gh, flat, Q))
+        for g in (gd, gh):
+            deg = zero_degree_nodes(g.save(), n)
+            assert deg.max() <= 32 and (deg == 0).sum() == 0 and deg.mean() > 8
+    print("K9 %s  host %s  (30000 x 64, %s, ef 64)" % (np.round(rd, 4), np.round(rh, 4), metric))
+    assert np.mean(rd) >= np.mean(rh) - 0.005, (rd, rh)
+    assert np.mean(rd) >= 0.9, rd
     # every structural rule LoadIndex checks (counts, id ranges, levels, entry point) holds, and the
     # host mirror the chunks are written from equals the device graph: the CPU oracle walking the saved
     # graph must give the device's answers
@@ -68,10 +87,35 @@ def test_device_build_recall_and_invariants(vsa, oracle, metric):
         d0, l0 = gd.search(q, 10, ef=64)
         d1, l1 = o.search(q, 10, ef=64)
         assert l0.tolist() == l1.tolist() and d0.view(np.uint32).tolist() == d1.view(np.uint32).tolist()
-    # level-0 degree: nobody above 2M, almost nobody isolated
-    M0 = 32
-    deg = np.array([int(np.frombuffer(c[:4], np.uint32)[0] & 0xFFFF) for c in chunks[1:1 + n]])
-    assert deg.max() <= M0 and (deg == 0).sum() == 0 and deg.mean() > 8
+
+
+def test_k9_recall_at_200k_x_768_over_three_seeds(vsa):
+    """The same bar at the benchmark's dimension and BASELINE.json's data model (rank-32 latent, M = 16, efC = 200): 200 000
+    rows, 3 data seeds x 2048 queries, ef 64 and 128.  (1M and 10M rows: scripts/k9_recall_vs_host.py, profiles/r06_k9_vs_host_*.)"""
+    n, dim, nq = 200_000, 768, 2048
+    rd, rh = {64: [], 128: []}, {64: [], 128: []}
+    for seed in range(3):
+        A = np.random.default_rng(1234 + seed).standard_normal((dim, 32)).astype(np.float32)
+
+        def gen(m, sd):
+            r = np.random.default_rng(sd)
+            x = r.standard_normal((m, 32)).astype(np.float32) @ A.T + 0.05 * r.standard_normal((m, dim)).astype(np.float32)
+            return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+        x, Q = gen(n, 100 + seed), gen(nq, 900 + seed)
+        flat = vsa.Index("FLAT", dim, "IP", initial_cap=n)
+        flat.add_batch(x)
+        for device, out in ((True, rd), (False, rh)):
+            g = build(vsa, x, device, "IP", M=16, efc=200)
+            for ef in (64, 128):
+                out[ef].append(recall(g, flat, Q, ef=ef))
+            st = g.stats()
+            deg = zero_degree_nodes(g.save(), n) if seed == 0 else None
+            assert st.count == n and (deg is None or ((deg == 0).sum() == 0 and deg.max() <= 32))
+            del g
+    for ef in (64, 128):
+        print("200k x 768 ef %d: K9 %s  host %s" % (ef, np.round(rd[ef], 4), np.round(rh[ef], 4)))
+        assert np.mean(rd[ef]) >= np.mean(rh[ef]) - 0.005, (ef, rd[ef], rh[ef])
 
 
 def test_self_retrieval_and_mutations_after_device_build(vsa):

@@ -186,12 +186,16 @@ def test_bulk_adds_fill_vacancies_first(vsa, oracle):
     dead = rng.choice(n, 300, replace=False)
     for lab in dead:
         assert g.remove(int(lab)) == 0
+    # (a multi-threaded build hands out slots in arrival order: where the dead labels sit is read off the graph)
+    before = np.array(oracle.HNSW.from_product_index(g.save_raw, dim, "L2", M, ef_construction=60).export_graph()["labels"])
+    dead_slots = np.flatnonzero(np.isin(before, dead))
+    assert len(dead_slots) == 300
     g.add_batch(x[n:], np.arange(n, n + 5000, dtype=np.uint64))
     st = g.stats()
     assert st.deleted == 0 and st.count == n + 5000 - 300
     saved = oracle.HNSW.from_product_index(g.save_raw, dim, "L2", M, ef_construction=60)
     labels = np.array(saved.export_graph()["labels"])
-    assert np.all(labels[np.sort(dead)] >= n) and len(set(labels.tolist())) == st.count
+    assert np.all(labels[dead_slots] >= n) and len(set(labels.tolist())) == st.count == len(labels)
     f = vsa.Index("FLAT", dim, "L2", initial_cap=n + 5000)
     keep = np.setdiff1d(np.arange(n + 5000), dead)
     f.add_batch(x[keep], keep.astype(np.uint64))

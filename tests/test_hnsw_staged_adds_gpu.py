@@ -5,7 +5,7 @@ reference side calls.  Now single adds of new labels are staged and linked in bu
 phase switch) -- on the device when >= 4096 wait.  Pinned:
   * 1M x 768 single adds from 16 native writer threads + flush take at most 1.5x the time of one add_batch of the same rows,
     every staged row went through the device build, recall = add_batch's (same builder, same relaxation);
-  * at 200k x 768 (where the host builder is affordable inside the suite): recall >= the host (hnswlib-order) build - 0.02,
+  * at 200k x 768 (where the host builder is affordable inside the suite): recall within half a percent of the host (hnswlib-order) build over 2048 queries,
     and the CPU oracle, loaded from the graph the product SAVED, reproduces the product's answers id for id and bit for bit;
   * addPoint semantics while staged: the same label again = the later row; remove of a staged label; capacity error and the
     resize-and-retry loop (vector_hnsw.cc:238-271); contains / get_row / count see staged rows; a search flushes."""
@@ -31,19 +31,26 @@ def latent(n, dim, seed, rank=32):
 
 
 def recall(g, gt, Q, k=10, ef=128):
-    D, L, N = g.search_batch(Q, k, ef=ef)
-    return float(np.mean([len(set(L[i, :N[i]].tolist()) & set(gt[i].tolist())) / k for i in range(len(Q))]))
+    hit = 0
+    for lo in range(0, len(Q), 512):
+        D, L, N = g.search_batch(Q[lo:lo + 512], k, ef=ef)
+        hit += sum(len(set(L[i, :N[i]].tolist()) & set(gt[lo + i].tolist())) for i in range(L.shape[0]))
+    return hit / float(k * len(Q))
+
+
+def exact(flat, Q, k):
+    return np.concatenate([flat.search_batch(Q[lo:lo + 256], k)[1] for lo in range(0, len(Q), 256)])
 
 
 def test_single_adds_reach_the_device_build(vsa, oracle):
     dim, k = 768, 10
-    Q = latent(256, dim, 99)
+    Q = latent(2048, dim, 99)
     # ---- 1M rows: single adds from 16 threads + flush against one add_batch
     n = 1_000_000
     x = latent(n, dim, 3)
     flat = vsa.Index("FLAT", dim, "IP", initial_cap=n)
     flat.add_batch(x)
-    gt = flat.search_batch(Q, k)[1]
+    gt = exact(flat, Q, k)
     del flat
     gb = vsa.Index("HNSW", dim, "IP", initial_cap=n, m=16, ef_construction=200, ef_runtime=128)
     t0 = time.perf_counter()
@@ -66,14 +73,14 @@ def test_single_adds_reach_the_device_build(vsa, oracle):
     r_single = recall(gs, gt, Q)
     print(f"1M x 768: add_batch {t_batch:.1f} s (recall {r_batch:.4f}); 16 threads x single adds {t_adds:.1f} s + flush = {t_single:.1f} s (recall {r_single:.4f})")
     assert t_single <= 1.5 * t_batch, (t_single, t_batch)
-    assert r_single >= r_batch - 0.02, (r_single, r_batch)
+    assert r_single >= r_batch - 0.005, (r_single, r_batch)      # (the same builder: 2048 queries apart)
     del gs, x
     # ---- 200k rows: against the host build, and the oracle on the saved graph
     n = 200_000
     x = latent(n, dim, 4)
     flat = vsa.Index("FLAT", dim, "IP", initial_cap=n)
     flat.add_batch(x)
-    gt = flat.search_batch(Q, k)[1]
+    gt = exact(flat, Q, k)
     del flat
     gh = vsa.Index("HNSW", dim, "IP", initial_cap=n, m=16, ef_construction=200, ef_runtime=128, options={"hnsw-device-build": 0})
     gh.add_batch(x)
@@ -85,7 +92,7 @@ def test_single_adds_reach_the_device_build(vsa, oracle):
     r_single = recall(gs, gt, Q)          # (the search links what is staged: no explicit flush)
     assert gs.stats().staged_adds_device > 0
     print(f"200k x 768: host build recall {r_host:.4f}, single adds -> device build {r_single:.4f}")
-    assert r_single >= r_host - 0.02, (r_single, r_host)
+    assert r_single >= r_host - 0.005, (r_single, r_host)        # north_star: recall >= reference at identical ef (2048 queries)
     o = oracle.HNSW.from_product_index(gs.save_raw, dim, "IP", 16, ef_construction=200)
     D, L, N = gs.search_batch(Q[:64], k, ef=128)
     for i in range(64):

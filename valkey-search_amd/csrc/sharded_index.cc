@@ -37,6 +37,12 @@ typedef enum { ncclUint64 = 5, ncclFloat32 = 7 } ncclDataType_t;
 #endif
 
 #include "index.hpp"
+#include "shard_layout.hpp"
+
+// Test seam (link time, not run time): a program that defines this symbol names the library the gather loads instead of the
+// system's librccl -- the multi-device pre-flight (tests/helpers/san_sharded_main.cc) carries an in-process model of the five
+// entry points.  libvkindex.so does not define it.
+extern "C" const char *vk_test_rccl_library() __attribute__((weak));
 
 namespace vk {
 
@@ -171,13 +177,18 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
-  std::vector<ncclComm_t> comms;   // one per DISTINCT device of the index, rank = position in dev_groups_
+  std::vector<ncclComm_t> comms;   // one per DISTINCT device of the index, rank = the device's group index (ShardLayout)
 
   Status load() {
     if (lib) return Status::Ok();
-    for (const char *name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (lib) break;
+    if (vk_test_rccl_library) {
+      const char *name = vk_test_rccl_library();
+      lib = name ? dlopen(name, RTLD_NOW | RTLD_LOCAL) : dlopen(nullptr, RTLD_NOW);   // nullptr: the program itself
+    } else {
+      for (const char *name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+      }
     }
     if (!lib) return Status::Err(VK_ERR_INTERNAL, std::string("shard-gather = 1 needs RCCL: ") + dlerror());
     auto sym = [&](const char *n) { return dlsym(lib, n); };
@@ -235,20 +246,8 @@ class ShardedIndex final : public Index {
     // thread, 230-620 us from eight threads); across devices the enqueueing does run side by side.  The caller's thread
     // takes the serving device's shards.
     const bool threads_on = opt_.get(kOptShardThreads) != 0;
-    for (size_t s = 0; s < S; ++s) {
-      size_t gi = 0;
-      for (; gi < dev_groups_.size(); ++gi)
-        if (devices_[dev_groups_[gi][0]] == devices_[s]) break;
-      if (gi == dev_groups_.size()) dev_groups_.emplace_back();
-      dev_groups_[gi].push_back(s);
-    }
-    if (dev_groups_.size() > 1 && threads_on) workers_ = std::make_unique<ShardWorkers>(dev_groups_.size() - 1);
-    shard_group_.assign(S, 0);
-    shard_pos_.assign(S, 0);
-    for (size_t gi = 0; gi < dev_groups_.size(); ++gi) {
-      group_max_ = std::max(group_max_, dev_groups_[gi].size());
-      for (size_t i = 0; i < dev_groups_[gi].size(); ++i) { shard_group_[dev_groups_[gi][i]] = (uint32_t)gi; shard_pos_[dev_groups_[gi][i]] = (uint32_t)i; }
-    }
+    lay_ = ShardLayout::from_devices(devices_);   // (shard_layout.hpp: groups by device, the serving device's first)
+    if (lay_.G() > 1 && threads_on) workers_ = std::make_unique<ShardWorkers>(lay_.G() - 1);
     // Peer access between the devices involved.  The fan-out's broadcast and gather are peer copies over xGMI; without peer
     // access the runtime would stage every one of them through host memory -- an index that LOOKS multi-GPU and runs at PCIe
     // latency.  That is refused here, loudly, rather than discovered in production (the option shard-allow-staged lifts it
@@ -724,9 +723,9 @@ class ShardedIndex final : public Index {
             (void)hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
             (void)hipEventCreateWithFlags(&l.done, hipEventDisableTiming);
           }
-          n->group.resize(dev_groups_.size());
-          for (size_t gi = 0; gi < dev_groups_.size(); ++gi) {
-            n->group[gi].device = devices_[dev_groups_[gi][0]];
+          n->group.resize(lay_.G());
+          for (size_t gi = 0; gi < lay_.G(); ++gi) {
+            n->group[gi].device = lay_.group_device[gi];
             (void)hipSetDevice(n->group[gi].device);
             (void)hipEventCreateWithFlags(&n->group[gi].gathered, hipEventDisableTiming);
           }
@@ -783,8 +782,8 @@ class ShardedIndex final : public Index {
       ef = (ef * ef_pct + 99) / 100;
       srq.ef = std::max<uint64_t>(std::max<uint64_t>(ef, rq.k), 1);
     }
-    float *od = mc->d_all_d.as<float>() + s * nk;
-    uint64_t *ol = mc->d_all_l.as<uint64_t>() + s * nk;
+    float *od = mc->d_all_d.as<float>() + lay_.peer_slice(s, nk);
+    uint64_t *ol = mc->d_all_l.as<uint64_t>() + lay_.peer_slice(s, nk);
     uint32_t *on = mc->d_all_n.as<uint32_t>() + s * rq.nq;
     const bool local = l.device == mc->dev0;
     if (!local) {   // broadcast by peer copy, answer into the shard's own buffers
@@ -804,15 +803,15 @@ class ShardedIndex final : public Index {
       on = l.d_out_n.as<uint32_t>();
     }
     if (rccl) {   // the lists go to this shard's slot of its DEVICE's send buffer; the all-gather moves them (fan_out)
-      GatherGroup &g = mc->group[shard_group_[s]];
-      od = g.send_d.as<float>() + shard_pos_[s] * nk;
-      ol = g.send_l.as<uint64_t>() + shard_pos_[s] * nk;
+      GatherGroup &g = mc->group[lay_.group_of[s]];
+      od = g.send_d.as<float>() + lay_.send_slot(s, nk);
+      ol = g.send_l.as<uint64_t>() + lay_.send_slot(s, nk);
     }
     VK_TRY(shards_[s]->search_device(srq, od, ol, on, l.stream));
     VK_HIP_TRY(hipSetDevice(l.device));
     if (!local && !rccl) {   // the shard's lists -> their slice of the gathered array on the serving device
-      VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_d.as<float>() + s * nk, mc->dev0, od, l.device, nk * 4, l.stream));
-      VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_l.as<uint64_t>() + s * nk, mc->dev0, ol, l.device, nk * 8, l.stream));
+      VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_d.as<float>() + lay_.peer_slice(s, nk), mc->dev0, od, l.device, nk * 4, l.stream));
+      VK_HIP_TRY(hipMemcpyPeerAsync(mc->d_all_l.as<uint64_t>() + lay_.peer_slice(s, nk), mc->dev0, ol, l.device, nk * 8, l.stream));
     }
     VK_HIP_TRY(hipEventRecord(l.done, l.stream));
     return Status::Ok();
@@ -833,28 +832,26 @@ class ShardedIndex final : public Index {
   // shard-gather = 1, before the shards are enqueued: the communicators (first use), every device's send / receive buffers,
   // and (+inf, no label) in the send slots no shard of that device writes
   Status rccl_prepare(MultiCtx *mc, const SearchRequest &rq, size_t nk, hipStream_t s0) {
-    const size_t G = dev_groups_.size(), P = group_max_;
+    const size_t G = lay_.G();
     {
       std::lock_guard<std::mutex> lk(rccl_mu_);
       VK_TRY(rccl_.load());
       if (rccl_.comms.empty()) {
-        std::vector<int> devs(G);
-        for (size_t gi = 0; gi < G; ++gi) devs[gi] = devices_[dev_groups_[gi][0]];
-        std::vector<ncclComm_t> comms(G, nullptr);
-        VK_TRY(rccl_.check(rccl_.CommInitAll(comms.data(), (int)G, devs.data()), "ncclCommInitAll"));
+        std::vector<ncclComm_t> comms(G, nullptr);   // rank = group index: the receive buffer is laid out in that order
+        VK_TRY(rccl_.check(rccl_.CommInitAll(comms.data(), (int)G, lay_.group_device.data()), "ncclCommInitAll"));
         rccl_.comms = std::move(comms);
       }
     }
     for (size_t gi = 0; gi < G; ++gi) {
       GatherGroup &g = mc->group[gi];
       VK_HIP_TRY(hipSetDevice(g.device));
-      VK_TRY(g.send_d.ensure(P * nk * 4));
-      VK_TRY(g.send_l.ensure(P * nk * 8));
-      VK_TRY(g.recv_d.ensure(G * P * nk * 4));
-      VK_TRY(g.recv_l.ensure(G * P * nk * 8));
-      if (dev_groups_[gi].size() < P && g.filled_nk != nk) {   // the pad slots, once per batch shape (on the stream that gathers)
-        hipStream_t cs = mc->lane[dev_groups_[gi].back()].stream;
-        for (size_t p = dev_groups_[gi].size(); p < P; ++p)
+      VK_TRY(g.send_d.ensure(lay_.send_entries(nk) * 4));
+      VK_TRY(g.send_l.ensure(lay_.send_entries(nk) * 8));
+      VK_TRY(g.recv_d.ensure(lay_.recv_entries(nk) * 4));
+      VK_TRY(g.recv_l.ensure(lay_.recv_entries(nk) * 8));
+      if (lay_.pad_begin(gi) < lay_.P && g.filled_nk != nk) {   // the pad slots, once per batch shape (on the stream that gathers)
+        hipStream_t cs = mc->lane[lay_.collective_lane(gi)].stream;
+        for (size_t p = lay_.pad_begin(gi); p < lay_.P; ++p)
           VK_HIP_TRY(launch_fill_empty(g.send_d.as<float>() + p * nk, g.send_l.as<uint64_t>() + p * nk, nullptr, (uint32_t)rq.nq, (uint32_t)rq.k, cs));
         g.filled_nk = nk;
       }
@@ -865,11 +862,11 @@ class ShardedIndex final : public Index {
   // ... and after them: on every device the stream of its last shard waits for the device's other shards, then ONE group
   // call issues the all-gathers of all devices (distances, labels) from this thread
   Status rccl_all_gather(MultiCtx *mc, size_t nk) {
-    const size_t G = dev_groups_.size(), P = group_max_;
+    const size_t G = lay_.G();
     for (size_t gi = 0; gi < G; ++gi) {
       VK_HIP_TRY(hipSetDevice(mc->group[gi].device));
-      hipStream_t cs = mc->lane[dev_groups_[gi].back()].stream;
-      for (size_t i = 0; i + 1 < dev_groups_[gi].size(); ++i) VK_HIP_TRY(hipStreamWaitEvent(cs, mc->lane[dev_groups_[gi][i]].done, 0));
+      hipStream_t cs = mc->lane[lay_.collective_lane(gi)].stream;
+      for (size_t i = 0; i + 1 < lay_.groups[gi].size(); ++i) VK_HIP_TRY(hipStreamWaitEvent(cs, mc->lane[lay_.groups[gi][i]].done, 0));
     }
     {
       std::lock_guard<std::mutex> lk(rccl_mu_);
@@ -877,9 +874,9 @@ class ShardedIndex final : public Index {
       Status st = Status::Ok();
       for (size_t gi = 0; gi < G && st.ok(); ++gi) {
         GatherGroup &g = mc->group[gi];
-        hipStream_t cs = mc->lane[dev_groups_[gi].back()].stream;
-        st = rccl_.check(rccl_.AllGather(g.send_d.p, g.recv_d.p, P * nk, ncclFloat32, rccl_.comms[gi], cs), "ncclAllGather(distances)");
-        if (st.ok()) st = rccl_.check(rccl_.AllGather(g.send_l.p, g.recv_l.p, P * nk, ncclUint64, rccl_.comms[gi], cs), "ncclAllGather(labels)");
+        hipStream_t cs = mc->lane[lay_.collective_lane(gi)].stream;
+        st = rccl_.check(rccl_.AllGather(g.send_d.p, g.recv_d.p, lay_.send_entries(nk), ncclFloat32, rccl_.comms[gi], cs), "ncclAllGather(distances)");
+        if (st.ok()) st = rccl_.check(rccl_.AllGather(g.send_l.p, g.recv_l.p, lay_.send_entries(nk), ncclUint64, rccl_.comms[gi], cs), "ncclAllGather(labels)");
       }
       Status en = rccl_.check(rccl_.GroupEnd(), "ncclGroupEnd");
       VK_TRY(st);
@@ -887,10 +884,10 @@ class ShardedIndex final : public Index {
     }
     for (size_t gi = 0; gi < G; ++gi) {
       VK_HIP_TRY(hipSetDevice(mc->group[gi].device));
-      hipStream_t cs = mc->lane[dev_groups_[gi].back()].stream;
+      hipStream_t cs = mc->lane[lay_.collective_lane(gi)].stream;
       VK_HIP_TRY(hipEventRecord(mc->group[gi].gathered, cs));
       // (the lane's `done` event is what quiesce / the next user of the context wait for: move it behind the collective)
-      VK_HIP_TRY(hipEventRecord(mc->lane[dev_groups_[gi].back()].done, cs));
+      VK_HIP_TRY(hipEventRecord(mc->lane[lay_.collective_lane(gi)].done, cs));
     }
     rccl_gathers_.fetch_add(1, std::memory_order_relaxed);
     return Status::Ok();
@@ -908,7 +905,6 @@ class ShardedIndex final : public Index {
     VK_TRY(mc->d_all_l.ensure(S * nk * 8));
     VK_TRY(mc->d_all_n.ensure(S * rq.nq * 4));
     const bool rccl = opt_.get(kOptShardGather) != 0;
-    const size_t G = dev_groups_.size(), P = group_max_;
     if (rccl) {
       Status st = rccl_prepare(mc, rq, nk, s0);
       if (!st.ok()) { quiesce(mc, s0); return st; }
@@ -918,9 +914,9 @@ class ShardedIndex final : public Index {
     std::vector<Status> res(S);
     if (workers_) {
       ShardWorkers::Latch latch;
-      latch.left = (uint32_t)(dev_groups_.size() - 1);
+      latch.left = (uint32_t)(lay_.G() - 1);
       auto run_group = [this, mc, &rq, &res, rccl](size_t gi) {
-        for (size_t s : dev_groups_[gi]) {
+        for (size_t s : lay_.groups[gi]) {
           try {
             res[s] = enqueue_shard(mc, s, rq, rccl);
           } catch (const std::exception &e) {
@@ -929,7 +925,7 @@ class ShardedIndex final : public Index {
           if (!res[s].ok()) break;
         }
       };
-      for (size_t gi = 1; gi < dev_groups_.size(); ++gi)
+      for (size_t gi = 1; gi < lay_.G(); ++gi)
         workers_->post(gi - 1, [gi, &run_group, &latch] {
           run_group(gi);
           latch.done();
@@ -956,12 +952,12 @@ class ShardedIndex final : public Index {
         VK_HIP_TRY(hipStreamWaitEvent(s0, mc->group[0].gathered, 0));
         m.in_dist = mc->group[0].recv_d.as<float>();
         m.in_label = mc->group[0].recv_l.as<uint64_t>();
-        m.parts = (uint32_t)(G * P);
+        m.parts = (uint32_t)lay_.rccl_parts();
       } else {
         for (size_t s = 0; s < S; ++s) VK_HIP_TRY(hipStreamWaitEvent(s0, mc->lane[s].done, 0));
         m.in_dist = mc->d_all_d.as<float>();
         m.in_label = mc->d_all_l.as<uint64_t>();
-        m.parts = (uint32_t)S;
+        m.parts = (uint32_t)lay_.peer_parts();
       }
       m.part_stride = nk;
       m.q_stride = rq.k;
@@ -1008,9 +1004,7 @@ class ShardedIndex final : public Index {
 
   std::vector<int> devices_;
   std::unique_ptr<ShardWorkers> workers_;
-  std::vector<std::vector<size_t>> dev_groups_;           // shards by device, the serving device's group first
-  std::vector<uint32_t> shard_group_, shard_pos_;         // shard -> its device group and its place in it
-  size_t group_max_ = 0;                                   // the most shards any device holds
+  ShardLayout lay_;                                        // shards by device, send slots, receive offsets (shard_layout.hpp)
   Rccl rccl_;                                              // shard-gather = 1 (loaded and initialised on first use, under rccl_mu_)
   std::mutex rccl_mu_;                                     // collectives of one communicator set are issued by one thread at a time
   std::atomic<uint64_t> rccl_gathers_{0};
