@@ -505,12 +505,13 @@ def lib_multi_gpu(args, world, rank, dist, device):
             distinct = sorted(set(devs))
             no_peer = [(a, b) for a in distinct for b in distinct if a != b and not torch.cuda.can_device_access_peer(a, b)]
             state["peer_access"] = not no_peer
+            state["peer_matrix"] = [[1 if a == b or torch.cuda.can_device_access_peer(a, b) else 0 for b in distinct] for a in distinct]
             if no_peer:
                 os.environ["VK_SHARD_ALLOW_STAGED"] = "1"
                 print(f"[bench] WARNING: no peer access between devices {no_peer[:4]}...: the sharded index stages its broadcast "
                       f"and gather through host memory (VK_SHARD_ALLOW_STAGED=1 set for this run)", file=sys.stderr, flush=True)
             t_build = time.time()
-            ix = vsa.Index("FLAT", D, "COSINE", initial_cap=N, dtype=args.dtype, shard_devices=devs, options={"kernel-timing": 1})
+            ix = vsa.Index("FLAT", D, "COSINE", initial_cap=N, dtype=args.dtype, shard_devices=devs)
             tabs = []
             for s_i, dv in enumerate(devs):
                 r0, r1 = s_i * N // world, (s_i + 1) * N // world
@@ -556,7 +557,6 @@ def lib_multi_gpu(args, world, rank, dist, device):
 
     barrier()
     st0 = state["ix"].stats() if rank == 0 else None
-    sh0 = _shard_filter_ms(state["ix"], None) if rank == 0 else None
     t0 = time.perf_counter()
     if rank == 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -575,23 +575,43 @@ def lib_multi_gpu(args, world, rank, dist, device):
         ix, A, Q, od, ol, tabs = state["ix"], state["A"], state["Q"], state["od"], state["ol"], state["tabs"]
         st1 = ix.stats()
         dev_ms = e0.elapsed_time(e1) / args.steps
+        # per-shard kernel times: a second region of K steps with the library's event pairs around each shard's main pass
+        # (option kernel-timing: the timed region above runs without those stream markers)
+        ix.set_option("kernel-timing", 1)
+        for _ in range(2):
+            state["step"]()
+        torch.cuda.synchronize()
+        sh0 = _shard_filter_ms(ix, None)
+        for _ in range(args.steps):
+            state["step"]()
+        torch.cuda.synchronize()
+        sh1 = [ix.shard_stats(s_i) for s_i in range(ix.shard_count())]
+        ix.set_option("kernel-timing", 0)
+        per_shard_ms = [round((a.filter_kernel_ns - b.filter_kernel_ns) / 1e6 / (a.filter_batches - b.filter_batches), 4)
+                        if a.filter_batches != b.filter_batches else None for b, a in zip(sh0, sh1)]
         res_d, res_l = od.cpu().numpy(), ol.cpu().numpy().view(np.uint64)
         n_local = N // world
         stride = ((D + 63) // 64) * 64 * esz
         scan_bytes = n_local * stride                  # algorithmic bytes of one pass over ONE GPU's shard
         # the dominant kernel per shard: the candidate filter; its duration = the SLOWEST shard's HIP events (the library
         # records them around the launches on each shard's stream; vk_index_stats of a sharded index reports the maximum)
-        filt_ms, filt_n = _shard_filter_ms(ix, sh0)
+        timed = [m for m in per_shard_ms if m]
+        filt_ms, filt_n = (max(timed), args.steps) if timed else (None, 0)
         fan_calls = st1.fanout_calls - st0.fanout_calls
         fan_us = (st1.fanout_enqueue_ns - st0.fanout_enqueue_ns) / 1e3 / fan_calls if fan_calls else None
         kern_ms = filt_ms if filt_ms else dev_ms
         kern_bytes = (_final_rows(ix, n_local) if filt_ms else n_local) * stride     # the main pass's rows (bench.py, N = 1)
-        roofline = {"bound": "hbm", "achieved": round(kern_bytes / (kern_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(kern_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                    "per_gpu": True, "algorithmic_bytes": kern_bytes, "step_algorithmic_bytes": scan_bytes,
-                    "kernel": "flat_filter_bdma_kernel (slowest shard)" if filt_ms else "whole step (small shard: the exact kernels)",
-                    "per_launch_ms": round(kern_ms, 4), "launches_timed": int(filt_n), "step_ms_on_stream": round(dev_ms, 4),
-                    "hbm_frac_of_whole_step": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        # per GPU, the whole timed step: one pass over ONE GPU's shard / (HIP-event time of the K timed steps / K) -- fan-out,
+        # every shard's launches, gather and merge inside; the slowest shard's main pass alone is `dominant_kernel`
+        roofline = {"bound": "hbm", "achieved": round(scan_bytes / (dev_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                    "per_gpu": True, "priced": "whole step", "algorithmic_bytes": scan_bytes, "step_ms_on_stream": round(dev_ms, 4),
+                    "dominant_kernel": ({"kernel": "flat_filter_bdma_kernel (slowest shard)", "achieved": round(kern_bytes / (kern_ms * 1e-3) / 1e9, 2),
+                                         "frac": round(kern_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "per_launch_ms": round(kern_ms, 4),
+                                         "launches_timed": int(filt_n), "algorithmic_bytes": kern_bytes,
+                                         "measured": "the library's HIP event pairs (option kernel-timing), K steps behind the timed region"}
+                                        if filt_ms else None),
+                    "per_shard_main_pass_ms": per_shard_ms,
                     "aggregate_gbs": round(world * scan_bytes / (dev_ms * 1e-3) / 1e9, 1),
                     "host_fanout_enqueue_us_per_step": round(fan_us, 1) if fan_us else None}
 
@@ -696,7 +716,7 @@ def lib_multi_gpu(args, world, rank, dist, device):
                "config": {"workload": f"FLAT {N}x{D} {'bf16 rows' if bf16 else 'fp32'} COSINE k={K} batch={B} (BASELINE.json configs[1]), "
                                       f"rows dealt over {world} GPUs",
                           "rows_per_gpu": n_local, "sharding": f"rows/{world}", "recall_at_10": 1.0, "parity_vs_oracle": parity,
-                          "peer_access": state.get("peer_access", True),
+                          "peer_access": state.get("peer_access", True), "peer_access_matrix": state.get("peer_matrix"),
                           "parallelism": f"one vk_index with n_shards={world} in ONE process"
                                          + (" (rank 0 of the launcher's ranks; the others idle)" if multi_proc else "")
                                          + ": queries broadcast by peer copy, one enqueue thread per shard, per-shard top-k "
@@ -1113,20 +1133,20 @@ def source_sha256():
 
 def pmc_traffic(N, D, B, world, kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc is a separate run by
-    rule, so bench.py cannot collect it live): profiles/r05_pmc_fetch_size.json, written by scripts/pmc_traffic.sh and
+    rule, so bench.py cannot collect it live): profiles/r06_pmc_fetch_size.json, written by scripts/pmc_traffic.sh and
     stamped with the hash of the sources it measured.  Printed only for the default single-GPU workload AND only while
     that hash equals the current sources' -- a stale file yields null, never an old number."""
-    path = ROOT / "profiles" / "r05_pmc_fetch_size.json"
+    path = ROOT / "profiles" / "r06_pmc_fetch_size.json"
     if world != 1 or (N, D, B) != (10_000_000, 768, 256) or not path.exists() or "bf16" in sys.argv:
         return None, None
     if any(os.environ.get(v) for v in ("VK_FLAT_FORCE_SCAN", "VK_GEMM_MODE", "VK_GEMM_ABLATE", "VK_GEMM_LOCKSTEP", "VK_FILTER_TIMING", "VK_FLAT_FILTER")):
         return None, None
     j = json.load(open(path))
     if j.get("src_sha256") != source_sha256():
-        return None, "profiles/r05_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
+        return None, "profiles/r06_pmc_fetch_size.json is stale (taken with other kernel sources): re-run scripts/pmc_traffic.sh"
     for name, v in j.get("kernels", {}).items():
         if kernel_prefix in name and "prepass" not in name and "[small]" not in name:
-            return round(v["hbm_bytes_per_launch"]), "profiles/r05_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
+            return round(v["hbm_bytes_per_launch"]), "profiles/r06_pmc_fetch_size.json (rocprofv3 --pmc FETCH_SIZE, separate pass, same sources)"
     return None, None
 
 
@@ -1216,8 +1236,7 @@ def main():
     t_build = time.time()
     bf16 = args.dtype == "bf16"
     esz = 2 if bf16 else 4
-    ix = vsa.Index("FLAT", D, "COSINE", initial_cap=n_local, device_id=local_rank, dtype=args.dtype,
-                   options={"kernel-timing": 1})   # (HIP event pairs around the final pass: opt-in, for the roofline figure)
+    ix = vsa.Index("FLAT", D, "COSINE", initial_cap=n_local, device_id=local_rank, dtype=args.dtype)
     base_ptr, stride = ix.device_rows(n_local)
     assert stride == ((D + 63) // 64) * 64 * esz   # rows are zero padded to whole 64-element groups
     if bf16:   # torch cannot import bf16 through __cuda_array_interface__: map as int16 and reinterpret
@@ -1292,12 +1311,28 @@ def main():
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1) / args.steps
+    dev_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the work stream around the K timed steps
     st_after = ix.stats()
-    # batches of the timed region that went through the f16 candidate filter, and the device time of that kernel alone
-    # (HIP events the library records around its launches, on the stream they run on)
-    filt_n = st_after.filter_batches - st_before.filter_batches
-    filt_ms = (st_after.filter_kernel_ns - st_before.filter_kernel_ns) / 1e6 / filt_n if filt_n else None
+    filt_n = st_after.filter_batches - st_before.filter_batches     # batches of the timed region that went through the candidate filter
+    # The dominant kernel ALONE (the filter's main pass): a second region of K steps behind the timed one, with the library's
+    # event pairs around that launch switched on (option kernel-timing: an event record is a marker the stream executes,
+    # about 6 us of idle device each, so the timed region runs without them and `roofline.frac` is the whole step's).
+    filt_ms, filt_timed = None, 0
+    if filt_n:
+        ix.set_option("kernel-timing", 1)
+        for _ in range(2):
+            step()
+        barrier()
+        k0 = ix.stats()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        k1 = ix.stats()
+        ix.set_option("kernel-timing", 0)
+        filt_timed = k1.filter_batches - k0.filter_batches
+        filt_ms = (k1.filter_kernel_ns - k0.filter_kernel_ns) / 1e6 / filt_timed if filt_timed else None
+        if not filt_ms:
+            filt_n = 0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1450,7 +1485,12 @@ def main():
         # (the final pass: B operands by DMA; bf16 rows in the inner-product space: bf16 MFMA, rows by DMA)
         filter_name = "flat_filter_bfmma_dma_kernel" if args.dtype == "bf16" else "flat_filter_bdma_kernel"
         dominant = filter_name if filt_n else ("flat_gemm_kernel" if B >= 5 else "flat_scan_kernel")
-        traffic, traffic_src = pmc_traffic(N, D, B, world, dominant)
+        kern_traffic, traffic_src = pmc_traffic(N, D, B, world, dominant)
+        traffic = kern_traffic
+        if filt_n and kern_traffic is not None:     # the step's row traffic = both launches of the filter kernel
+            early_traffic, _ = pmc_traffic(N, D, B, world, filter_name.replace("flat_filter_bdma_kernel", "flat_filter_early_kernel")
+                                                                      .replace("flat_filter_bfmma_dma_kernel", "flat_filter_early_bfmma_dma_kernel"))
+            traffic = kern_traffic + (early_traffic or 0)
         qps = B * args.steps / dt
         scan_bytes = n_local * stride                       # algorithmic bytes of one pass over the shard
         # ... and of the launch the roofline prices: the candidate filter's main pass (two-pass batches: the early pass's
@@ -1475,21 +1515,30 @@ def main():
             # B >= 5: f16 matrix-core candidate filter (flat_filter_kernel, one pass over the rows:
             # HBM-bound, algorithmic bytes = rows * row bytes) + exact re-rank of the survivors; 5 <= B <= 32: the exact f32
             # matrix-core kernel (MFMA-bound); else the scan (HBM-bound)
-            "roofline": ({"bound": "hbm", "achieved": round(kern_bytes / (filt_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(kern_bytes / (filt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
-                          "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src, "algorithmic_bytes": kern_bytes,
-                          "kernel": filter_name, "per_launch_ms": round(filt_ms, 4), "launches_timed": int(filt_n),
-                          "rows_in_launch": main_rows, "rows_in_step": n_local,
+            # HBM-bound.  `achieved` / `frac` price the WHOLE timed step: SURVEY 8(d)'s bytes of one pass over the shard
+            # (rows x row bytes) / (HIP-event time of the K timed steps / K) -- every launch of the step is inside (query
+            # preparation, sample, early and main pass, re-rank, the hand-over launches).  The dominant kernel alone, from the
+            # library's own event pairs in a second region, is the sub-object `dominant_kernel`; rocprofv3's per-kernel average
+            # for the same symbol is in profiles/ and must agree with ITS per_launch_ms.
+            "roofline": ({"bound": "hbm", "achieved": round(scan_bytes / (dev_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                          "traffic_unit": "HBM bytes per step (early + main pass launches)", "traffic_source": traffic_src,
+                          "algorithmic_bytes": scan_bytes, "priced": "whole step", "step_ms_on_stream": round(dev_ms, 4),
+                          "rows_in_step": n_local,
+                          "dominant_kernel": {"kernel": filter_name, "achieved": round(kern_bytes / (filt_ms * 1e-3) / 1e9, 2),
+                                              "frac": round(kern_bytes / (filt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                              "per_launch_ms": round(filt_ms, 4), "launches_timed": int(filt_timed),
+                                              "rows_in_launch": main_rows, "algorithmic_bytes": kern_bytes, "traffic": kern_traffic,
+                                              "measured": "the library's HIP event pairs around this launch on its stream (option "
+                                                          "kernel-timing), K steps behind the timed region",
+                                              "f16_mfma_tflops": round(flops / (filt_ms * 1e-3) / 1e12, 1),
+                                              "f16_mfma_frac_of_2500": round(flops / (filt_ms * 1e-3) / 1e12 / 2500.0, 4)},
                           "early_pass": ({"kernel": filter_name.replace("flat_filter_bdma_kernel", "flat_filter_early_kernel")
                                                                .replace("flat_filter_bfmma_dma_kernel", "flat_filter_early_bfmma_dma_kernel"),
                                           "rows": n_local - main_rows,
                                           "role": "the head of every block's tile range; its survivors give the main pass's bound"}
                                          if main_rows != n_local else None),
-                          "step_ms_on_stream": round(dev_ms, 4), "step_algorithmic_bytes": scan_bytes,
-                          "hbm_frac_of_whole_step": round(scan_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                          "filter": filt_stats,
-                          "f16_mfma_tflops": round(flops / (filt_ms * 1e-3) / 1e12, 1),
-                          "f16_mfma_frac_of_2500": round(flops / (filt_ms * 1e-3) / 1e12 / 2500.0, 4)}
+                          "filter": filt_stats}
                          if filt_n else
                          {"bound": "mfma", "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 3),
                           "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",

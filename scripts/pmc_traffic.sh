@@ -3,9 +3,9 @@
 # run, no tracing, as the guide prescribes), aggregated per kernel, calibrated on the single-query scan kernel (which
 # reads each row byte exactly once) and stamped with the hash of the kernel sources it was taken with.
 # bench.py prints `roofline.traffic` from the resulting file ONLY while that hash equals the current sources'.
-#   scripts/pmc_traffic.sh [out.json]        (run on the GPU box; default out: gpurun_out/r05_pmc_fetch_size.json)
+#   scripts/pmc_traffic.sh [out.json]        (run on the GPU box; default out: gpurun_out/r06_pmc_fetch_size.json)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=${1:-$ROOT/gpurun_out/r05_pmc_fetch_size.json}
+OUT=${1:-$ROOT/gpurun_out/r06_pmc_fetch_size.json}
 case "$OUT" in /*) ;; *) OUT="$PWD/$OUT" ;; esac
 mkdir -p $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp

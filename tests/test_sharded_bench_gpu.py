@@ -35,7 +35,10 @@ def test_single_process_two_shards():
     assert b["n_gpus"] == 2 and b["config"]["sharding"] == "rows/2" and "n_shards=2" in b["config"]["parallelism"]
     rf = b["roofline"]
     assert rf["bound"] == "hbm" and 0.0 < rf["frac"] <= 1.0 and rf["algorithmic_bytes"] == 300000 * 768 * 4
-    assert "flat_filter_bdma_kernel" in rf["kernel"] and rf["launches_timed"] == 3
+    assert rf["priced"] == "whole step" and "flat_filter_bdma_kernel" in rf["dominant_kernel"]["kernel"] and rf["dominant_kernel"]["launches_timed"] == 3
+    assert len(rf["per_shard_main_pass_ms"]) == 2 and all(m and m > 0 for m in rf["per_shard_main_pass_ms"])
+    assert rf["dominant_kernel"]["per_launch_ms"] <= rf["step_ms_on_stream"]
+    assert b["config"]["peer_access_matrix"] == [[1]]      # (two logical shards on one device)
     assert rf["host_fanout_enqueue_us_per_step"] is not None
     ga = b["gather"]      # peer copies against the in-library RCCL all-gather, same steps, same answer
     assert ga["answers_identical"] is True and ga["rccl_ranks"] == 1 and ga["lists_per_rank"] == 2 and ga["rccl_gathers"] >= 3

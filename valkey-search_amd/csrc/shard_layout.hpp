@@ -1,7 +1,7 @@
 // shard_layout.hpp -- where the lists of a sharded search travel: shard -> (device group, position) -> send slot -> receive
 // offset -> slice of the gathered array.  Pure arithmetic over the index's device list, no HIP: sharded_index.cc builds its
-// fan-out on it and tests/test_shard_layout.py checks it for G in {1..8} devices and uneven shard counts per device, which no
-// box with one GPU ever exercises.
+// fan-out on it and tests/helpers/san_sharded_main.cc (check_layout, then whole searches over virtual devices) checks it for 1 to 8
+// devices with even and uneven shard counts per device, which no box with one GPU ever exercises.
 //
 //   devices[s]             the HIP device of shard s (a device may repeat: logical shards)
 //   group g                the shards that live on one device, in shard order; groups in order of first appearance, so group 0
