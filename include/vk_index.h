@@ -309,7 +309,7 @@ int vk_index_set_coalescing(vk_index *ix, uint32_t max_batch, uint32_t max_wait_
  * of reader threads.  Coalescing must be on (vk_index_set_coalescing with max_batch > 1), else VK_ERR_INVALID.
  *   done(user, status) is called exactly once, from a library thread, after out_dist / out_label / *out_n have been
  *   written; status is the vk_status of the batch the request travelled in (VK_ERR_CANCELLED as for vk_index_search).
- *   The callbacks of a batch run on the library's completer threads (option completer-threads, default 4; one pool for all
+ *   The callbacks of a batch run on the library's completer threads (option completer-threads, default 6; one pool for all
  *   indexes of the process), several
  *   side by side and in no particular order; one must not block for long (it holds up the completions queued behind
  *   it) and must not destroy the index.
@@ -322,6 +322,23 @@ int vk_index_search_submit(vk_index *ix, const void *query, uint64_t k, uint64_t
                            const volatile int *cancel_flag, int partial_ok,
                            float *out_dist, uint64_t *out_label, uint64_t *out_n,
                            vk_search_done_fn done, void *user);
+/* Completions told in bulk.  The reference's completion (search.cc:905-908) runs once per FT.SEARCH and re-posts to the main
+ * thread; at half a million HNSW queries per second per GPU that per-request hand-over -- a callback, a queue operation and a
+ * wake each -- is what bounds the serving rate (r05: 7 us per callback on four completer threads).  With a hook set, the
+ * completions of EVERY request submitted to this index are told through it: one call per piece of a finished batch (option
+ * handout-chunk; a request answered alone -- its token went up, the index is shutting down -- is a call with n = 1), from a
+ * completer thread, after the members' outputs have been written.  items[i].user is the `user` given at submission, .status
+ * what its callback would have received; the per-request callbacks are then NOT called (vk_index_search_submit still needs a
+ * non-NULL one).  The caller answers the span in one go: one queue operation and one wake towards its main thread per piece.
+ * Set it before the first submission (NULL restores per-request callbacks); the rules for a callback apply to the hook. */
+typedef struct vk_completion {
+  void *user;
+  int32_t status;   /* vk_status */
+  uint32_t reserved;
+} vk_completion;
+typedef void (*vk_batch_done_fn)(void *hook_user, const vk_completion *items, uint64_t n);
+int vk_index_set_batch_completion(vk_index *ix, vk_batch_done_fn hook, void *hook_user);
+
 /* ---- device-resident filters ---------------------------------------------------------------------------------------------
  * The reference filters an HNSW search with InlineVectorFilter (src/query/search.cc:103-134), a functor called per visited
  * candidate.  A kernel cannot call a functor: a search carries a bitmap over the labels.  What the query layer HOLDS for a

@@ -236,6 +236,7 @@ class VectorGpu : public VectorBase {
 #endif
   ~VectorGpu() override {
     if (owns_) vk_index_destroy(ix_);   // (answers what is queued and waits for the completions)
+    else if (ix_) (void)vk_index_set_batch_completion(ix_, nullptr, nullptr);   // (an adopted index goes back as it came)
   }
   size_t GetDataTypeSize() const override { return sizeof(T); }
   size_t GetCapacity() const override { return Stats().capacity; }
@@ -337,6 +338,19 @@ class VectorGpu : public VectorBase {
     return absl::OkStatus();
   }
 
+  // Completions in bulk.  The library tells the completions of a piece of a finished batch in ONE call (vk_index.h:
+  // vk_index_set_batch_completion); the replies of the piece are built here (CreateReply's key lookups) and handed on
+  //   * one `done` call per request (the default: what query::SearchAsync's callback is today, search.cc:905-908), or
+  //   * ALL AT ONCE to the sink set with SetBulkDone: the module posts ONE task to its main thread that answers the whole
+  //     span (one queue operation and one wake per piece instead of one per FT.SEARCH -- at half a million HNSW queries a
+  //     second the per-request hand-over, not the search, was the bound: r05 0.76-0.83 of the device rate).
+  struct CompletedSearch {
+    SearchDone done;
+    absl::StatusOr<std::vector<Neighbor>> result;
+  };
+  using BulkDone = std::function<void(std::vector<CompletedSearch> &&)>;
+  void SetBulkDone(BulkDone sink) { bulk_done_ = std::move(sink); }   // before the first SearchAsync
+
   // The blocking forms (the reference's signature, and the same with a prebuilt filter)
   absl::StatusOr<std::vector<Neighbor>> Search(absl::string_view query, uint64_t count, cancel::Token &cancellation_token,
                                                std::unique_ptr<hnswlib::BaseFilterFunctor> filter = nullptr,
@@ -397,6 +411,8 @@ class VectorGpu : public VectorBase {
     // costs the same for 1 query or 256 (and its window waits for the callers of the batch that has just finished), an HNSW
     // launch wants thousands of waves.  A lone query is held for a quarter of the window at most.
     const uint32_t device_batch = algo_ == VK_ALGO_FLAT ? 256u : 8192u;
+    // completions arrive a piece of a batch at a time (BatchCompleted), not one call per request
+    if (int rc = vk_index_set_batch_completion(ix_, &VectorGpu::BatchCompleted, this); rc != VK_OK) return VkToStatus(rc);
     return VkToStatus(vk_index_set_coalescing(ix_, std::max(reader_threads, device_batch), algo_ == VK_ALGO_FLAT ? 400 : 2000));
   }
   // an index that exists already (built by a bulk loader, or -- scripts/adaptor_probe.cc -- by the benchmark): served through
@@ -566,7 +582,9 @@ class VectorGpu : public VectorBase {
     for (uint64_t i = 0; i < n; ++i) {
       auto key = GetKeyDuringSearch(label[i]);
       if (!key.ok()) continue;
-      out.emplace_back(key.value(), dist[i]);
+      // (moved, not copied: a key's reference count is one cache line every reply that names the key bounces between the
+      //  completer threads -- the popular neighbours of an HNSW graph are in most replies)
+      out.emplace_back(std::move(key.value()), dist[i]);
     }
     return out;
   }
@@ -596,6 +614,24 @@ class VectorGpu : public VectorBase {
       else rq->done(rq->self->Reply(rq->dist, rq->out.get(), rq->n));
     }
   };
+  // vk_batch_done_fn: a completer thread of the library, the outputs of every member are written
+  static void BatchCompleted(void *self_p, const vk_completion *items, uint64_t n) {
+    VectorGpu *self = static_cast<VectorGpu *>(self_p);
+    std::vector<CompletedSearch> span;
+    span.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) {
+      std::unique_ptr<AsyncSearch> rq(static_cast<AsyncSearch *>(items[i].user));
+      if (rq->watched) VkTokenWatch::Instance().Unregister(rq->watch);
+      if (items[i].status != VK_OK) span.push_back(CompletedSearch{std::move(rq->done), VkCompletionStatus(items[i].status)});
+      else span.push_back(CompletedSearch{std::move(rq->done), self->Reply(rq->dist, rq->out.get(), rq->n)});
+    }
+    if (self->bulk_done_) {
+      self->bulk_done_(std::move(span));
+    } else {
+      for (CompletedSearch &c : span) c.done(std::move(c.result));
+    }
+  }
+  BulkDone bulk_done_;
 
   vk_algo algo_;
   vk_index *ix_ = nullptr;

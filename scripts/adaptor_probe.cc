@@ -12,6 +12,7 @@
 // Every reply is compared with a reference answer of the same query (ids and distance bits).  bench.py:
 // single_query_serving.adaptor.  Built by __graft_entry__.build() as a shared library (g++, no HIP).
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -108,7 +109,9 @@ struct Run {
     if (r.size() != k) return false;
     for (uint64_t i = 0; i < k; ++i) {
       if (memcmp(&r[i].distance, ref_d + qi * k + i, 4) != 0) return false;
-      if (strtoull(std::string(r[i].external_id->Str()).c_str(), nullptr, 10) != ref_l[qi * k + i]) return false;
+      uint64_t id = 0;   // (the mock's key of internal id N is the string "N")
+      for (char c : r[i].external_id->Str()) id = id * 10 + (uint64_t)(c - '0');
+      if (id != ref_l[qi * k + i]) return false;
     }
     return true;
   }
@@ -116,6 +119,16 @@ struct Run {
 
 // one front thread (the main thread, or one of the io threads that parse commands next to it): its share of the clients'
 // concurrency and of the requests
+struct Front;
+// what a completer thread has answered for one front thread inside the span it is handing over (the bulk sink below): the
+// replies of a piece go back to their front thread in ONE queue operation and one wake -- the RunByMain step, once per span
+struct Pending {
+  Front *front;
+  std::vector<float> lat_us;
+  uint64_t errors = 0, mismatches = 0;
+};
+thread_local std::vector<Pending> *t_span = nullptr;   // non-null while the bulk sink runs on this thread
+
 struct Front {
   Run *run = nullptr;
   std::mutex mu;
@@ -125,14 +138,38 @@ struct Front {
   std::vector<float> lat_us;
   void finish(uint64_t qi, Clock::time_point t0, const absl::StatusOr<std::vector<Neighbor>> &r) {
     const float us = (float)std::chrono::duration<double, std::micro>(Clock::now() - t0).count();
-    if (!r.ok()) run->errors.fetch_add(1, std::memory_order_relaxed);
-    else if (!run->same(qi, r.value())) run->mismatches.fetch_add(1, std::memory_order_relaxed);
+    const bool err = !r.ok(), mis = !err && !run->same(qi, r.value());
+    if (t_span) {   // inside a span: collected, handed over by flush()
+      Pending *p = nullptr;
+      for (Pending &x : *t_span)
+        if (x.front == this) p = &x;
+      if (!p) { t_span->push_back(Pending{this, {}, 0, 0}); p = &t_span->back(); }
+      p->lat_us.push_back(us);
+      p->errors += err;
+      p->mismatches += mis;
+      return;
+    }
+    if (err) run->errors.fetch_add(1, std::memory_order_relaxed);
+    if (mis) run->mismatches.fetch_add(1, std::memory_order_relaxed);
     run->completed.fetch_add(1, std::memory_order_relaxed);
     bool wake;
     {
       std::lock_guard<std::mutex> lk(mu);
       lat_us.push_back(us);
       free_slots += 1;
+      wake = waiting;
+    }
+    if (wake) cv.notify_one();
+  }
+  void flush(Pending &p) {
+    if (p.errors) run->errors.fetch_add(p.errors, std::memory_order_relaxed);
+    if (p.mismatches) run->mismatches.fetch_add(p.mismatches, std::memory_order_relaxed);
+    run->completed.fetch_add(p.lat_us.size(), std::memory_order_relaxed);
+    bool wake;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      lat_us.insert(lat_us.end(), p.lat_us.begin(), p.lat_us.end());
+      free_slots += (int)p.lat_us.size();
       wake = waiting;
     }
     if (wake) cv.notify_one();
@@ -153,6 +190,19 @@ int drive(Ix &ix, const float *queries, uint64_t nq, uint32_t dim, uint64_t k, u
     fs.back()->lat_us.reserve((size_t)(total / fronts) + 16);
   }
   cancel::Token token = std::make_shared<NeverCancelled>();
+  // the replies of a piece of a batch arrive together (VectorGpu::SetBulkDone): each is checked, then every front thread
+  // gets ITS share in one go
+  // (A/B inside one process: VK_PROBE_BULK=0 takes the hook off again -- one callback per request, as r05 had it)
+  const bool bulk = !getenv("VK_PROBE_BULK") || atoi(getenv("VK_PROBE_BULK")) != 0;
+  if (!bulk) vk_index_set_batch_completion(ix.handle(), nullptr, nullptr);
+  if (!blocking && bulk)
+    ix.SetBulkDone([](std::vector<typename Ix::CompletedSearch> &&span) {
+      std::vector<Pending> mine;
+      t_span = &mine;
+      for (auto &c : span) c.done(std::move(c.result));
+      t_span = nullptr;
+      for (Pending &p : mine) p.front->flush(p);
+    });
   const Clock::time_point t0 = Clock::now();
   {
     Pool pool(readers);

@@ -54,7 +54,7 @@ if NF:
             vsa.adaptor_probe(ix, hq, K, 1024, readers, 1024, 0, hnsw=False, ref=(rd, rl), fronts=fronts)
             line(f"FLAT adaptor async, {readers} readers, fronts {fronts}, completers {comp}", ix,
                  lambda: vsa.adaptor_probe(ix, hq, K, 10240, readers, 1024, 0, hnsw=False, ref=(rd, rl), fronts=fronts), dq)
-    ix.set_option("completer-threads", 4)
+    ix.set_option("completer-threads", 6)
     line("FLAT blocking, 256 callers", ix, lambda: vsa.probe_blocking(ix, hq, K, 256, 24, 0, ref=(rd, rl)), dq)
     ix.set_coalescing(0, 0)
     del ix, t
@@ -87,8 +87,9 @@ if NH:
         h.set_coalescing(nq, 2000)
         vsa.probe_submit(h, hq, K, 4 * nq, 8, 4 * nq, 128, ref=(rd, rl))
         line(f"HNSW raw submit, 8 producers, completers {comp}", h, lambda: vsa.probe_submit(h, hq, K, 16 * nq, 8, 4 * nq, 128, ref=(rd, rl)), dq)
-        for fronts in (1, 2, 4):
-            for mb, wu in ((0, 0), (8192, 2000)):
-                vsa.adaptor_probe(h, hq, K, 4 * nq, readers, 4 * nq, 128, hnsw=True, ref=(rd, rl), fronts=fronts, max_batch=mb, wait_us=wu)
-                line(f"HNSW adaptor async, fronts {fronts}, completers {comp}, coalescing {mb or 'own'}/{wu or 'own'}", h,
-                     lambda: vsa.adaptor_probe(h, hq, K, 16 * nq, readers, 4 * nq, 128, hnsw=True, ref=(rd, rl), fronts=fronts, max_batch=mb, wait_us=wu), dq)
+        for fronts in (1, 4):
+            for bulk in ("1", "0", "1", "0"):   # completions a piece of a batch at a time / one callback per request, alternating
+                __import__("os").environ["VK_PROBE_BULK"] = bulk
+                vsa.adaptor_probe(h, hq, K, 4 * nq, readers, 4 * nq, 128, hnsw=True, ref=(rd, rl), fronts=fronts)
+                line(f"HNSW adaptor async, fronts {fronts}, completers {comp}, completions {'in bulk' if bulk == '1' else 'one by one'}", h,
+                     lambda: vsa.adaptor_probe(h, hq, K, 16 * nq, readers, 4 * nq, 128, hnsw=True, ref=(rd, rl), fronts=fronts), dq)

@@ -30,11 +30,17 @@ def show(lo, hi):
         prev_end = e if prev_end is None else max(prev_end, e); busy += e - s
     total = (rows[hi][0] - t0) / 1e3
     print(f"  step (qprep start -> next qprep start) {total:.1f} us, kernels busy {busy / 1e3:.1f} us, idle {total - busy / 1e3:.1f} us")
+# bench.py: 3 warm-up steps, the 10 TIMED steps (no event records), then 2 + 10 steps with the library's event pairs around the
+# main pass (the dominant-kernel figure): the timed region is steps 3 .. 12
+timed = steps[3:13] if len(steps) >= 13 else steps
 print("last but one step of the timed region:")
-show(*steps[-2])
+show(*timed[-2])
 import statistics
-tot = [(rows[b][0] - rows[a][0]) / 1e3 for a, b in steps[-9:]]
-print("last 9 step periods (us):", [round(t, 1) for t in tot], "median", round(statistics.median(tot), 1))
+tot = [(rows[b][0] - rows[a][0]) / 1e3 for a, b in timed[-9:]]
+print("last 9 step periods of the timed region (us):", [round(t, 1) for t in tot], "median", round(statistics.median(tot), 1))
+if len(steps) >= 25:
+    print("a step of the second region (kernel-timing on: an event record in front of and behind the main pass):")
+    show(*steps[-3])
 PY
 tail -c 600 $ROOT/gpurun_out/${TAG}_bench.log
 rm -rf $D

@@ -154,7 +154,22 @@ void async_done(void *user, int status) {
   s->completions->fetch_add(1);
   s->done.fetch_add(1, std::memory_order_release);
 }
+// completions told in bulk (Dispatcher::set_batch_done): the per-request callback must then never be called
+std::atomic<int> g_bulk_mode{0};
+std::atomic<uint64_t> g_bulk_calls{0}, g_bulk_max_span{0}, g_stray_callbacks{0};
+void never_done(void *, int) { g_stray_callbacks.fetch_add(1); }
+void bulk_done(void *, void *const *users, const int *statuses, uint64_t n) {
+  g_bulk_calls.fetch_add(1);
+  uint64_t m = g_bulk_max_span.load();
+  while (n > m && !g_bulk_max_span.compare_exchange_weak(m, n)) {}
+  for (uint64_t i = 0; i < n; ++i) async_done(users[i], statuses[i]);
+}
 }  // namespace
+
+// the next dispatcher_async_run tells its completions through the bulk hook; out[0..2] of dispatcher_bulk_stats: hook calls,
+// the largest span, per-request callbacks that fired although the hook was set (must be 0)
+extern "C" void dispatcher_async_bulk(int on) { g_bulk_mode = on; g_bulk_calls = 0; g_bulk_max_span = 0; g_stray_callbacks = 0; }
+extern "C" void dispatcher_bulk_stats(uint64_t *out) { out[0] = g_bulk_calls; out[1] = g_bulk_max_span; out[2] = g_stray_callbacks; }
 
 extern "C" int dispatcher_async_run(int producers, int per_producer, int window, uint32_t max_batch, uint32_t max_wait_us,
                                     uint32_t in_flight, uint64_t queue_depth, int delay_us, int hnsw, uint64_t *out) {
@@ -171,6 +186,8 @@ extern "C" int dispatcher_async_run(int producers, int per_producer, int window,
     dp.configure(max_batch, max_wait_us);
     dp.set_in_flight(in_flight);
     dp.set_queue_depth(queue_depth);
+    const bool bulk = g_bulk_mode.load() != 0;
+    if (bulk) dp.set_batch_done(&bulk_done, nullptr);
     auto producer = [&](int t) {
       std::vector<std::unique_ptr<AsyncSlot>> slots;
       size_t checked = 0;
@@ -200,7 +217,7 @@ extern "C" int dispatcher_async_run(int producers, int per_producer, int window,
         s->n = 99;
         s->completions = &completions;
         vk::Status st = dp.submit(s->q, 3, 100, s->filtered ? s->bits : nullptr, s->filtered ? 64 : 0, nullptr, s->id % 2 ? &s->flag : (s->cancelled ? &s->flag : nullptr),
-                                  /*partial_ok=*/false, s->d, s->l, &s->n, async_done, s.get());
+                                  /*partial_ok=*/false, s->d, s->l, &s->n, bulk ? never_done : async_done, s.get());
         if (!st.ok()) {
           if (st.code != VK_ERR_BUSY) bad += 1;
           rejected += 1;

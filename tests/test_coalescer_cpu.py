@@ -24,6 +24,8 @@ def shim(tmp_path_factory):
     lib.coalescer_run.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     lib.dispatcher_async_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int,
                                          C.POINTER(C.c_uint64)]
+    lib.dispatcher_async_bulk.argtypes = [C.c_int]
+    lib.dispatcher_bulk_stats.argtypes = [C.POINTER(C.c_uint64)]
     lib.dispatcher_destroy_run.argtypes = [C.c_int, C.c_int]
     lib.dispatcher_two_indexes_run.argtypes = [C.c_int, C.c_int]
     lib.dispatcher_batch_cancel_run.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
@@ -107,6 +109,23 @@ def test_submit_completes_every_request_once_with_two_batches_in_flight(shim):
     assert st["calls"] < 3200 // 8 and 8 < st["max_batch"] <= 64
     assert st["in_flight"] == 2 and st["concurrent_passes"] == 2
     assert st["cancelled"] == sum(1 for i in range(3200) if i % 29 == 11)
+
+
+def test_completions_told_in_bulk(shim):
+    """vk_index_set_batch_completion: with the hook set every submitted request completes exactly once THROUGH THE HOOK -- a
+    piece of a finished batch per call, a lone call for a request answered on its raised token -- and the per-request callback
+    given at submission is never called."""
+    shim.dispatcher_async_bulk(1)
+    try:
+        bad, st = arun(shim, 8, 400, 128, 64, 500, 2, 100000, hnsw=1)
+    finally:
+        bs = (C.c_uint64 * 3)()
+        shim.dispatcher_bulk_stats(bs)
+        shim.dispatcher_async_bulk(0)
+    assert bad == 0 and st["completions"] == 3200 and st["rejected"] == 0
+    assert st["cancelled"] == sum(1 for i in range(3200) if i % 29 == 11)
+    assert bs[2] == 0                                # no stray per-request callback
+    assert bs[0] < 3200 and bs[1] > 1, list(bs)      # fewer hook calls than requests: spans
 
 
 def test_flat_filtered_requests_travel_in_lanes_of_their_filter(shim):

@@ -19,7 +19,7 @@
 // batch waits until the batch is full, the oldest request has waited max_wait_us, or nobody has arrived for a quarter
 // of that (20-200 us): callers of the batch that just finished come back within microseconds of each other.
 //
-// COMPLETER threads (option completer-threads, default 4; the PROCESS's, shared by all its indexes: CompleterPool) hand the
+// COMPLETER threads (option completer-threads, default 6; the PROCESS's, shared by all its indexes: CompleterPool) hand the
 // answers of a finished batch to the callers' callbacks, a piece of the batch each: a callback runs the caller's code (the adaptor builds the neighbour list and posts it on; 7-18 us
 // each measured), and with the runner doing that a FLAT pass started 1.5 ms late (0.77 of the device rate through the
 // adaptor, 0.98 with completers) and an HNSW runner spent more time answering than searching (0.35 -> 0.86).
@@ -152,6 +152,15 @@ class Dispatcher {
     return Times{t_idle_.load(std::memory_order_relaxed) / 1000, t_window_.load(std::memory_order_relaxed) / 1000,
                  t_search_.load(std::memory_order_relaxed) / 1000, t_handout_.load(std::memory_order_relaxed) / 1000,
                  t_completer_.load(std::memory_order_relaxed) / 1000};
+  }
+
+  // vk_index_set_batch_completion: with a hook set, the completions of submitted requests are told through IT -- one call per
+  // piece of a finished batch (`users` / `statuses` of its members; a request answered alone, e.g. when its token goes up, is a
+  // call with one member) -- and the per-request callbacks are not called.  Set before requests are submitted.
+  using BatchDoneFn = void (*)(void *hook_user, void *const *users, const int *statuses, uint64_t n);
+  void set_batch_done(BatchDoneFn fn, void *hook_user) {
+    batch_user_ = hook_user;
+    batch_fn_.store(fn, std::memory_order_release);
   }
 
   // vk_index_search_submit: queue one single-query request and return.  `done(user, status)` is called exactly once, from
@@ -435,7 +444,12 @@ class Dispatcher {
     uint32_t exp = kInBatch;
     return r.state.compare_exchange_strong(exp, kCompleting, std::memory_order_acq_rel);
   }
-  static void deliver(Req &r, const Status &st, const float *d, const uint64_t *l, uint64_t n) {
+  // completions of submitted requests that are told in ONE call (set_batch_done): the members of a piece of a finished batch
+  struct Bulk {
+    std::vector<void *> users;
+    std::vector<int> codes;
+  };
+  void deliver(Req &r, const Status &st, const float *d, const uint64_t *l, uint64_t n, Bulk *bulk = nullptr) {
     *r.on = st.ok() ? n : 0;
     if (st.ok() && n) {
       memcpy(r.od, d, (size_t)n * 4);
@@ -443,7 +457,17 @@ class Dispatcher {
     }
     if (r.cb) {
       r.state.store(kDone, std::memory_order_release);
-      r.cb(r.user, st.code);
+      BatchDoneFn hook = batch_fn_.load(std::memory_order_acquire);
+      if (hook && bulk) {
+        bulk->users.push_back(r.user);
+        bulk->codes.push_back(st.code);
+      } else if (hook) {
+        void *u = r.user;
+        const int c = st.code;
+        hook(batch_user_, &u, &c, 1);
+      } else {
+        r.cb(r.user, st.code);
+      }
     } else {
       r.st = st;
       r.state.store(kDone, std::memory_order_release);   // (the sleeper is woken by wake_blocked(), once per batch)
@@ -628,6 +652,8 @@ class Dispatcher {
 
   void hand_out(std::vector<std::shared_ptr<Req>> &batch, Scratch &sc, const Status &st, const std::vector<Status> &each, uint64_t k, bool hnsw,
                 uint64_t first, uint64_t count) {
+    Bulk bulk;
+    if (batch_fn_.load(std::memory_order_relaxed)) { bulk.users.reserve(count); bulk.codes.reserve(count); }
     for (uint64_t i = first; i < first + count; ++i) {
       Req &r = *batch[i];
       if (!claim(r)) continue;   // (it left, or was answered when its token went up; its token may be gone: not read)
@@ -639,7 +665,10 @@ class Dispatcher {
         n = 0;
         mine = Status::Err(VK_ERR_CANCELLED, "Search operation cancelled due to timeout");
       }
-      deliver(r, mine, sc.D.data() + i * k, sc.L.data() + i * k, n);
+      deliver(r, mine, sc.D.data() + i * k, sc.L.data() + i * k, n, &bulk);
+    }
+    if (!bulk.users.empty()) {   // one call for the piece's submitted members (set_batch_done)
+      if (BatchDoneFn hook = batch_fn_.load(std::memory_order_acquire)) hook(batch_user_, bulk.users.data(), bulk.codes.data(), bulk.users.size());
     }
     wake_blocked();
   }
@@ -760,11 +789,13 @@ class Dispatcher {
   uint32_t max_wait_us_ = 0;
   std::atomic<uint32_t> wake_seq_{0}, sleepers_{0};
   std::atomic<uint64_t> queue_depth_{100000};
-  std::atomic<uint32_t> completer_threads_{4}, handout_chunk_{64};
+  std::atomic<uint32_t> completer_threads_{6}, handout_chunk_{64};
   std::atomic<uint64_t> t_idle_{0}, t_window_{0}, t_search_{0}, t_handout_{0}, t_completer_{0};   // nanoseconds
   std::atomic<uint64_t> queued_{0}, batches_{0}, queries_{0}, submitted_{0}, rejected_{0}, max_active_seen_{0}, left_early_{0};
   std::mutex cmu_;
   std::condition_variable ccv_;
+  std::atomic<BatchDoneFn> batch_fn_{nullptr};
+  void *batch_user_ = nullptr;
   uint64_t pieces_out_ = 0;   // pieces of finished batches the process's completer threads still hold (under cmu_)
   std::mutex wmu_;
   std::condition_variable wcv_;

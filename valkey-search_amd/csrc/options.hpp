@@ -62,7 +62,7 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"coalesce-max-wait-us", nullptr, 200, 0, 10000000},
       {"max-query-queue-depth", nullptr, 100000, 0, 0x7FFFFFFF},
       {"batches-in-flight", "VK_BATCHES_IN_FLIGHT", 2, 1, 8},
-      {"completer-threads", "VK_COMPLETER_THREADS", 4, 0, 16},
+      {"completer-threads", "VK_COMPLETER_THREADS", 6, 0, 16},
       {"handout-chunk", "VK_HANDOUT_CHUNK", 64, 16, 16384},
       {"shard-ef-pct", nullptr, 100, 1, 1000},
       {"shard-gather", "VK_SHARD_GATHER", 0, 0, 1},

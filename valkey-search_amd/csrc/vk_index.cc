@@ -69,6 +69,8 @@ struct vk_index {
   std::unique_ptr<vk::Index> impl;
   VkCounters counters;
   VkFilterCache filters;
+  std::atomic<vk_batch_done_fn> batch_done{nullptr};   // vk_index_set_batch_completion
+  void *batch_user = nullptr;
   std::unique_ptr<vk::Dispatcher> dispatcher;   // (declared after impl: destroyed first, while the index is still there)
 };
 
@@ -285,7 +287,33 @@ void submit_done(void *p, int status) {
   delete c;
   done(user, status);
 }
+// ... and the same for a span of requests (Dispatcher::set_batch_done): one clock reading, one call of the caller's hook
+void submit_done_batch(void *p, void *const *users, const int *statuses, uint64_t n) {
+  vk_index *ix = static_cast<vk_index *>(p);
+  vk_batch_done_fn hook = ix->batch_done.load(std::memory_order_acquire);
+  const auto now = std::chrono::steady_clock::now();
+  thread_local std::vector<vk_completion> items;
+  items.resize(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    SubmitCtx *c = static_cast<SubmitCtx *>(users[i]);
+    ix->counters.record(1, statuses[i], (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - c->t0).count());
+    items[i].user = c->user;
+    items[i].status = statuses[i];
+    items[i].reserved = 0;
+    if (!hook) c->done(c->user, statuses[i]);   // (the hook was taken away while requests were in flight)
+    delete c;
+  }
+  if (hook) hook(ix->batch_user, items.data(), n);
+}
 }  // namespace
+
+int vk_index_set_batch_completion(vk_index *ix, vk_batch_done_fn hook, void *hook_user) {
+  VK_NEED(ix);
+  ix->batch_user = hook_user;
+  ix->batch_done.store(hook, std::memory_order_release);
+  ix->dispatcher->set_batch_done(hook ? &submit_done_batch : nullptr, ix);
+  return VK_OK;
+}
 
 int vk_index_search_submit(vk_index *ix, const void *query, uint64_t k, uint64_t ef_runtime, const uint64_t *allow_bits,
                            uint64_t allow_nbits, const volatile int *cancel_flag, int partial_ok, float *out_dist,
