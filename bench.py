@@ -237,7 +237,7 @@ def hnsw_leg(args, flat_ix, host_rows, A, device, stream_ptr, total_rows):
             "build_s": round(build_s, 2), "build_inserts_per_s": round(Nh / build_s, 1), "build": "device-assisted (K9)", "build_routes_1M": routes,
             **head, "single_query_ms": round(lat_ms, 3),
             "roofline": {"bound": "hbm", "achieved": head["useful_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": head["frac_of_hbm_peak"],
+                         "frac": head["frac_of_hbm_peak"], **hnsw_pmc_traffic(Nh, nq, ef),
                          "kernel": VIS[vis_modes[ef]][0], "visited_set": VIS[vis_modes[ef]][1] + " (vk_index_stats.last_visited_mode)",
                          "bytes": "n_eval*(D*4+4) + n_hops*132 per query, counted by the kernel",
                          "gather_ceiling_gbs": GATHER_CEILING_GBS, "gather_ceiling_source": "profiles/r01_gather_ceiling_10Mx768.log"},
@@ -1129,6 +1129,23 @@ def source_sha256():
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()
+
+
+def hnsw_pmc_traffic(rows, nq, ef):
+    """memory-side traffic of the HNSW search launch from the committed PMC passes (scripts/pmc_hnsw_traffic.sh: FETCH_SIZE
+    calibrated on the single-query FLAT scan of the same run, the L2's hit rate, the fabric read requests), against the useful
+    bytes the kernel counts: printed only while the file was taken with the current kernel sources and this workload"""
+    path = ROOT / "profiles" / "r06_pmc_hnsw_traffic.json"
+    if not path.exists():
+        return {"traffic": None}
+    j = json.load(open(path))
+    if j.get("src_sha256") != source_sha256():
+        return {"traffic": None, "traffic_source": "profiles/r06_pmc_hnsw_traffic.json is stale (other kernel sources): re-run scripts/pmc_hnsw_traffic.sh"}
+    if (j.get("rows"), j.get("queries_per_launch"), j.get("ef")) != (rows, nq, ef) or "traffic_bytes_per_launch" not in j:
+        return {"traffic": None, "traffic_source": f"profiles/r06_pmc_hnsw_traffic.json holds {j.get('rows')} rows x {j.get('queries_per_launch')} queries at ef {j.get('ef')}"}
+    return {"traffic": round(j["traffic_bytes_per_launch"]), "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE, calibrated; Infinity-Cache hits not excluded)",
+            "useful_bytes_per_launch": j.get("useful_bytes_per_launch"), "traffic_over_useful": j.get("traffic_over_useful"),
+            "l2_hit_rate": j.get("l2_hit_rate"), "traffic_source": "profiles/r06_pmc_hnsw_traffic.json (own --pmc passes, same sources)"}
 
 
 def pmc_traffic(N, D, B, world, kernel_prefix):

@@ -22,8 +22,70 @@ from _pkg import vsa
 import bench as B
 
 
+class ClockSampler:
+    """engine clock (MHz) and socket power (W) of GPU 0 while a loop of launches runs: sysfs hwmon where it is there (a read per
+    millisecond), else `rocm-smi --showclocks --showpower` as fast as it answers"""
+
+    def __init__(self):
+        import ctypes, glob
+        # the hwmon node of THE device the kernels run on (a box holds eight cards): by PCI bus id of HIP device 0
+        bus = None
+        try:
+            buf = ctypes.create_string_buffer(64)
+            hip = ctypes.CDLL("libamdhip64.so")
+            if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+                bus = buf.value.decode().lower()
+        except OSError:
+            pass
+        base = f"/sys/bus/pci/devices/{bus}/hwmon/hwmon*/" if bus else "/sys/class/drm/card*/device/hwmon/hwmon*/"
+        self.freq = (glob.glob(base + "freq1_input") or [None])[0]
+        pw = glob.glob(base + "power1_average") + glob.glob(base + "power1_input")
+        self.power = pw[0] if pw else None
+        self.source = f"sysfs hwmon of {bus}" if self.freq else "rocm-smi"
+        self.mhz, self.watts, self._stop = [], [], False
+
+    def _once(self):
+        if self.freq:
+            try:
+                self.mhz.append(int(open(self.freq).read()) / 1e6)
+                if self.power:
+                    self.watts.append(int(open(self.power).read()) / 1e6)
+            except (OSError, ValueError):
+                pass
+            return
+        import re, subprocess
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True).stdout
+        m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+        if m:
+            self.mhz.append(float(m.group(1)))
+        m = re.search(r"Socket (?:Graphics Package )?Power \(W\): ([0-9.]+)", out)
+        if m:
+            self.watts.append(float(m.group(1)))
+
+    def run(self, fn):
+        import threading, time
+
+        def loop():
+            while not self._stop:
+                self._once()
+                if self.freq:
+                    time.sleep(0.001)
+        self.mhz, self.watts, self._stop = [], [], False
+        t = threading.Thread(target=loop)
+        t.start()
+        try:
+            fn()
+        finally:
+            self._stop = True
+            t.join()
+        q = lambda v, f: round(sorted(v)[min(len(v) - 1, int(f * len(v)))], 1) if v else None
+        return {"source": self.source, "samples": len(self.mhz), "sclk_mhz_p10": q(self.mhz, 0.1), "sclk_mhz_p50": q(self.mhz, 0.5),
+                "sclk_mhz_p90": q(self.mhz, 0.9), "power_w_p50": q(self.watts, 0.5), "power_w_max": max(self.watts) if self.watts else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--sample-clock", action="store_true", help="engine clock and socket power sampled while each variant's loop runs")
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--dtypes", default="bf16,f32")
@@ -33,6 +95,7 @@ def main():
     ap.add_argument("--prio", default="0", help="VK_FILTER_PRIO values to run every ablation with")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    sampler = ClockSampler() if args.sample_clock else None
     N, D, NB, K = args.rows, args.dim, 256, 10
     for dt in args.dtypes.split(","):
         bf = dt == "bf16"
@@ -67,16 +130,22 @@ def main():
                 ix.search_batch_device(Q.data_ptr(), NB, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), stream=st.cuda_stream)
                 torch.cuda.synchronize()
                 s0 = ix.stats()
-                for _ in range(args.steps):
-                    ix.search_batch_device(Q.data_ptr(), NB, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), stream=st.cuda_stream)
-                torch.cuda.synchronize()
+
+                def loop():
+                    for i in range(args.steps):
+                        ix.search_batch_device(Q.data_ptr(), NB, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), stream=st.cuda_stream)
+                        if i % 16 == 15:   # (the library keeps 32 event pairs per context: none may be reused before it completed)
+                            torch.cuda.synchronize()
+                    torch.cuda.synchronize()
+                clock = sampler.run(loop) if sampler else (loop(), None)[1]
                 ix.search_batch_device(Q.data_ptr(), NB, K, od.data_ptr(), ol.data_ptr(), on.data_ptr(), stream=st.cuda_stream)
                 torch.cuda.synchronize()
                 s1 = ix.stats()
             nb = s1.filter_batches - s0.filter_batches
             ms = (s1.filter_kernel_ns - s0.filter_kernel_ns) / 1e6 / nb if nb else None
             print(json.dumps({"dtype": dt, "rows": N, "ablate": abl, "prio": int(prio), "filter_kernel_ms": ms, "launches": int(nb),
-                              "survivors_per_query": round(s1.last_filter_candidates / NB, 1), "handed_over": int(s1.last_filter_fallback)}), flush=True)
+                              "survivors_per_query": round(s1.last_filter_candidates / NB, 1), "handed_over": int(s1.last_filter_fallback),
+                              "clock": clock}), flush=True)
         del ix, table
         torch.cuda.empty_cache()
 

@@ -14,6 +14,8 @@ ap.add_argument("--nq", type=int, default=1024)
 ap.add_argument("--ef", type=int, default=128)
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--dtype", default="f32")
+ap.add_argument("--tombstone", action="store_true", help="after the first measurement: remove ONE label and measure again (a tombstone sends the search to the HBM-frontier kernel without any filter)")
+ap.add_argument("--calibrate", action="store_true", help="one single-query FLAT scan (reads rows x row bytes exactly once: the PMC calibration)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 N, D = args.rows, args.dim
@@ -34,7 +36,11 @@ print(f"build {N}x{D}: {tb:.1f}s = {N/tb:.0f} inserts/s, threads={args.threads o
 f = vsa.Index("FLAT", D, "COSINE", initial_cap=N)
 f.add_batch(hx)
 _, Lf, _ = f.search_batch(Q, 10)
-for ef in (args.ef, 256):
+if args.calibrate:
+    for _ in range(2):
+        f.search(Q[0], 10)
+    print(f"calibration: flat_scan_kernel<1, ...> over {N} rows x {D * 4} B", flush=True)
+for ef in (args.ef,) + ((256,) if not args.calibrate else ()):
     h.search_batch(Q[:64], 10, ef=ef)
     t = time.time()
     reps = 5
@@ -46,6 +52,33 @@ for ef in (args.ef, 256):
     useful = (st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132)
     print(f"ef={ef}: {len(Q)/dt:.0f} QPS ({dt*1e3:.2f} ms per {len(Q)}-batch), recall@10={rec:.4f}, "
           f"n_eval/q={st.last_n_eval/len(Q):.0f} hops/q={st.last_n_hops/len(Q):.0f}, useful {useful/dt/1e9:.0f} GB/s", flush=True)
+if args.tombstone:
+    assert h.remove(N - 1) == 0
+    h.flush()
+    for ef in (args.ef, 256):
+        h.search_batch(Q[:64], 10, ef=ef)
+        t = time.time()
+        for _ in range(5):
+            Dh, Lh, Nh = h.search_batch(Q, 10, ef=ef)
+        dt = (time.time() - t) / 5
+        st = h.stats()
+        useful = (st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132)
+        print(f"one tombstone (HBM-frontier kernel, no filter) ef={ef}: {len(Q)/dt:.0f} QPS, n_eval/q={st.last_n_eval/len(Q):.0f}, useful {useful/dt/1e9:.0f} GB/s, "
+              f"visited mode {st.last_visited_mode}", flush=True)
+    # ... and with a 10 % allow-set on top (configs[4]'s shape): the filter's own cost
+    rng = np.random.default_rng(5)
+    bits = np.zeros((N + 63) // 64, np.uint64)
+    allowed = np.flatnonzero(rng.random(N) < 0.1)
+    np.bitwise_or.at(bits, allowed >> 6, np.uint64(1) << (allowed & 63).astype(np.uint64))
+    for ef in (256,):
+        h.search_batch(Q[:64], 10, ef=ef, allow=bits, allow_nbits=N)
+        t = time.time()
+        for _ in range(5):
+            Dh, Lh, Nh = h.search_batch(Q, 10, ef=ef, allow=bits, allow_nbits=N)
+        dt = (time.time() - t) / 5
+        st = h.stats()
+        useful = (st.last_n_eval * (D * 4 + 4) + st.last_n_hops * 132)
+        print(f"10 % allow-set ef={ef}: {len(Q)/dt:.0f} QPS, n_eval/q={st.last_n_eval/len(Q):.0f} hops/q={st.last_n_hops/len(Q):.0f}, useful {useful/dt/1e9:.0f} GB/s", flush=True)
 t = time.time()
 for i in range(50):
     h.search(Q[i], 10, ef=args.ef)

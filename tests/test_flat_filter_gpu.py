@@ -475,31 +475,15 @@ def test_k_up_to_1024_through_the_filter(vsa, oracle, metric):
         assert L[i].tolist() == ol.tolist() and D[i].view(np.uint32).tolist() == od.view(np.uint32).tolist()
 
 
-def test_four_fat_waves_kernel_gives_the_same_survivors():
-    """The experimental 256-row-tile kernel (four waves of 512 registers) lives in the -DVK_EXPERIMENTS build of the
-    library only (libvkindex_exp.so, VK_FILTER_FAT=1 read per launch there): behind the same gate it must give the same
-    answer and the same survivor counts as the wave-specialised kernel.  Runs in its own process with that library."""
-    import subprocess
-    import sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parent.parent
-    exp = root / "valkey-search_amd" / "libvkindex_exp.so"
-    if not exp.exists():
-        pytest.skip("libvkindex_exp.so not built (make -C valkey-search_amd/csrc experiments)")
-    r = subprocess.run([sys.executable, str(root / "tests" / "helpers" / "exp_fat_check.py")], cwd=root, capture_output=True, text=True,
-                       env=dict(os.environ, VKINDEX_LIB=str(exp)), timeout=600)
-    assert r.returncode == 0 and "fat kernel ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
-
-
 def test_experiment_switches_do_nothing_in_the_product_library(vsa):
-    """An environment variable must not be able to make a drop-in index return wrong neighbours: the ablation / timing /
-    fat-kernel switches of the experiments build are not compiled into libvkindex.so -- no such kernels in the binary, and
+    """An environment variable must not be able to make a drop-in index return wrong neighbours: the ablation / timing
+    switches of the experiments build are not compiled into libvkindex.so -- no such kernels in the binary, and
     with every one of them set the answer is the exact one."""
     import subprocess
     from pathlib import Path
     lib = Path(vsa.LIB_PATH)
     names = subprocess.run(["strings", str(lib)], capture_output=True, text=True).stdout
-    for needle in ("abl_kernel", "filter_fat_kernel", "VK_FILTER_ABLATE", "VK_GEMM_ABLATE", "VK_FILTER_TIMING", "VK_FAT_DBG", "VK_FILTER_FAT"):
+    for needle in ("abl_kernel", "VK_FILTER_ABLATE", "VK_GEMM_ABLATE", "VK_FILTER_TIMING"):
         assert needle not in names, needle
     rng = np.random.default_rng(77)
     n, dim = 60_000, 128
@@ -507,7 +491,7 @@ def test_experiment_switches_do_nothing_in_the_product_library(vsa):
     Q = _unit(rng.standard_normal((64, dim)).astype(np.float32))
     f, e = _pair(vsa, dim, "COSINE", x)
     want = e.search_batch(Q, 10)
-    with _Env(VK_FILTER_ABLATE=1, VK_GEMM_ABLATE=3, VK_FILTER_TIMING=1, VK_FILTER_FAT=1, VK_FAT_DBG=1, VK_FILTER_PRIO=21):
+    with _Env(VK_FILTER_ABLATE=1, VK_GEMM_ABLATE=3, VK_FILTER_TIMING=1, VK_FILTER_PRIO=21):
         f2, e2 = _pair(vsa, dim, "COSINE", x)                     # (even an index CREATED under them)
         _same(f.search_batch(Q, 10), want)
         _same(f2.search_batch(Q, 10), want)

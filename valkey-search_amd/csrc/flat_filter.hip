@@ -1283,265 +1283,6 @@ __device__ __forceinline__ void flat_filter_body(const FlatFilterArgs &a) {
   ring_flush(a, ring, lane);
 }
 
-#ifdef VK_EXPERIMENTS
-// ---- the filter, four fat waves (r03) ---------------------------------------------------------------------------------
-// The wave-specialised kernel above moves, per 128-row tile, as many B-operand bytes from L2 as row bytes from HBM (the
-// batch's 384 KB of f16 queries per tile), and its four multiplying waves read 96 KB of LDS per 64-k stage for 128 MFMAs:
-// over bf16 rows, where a stage is half the HBM time, the multiplying waves ARE the stage (PMC / cycle counters: MFMA
-// phase 2 450 clocks per stage for 1 024 clocks of MFMAs).  Both costs are per TILE AREA and halve with the tile's
-// height -- which needs the tile's 256 x 256 accumulators, half the CU's register file.  Here they are: four waves of
-// 512 registers (one per SIMD), wave (wr, wc) owning rows 128 wr .. and query tiles 4 wc .. of a 256-row tile -- sixteen
-// 32 x 32 accumulator tiles -- and every wave also doing a quarter of the producing:
-//   per 64-k stage and wave   64 MFMAs (4 K-steps x 16), operands from LDS: 4 A + 4 B fragments per K-step (half the
-//                             LDS bytes per MFMA of the 4 x 2 blocking above), fetched one K-step ahead
-//                             rows: 16 (bf16: 8) 16-byte loads, two stages ahead, converted to f16 into LDS one stage ahead
-//                             B: 8 loads (K-step `wave` of all eight query tiles), one stage ahead (a stage is twice as
-//                             long as above: an L2 round trip fits)
-// The producing is spread over the K-steps of the stage (stores of the next stage's rows behind K-steps 0 and 1, the
-// row loads behind K-step 2, B behind K-step 3), so the address path sees a trickle, not a burst per stage.
-// Inner-product space; L2 and the sample pass stay on the kernel above.
-constexpr int kFatRows = 256;
-constexpr int kFatThreads = 256;
-constexpr int kFatBStage = 8 * 4 * kWave;                      // 16-byte slots of one B stage
-constexpr uint32_t kFatABuf = kFatRows * kFAStride;            // halfs of one A stage
-template <bool kBf16> struct FatRows { f32x4v v[16]; };        // 256 rows x 64 k / 256 threads
-template <> struct FatRows<true> { u32x4v v[8]; };
-struct FatB { u32x4v v[8]; };
-
-template <bool kBf16>
-__device__ __forceinline__ void fat_rows_load(FatRows<kBf16> &s, const FlatFilterArgs &a, uint32_t row0, uint32_t st, uint32_t voff) {
-  constexpr size_t esz = kBf16 ? 2 : 4;
-  const __amdgpu_buffer_rsrc_t r = ws_rsrc(static_cast<const char *>(a.rows) + ((size_t)row0 * a.row_stride_f + (size_t)st * kFStageK) * esz);
-  if constexpr (kBf16) {   // piece idx = t + 256 u: row idx / 8 = t / 8 + 32 u, 8-element column t % 8
-    const uint32_t step = 32u * a.row_stride_f * (uint32_t)esz;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s.v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(u * step), 2);
-  } else {                 // row idx / 16 = t / 16 + 16 u, 4-element column t % 16
-    const uint32_t step = 16u * a.row_stride_f * (uint32_t)esz;
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-      s.v[u] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)(u * step), 2));
-  }
-}
-// pieces [kU0, kU1) of a stage -> f16 in LDS (see ws_rows_store)
-template <bool kBf16, int kU0, int kU1>
-__device__ __forceinline__ void fat_rows_store(_Float16 *buf, uint32_t t, const FatRows<kBf16> &s) {
-  if constexpr (kBf16) {
-    _Float16 *dst = buf + (t >> 3) * kFAStride + (t & 7) * 8;
-#pragma unroll
-    for (int u = kU0; u < kU1; ++u) {
-      f16x8 h;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        h[2 * w] = (_Float16)__uint_as_float(s.v[u][w] << 16);
-        h[2 * w + 1] = (_Float16)__uint_as_float(s.v[u][w] & 0xFFFF0000u);
-      }
-      *reinterpret_cast<f16x8 *>(dst + u * 32 * kFAStride) = h;
-    }
-  } else {
-    _Float16 *dst = buf + (t >> 4) * kFAStride + (t & 15) * 4;
-#pragma unroll
-    for (int u = kU0; u < kU1; ++u) {
-      f16x4 h;
-      h[0] = (_Float16)s.v[u][0];
-      h[1] = (_Float16)s.v[u][1];
-      h[2] = (_Float16)s.v[u][2];
-      h[3] = (_Float16)s.v[u][3];
-      *reinterpret_cast<f16x4 *>(dst + u * 16 * kFAStride) = h;
-    }
-  }
-}
-// wave w fetches K-step w of the stage for all eight query tiles
-__device__ __forceinline__ void fat_b_load(FatB &b, const FlatFilterArgs &a, uint32_t w, uint32_t st, uint32_t lane) {
-  const uint32_t ks_n = a.row_stride_f / 16;
-  const __amdgpu_buffer_rsrc_t r = ws_rsrc(a.q16);
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const uint32_t jt = (uint32_t)u < a.nqt ? (uint32_t)u : a.nqt - 1;
-    b.v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(lane * 16), (int)(((jt * ks_n + st * 4 + w) * kWave) * 16), 0);
-  }
-}
-__device__ __forceinline__ void fat_b_store(uint4 *slot, uint32_t w, uint32_t lane, const FatB &b) {
-  u32x4v *dst = reinterpret_cast<u32x4v *>(slot) + w * kWave + lane;      // [query tile 8][K-step 4][lane 64]
-#pragma unroll
-  for (int u = 0; u < 8; ++u) dst[u * 4 * kWave] = b.v[u];
-}
-
-template <bool kBf16, bool kDbg = false>
-__global__ __launch_bounds__(kFatThreads, 1) void flat_filter_fat_kernel(FlatFilterArgs a) {
-  unsigned long long dbg_bar = 0, dbg_gate = 0, dbg_t0 = 0, dbg_start = 0;
-  if constexpr (kDbg) dbg_start = __builtin_readcyclecounter();
-  extern __shared__ _Float16 lds_a[];                                         // [2][256 rows][72 halfs]
-  uint4 *lds_b = reinterpret_cast<uint4 *>(lds_a + 2 * kFatABuf);             // [2][kFatBStage]
-  uint32_t *lds_ring = reinterpret_cast<uint32_t *>(lds_b + 2 * kFatBStage);  // [4 waves][3][64]
-  volatile __attribute__((address_space(3))) uint32_t *lds_stop =
-      (volatile __attribute__((address_space(3))) uint32_t *)(lds_ring + 4 * kRingWords);   // [2], as in the kernel above
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t wr = wave >> 1, wc = wave & 1, li = lane & 31, g = lane >> 5;
-  const uint32_t stages = a.row_stride_f / kFStageK;
-  const uint32_t n_tiles = a.n_tiles;                                         // tiles of 256 rows
-  const uint32_t t_base = n_tiles / gridDim.x, t_rem = n_tiles % gridDim.x;
-  const uint32_t first_tile = blockIdx.x * t_base + (blockIdx.x < t_rem ? blockIdx.x : t_rem);
-  const uint32_t my_tiles = t_base + (blockIdx.x < t_rem ? 1u : 0u);
-  if (my_tiles == 0) return;
-  const uint32_t total = my_tiles * stages;
-  if (tid < 2) lds_stop[tid] = 0;
-
-  // gates of the wave's four query tiles
-  GateCol<false> col[4];
-#pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    const bool have = wc * 4 + qt < a.nqt;
-    const uint32_t jc = have ? (wc * 4 + qt) * 32 + li : 0u;
-    const float4 co = a.qcoef[jc];
-    col[qt].c1 = co.y;
-    col[qt].c0 = co.z;
-    col[qt].bound = (!have || co.w != 0.f) ? __builtin_inff() : a.qbound[jc];
-  }
-  SurvivorRing ring;
-  ring.ent = lds_ring + wave * kRingWords;
-  ring.cnt = 0;
-
-  // producer side: stream positions of the next row load (three stages ahead of the multiply) and the next B load (two)
-  const uint32_t voff = kBf16 ? ((tid >> 3) * a.row_stride_f + (tid & 7) * 8) * 2u : ((tid >> 4) * a.row_stride_f + (tid & 15) * 4) * 4u;
-  FPos ld{first_tile * kFatRows, 0, total, (uint32_t)kFatRows}, lb = ld;
-  FatRows<kBf16> x0, x1;
-  FatB bv;
-  fat_rows_load<kBf16>(x0, a, ld.row0, ld.st, voff);
-  fpos_advance(ld, stages);
-  fat_b_load(bv, a, wave, lb.st, lane);
-  fpos_advance(lb, stages);
-  fat_rows_load<kBf16>(x1, a, ld.row0, ld.st, voff);
-  fpos_advance(ld, stages);
-  fat_rows_store<kBf16, 0, (kBf16 ? 8 : 16)>(lds_a, tid, x0);
-  fat_b_store(lds_b, wave, lane, bv);
-  fat_rows_load<kBf16>(x0, a, ld.row0, ld.st, voff);
-  fpos_advance(ld, stages);
-  fat_b_load(bv, a, wave, lb.st, lane);
-  fpos_advance(lb, stages);
-
-  f32x16 acc[4][4];                                                           // [query tile][row tile]
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  uint32_t tile_row0 = first_tile * kFatRows, st_c = 0, tile_c = 0, par = 0;
-  bool stop = false;
-  const __amdgpu_buffer_rsrc_t tile_rsrc = ws_rsrc(a.tile_norm);
-  uint32_t norm_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / 128u + wr) * 4u), 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-#define VK_FAT_FRAGS(FA, FB, KK)                                                                                    \
-  _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                  \
-    FA[rt] = *reinterpret_cast<const f16x8 *>(ab + rt * 32 * kFAStride + (KK) * 16);                                \
-  _Pragma("unroll") for (int qt = 0; qt < 4; ++qt) FB[qt] = bb[(qt * 4 + (KK)) * kWave];
-#define VK_FAT_MM(FA, FB)                                                                                           \
-  _Pragma("unroll") for (int qt = 0; qt < 4; ++qt)                                                                  \
-    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                \
-      acc[qt][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB[qt], acc[qt][rt], 0, 0, 0);
-  // (first K-step of a tile: the accumulators start from the constant 0 instead of being cleared)
-#define VK_FAT_MMZ(FA, FB)                                                                                          \
-  _Pragma("unroll") for (int qt = 0; qt < 4; ++qt)                                                                  \
-    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                \
-      acc[qt][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[rt], FB[qt], zero, 0, 0, 0);
-  // one stage: XS = the register set that holds the rows of stage s+1 (stored now, then reloaded with stage s+3)
-#define VK_FAT_STAGE(XS, MM0)                                                                                       \
-  {                                                                                                                 \
-    const _Float16 *ab = lds_a + par * kFatABuf + (wr * 128 + li) * kFAStride + g * 8;                              \
-    const f16x8 *bb = reinterpret_cast<const f16x8 *>(lds_b + par * kFatBStage + (wc * 4) * 4 * kWave) + lane;     \
-    _Float16 *an = lds_a + (par ^ 1) * kFatABuf;                                                                    \
-    if (tid == 0 && st_c == 0 && a.cancel && (tile_c % kCancelPollTiles) == 0) {                                        \
-      if (__hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) lds_stop[tile_c & 1] = 1;  \
-    }                                                                                                               \
-    f16x8 fa0[4], fb0[4], fa1[4], fb1[4];                                                                           \
-    VK_FAT_FRAGS(fa0, fb0, 0)                                                                                       \
-    VK_FAT_FRAGS(fa1, fb1, 1)                                                                                       \
-    MM0(fa0, fb0)                                                                                                   \
-    fat_rows_store<kBf16, 0, (kBf16 ? 4 : 8)>(an, tid, XS);                                                         \
-    VK_FAT_FRAGS(fa0, fb0, 2)                                                                                       \
-    VK_FAT_MM(fa1, fb1)                                                                                             \
-    fat_rows_store<kBf16, (kBf16 ? 4 : 8), (kBf16 ? 8 : 16)>(an, tid, XS);                                          \
-    VK_FAT_FRAGS(fa1, fb1, 3)                                                                                       \
-    VK_FAT_MM(fa0, fb0)                                                                                             \
-    fat_rows_load<kBf16>(XS, a, ld.row0, ld.st, voff);                                                              \
-    fpos_advance(ld, stages);                                                                                       \
-    VK_FAT_MM(fa1, fb1)                                                                                             \
-    fat_b_store(lds_b + (par ^ 1) * kFatBStage, wave, lane, bv);                                                    \
-    fat_b_load(bv, a, wave, lb.st, lane);                                                                           \
-    fpos_advance(lb, stages);                                                                                       \
-    /* the order the stage is ISSUED in (left to itself the compiler fetches every fragment right in front of the    */ \
-    /* MFMAs that need it and waits for it there): both first K-steps' fragments, then one MFMA at a time with a     */ \
-    /* piece of the producing -- or a fragment read of the K-step after next -- in its shadow                         */ \
-    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);                                                             \
-    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {   /* K-steps 0 and 1: half the row stores, then 8 fragment reads */ \
-      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                          \
-        __builtin_amdgcn_sched_group_barrier(0x002, kBf16 ? 8 : 2, 0);                                              \
-        if (!kBf16 || (i_ & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                  \
-      }                                                                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                          \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                          \
-      }                                                                                                             \
-    }                                                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {  /* K-step 2: the row loads of stage s+3                     */ \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                            \
-      if (!kBf16 || (i_ & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                    \
-    }                                                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {   /* K-step 3: B of stage s+1 into LDS, B of stage s+2 requested */ \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                            \
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                            \
-    }                                                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                              \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                            \
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                            \
-    }                                                                                                               \
-    st_c += 1;                                                                                                      \
-    par ^= 1;                                                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
-    if constexpr (kDbg) dbg_t0 = __builtin_readcyclecounter();                                                      \
-    __builtin_amdgcn_s_barrier();                                                                                   \
-    if constexpr (kDbg) dbg_bar += __builtin_readcyclecounter() - dbg_t0;                                           \
-    asm volatile("" ::: "memory");                                                                                  \
-  }
-  // Tile by tile, the stages of a tile in pairs (the stage count is even: the launcher sends other row lengths to the
-  // kernel above).  The nesting matters to the compiler: with the gate as a conditional block of ONE flat loop over the
-  // stages it moved all 256 accumulators out of and back into the accumulation registers around every stage.
-  for (uint32_t tl = 0; tl < my_tiles && !stop; ++tl) {
-    VK_FAT_STAGE(x1, VK_FAT_MMZ)
-    VK_FAT_STAGE(x0, VK_FAT_MM)
-    for (uint32_t sp = 2; sp < stages; sp += 2) {
-      VK_FAT_STAGE(x1, VK_FAT_MM)
-      VK_FAT_STAGE(x0, VK_FAT_MM)
-    }
-    if constexpr (kDbg) dbg_t0 = __builtin_readcyclecounter();
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt)
-      filter_gate<4, false>(a, acc[qt], gate_thr<false>(col[qt], norm_bits), tile_row0 + wr * 128, wc * 4 + qt, li, g, ring, lane);
-    if constexpr (kDbg) dbg_gate += __builtin_readcyclecounter() - dbg_t0;
-    tile_row0 += kFatRows;
-    norm_bits = __builtin_amdgcn_raw_buffer_load_b32(tile_rsrc, 0, (int)((tile_row0 / 128u + wr) * 4u), 0);
-    uint32_t sv_;   // (cancellation seen during this tile; written before the tile's last barrier, see the kernel above)
-    asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(sv_) : "v"((uint32_t)(uintptr_t)(lds_stop + (tile_c & 1))) : "memory");
-    stop = sv_ != 0;
-    st_c = 0;
-    tile_c += 1;
-  }
-#undef VK_FAT_STAGE
-#undef VK_FAT_MM
-#undef VK_FAT_MMZ
-#undef VK_FAT_FRAGS
-  ring_flush(a, ring, lane);
-  if constexpr (kDbg) {
-    if (lane == 0 && a.dbg) {
-      atomicAdd(&a.dbg[0], dbg_bar);
-      atomicAdd(&a.dbg[1], dbg_gate);
-      atomicAdd(&a.dbg[2], (unsigned long long)(__builtin_readcyclecounter() - dbg_start));
-    }
-  }
-}
-
-#endif  // VK_EXPERIMENTS (the four-fat-waves kernel)
 
 template <bool kBf16, bool kL2, bool kTiming, int kAbl = 0>
 __global__ __launch_bounds__(kWsThreads, 1) void flat_filter_kernel(FlatFilterArgs a) {
@@ -1608,34 +1349,8 @@ hipError_t launch_flat_qprep(const FlatFilterArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-#ifdef VK_EXPERIMENTS
-size_t flat_filter_fat_lds_bytes() {
-  return (size_t)2 * kFatABuf * sizeof(_Float16) + (size_t)2 * kFatBStage * 16 + (size_t)4 * kRingWords * 4 + 16;
-}
-// the four-fat-waves kernel serves the final pass in the inner-product space (experiments build, VK_FILTER_FAT=1)
-bool flat_filter_fat_enabled(const FlatFilterArgs &a) {
-  // (measured slower than the wave-specialised kernel -- 10M x 768, B = 256, same lease: f32 6.1-7.1 ms against
-  // 5.3, bf16 4.50 against 4.55 per step; its cycle counters, VK_FAT_DBG=1: a stage takes 2.1-2.7x its MFMA time)
-  return a.fat && a.mode == 0 && !a.l2 && !a.timing && !a.qbf16 && (a.row_stride_f / kFStageK) % 2 == 0;
-}
-#endif
-
 hipError_t launch_flat_filter(const FlatFilterArgs &a, uint32_t blocks, hipStream_t s) {
   if (a.nqt == 0 || a.nqt > 8 || blocks == 0 || a.n_tiles == 0 || (a.mode == 1 && a.sample_gap == 0)) return hipErrorInvalidValue;
-#ifdef VK_EXPERIMENTS
-  if (flat_filter_fat_enabled(a)) {
-    const size_t lds = flat_filter_fat_lds_bytes();
-    const void *fn = a.bf16 ? reinterpret_cast<const void *>(&flat_filter_fat_kernel<true>) : reinterpret_cast<const void *>(&flat_filter_fat_kernel<false>);
-    if (a.dbg) fn = a.bf16 ? reinterpret_cast<const void *>(&flat_filter_fat_kernel<true, true>) : reinterpret_cast<const void *>(&flat_filter_fat_kernel<false, true>);
-    hipError_t e = ensure_max_lds(fn);
-    if (e != hipSuccess) return e;
-    FlatFilterArgs args = a;
-    args.n_tiles = (a.n_rows + kFatRows - 1) / kFatRows;
-    void *params[] = {&args};
-    const uint32_t nb = blocks < args.n_tiles ? blocks : args.n_tiles;
-    return hipLaunchKernel(fn, dim3(nb), dim3(kFatThreads), params, lds, s);
-  }
-#endif
   size_t lds = flat_filter_lds_bytes();
   const void *fn = a.bf16 ? (a.l2 ? reinterpret_cast<const void *>(&flat_filter_kernel<true, true, false>)
                                   : reinterpret_cast<const void *>(&flat_filter_kernel<true, false, false>))

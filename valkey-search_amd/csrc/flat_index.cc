@@ -982,8 +982,7 @@ class FlatIndex final : public Index {
     // (the experiments build of the library only -- scripts/filter_ablate.py, scripts/build_experiments.sh: kernels whose
     //  ANSWERS ARE INVALID, selected through the environment per launch; none of this exists in libvkindex.so)
     const bool timing = getenv("VK_FILTER_TIMING") && atoi(getenv("VK_FILTER_TIMING")) != 0;
-    const bool filter_experiment = getenv("VK_FILTER_TIMING") || (getenv("VK_FILTER_ABLATE") && !getenv("VK_FILTER_ABLATE_DMA")) || getenv("VK_FAT_DBG") ||
-                                   (getenv("VK_FILTER_FAT") && atoi(getenv("VK_FILTER_FAT")) != 0);
+    const bool filter_experiment = getenv("VK_FILTER_TIMING") || (getenv("VK_FILTER_ABLATE") && !getenv("VK_FILTER_ABLATE_DMA"));
 #else
     constexpr bool filter_experiment = false;
 #endif
@@ -1076,9 +1075,7 @@ class FlatIndex final : public Index {
       fm.mode = 0;
       fm.n_tiles = (uint32_t)((count + 127) / 128);
 #ifdef VK_EXPERIMENTS
-      const bool fat_dbg = getenv("VK_FAT_DBG") != nullptr;   // cycle counters of the four-fat-waves kernel
-      fm.timing = timing && !l2() && !fat_dbg;
-      fm.fat = (getenv("VK_FILTER_FAT") && atoi(getenv("VK_FILTER_FAT")) != 0) ? 1u : 0u;
+      fm.timing = timing && !l2();
       fm.prio = getenv("VK_FILTER_PRIO") ? (uint32_t)atoi(getenv("VK_FILTER_PRIO")) : 0u;
       if (!l2() && getenv("VK_FILTER_ABLATE") && (!fm.qbf16 || fm.dma)) {
         fm.ablate_on = 1;
@@ -1088,7 +1085,7 @@ class FlatIndex final : public Index {
       fm.dump_thr = g_exp_dump.thr;
       fm.dump_rows = g_exp_dump.rows;
       fm.dump_ld = g_exp_dump.ld;
-      if (fat_dbg || fm.timing) {   // phase timing experiments: up to nine counters
+      if (fm.timing) {   // phase timing experiment: nine counters
         VK_TRY(ctx->d_idx.ensure(128));
         VK_HIP_TRY(hipMemsetAsync(ctx->d_idx.p, 0, 128, s));
         fm.dbg = ctx->d_idx.as<unsigned long long>();
@@ -1146,13 +1143,6 @@ class FlatIndex final : public Index {
                                       hipMemcpyDeviceToDevice, s));
         VK_HIP_TRY(hipMemcpyAsync(g_exp_dump.qstate + (size_t)4 * g_exp_dump.ld, f.qbound, nq * 4, hipMemcpyDeviceToDevice, s));
         VK_HIP_TRY(hipMemcpyAsync(g_exp_dump.qstate + (size_t)5 * g_exp_dump.ld, f.qwit, nq * 4, hipMemcpyDeviceToDevice, s));
-      }
-      if (fat_dbg) {
-        unsigned long long h[3];
-        VK_HIP_TRY(hipStreamSynchronize(s));
-        VK_HIP_TRY(hipMemcpy(h, ctx->d_idx.p, sizeof h, hipMemcpyDeviceToHost));
-        const double w = (double)std::min<uint64_t>(filter_blocks_, (count + 255) / 256) * 4;
-        fprintf(stderr, "[vk] fat filter, ticks per wave: total %.0f  barrier %.0f  gate %.0f\n", h[2] / w, h[0] / w, h[1] / w);
       }
       if (fm.timing) {
         unsigned long long h[9];

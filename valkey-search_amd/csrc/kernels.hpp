@@ -186,7 +186,6 @@ struct FlatFilterArgs {
   unsigned long long *dbg;    // timing: [9] cycles per phase, summed over the waves (see the kernel)
   uint32_t prio;              // wave priorities of the three roles, 2 bits each (rows | queries << 2 | consumers << 4)
   uint32_t ablate_on, ablate; // VK_FILTER_ABLATE: pieces of the pipeline switched off, see flat_filter_body
-  uint32_t fat;               // VK_FILTER_FAT=1: the four-fat-waves kernel (256-row tiles)
   // margin audit (tests/helpers/exp_margin_check.py through vk_exp_filter_dump): the final pass writes what its gate saw for the
   // first dump_rows rows -- the approximate score of every (row, query) pair and the threshold of every (tile, query) --
   // so that a test can hold them against exact arithmetic.  Answers stay valid.
