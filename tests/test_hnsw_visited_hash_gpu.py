@@ -179,3 +179,53 @@ def test_a_search_that_outgrows_the_lds_set_spills_into_memory(vsa, oracle):
     g.set_option("hnsw-visited-mode", 3)     # the default rule: 256 x 64 is beyond both LDS sets' budgets -> the table in memory
     st = _check(g, o, Q, 10, 256)
     assert st.last_frontier_redo == 0
+
+
+@pytest.mark.parametrize("mode,log2", [(0, None), (4, None), (0, 7)])
+def test_a_few_tombstones_keep_the_frontier_on_chip(vsa, oracle, mode, log2):
+    """r06: one deleted key used to send EVERY search of an index to the HBM-frontier kernel (0.58 of the HBM peak against 0.74
+    at 1.25M x 768, no filter involved).  Up to 1 / 16 of the nodes tombstoned and no filter: the batch takes the launch with the
+    frontier in LDS and the visited set on chip; a query that outgrows either is re-run by the launch nothing can overflow
+    (log2 = 7: nearly all of them).  Tombstone semantics (hnswalg.h:373-388, :515-524) are the shared kernel body's: ids,
+    distance bits and work counters are the oracle's on the same graph; beyond 1 / 16, with the option off, or with a filter
+    the HBM frontier is back."""
+    rng = np.random.default_rng(4100 + mode)
+    n, dim, M = 6000, 48, 8
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    env = {"VK_HNSW_VISITED_HASH": 2, "VK_HNSW_VISITED_MODE": mode}
+    if log2:
+        env["VK_HNSW_HASH_LOG2"] = log2
+    with _Env(**env):
+        g = vsa.Index("HNSW", dim, "L2", initial_cap=n, m=M, ef_construction=40, build_threads=1)
+    g.add_batch(x)
+    dead = rng.choice(n, n // 100, replace=False)
+    for lab in dead:
+        assert g.remove(int(lab)) == 0
+    g.flush()
+    o = oracle.HNSW.from_product_index(g.save_raw, dim, "L2", M, ef_construction=40)
+    assert o.deleted_count == len(dead)
+    Q = rng.standard_normal((70, dim)).astype(np.float32)
+    for ef, k in ((64, 10), (300, 40)):
+        st = _check(g, o, Q, k, ef)
+        assert st.last_visited_mode != 0, "a few tombstones: the optimistic launch"
+        assert (st.last_frontier_redo > 0) == (log2 == 7)
+        L = g.search_batch(Q, k, ef=ef)[1]
+        assert not set(L.ravel().tolist()) & set(int(v) for v in dead)
+    # the option off: the HBM frontier, same answers
+    g.set_option("hnsw-optimistic-tombstones", 0)
+    assert _check(g, o, Q, 10, 64).last_visited_mode == 0
+    g.set_option("hnsw-optimistic-tombstones", 1)
+    # a filter on top: HBM frontier (the frontier grows like 1 / selectivity)
+    bits = oracle.allow_bitmap(np.flatnonzero(rng.random(n) < 0.3), n)
+    D, L, N = g.search_batch(Q[:20], 10, ef=64, allow=bits, allow_nbits=n)
+    assert g.stats().last_visited_mode == 0
+    for i in range(20):
+        od, ol = o.search(Q[i], 10, ef=64, allow=bits, allow_nbits=n)
+        assert L[i, :N[i]].tolist() == ol.tolist() and D[i, :N[i]].view(np.uint32).tolist() == od.view(np.uint32).tolist()
+    # more than 1 / 16 of the nodes deleted: HBM frontier again
+    more = [int(v) for v in rng.permutation(n) if v not in set(dead.tolist())][: n // 12]
+    for lab in more:
+        assert g.remove(lab) == 0
+    g.flush()
+    o2 = oracle.HNSW.from_product_index(g.save_raw, dim, "L2", M, ef_construction=40)
+    assert _check(g, o2, Q, 10, 64).last_visited_mode == 0

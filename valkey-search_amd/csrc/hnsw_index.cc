@@ -728,7 +728,25 @@ class HnswIndex final : public Index {
     tab_ = nullptr;          // (set by search() around its launch() calls only)
     tab_nbits_ = nullptr;
     // (a result list beyond 2048 entries takes the LDS the frontier would need: the frontier moves to HBM then, too)
-    const bool gpool = d_allow != nullptr || a.allow_tab != nullptr || pub_.deleted > 0 || ef > 2048;
+    //
+    // A FEW tombstones (up to 1 / 16 of the nodes) and no filter: the frontier grows by about their share, and what keeps the
+    // result list from filling is rare -- such a batch takes the optimistic launch below (frontier in LDS, visited set on chip)
+    // like an index without deletions; a query whose LDS frontier does fill up is given up there and answered by the launch
+    // with the graph-sized frontier (the redo list every hash-set launch carries), so nothing is ever truncated.  One
+    // deleted key in 1.25M used to cost every search of the index 21 % (the HBM-frontier kernel without any filter: 0.58 of
+    // the HBM peak against 0.74, profiles/r06_hnsw_gpool_probe.log).  Only where that launch serves the batch at all (below:
+    // a batch that fills the device, a graph large enough for the hash sets); small batches keep the HBM frontier.
+    const bool filtered = d_allow != nullptr || a.allow_tab != nullptr;
+    auto hash_set_log2 = [&]() -> uint32_t {   // the table of the hash-set launch, 0 = that launch does not serve this batch
+      if (visited_hash_ == 0 || !(visited_hash_ == 2 || !hnsw_uses_latency_variant(a))) return 0;
+      uint32_t lg = 14;      // (a search evaluates about 25 x ef nodes on the graphs measured: 64 x ef words, at least 64 KB)
+      while (lg < 17 && ((uint64_t)1 << lg) < hash_per_ef_ * ef) ++lg;
+      if (hash_log2_forced_) lg = hash_log2_forced_;
+      return visited_hash_ == 2 || ((uint64_t)8 << lg) <= (uint64_t)a.bitmap_words * 4 ? lg : 0;   // (at most half the bitmap's size)
+    };
+    const bool few_tombstones = pub_.deleted > 0 && !filtered && ef <= 2048 && (uint64_t)pub_.deleted * 16 <= count &&
+                                opt_.get(kOptHnswOptimisticTombstones) != 0 && hash_set_log2() != 0;
+    const bool gpool = filtered || (pub_.deleted > 0 && !few_tombstones) || ef > 2048;
     a.gpool_level = gpool ? 1 : 0;
     if (gpool)   // (a multiple of 128: the kernel keeps one minimum per 64 entries in the LDS words of the pool)
       a.cand_cap = (uint32_t)std::min<uint64_t>(gpool_cap(), (std::max<uint64_t>(a.cand_cap, count) + 127) & ~(uint64_t)127);
@@ -752,13 +770,7 @@ class HnswIndex final : public Index {
     const uint64_t wpb = (uint64_t)hnsw_waves_per_block(a);
     uint64_t blocks = std::min<uint64_t>((nq + wpb - 1) / wpb, (uint64_t)max_blocks);
     const uint64_t bm_bytes = (uint64_t)a.bitmap_words * 4;
-    uint32_t hash_log2 = 0;
-    if (!gpool && visited_hash_ != 0 && (visited_hash_ == 2 || !hnsw_uses_latency_variant(a))) {
-      uint32_t lg = 14;      // (a search evaluates about 25 x ef nodes on the graphs measured: 64 x ef words, at least 64 KB)
-      while (lg < 17 && ((uint64_t)1 << lg) < hash_per_ef_ * ef) ++lg;
-      if (hash_log2_forced_) lg = hash_log2_forced_;
-      if (visited_hash_ == 2 || ((uint64_t)8 << lg) <= bm_bytes) hash_log2 = lg;   // (at most half the bitmap's size)
-    }
+    const uint32_t hash_log2 = gpool ? 0 : hash_set_log2();
     HnswSearchArgs h{};
     uint64_t blocks_h = 0, wpb_h = wpb;
     if (hash_log2) {

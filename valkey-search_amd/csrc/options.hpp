@@ -41,7 +41,7 @@ enum OptId : uint32_t {
   kOptGemmLockstep, kOptGemmPrepassRows, kOptGemmContig, kOptScanMinNrp, kOptUploadParallel,
   // ---- HNSW ----------------------------------------------------------------------------------------------------------------
   kOptHnswStageAdds, kOptHnswStageMax,
-  kOptHnswDeviceBuild, kOptHnswBuildBatch, kOptHnswBuildMinGraph, kOptHnswBuildMinBatch, kOptHnswBuildFrac,
+  kOptHnswOptimisticTombstones, kOptHnswDeviceBuild, kOptHnswBuildBatch, kOptHnswBuildMinGraph, kOptHnswBuildMinBatch, kOptHnswBuildFrac,
   kOptHnswBuildVerbose, kOptHnswPoolFloor, kOptHnswGpoolCap, kOptHnswVisitedHash, kOptHnswHashPerEf, kOptHnswHashLog2, kOptHnswVisitedMode, kOptHnswLdsWork, kOptHnswLdsWorkBig,
   kOptHnswPoolBytes, kOptHnswVisitedBytes, kOptHnswRedoBytes,
   // ---- sharded index ---------------------------------------------------------------------------------------------------
@@ -91,6 +91,7 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"upload-parallel", "VK_UPLOAD_PARALLEL", 1, 0, 1},
       {"hnsw-stage-adds", "VK_HNSW_STAGE_ADDS", 1, 0, 1},                         // single vk_index_add calls of new labels are staged and linked in bulk
       {"hnsw-stage-max", "VK_HNSW_STAGE_MAX", 262144, 1, 1u << 26},               // ... at most this many rows wait (the writer that fills it links them)
+      {"hnsw-optimistic-tombstones", "VK_HNSW_OPTIMISTIC_TOMBSTONES", 1, 0, 1},     // a few tombstones (<= 1/16 of the nodes), no filter: the LDS-frontier launch + re-run of what outgrows it
       {"hnsw-device-build", "VK_HNSW_DEVICE_BUILD", 1, 0, 1},
       {"hnsw-build-batch", "VK_HNSW_BUILD_BATCH", 8192, 1, 1u << 20},
       {"hnsw-build-min-graph", "VK_HNSW_BUILD_MIN_GRAPH", 16384, 1, kMax},
