@@ -803,8 +803,8 @@ def sharded_hybrid_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows
       shared_tags_cold   16 tags over 4096 queries, a write phase before every step (epoch bump): all 16 filters are rebuilt
                          from their 10 %-of-N id lists inside the step; each query looks its predicate up
       shared_tags_warm   the same without the write phase: 4096 cache hits
-      distinct_per_query 1024 queries, each with a predicate nobody shares (tag_a OR tag_b, 1024 distinct pairs): one
-                         vk_filter_combine of two cached terms per query inside the step
+      distinct_per_query 1024 queries, each with a predicate nobody shares (tag_a OR tag_b, 1024 distinct pairs): the step's
+                         predicates combined from cached terms in ONE vk_filter_combine_batch call inside the step
     Reported per step: QPS, recall@10 against the exact filtered FLAT answer per query, the layer-0 work counters, the useful
     bytes they imply and their fraction of the HBM peak (through the host entry point: query upload and result copy-out are
     inside), and -- a sample -- the CPU oracle searching the SAME graphs with the SAME bitmaps (ids compared, timed)."""
@@ -907,7 +907,7 @@ def sharded_hybrid_leg(args, flat_ix, host_rows, A, device, ws, devs, total_rows
 
     def step_distinct():
         t0 = time.perf_counter()
-        fl = [h.combine_filters(terms[a], terms[b], "or") for a, b in pairs]
+        fl = h.combine_filters_batch([(terms[a], terms[b]) for a, b in pairs], "or")      # (one launch for the step's 1024 predicates)
         t_filters[0] += time.perf_counter() - t0
         n_built[0] += nd
         last["out"] = h.search_batch_filter_handles(hq[:nd], K, fl, ef=ef_h)

@@ -358,6 +358,10 @@ typedef struct vk_filter vk_filter;
 int vk_filter_create(vk_index *ix, uint64_t nbits, const uint64_t *labels, uint64_t n_labels, const uint64_t *runs,
                      uint64_t n_runs, const uint64_t *base_bits, vk_filter **out);
 int vk_filter_combine(vk_index *ix, const vk_filter *a, const vk_filter *b, uint32_t op, vk_filter **out);
+/* ... and n of them at once (a batch of requests each with its own composed predicate): out[i] = a[i] ops[i] b[i], one launch
+ * and one wait per device instead of n (n <= 65535; all or nothing: on an error no out[i] is set). */
+int vk_filter_combine_batch(vk_index *ix, const vk_filter *const *a, const vk_filter *const *b, const uint32_t *ops, uint64_t n,
+                            vk_filter **out);
 void vk_filter_retain(vk_filter *f);
 void vk_filter_release(vk_filter *f);
 /* nbits, and the number of allowed labels (counted on the device: what query::UsePreFiltering, planner.cc:21-45, wants as

@@ -127,6 +127,30 @@ hipError_t launch_filter_combine(uint64_t *dst, const uint64_t *a, const uint64_
   });
   return hipSuccess;
 }
+hipError_t launch_filter_combine_batch(const uint64_t *d_items, uint32_t n, uint64_t words, unsigned long long *d_counts, hipStream_t s) {
+  std::vector<hipv::Access> touched = {{d_items, (size_t)n * 32, "items"}, {d_counts, (size_t)n * 8, "counts"}};
+  hipv::launch(s, "filter_combine_batch_kernel", touched, [=] {
+    for (uint32_t i = 0; i < n; ++i) {
+      uint64_t *dst = reinterpret_cast<uint64_t *>(d_items[4 * i]);
+      const uint64_t *a = reinterpret_cast<const uint64_t *>(d_items[4 * i + 1]), *b = reinterpret_cast<const uint64_t *>(d_items[4 * i + 2]);
+      const uint64_t op = d_items[4 * i + 3];
+      // (the operands named inside the table are checked here, where they are known: each must lie on this stream's device)
+      const int dev = hipv::stream_device(s);
+      if (hipv::memory_device(dst, (words + 1) * 8) != dev || hipv::memory_device(a, words * 8) != dev || hipv::memory_device(b, words * 8) != dev) {
+        fprintf(stderr, "VIOLATION filter_combine_batch_kernel: item %u names memory of another device\n", i);
+        abort();
+      }
+      unsigned long long c = 0;
+      for (uint64_t w = 0; w < words; ++w) {
+        dst[w] = op == 0 ? (a[w] & b[w]) : op == 1 ? (a[w] | b[w]) : (a[w] & ~b[w]);
+        c += (unsigned long long)__builtin_popcountll(dst[w]);
+      }
+      dst[words] = 0;
+      d_counts[i] += c;
+    }
+  });
+  return hipSuccess;
+}
 }  // namespace vk
 
 // ---- a fake shard ----------------------------------------------------------------------------------------------------------
@@ -513,6 +537,20 @@ void run_world(const std::vector<int> &devices, bool hnsw, bool threads) {
       for (uint64_t i = 0; i < fc->words(); ++i) { CHECK(bc[i] == (ba[i] | bb[i]), "combine word %llu", (unsigned long long)i); cnt += __builtin_popcountll(bc[i]); }
       CHECK(fc->allowed() == cnt && fa->allowed() == ids.size(), "allowed() counts");
       for (int d : devices) CHECK(fc->bits_on(d) != nullptr && hipv::memory_device(fc->bits_on(d), fc->words() * 8) == d, "a copy on device %d", d);
+      {   // a batch of combinations in one launch per device: the same bitmaps and counts as one by one
+        const vk::FilterSet *as[] = {fa.get(), fb.get(), fa.get()}, *bs[] = {fb.get(), fa.get(), fb.get()};
+        const uint32_t ops[] = {1, 0, 2};
+        std::vector<std::shared_ptr<vk::FilterSet>> many;
+        st = vk::FilterSet::combine_batch(as, bs, ops, 3, &many);
+        CHECK(st.ok() && many.size() == 3, "combine_batch: %s", st.msg.c_str());
+        if (st.ok()) {
+          std::vector<uint64_t> got(fc->words() + 1);
+          CHECK(many[0]->read(got.data(), got.size()).ok() && got == bc && many[0]->allowed() == fc->allowed(), "combine_batch[0] = a | b");
+          CHECK(many[1]->read(got.data(), got.size()).ok(), "read");
+          for (uint64_t i = 0; i < fc->words(); ++i) CHECK(got[i] == (ba[i] & bb[i]), "combine_batch[1] = b & a, word %llu", (unsigned long long)i);
+          for (int d : devices) CHECK(many[2]->bits_on(d) != nullptr && hipv::memory_device(many[2]->bits_on(d), fc->words() * 8) == d, "a copy on device %d", d);
+        }
+      }
       host_search(w, gm, 9, 10, nullptr, 0, fa.get(), &ba);
       host_search(w, gm, 40, 4, nullptr, 0, fc.get(), &bc);
       // one filter per query (the dispatcher's batches of hybrid queries): HNSW hands the table to the shards, FLAT runs per filter

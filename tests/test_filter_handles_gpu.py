@@ -66,6 +66,17 @@ def test_id_lists_and_runs_build_the_oracle_bitmap(vsa, oracle, graphs):
         fc = g.combine_filters(fa, fb, op)
         w = fn(a_ids, b_ids)
         assert fc.read().tolist() == oracle.allow_bitmap(w, n).tolist() and fc.info()[1] == w.size, op
+    # ... and a batch of them in one launch (vk_filter_combine_batch): the same bitmaps and counts as one by one
+    terms = [g.make_filter(n, labels=np.flatnonzero(rng.random(n) < p).astype(np.uint64)) for p in (0.05, 0.2, 0.5, 0.9)]
+    pairs = [(terms[i % 4], terms[(i * 7 + 1) % 4], ("and", "or", "andnot")[i % 3]) for i in range(97)]
+    batch = g.combine_filters_batch(pairs)
+    assert len(batch) == 97
+    for (a, b, op), fc in zip(pairs, batch):
+        one = g.combine_filters(a, b, op)
+        assert fc.read().tolist() == one.read().tolist() and fc.info() == one.info(), op
+    assert g.combine_filters_batch([]) == []
+    with pytest.raises(vsa.VkError):
+        g.combine_filters_batch([(fa, fb), (fa, g.make_filter(n - 1, labels=a_ids))])   # one pair of different sizes fails the call
     with pytest.raises(vsa.VkError):
         g.combine_filters(fa, g.make_filter(n - 1, labels=a_ids), "and")    # different sizes
     with pytest.raises(vsa.VkError):

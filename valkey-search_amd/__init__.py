@@ -141,6 +141,7 @@ def lib() -> C.CDLL:
     L.vk_index_load_tracked.argtypes = [C.POINTER(Params), READ_CHUNK, vp, ROW_FN, vp, C.POINTER(vp)]
     L.vk_filter_create.argtypes = [vp, u64, vp, u64, vp, u64, vp, C.POINTER(vp)]
     L.vk_filter_combine.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
+    L.vk_filter_combine_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u32), u64, C.POINTER(vp)]
     L.vk_filter_retain.argtypes = [vp]
     L.vk_filter_retain.restype = None
     L.vk_filter_release.argtypes = [vp]
@@ -291,6 +292,17 @@ class Index:
         h = C.c_void_p()
         _check(lib().vk_filter_combine(self._h, a._h, b._h, {"and": 0, "or": 1, "andnot": 2}[op], C.byref(h)))
         return Filter(h)
+
+    def combine_filters_batch(self, pairs, op="or"):
+        """vk_filter_combine_batch: [(a, b), ...] (or (a, b, op)) -> one Filter each, one launch and one wait per device"""
+        n = len(pairs)
+        code = {"and": 0, "or": 1, "andnot": 2}
+        A = (C.c_void_p * n)(*[p[0]._h for p in pairs])
+        B = (C.c_void_p * n)(*[p[1]._h for p in pairs])
+        O = (C.c_uint32 * n)(*[code[p[2] if len(p) > 2 else op] for p in pairs])
+        out = (C.c_void_p * n)()
+        _check(lib().vk_filter_combine_batch(self._h, A, B, O, n, out))
+        return [Filter(C.c_void_p(out[i])) for i in range(n)]
 
     def filter_cache_get(self, key: bytes, epoch: int):
         h = C.c_void_p()

@@ -277,6 +277,67 @@ Status FilterSet::combine(const FilterSet &a, const FilterSet &b, uint32_t op, s
   return Status::Ok();
 }
 
+Status FilterSet::combine_batch(const FilterSet *const *a, const FilterSet *const *b, const uint32_t *ops, uint64_t n,
+                                std::vector<std::shared_ptr<FilterSet>> *out) {
+  out->clear();
+  if (n == 0) return Status::Ok();
+  if (n > 65535) return Status::Err(1, "filter: at most 65535 combinations per call");
+  const FilterSet &f0 = *a[0];
+  std::vector<int> devs;
+  for (const Copy &c : f0.copies_) devs.push_back(c.device);
+  for (uint64_t i = 0; i < n; ++i) {
+    if (ops[i] > 2) return Status::Err(1, "filter: unknown combine op");
+    if (a[i]->nbits_ != f0.nbits_ || b[i]->nbits_ != f0.nbits_)
+      return Status::Err(1, "filter: combine needs filters of one size (build both with the same nbits)");
+    if (a[i]->copies_.size() != devs.size() || b[i]->copies_.size() != devs.size()) return Status::Err(1, "filter: the filters live on different devices");
+    for (int d : devs)
+      if (!a[i]->bits_on(d) || !b[i]->bits_on(d)) return Status::Err(1, "filter: the filters live on different devices");
+  }
+  std::vector<std::shared_ptr<FilterSet>> res(n);
+  for (uint64_t i = 0; i < n; ++i) VK_TRY(allocate(devs, f0.nbits_, &res[i]));
+  const size_t words = (size_t)f0.words();
+  const size_t tab_bytes = (size_t)n * 32, cnt_bytes = (size_t)n * 8;
+  std::vector<BuildLane *> lanes;
+  struct DrainAll {   // (an error return lets the results go while kernels that write them may still run)
+    std::vector<BuildLane *> &ls; const std::vector<int> &ds; bool armed = true;
+    ~DrainAll() {
+      if (!armed) return;
+      for (size_t i = 0; i < ls.size(); ++i) { (void)hipSetDevice(ds[i]); (void)hipStreamSynchronize(ls[i]->stream); }
+    }
+  } drain_on_error{lanes, devs};
+  std::vector<unsigned long long> counts(n, 0);
+  for (size_t di = 0; di < devs.size(); ++di) {
+    BuildLane *l = lane_of(devs[di]);
+    std::lock_guard<std::mutex> lk(l->mu);
+    VK_HIP_TRY(hipSetDevice(devs[di]));
+    VK_TRY(lane_ready(l));
+    lanes.push_back(l);
+    if (tab_bytes + cnt_bytes > l->pin_cap) return Status::Err(1, "filter: batch too large for the staging block");
+    VK_TRY(stage_ensure(l, tab_bytes + cnt_bytes));
+    uint64_t *tab = reinterpret_cast<uint64_t *>(l->pin);   // (the lane's pinned block: free while its lock is held)
+    for (uint64_t i = 0; i < n; ++i) {
+      tab[4 * i + 0] = reinterpret_cast<uint64_t>(res[i]->copies_[di].bits);
+      tab[4 * i + 1] = reinterpret_cast<uint64_t>(a[i]->bits_on(devs[di]));
+      tab[4 * i + 2] = reinterpret_cast<uint64_t>(b[i]->bits_on(devs[di]));
+      tab[4 * i + 3] = ops[i];
+    }
+    char *stage = static_cast<char *>(l->d_stage);
+    VK_HIP_TRY(hipMemcpyAsync(stage, tab, tab_bytes, hipMemcpyHostToDevice, l->stream));
+    VK_HIP_TRY(hipMemsetAsync(stage + tab_bytes, 0, cnt_bytes, l->stream));
+    VK_HIP_TRY(launch_filter_combine_batch(reinterpret_cast<const uint64_t *>(stage), (uint32_t)n, words,
+                                           reinterpret_cast<unsigned long long *>(stage + tab_bytes), l->stream));
+    // the counts come back with the first device's copy (every copy holds the same bits); every device is waited for under
+    // its lane's lock: the table travels from the lane's pinned block, which the lock's next holder overwrites
+    if (di == 0) VK_HIP_TRY(hipMemcpyAsync(l->pin + tab_bytes, stage + tab_bytes, cnt_bytes, hipMemcpyDeviceToHost, l->stream));
+    VK_HIP_TRY(hipStreamSynchronize(l->stream));
+    if (di == 0) memcpy(counts.data(), l->pin + tab_bytes, cnt_bytes);
+  }
+  drain_on_error.armed = false;
+  for (uint64_t i = 0; i < n; ++i) res[i]->allowed_ = counts[i];
+  out->swap(res);
+  return Status::Ok();
+}
+
 Status FilterSet::read(uint64_t *out_words, uint64_t n_words) const {
   if (copies_.empty()) return Status::Err(4, "filter: no device copy");
   const uint64_t n = std::min<uint64_t>(n_words, words());

@@ -38,6 +38,9 @@ class FilterSet {
                       uint64_t n_runs, const uint64_t *host_bits, std::shared_ptr<FilterSet> *out);
   // dst = a OP b (0 and, 1 or, 2 and-not) on every device both live on; the two must have the same nbits (else an error)
   static Status combine(const FilterSet &a, const FilterSet &b, uint32_t op, std::shared_ptr<FilterSet> *out);
+  // n combinations, one launch and one wait per device: out[i] = a[i] OP[i] b[i] (all of one index and one nbits)
+  static Status combine_batch(const FilterSet *const *a, const FilterSet *const *b, const uint32_t *ops, uint64_t n,
+                              std::vector<std::shared_ptr<FilterSet>> *out);
 
  private:
   FilterSet() = default;

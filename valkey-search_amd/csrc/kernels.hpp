@@ -416,5 +416,7 @@ hipError_t launch_filter_popcount(const uint64_t *bits, uint64_t words, unsigned
 uint32_t filter_combine_blocks(uint64_t words);
 hipError_t launch_filter_combine(uint64_t *dst, const uint64_t *a, const uint64_t *b, uint64_t words, uint32_t op, unsigned long long *d_partial,
                                  hipStream_t s);   // 0 and, 1 or, 2 and-not
+// n combinations in one launch: d_items [n][4] = {dst, a, b, op} device pointers / op code, d_counts [n] zeroed (the results' bits)
+hipError_t launch_filter_combine_batch(const uint64_t *d_items, uint32_t n, uint64_t words, unsigned long long *d_counts, hipStream_t s);
 
 }  // namespace vk

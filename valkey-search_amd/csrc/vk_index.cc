@@ -572,6 +572,26 @@ int vk_filter_combine(vk_index *ix, const vk_filter *a, const vk_filter *b, uint
   });
 }
 
+int vk_filter_combine_batch(vk_index *ix, const vk_filter *const *a, const vk_filter *const *b, const uint32_t *ops, uint64_t n,
+                            vk_filter **out) {
+  VK_NEED(ix);
+  if (n && (!a || !b || !ops || !out)) return fail(VK_ERR_INVALID, "NULL argument");
+  for (uint64_t i = 0; i < n; ++i) {
+    out[i] = nullptr;
+    if (!a[i] || !b[i]) return fail(VK_ERR_INVALID, "NULL filter");
+    if (a[i]->owner != ix || b[i]->owner != ix) return fail(VK_ERR_INVALID, "the filter belongs to another index");
+  }
+  return guarded([&]() -> vk::Status {
+    std::vector<const vk::FilterSet *> sa(n), sb(n);
+    for (uint64_t i = 0; i < n; ++i) { sa[i] = a[i]->set.get(); sb[i] = b[i]->set.get(); }
+    std::vector<std::shared_ptr<vk::FilterSet>> sets;
+    VK_TRY(vk::FilterSet::combine_batch(sa.data(), sb.data(), ops, n, &sets));
+    ix->filters.built.fetch_add(n, std::memory_order_relaxed);
+    for (uint64_t i = 0; i < n; ++i) out[i] = new vk_filter{std::move(sets[i]), ix};
+    return vk::Status::Ok();
+  });
+}
+
 void vk_filter_retain(vk_filter *f) {
   if (f) f->refs.fetch_add(1, std::memory_order_relaxed);
 }
