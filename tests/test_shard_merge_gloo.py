@@ -5,7 +5,9 @@ is the reference's cluster-level analogue, whose arrival-order tie rule this tot
 is the oracle's (there is no GPU in this container): it pins the rule and the world-size-2 plumbing of bench.py's
 fallback mode.  The PRODUCT's sharding, gather and merge kernel are tested where a GPU is:
 tests/test_sharded_index_gpu.py (the in-library sharded index against the unsharded one and the oracle) and
-tests/test_sharded_bench_gpu.py (both bench.py modes)."""
+tests/test_sharded_bench_gpu.py (both bench.py modes) -- and, without any GPU, in tests/test_host_sanitizers.py: the product's
+sharded_index.cc itself over eight virtual devices (the multi-GPU index lives in ONE process, as valkey-server is one: there
+is no product code that runs one rank per GPU, so nothing of the product could run under torch.distributed here)."""
 import os
 import socket
 import sys
