@@ -284,3 +284,25 @@ def test_hnsw_config2_at_full_size_equals_the_oracle_on_the_same_graph(world):
     _, gt, _ = flat.search_batch(hq[:256], K)
     rec = np.mean([len(set(gl[i].tolist()) & set(gt[i].tolist())) for i in range(256)]) / K
     assert 0.6 <= rec <= 0.85, rec
+    # r06: tombstones at full size with DEFAULT options.  A thousand deleted keys (and among them neighbours of the queries):
+    # the full batch still takes the optimistic launch (frontier and visited set on chip, vk_index_stats.last_visited_mode != 0),
+    # the 64-query batch the HBM-frontier kernel -- both must give the oracle's answer on the same graph with the same tombstones
+    dead = sorted(set(np.random.default_rng(6).choice(N, 900, replace=False).tolist()) | set(int(v) for v in gl[sample[:10], :10].ravel()))
+    for lab in dead:
+        assert h.remove(lab) == 0 and o.mark_delete(lab) == 0
+    h.flush()
+    D3, L3, N3 = h.search_batch(hq, K, ef=128)
+    st = h.stats()
+    assert st.last_visited_mode != 0 and st.last_frontier_dropped == 0 and st.deleted == len(dead)
+    assert not set(L3.ravel().tolist()) & set(dead)
+    ne = nh = 0
+    for i in sample:
+        e_d, e_l, e, hp = o.search(hq[i], K, ef=128, stats=True)
+        assert L3[i, :len(e_l)].tolist() == e_l.tolist(), i
+        assert D3[i, :len(e_d)].view(np.uint32).tolist() == e_d.view(np.uint32).tolist(), i
+        ne += e
+        nh += hp
+    Ds, Ls, Ns = h.search_batch(hq[sample], K, ef=128)
+    st = h.stats()
+    assert st.last_visited_mode == 0 and (st.last_n_eval, st.last_n_hops) == (ne, nh)
+    assert (Ls == L3[sample]).all() and (Ds.view(np.uint32) == D3[sample].view(np.uint32)).all()
