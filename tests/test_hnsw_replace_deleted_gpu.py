@@ -207,3 +207,28 @@ def test_bulk_adds_fill_vacancies_first(vsa, oracle):
         _same(D[qi][:N[qi]], L[qi][:N[qi]], *saved.search(q, 10, ef=128))
         hit += len(set(L[qi].tolist()) & set(Lf[qi].tolist()))
     assert hit / 640.0 >= 0.9
+
+
+def test_reference_cases_through_the_abi(vsa):
+    """testing/vector_test.cc:583-617 AllowReplaceDeletedNoLabelReuse (ten keys, two removed, five new ones: 13 nodes, a search
+    for 13 finds 13) and :973-1001 (a known label is updated in its own slot while another slot is tombstoned)."""
+    from conftest import reference_vectors
+    v, w = reference_vectors(10, 100, 10.0), reference_vectors(5, 100, 20.0)
+    g = vsa.Index("HNSW", 100, "L2", initial_cap=15000, m=16, ef_construction=20, ef_runtime=20, build_threads=1, allow_replace_deleted=True)
+    for i in range(10):
+        assert g.add(i, v[i]) == 0
+    assert g.remove(8) == 0 and g.remove(9) == 0
+    st = g.stats()
+    assert (st.count, st.deleted, st.max_label) == (10, 2, 9)
+    for i in range(5):
+        assert g.add(10 + i, w[i]) == 0
+    st = g.stats()
+    assert (st.count, st.deleted) == (13, 0)                     # "Verifies we reused tombstoned hnsw nodes"
+    d, l = g.search(w[0], 13)
+    assert sorted(l.tolist()) == [0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14]
+    h = vsa.Index("HNSW", 100, "L2", initial_cap=1000, m=16, ef_construction=20, build_threads=1, allow_replace_deleted=True)
+    assert h.add(0, v[0]) == 0 and h.add(1, v[1]) == 0 and h.remove(0) == 0
+    assert h.add(1, v[0]) == 0
+    st = h.stats()
+    assert (st.count, st.deleted) == (2, 1) and not h.contains(0) and h.contains(1)
+    assert h.get_row(1).tolist() == v[0].tolist()

@@ -204,6 +204,28 @@ def test_replace_deleted_slots_follow_hnswalg(gs, oracle):
     gs.gs_free(g)
 
 
+def test_reference_replace_deleted_cases_on_the_product_builder(gs):
+    """testing/vector_test.cc:973-1001 (a known label is updated in ITS slot, the tombstoned one stays) and :583-617 at the
+    hnswlib level (two of five new labels take the tombstoned nodes: 13 nodes) on the product's host builder."""
+    v = reference_vectors(2, 100, 10.0)
+    g = gs.gs_new(100, 1, 1000, 16, 20, 100, 1)
+    assert gs.gs_add(g, v[0].ctypes.data, 0) == 0 and gs.gs_add(g, v[1].ctypes.data, 1) == 0
+    assert gs.gs_mark_delete(g, 0) == 0
+    assert gs.gs_add_at(g, v[0].ctypes.data, 1) == 1
+    assert gs.gs_count(g) == 2 and [gs.gs_label_of(g, i) for i in (0, 1)] == [0, 1]
+    assert gs.gs_is_deleted(g, 0) and not gs.gs_is_deleted(g, 1)
+    gs.gs_free(g)
+    v, w = reference_vectors(10, 100, 10.0), reference_vectors(5, 100, 20.0)
+    g = gs.gs_new(100, 1, 15000, 16, 20, 100, 1)
+    for i in range(10):
+        assert gs.gs_add(g, v[i].ctypes.data, i) == 0
+    assert gs.gs_mark_delete(g, 8) == 0 and gs.gs_mark_delete(g, 9) == 0
+    slots = [gs.gs_add_at(g, w[i].ctypes.data, 10 + i) for i in range(5)]
+    assert sorted(slots[:2]) == [8, 9] and slots[2:] == [10, 11, 12] and gs.gs_count(g) == 13
+    assert not any(gs.gs_is_deleted(g, i) for i in range(13))
+    gs.gs_free(g)
+
+
 def test_host_distance_equals_oracle_bits(gs, oracle):
     rng = np.random.default_rng(9)
     for n in (1, 7, 16, 100, 768, 771):

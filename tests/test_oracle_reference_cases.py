@@ -181,3 +181,31 @@ def test_hnsw_tombstones_and_replace(oracle):
     d, l = h.search(vectors[0], 10)
     assert min(l.tolist()) >= 20 and len(l) == 10
     assert h.distance(5, vectors[0]) is None
+
+
+def test_replace_deleted_does_not_duplicate_a_label(oracle):
+    """testing/vector_test.cc:973-1001 HnswAddPointReplaceDeletedDoesNotDuplicateLabel: labels 0, 1 on slots 0, 1; slot 0
+    tombstoned; label 1 added again with replace_deleted: it must update ITS slot, not take over the tombstoned one."""
+    v = reference_vectors(2, 100, 10.0)
+    h = oracle.HNSW(100, "L2", max_elements=1000, M=16, ef_construction=20, seed=100, allow_replace_deleted=True)
+    assert h.add(v[0], 0) == 0 and h.add(v[1], 1) == 0
+    assert h.mark_delete(0) == 0
+    assert h.add(v[0], 1) == 0
+    g = h.export_graph()
+    assert h.count == 2 and g["labels"].tolist() == [0, 1] and g["deleted"].tolist() == [1, 0]
+    assert g["rows"][1].tolist() == v[0].tolist() and h.vacant() == [0]
+
+
+def test_allow_replace_deleted_reuses_tombstoned_nodes(oracle):
+    """testing/vector_test.cc:583-617 AllowReplaceDeletedNoLabelReuse at the hnswlib level: ten labels, the last two removed,
+    five NEW labels (VectorBase never reuses an internal id: 10 .. 14) -- two take the tombstoned nodes, three new ones:
+    13 nodes, and a search for 13 returns 13."""
+    v, w = reference_vectors(10, 100, 10.0), reference_vectors(5, 100, 20.0)
+    h = oracle.HNSW(100, "L2", max_elements=15000, M=16, ef_construction=20, ef=20, seed=100, allow_replace_deleted=True)
+    h.add_many(v)
+    assert h.mark_delete(8) == 0 and h.mark_delete(9) == 0 and h.count == 10
+    for i in range(5):
+        assert h.add(w[i], 10 + i) == 0
+    assert h.count == 13 and h.deleted_count == 0
+    d, l = h.search(w[0], 13)
+    assert sorted(l.tolist()) == [0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14]
