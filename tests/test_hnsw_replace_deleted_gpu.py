@@ -232,3 +232,27 @@ def test_reference_cases_through_the_abi(vsa):
     st = h.stats()
     assert (st.count, st.deleted) == (2, 1) and not h.contains(0) and h.contains(1)
     assert h.get_row(1).tolist() == v[0].tolist()
+
+
+@pytest.mark.parametrize("allow", [True, False])
+def test_reload_with_tombstones_then_new_labels(vsa, allow):
+    """integration/test_hnsw_allow_replace_deleted.py: ten vectors, the two highest labels deleted, SAVE + restart, five new
+    vectors -- no add error under either setting (the id counter resumes behind the largest label the stream holds, tombstoned
+    or not: GetMaxInternalLabel, vector_hnsw.cc:387-394), 13 documents, and KNN 13 finds all 13."""
+    rows = np.array([[float(i) + 0.1 * d for d in range(4)] for i in range(10)], np.float32)
+    new = np.array([[100.0 + i + 0.1 * d for d in range(4)] for i in range(5)], np.float32)
+    g = vsa.Index("HNSW", 4, "L2", initial_cap=1024, m=16, ef_construction=200, ef_runtime=10, build_threads=1, allow_replace_deleted=allow)
+    for i in range(10):
+        assert g.add(i, rows[i]) == 0
+    assert g.remove(8) == 0 and g.remove(9) == 0
+    chunks = g.save()
+    h = vsa.Index.load(chunks, "HNSW", 4, "L2", initial_cap=1024, m=16, ef_construction=200, ef_runtime=10, build_threads=1,
+                       allow_replace_deleted=allow)
+    st = h.stats()
+    assert (st.count, st.deleted, st.max_label) == (10, 2, 9)
+    for i in range(5):
+        assert h.add(int(st.max_label) + 1 + i, new[i]) == 0          # inc_id_ = GetMaxInternalLabel() + 1 (vector_base.cc:480-481)
+    st = h.stats()
+    assert (st.count, st.deleted) == ((13, 0) if allow else (15, 2))
+    d, l = h.search(np.array([50.0, 50.1, 50.2, 50.3], np.float32), 13, ef=13)
+    assert sorted(l.tolist()) == [0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 14]
