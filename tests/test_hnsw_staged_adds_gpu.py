@@ -143,3 +143,68 @@ def test_addpoint_semantics_while_staged(vsa):
     assert st2.staged_adds == st.staged_adds + 98 and st2.staged_adds_device == st.staged_adds_device
     g.set_option("hnsw-stage-adds", 0)
     assert g.add(n0 + 5100, x[n0 + 5100]) == vsa.VK_OK and g.stats().staged_adds == st2.staged_adds
+
+
+def test_a_delete_is_not_lost_while_its_bulk_is_being_linked(vsa):
+    """drain_pending() swaps the staged rows out and links them later; in between, a remove / contains /
+    get_row / second add of a label whose add() had already returned found the label NOWHERE -- the delete was lost and the
+    vector linked behind it (a ghost for a deleted key).  Four writer threads stage single adds with a small staging area (a
+    bulk is linked every 8192 rows, on the device, by whichever writer fills it, while the others keep adding) and remove every fifth label
+    right after adding it; a fifth of the rest is added a second time with another row.  Afterwards: every removed label is
+    gone (not contained, no distance, never a search result), every other label is there with its LAST row, the count is right."""
+    import threading
+    dim, n0, per, T = 16, 20_000, 12_000, 4
+    rng = np.random.default_rng(81)
+    base = rng.standard_normal((n0, dim)).astype(np.float32)
+    new = rng.standard_normal((T * per, dim)).astype(np.float32)
+    again = rng.standard_normal((T * per, dim)).astype(np.float32)
+    g = vsa.Index("HNSW", dim, "L2", initial_cap=n0 + T * per, m=8, ef_construction=40, ef_runtime=64, options={"hnsw-stage-max": 8192})
+    g.add_batch(base)
+    g.flush()
+    removed, readded, errors = [set() for _ in range(T)], [set() for _ in range(T)], []
+
+    def writer(t):
+        try:
+            for i in range(per):
+                j = t * per + i
+                lab = n0 + j
+                assert g.add(lab, new[j]) == vsa.VK_OK
+                if j % 5 == 0:
+                    assert g.remove(lab) == vsa.VK_OK, lab
+                    assert not g.contains(lab), lab
+                    removed[t].add(lab)
+                elif j % 5 == 1:
+                    assert g.contains(lab), lab
+                    assert g.add(lab, again[j]) == vsa.VK_OK          # the same label again: an update, never a second element
+                    readded[t].add(lab)
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=writer, args=(t,)) for t in range(T)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
+    g.flush()
+    gone = set().union(*removed)
+    twice = set().union(*readded)
+    st = g.stats()
+    assert st.staged_ops == 0 and st.staged_adds_device > 0
+    # (a label removed while staged never entered the graph; one removed after it was linked is a tombstone)
+    assert st.count - st.deleted == n0 + T * per - len(gone), (st.count, st.deleted, len(gone))
+    probe = rng.permutation(T * per)[:3000]
+    for j in probe:
+        lab = n0 + int(j)
+        if lab in gone:
+            assert not g.contains(lab) and g.distance(lab, new[j]) is None, lab
+        else:
+            want = again[j] if lab in twice else new[j]
+            assert g.contains(lab) and g.get_row(lab).tolist() == want.tolist(), lab
+    qs = np.stack([new[int(j)] for j in probe[:512]])
+    D, L, N = g.search_batch(qs, 5, ef=64)
+    assert not set(L.ravel().tolist()) & gone, "a deleted key came back from a search"
+    # the live probes find themselves (an approximate index: nearly all of them, vector_test.cc's self-retrieval bar)
+    live = [(r, n0 + int(j)) for r, j in enumerate(probe[:512]) if n0 + int(j) not in gone and n0 + int(j) not in twice]
+    hit = sum(int(L[r, 0] == lab and D[r, 0] == 0.0) for r, lab in live)
+    assert hit >= 0.97 * len(live), (hit, len(live))
