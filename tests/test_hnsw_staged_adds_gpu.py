@@ -67,11 +67,14 @@ def test_single_adds_reach_the_device_build(vsa, oracle):
     st = gs.stats()
     assert failed == 0 and st.count == n and st.staged_ops == 0
     # (the first 16384 points are linked by the host builder as they come: the device build needs a graph to extend)
-    # (... and the writers keep staging while a bulk is being linked, so the LAST bulk can be a remainder below 4096 rows,
-    #  which the host builder's threads link)
+    # (... and the writers keep staging while a bulk is being linked, so the LAST bulk -- the flush's -- can be a remainder below
+    #  4096 rows, which the host builder's threads link.  Only that one: a writer that waited behind a bulk and finds fewer
+    #  rows than a device bulk takes goes back to staging -- before r06 each of the queued writers linked the handful it found,
+    #  up to 3 800 rows of this million in bulks of tens, and one run in eight or so crossed the 4096 of this assertion)
     assert st.staged_adds >= n - 16384 - 64 and st.staged_adds - st.staged_adds_device < 4096, (st.staged_adds, st.staged_adds_device)
     r_single = recall(gs, gt, Q)
-    print(f"1M x 768: add_batch {t_batch:.1f} s (recall {r_batch:.4f}); 16 threads x single adds {t_adds:.1f} s + flush = {t_single:.1f} s (recall {r_single:.4f})")
+    print(f"1M x 768: add_batch {t_batch:.1f} s (recall {r_batch:.4f}); 16 threads x single adds {t_adds:.1f} s + flush = {t_single:.1f} s (recall {r_single:.4f}); "
+          f"staged {st.staged_adds}, of them linked by the host builder {st.staged_adds - st.staged_adds_device}")
     assert t_single <= 1.5 * t_batch, (t_single, t_batch)
     assert r_single >= r_batch - 0.005, (r_single, r_batch)      # (the same builder: 2048 queries apart)
     del gs, x

@@ -446,6 +446,7 @@ class Dispatcher {
   }
   // completions of submitted requests that are told in ONE call (set_batch_done): the members of a piece of a finished batch
   struct Bulk {
+    BatchDoneFn hook = nullptr;   // read ONCE per piece: what was collected for it is told through it, whatever happens to the setting meanwhile
     std::vector<void *> users;
     std::vector<int> codes;
   };
@@ -457,7 +458,7 @@ class Dispatcher {
     }
     if (r.cb) {
       r.state.store(kDone, std::memory_order_release);
-      BatchDoneFn hook = batch_fn_.load(std::memory_order_acquire);
+      BatchDoneFn hook = bulk ? bulk->hook : batch_fn_.load(std::memory_order_acquire);
       if (hook && bulk) {
         bulk->users.push_back(r.user);
         bulk->codes.push_back(st.code);
@@ -653,7 +654,8 @@ class Dispatcher {
   void hand_out(std::vector<std::shared_ptr<Req>> &batch, Scratch &sc, const Status &st, const std::vector<Status> &each, uint64_t k, bool hnsw,
                 uint64_t first, uint64_t count) {
     Bulk bulk;
-    if (batch_fn_.load(std::memory_order_relaxed)) { bulk.users.reserve(count); bulk.codes.reserve(count); }
+    bulk.hook = batch_fn_.load(std::memory_order_acquire);
+    if (bulk.hook) { bulk.users.reserve(count); bulk.codes.reserve(count); }
     for (uint64_t i = first; i < first + count; ++i) {
       Req &r = *batch[i];
       if (!claim(r)) continue;   // (it left, or was answered when its token went up; its token may be gone: not read)
@@ -667,9 +669,8 @@ class Dispatcher {
       }
       deliver(r, mine, sc.D.data() + i * k, sc.L.data() + i * k, n, &bulk);
     }
-    if (!bulk.users.empty()) {   // one call for the piece's submitted members (set_batch_done)
-      if (BatchDoneFn hook = batch_fn_.load(std::memory_order_acquire)) hook(batch_user_, bulk.users.data(), bulk.codes.data(), bulk.users.size());
-    }
+    if (!bulk.users.empty())   // one call for the piece's submitted members (set_batch_done)
+      bulk.hook(batch_user_, bulk.users.data(), bulk.codes.data(), bulk.users.size());
     wake_blocked();
   }
   void piece_done() {

@@ -105,7 +105,7 @@ class HnswIndex final : public Index {
     }
     // (the staging area is bounded: a writer that finds it full links what is there -- or waits for the writer that is
     //  doing so -- before it returns, like a caller of one long add_batch)
-    if (staged) return full ? drain_pending() : Status::Ok();
+    if (staged) return full ? drain_pending(/*only_if_full=*/true) : Status::Ok();
     if (in_bulk) wait_for_bulk();
     std::shared_lock<std::shared_mutex> lk(rw_);
     return add_one(label, row);
@@ -127,8 +127,12 @@ class HnswIndex final : public Index {
     return add_batch_host(labels, rows, n);
   }
 
-  // link what the single adds staged (see add()); called without the index lock
-  Status drain_pending() {
+  // link what the single adds staged (see add()); called without the index lock.  only_if_full: the caller is a writer that
+  // found the staging area full -- when it gets its turn behind the writer that linked that bulk and fewer rows wait than a
+  // device bulk takes, it goes back to staging (sixteen writers queue up behind one bulk; each of them linking the handful of
+  // rows the others staged meanwhile sent up to 3 700 of a million rows to the host builder in bulks of tens:
+  // scripts/staged_remainder_probe.py); with a device bulk's worth waiting it links them at once, the device does not idle.
+  Status drain_pending(bool only_if_full = false) {
     {   // (cheap exit: nothing staged and nobody linking -- a flush, a save or a search that arrives while ANOTHER thread
         //  links what it swapped out waits for it below: every add that was acknowledged is in the graph when this returns)
       std::lock_guard<std::mutex> pl(pend_.mu);
@@ -142,6 +146,7 @@ class HnswIndex final : public Index {
     {
       std::lock_guard<std::mutex> pl(pend_.mu);
       if (pend_.labels.empty()) return Status::Ok();
+      if (only_if_full && pend_.labels.size() < std::min<uint64_t>(opt_.get(kOptHnswStageMax), kDeviceBuildMinBatch)) return Status::Ok();
       if (pend_.live == pend_.labels.size()) {
         rows.swap(pend_.rows);
         labels.swap(pend_.labels);
