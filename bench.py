@@ -1120,12 +1120,19 @@ def _baseline_metric():
 BASELINE_METRIC = _baseline_metric()
 
 
+STAMPED_SOURCES = ("*.hip", "device_common.hpp", "kernels.hpp", "options.hpp", "flat_index.cc", "hnsw_index.cc")
+
+
 def source_sha256():
-    """Hash of the kernel and library sources (csrc/*.hip, *.hpp, *.cc): the build id a PMC traffic file is stamped with."""
+    """Hash of what decides a launch's memory traffic -- the device sources (csrc/*.hip and the two headers they include), the
+    option defaults and the two files that choose kernel variant, grid and work split (flat_index.cc, hnsw_index.cc): the build
+    id a PMC traffic file is stamped with.  (Host-only files -- dispatcher, filter handles, sharding, the ABI -- are not in it:
+    until r06 a change there made the bench line drop its `traffic` although no kernel or launch had changed.)"""
     import hashlib
     h = hashlib.sha256()
     csrc = ROOT / "valkey-search_amd" / "csrc"
-    for f in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.hpp")) + list(csrc.glob("*.cc"))):
+    files = sorted({f for pat in STAMPED_SOURCES for f in csrc.glob(pat)})
+    for f in files:
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()

@@ -125,6 +125,7 @@ Status RowStore::reserve(uint64_t rows) {
   // (every failure from here on gives the new arrays back: the store keeps its old ones)
   auto step = [&](hipError_t err, const char *what) -> Status {
     if (err == hipSuccess) return Status::Ok();
+    (void)hipGetLastError();   // (the thread's sticky copy of it)
     (void)hipStreamSynchronize(stream_);
     (void)hipFree(nr);
     if (nl) (void)hipFree(nl);

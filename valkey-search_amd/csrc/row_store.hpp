@@ -28,8 +28,10 @@ struct Status {
 #define VK_HIP_TRY(expr)                                                                      \
   do {                                                                                        \
     hipError_t _e = (expr);                                                                   \
-    if (_e != hipSuccess)                                                                     \
+    if (_e != hipSuccess) {                                                                   \
+      (void)hipGetLastError(); /* the thread's sticky copy: a later launch check must not find it */ \
       return ::vk::Status::Err(4, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    }                                                                                         \
   } while (0)
 
 #define VK_TRY(expr)                       \
