@@ -297,6 +297,11 @@ class FlatIndex final : public Index {
       if (run_labels.empty()) return Status::Ok();
       const uint32_t first = (uint32_t)(count_ - run_labels.size());
       Status s = store_.bulk_write(first, rows + run_begin * params_.dim, end - run_begin, run_labels.data());
+      if (!s.ok()) {   // (the table could not grow: the run never reached it -- its labels and slots are given back, so the
+                       //  index keeps answering over what it holds and the caller may send the batch again)
+        for (uint64_t l : run_labels) slot_of_.erase(l);
+        count_ -= run_labels.size();
+      }
       run_labels.clear();
       return s;
     };
@@ -307,6 +312,7 @@ class FlatIndex final : public Index {
         if (run_labels.empty()) run_begin = i;
         slot_of_.emplace(label, (uint32_t)count_++);
         run_labels.push_back(label);
+        if (label > max_label_) max_label_ = label;   // ("ever held": a run that is given back below leaves it, like a removed label does)
         continue;
       }
       VK_TRY(close_run(i));

@@ -120,8 +120,14 @@ Status RowStore::reserve(uint64_t rows) {
   uint64_t *nl = nullptr;
   // kRowSlack rows beyond the capacity stay allocated (and zero): the tiled kernels read whole
   // 128-row tiles and mask the rows past the count afterwards, instead of clamping every address
-  VK_HIP_TRY(hipMalloc(&nr, (want + kRowSlack) * row_bytes()));
-  hipError_t e = hipMalloc(reinterpret_cast<void **>(&nl), want * 8);
+  hipError_t e = hipMalloc(&nr, (want + kRowSlack) * row_bytes());
+  if (e != hipSuccess && want > std::max<uint64_t>(rows, 1024)) {   // no room for half as much again: exactly what is asked for, then
+    (void)hipGetLastError();
+    want = std::max<uint64_t>(rows, 1024);
+    e = hipMalloc(&nr, (want + kRowSlack) * row_bytes());
+  }
+  VK_HIP_TRY(e);
+  e = hipMalloc(reinterpret_cast<void **>(&nl), want * 8);
   // (every failure from here on gives the new arrays back: the store keeps its old ones)
   auto step = [&](hipError_t err, const char *what) -> Status {
     if (err == hipSuccess) return Status::Ok();
