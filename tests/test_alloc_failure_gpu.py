@@ -122,3 +122,98 @@ def test_max_label_after_a_bulk_add(vsa):
         g.remove(5000)
         g.flush()
         assert g.stats().max_label == 5000, algo     # the largest label EVER held
+
+
+def test_staged_adds_under_memory_pressure(vsa, oracle):
+    """single adds are acknowledged when they are STAGED (host memory); the device is asked for room when the bulk is linked.
+    No room: the flush fails, every acknowledged add is still there (readable, removable, updatable), and the same flush
+    links them once memory is back"""
+    import torch
+    dim, k = 8192, 10                                 # 32 KB rows: the device build takes them
+    n0, n1 = 20_000, 30_000                           # 655 MB in the graph, 983 MB staged behind it
+    rng = np.random.default_rng(7)
+    lat = rng.standard_normal((n0 + n1, 24)).astype(np.float32)
+    x = lat @ rng.standard_normal((24, dim)).astype(np.float32) + 0.05 * rng.standard_normal((n0 + n1, dim)).astype(np.float32)
+    Q = x[rng.integers(0, n0 + n1, 6)] + 0.01 * rng.standard_normal((6, dim)).astype(np.float32)
+    g = vsa.Index("HNSW", dim, "L2", initial_cap=n0 + n1, m=8, ef_construction=32, ef_runtime=64)
+    g.add_batch(x[:n0])
+    g.flush()
+    held = _occupy(torch, 256 << 20)
+    try:
+        for i in range(n0, n0 + n1):
+            assert g.add(i, x[i]) == vsa.VK_OK
+        st = g.stats()
+        assert st.count == n0 + n1 and st.staged_ops >= n1
+        with pytest.raises(vsa.VkError) as e:
+            g.flush()
+        assert e.value.code == vsa.VK_ERR_INTERNAL, e.value
+        st = g.stats()
+        assert st.count == n0 + n1 and st.staged_ops >= n1, (st.count, st.staged_ops)     # nothing left the staging area
+        for i in (n0, n0 + 7, n0 + n1 - 1):
+            assert np.array_equal(g.get_row(i), x[i])
+        assert g.remove(n0 + 5) == vsa.VK_OK          # a delete and an update of rows that wait
+        assert g.add(n0 + 6, x[0]) == vsa.VK_OK
+        with pytest.raises(vsa.VkError):              # a search links what is staged first: the same refusal, no answer over half an index
+            g.search(Q[0], k)
+    finally:
+        del held
+        torch.cuda.empty_cache()
+    g.flush()
+    st = g.stats()
+    assert st.count == n0 + n1 - 1 and st.deleted == 0 and st.staged_ops == 0 and st.staged_adds_device > 0
+    assert np.array_equal(g.get_row(n0 + 6), x[0]) and np.array_equal(g.get_row(n0 + n1 - 1), x[-1])
+    assert g.get_row(n0 + 5) is None and not g.contains(n0 + 5)
+    o = oracle.HNSW.from_product_index(g.save_raw, dim, "L2", 8, ef_construction=32)
+    for q in Q:
+        _same(*g.search(q, k, ef=64), *o.search(q, k, ef=64))
+    hits = 0
+    for i in rng.integers(n0, n0 + n1, 50):
+        if i in (n0 + 5, n0 + 6):
+            continue
+        d, l = g.search(x[i], 1, ef=64)
+        hits += l.tolist() == [i]
+    assert hits >= 45, hits                           # the staged rows are linked INTO the graph, not just stored
+
+
+def test_a_bulk_that_fails_part_of_the_way_loses_nothing(vsa, oracle):
+    """The room for the rows is taken before a bulk leaves the staging area; what can still fail is the scratch of a device
+    batch.  The failpoint option makes the second batch of the bulk fail behind its registration: its elements are in the
+    graph with empty lists, the batches behind it never got there.  Nothing acknowledged may be lost: the registered ones are
+    linked by the host builder, the others go back to staging, the error goes to the caller of the flush."""
+    dim, k = 64, 10
+    n0, n1 = 20_000, 20_000
+    rng = np.random.default_rng(11)
+    lat = rng.standard_normal((n0 + n1, 16)).astype(np.float32)
+    x = lat @ rng.standard_normal((16, dim)).astype(np.float32) + 0.05 * rng.standard_normal((n0 + n1, dim)).astype(np.float32)
+    Q = x[rng.integers(0, n0 + n1, 16)] + 0.01 * rng.standard_normal((16, dim)).astype(np.float32)
+    g = vsa.Index("HNSW", dim, "L2", initial_cap=n0 + n1, m=8, ef_construction=64, ef_runtime=64)
+    g.add_batch(x[:n0])
+    g.flush()
+    for i in range(n0, n0 + n1):
+        assert g.add(i, x[i]) == vsa.VK_OK
+    g.set_option("hnsw-failpoint-batch", 2)
+    with pytest.raises(vsa.VkError) as e:
+        g.flush()
+    assert e.value.code == vsa.VK_ERR_INTERNAL and "failpoint" in e.value.msg
+    st = g.stats()
+    # the first batch (n0 / 32 = 625 rows) is linked, the second registered; the rest waits again
+    assert st.count == n0 + n1 and 0 < st.staged_ops < n1, (st.count, st.staged_ops)
+    for i in range(n0, n0 + n1, 97):
+        assert np.array_equal(g.get_row(i), x[i]) and g.contains(i)
+    assert g.remove(n0 + n1 - 1) == vsa.VK_OK and g.remove(n0) == vsa.VK_OK        # one that waits again, one that was linked
+    g.set_option("hnsw-failpoint-batch", 0)
+    g.flush()
+    st = g.stats()
+    assert st.count == n0 + n1 - 1 and st.deleted == 1 and st.staged_ops == 0
+    chunks = g.save()
+    deg = np.array([int(np.frombuffer(c[:4], np.uint32)[0] & 0xFFFF) for c in chunks[1:1 + n0 + n1 - 1]])
+    assert (deg == 0).sum() == 0, int((deg == 0).sum())       # nobody was left registered and unlinked
+    o = oracle.HNSW.from_product_index(g.save_raw, dim, "L2", 8, ef_construction=64)
+    for q in Q:
+        _same(*g.search(q, k, ef=64), *o.search(q, k, ef=64))
+    hits = 0
+    probe = [int(i) for i in rng.integers(n0 + 1, n0 + n1 - 1, 200)]
+    for i in probe:
+        d, l = g.search(x[i], 1, ef=64)
+        hits += l.tolist() == [i]
+    assert hits >= 190, hits

@@ -78,35 +78,38 @@ class HnswIndex final : public Index {
     // A label that is staged, or in the bulk being linked right now, is looked for there whatever stage_candidate() says
     // by now (a remove of a linked element switches staging off under hnsw-allow-replace-deleted while rows still wait).
     const bool can_stage = stage_candidate();
-    bool full = false, staged = false, in_bulk = false;
-    {
-      std::lock_guard<std::mutex> pl(pend_.mu);
-      auto it = pend_.pos.find(label);
-      uint32_t id;
-      if (it != pend_.pos.end()) {   // the same label again before it was linked: the later row wins (an in-place update)
-        memcpy(pend_.rows.data() + it->second * params_.dim, row, (size_t)params_.dim * 4);
-        return Status::Ok();
+    for (;;) {
+      bool full = false, staged = false, in_bulk = false;
+      {
+        std::lock_guard<std::mutex> pl(pend_.mu);
+        auto it = pend_.pos.find(label);
+        uint32_t id;
+        if (it != pend_.pos.end()) {   // the same label again before it was linked: the later row wins (an in-place update)
+          memcpy(pend_.rows.data() + it->second * params_.dim, row, (size_t)params_.dim * 4);
+          return Status::Ok();
+        }
+        if (pend_.linking.count(label)) {
+          in_bulk = true;   // its first row is being linked right now: this one is an update behind that bulk
+        } else if (can_stage && !graph_->lookup(label, &id)) {   // (an update of a linked element goes to the host builder below)
+          if (graph_->count() + pend_.live + draining_.load(std::memory_order_relaxed) >= graph_->max_elements())
+            return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+          if (pend_.rows.capacity() == 0) pend_.rows.reserve((size_t)std::min<uint64_t>(opt_.get(kOptHnswStageMax), 1u << 20) * params_.dim);
+          pend_.pos.emplace(label, pend_.labels.size());
+          pend_.labels.push_back(label);
+          pend_.rows.insert(pend_.rows.end(), row, row + params_.dim);
+          pend_.live += 1;
+          graph_->note_label(label);
+          staged_adds_.fetch_add(1, std::memory_order_relaxed);
+          full = pend_.labels.size() >= opt_.get(kOptHnswStageMax);
+          staged = true;
+        }
       }
-      if (pend_.linking.count(label)) {
-        in_bulk = true;   // its first row is being linked right now: this one is an update behind that bulk
-      } else if (can_stage && !graph_->lookup(label, &id)) {   // (an update of a linked element goes to the host builder below)
-        if (graph_->count() + pend_.live + draining_.load(std::memory_order_relaxed) >= graph_->max_elements())
-          return Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
-        if (pend_.rows.capacity() == 0) pend_.rows.reserve((size_t)std::min<uint64_t>(opt_.get(kOptHnswStageMax), 1u << 20) * params_.dim);
-        pend_.pos.emplace(label, pend_.labels.size());
-        pend_.labels.push_back(label);
-        pend_.rows.insert(pend_.rows.end(), row, row + params_.dim);
-        pend_.live += 1;
-        graph_->note_label(label);
-        staged_adds_.fetch_add(1, std::memory_order_relaxed);
-        full = pend_.labels.size() >= opt_.get(kOptHnswStageMax);
-        staged = true;
-      }
+      // (the staging area is bounded: a writer that finds it full links what is there -- or waits for the writer that is
+      //  doing so -- before it returns, like a caller of one long add_batch)
+      if (staged) return full ? drain_pending(/*only_if_full=*/true) : Status::Ok();
+      if (!in_bulk) break;
+      wait_for_bulk();   // ... and look again: a bulk that FAILED put the rows that had not reached the graph back into staging
     }
-    // (the staging area is bounded: a writer that finds it full links what is there -- or waits for the writer that is
-    //  doing so -- before it returns, like a caller of one long add_batch)
-    if (staged) return full ? drain_pending(/*only_if_full=*/true) : Status::Ok();
-    if (in_bulk) wait_for_bulk();
     std::shared_lock<std::shared_mutex> lk(rw_);
     return add_one(label, row);
   }
@@ -143,10 +146,31 @@ class HnswIndex final : public Index {
     std::vector<uint64_t> &labels = spare_labels_;   //  stage size is not reallocated and re-faulted every time)
     rows.clear();
     labels.clear();
+    uint64_t waiting = 0;
     {
       std::lock_guard<std::mutex> pl(pend_.mu);
       if (pend_.labels.empty()) return Status::Ok();
       if (only_if_full && pend_.labels.size() < std::min<uint64_t>(opt_.get(kOptHnswStageMax), kDeviceBuildMinBatch)) return Status::Ok();
+      waiting = pend_.labels.size();
+    }
+    // The row table grows BEFORE the bulk leaves the staging area: if the device has no room for it, the call fails here with
+    // every acknowledged add still staged and nothing registered in the graph (the usual way to run out: the table of a large
+    // index growing by half).  What can still fail behind this point is a few megabytes of scratch; see the end of this function.
+    {
+      bool grow;
+      {
+        std::shared_lock<std::shared_mutex> lk(rw_);
+        grow = graph_->count() + waiting > store_.alloc_rows();
+      }
+      if (grow) {
+        std::unique_lock<std::shared_mutex> lk(rw_);
+        (void)hipSetDevice(store_.device());
+        VK_TRY(store_.reserve(graph_->count() + waiting));
+      }
+    }
+    {
+      std::lock_guard<std::mutex> pl(pend_.mu);
+      if (pend_.labels.empty()) return Status::Ok();
       if (pend_.live == pend_.labels.size()) {
         rows.swap(pend_.rows);
         labels.swap(pend_.labels);
@@ -177,7 +201,34 @@ class HnswIndex final : public Index {
     bool on_device = false;
     Status st = add_batch_now(labels.data(), rows.data(), labels.size(), &on_device);
     if (st.ok() && on_device) staged_adds_device_.fetch_add(labels.size(), std::memory_order_relaxed);
+    if (!st.ok()) restage_after_failure(labels, rows);
     return st;
+  }
+
+  // A bulk failed part of the way (the error goes to the caller of the drain): no acknowledged add may be lost with it.
+  // Rows that never reached the graph go back into the staging area (remove / get_row / a second add of such a label look
+  // there again after waiting for the bulk); elements that were registered for a batch the device never linked -- in the
+  // graph, with an empty level-0 list, reachable by nothing -- are linked by the host builder's update path, which needs
+  // the host graph alone.  Called with drain_mu_ held, `linking` still naming the bulk.
+  void restage_after_failure(const std::vector<uint64_t> &labels, const std::vector<float> &rows) {
+    const uint32_t dim = params_.dim;
+    std::vector<size_t> back;
+    {
+      std::shared_lock<std::shared_mutex> lk(rw_);
+      for (size_t i = 0; i < labels.size(); ++i) {
+        uint32_t id;
+        if (!graph_->lookup(labels[i], &id)) back.push_back(i);
+        else if ((graph_->links0(id)[0] & 0xFFFFu) == 0 && !graph_->is_deleted(id) && graph_->count() > 1)
+          (void)add_one(labels[i], rows.data() + i * dim);
+      }
+    }
+    std::lock_guard<std::mutex> pl(pend_.mu);
+    for (size_t i : back) {
+      if (!pend_.pos.emplace(labels[i], pend_.labels.size()).second) continue;
+      pend_.labels.push_back(labels[i]);
+      pend_.rows.insert(pend_.rows.end(), rows.begin() + i * dim, rows.begin() + (i + 1) * dim);
+      pend_.live += 1;
+    }
   }
 
   Status add_batch_host(const uint64_t *labels, const float *rows, uint64_t n) {
@@ -217,18 +268,22 @@ class HnswIndex final : public Index {
   }
 
   Status remove(uint64_t label) override {
-    bool in_bulk = false;
-    {
-      std::lock_guard<std::mutex> pl(pend_.mu);
-      auto it = pend_.pos.find(label);
-      if (it != pend_.pos.end()) {   // staged and not linked yet: it never enters the graph
-        pend_.pos.erase(it);
-        pend_.live -= 1;
-        return Status::Ok();
+    for (;;) {
+      bool in_bulk = false;
+      {
+        std::lock_guard<std::mutex> pl(pend_.mu);
+        auto it = pend_.pos.find(label);
+        if (it != pend_.pos.end()) {   // staged and not linked yet: it never enters the graph
+          pend_.pos.erase(it);
+          pend_.live -= 1;
+          return Status::Ok();
+        }
+        in_bulk = pend_.linking.count(label) != 0;
       }
-      in_bulk = pend_.linking.count(label) != 0;
+      if (!in_bulk) break;
+      wait_for_bulk();   // (being linked right now: the tombstone goes on the linked element -- or, the bulk having failed, the
+                         //  row is back in the staging area: look again)
     }
-    if (in_bulk) wait_for_bulk();   // (being linked right now: the tombstone goes on the linked element)
     std::shared_lock<std::shared_mutex> lk(rw_);
     return graph_->mark_delete(label);
   }
@@ -413,17 +468,20 @@ class HnswIndex final : public Index {
   }
 
   Status get_row(uint64_t label, float *out) override {
-    bool in_bulk = false;
-    {
-      std::lock_guard<std::mutex> pl(pend_.mu);
-      auto it = pend_.pos.find(label);
-      if (it != pend_.pos.end()) {
-        memcpy(out, pend_.rows.data() + it->second * params_.dim, (size_t)params_.dim * 4);
-        return Status::Ok();
+    for (;;) {
+      bool in_bulk = false;
+      {
+        std::lock_guard<std::mutex> pl(pend_.mu);
+        auto it = pend_.pos.find(label);
+        if (it != pend_.pos.end()) {
+          memcpy(out, pend_.rows.data() + it->second * params_.dim, (size_t)params_.dim * 4);
+          return Status::Ok();
+        }
+        in_bulk = pend_.linking.count(label) != 0;
       }
-      in_bulk = pend_.linking.count(label) != 0;
+      if (!in_bulk) break;
+      wait_for_bulk();   // (then look again: see remove())
     }
-    if (in_bulk) wait_for_bulk();
     std::shared_lock<std::shared_mutex> lk(rw_);
     uint32_t id;
     if (!graph_->lookup(label, &id)) return Status::Err(VK_ERR_NOT_FOUND, "label not found");
@@ -534,11 +592,20 @@ class HnswIndex final : public Index {
   Status flush_locked() {
     (void)hipSetDevice(store_.device());
     VK_TRY(store_.flush());
-    if (!graph_->any_dirty()) { publish_snapshot(); return Status::Ok(); }
-    Status st = flush_links();
-    if (st.ok()) publish_snapshot();
+    if (!graph_->any_dirty() && !links_stale_) { publish_snapshot(); return Status::Ok(); }
+    // (flush_links consumes the dirty marks before it touches the device: a failure in there -- an allocation under memory
+    //  pressure drops the table it wanted to grow -- leaves the device's copy of the links behind the host's with nothing
+    //  marked.  Until one pass has succeeded the next one republishes everything from the host graph, which is the truth.)
+    const bool everything = links_stale_;
+    links_stale_ = true;
+    Status st = flush_links(everything);
+    if (st.ok()) {
+      links_stale_ = false;
+      publish_snapshot();
+    }
     return st;
   }
+  bool links_stale_ = false;   // under rw_ exclusive, like flush_locked itself
 
   void publish_snapshot() {   // caller holds rw_ exclusively: no add / remove is running
     pub_.count = (uint32_t)graph_->count();
@@ -547,13 +614,13 @@ class HnswIndex final : public Index {
     pub_.deleted = graph_->deleted_count();
   }
 
-  Status flush_links() {
+  Status flush_links(bool everything) {
     graph_->clear_any_dirty();
     const uint32_t count = (uint32_t)graph_->count();
     const uint32_t l0s = (uint32_t)graph_->maxM0() + 1, ups = (uint32_t)graph_->maxM() + 1;
     const uint64_t cap = std::max<uint64_t>(store_.alloc_rows(), count);
     hipStream_t s = store_.stream();
-    bool full = false;
+    bool full = everything;
     if (d_links0_.cap < cap * l0s * 4 || d_upper_slot_.cap < cap * 4) {
       VK_TRY(d_links0_.ensure(cap * l0s * 4));       // DevBuf::ensure drops the old contents:
       VK_TRY(d_upper_slot_.ensure(cap * 4));         // republish everything
@@ -1010,6 +1077,9 @@ class HnswIndex final : public Index {
     bt_.batches += 1;
     bt_.points += P;
     VK_TRY(flush_locked());          // rows, labels, the new (empty) lists, upper lists of earlier batches
+    // (test failpoint: what an allocation failure of the scratch below looks like -- the batch is registered, nothing of it linked)
+    if (const uint64_t f = opt_.get(kOptHnswFailpointBatch); f != 0 && bt_.batches == f)
+      return Status::Err(VK_ERR_INTERNAL, "failpoint: device batch");
     CtxLease lease(pool_);
     SearchCtx *ctx = lease.ctx;
     hipStream_t s = ctx->stream;

@@ -42,7 +42,7 @@ enum OptId : uint32_t {
   // ---- HNSW ----------------------------------------------------------------------------------------------------------------
   kOptHnswStageAdds, kOptHnswStageMax,
   kOptHnswOptimisticTombstones, kOptHnswDeviceBuild, kOptHnswBuildBatch, kOptHnswBuildMinGraph, kOptHnswBuildMinBatch, kOptHnswBuildFrac,
-  kOptHnswBuildVerbose, kOptHnswPoolFloor, kOptHnswGpoolCap, kOptHnswVisitedHash, kOptHnswHashPerEf, kOptHnswHashLog2, kOptHnswVisitedMode, kOptHnswLdsWork, kOptHnswLdsWorkBig,
+  kOptHnswBuildVerbose, kOptHnswFailpointBatch, kOptHnswPoolFloor, kOptHnswGpoolCap, kOptHnswVisitedHash, kOptHnswHashPerEf, kOptHnswHashLog2, kOptHnswVisitedMode, kOptHnswLdsWork, kOptHnswLdsWorkBig,
   kOptHnswPoolBytes, kOptHnswVisitedBytes, kOptHnswRedoBytes,
   // ---- sharded index ---------------------------------------------------------------------------------------------------
   kOptShardThreads, kOptShardAllowStaged,
@@ -98,6 +98,7 @@ inline const OptDesc &opt_desc(uint32_t id) {
       {"hnsw-build-min-batch", "VK_HNSW_BUILD_MIN_BATCH", 64, 1, kMax},
       {"hnsw-build-frac", "VK_HNSW_BUILD_FRAC", 32, 1, 1u << 20},
       {"hnsw-build-verbose", "VK_HNSW_BUILD_VERBOSE", 0, 0, 1},
+      {"hnsw-failpoint-batch", "VK_HNSW_FAILPOINT_BATCH", 0, 0, kMax},            // TEST failpoint: the n-th device batch of a bulk fails behind its registration (0 = off)
       {"hnsw-pool-floor", "VK_HNSW_POOL_FLOOR", 512, 64, 1u << 20},
       {"hnsw-gpool-cap", "VK_HNSW_GPOOL_CAP", 65536, 128, 65536},
       {"hnsw-visited-hash", "VK_HNSW_VISITED_HASH", 1, 0, 2},
