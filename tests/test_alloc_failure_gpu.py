@@ -25,9 +25,12 @@ def _same(gd, gl, od, ol):
 
 
 def _occupy(torch, leave_bytes):
-    """take the device's free memory down to about leave_bytes (blocks of 1 GiB, then 64 MiB)"""
+    """take the device's free memory down to about leave_bytes (blocks of 1 GiB, then 64 MiB, then 4 MiB)"""
+    import gc
+    gc.collect()                 # (an index of an earlier test that dies in the middle of this one would give its memory back)
+    torch.cuda.empty_cache()
     held = []
-    for block in (1 << 30, 64 << 20):
+    for block in (1 << 30, 64 << 20, 4 << 20):
         while torch.cuda.mem_get_info()[0] > leave_bytes + block:
             held.append(torch.empty(block, dtype=torch.uint8, device="cuda"))
     return held
@@ -217,3 +220,106 @@ def test_a_bulk_that_fails_part_of_the_way_loses_nothing(vsa, oracle):
         d, l = g.search(x[i], 1, ef=64)
         hits += l.tolist() == [i]
     assert hits >= 190, hits
+
+
+def test_flat_single_adds_under_memory_pressure(vsa, oracle):
+    """AddRecord one key at a time: the rows wait in pinned host memory; the search that has to publish them is refused while
+    the table cannot grow, and answers over all of them once it can"""
+    import torch
+    rng = np.random.default_rng(13)
+    n0, n1, k = 1000, 12_000, 10
+    x = rng.standard_normal((n0 + n1, DIM)).astype(np.float32)
+    Q = rng.standard_normal((4, DIM)).astype(np.float32)
+    g = vsa.Index("FLAT", DIM, "L2", initial_cap=n0 + n1)
+    g.add_batch(x[:n0])
+    g.flush()
+    held = _occupy(torch, 384 << 20)
+    try:
+        for i in range(n0, n0 + n1):
+            assert g.add(i, x[i]) == vsa.VK_OK
+        assert g.stats().count == n0 + n1
+        with pytest.raises(vsa.VkError) as e:
+            g.search(Q[0], k)
+        assert e.value.code == vsa.VK_ERR_INTERNAL, e.value
+        assert g.remove(n0 + 3) == vsa.VK_OK
+    finally:
+        del held
+        torch.cuda.empty_cache()
+    o = oracle.Flat(DIM, "L2", max_elements=n0 + n1)
+    keep = np.array([i for i in range(n0 + n1) if i != n0 + 3], dtype=np.uint64)
+    o.add_many(x[keep], keep)
+    for q in Q:
+        _same(*g.search(q, k), *o.search(q, k))
+    d, l, c = g.search_batch(Q, k)
+    for i, q in enumerate(Q):
+        _same(d[i, :c[i]], l[i, :c[i]], *o.search(q, k))
+    assert g.stats().count == n0 + n1 - 1
+
+
+def test_filter_builds_under_memory_pressure(vsa, oracle):
+    """vk_filter_create / combine when the bitmap cannot be had: VK_ERR_INTERNAL, the handles that exist keep working, and the
+    same build passes once memory is back"""
+    import torch
+    rng = np.random.default_rng(17)
+    n, dim, k = 4000, 64, 10
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    g = vsa.Index("FLAT", dim, "L2", initial_cap=n)
+    g.add_batch(x)
+    g.flush()
+    ids = rng.choice(n, 500, replace=False).astype(np.uint64)
+    small = g.make_filter(n, labels=ids)
+    o = oracle.Flat(dim, "L2", max_elements=n)
+    o.add_many(x)
+    bits = oracle.allow_bitmap(ids, n)
+    want = o.search(q, k, allow=bits, allow_nbits=n)
+    held = _occupy(torch, 192 << 20)
+    big_bits = 1 << 34                                # a 2 GiB bitmap
+    try:
+        with pytest.raises(vsa.VkError) as e:
+            g.make_filter(big_bits, labels=ids)
+        assert e.value.code == vsa.VK_ERR_INTERNAL, e.value
+        _same(*g.search_filter(q, k, small), *want)   # (the next launches of this thread are not charged with it)
+        both = g.combine_filters(small, small, "and")
+        assert both.info()[1] == 500
+    finally:
+        del held
+        torch.cuda.empty_cache()
+    big = g.make_filter(big_bits, labels=ids)
+    assert big.info() == (big_bits, 500)
+    _same(*g.search_filter(q, k, big), *want)
+
+
+@pytest.mark.parametrize("algo", ["FLAT", "HNSW"])
+def test_search_scratch_under_memory_pressure(vsa, algo):
+    """the per-call scratch of a large batch (query block, partial lists, visited sets) cannot be had: the batch is refused or
+    served -- never a fault -- and the same batch gives the same answer as before once memory is back"""
+    import torch
+    rng = np.random.default_rng(19)
+    n, dim, nq, k = 20_000, 2048, 4096, 64
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    Q = rng.standard_normal((nq, dim)).astype(np.float32)
+    g = vsa.Index(algo, dim, "L2", initial_cap=n, m=8, ef_construction=32, ef_runtime=128)
+    g.add_batch(x)
+    g.flush()
+    d1, l1, c1 = g.search_batch(Q[:8], k)             # (small batch first: its scratch exists before the squeeze)
+    held = _occupy(torch, 8 << 20)
+    refused = 0
+    try:
+        for _ in range(2):
+            try:
+                g.search_batch(Q, k)
+            except vsa.VkError as e:
+                assert e.code == vsa.VK_ERR_INTERNAL, e
+                refused += 1
+        d2, l2, c2 = g.search_batch(Q[:8], k)         # what fits the scratch it already has still runs
+        assert l2.tolist() == l1.tolist() and d2.view(np.uint32).tolist() == d1.view(np.uint32).tolist()
+    finally:
+        del held
+        torch.cuda.empty_cache()
+    D, L, N = g.search_batch(Q, k)
+    assert N.min() == k
+    assert L[:8].tolist() == l1.tolist() and D[:8].view(np.uint32).tolist() == d1.view(np.uint32).tolist()
+    D2, L2, _ = g.search_batch(Q, k)
+    assert L2.tolist() == L.tolist() and D2.view(np.uint32).tolist() == D.view(np.uint32).tolist()
+    print(f"{algo}: {refused} of 2 large batches refused under pressure")
