@@ -323,3 +323,47 @@ def test_search_scratch_under_memory_pressure(vsa, algo):
     D2, L2, _ = g.search_batch(Q, k)
     assert L2.tolist() == L.tolist() and D2.view(np.uint32).tolist() == D.view(np.uint32).tolist()
     print(f"{algo}: {refused} of 2 large batches refused under pressure")
+
+
+@pytest.mark.parametrize("algo", ["FLAT", "HNSW"])
+def test_sharded_write_under_memory_pressure(vsa, oracle, algo):
+    """the same through the sharded index (four logical shards on the one device): a shard that finds no room gives its run
+    back, the router forgets the labels no shard holds, and the same batch passes -- with the same answers as one unsharded
+    FLAT index -- once memory is back"""
+    import torch
+    rng = np.random.default_rng(23)
+    n0, n1, k = 2000, 24_000, 10
+    x = rng.standard_normal((n0 + n1, DIM)).astype(np.float32)
+    Q = rng.standard_normal((4, DIM)).astype(np.float32)
+    g = vsa.Index(algo, DIM, "L2", initial_cap=n0 + n1, m=8, ef_construction=32, ef_runtime=64, shard_devices=[0, 0, 0, 0])
+    g.add_batch(x[:n0])
+    g.flush()
+    before = [g.search(q, k) for q in Q]
+    held = _occupy(torch, 256 << 20)
+    try:
+        with pytest.raises(vsa.VkError) as e:
+            g.add_batch(x[n0:], labels=np.arange(n0, n0 + n1, dtype=np.uint64))
+            g.flush()
+            g.search(Q[0], k)
+        assert e.value.code == vsa.VK_ERR_INTERNAL, e.value
+    finally:
+        del held
+        torch.cuda.empty_cache()
+    st = g.stats()
+    assert n0 <= st.count <= n0 + n1
+    if algo == "FLAT":
+        allow = oracle.allow_bitmap(np.arange(n0, dtype=np.uint64), n0 + n1)
+        for q, (d0, l0) in zip(Q, before):
+            _same(*g.search(q, k, allow=allow, allow_nbits=n0 + n1), d0, l0)
+    held_now = sum(g.contains(i) for i in range(n0, n0 + n1, 13))
+    g.add_batch(x[n0:], labels=np.arange(n0, n0 + n1, dtype=np.uint64))
+    g.flush()
+    st = g.stats()
+    assert st.count == n0 + n1 and st.deleted == 0, (st.count, held_now)
+    for i in (0, n0 - 1, n0, n0 + n1 // 2, n0 + n1 - 1):
+        assert np.array_equal(g.get_row(i), x[i])
+    if algo == "FLAT":
+        o = oracle.Flat(DIM, "L2", max_elements=n0 + n1)
+        o.add_many(x)
+        for q in Q[:2]:
+            _same(*g.search(q, k), *o.search(q, k))
