@@ -22,7 +22,9 @@
  *    caller's pointer: bruteforce.h:81, hnswalg.h:1576-1577).
  *  - COSINE: as in the reference (vector_base.cc:61-76,140-150) the caller
  *    normalises rows and queries; the library then works in the inner-product space.
- *  - labels are the u64 "internal ids" VectorBase hands to hnswlib (vector_base.cc:340-358).
+ *  - labels are the u64 "internal ids" VectorBase hands to hnswlib (vector_base.cc:340-358): a counter from zero.
+ *    UINT64_MAX is reserved -- it is the padding label of result lists -- and refused with VK_ERR_INVALID by every call
+ *    that brings a label in (add, add_batch, the device bulk load, a stream being loaded).
  *  - results are ascending by (distance, label) -- the order VectorBase::CreateReply
  *    produces from hnswlib's heap (vector_base.cc:258-277).
  *  - all entry points are thread safe; searches may run concurrently, mutations are

@@ -1340,6 +1340,7 @@ Status FlatIndex::load_from(vk_read_chunk_fn fn, void *user) {
       return Status::Err(VK_ERR_INTERNAL, "truncated element chunk");
     uint64_t lab;
     memcpy(&lab, buf.data() + (size_t)params_.dim * 4, 8);
+    if (lab == ~0ull) return Status::Err(VK_ERR_INVALID, "label UINT64_MAX is reserved (the padding of result lists)");
     VK_TRY(observe_loaded_row(lab, buf.data()));
     VK_TRY(add_locked(lab, reinterpret_cast<const float *>(buf.data())));
     if (store_.staged_bytes() >= ((size_t)256 << 20)) VK_TRY(store_.flush());

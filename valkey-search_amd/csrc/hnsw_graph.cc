@@ -570,6 +570,8 @@ Status HnswGraph::load_element(uint32_t id, const uint32_t *links0_words, const 
 // by older versions; the lookup must point at the live slot (:1033-1052).
 Status HnswGraph::load_labels(size_t count) {
   for (uint32_t i = 0; i < count; ++i) {
+    if (labels_[i] == ~0ull && !is_deleted(i))
+      return Status::Err(1 /* VK_ERR_INVALID */, "label UINT64_MAX is reserved (the padding of result lists)");
     auto it = label_lookup_.find(labels_[i]);
     if (it == label_lookup_.end()) {
       label_lookup_[labels_[i]] = i;

@@ -174,15 +174,27 @@ void vk_index_destroy(vk_index *ix) {
 #define VK_NEED(ix)                                             \
   if (!(ix) || !(ix)->impl) return fail(VK_ERR_INVALID, "index is NULL")
 
+// UINT64_MAX is the padding label of every result list ((+inf, UINT64_MAX) past the count, vk_index.h): a row under it would
+// be taken for padding by the selection kernels.  The reference's labels are VectorBase's counter from zero.
+static const char kReservedLabel[] = "label UINT64_MAX is reserved (the padding of result lists)";
+static bool has_reserved_label(const uint64_t *labels, uint64_t n) {
+  if (!labels) return false;
+  for (uint64_t i = 0; i < n; ++i)
+    if (labels[i] == ~0ull) return true;
+  return false;
+}
+
 int vk_index_add(vk_index *ix, uint64_t label, const void *row) {
   VK_NEED(ix);
   if (!row) return fail(VK_ERR_INVALID, "row is NULL");
+  if (label == ~0ull) return fail(VK_ERR_INVALID, kReservedLabel);
   return guarded([&] { return ix->impl->add(label, static_cast<const float *>(row)); });
 }
 
 int vk_index_add_batch(vk_index *ix, const uint64_t *labels, const void *rows, uint64_t n) {
   VK_NEED(ix);
   if (n && !rows) return fail(VK_ERR_INVALID, "rows is NULL");
+  if (has_reserved_label(labels, n)) return fail(VK_ERR_INVALID, kReservedLabel);   // (before anything of the batch is in)
   return guarded([&] { return ix->impl->add_batch(labels, static_cast<const float *>(rows), n); });
 }
 
@@ -463,6 +475,7 @@ int vk_index_device_rows(vk_index *ix, uint64_t n_rows, void **d_rows, uint64_t 
 
 int vk_index_commit_device_rows(vk_index *ix, uint64_t n_rows, const uint64_t *labels) {
   VK_NEED(ix);
+  if (has_reserved_label(labels, n_rows)) return fail(VK_ERR_INVALID, kReservedLabel);
   return guarded([&] { return ix->impl->commit_device_rows(n_rows, labels); });
 }
 
@@ -481,6 +494,7 @@ int vk_index_shard_device_rows(vk_index *ix, uint32_t shard, uint64_t n_rows, vo
 
 int vk_index_shard_commit_device_rows(vk_index *ix, uint32_t shard, uint64_t n_rows, const uint64_t *labels) {
   VK_NEED(ix);
+  if (has_reserved_label(labels, n_rows)) return fail(VK_ERR_INVALID, kReservedLabel);
   return guarded([&] { return ix->impl->shard_commit_device_rows(shard, n_rows, labels); });
 }
 
