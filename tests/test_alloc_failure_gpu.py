@@ -367,3 +367,61 @@ def test_sharded_write_under_memory_pressure(vsa, oracle, algo):
         o.add_many(x)
         for q in Q[:2]:
             _same(*g.search(q, k), *o.search(q, k))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("algo", ["FLAT", "HNSW"])
+def test_coalesced_callers_under_memory_pressure(vsa, algo):
+    """the reader pool's blocking Search() calls merged into device batches while the batch's scratch cannot be had: every
+    caller gets an answer or VK_ERR_INTERNAL -- nobody hangs, nobody gets another caller's answer -- and the same callers all
+    get their answers once memory is back"""
+    import threading
+    import torch
+    rng = np.random.default_rng(29)
+    n, dim, k, callers, each = 20_000, 2048, 1000, 96, 6      # (k = 1000: tens of MB of partial lists per batch)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    Q = rng.standard_normal((callers * each, dim)).astype(np.float32)
+    g = vsa.Index(algo, dim, "L2", initial_cap=n, m=8, ef_construction=32, ef_runtime=1500)
+    g.add_batch(x)
+    g.flush()
+    g.set_coalescing(callers, 3000)                     # (no search yet: the contexts have no scratch of their own)
+
+    def run(out):
+        def work(t):
+            for j in range(each):
+                i = t * each + j
+                try:
+                    out[i] = g.search_one(Q[i], k)
+                except vsa.VkError as e:
+                    out[i] = e
+        th = [threading.Thread(target=work, args=(t,)) for t in range(callers)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    held = _occupy(torch, 0)
+    got = [None] * len(Q)
+    try:
+        run(got)
+    finally:
+        del held
+        torch.cuda.empty_cache()
+    refused = 0
+    for i, r in enumerate(got):
+        assert r is not None, i
+        if isinstance(r, vsa.VkError):
+            assert r.code == vsa.VK_ERR_INTERNAL, r
+            refused += 1
+    again = [None] * len(Q)
+    run(again)
+    g.set_coalescing(0, 0)
+    want = [g.search_one(q, k) for q in Q[:24]]         # one query per call, no merging
+    for i, r in enumerate(again):
+        assert not isinstance(r, vsa.VkError), (i, r)
+        assert len(r[1]) == k
+        if i < len(want):
+            assert r[1].tolist() == want[i][1].tolist() and r[0].view(np.uint32).tolist() == want[i][0].view(np.uint32).tolist()
+        if not isinstance(got[i], vsa.VkError):
+            assert got[i][1].tolist() == r[1].tolist()
+    print(f"{algo}: {refused} of {len(Q)} coalesced calls refused under pressure")
