@@ -232,12 +232,55 @@ class HnswIndex final : public Index {
   }
 
   Status add_batch_host(const uint64_t *labels, const float *rows, uint64_t n) {
+    // The rows of a batch take effect in their order.
+    // (1) A batch that does not fit is cut where addPoint would throw: everything in front of that row is in, nothing behind
+    //     it (the builder's threads would otherwise stop wherever they were when one of them met the limit: rows in front of
+    //     the failing one left out, rows behind it in).
+    // (2) A label twice in what is left means the later row stands: the threads take rows as they come, so only the LAST row
+    //     of such a label is handed to them (r06: with three rows of one label in a batch the first one could win).
     std::shared_lock<std::shared_mutex> lk(rw_);
+    Status over = Status::Ok();
+    std::vector<uint64_t> ul;
+    std::vector<float> ur;
+    if (n > 1 || (n == 1 && graph_->count() >= graph_->max_elements())) {
+      uint64_t room = graph_->max_elements() > graph_->count() ? graph_->max_elements() - graph_->count() : 0;
+      if (params_.allow_replace_deleted) room += graph_->deleted_count();   // (such an insert takes over a tombstoned slot)
+      std::unordered_map<uint64_t, uint64_t> last;      // label -> its last row in front of the cut
+      std::unordered_set<uint64_t> fresh;               // new labels in front of the cut
+      last.reserve(n * 2);
+      for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t label = labels ? labels[i] : i;
+        uint32_t id;
+        if (!graph_->lookup(label, &id) && !fresh.count(label)) {
+          if (fresh.size() == room) {
+            n = i;
+            over = Status::Err(VK_ERR_CAPACITY, "The number of elements exceeds the specified limit");
+            break;
+          }
+          fresh.insert(label);
+        }
+        last[label] = i;
+      }
+      if (last.size() < n) {
+        const uint32_t dim = params_.dim;
+        ul.reserve(last.size());
+        ur.reserve(last.size() * dim);
+        for (uint64_t i = 0; i < n; ++i) {
+          const uint64_t label = labels ? labels[i] : i;
+          if (last[label] != i) continue;
+          ul.push_back(label);
+          ur.insert(ur.end(), rows + i * dim, rows + (i + 1) * dim);
+        }
+        labels = ul.data();
+        rows = ur.data();
+        n = ul.size();
+      }
+    }
     unsigned threads = params_.build_threads ? params_.build_threads : effective_cpus();
     threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n / 16 + 1));
     if (threads == 1) {
       for (uint64_t i = 0; i < n; ++i) VK_TRY(add_one(labels ? labels[i] : i, rows + i * params_.dim));
-      return Status::Ok();
+      return over;
     }
     // the first element is inserted alone so every worker starts from a non-empty graph
     uint64_t first = 0;
@@ -264,7 +307,7 @@ class HnswIndex final : public Index {
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work);
     for (auto &t : pool) t.join();
-    return failed.load() ? err : Status::Ok();
+    return failed.load() ? err : over;
   }
 
   Status remove(uint64_t label) override {

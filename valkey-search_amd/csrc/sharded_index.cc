@@ -304,19 +304,28 @@ class ShardedIndex final : public Index {
       std::unique_lock<std::shared_mutex> lk(rw_);
       uint64_t total = 0;
       for (uint64_t c : counts_) total += c;
-      std::vector<uint64_t> fresh_idx;
+      // (one hash operation per row: a new label gets its route entry at once, with a placeholder for the shard -- so that the
+      //  same label again later in the batch is recognised and counted once; r06 found the capacity check counting it twice)
+      std::vector<uint64_t> pending;        // rows whose label is new in this call, first occurrences and repeats, in order
+      std::vector<uint32_t *> slot;         // ... and the route entry of each (node-based map: the address is stable)
+      uint64_t n_fresh = 0;
       for (uint64_t i = 0; i < n; ++i) {
-        auto it = route_.find(labels[i]);
-        if (it != route_.end()) { shard_of[i] = it->second; continue; }
-        if (total + fresh_idx.size() >= capacity_) {   // addPoint fails at the limit; everything before it is in
-          over_capacity = true;
-          n_used = i;
-          break;
+        auto ins = route_.emplace(labels[i], kMaxShards);
+        if (!ins.second && ins.first->second != kMaxShards) { shard_of[i] = ins.first->second; continue; }
+        if (ins.second) {
+          if (total + n_fresh >= capacity_) {   // addPoint fails at the limit; everything before it is in
+            route_.erase(ins.first);
+            over_capacity = true;
+            n_used = i;
+            break;
+          }
+          ++n_fresh;
         }
         shard_of[i] = kMaxShards;   // marks "new"
-        fresh_idx.push_back(i);
+        pending.push_back(i);
+        slot.push_back(&ins.first->second);
       }
-      const uint64_t after = total + fresh_idx.size();
+      const uint64_t after = total + n_fresh;
       size_t s = 0;
       uint64_t quota = 0;
       auto next_quota = [&]() {
@@ -328,12 +337,17 @@ class ShardedIndex final : public Index {
         s = S - 1;
       };
       next_quota();
-      for (uint64_t i : fresh_idx) {
-        if (quota == 0) { ++s; next_quota(); }
-        // a label twice in one batch: the second occurrence follows the first
-        auto ins = route_.emplace(labels[i], (uint32_t)s);
-        if (ins.second) { counts_[s]++; quota--; fresh_row[i] = 1; }
-        shard_of[i] = ins.first->second;
+      for (size_t t = 0; t < pending.size(); ++t) {
+        const uint64_t i = pending[t];
+        uint32_t &r = *slot[t];
+        if (r == kMaxShards) {             // its first occurrence: dealt out; a repeat follows the first
+          if (quota == 0) { ++s; next_quota(); }
+          r = (uint32_t)s;
+          counts_[s]++;
+          quota--;
+          fresh_row[i] = 1;
+        }
+        shard_of[i] = r;
       }
     }
     // one add_batch per shard, concurrently (each shard has its own device, streams and -- HNSW -- graph builder)
