@@ -223,7 +223,11 @@ uint64_t vk_abi_struct_size(int which);
  * which is how ModifyRecordImpl is expressed: vector_flat.cc:178-193, vector_hnsw.cc:273-286). */
 int vk_index_add(vk_index *ix, uint64_t label, const void *row);
 /* n rows, row-contiguous.  HNSW inserts them with params.build_threads host threads
- * (the reference's writer pool calling addPoint concurrently: valkey_search.cc:1171-1174). */
+ * (the reference's writer pool calling addPoint concurrently: valkey_search.cc:1171-1174), or on the device.
+ * The rows take effect in their order: a label twice in the batch = the later row stands; at the capacity limit the
+ * call returns VK_ERR_CAPACITY with every row in front of the one addPoint would have thrown at in the index and none
+ * behind it.  Any other failure (VK_ERR_INTERNAL: the device had no room) may leave some of the batch's rows in; the
+ * batch may be sent again as it is. */
 int vk_index_add_batch(vk_index *ix, const uint64_t *labels, const void *rows, uint64_t n);
 /* removePoint bruteforce.h:92-113 (last element moves into the hole) /
  * markDelete hnswalg.h:1173-1187 (tombstone). */
