@@ -191,7 +191,7 @@ def test_flat_callers_keep_travelling_together(shim):
     (r04: ~half).  An HNSW batch costs per query: its lanes are taken as they come (two half batches overlap)."""
     out = (C.c_uint64 * 8)()
     assert shim.dispatcher_flat_fill_run(64, 12, 3000, 0, out) == 0
-    assert out[1] == 64 * 12 and out[1] / out[0] >= 48, (out[0], out[1])
+    assert out[1] == 64 * 12 and out[1] / out[0] >= 40, (out[0], out[1])     # (r04's rule gave ~32; 56-64 on an idle host, 44 seen beside a 16-thread compile)
 
 
 @pytest.mark.parametrize("hnsw", [1, 0])
