@@ -3,10 +3,14 @@ twice in the batch (the later row wins: addPoint of an existing label is an upda
 labels removed earlier coming back, and the batch that hits the capacity limit part of the way (addPoint throws there:
 everything before it is in, the rest is not).  FLAT takes runs of new labels by one strided copy and the rest through the
 staging log -- the order of effects must be the order of the rows.  Checked against the oracle fed one row at a time."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+OFFSET = int(os.environ.get("VK_SWEEP_OFFSET", "0"))      # other random batches: VK_SWEEP_OFFSET=<n>
 
 
 @pytest.fixture(scope="module")
@@ -23,7 +27,7 @@ def _same(gd, gl, od, ol):
 @pytest.mark.parametrize("shards", [0, 3])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_flat_mixed_batches(vsa, oracle, seed, shards):
-    rng = np.random.default_rng(100 + seed)
+    rng = np.random.default_rng(100 + seed + 1000 * OFFSET)
     dim, k, cap = 24, 10, 2500          # (reached in the fourth or fifth batch)
     kw = dict(shard_devices=[0] * shards) if shards else {}
     g = vsa.Index("FLAT", dim, "L2", initial_cap=cap, **kw)
@@ -76,7 +80,7 @@ def test_flat_mixed_batches(vsa, oracle, seed, shards):
             _same(D[i, :N[i]], L[i, :N[i]], od, ol)
         for lab in rng.choice(list(held), 20, replace=False):
             assert np.array_equal(g.get_row(int(lab)), latest[int(lab)])
-    assert hit_capacity >= 1
+    assert hit_capacity >= 1 or OFFSET != 0        # (the sizes are tuned so that the default seeds reach the limit)
 
 
 @pytest.mark.parametrize("shards", [0, 3])
@@ -84,7 +88,7 @@ def test_flat_mixed_batches(vsa, oracle, seed, shards):
 def test_hnsw_mixed_batches(vsa, oracle, seed, shards):
     """the same for HNSW (updates relink, removed labels come back as updates of their tombstone): count, tombstones, the row
     behind every label, and the answers of the saved graph walked by the oracle"""
-    rng = np.random.default_rng(200 + seed)
+    rng = np.random.default_rng(200 + seed + 1000 * OFFSET)
     dim, k, cap = 24, 10, 2200          # (reached around the fifth batch; a tombstone keeps its slot)
     kw = dict(shard_devices=[0] * shards) if shards else {}
     g = vsa.Index("HNSW", dim, "L2", initial_cap=cap, m=8, ef_construction=48, ef_runtime=48, **kw)
@@ -143,4 +147,4 @@ def test_hnsw_mixed_batches(vsa, oracle, seed, shards):
         assert lost <= max(3, len(probe) // 15), (step, lost, len(probe))
         for lab in list(dead)[:20]:
             assert not g.contains(int(lab))
-    assert hit_capacity >= 1
+    assert hit_capacity >= 1 or OFFSET != 0        # (the sizes are tuned so that the default seeds reach the limit)
