@@ -6,6 +6,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+OFFSET = int(__import__("os").environ.get("VK_SWEEP_OFFSET", "0"))     # other random operation sequences: VK_SWEEP_OFFSET=<n>
+
 
 @pytest.fixture(scope="module")
 def vsa():
@@ -20,7 +22,7 @@ def _same(gd, gl, od, ol, ctx):
 
 @pytest.mark.parametrize("metric,seed", [("L2", 1), ("IP", 2), ("IP", 3)])
 def test_flat_random_operations(vsa, oracle, metric, seed):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + 1000 * OFFSET)
     dim, cap = 64, 600
     g = vsa.Index("FLAT", dim, metric, initial_cap=cap)
     o = oracle.Flat(dim, metric, max_elements=cap)
@@ -75,7 +77,7 @@ def test_flat_random_operations(vsa, oracle, metric, seed):
 
 @pytest.mark.parametrize("metric,seed", [("L2", 11), ("IP", 12)])
 def test_hnsw_random_operations(vsa, oracle, metric, seed):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + 1000 * OFFSET)
     dim, cap = 32, 3000
     g = vsa.Index("HNSW", dim, metric, initial_cap=cap, m=8, ef_construction=40, ef_runtime=30, build_threads=1)
     o = oracle.HNSW(dim, metric, max_elements=cap, M=8, ef_construction=40, ef=30)
