@@ -12,6 +12,7 @@ import pytest
 from conftest import reference_vectors
 
 ROOT = Path(__file__).resolve().parent.parent
+OFFSET = int(__import__("os").environ.get("VK_SWEEP_OFFSET", "0"))     # other random inputs: VK_SWEEP_OFFSET=<n>
 CSRC = ROOT / "valkey-search_amd" / "csrc"
 
 
@@ -78,7 +79,7 @@ def oracle_graph(o):
 @pytest.mark.parametrize("space,dim,n,M,efc", [("L2", 32, 1500, 8, 40), ("IP", 48, 1200, 16, 100),
                                                 ("L2", 100, 1000, 16, 20)])
 def test_single_threaded_build_equals_oracle_graph(gs, oracle, space, dim, n, M, efc):
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + 1000 * OFFSET)
     x = rng.standard_normal((n, dim)).astype(np.float32) if dim != 100 else reference_vectors(n, 100, 2.2)
     labels = rng.permutation(10 * n)[:n].astype(np.uint64)
     g = gs.gs_new(dim, int(space == "L2"), n, M, efc, 100, 0)
@@ -95,7 +96,7 @@ def test_single_threaded_build_equals_oracle_graph(gs, oracle, space, dim, n, M,
 
 
 def test_tombstones_updates_and_capacity(gs, oracle):
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(8 + 1000 * OFFSET)
     dim, n, M = 24, 400, 8
     x = rng.standard_normal((n + 50, dim)).astype(np.float32)
     g = gs.gs_new(dim, 1, n, M, 60, 100, 0)
@@ -132,7 +133,7 @@ def test_replace_deleted_slots_follow_hnswalg(gs, oracle):
     like an update of it; a known deleted label is un-deleted in place; with no vacancy the graph grows.  Which vacant slot
     `*deleted_elements.begin()` names is the unordered_set's business: the product chooses, the oracle replays the choice
     (and refuses a slot that is not vacant), everything else must agree."""
-    rng = np.random.default_rng(18)
+    rng = np.random.default_rng(18 + 1000 * OFFSET)
     dim, n, M, efc = 24, 500, 8, 60
     x = rng.standard_normal((n + 400, dim)).astype(np.float32)
     g = gs.gs_new(dim, 1, n + 40, M, efc, 100, 1)
