@@ -1236,10 +1236,14 @@ def main():
     if procs > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (rank 0 runs the legs behind the timed region -- CPU baseline, HNSW builds, configs[3] / [4] -- for minutes while the
+        #  other ranks wait in the last barrier: the process group's default watchdog of ten minutes must not end the job there)
+        import datetime
+        patience = datetime.timedelta(hours=3)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", device_id=device, timeout=patience)  # "nccl" is RCCL on ROCm
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=patience)
 
     N, D, B, K = args.rows, args.dim, args.batch, args.k
     if args.hnsw_rows < 0:
