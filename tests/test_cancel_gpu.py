@@ -13,6 +13,8 @@ import time
 import numpy as np
 import pytest
 
+from conftest import timing_bound
+
 pytestmark = pytest.mark.gpu
 
 
@@ -43,6 +45,7 @@ def _timed_cancel(fn, flag, after_s):
     return out, err, (t_done - t_raise[0]) if t_raise[0] is not None and t_done > t_raise[0] else None
 
 
+@timing_bound()
 def test_hnsw_cancel_interrupts_a_long_filtered_batch(vsa, oracle):
     rng = np.random.default_rng(31)
     n, dim = 60_000, 64
@@ -91,6 +94,7 @@ def _bf16_rne(x):
 
 @pytest.mark.parametrize("metric,nq,filt,dtype", [("L2", 2048, 0, "f32"), ("COSINE", 4096, 0, "f32"), ("COSINE", 4096, 1, "f32"),
                                                   ("L2", 4096, 1, "f32"), ("COSINE", 32768, 1, "f32"), ("COSINE", 32768, 1, "bf16")])
+@timing_bound()
 def test_flat_cancel_returns_what_it_has(vsa, oracle, metric, nq, filt, dtype):
     """filt = 0: the exact kernels (VALU scan / f32 matrix-core kernel: batches long enough to time the reaction);
     filt = 1: the matrix-core candidate filter + re-rank (a batch of a few milliseconds: only the answer is checked);
@@ -145,6 +149,7 @@ def test_flat_cancel_returns_what_it_has(vsa, oracle, metric, nq, filt, dtype):
     assert (L < k).all() and (N == k).all()
 
 
+@timing_bound()
 def test_one_cancelled_member_of_a_live_batch_returns_at_once(vsa, oracle):
     """VERDICT r04 missing #5.  The reference stops ONE search within one distance evaluation of its token
     (hnswalg.h:400-402); r04 made a cancelled member wait out the device batch it travelled in (tens of milliseconds for a

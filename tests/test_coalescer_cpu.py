@@ -11,6 +11,8 @@ from pathlib import Path
 
 import pytest
 
+from conftest import timing_bound
+
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "valkey-search_amd" / "csrc"
 
@@ -34,26 +36,6 @@ def shim(tmp_path_factory):
     lib.dispatcher_flat_fill_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     lib.dispatcher_queued_cancel_run.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     return lib
-
-
-def timing_bound(attempts=3):
-    """The tests below assert TIME bounds (a cancelled caller back within a millisecond, a stopped pass within 200 ms) on
-    threads of this host: a container whose CPU quota was just spent on the sanitizer builds stalls a thread for tens of
-    milliseconds now and then.  A bound must fail `attempts` times in a row to fail the test."""
-    import functools
-
-    def deco(fn):
-        @functools.wraps(fn)
-        def wrapper(*a, **kw):
-            for i in range(attempts):
-                try:
-                    return fn(*a, **kw)
-                except AssertionError:
-                    if i == attempts - 1:
-                        raise
-                    time.sleep(0.5)
-        return wrapper
-    return deco
 
 
 def run(lib, threads, per_thread, max_batch, max_wait_us, lanes=1, failing=0):

@@ -6,6 +6,8 @@ import threading
 import numpy as np
 import pytest
 
+from conftest import timing_bound
+
 pytestmark = pytest.mark.gpu
 
 
@@ -91,6 +93,7 @@ def test_hnsw_coalesced_lanes_by_k_and_ef(vsa):
     assert st.coalesced_queries == 2 * len(Q) and st.coalesced_batches < 2 * len(Q)
 
 
+@timing_bound()
 def test_single_caller_is_not_held_for_the_whole_window(vsa):
     import time
     rng = np.random.default_rng(13)
@@ -164,6 +167,7 @@ def test_64_callers_each_with_its_own_tag_filter(vsa, oracle):
         assert L[i, :N[i]].tolist() == l.tolist() and D[i, :N[i]].view(np.uint32).tolist() == d.view(np.uint32).tolist()
 
 
+@timing_bound()
 def test_a_cancelled_caller_leaves_a_coalesced_batch_at_once(vsa):
     import ctypes as C
     import time

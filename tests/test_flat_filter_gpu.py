@@ -10,6 +10,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import timing_bound
+
 pytestmark = pytest.mark.gpu
 
 
@@ -255,6 +257,7 @@ def test_rows_loaded_cluster_by_cluster(vsa, oracle):
     assert st.last_filter_candidates < 3 * fs.stats().last_filter_candidates + 256 * 64
 
 
+@timing_bound()
 def test_a_heavy_query_costs_the_batch_little(vsa, oracle):
     """One query of a 256-batch sits on 40 000 duplicates: its extra work is the gate's slow path for those 40 000 pairs (they
     all sit in a dozen blocks' tile ranges) and their exact re-rank, not an exact pass over the index -- at most 40 ns per
