@@ -32,7 +32,10 @@ def _occupy(torch, leave_bytes):
     held = []
     for block in (1 << 30, 64 << 20, 4 << 20):
         while torch.cuda.mem_get_info()[0] > leave_bytes + block:
-            held.append(torch.empty(block, dtype=torch.uint8, device="cuda"))
+            try:
+                held.append(torch.empty(block, dtype=torch.uint8, device="cuda"))
+            except torch.OutOfMemoryError:      # (free in pieces smaller than this block: go on with the next size)
+                break
     return held
 
 
